@@ -1,0 +1,1082 @@
+/* mp2_oracle.c -- TEST INFRASTRUCTURE ONLY (see mp2_oracle.h for the parity statement).
+ *
+ * Plain-C restatement of libtoolame-dab's Layer II encode path.  All citations are relative to
+ * /root/reference/libtoolame-dab/.  Arithmetic is fp64 with no contraction (-ffp-contract=off) and
+ * follows the reference's evaluation order wherever order changes rounding.  Unlike the reference
+ * (process-global statics, toolame.c:24-118) every piece of state lives in a context struct.
+ */
+#include "mp2_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../odr-audioenc_amd/csrc/mp2_tables.inc"
+
+#define SBLIMIT 32
+#define DBMIN (-200.0)
+#define POWERNORM 90.3090            /* encoder.h:34 */
+#define REF_PI 3.14159265358979      /* common.h:26 (truncated on purpose) */
+#define BUFSZ 4096                   /* common.h BUFFER_SIZE */
+#define T_FALSE 0
+#define T_NOISE 10
+#define T_TONE 20
+#define L_LAST (-1)
+#define L_STOP (-100)
+
+/* ------------------------------------------------------------------------------------------ */
+/* static tables rebuilt from the scaled-integer .inc                                          */
+static double g_enwindow[512], g_scalefactor[64], g_snr[18], g_qa[18], g_qb[18];
+static double g_dct[16][32];
+static double g_hann[1024];
+static double g_dbtable[1000];
+static double g_fht_tw[166][4];      /* (c1,s1,c2,s2) per (pass,i) in fft.c:1141-1149 order */
+static unsigned short g_bitrev[1024];
+static int g_tables_ready;
+
+static const int kBitrate[2][15] = {  /* common.c:28-31 */
+    {0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160},
+    {0, 32, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384}};
+static const double kSfreq[2][4] = {{22.05, 24, 16, 0}, {44.1, 48, 32, 0}};  /* common.c:26 */
+
+static double u64_as_double(unsigned long long u) { double d; memcpy(&d, &u, 8); return d; }
+
+static void build_tables(void)
+{
+    if (g_tables_ready) return;
+    for (int i = 0; i < 512; i++) g_enwindow[i] = (double)TL_ENWINDOW_E9[i] / 1e9;
+    for (int i = 0; i < 63; i++) g_scalefactor[i] = (double)TL_SCALEFACTOR_E14[i] / 1e14;
+    g_scalefactor[63] = 1e-20;
+    for (int i = 0; i < 18; i++) {
+        g_snr[i] = (double)TL_SNR_E2[i] / 100.0;
+        g_qa[i] = (double)TL_QUANT_A_E9[i] / 1e9;
+        g_qb[i] = (double)TL_QUANT_B_E9[i] / 1e9;
+    }
+    /* create_dct_matrix, subband.c:125-137: cos scaled by 1e9, rounded half away, scaled back */
+    for (int i = 0; i < 16; i++)
+        for (int k = 0; k < 32; k++) {
+            double f = 1e9 * cos((double)((2 * i + 1) * k * REF_PI / 64));
+            double ip;
+            if (f >= 0) modf(f + 0.5, &ip); else modf(f - 0.5, &ip);
+            g_dct[i][k] = ip * 1e-9;
+        }
+    /* Hann window incl. sqrt(8/3)/N, psycho_1.c:225-233 == psycho_3.c:135-141 */
+    {
+        double sqrt_8_over_3 = pow(8.0 / 3.0, 0.5);
+        for (int i = 0; i < 1024; i++)
+            g_hann[i] = sqrt_8_over_3 * 0.5 * (1 - cos(2.0 * REF_PI * i / 1024)) / 1024;
+    }
+    /* add_db table, psycho_1.c:170-178 == psycho_3.c:249-257 */
+    for (int i = 0; i < 1000; i++) {
+        double x = (double)i / 10.0;
+        g_dbtable[i] = 10 * log10(1 + pow(10.0, x / 10.0)) - x;
+    }
+    /* FHT: bit reversal (fft.c:85-1090 is the 10-bit reversal, proven in tools/gen_tables.py) */
+    for (int i = 0; i < 1024; i++) {
+        int r = 0;
+        for (int b = 0; b < 10; b++) if (i & (1 << b)) r |= 1 << (9 - b);
+        g_bitrev[i] = (unsigned short)r;
+    }
+    /* Buneman trig recurrence, fft.c:1139-1149, tabulated: passes k = 2,4,6,8 */
+    {
+        int n = 0;
+        for (int k = 2; k <= 8; k += 2) {
+            int kx = (1 << k) >> 1;
+            double t_c = u64_as_double(TL_FHT_COS_BITS[k]), t_s = u64_as_double(TL_FHT_SIN_BITS[k]);
+            double c1 = 1, s1 = 0;
+            for (int i = 1; i < kx; i++) {
+                double t = c1;
+                c1 = t * t_c - s1 * t_s;
+                s1 = t * t_s + s1 * t_c;
+                g_fht_tw[n][0] = c1;
+                g_fht_tw[n][1] = s1;
+                g_fht_tw[n][2] = c1 * c1 - s1 * s1;
+                g_fht_tw[n][3] = 2 * (c1 * s1);
+                n++;
+            }
+        }
+    }
+    g_tables_ready = 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int line; double bark, hear, x; } thr_line;
+
+struct mp2o_enc {
+    /* configuration (frame_header / frame_info, common.h:97-140) */
+    int version, fs_idx, br_idx, kbps, mode0, mode_ext0, nch, psy, tab, sblimit;
+    int dab_ext, dab_length;
+    /* per-frame mutable header state */
+    int mode, mode_ext, jsbound, padding;
+    double slot_lag;                /* availbits.c:27-33 */
+    int frame_num;
+    /* filterbank FIFO, canonical order X[0..511] (subband.c:211) */
+    double fifo[2][512];
+    /* psy 1/3 input ring as linear history: last 256 samples of the previous frames */
+    short psy_hist[2][256];
+    /* psy-1 tables */
+    int p1_ncb, p1_cbound[28], p1_sub;
+    thr_line p1_ltg[134];
+    int p1_map[513];
+    /* psy-3 tables */
+    double p3_bark[513], p3_ath[513];
+    int p3_cbands, p3_cbidx[34], p3_subset[136];
+    /* psy-0 */
+    double p0_athmin[32];
+    /* psy-2 state (psycho_2.c:16-48) */
+    void *psy2;
+    /* output byte buffer emulating bitstream.c (forward-indexed) */
+    unsigned char buf[BUFSZ];
+    int fill;                       /* whole bytes in buf                                  */
+    unsigned cur; int cur_bits;     /* partial byte being assembled                        */
+    int minimum;
+    unsigned char *out; size_t out_size; int out_written;
+    mp2o_taps taps;
+};
+
+/* ------------------------------------------------------------------------------------------ */
+/* bit writer: bitstream.c:111-150 (putbits / put1bit), :46-71 (empty_buffer)                  */
+static void bs_flush(mp2o_enc *e, int keep)
+{
+    /* hand out the oldest bytes, keep the newest `keep` (bitstream.c:46-71) */
+    int n = e->fill - keep, j = 0;
+    for (int i = 0; i < n; i++) {
+        if ((size_t)j >= e->out_size) break;         /* "output buffer too small" path */
+        e->out[j++] = e->buf[i];
+    }
+    e->out_written = j;
+    memmove(e->buf, e->buf + n, (size_t)keep);
+    e->fill = keep;
+}
+static void bs_put(mp2o_enc *e, unsigned val, int n)
+{
+    for (int b = n - 1; b >= 0; b--) {
+        e->cur = (e->cur << 1) | ((val >> b) & 1u);
+        if (++e->cur_bits == 8) {
+            e->buf[e->fill++] = (unsigned char)e->cur;
+            e->cur = 0; e->cur_bits = 0;
+            if (e->fill == BUFSZ) bs_flush(e, e->minimum);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* CRCs: crc.c:12-56 (CRC-16, poly 0x8005) and crc.c:58-113 (DAB ScF-CRC, poly 0x1D)           */
+static void crc_upd(unsigned *crc, unsigned data, int len, unsigned poly, unsigned top, unsigned mask)
+{
+    for (int b = len - 1; b >= 0; b--) {
+        unsigned carry = *crc & top;
+        *crc <<= 1;
+        if ((!carry) ^ (!((data >> b) & 1u))) *crc ^= poly;
+    }
+    *crc &= mask;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* init-time helpers                                                                           */
+static double ath_db(double f, double value)      /* ath.c:7-47 */
+{
+    if (f < -.3) f = 3410;
+    f /= 1000;
+    f = f > 0.01 ? f : 0.01;
+    f = f < 18.0 ? f : 18.0;
+    double ath = 3.640 * pow(f, -0.8) - 6.800 * exp(-0.6 * pow(f - 3.4, 2.0))
+               + 6.000 * exp(-0.15 * pow(f - 8.7, 2.0)) + (0.6 + 0.04 * 0.0) * 0.001 * pow(f, 4.0);
+    return ath + value;
+}
+static double freq2bark(double freq)              /* ath.c:73-78 */
+{
+    if (freq < 0) freq = 0;
+    freq = freq * 0.001;
+    return 13.0 * atan(.76 * freq) + 3.5 * atan(freq * freq / (7.5 * 7.5));
+}
+
+static void psy1_init(mp2o_enc *e)                /* psycho_1.c:39-56, :94-168 */
+{
+    int t = e->version == 1 ? e->fs_idx : e->fs_idx + 4;
+    e->p1_ncb = TL_PSY1_CBOUND[t * 28];
+    for (int i = 0; i < e->p1_ncb; i++) e->p1_cbound[i] = TL_PSY1_CBOUND[t * 28 + 1 + i];
+    e->p1_sub = TL_PSY1_FREQ_ENTRIES[t] + 1;
+    e->p1_ltg[0].line = 0; e->p1_ltg[0].bark = 0.0; e->p1_ltg[0].hear = 0.0;
+    for (int i = 1; i < e->p1_sub; i++) {
+        e->p1_ltg[i].line = TL_PSY1_LINE[t * 132 + i - 1];
+        e->p1_ltg[i].bark = (double)TL_PSY1_BARK_E3[t * 132 + i - 1] / 1000.0;
+        e->p1_ltg[i].hear = (double)TL_PSY1_HEAR_E2[t * 132 + i - 1] / 100.0;
+    }
+    memset(e->p1_map, 0, sizeof e->p1_map);       /* lines above the last table line keep 0 */
+    for (int i = 1; i < e->p1_sub; i++)
+        for (int j = e->p1_ltg[i - 1].line; j <= e->p1_ltg[i].line; j++) e->p1_map[j] = i;
+}
+
+static void psy3_init(mp2o_enc *e)                /* psycho_3.c:434-512 */
+{
+    double sfreq = kSfreq[e->version][e->fs_idx] * 1000;
+    e->p3_bark[0] = 0; e->p3_ath[0] = 0;          /* zero-initialised globals in the reference */
+    for (int i = 1; i < 513; i++) {
+        double freq = i * sfreq / 1024;
+        e->p3_bark[i] = freq2bark(freq);
+        e->p3_ath[i] = ath_db(freq, 0);
+    }
+    int cbase = 0, cb = 0;
+    e->p3_cbidx[0] = 1;
+    for (int i = 1; i < 513; i++)
+        if ((e->p3_bark[i] - e->p3_bark[cbase]) > 1.0) { cbase = i; cb++; e->p3_cbidx[cb] = cbase; }
+    cb++;
+    e->p3_cbidx[cb] = 513;
+    e->p3_cbands = cb;
+    int n = 0, i = 1;
+    for (; i < 3 * 16 + 1; i++) e->p3_subset[n++] = i;
+    for (; i < 6 * 16 + 1; i += 2) e->p3_subset[n++] = i;
+    for (; i < 12 * 16 + 1; i += 4) e->p3_subset[n++] = i;
+    for (; i < 32 * 16 + 1; i += 8) e->p3_subset[n++] = i;
+}
+
+static void psy0_init(mp2o_enc *e)                /* psycho_0.c:36-50 */
+{
+    double sfreq = kSfreq[e->version][e->fs_idx] * 1000;
+    double per_line = sfreq / 1024.0;
+    for (int sb = 0; sb < 32; sb++) e->p0_athmin[sb] = 1000;
+    for (int i = 0; i < 512; i++) {
+        double v = ath_db(i * per_line, 0);
+        if (v < e->p0_athmin[i >> 4]) e->p0_athmin[i >> 4] = v;
+    }
+}
+
+static void psy2_init(mp2o_enc *e);
+static void psy2_run(mp2o_enc *e, const short *pcm, int ch, double *smr);
+
+/* ------------------------------------------------------------------------------------------ */
+mp2o_enc *mp2o_create(long samplerate, char mode, int kbps, int psy, int pad_len)
+{
+    build_tables();
+    mp2o_enc *e = calloc(1, sizeof *e);
+    if (!e) return NULL;
+    /* SmpFrqIndex, common.c:118-144 */
+    switch (samplerate) {
+    case 44100: e->version = 1; e->fs_idx = 0; break;
+    case 48000: e->version = 1; e->fs_idx = 1; break;
+    case 32000: e->version = 1; e->fs_idx = 2; break;
+    case 24000: e->version = 0; e->fs_idx = 1; break;
+    case 22050: e->version = 0; e->fs_idx = 0; break;
+    case 16000: e->version = 0; e->fs_idx = 2; break;
+    default: free(e); return NULL;
+    }
+    if (psy < 0 || psy > 4) { free(e); return NULL; }      /* ABI range is 0..3, toolame.c:202-210; 4 = extension */
+    e->psy = psy;
+    /* toolame_set_channel_mode, toolame.c:174-200 */
+    switch (mode) {
+    case 's': e->mode0 = 0; e->mode_ext0 = 0; break;
+    case 'd': e->mode0 = 2; e->mode_ext0 = 0; break;
+    case 'j': e->mode0 = 1; e->mode_ext0 = 2; break;
+    case 'm': e->mode0 = 3; e->mode_ext0 = 0; break;
+    default: free(e); return NULL;
+    }
+    e->nch = e->mode0 == 3 ? 1 : 2;
+    /* toolame_set_bitrate, toolame.c:212-237; BitrateIndex common.c:95-116 */
+    if (kbps == 0) kbps = kBitrate[e->version][10];
+    e->br_idx = -1;
+    for (int i = 0; i < 15; i++) if (kBitrate[e->version][i] == kbps) { e->br_idx = i; break; }
+    if (e->br_idx < 0) { free(e); return NULL; }            /* the reference exit(-1)s here */
+    e->kbps = kbps;
+    e->dab_ext = 4;
+    if (e->version == 1 && (kbps / (e->mode0 == 3 ? 1 : 2) < 56)) e->dab_ext = 2;
+    if (pad_len < 0) { free(e); return NULL; }
+    e->dab_length = pad_len;                                 /* toolame_set_pad, toolame.c:250 */
+    /* encode_init / pick_table, encode_new.c:104-125, tables.c:18-45 */
+    {
+        int br_per_ch = kbps / e->nch;
+        int sfrq = (int)kSfreq[e->version][e->fs_idx];
+        if (e->version == 1) {
+            if ((sfrq == 48 && br_per_ch >= 56) || (br_per_ch >= 56 && br_per_ch <= 80)) e->tab = 0;
+            else if (sfrq != 48 && br_per_ch >= 96) e->tab = 1;
+            else if (sfrq != 32 && br_per_ch <= 48) e->tab = 2;
+            else e->tab = 3;
+        } else e->tab = 4;
+        e->sblimit = TL_TABLE_SBLIMIT[e->tab];
+    }
+    e->mode = e->mode0; e->mode_ext = e->mode_ext0;
+    {   /* hdr_to_frps, common.c:76-93 / js_bound common.c:64-74 */
+        static const int jsb[4] = {4, 8, 12, 16};
+        e->jsbound = e->mode0 == 1 ? jsb[e->mode_ext0] : e->sblimit;
+    }
+    e->minimum = 4;                                          /* bitstream.c:38 MINIMUM */
+    psy1_init(e);
+    psy3_init(e);
+    psy0_init(e);
+    if (psy == 2 || psy == 4) psy2_init(e);
+    return e;
+}
+
+void mp2o_destroy(mp2o_enc *e) { if (e) { free(e->psy2); free(e); } }
+int mp2o_nch(const mp2o_enc *e) { return e->nch; }
+int mp2o_sblimit(const mp2o_enc *e) { return e->sblimit; }
+int mp2o_tablenum(const mp2o_enc *e) { return e->tab; }
+int mp2o_dab_extension(const mp2o_enc *e) { return e->dab_ext; }
+const mp2o_taps *mp2o_get_taps(const mp2o_enc *e) { return &e->taps; }
+
+/* available_bits, availbits.c:36-67 */
+static int available_bits(mp2o_enc *e, int commit)
+{
+    double average = (1152.0 / kSfreq[e->version][e->fs_idx]) * ((double)kBitrate[e->version][e->br_idx] / 8.0);
+    int whole = (int)average, extra = 0;
+    double frac = average - (double)whole;
+    if (frac != 0) {
+        double lag = e->slot_lag;
+        int pad;
+        if (lag > (frac - 1.0)) { lag -= frac; pad = 0; } else { extra = 1; pad = 1; lag += (1 - frac); }
+        if (commit) { e->slot_lag = lag; e->padding = pad; }
+    }
+    return (whole + extra) * 8;
+}
+int mp2o_frame_bytes(const mp2o_enc *e)
+{
+    mp2o_enc tmp = *e;
+    return available_bits(&tmp, 0) / 8;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* K1: polyphase analysis filterbank, subband.c:201-310 in canonical ISO form                  */
+void mp2o_filterbank_block(mp2o_enc *e, int ch, const short pcm32[32], double s[32])
+{
+    double *X = e->fifo[ch];
+    double y[64], yp[32];
+    memmove(X + 32, X, 480 * sizeof(double));
+    for (int i = 0; i < 32; i++) X[31 - i] = (double)pcm32[i] / 32768;     /* subband.c:232-233 */
+    for (int i = 0; i < 64; i++) {                                         /* subband.c:246-283 */
+        double t = X[i] * g_enwindow[i];
+        for (int j = 1; j < 8; j++) t += X[i + 64 * j] * g_enwindow[i + 64 * j];
+        y[i] = t;
+    }
+    yp[0] = y[16];                                                         /* subband.c:260,285-291 */
+    for (int i = 1; i <= 16; i++) yp[i] = y[i + 16] + y[16 - i];
+    for (int i = 17; i <= 31; i++) yp[i] = y[i + 16] - y[80 - i];
+    for (int i = 15; i >= 0; i--) {                                        /* subband.c:293-305 */
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = 0; k < 32; k += 2) {
+            s0 += g_dct[i][k] * yp[k];
+            s1 += g_dct[i][k + 1] * yp[k + 1];
+        }
+        s[i] = s0 + s1;
+        s[31 - i] = s0 - s1;
+    }
+}
+
+/* K2: scalefactor index, encode_new.c:179-230 */
+static unsigned sf_index_of(double cur_max)
+{
+    unsigned sf = 32;
+    for (unsigned l = 16; l; l >>= 1) { if (cur_max <= g_scalefactor[sf]) sf += l; else sf -= l; }
+    if (cur_max > g_scalefactor[sf]) sf--;
+    return sf;
+}
+static void scalefactors(const double smp[][3][12][32], unsigned sf[][3][32], int nch, int sblimit)
+{
+    for (int ch = 0; ch < nch; ch++)
+        for (int gr = 0; gr < 3; gr++)
+            for (int sb = 0; sb < sblimit; sb++) {
+                double m = fabs(smp[ch][gr][11][sb]);
+                for (int j = 10; j >= 0; j--) { double t = fabs(smp[ch][gr][j][sb]); if (t > m) m = t; }
+                sf[ch][gr][sb] = sf_index_of(m);
+            }
+}
+
+/* sf_transmission_pattern, encode_new.c:288-354 (ISO Table C.4) */
+static void sf_pattern(mp2o_enc *e, unsigned sf[2][3][32], unsigned scfsi[2][32])
+{
+    static const int pattern[5][5] = {{0x123, 0x122, 0x122, 0x133, 0x123},
+                                      {0x113, 0x111, 0x111, 0x444, 0x113},
+                                      {0x111, 0x111, 0x111, 0x333, 0x113},
+                                      {0x222, 0x222, 0x222, 0x333, 0x123},
+                                      {0x123, 0x122, 0x122, 0x133, 0x123}};
+    for (int k = 0; k < e->nch; k++)
+        for (int i = 0; i < e->sblimit; i++) {
+            int d[2] = {(int)sf[k][0][i] - (int)sf[k][1][i], (int)sf[k][1][i] - (int)sf[k][2][i]};
+            int cls[2];
+            for (int j = 0; j < 2; j++)
+                cls[j] = d[j] <= -3 ? 0 : d[j] < 0 ? 1 : d[j] == 0 ? 2 : d[j] < 3 ? 3 : 4;
+            switch (pattern[cls[0]][cls[1]]) {
+            case 0x123: scfsi[k][i] = 0; break;
+            case 0x122: scfsi[k][i] = 3; sf[k][2][i] = sf[k][1][i]; break;
+            case 0x133: scfsi[k][i] = 3; sf[k][1][i] = sf[k][2][i]; break;
+            case 0x113: scfsi[k][i] = 1; sf[k][1][i] = sf[k][0][i]; break;
+            case 0x111: scfsi[k][i] = 2; sf[k][1][i] = sf[k][2][i] = sf[k][0][i]; break;
+            case 0x222: scfsi[k][i] = 2; sf[k][0][i] = sf[k][2][i] = sf[k][1][i]; break;
+            case 0x333: scfsi[k][i] = 2; sf[k][0][i] = sf[k][1][i] = sf[k][2][i]; break;
+            case 0x444:
+                scfsi[k][i] = 2;
+                if (sf[k][0][i] > sf[k][2][i]) sf[k][0][i] = sf[k][2][i];
+                sf[k][1][i] = sf[k][2][i] = sf[k][0][i];
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* K3: 1024-point FHT, fft.c:78-1185, + energy fft.c:1278-1293                                */
+void mp2o_fht1024(double *fz)
+{
+    build_tables();
+    for (int i = 0; i < 1024; i++) {                 /* fft.c:1085-1090 swap pairs */
+        int r = g_bitrev[i];
+        if (r > i) { double a = fz[i]; fz[i] = fz[r]; fz[r] = a; }
+    }
+    for (double *fi = fz; fi < fz + 1024; fi += 4) { /* fft.c:1092-1102 */
+        double f1 = fi[0] - fi[1], f0 = fi[0] + fi[1], f3 = fi[2] - fi[3], f2 = fi[2] + fi[3];
+        fi[2] = f0 - f2; fi[0] = f0 + f2; fi[3] = f1 - f3; fi[1] = f1 + f3;
+    }
+    const double SQRT2 = 1.4142135623730951454746218587388284504414;
+    int tw = 0;
+    for (int k = 2; k <= 8; k += 2) {                /* fft.c:1104-1184 */
+        int k1 = 1 << k, k2 = k1 << 1, k4 = k2 << 1, k3 = k2 + k1, kx = k1 >> 1;
+        for (int base = 0; base < 1024; base += k4) {
+            double *fi = fz + base, *gi = fi + kx;
+            double f1 = fi[0] - fi[k1], f0 = fi[0] + fi[k1], f3 = fi[k2] - fi[k3], f2 = fi[k2] + fi[k3];
+            fi[k2] = f0 - f2; fi[0] = f0 + f2; fi[k3] = f1 - f3; fi[k1] = f1 + f3;
+            double g1 = gi[0] - gi[k1], g0 = gi[0] + gi[k1], g3 = SQRT2 * gi[k3], g2 = SQRT2 * gi[k2];
+            gi[k2] = g0 - g2; gi[0] = g0 + g2; gi[k3] = g1 - g3; gi[k1] = g1 + g3;
+        }
+        for (int i = 1; i < kx; i++, tw++) {
+            double c1 = g_fht_tw[tw][0], s1 = g_fht_tw[tw][1], c2 = g_fht_tw[tw][2], s2 = g_fht_tw[tw][3];
+            for (int base = 0; base < 1024; base += k4) {
+                double *fi = fz + base + i, *gi = fz + base + k1 - i;
+                double a, b, g0, f0, f1, g1, f2, g2, f3, g3;
+                b = s2 * fi[k1] - c2 * gi[k1]; a = c2 * fi[k1] + s2 * gi[k1];
+                f1 = fi[0] - a; f0 = fi[0] + a; g1 = gi[0] - b; g0 = gi[0] + b;
+                b = s2 * fi[k3] - c2 * gi[k3]; a = c2 * fi[k3] + s2 * gi[k3];
+                f3 = fi[k2] - a; f2 = fi[k2] + a; g3 = gi[k2] - b; g2 = gi[k2] + b;
+                b = s1 * f2 - c1 * g3; a = c1 * f2 + s1 * g3;
+                fi[k2] = f0 - a; fi[0] = f0 + a; gi[k3] = g1 - b; gi[k1] = g1 + b;
+                b = c1 * g2 - s1 * f3; a = s1 * g2 + c1 * f3;
+                gi[k2] = g0 - a; gi[0] = g0 + a; fi[k3] = f1 - b; fi[k1] = f1 + b;
+            }
+        }
+    }
+}
+
+/* window [t-192, t+832) of the channel, Hann, FHT, energy (psycho_1.c:57-76,215-239) */
+static void psy_spectrum(mp2o_enc *e, const short *pcm, int ch, double energy[513])
+{
+    double x[1024];
+    for (int i = 0; i < 192; i++) x[i] = ((double)e->psy_hist[ch][64 + i] / 32768) * g_hann[i];
+    for (int i = 0; i < 832; i++) x[192 + i] = ((double)pcm[i] / 32768) * g_hann[192 + i];
+    memcpy(e->psy_hist[ch], pcm + 1152 - 256, 256 * sizeof(short));
+    mp2o_fht1024(x);
+    energy[0] = x[0] * x[0];
+    for (int i = 1; i < 512; i++) { double a = x[i], b = x[1024 - i]; energy[i] = (a * a + b * b) / 2.0; }
+    energy[512] = x[512] * x[512];
+}
+
+static double add_db(double a, double b)            /* psycho_1.c:180-205 == psycho_3.c:44-69 */
+{
+    double fdiff = 10.0 * (a - b);
+    if (fdiff > 990.0) return a;
+    if (fdiff < -990.0) return b;
+    int idiff = (int)fdiff;
+    if (idiff >= 0) return a + g_dbtable[idiff];
+    return b + g_dbtable[-idiff];
+}
+
+/* masking function shared by psy 1 and 3 (psycho_1.c:494-503, psycho_3.c:359-369) */
+static double mask_vf(double dz, double x)
+{
+    if (dz < -1) return 17 * (dz + 1) - (0.4 * x + 6);
+    if (dz < 0) return (0.4 * x + 6) * dz;
+    if (dz < 1) return -17 * dz;
+    return -(dz - 1) * (17 - 0.15 * x) - 17;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* psy model 1, psycho_1.c:22-87 and :215-581                                                 */
+static void psy1_run(mp2o_enc *e, const short *pcm, int ch, const double *scale, double *smr)
+{
+    double energy[1024] = {0};
+    double px[513];
+    int ptype[513], pnext[513];
+    double spike[32];
+    int tone = 0, noise = 0;   /* `tone`/`noise` persist across channels in the reference (psycho_1.c:28) */
+    thr_line *ltg = e->p1_ltg;
+    const int *map = e->p1_map;
+    const int sub = e->p1_sub;
+
+    psy_spectrum(e, pcm, ch, energy);
+    for (int i = 0; i < 512; i++) {                          /* psycho_1.c:241-248 */
+        px[i] = energy[i] < 1E-20 ? -200.0 + POWERNORM : 10 * log10(energy[i]) + POWERNORM;
+        pnext[i] = L_STOP; ptype[i] = T_FALSE;
+    }
+    for (int i = 0; i < 512; i += 16) {                      /* psycho_1.c:252-257 */
+        double sum = 1E-20;
+        for (int j = 0; j < 16; j++) sum += 1073741824 * energy[i + j];
+        spike[i >> 4] = 10.0 * log10(sum);
+    }
+    /* --- tonal label, psycho_1.c:267-340 --- */
+    {
+        int last = L_LAST, first, run, last_but_one = L_LAST;
+        tone = L_LAST;
+        for (int i = 2; i < 500; i++)
+            if (px[i] > px[i - 1] && px[i] >= px[i + 1]) {
+                ptype[i] = T_TONE; pnext[i] = L_LAST;
+                if (last != L_LAST) pnext[last] = i; else first = tone = i;
+                last = i;
+            }
+        last = L_LAST; first = tone; tone = L_LAST;
+        while (first != L_LAST && first != L_STOP) {
+            if (first < 3 || first > 500) run = 0;
+            else if (first < 63) run = 2;
+            else if (first < 127) run = 3;
+            else if (first < 255) run = 6;
+            else run = 12;
+            double max = px[first] - 7;
+            for (int j = 2; j <= run; j++)
+                if (max < px[first - j] || max < px[first + j]) { ptype[first] = T_FALSE; break; }
+            if (ptype[first] == T_TONE) {
+                int help = first;
+                if (tone == L_LAST) tone = first;
+                while (pnext[help] != L_LAST && (pnext[help] - first) <= run) help = pnext[help];
+                help = pnext[help];
+                pnext[first] = help;
+                if ((first - last) <= run) { if (last_but_one != L_LAST) pnext[last_but_one] = first; }
+                if (first > 1 && first < 500) {
+                    double tmp = add_db(px[first - 1], px[first + 1]);
+                    px[first] = add_db(px[first], tmp);
+                }
+                for (int j = 1; j <= run; j++) {
+                    px[first - j] = px[first + j] = DBMIN;
+                    pnext[first - j] = pnext[first + j] = L_STOP;
+                    ptype[first - j] = ptype[first + j] = T_FALSE;
+                }
+                last_but_one = last; last = first; first = pnext[first];
+            } else {
+                if (last != L_LAST) pnext[last] = pnext[first];
+                int ll = first;
+                first = pnext[first];
+                pnext[ll] = L_STOP;
+            }
+        }
+    }
+    /* --- noise label, psycho_1.c:350-400 --- */
+    {
+        int last = L_LAST;
+        const int *cb = e->p1_cbound;
+        for (int i = 0; i < e->p1_ncb - 1; i++) {
+            double weight = 0.0, sum = DBMIN;
+            for (int j = cb[i]; j < cb[i + 1]; j++)
+                if (ptype[j] != T_TONE && px[j] != DBMIN) {
+                    sum = add_db(px[j], sum);
+                    weight += 1073741824 * energy[j] * (double)(j - cb[i]) / (double)(cb[i + 1] - cb[i]);
+                    px[j] = DBMIN;
+                }
+            int centre;
+            if (sum <= DBMIN) centre = (cb[i + 1] + cb[i]) / 2;
+            else {
+                double index = weight * pow(10.0, -0.1 * sum);
+                centre = cb[i] + (int)(index * (double)(cb[i + 1] - cb[i]));
+            }
+            if (ptype[centre] == T_TONE) { if (ptype[centre + 1] == T_TONE) centre++; else centre--; }
+            if (last == L_LAST) noise = centre;
+            else { pnext[centre] = L_LAST; pnext[last] = centre; }
+            px[centre] = sum; ptype[centre] = T_NOISE; last = centre;
+        }
+    }
+    /* --- subsampling / decimation, psycho_1.c:409-470 --- */
+    {
+        int i = tone, old = L_STOP;
+        while (i != L_LAST && i != L_STOP) {
+            if (px[i] < ltg[map[i]].hear) {
+                ptype[i] = T_FALSE; px[i] = DBMIN;
+                if (old == L_STOP) tone = pnext[i]; else pnext[old] = pnext[i];
+            } else old = i;
+            i = pnext[i];
+        }
+        i = noise; old = L_STOP;
+        while (i != L_LAST && i != L_STOP) {
+            if (px[i] < ltg[map[i]].hear) {
+                ptype[i] = T_FALSE; px[i] = DBMIN;
+                if (old == L_STOP) noise = pnext[i]; else pnext[old] = pnext[i];
+            } else old = i;
+            i = pnext[i];
+        }
+        i = tone; old = L_STOP;
+        while (i != L_LAST && i != L_STOP) {
+            if (pnext[i] == L_LAST) break;
+            if (ltg[map[pnext[i]]].bark - ltg[map[i]].bark < 0.5) {
+                if (px[pnext[i]] > px[i]) {
+                    if (old == L_STOP) tone = pnext[i]; else pnext[old] = pnext[i];
+                    ptype[i] = T_FALSE; px[i] = DBMIN; i = pnext[i];
+                } else {
+                    ptype[pnext[i]] = T_FALSE; px[pnext[i]] = DBMIN;
+                    pnext[i] = pnext[pnext[i]]; old = i;
+                }
+            } else { old = i; i = pnext[i]; }
+        }
+    }
+    /* --- individual + global thresholds, psycho_1.c:480-532 --- */
+    {
+        int bit_rate = kBitrate[e->version][e->br_idx] / e->nch;
+        for (int k = 1; k < sub; k++) {
+            ltg[k].x = DBMIN;
+            for (int t = tone; t != L_LAST && t != L_STOP; t = pnext[t]) {
+                double dz = ltg[k].bark - ltg[map[t]].bark;
+                if (dz >= -3.0 && dz < 8.0) {
+                    double tmps = -1.525 - 0.275 * ltg[map[t]].bark - 4.5 + px[t];
+                    ltg[k].x = add_db(ltg[k].x, tmps + mask_vf(dz, px[t]));
+                }
+            }
+            for (int t = noise; t != L_LAST && t != L_STOP; t = pnext[t]) {
+                double dz = ltg[k].bark - ltg[map[t]].bark;
+                if (dz >= -3.0 && dz < 8.0) {
+                    double tmps = -1.525 - 0.175 * ltg[map[t]].bark - 0.5 + px[t];
+                    ltg[k].x = add_db(ltg[k].x, tmps + mask_vf(dz, px[t]));
+                }
+            }
+            if (bit_rate < 96) ltg[k].x = add_db(ltg[k].hear, ltg[k].x);
+            else ltg[k].x = add_db(ltg[k].hear - 12.0, ltg[k].x);
+        }
+    }
+    /* --- minimum per subband, psycho_1.c:541-559, then SMR :568-581 --- */
+    {
+        int j = 1;
+        for (int i = 0; i < e->sblimit; i++)
+            if (j >= sub - 1) smr[i] = ltg[sub - 1].hear;
+            else {
+                double min = ltg[j].x;
+                while (j < sub && (ltg[j].line >> 4) == i) {   /* ref tests line before j<sub_size; see Appendix C */
+                    if (min > ltg[j].x) min = ltg[j].x;
+                    j++;
+                }
+                smr[i] = min;
+            }
+        for (int i = 0; i < e->sblimit; i++) {
+            double max = 20 * log10(scale[i] * 32768) - 10;
+            if (spike[i] > max) max = spike[i];
+            smr[i] = max - smr[i];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* psy model 3, psycho_3.c:71-432                                                             */
+static void psy3_run(mp2o_enc *e, const short *pcm, int ch, const double *scale, double *smr)
+{
+    double energy[1024] = {0};
+    double power[513], Xtm[513], Xnm[513], LTg[136], Lsb[32], Xmax[32];
+    int tonelabel[513], noiselabel[513], maxima[513];
+    const double *bark = e->p3_bark, *ath = e->p3_ath;
+
+    psy_spectrum(e, pcm, ch, energy);
+    /* power[0] is never written by the reference (psycho_3.c:152-160 starts at 1) yet is read once,
+       at psycho_3.c:231 for k=2,j=-2: an uninitialised stack slot.  In the reference build used for
+       the golden vectors that slot holds 0.0 (see DESIGN.md "psy-3 power[0]"); pin that value. */
+    power[0] = 0.0;
+    for (int i = 1; i < 513; i++)
+        power[i] = energy[i] < 1E-20 ? -200.0 + POWERNORM : 10 * log10(energy[i]) + POWERNORM;
+    /* SPL, psycho_3.c:163-183 (line 512 would index Xmax[32]; skipped) */
+    for (int i = 0; i < 32; i++) Xmax[i] = DBMIN;
+    for (int i = 1; i < 512; i++) if (Xmax[i >> 4] < power[i]) Xmax[i >> 4] = power[i];
+    for (int i = 0; i < 32; i++) {
+        double val = 20 * log10(scale[i] * 32768) - 10;
+        Lsb[i] = Xmax[i] > val ? Xmax[i] : val;
+    }
+    /* tonal label, psycho_3.c:186-247 */
+    maxima[0] = maxima[512] = 0; tonelabel[0] = tonelabel[512] = 0; Xtm[0] = Xtm[512] = DBMIN;
+    for (int i = 1; i < 512; i++) {
+        tonelabel[i] = 0; Xtm[i] = DBMIN;
+        maxima[i] = (power[i] > power[i - 1] && power[i] > power[i + 1]);
+    }
+    static const int rng[4][3] = {{2, 63, 2}, {63, 127, 3}, {127, 255, 6}, {255, 500, 12}};
+    for (int r = 0; r < 4; r++)
+        for (int k = rng[r][0]; k < rng[r][1]; k++)
+            if (maxima[k]) {
+                int sr = rng[r][2];
+                tonelabel[k] = T_TONE;
+                for (int j = -sr; j <= sr; j++)
+                    if (abs(j) > 1 && (power[k] - power[k + j]) < 7.0) tonelabel[k] = 0;
+                if (tonelabel[k] == T_TONE) {
+                    double temp = add_db(power[k - 1], power[k]);
+                    Xtm[k] = add_db(temp, power[k + 1]);
+                    for (int j = -sr; j <= sr; j++) power[k + j] = DBMIN;
+                }
+            }
+    /* noise label, psycho_3.c:264-304 (noiselabel[] is uninitialised in the reference; stale
+       entries always meet Xnm==DBMIN and are deleted at :314-319, so zero-init is equivalent) */
+    memset(noiselabel, 0, sizeof noiselabel);
+    Xnm[0] = DBMIN;
+    for (int i = 0; i < e->p3_cbands; i++) {
+        double sum = DBMIN, esum = 0, cw = 0;
+        int lo = e->p3_cbidx[i], hi = e->p3_cbidx[i + 1];
+        for (int j = lo; j < hi; j++) {
+            Xnm[j] = DBMIN;
+            if (power[j] != DBMIN) { sum = add_db(power[j], sum); esum += energy[j]; cw += (j - lo) * energy[j]; }
+        }
+        int centre = sum <= DBMIN ? (lo + hi) / 2 : lo + (int)(cw / esum);
+        Xnm[centre] = sum; noiselabel[centre] = T_NOISE;
+    }
+    /* decimation, psycho_3.c:309-331 */
+    for (int i = 1; i < 513; i++) {
+        if (noiselabel[i] == T_NOISE && Xnm[i] < ath[i]) { Xnm[i] = DBMIN; noiselabel[i] = 0; }
+        if (tonelabel[i] == T_TONE && Xtm[i] < ath[i]) { Xtm[i] = DBMIN; tonelabel[i] = 0; }
+    }
+    /* thresholds, psycho_3.c:339-406 */
+    {
+        int bit_rate = kBitrate[e->version][e->br_idx] / e->nch;
+        double LTtm[136], LTnm[136];
+        for (int i = 0; i < 136; i++) LTtm[i] = LTnm[i] = DBMIN;
+        for (int k = 1; k < 513; k++) {
+            if (tonelabel[k] == T_TONE)
+                for (int j = 0; j < 136; j++) {
+                    double dz = bark[e->p3_subset[j]] - bark[k];
+                    if (dz >= -3.0 && dz < 8.0) {
+                        double av = -1.525 - 0.275 * bark[k] - 4.5 + Xtm[k];
+                        LTtm[j] = add_db(LTtm[j], av + mask_vf(dz, Xtm[k]));
+                    }
+                }
+            if (noiselabel[k] == T_NOISE)
+                for (int j = 0; j < 136; j++) {
+                    double dz = bark[e->p3_subset[j]] - bark[k];
+                    if (dz >= -3.0 && dz < 8.0) {
+                        double av = -1.525 - 0.175 * bark[k] - 0.5 + Xnm[k];
+                        LTnm[j] = add_db(LTnm[j], av + mask_vf(dz, Xnm[k]));
+                    }
+                }
+        }
+        for (int i = 0; i < 136; i++) {
+            LTg[i] = add_db(LTnm[i], LTtm[i]);
+            if (bit_rate < 96) LTg[i] = add_db(ath[e->p3_subset[i]], LTg[i]);
+            else LTg[i] = add_db(ath[e->p3_subset[i]] - 12.0, LTg[i]);
+        }
+    }
+    /* minimum masking + SMR, psycho_3.c:409-432 (all 32 subbands) */
+    for (int i = 0; i < 32; i++) smr[i] = 999999.9;
+    for (int i = 0; i < 136; i++) { int sb = e->p3_subset[i] >> 4; if (smr[sb] > LTg[i]) smr[sb] = LTg[i]; }
+    for (int i = 0; i < 32; i++) smr[i] = Lsb[i] - smr[i];
+}
+
+/* psy model 0, psycho_0.c:27-69 */
+static void psy0_run(mp2o_enc *e, unsigned sf[2][3][32], double smr[2][32])
+{
+    for (int ch = 0; ch < e->nch; ch++)
+        for (int sb = 0; sb < 32; sb++) {
+            int m = (int)sf[ch][0][sb];
+            for (int gr = 1; gr < 3; gr++) if (m > (int)sf[ch][gr][sb]) m = (int)sf[ch][gr][sb];
+            smr[ch][sb] = 2.0 * (30.0 - m) - e->p0_athmin[sb];
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* K5: bit allocation, encode_new.c:634-705 (bits_for_nonoise_new), :733-886, :1061-1187       */
+static int line_of(const mp2o_enc *e, int sb) { return TL_LINE[e->tab * 32 + sb]; }
+static int stepidx(const mp2o_enc *e, int sb, unsigned ba) { return TL_STEP_INDEX[line_of(e, sb) * 16 + ba]; }
+static const int kSfsPerScfsi[4] = {3, 2, 1, 2};
+
+static int bits_for_nonoise(mp2o_enc *e, double SMR[2][32], unsigned scfsi[2][32], double min_mnr,
+                            unsigned bit_alloc[2][32])
+{
+    int nch = e->nch, sblimit = e->sblimit, jsbound = e->jsbound;
+    int bbal = 0, berr = 16, banc = 32;            /* error_protection is always on, toolame.c:146 */
+    for (int sb = 0; sb < jsbound; sb++) bbal += nch * TL_NBAL[line_of(e, sb)];
+    for (int sb = jsbound; sb < sblimit; sb++) bbal += TL_NBAL[line_of(e, sb)];
+    int req = banc + bbal + berr;
+    for (int sb = 0; sb < sblimit; sb++)
+        for (int ch = 0; ch < (sb < jsbound ? nch : 1); ch++) {
+            int maxAlloc = (1 << TL_NBAL[line_of(e, sb)]) - 1, ba;
+            for (ba = 0; ba < maxAlloc - 1; ba++)
+                if ((g_snr[stepidx(e, sb, ba)] - SMR[ch][sb]) >= min_mnr) break;
+            if (nch == 2 && sb >= jsbound)
+                for (; ba < maxAlloc - 1; ba++)
+                    if ((g_snr[stepidx(e, sb, ba)] - SMR[1 - ch][sb]) >= min_mnr) break;
+            if (ba > 0) {
+                int q = stepidx(e, sb, ba);
+                int smp = 12 * TL_GROUP[q] * TL_BITS[q], sel = 2, sc = 6 * kSfsPerScfsi[scfsi[ch][sb]];
+                if (nch == 2 && sb >= jsbound) { sel += 2; sc += 6 * kSfsPerScfsi[scfsi[1 - ch][sb]]; }
+                req += smp + sel + sc;
+            }
+            bit_alloc[ch][sb] = ba;
+        }
+    return req;
+}
+
+static void bit_allocation(mp2o_enc *e, double SMR[2][32], unsigned scfsi[2][32], unsigned bit_alloc[2][32], int *adb)
+{
+    int nch = e->nch, sblimit = e->sblimit;
+    if (e->mode0 == 1) {                            /* joint stereo, encode_new.c:803-819 */
+        static const int jsb[4] = {4, 8, 12, 16};
+        e->mode = 0; e->mode_ext = 0; e->jsbound = sblimit;
+        if (bits_for_nonoise(e, SMR, scfsi, 0, bit_alloc) > *adb) {
+            e->mode = 1;
+            int mode_ext = 4, rq;
+            do {
+                --mode_ext;
+                e->jsbound = jsb[mode_ext];
+                rq = bits_for_nonoise(e, SMR, scfsi, 0, bit_alloc);
+            } while (rq > *adb && mode_ext > 0);
+            e->mode_ext = mode_ext;
+        }
+    }
+    /* a_bit_allocation_new, encode_new.c:1078-1187 */
+    int jsbound = e->jsbound;
+    double mnr[2][32]; char used[2][32];
+    int bbal = 0, berr = 16, banc = 32;
+    for (int sb = 0; sb < jsbound; sb++) bbal += nch * TL_NBAL[line_of(e, sb)];
+    for (int sb = jsbound; sb < sblimit; sb++) bbal += TL_NBAL[line_of(e, sb)];
+    *adb -= bbal + berr + banc;
+    int ad = *adb;
+    for (int sb = 0; sb < sblimit; sb++)
+        for (int ch = 0; ch < nch; ch++) { mnr[ch][sb] = g_snr[0] - SMR[ch][sb]; bit_alloc[ch][sb] = 0; used[ch][sb] = 0; }
+    int bspl = 0, bscf = 0, bsel = 0;
+    for (;;) {
+        int min_sb = -1, min_ch = -1;               /* maxmnr_new, encode_new.c:1061-1077 */
+        double small = 999999.0;
+        for (int ch = 0; ch < nch; ch++)
+            for (int sb = 0; sb < sblimit; sb++)
+                if (used[ch][sb] != 2 && small > mnr[ch][sb]) { small = mnr[ch][sb]; min_sb = sb; min_ch = ch; }
+        if (min_sb < 0) break;
+        int q_next = stepidx(e, min_sb, bit_alloc[min_ch][min_sb] + 1);
+        int increment = 12 * TL_GROUP[q_next] * TL_BITS[q_next];
+        int oth = 1 - min_ch, scale = 0, seli = 0;
+        if (used[min_ch][min_sb]) {
+            int q = stepidx(e, min_sb, bit_alloc[min_ch][min_sb]);
+            increment -= 12 * TL_GROUP[q] * TL_BITS[q];
+        } else {
+            seli = 2; scale = 6 * kSfsPerScfsi[scfsi[min_ch][min_sb]];
+            if (nch == 2 && min_sb >= jsbound) { seli += 2; scale += 6 * kSfsPerScfsi[scfsi[oth][min_sb]]; }
+        }
+        if (ad >= bspl + bscf + bsel + seli + scale + increment) {
+            unsigned ba = ++bit_alloc[min_ch][min_sb];
+            bspl += increment; bscf += scale; bsel += seli;
+            used[min_ch][min_sb] = 1;
+            mnr[min_ch][min_sb] = g_snr[stepidx(e, min_sb, ba)] - SMR[min_ch][min_sb];
+            if ((int)ba >= (1 << TL_NBAL[line_of(e, min_sb)]) - 1) used[min_ch][min_sb] = 2;
+        } else used[min_ch][min_sb] = 2;
+        if (min_sb >= jsbound && nch == 2) {
+            unsigned ba = bit_alloc[oth][min_sb] = bit_alloc[min_ch][min_sb];
+            used[oth][min_sb] = used[min_ch][min_sb];
+            mnr[oth][min_sb] = g_snr[stepidx(e, min_sb, ba)] - SMR[oth][min_sb];
+        }
+    }
+    ad -= bspl + bscf + bsel;
+    *adb = ad;
+    for (int ch = 0; ch < nch; ch++) for (int sb = sblimit; sb < 32; sb++) bit_alloc[ch][sb] = 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* one frame: toolame.c:267-554                                                                */
+int mp2o_encode_frame(mp2o_enc *e, const short pcm[2][1152], const unsigned char *xpad, size_t xpad_len,
+                      unsigned char *out, size_t out_size)
+{
+    mp2o_taps *T = &e->taps;
+    const int nch = e->nch, sblimit = e->sblimit;
+    e->frame_num++;
+    e->out = out; e->out_size = out_size; e->out_written = 0;
+
+    int adb = available_bits(e, 1);
+    int lg_frame = adb / 8;
+    if (e->frame_num == 1) e->minimum = lg_frame + 4;          /* toolame.c:298-300 */
+    adb -= e->dab_ext * 8 + (int)(xpad_len ? xpad_len : 2) * 8; /* toolame.c:301 */
+
+    for (int gr = 0; gr < 3; gr++)                             /* toolame.c:308-312 */
+        for (int bl = 0; bl < 12; bl++)
+            for (int ch = 0; ch < nch; ch++)
+                mp2o_filterbank_block(e, ch, &pcm[ch][gr * 384 + 32 * bl], T->sb_sample[ch][gr][bl]);
+
+    scalefactors((const double(*)[3][12][32])T->sb_sample, T->scalar, nch, sblimit);
+    for (int ch = 0; ch < nch; ch++)                           /* find_sf_max, encode_new.c:260-277 */
+        for (int sb = 0; sb < sblimit; sb++) {
+            unsigned lo = T->scalar[ch][0][sb];
+            for (int gr = 1; gr < 3; gr++) if (lo > T->scalar[ch][gr][sb]) lo = T->scalar[ch][gr][sb];
+            T->max_sc[ch][sb] = g_scalefactor[lo];
+        }
+    for (int sb = sblimit; sb < 32; sb++) T->max_sc[0][sb] = T->max_sc[1][sb] = 1E-20;
+    if (e->mode0 == 1) {                                       /* toolame.c:332-337 */
+        for (int sb = 0; sb < sblimit; sb++)
+            for (int s = 0; s < 12; s++)
+                for (int gr = 0; gr < 3; gr++)
+                    T->j_sample[gr][s][sb] = .5 * (T->sb_sample[0][gr][s][sb] + T->sb_sample[1][gr][s][sb]);
+        scalefactors((const double(*)[3][12][32])T->j_sample, (unsigned(*)[3][32])T->j_scale, 1, sblimit);
+    }
+    memcpy(T->scalar_pre, T->scalar, sizeof T->scalar);
+
+    switch (e->psy) {                                          /* toolame.c:361-452 */
+    case 0: psy0_run(e, T->scalar, T->smr); break;
+    case 1: for (int ch = 0; ch < nch; ch++) psy1_run(e, pcm[ch], ch, T->max_sc[ch], T->smr[ch]); break;
+    case 3: for (int ch = 0; ch < nch; ch++) psy3_run(e, pcm[ch], ch, T->max_sc[ch], T->smr[ch]); break;
+    case 2: case 4: for (int ch = 0; ch < nch; ch++) psy2_run(e, pcm[ch], ch, T->smr[ch]); break;
+    }
+
+    sf_pattern(e, T->scalar, T->scfsi);
+    bit_allocation(e, T->smr, T->scfsi, T->bit_alloc, &adb);
+    T->adb_left = adb; T->mode = e->mode; T->mode_ext = e->mode_ext; T->jsbound = e->jsbound;
+    const int jsbound = e->jsbound;
+
+    /* CRC_calc, crc.c:12-41 */
+    unsigned crc = 0xffff;
+    {
+        const unsigned hv[9][2] = {{(unsigned)e->br_idx, 4}, {(unsigned)e->fs_idx, 2}, {(unsigned)e->padding, 1}, {0, 1},
+                                   {(unsigned)e->mode, 2}, {(unsigned)e->mode_ext, 2}, {0, 1}, {0, 1}, {0, 2}};
+        for (int i = 0; i < 9; i++) crc_upd(&crc, hv[i][0], (int)hv[i][1], 0x8005, 0x8000, 0xffff);
+        for (int sb = 0; sb < sblimit; sb++)
+            for (int ch = 0; ch < (sb < jsbound ? nch : 1); ch++)
+                crc_upd(&crc, T->bit_alloc[ch][sb], TL_NBAL[line_of(e, sb)], 0x8005, 0x8000, 0xffff);
+        for (int sb = 0; sb < sblimit; sb++)
+            for (int ch = 0; ch < nch; ch++)
+                if (T->bit_alloc[ch][sb]) crc_upd(&crc, T->scfsi[ch][sb], 2, 0x8005, 0x8000, 0xffff);
+    }
+    T->crc16 = crc;
+    /* write_header, encode_new.c:356-373 */
+    bs_put(e, 0xfff, 12); bs_put(e, (unsigned)e->version, 1); bs_put(e, 4 - 2, 2); bs_put(e, 0, 1);
+    bs_put(e, (unsigned)e->br_idx, 4); bs_put(e, (unsigned)e->fs_idx, 2); bs_put(e, (unsigned)e->padding, 1);
+    bs_put(e, 0, 1); bs_put(e, (unsigned)e->mode, 2); bs_put(e, (unsigned)e->mode_ext, 2);
+    bs_put(e, 0, 1); bs_put(e, 0, 1); bs_put(e, 0, 2);
+    bs_put(e, crc, 16);                                        /* toolame.c:478-480 */
+    for (int sb = 0; sb < sblimit; sb++)                       /* write_bit_alloc, encode_new.c:383-399 */
+        for (int ch = 0; ch < (sb < jsbound ? nch : 1); ch++)
+            bs_put(e, T->bit_alloc[ch][sb], TL_NBAL[line_of(e, sb)]);
+    for (int sb = 0; sb < sblimit; sb++)                       /* write_scalefactors, encode_new.c:413-444 */
+        for (int ch = 0; ch < nch; ch++)
+            if (T->bit_alloc[ch][sb]) bs_put(e, T->scfsi[ch][sb], 2);
+    for (int sb = 0; sb < sblimit; sb++)
+        for (int ch = 0; ch < nch; ch++)
+            if (T->bit_alloc[ch][sb])
+                switch (T->scfsi[ch][sb]) {
+                case 0: for (int gr = 0; gr < 3; gr++) bs_put(e, T->scalar[ch][gr][sb], 6); break;
+                case 1: case 3: bs_put(e, T->scalar[ch][0][sb], 6); bs_put(e, T->scalar[ch][2][sb], 6); break;
+                case 2: bs_put(e, T->scalar[ch][0][sb], 6);
+                }
+    /* subband_quantization_new, encode_new.c:479-547 */
+    for (int gr = 0; gr < 3; gr++)
+        for (int j = 0; j < 12; j++)
+            for (int sb = 0; sb < sblimit; sb++)
+                for (int ch = 0; ch < (sb < jsbound ? nch : 1); ch++)
+                    if (T->bit_alloc[ch][sb]) {
+                        double d;
+                        if (nch == 2 && sb >= jsbound) d = T->j_sample[gr][j][sb] / g_scalefactor[T->j_scale[gr][sb]];
+                        else d = T->sb_sample[ch][gr][j][sb] / g_scalefactor[T->scalar[ch][gr][sb]];
+                        int q = stepidx(e, sb, T->bit_alloc[ch][sb]), sig;
+                        d = d * g_qa[q] + g_qb[q];
+                        if (d >= 0) sig = 1; else { sig = 0; d += 1.0; }
+                        unsigned v = (unsigned)(d * (double)TL_STEPS2N[q]);
+                        if (sig) v |= (unsigned)TL_STEPS2N[q];
+                        T->subband[ch][gr][j][sb] = v;
+                    }
+    for (int ch = 0; ch < nch; ch++)
+        for (int gr = 0; gr < 3; gr++)
+            for (int j = 0; j < 12; j++)
+                for (int sb = sblimit; sb < 32; sb++) T->subband[ch][gr][j][sb] = 0;
+    /* write_samples_new, encode_new.c:560-598 */
+    for (int gr = 0; gr < 3; gr++)
+        for (int j = 0; j < 12; j += 3)
+            for (int sb = 0; sb < sblimit; sb++)
+                for (int ch = 0; ch < (sb < jsbound ? nch : 1); ch++)
+                    if (T->bit_alloc[ch][sb]) {
+                        int q = stepidx(e, sb, T->bit_alloc[ch][sb]);
+                        if (TL_GROUP[q] == 3)
+                            for (int x = 0; x < 3; x++) bs_put(e, T->subband[ch][gr][j + x][sb], TL_BITS[q]);
+                        else {
+                            unsigned y = (unsigned)TL_STEPS[q];
+                            unsigned t = T->subband[ch][gr][j][sb] + T->subband[ch][gr][j + 1][sb] * y
+                                       + T->subband[ch][gr][j + 2][sb] * y * y;
+                            bs_put(e, t, TL_BITS[q]);
+                        }
+                    }
+    for (int i = 0; i < adb; i++) bs_put(e, 0, 1);             /* stuffing, toolame.c:510-512 */
+    if (xpad_len)                                              /* X-PAD, toolame.c:515-524 */
+        for (int i = e->dab_length - (int)xpad_len; i < e->dab_length - 2; i++) bs_put(e, xpad[i], 8);
+    /* ScF-CRC, toolame.c:527-542 + crc.c:58-97 */
+    for (int i = e->dab_ext - 1; i >= 0; i--) {
+        static const int f[5] = {0, 4, 8, 16, 30};
+        int first = f[i], last = f[i + 1] > sblimit ? sblimit : f[i + 1];
+        unsigned c8 = 0;
+        for (int sb = first; sb < last; sb++)
+            for (int ch = 0; ch < nch; ch++)
+                if (T->bit_alloc[ch][sb])
+                    switch (T->scfsi[ch][sb]) {
+                    case 0: for (int g = 0; g < 3; g++) crc_upd(&c8, T->scalar[ch][g][sb] >> 3, 3, 0x1D, 0x80, 0xff); break;
+                    case 1: case 3:
+                        crc_upd(&c8, T->scalar[ch][0][sb] >> 3, 3, 0x1D, 0x80, 0xff);
+                        crc_upd(&c8, T->scalar[ch][2][sb] >> 3, 3, 0x1D, 0x80, 0xff); break;
+                    case 2: crc_upd(&c8, T->scalar[ch][0][sb] >> 3, 3, 0x1D, 0x80, 0xff);
+                    }
+        T->scfcrc[e->dab_ext - 1 - i] = (unsigned char)c8;
+        /* patch the byte written lg_frame bytes ago = the previous frame's slot (toolame.c:530-532) */
+        if (e->fill - lg_frame >= 0) e->buf[e->fill - lg_frame] = (unsigned char)c8;
+        bs_put(e, c8, 8);
+    }
+    if (xpad_len) { bs_put(e, xpad[e->dab_length - 2], 8); bs_put(e, xpad[e->dab_length - 1], 8); }
+    else bs_put(e, 0, 16);                                     /* F-PAD, toolame.c:544-551 */
+    return e->out_written;
+}
+
+int mp2o_finish(mp2o_enc *e, unsigned char *out, size_t out_size)   /* bitstream.c:87-92 */
+{
+    e->out = out; e->out_size = out_size; e->out_written = 0;
+    bs_put(e, 0, 7);
+    bs_flush(e, 0);
+    return e->out_written;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* psy model 2 (psycho_2.c:52-436) -- filled in by mp2_oracle_psy2.inc when present            */
+#if __has_include("mp2_oracle_psy2.inc")
+#include "mp2_oracle_psy2.inc"
+#else
+static void psy2_init(mp2o_enc *e) { (void)e; }
+static void psy2_run(mp2o_enc *e, const short *pcm, int ch, double *smr)
+{ (void)e; (void)pcm; (void)ch; for (int i = 0; i < 32; i++) smr[i] = 0; }
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* integer-only PCM generator (mirrored in tests/pcmgen.py)                                    */
+static uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+static int tri16(uint32_t phase)           /* triangle in [-16384, 16383] from a 16-bit phase */
+{
+    uint32_t p = phase & 0xFFFFu;
+    int t = p < 32768u ? (int)p : (int)(65535u - p);
+    return t - 16384;
+}
+static int asr(int v, int s) { return v >= 0 ? v >> s : -((-v + (1 << s) - 1) >> s); }  /* floor shift */
+
+static int gen_sample(uint32_t seed, int kind, int ch, uint32_t n)
+{
+    int c = (kind == 5) ? 0 : ch;
+    uint32_t h = mix32(n * 0x9E3779B1u ^ (seed * 0x85EBCA6Bu + (uint32_t)c * 0xC2B2AE35u + 0x165667B1u));
+    switch (kind) {
+    case 1: return 0;
+    case 2: { uint32_t P = 2 + seed % 63; return ((n / P) & 1u) ? 32767 : -32768; }
+    case 3: return (n % 5000u) == 100u ? 32767 : 0;
+    case 4: return (int)(h & 0xFFFFu) - 32768;
+    case 6: return (int)(h % 3u) - 1;
+    default: break;
+    }
+    uint32_t s0 = 150 + mix32(seed * 3u + 1u) % 3000u;
+    uint32_t s1 = 3000 + mix32(seed * 3u + 2u) % 9000u + (uint32_t)c * 37u;
+    uint32_t s2 = 12000 + mix32(seed * 3u + 3u) % 10000u;
+    int v = asr(tri16(n * s0 + (uint32_t)c * 9000u), 1) + asr(tri16(n * s1), 2) + asr(tri16(n * s2 + (uint32_t)c * 20000u), 3);
+    v += (int)(h & 0x1FFFu) - 4096;
+    if (kind == 7) v = asr(v, (int)((n >> 9) % 8u));
+    return v;
+}
+void mp2o_gen_pcm(uint32_t seed, int kind, int frame, short pcm[2][1152])
+{
+    for (int ch = 0; ch < 2; ch++)
+        for (int i = 0; i < 1152; i++) {
+            int v = gen_sample(seed, kind, ch, (uint32_t)frame * 1152u + (uint32_t)i);
+            pcm[ch][i] = (short)(v > 32767 ? 32767 : v < -32768 ? -32768 : v);
+        }
+}
+
+long mp2o_bench_stream(long samplerate, char mode, int kbps, int psy, uint32_t seed, int nframes)
+{
+    mp2o_enc *e = mp2o_create(samplerate, mode, kbps, psy, 0);
+    if (!e) return -1;
+    static _Thread_local short pcm[2][1152];
+    unsigned char out[4096];
+    long total = 0;
+    for (int f = 0; f < nframes; f++) {
+        mp2o_gen_pcm(seed, 0, f, pcm);
+        total += mp2o_encode_frame(e, (const short(*)[1152])pcm, NULL, 0, out, sizeof out);
+    }
+    total += mp2o_finish(e, out, sizeof out);
+    mp2o_destroy(e);
+    return total;
+}
