@@ -33,6 +33,8 @@ static double g_dbtable[1000];
 static double g_fht_tw[166][4];      /* (c1,s1,c2,s2) per (pass,i) in fft.c:1141-1149 order */
 static unsigned short g_bitrev[1024];
 static int g_tables_ready;
+static double g_p3_power0 = 0.0;   /* see psy3_run */
+void mp2o_debug_set_p3_power0(double v) { g_p3_power0 = v; }
 
 static const int kBitrate[2][15] = {  /* common.c:28-31 */
     {0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160},
@@ -665,7 +667,7 @@ static void psy3_run(mp2o_enc *e, const short *pcm, int ch, const double *scale,
     /* power[0] is never written by the reference (psycho_3.c:152-160 starts at 1) yet is read once,
        at psycho_3.c:231 for k=2,j=-2: an uninitialised stack slot.  In the reference build used for
        the golden vectors that slot holds 0.0 (see DESIGN.md "psy-3 power[0]"); pin that value. */
-    power[0] = 0.0;
+    power[0] = g_p3_power0;
     for (int i = 1; i < 513; i++)
         power[i] = energy[i] < 1E-20 ? -200.0 + POWERNORM : 10 * log10(energy[i]) + POWERNORM;
     /* SPL, psycho_3.c:163-183 (line 512 would index Xmax[32]; skipped) */
@@ -706,7 +708,10 @@ static void psy3_run(mp2o_enc *e, const short *pcm, int ch, const double *scale,
             Xnm[j] = DBMIN;
             if (power[j] != DBMIN) { sum = add_db(power[j], sum); esum += energy[j]; cw += (j - lo) * energy[j]; }
         }
-        int centre = sum <= DBMIN ? (lo + hi) / 2 : lo + (int)(cw / esum);
+        /* esum == 0 (every line of the band has exactly zero energy, i.e. digital silence) makes the
+           reference evaluate (int)(0.0/0.0) and index Xnm[] out of bounds -- it segfaults
+           (psycho_3.c:299-301).  Defined here (and in the HIP path) as the band centre. */
+        int centre = (sum <= DBMIN || esum == 0) ? (lo + hi) / 2 : lo + (int)(cw / esum);
         Xnm[centre] = sum; noiselabel[centre] = T_NOISE;
     }
     /* decimation, psycho_3.c:309-331 */
@@ -1020,6 +1025,26 @@ static void psy2_init(mp2o_enc *e) { (void)e; }
 static void psy2_run(mp2o_enc *e, const short *pcm, int ch, double *smr)
 { (void)e; (void)pcm; (void)ch; for (int i = 0; i < 32; i++) smr[i] = 0; }
 #endif
+
+/* table taps for tests/test_oracle_golden.py::test_tables */
+int mp2o_get_table(const mp2o_enc *e, const char *name, double *out, int n)
+{
+    const double *src = NULL; int len = 0;
+    double tmp[136];
+    if (!strcmp(name, "enwindow")) { src = g_enwindow; len = 512; }
+    else if (!strcmp(name, "scalefactor")) { src = g_scalefactor; len = 64; }
+    else if (!strcmp(name, "dct")) { src = &g_dct[0][0]; len = 512; }
+    else if (!strcmp(name, "hann")) { src = g_hann; len = 1024; }
+    else if (!strcmp(name, "dbtable")) { src = g_dbtable; len = 1000; }
+    else if (!strcmp(name, "p3_bark")) { src = e->p3_bark; len = 513; }
+    else if (!strcmp(name, "p3_ath")) { src = e->p3_ath; len = 513; }
+    else if (!strcmp(name, "p3_cbidx")) { for (int i = 0; i <= e->p3_cbands; i++) tmp[i] = e->p3_cbidx[i]; src = tmp; len = e->p3_cbands + 1; }
+    else if (!strcmp(name, "p3_subset")) { for (int i = 0; i < 136; i++) tmp[i] = e->p3_subset[i]; src = tmp; len = 136; }
+    else return -1;
+    if (n < len) return -1;
+    memcpy(out, src, (size_t)len * sizeof(double));
+    return len;
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* integer-only PCM generator (mirrored in tests/pcmgen.py)                                    */

@@ -69,6 +69,11 @@ const mp2o_taps *mp2o_get_taps(const mp2o_enc *e);
 void mp2o_filterbank_block(mp2o_enc *e, int ch, const short pcm32[32], double s[32]);
 void mp2o_fht1024(double *x);
 
+/* Init-time table taps (enwindow, scalefactor, dct, hann, dbtable, p3_bark, p3_ath, p3_cbidx,
+ * p3_subset) as doubles; returns the length or -1. */
+int mp2o_get_table(const mp2o_enc *e, const char *name, double *out, int n);
+void mp2o_debug_set_p3_power0(double v);
+
 /* Integer-only synthetic PCM (identical in numpy: tests/pcmgen.py).  kind: 0 tones+noise,
  * 1 silence, 2 full-scale square, 3 impulse, 4 full-scale noise, 5 channel-identical tones,
  * 6 low-level (+-1 LSB) noise.  Fills planar pcm[2][1152] for frame index `frame` of stream `seed`. */

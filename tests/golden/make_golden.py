@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference
+(oracle/_ref/libtoolame_ref.so, built by oracle/Makefile from /root/reference/libtoolame-dab/*.c)
+on seeded integer PCM (tests/pcmgen.py).  Runs only in the build container; the .npz files are
+committed and are the fixtures every parity test (oracle, HIP path) is anchored on.
+
+Each case file holds: the configuration, the PCM seed/kind (PCM itself is regenerated), the
+reference's output bytes (all toolame_encode_frame calls + toolame_finish), the per-call return
+lengths (pins the 4096-byte burst cadence), and per-frame stage taps read from the
+reference's own statics (toolame.c:96-115): scalar, scfsi, bit_alloc, smr, max_sc, mode/mode_ext,
+plus sb_sample / quantised subband samples for selected frames.
+"""
+import ctypes as C
+import pickle
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent))
+import oraclelib as O  # noqa: E402
+from pcmgen import gen_pcm  # noqa: E402
+
+NFRAMES = 16
+BIG_TAP_FRAMES = (0, 5)
+
+CONFIGS = [  # (samplerate, mode, kbps)
+    (48000, "s", 128), (48000, "j", 128), (48000, "s", 192), (32000, "m", 64), (24000, "m", 64),
+    (48000, "s", 96), (48000, "j", 192), (48000, "d", 128), (24000, "j", 64), (48000, "m", 64),
+]
+
+
+def cases():
+    out = []
+    for psy in (0, 1, 3):
+        for i, (fs, mode, kbps) in enumerate(CONFIGS):
+            out.append(dict(name=f"p{psy}_{fs // 1000}k_{mode}_{kbps}_k0", samplerate=fs, mode=mode, kbps=kbps,
+                            psy=psy, kind=0, seed=100 + i, pad_len=0))
+    for psy in (1, 3):
+        for mode in ("s", "j"):
+            for kind in range(1, 8):
+                if psy == 3 and kind in (1, 3):
+                    continue  # the reference segfaults on digital silence with psy 3 (psycho_3.c:299)
+                out.append(dict(name=f"p{psy}_48k_{mode}_128_k{kind}", samplerate=48000, mode=mode, kbps=128,
+                                psy=psy, kind=kind, seed=7 + kind, pad_len=0))
+    out.append(dict(name="p1_48k_j_128_xpad", samplerate=48000, mode="j", kbps=128, psy=1, kind=0, seed=42, pad_len=58))
+    out.append(dict(name="p3_48k_s_192_xpad", samplerate=48000, mode="s", kbps=192, psy=3, kind=0, seed=43, pad_len=58))
+    return out
+
+
+def xpads_for(case):
+    if not case["pad_len"]:
+        return None
+    rng = np.random.default_rng(case["seed"])
+    lens = [58, 10, 2, 0, 34, 58]
+    return [(bytes(rng.integers(0, 256, case["pad_len"] + 1, dtype=np.uint8)), lens[i % 6]) for i in range(NFRAMES)]
+
+
+_TABLE_CHILD = r"""
+import ctypes as C, sys, numpy as np, pickle
+L = C.CDLL(sys.argv[1])
+L.toolame_set_samplerate.argtypes = [C.c_long]; L.toolame_set_channel_mode.argtypes = [C.c_char]
+L.toolame_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+L.toolame_init(); L.toolame_set_samplerate(48000); L.toolame_set_psy_model(int(sys.argv[3]))
+L.toolame_set_channel_mode(b's'); L.toolame_set_bitrate(128); L.toolame_set_pad(0)
+pcm = ((np.arange(2304) * 7919) % 2001 - 1000).astype(np.int16).reshape(2,1152); out = (C.c_ubyte*4096)()
+L.toolame_encode_frame(pcm.ctypes.data, None, 0, out, 4096)
+g = lambda name, ct, n: np.ctypeslib.as_array((ct*n).in_dll(L, name)).copy()
+d = dict(enwindow=g('enwindow', C.c_double, 512), scalefactor=g('scalefactor', C.c_double, 64),
+         multiple=g('multiple', C.c_double, 64))
+m = (C.c_double*512)(); L.create_dct_matrix(m); d['dct'] = np.ctypeslib.as_array(m).copy()
+if sys.argv[3] == '1':
+    d['dbtable'] = g('dbtable', C.c_double, 1000)
+else:
+    d['p3_bark'] = g('bark', C.c_double, 513); d['p3_ath'] = g('ath', C.c_double, 513)
+    nb = C.c_int.in_dll(L, 'cbands').value
+    d['p3_cbidx'] = g('cbandindex', C.c_int, 32)[:nb+1]; d['p3_subset'] = g('freq_subset', C.c_int, 136)
+pickle.dump(d, open(sys.argv[2], 'wb'))
+"""
+
+
+def make_tables():
+    d = {}
+    for psy in ("1", "3"):
+        tmp = HERE / f"_tables{psy}.pkl"
+        subprocess.run([sys.executable, "-c", _TABLE_CHILD, str(O.REF_SO), str(tmp), psy], check=True,
+                       stderr=subprocess.DEVNULL)
+        d.update(pickle.load(open(tmp, "rb")))
+        tmp.unlink()
+    np.savez_compressed(HERE / "tables_48k.npz", **d)
+
+
+def main():
+    if not O.REF_SO.exists():
+        subprocess.run(["make", "-C", str(O.ORACLE_DIR), "ref"], check=True)
+    make_tables()
+    total = 0
+    for case in cases():
+        pcm = gen_pcm(case["seed"], case["kind"], 0, NFRAMES)
+        xp = xpads_for(case)
+        ref = O.reference_stream(pcm, samplerate=case["samplerate"], mode=case["mode"], kbps=case["kbps"],
+                                 psy=case["psy"], pad_len=case["pad_len"], xpads=xp, tap_frames=range(NFRAMES))
+        assert ref["rc"] == [0] * 6, ref["rc"]
+        t = ref["taps"]
+        arrs = dict(
+            data=np.frombuffer(ref["data"], dtype=np.uint8), lens=np.array(ref["lens"], dtype=np.int32),
+            scalar=np.stack([t[i]["scalar"] for i in range(NFRAMES)]).astype(np.uint8),
+            j_scale=np.stack([t[i]["j_scale"] for i in range(NFRAMES)]).astype(np.uint8),
+            scfsi=np.stack([t[i]["scfsi"] for i in range(NFRAMES)]).astype(np.uint8),
+            bit_alloc=np.stack([t[i]["bit_alloc"] for i in range(NFRAMES)]).astype(np.uint8),
+            smr=np.stack([t[i]["smr"] for i in range(NFRAMES)]),
+            max_sc=np.stack([t[i]["max_sc"] for i in range(NFRAMES)]),
+            mode=np.array([t[i]["mode"] for i in range(NFRAMES)], dtype=np.int8),
+            mode_ext=np.array([t[i]["mode_ext"] for i in range(NFRAMES)], dtype=np.int8),
+            cfg=np.array([case["samplerate"], ord(case["mode"]), case["kbps"], case["psy"], case["kind"],
+                          case["seed"], case["pad_len"], NFRAMES], dtype=np.int64),
+        )
+        if case["psy"] == 1 and case["kind"] == 0:      # the 18 KB/frame taps only where they add coverage
+            arrs["sb_sample"] = np.stack([t[i]["sb_sample"] for i in BIG_TAP_FRAMES])
+            arrs["subband"] = np.stack([t[i]["subband"] for i in BIG_TAP_FRAMES]).astype(np.uint16)
+            arrs["big_tap_frames"] = np.array(BIG_TAP_FRAMES, dtype=np.int32)
+        if xp is not None:
+            arrs["xpad"] = np.stack([np.frombuffer(x[0], dtype=np.uint8) for x in xp])
+            arrs["xpad_len"] = np.array([x[1] for x in xp], dtype=np.int32)
+        f = HERE / (case["name"] + ".npz")
+        np.savez_compressed(f, **arrs)
+        total += f.stat().st_size
+    print(len(cases()), "cases,", total // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

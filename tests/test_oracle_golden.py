@@ -1,0 +1,96 @@
+"""The oracle (oracle/mp2_oracle.c) against the golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  Bit-exact: bytes, burst cadence, every integer tap, and the fp64
+taps compared as raw bit patterns.  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oraclelib as O
+from conftest import golden_cases
+from pcmgen import gen_pcm
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.mark.parametrize("path", golden_cases(), ids=lambda p: p.stem)
+def test_oracle_matches_reference_golden(path):
+    g = np.load(path)
+    fs, mode, kbps, psy, kind, seed, pad_len, nframes = (int(v) for v in g["cfg"])
+    pcm = gen_pcm(seed, kind, 0, nframes)
+    e = O.OracleEncoder(samplerate=fs, mode=chr(mode), kbps=kbps, psy=psy, pad_len=pad_len)
+    nch, sbl = e.nch, e.sblimit
+    chunks, lens = [], []
+    big = {int(f): i for i, f in enumerate(g["big_tap_frames"])} if "big_tap_frames" in g else {}
+    for i in range(nframes):
+        if "xpad" in g:
+            b = e.encode(pcm[i], bytes(g["xpad"][i]), int(g["xpad_len"][i]))
+        else:
+            b = e.encode(pcm[i])
+        chunks.append(b)
+        lens.append(len(b))
+        t = e.taps()
+        assert np.array_equal(t["scalar"][:nch, :, :sbl], g["scalar"][i][:nch, :, :sbl]), ("scalar", i)
+        assert np.array_equal(t["scfsi"][:nch, :sbl], g["scfsi"][i][:nch, :sbl]), ("scfsi", i)
+        assert np.array_equal(t["bit_alloc"][:nch], g["bit_alloc"][i][:nch]), ("bit_alloc", i)
+        assert np.array_equal(_bits(t["max_sc"][:nch]), _bits(g["max_sc"][i][:nch])), ("max_sc", i)
+        nsmr = 32 if psy in (0, 3) else sbl          # psy 1 writes only sblimit entries
+        assert np.array_equal(_bits(t["smr"][:nch, :nsmr]), _bits(g["smr"][i][:nch, :nsmr])), ("smr", i)
+        assert (t["mode"], t["mode_ext"]) == (int(g["mode"][i]), int(g["mode_ext"][i])), ("mode", i)
+        if chr(mode) == "j":
+            assert np.array_equal(t["j_scale"][:, :sbl], g["j_scale"][i][:, :sbl]), ("j_scale", i)
+        if i in big:
+            assert np.array_equal(_bits(t["sb_sample"][:nch]), _bits(g["sb_sample"][big[i]][:nch])), ("sb_sample", i)
+            assert np.array_equal(t["subband"][:nch], g["subband"][big[i]][:nch]), ("subband", i)
+    b = e.finish()
+    chunks.append(b)
+    lens.append(len(b))
+    assert lens == list(g["lens"])
+    assert b"".join(chunks) == g["data"].tobytes()
+    assert len(g["data"]) == nframes * e.frame_bytes       # whole frames, incl. the finish() tail
+
+
+def test_tables_match_reference(golden_dir):
+    g = np.load(golden_dir / "tables_48k.npz")
+    e = O.OracleEncoder(psy=3)
+    L = O.lib()
+    L.mp2o_get_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+    buf = np.zeros(1024, dtype=np.float64)
+    for name in ("enwindow", "scalefactor", "dct", "dbtable", "p3_bark", "p3_ath", "p3_cbidx", "p3_subset"):
+        n = L.mp2o_get_table(e.h, name.encode(), buf.ctypes.data, 1024)
+        ref = np.asarray(g[name], dtype=np.float64).ravel()
+        assert n == len(ref), name
+        if name in ("p3_bark", "p3_ath"):           # index 0 is never written by the reference
+            assert np.array_equal(_bits(buf[1:n]), _bits(ref[1:])), name
+        else:
+            assert np.array_equal(_bits(buf[:n]), _bits(ref)), name
+    assert np.array_equal(_bits(g["multiple"]), _bits(g["scalefactor"]))
+
+
+def test_burst_cadence_128k():
+    """0 bytes for 10 calls, 3708 on the 11th, ... and finish() flushes the rest."""
+    pcm = gen_pcm(1, 0, 0, 24)
+    data, lens = O.oracle_stream(pcm, psy=1)
+    assert lens[:10] == [0] * 10 and lens[10] == 3708 and lens[20] == 3708
+    assert sum(lens) == 24 * 384 == len(data)
+
+
+def test_header_bytes_128k_stereo():
+    """Appendix A: FF FC 84 00 for 48 kHz / 128 kbps / mode 's'."""
+    data, _ = O.oracle_stream(gen_pcm(2, 0, 0, 3), psy=1)
+    for f in range(3):
+        assert data[f * 384: f * 384 + 4] == bytes([0xFF, 0xFC, 0x84, 0x00])
+
+
+def test_illegal_configs_rejected():
+    for kw in (dict(samplerate=44000), dict(kbps=100), dict(mode="x"), dict(psy=7), dict(pad_len=-1)):
+        with pytest.raises(ValueError):
+            O.OracleEncoder(**kw)
+
+
+def test_silence_psy3_is_defined():
+    """The reference segfaults here (psycho_3.c:299, (int)(0/0) index); the oracle defines it."""
+    data, _ = O.oracle_stream(gen_pcm(0, 1, 0, 4), psy=3)
+    assert len(data) == 4 * 384
