@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the batched DAB MP2 encode path on MI355X.
+
+Metric (BASELINE.json): real-time stereo DAB MP2 streams sustained, as frames/s, @128 kbps / 48 kHz.
+Workload at N=1 = BASELINE.json configs[1]: 4096 streams x 48 kHz stereo x 128 kbps, psy model 1, full
+encode (filterbank + psy + allocation + quantise + pack + CRC/ScF-CRC), PCM resident in HBM.
+
+A "step" = one launch of the hot path: every stream encodes FRAMES_PER_STEP consecutive frames
+(per-stream state stays in LDS between them).  One process per GPU; streams shard with no data-path
+collective (weak scaling: each rank owns its own 4096 streams); RCCL is used only for the barrier
+and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+STREAMS_PER_GPU = 4096
+FRAMES_PER_STEP = 8
+FS, MODE, KBPS, PSY = 48000, "s", 128, 1
+ALGO_BYTES_PER_FRAME = 2 * 1152 * 2 + 144000 * KBPS // FS      # PCM in + bitstream out = 4992
+HBM_PEAK_GBS = 8000.0                                           # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def cpu_baseline(seconds_target=12.0):
+    """The REAL reference (oracle/_ref/libtoolame_ref.so, built from the reference's own sources) when
+    it travelled with the repo, else the oracle port; one core, bounded sample of the same workload."""
+    ref_so = ROOT / "oracle" / "_ref" / "libtoolame_ref.so"
+    ora_so = ROOT / "oracle" / "libmp2oracle.so"
+    if not ora_so.exists():
+        subprocess.run(["make", "-s", "-C", str(ROOT / "oracle"), "libmp2oracle.so"], check=False)
+    nframes = int(seconds_target * 4500)
+    child = r"""
+import ctypes as C, sys, time, numpy as np
+ref, ora, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
+O = C.CDLL(ora); O.mp2o_gen_pcm.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+pcm = np.zeros((64, 2, 1152), dtype=np.int16)
+for f in range(64): O.mp2o_gen_pcm(0, 0, f, pcm[f].ctypes.data)
+out = (C.c_ubyte * 4096)()
+if ref:
+    L = C.CDLL(ref)
+    L.toolame_set_samplerate.argtypes = [C.c_long]; L.toolame_set_channel_mode.argtypes = [C.c_char]
+    L.toolame_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.toolame_init(); L.toolame_set_samplerate(%d); L.toolame_set_psy_model(%d); L.toolame_set_channel_mode(b'%s')
+    L.toolame_set_bitrate(%d); L.toolame_set_pad(0)
+    ptrs = [pcm[f].ctypes.data for f in range(64)]
+    t = time.perf_counter()
+    for i in range(n): L.toolame_encode_frame(ptrs[i & 63], None, 0, out, 4096)
+    dt = time.perf_counter() - t
+else:
+    O.mp2o_create.restype = C.c_void_p; O.mp2o_create.argtypes = [C.c_long, C.c_char, C.c_int, C.c_int, C.c_int]
+    O.mp2o_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    h = O.mp2o_create(%d, b'%s', %d, %d, 0)
+    ptrs = [pcm[f].ctypes.data for f in range(64)]
+    t = time.perf_counter()
+    for i in range(n): O.mp2o_encode_frame(h, ptrs[i & 63], None, 0, out, 4096)
+    dt = time.perf_counter() - t
+print(n / dt)
+""" % (FS, PSY, MODE, KBPS, FS, MODE, KBPS, PSY)
+    kind = "reference" if ref_so.exists() else "port"
+    try:
+        r = subprocess.run([sys.executable, "-c", child, str(ref_so) if ref_so.exists() else "", str(ora_so), str(nframes)],
+                           capture_output=True, text=True, timeout=120)
+        fps = float(r.stdout.strip().splitlines()[-1])
+    except Exception as ex:  # noqa: BLE001
+        return {"value": None, "unit": "frames/s", "cores": 1, "kind": kind, "sample": f"failed: {ex}"}
+    return {"value": round(fps, 1), "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": f"{nframes} frames of one stream (seed 0, tones+noise), {FS} Hz mode '{MODE}' {KBPS} kbps psy {PSY}, "
+                      f"{'libtoolame-dab compiled from the reference sources' if kind == 'reference' else 'oracle/mp2_oracle.c'}, gcc -O2, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU")
+    ap.add_argument("--frames-per-step", type=int, default=FRAMES_PER_STEP)
+    ap.add_argument("--psy", type=int, default=PSY)
+    ap.add_argument("--mode", default=MODE)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import odr_audioenc_amd as M
+    from pcmgen import gen_pcm
+
+    S, F = args.streams, args.frames_per_step
+    # stream i of rank r uses seed r*S + i; two alternating PCM buffers = frames [0,F) and [F,2F)
+    t0 = time.time()
+    host = np.empty((2 * F, S, 2, 1152), dtype=np.int16)
+    for s in range(S):
+        host[:, s] = gen_pcm(rank * S + s, 0, 0, 2 * F)
+    pcm = [torch.from_numpy(host[:F].copy()).cuda(), torch.from_numpy(host[F:].copy()).cuda()]
+    del host
+    batch = M.Batch([M.StreamConfig(samplerate=FS, mode=args.mode, bitrate=KBPS, psy_model=args.psy)] * S, device=local_rank)
+    out = torch.zeros((F, S, batch.out_stride), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    def step(i):
+        batch.encode_device(pcm[i & 1].data_ptr(), F, out.data_ptr(), stream=stream.cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        evs[i][0].record(stream)
+        step(args.warmup + i)
+        evs[i][1].record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    last_ms = batch.last_kernel_ms()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the frames are real frames (sync word + right length), never timed
+    chk = out[1, :4].cpu().numpy()
+    assert all(bytes(chk[s, :2]) == b"\xff\xfc" for s in range(4)), "output is not an MPEG audio frame"
+
+    if rank == 0:
+        frames = world * S * F * args.steps
+        value = frames / elapsed
+        algo_bytes_per_launch = ALGO_BYTES_PER_FRAME * S * F
+        achieved = algo_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "metric": "real-time stereo DAB MP2 streams sustained (frames/s) @128 kbps/48 kHz",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{S} streams/GPU x 48 kHz stereo (mode '{args.mode}') x 128 kbps, psy {args.psy}, full encode "
+                                   f"(BASELINE configs[1]), {F} frames/stream/step", "streams_per_gpu": S, "frames_per_step": F,
+                       "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
+            "realtime_streams": round(value / (FS / 1152.0), 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "kernel": "tl_encode_kernel", "kernel_ms": round(kernel_ms, 4), "last_kernel_ms_hip_events": round(last_ms, 4),
+                         "algorithmic_bytes_per_launch": algo_bytes_per_launch,
+                         "note": "the path is fp64-VALU/LDS-latency bound, not HBM bound (SURVEY F9): compulsory traffic is "
+                                 "4992 B per 0.35 MFLOP frame"},
+            "lds_bytes_per_stream": M.lds_bytes_per_stream(),
+            "setup_s": round(time.time() - t0, 1),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline()
+        elif world > 1:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

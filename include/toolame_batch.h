@@ -1,0 +1,116 @@
+/* toolame_batch.h -- C-ABI of the MI355X-native batched DAB MP2 (MPEG-1/2 Layer II) encoder.
+ *
+ * Drop-in boundary.  The library exports two groups of symbols:
+ *
+ *  (1) The reference's own nine-function ABI, unchanged, so src/odr-audioenc.cpp:89-92,686-735,
+ *      1135-1163 links against this library exactly as it links against libtoolame-dab.a.
+ *      Declarations: /root/reference/libtoolame-dab/toolame.h:13-48, export list
+ *      /root/reference/libtoolame-dab.sym.  They drive stream 0 of a private one-stream batch and
+ *      reproduce toolame_encode_frame()'s bursty 4096-byte output cadence (bitstream.c:46-71).
+ *
+ *  (2) A handle-based batched API (tlb_*) -- what the reference cannot offer because all of its
+ *      state is process-global (toolame.c:24-26,89-118): N independent streams, mixed
+ *      configurations, whole-frame output, device-resident buffers and an explicit HIP stream.
+ *
+ * All pointers are plain C pointers; "d_" parameters are HIP device pointers.  No torch types.
+ * Every function returns 0 on success and non-zero on error unless stated otherwise
+ * (toolame.h:9-10).  The library needs a gfx950 GPU: there is no CPU fallback, tlb_create()
+ * fails with TLB_ERR_NO_DEVICE when none is usable.
+ */
+#ifndef TOOLAME_BATCH_H
+#define TOOLAME_BATCH_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------
+ * (1) legacy ABI -- replaces libtoolame-dab/toolame.h:13-48 one for one
+ * ------------------------------------------------------------------------------------------ */
+int toolame_init(void);                                     /* toolame.c:120 */
+int toolame_finish(unsigned char *output_buffer, size_t output_buffer_size);   /* toolame.c:155 -> bytes written */
+int toolame_enable_byteswap(void);                          /* toolame.c:168 */
+int toolame_set_channel_mode(const char mode);              /* toolame.c:174  's','d','j','m' */
+int toolame_set_psy_model(int new_model);                   /* toolame.c:202  0..3 */
+int toolame_set_bitrate(int brate);                         /* toolame.c:212  kbps */
+int toolame_set_samplerate(long sample_rate);               /* toolame.c:239  Hz */
+int toolame_set_pad(int pad_len);                           /* toolame.c:250 */
+int toolame_encode_frame(short buffer[2][1152], unsigned char *xpad_data, size_t xpad_len,
+                         unsigned char *output_buffer, size_t output_buffer_size);   /* toolame.c:267 -> bytes written */
+
+/* ---------------------------------------------------------------------------------------------
+ * (2) batched API
+ * ------------------------------------------------------------------------------------------ */
+#define TLB_MAX_XPAD 200           /* X-PAD + F-PAD bytes per frame */
+#define TLB_SAMPLES_PER_FRAME 1152
+
+enum {
+    TLB_OK = 0,
+    TLB_ERR_SAMPLERATE = 1,        /* SmpFrqIndex, common.c:118-144 (+ 44.1/22.05 kHz: padding slots unsupported) */
+    TLB_ERR_MODE = 2,              /* toolame.c:195-197 */
+    TLB_ERR_PSY = 3,               /* toolame.c:204-207 */
+    TLB_ERR_BITRATE = 4,           /* common.c:95-116 (the reference exit(-1)s; we return an error) */
+    TLB_ERR_PAD = 5,               /* toolame.c:252-255 */
+    TLB_ERR_NO_DEVICE = 16,
+    TLB_ERR_HIP = 17,
+    TLB_ERR_ARG = 18,
+};
+
+/* The six knobs odr-audioenc sets (src/odr-audioenc.cpp:687-722), per stream. */
+typedef struct {
+    long samplerate;               /* 48000, 32000, 24000, 16000 */
+    char mode;                     /* 's' stereo, 'j' joint stereo, 'd' dual channel, 'm' mono */
+    int bitrate;                   /* kbps; 0 = the reference default (192 / 160) */
+    int psy_model;                 /* 0, 1, 3 */
+    int pad_len;                   /* toolame_set_pad(): upper bound of xpad_len, 0..TLB_MAX_XPAD */
+} tlb_stream_config;
+
+typedef struct tlb_batch tlb_batch;
+
+int tlb_device_count(void);
+/* Create `nstreams` encoders on HIP device `device`.  On failure returns NULL and stores a TLB_ERR_*
+ * code in *err (if err != NULL). */
+tlb_batch *tlb_create(int device, int nstreams, const tlb_stream_config *cfgs, int *err);
+void tlb_destroy(tlb_batch *b);
+int tlb_reset(tlb_batch *b);                       /* back to the state right after tlb_create() */
+
+int tlb_nstreams(const tlb_batch *b);
+int tlb_frame_bytes(const tlb_batch *b, int stream);   /* 144000*kbps/fs: 384 @128k/48k, 576 @192k/48k ... */
+int tlb_out_stride(const tlb_batch *b);                /* max frame_bytes over the batch, multiple of 4 */
+long tlb_frames_encoded(const tlb_batch *b);           /* per stream */
+
+/* Encode `nframes` frames of every stream, buffers resident in HBM.
+ *   d_pcm      int16  [nframes][nstreams][2][1152]   planar like `short buffer[2][1152]`; mono reads [0] only
+ *   d_xpad     uint8  [nframes][nstreams][TLB_MAX_XPAD] or NULL: the xpad_len bytes in transmission order
+ *              (X-PAD bytes, then the two F-PAD bytes; toolame.c:515-551)
+ *   d_xpad_len int32  [nframes][nstreams] or NULL; each 0 or 2..pad_len
+ *   d_out      uint8  [nframes][nstreams][tlb_out_stride()]
+ * Frame n of a stream is final only once frame n+1 has been analysed (its ScF-CRC is stored in frame
+ * n, toolame.c:527-542), so output slot f of this call holds the frame that was pending before input
+ * frame f: slot 0 = the last frame of the previous call (undefined on the very first call), slot f =
+ * input frame f-1.  tlb_flush_*() hands out the final pending frame.
+ * The launch is asynchronous on `hip_stream` (a hipStream_t, NULL = default stream). */
+int tlb_encode_device(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d_xpad,
+                      const int32_t *d_xpad_len, uint8_t *d_out, void *hip_stream);
+/* Same with host buffers (synchronous; copies over PCIe).  `taps`, if not NULL, receives
+ * [nframes][nstreams] TlTaps records (csrc/mp2_types.h) for stage-level parity tests. */
+int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t *xpad, const int32_t *xpad_len,
+                    uint8_t *out, void *taps);
+/* Copy every stream's pending (last) frame to out[nstreams][tlb_out_stride()] (host memory).
+ * Streams that have not encoded any frame yet get zero bytes.  Does not change state. */
+int tlb_flush_host(tlb_batch *b, uint8_t *out);
+int tlb_flush_device(tlb_batch *b, uint8_t *d_out, void *hip_stream);
+
+/* Duration in milliseconds of the most recent tlb_encode_device()/tlb_encode_host() kernel, measured
+ * with hipEvents on the launch stream (synchronises on that stream).  < 0 on error. */
+float tlb_last_kernel_ms(tlb_batch *b);
+/* LDS bytes per wavefront and resident waves per CU the kernel was built/launched with. */
+int tlb_lds_bytes_per_stream(void);
+const char *tlb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

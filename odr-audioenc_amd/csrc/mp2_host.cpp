@@ -1,0 +1,205 @@
+// mp2_host.cpp -- see mp2_host.h.  Compiled with -ffp-contract=off.
+#include "mp2_host.h"
+
+#include <math.h>
+#include <string.h>
+
+#include "mp2_tables.inc"
+
+namespace {
+const double kRefPi = 3.14159265358979;            // common.h:26 -- truncated in the reference
+const int kBitrate[2][15] = {                      // common.c:28-31
+    {0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160},
+    {0, 32, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384}};
+const double kSfreq[2][4] = {{22.05, 24, 16, 0}, {44.1, 48, 32, 0}};   // common.c:26
+
+double bits_to_double(unsigned long long u) { double d; memcpy(&d, &u, 8); return d; }
+
+double ath_db(double f, double value)              // ath.c:7-47
+{
+    if (f < -.3) f = 3410;
+    f /= 1000;
+    f = f > 0.01 ? f : 0.01;
+    f = f < 18.0 ? f : 18.0;
+    double ath = 3.640 * pow(f, -0.8) - 6.800 * exp(-0.6 * pow(f - 3.4, 2.0))
+               + 6.000 * exp(-0.15 * pow(f - 8.7, 2.0)) + (0.6 + 0.04 * 0.0) * 0.001 * pow(f, 4.0);
+    return ath + value;
+}
+double freq2bark(double freq)                      // ath.c:73-78
+{
+    if (freq < 0) freq = 0;
+    freq = freq * 0.001;
+    return 13.0 * atan(.76 * freq) + 3.5 * atan(freq * freq / (7.5 * 7.5));
+}
+}  // namespace
+
+void tl_build_tables(TlTables *T)
+{
+    memset(T, 0, sizeof *T);
+    for (int i = 0; i < 512; i++) T->enwindow[i] = (double)TL_ENWINDOW_E9[i] / 1e9;
+    for (int i = 0; i < 63; i++) T->scalefactor[i] = (double)TL_SCALEFACTOR_E14[i] / 1e14;
+    T->scalefactor[63] = 1e-20;
+    for (int q = 0; q < 18; q++) {
+        T->snr[q] = (double)TL_SNR_E2[q] / 100.0;
+        T->qa[q] = (double)TL_QUANT_A_E9[q] / 1e9;
+        T->qb[q] = (double)TL_QUANT_B_E9[q] / 1e9;
+        T->steps[q] = TL_STEPS[q];
+        T->steps2n[q] = TL_STEPS2N[q];
+        T->steps2n_f[q] = (double)TL_STEPS2N[q];
+        T->bits[q] = TL_BITS[q];
+        T->group[q] = TL_GROUP[q];
+    }
+    for (int l = 0; l < 9; l++) {
+        T->nbal_line[l] = TL_NBAL[l];
+        for (int b = 0; b < 16; b++) T->step_index[l][b] = TL_STEP_INDEX[l * 16 + b];
+    }
+    // matrixing coefficients: cos scaled by 1e9, rounded half away from zero, scaled back (subband.c:125-137)
+    for (int i = 0; i < 16; i++)
+        for (int k = 0; k < 32; k++) {
+            double f = 1e9 * cos((double)((2 * i + 1) * k * kRefPi / 64)), ip;
+            if (f >= 0) modf(f + 0.5, &ip); else modf(f - 0.5, &ip);
+            T->dct[i][k] = ip * 1e-9;
+        }
+    // Hann window with the sqrt(8/3)/N normalisation (psycho_1.c:225-233, psycho_3.c:135-141)
+    const double sqrt_8_over_3 = pow(8.0 / 3.0, 0.5);
+    for (int i = 0; i < 1024; i++) T->hann[i] = sqrt_8_over_3 * 0.5 * (1 - cos(2.0 * kRefPi * i / 1024)) / 1024;
+    // dB-sum table (psycho_1.c:170-178, psycho_3.c:249-257)
+    for (int i = 0; i < 1000; i++) {
+        double x = (double)i / 10.0;
+        T->dbtable[i] = 10 * log10(1 + pow(10.0, x / 10.0)) - x;
+    }
+    // Buneman recurrence of fft.c:1139-1149 unrolled into a table (passes k = 2,4,6,8)
+    int n = 0;
+    for (int k = 2; k <= 8; k += 2) {
+        const int kx = (1 << k) >> 1;
+        const double t_c = bits_to_double(TL_FHT_COS_BITS[k]), t_s = bits_to_double(TL_FHT_SIN_BITS[k]);
+        double c1 = 1, s1 = 0;
+        for (int i = 1; i < kx; i++, n++) {
+            double t = c1;
+            c1 = t * t_c - s1 * t_s;
+            s1 = t * t_s + s1 * t_c;
+            T->fht_tw[n][0] = c1; T->fht_tw[n][1] = s1;
+            T->fht_tw[n][2] = c1 * c1 - s1 * s1; T->fht_tw[n][3] = 2 * (c1 * s1);
+        }
+    }
+}
+
+int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, int pad_len)
+{
+    memset(C, 0, sizeof *C);
+    switch (samplerate) {                                         // SmpFrqIndex, common.c:118-144
+    case 48000: C->version = 1; C->fs_idx = 1; break;
+    case 32000: C->version = 1; C->fs_idx = 2; break;
+    case 24000: C->version = 0; C->fs_idx = 1; break;
+    case 16000: C->version = 0; C->fs_idx = 2; break;
+    // 44100 / 22050 need padding slots (availbits.c:49-62); DAB does not use them
+    // (src/odr-audioenc.cpp:560-563 accepts 24000/48000 only) -- rejected by the device path.
+    default: return TL_ERR_SAMPLERATE;
+    }
+    if (psy < 0 || psy > 3 || psy == 2) return TL_ERR_PSY;       // psy 2 (and the 4 extension): next round
+    C->psy = psy;
+    switch (mode) {                                               // toolame.c:174-200
+    case 's': C->mode0 = 0; C->mode_ext0 = 0; break;
+    case 'd': C->mode0 = 2; C->mode_ext0 = 0; break;
+    case 'j': C->mode0 = 1; C->mode_ext0 = 2; break;
+    case 'm': C->mode0 = 3; C->mode_ext0 = 0; break;
+    default: return TL_ERR_MODE;
+    }
+    C->nch = C->mode0 == 3 ? 1 : 2;
+    if (kbps == 0) kbps = kBitrate[C->version][10];               // toolame.c:217-218
+    C->br_idx = -1;
+    for (int i = 1; i < 15; i++) if (kBitrate[C->version][i] == kbps) C->br_idx = i;
+    if (C->br_idx < 0) return TL_ERR_BITRATE;
+    C->kbps = kbps;
+    C->br_per_ch = kbps / C->nch;
+    C->dab_ext = 4;                                               // toolame.c:147,225-232
+    if (C->version == 1 && (kbps / (C->mode0 == 3 ? 1 : 2) < 56)) C->dab_ext = 2;
+    if (pad_len < 0 || pad_len > TL_MAX_XPAD) return TL_ERR_PAD;
+    C->dab_length = pad_len;
+    {   // alloc table choice (encode_new.c:104-125)
+        const int sfrq = (int)kSfreq[C->version][C->fs_idx], b = C->br_per_ch;
+        if (C->version == 1) {
+            if ((sfrq == 48 && b >= 56) || (b >= 56 && b <= 80)) C->tab = 0;
+            else if (sfrq != 48 && b >= 96) C->tab = 1;
+            else if (sfrq != 32 && b <= 48) C->tab = 2;
+            else C->tab = 3;
+        } else C->tab = 4;
+    }
+    C->sblimit = TL_TABLE_SBLIMIT[C->tab];
+    {
+        const int jsb[4] = {4, 8, 12, 16};                        // common.c:64-74
+        C->jsbound0 = C->mode0 == 1 ? jsb[C->mode_ext0] : C->sblimit;
+    }
+    for (int sb = 0; sb < 32; sb++) {
+        C->line[sb] = TL_LINE[C->tab * 32 + sb];
+        C->nbal[sb] = sb < C->sblimit ? TL_NBAL[C->line[sb]] : 0;
+    }
+    {   // slots per frame (availbits.c:36-67); the supported rates never need a padding slot
+        const double average = (1152.0 / kSfreq[C->version][C->fs_idx]) * ((double)kbps / 8.0);
+        const int whole = (int)average;
+        if (average - (double)whole != 0) return TL_ERR_SAMPLERATE;
+        C->frame_bytes = whole;
+        if (whole > TL_MAX_FRAME_BYTES || (whole & 3)) return TL_ERR_BITRATE;
+    }
+    for (int i = 0; i < 63; i++) {
+        const double sf = (double)TL_SCALEFACTOR_E14[i] / 1e14;
+        C->scale_db[i] = 20 * log10(sf * 32768) - 10;             // psycho_1.c:575, psycho_3.c:180
+    }
+    C->scale_db[63] = 20 * log10(1e-20 * 32768) - 10;
+
+    // ---- psy model 1 tables (psycho_1.c:94-168) ----
+    {
+        const int t = C->version == 1 ? C->fs_idx : C->fs_idx + 4;
+        C->p1_ncb = TL_PSY1_CBOUND[t * 28];
+        for (int i = 0; i < C->p1_ncb; i++) C->p1_cbound[i] = TL_PSY1_CBOUND[t * 28 + 1 + i];
+        C->p1_sub = TL_PSY1_FREQ_ENTRIES[t] + 1;
+        C->p1_line[0] = 0; C->p1_bark[0] = 0.0; C->p1_hear[0] = 0.0;
+        for (int i = 1; i < C->p1_sub; i++) {
+            C->p1_line[i] = TL_PSY1_LINE[t * 132 + i - 1];
+            C->p1_bark[i] = (double)TL_PSY1_BARK_E3[t * 132 + i - 1] / 1000.0;
+            C->p1_hear[i] = (double)TL_PSY1_HEAR_E2[t * 132 + i - 1] / 100.0;
+        }
+        for (int i = 1; i < C->p1_sub; i++)
+            for (int j = C->p1_line[i - 1]; j <= C->p1_line[i]; j++) C->p1_map[j] = (uint8_t)i;
+        // resolve the sequential minimum-mask walk (psycho_1.c:541-559) into per-subband row ranges
+        int j = 1;
+        for (int sb = 0; sb < C->sblimit; sb++) {
+            if (j >= C->p1_sub - 1) { C->p1_mm_j0[sb] = 0; C->p1_mm_n[sb] = 0; continue; }
+            int j0 = j;
+            while (j < C->p1_sub && (C->p1_line[j] >> 4) == sb) j++;
+            C->p1_mm_j0[sb] = (int16_t)j0;
+            C->p1_mm_n[sb] = (int16_t)(j > j0 ? j - j0 : 1);     // empty subband: the walk reads row j0 once
+        }
+    }
+    // ---- psy model 3 tables (psycho_3.c:434-512) ----
+    {
+        const double sfreq = kSfreq[C->version][C->fs_idx] * 1000;
+        for (int i = 1; i < 513; i++) {
+            const double freq = i * sfreq / 1024;
+            C->p3_bark[i] = freq2bark(freq);
+            C->p3_ath[i] = ath_db(freq, 0);
+        }
+        int cbase = 0, cb = 0;
+        C->p3_cbidx[0] = 1;
+        for (int i = 1; i < 513; i++)
+            if ((C->p3_bark[i] - C->p3_bark[cbase]) > 1.0) { cbase = i; cb++; C->p3_cbidx[cb] = (int16_t)cbase; }
+        cb++;
+        C->p3_cbidx[cb] = 513;
+        C->p3_cbands = cb;
+        int n = 0, i = 1;
+        for (; i < 3 * 16 + 1; i++) C->p3_subset[n++] = (int16_t)i;
+        for (; i < 6 * 16 + 1; i += 2) C->p3_subset[n++] = (int16_t)i;
+        for (; i < 12 * 16 + 1; i += 4) C->p3_subset[n++] = (int16_t)i;
+        for (; i < 32 * 16 + 1; i += 8) C->p3_subset[n++] = (int16_t)i;
+    }
+    // ---- psy model 0 (psycho_0.c:36-50) ----
+    {
+        const double per_line = kSfreq[C->version][C->fs_idx] * 1000 / 1024.0;
+        for (int sb = 0; sb < 32; sb++) C->p0_athmin[sb] = 1000;
+        for (int i = 0; i < 512; i++) {
+            const double v = ath_db(i * per_line, 0);
+            if (v < C->p0_athmin[i >> 4]) C->p0_athmin[i >> 4] = v;
+        }
+    }
+    return TL_OK;
+}

@@ -1,0 +1,97 @@
+// mp2_types.h -- data layout shared by the host runtime and the HIP kernels.
+//
+// One *stream* = one independent DAB MP2 encoder instance (what the reference keeps in process
+// globals, libtoolame-dab/toolame.c:89-118).  Streams are grouped by *config* (sample rate, mode,
+// bitrate, psy model); a config carries every table the per-frame path needs, pre-computed on the
+// host with the host libm exactly like the reference's init code does.
+#pragma once
+#include <stdint.h>
+
+#define TL_MAX_FRAME_BYTES 1728      // 384 kbps @ 32 kHz
+#define TL_MAX_FRAME_WORDS (TL_MAX_FRAME_BYTES / 4)
+#define TL_HIST 480                  // filterbank history (512-32); psy-1/3 need the last 192
+#define TL_MAX_XPAD 200              // X-PAD + F-PAD bytes per frame handled on device
+
+// Tables common to every config.  (ref: enwindow.h, subband.c:125-137, psycho_1.c:170-178,225-233,
+// fft.c:38-73,1139-1149, encode_new.c:16-100,448-462)
+struct TlTables {
+    double enwindow[512];
+    double dct[16][32];
+    double hann[1024];
+    double dbtable[1000];
+    double fht_tw[166][4];       // (c1,s1,c2,s2) for passes k=2,4,6,8, i=1..kx-1
+    double scalefactor[64];
+    double snr[18];
+    double qa[18], qb[18];
+    double steps2n_f[18];        // (double)steps2n[q]
+    int32_t steps[18];
+    int32_t steps2n[18];
+    uint8_t bits[18];
+    uint8_t group[18];           // 3 = three codewords, 1 = one grouped codeword
+    uint8_t step_index[9][16];
+    uint8_t nbal_line[9];
+    uint8_t pad_[3];
+};
+
+// Per-config constants.  (ref: toolame.c:120-262, common.c:76-144, encode_new.c:104-125)
+struct TlConfig {
+    int32_t version, fs_idx, br_idx, kbps, nch, mode0, mode_ext0, tab, sblimit, jsbound0;
+    int32_t dab_ext, dab_length, psy, frame_bytes, br_per_ch;
+    int32_t p1_ncb, p1_sub, p3_cbands;
+    uint8_t line[32];            // alloc-table line per subband (255 above sblimit)
+    uint8_t nbal[32];            // bits of the bit_alloc field per subband
+    double scale_db[64];         // 20*log10(scalefactor[i]*32768) - 10   (psycho_1.c:575, psycho_3.c:180)
+    // psy model 1 (psycho_1.c:94-168; ISO Table D.1/D.2)
+    int16_t p1_cbound[28];
+    int16_t p1_line[136];
+    double p1_bark[136];
+    double p1_hear[136];
+    uint8_t p1_map[520];
+    int16_t p1_mm_j0[32];        // minimum-mask walk (psycho_1.c:541-559) resolved per subband:
+    int16_t p1_mm_n[32];         //   first table row, number of rows (0 => use hear[sub-1])
+    // psy model 3 (psycho_3.c:434-512)
+    double p3_bark[520];
+    double p3_ath[520];
+    int16_t p3_cbidx[36];
+    int16_t p3_subset[136];
+    // psy model 0 (psycho_0.c:36-50)
+    double p0_athmin[32];
+};
+
+// Per-stream state that persists across launches.
+struct TlStreamState {
+    int16_t hist[2][TL_HIST];               // last 480 PCM samples per channel
+    uint32_t pending[TL_MAX_FRAME_WORDS];   // previous frame, waiting for its ScF-CRC (toolame.c:527-542)
+    int32_t frames_done;
+    int32_t pad_;
+};
+
+// Optional per-frame stage taps for parity tests (written only when a tap buffer is given).
+struct TlTaps {
+    double sb_sample[2][3][12][32];
+    double smr[2][32];
+    double max_sc[2][32];
+    uint32_t subband[2][3][12][32];
+    uint8_t scalar_pre[2][3][32];
+    uint8_t scalar[2][3][32];
+    uint8_t j_scale[3][32];
+    uint8_t scfsi[2][32];
+    uint8_t bit_alloc[2][32];
+    int32_t adb_left, mode, mode_ext, jsbound, crc16;
+    uint8_t scfcrc[4];
+    int32_t pad_[2];
+};
+
+// Launch arguments (plain pointers; device pointers on the GPU, host pointers in the emulation).
+struct TlLaunch {
+    const TlTables *tables;
+    const TlConfig *configs;          // [nconfigs]
+    const int32_t *stream_cfg;        // [nstreams] -> config index
+    TlStreamState *state;             // [nstreams]
+    const int16_t *pcm;               // [nframes][nstreams][2][1152]
+    const uint8_t *xpad;              // [nframes][nstreams][TL_MAX_XPAD] or null
+    const int32_t *xpad_len;          // [nframes][nstreams] or null
+    uint8_t *out;                     // [nframes][nstreams][out_stride]: slot f holds frame (f-1); slot 0 = pending
+    TlTaps *taps;                     // [nframes][nstreams] or null
+    int32_t nstreams, nframes, out_stride, pad_;
+};

@@ -1,0 +1,1067 @@
+// mp2_wave.h -- the DAB MP2 (MPEG-1/2 Layer II) frame encoder as ONE WAVEFRONT PER STREAM.
+//
+// This is the MI355X-native restatement of toolame_encode_frame()
+// (/root/reference/libtoolame-dab/toolame.c:267-554): 64 lanes cooperate on one stream's frame,
+// all per-frame working state lives in LDS / registers, HBM sees PCM in and frame bytes out.
+//
+// The file is written in a lane-SPMD style that compiles two ways from the same source:
+//   * hipcc --offload-arch=gfx950 : TL_LANES_BEGIN/END open a per-lane scope, cross-lane
+//     exchange goes through LDS or wave shuffles, TL_SYNC() is a wavefront-scope fence;
+//   * -DTL_EMULATE (g++, tests only): TL_LANES_BEGIN/END are `for (lane = 0..63)` loops and
+//     per-lane "registers" are [64] arrays, so the CPU test-suite executes exactly the device
+//     algorithm (same arithmetic, same order) and compares it with the oracle.
+//
+// Exactness rules: fp64 everywhere, no FMA contraction (-ffp-contract=off),
+// every reduction that the reference performs sequentially is owned by ONE lane and performed in
+// the reference's order; lanes are only ever assigned whole outputs, never partial sums.
+#pragma once
+#include "mp2_types.h"
+#include "tl_math.h"
+
+// ------------------------------------------------------------------------------------------
+#ifdef TL_EMULATE
+#define TL_FN static inline
+#define TL_LANES_BEGIN for (int lane = 0; lane < 64; ++lane) {
+#define TL_LANES_END }
+#define TL_SYNC() ((void)0)
+#define PV(T, name) T name[64]
+#define PA(T, name, n) T name[64][n]
+#define L(name) name[lane]
+#define PARG(T, name) T (&name)[64]
+#define PARGA(T, name, n) T (&name)[64][n]
+#define TL_OTHER(name, idx, src) name[src] idx          /* value of another lane's register */
+#define TL_ATOMIC_OR(p, v) (*(p) |= (v))
+TL_FN uint64_t tlh_ballot(const bool (&p)[64]) { uint64_t m = 0; for (int i = 0; i < 64; i++) if (p[i]) m |= 1ull << i; return m; }
+TL_FN uint64_t tlh_min_u64(const uint64_t (&v)[64]) { uint64_t m = v[0]; for (int i = 1; i < 64; i++) if (v[i] < m) m = v[i]; return m; }
+TL_FN int tlh_sum_i32(const int (&v)[64]) { int s = 0; for (int i = 0; i < 64; i++) s += v[i]; return s; }
+TL_FN void tlh_exscan_i32(int (&d)[64], const int (&v)[64]) { int s = 0; for (int i = 0; i < 64; i++) { d[i] = s; s += v[i]; } }
+#define TL_BALLOT(name) tlh_ballot(name)
+#define TL_WAVE_MIN_U64(name) tlh_min_u64(name)
+#define TL_WAVE_SUM_I32(name) tlh_sum_i32(name)
+#define TL_WAVE_EXSCAN_I32(dst, src) tlh_exscan_i32(dst, src)
+#define TL_UNI_I(x) (x)
+#define TL_RESTRICT
+#else
+#define TL_FN __device__ __forceinline__
+#define TL_LANES_BEGIN { const int lane = (int)(threadIdx.x & 63u);
+#define TL_LANES_END } TL_SYNC();
+#define TL_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define PV(T, name) T name
+#define PA(T, name, n) T name[n]
+#define L(name) name
+#define PARG(T, name) T &name
+#define PARGA(T, name, n) T (&name)[n]
+#define TL_OTHER(name, idx, src) tld_shfl_f64(name idx, src)
+#define TL_ATOMIC_OR(p, v) atomicOr((p), (v))
+TL_FN double tld_shfl_f64(double v, int src) { return __shfl(v, src, 64); }
+TL_FN uint64_t tld_min_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { uint64_t t = __shfl_xor((unsigned long long)v, o, 64); v = t < v ? t : v; }
+    return v;
+}
+TL_FN int tld_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+TL_FN int tld_exscan_i32(int v) {
+    const int lane = (int)(threadIdx.x & 63u);
+    int s = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(s, o, 64); if (lane >= o) s += t; }
+    return s - v;
+}
+#define TL_BALLOT(name) ((uint64_t)__ballot(name))
+#define TL_WAVE_MIN_U64(name) tld_min_u64(name)
+#define TL_WAVE_SUM_I32(name) tld_sum_i32(name)
+#define TL_WAVE_EXSCAN_I32(dst, src) dst = tld_exscan_i32(src)
+#define TL_UNI_I(x) __builtin_amdgcn_readfirstlane(x)
+#define TL_RESTRICT __restrict__
+#endif
+
+#define TL_DBMIN (-200.0)
+#define TL_POWERNORM 90.3090
+#define TL_T_NOISE 10
+#define TL_T_TONE 20
+#define TL_LAST (-1)
+#define TL_STOP (-100)
+
+// ------------------------------------------------------------------------------------------
+// Per-wave LDS working set.
+struct TlWaveLds {
+    int16_t pcm[2][TL_HIST + 1152];     // [history | this frame], planar
+    union {
+        struct { double y[2][64]; double yp[2][32]; } fb;     // filterbank stage
+        double fft[1024];                                     // psy stage: FHT buffer, then energy[0..512]
+        double xch[12][64];                                   // joint-stereo sample exchange
+        uint32_t frame[TL_MAX_FRAME_WORDS];                   // packing stage
+    } u;
+    double px[520];                     // psy: power spectrum in dB
+    double ltg[136];                    // psy: thresholds on the subsampled lines
+    double mk_x[200];                   // psy: compacted maskers (tones first, then noise)
+    double mk_bark[200];
+    double smr[2][32];
+    double spike[32];                   // psy-1 spike / psy-3 Lsb
+    double nsum[32];                    // psy noise sums per critical band
+    int16_t pnext[520];                 // psy-1 linked list
+    int16_t cand[520];                  // compacted candidate list
+    int16_t mk_idx[200];
+    int16_t ncentre[32];
+    uint8_t ptype[520];
+    uint8_t scf[2][3][32];
+    uint8_t jscale[3][32];
+    uint8_t scfsi[2][32];
+    uint8_t balloc[2][32];
+    uint8_t minidx[2][32];
+    uint8_t xpad[TL_MAX_XPAD];
+};
+
+// ------------------------------------------------------------------------------------------
+TL_FN double tl_add_db(const double *TL_RESTRICT dbtable, double a, double b)
+{   // psycho_1.c:180-205 == psycho_3.c:44-69
+    double fdiff = 10.0 * (a - b);
+    if (fdiff > 990.0) return a;
+    if (fdiff < -990.0) return b;
+    int idiff = (int)fdiff;
+    if (idiff >= 0) return a + dbtable[idiff];
+    return b + dbtable[-idiff];
+}
+TL_FN double tl_mask_vf(double dz, double x)
+{   // psycho_1.c:494-503 == psycho_3.c:359-369
+    if (dz < -1) return 17 * (dz + 1) - (0.4 * x + 6);
+    if (dz < 0) return (0.4 * x + 6) * dz;
+    if (dz < 1) return -17 * dz;
+    return -(dz - 1) * (17 - 0.15 * x) - 17;
+}
+TL_FN unsigned tl_sf_index(const double *TL_RESTRICT sf, double cur_max)
+{   // encode_new.c:208-218
+    unsigned i = 32;
+    for (unsigned l = 16; l; l >>= 1) { if (cur_max <= sf[i]) i += l; else i -= l; }
+    if (cur_max > sf[i]) i--;
+    return i;
+}
+TL_FN void tl_put_bits(uint32_t *frame, int pos, uint32_t val, int nbits)
+{   // MSB-first bit field at bit offset `pos`; words are big-endian bit order (bitstream.c:130-150)
+    if (nbits <= 0) return;
+    int w = pos >> 5, o = pos & 31, room = 32 - o;
+    if (nbits <= room) TL_ATOMIC_OR(&frame[w], val << (room - nbits));
+    else {
+        TL_ATOMIC_OR(&frame[w], val >> (nbits - room));
+        TL_ATOMIC_OR(&frame[w + 1], val << (32 - (nbits - room)));
+    }
+}
+TL_FN uint32_t tl_get_bit(const uint32_t *frame, int pos) { return (frame[pos >> 5] >> (31 - (pos & 31))) & 1u; }
+TL_FN uint32_t tl_bswap(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
+TL_FN unsigned tl_crc_upd(unsigned crc, unsigned data, int len, unsigned poly, unsigned top)
+{   // crc.c:43-56 / :99-113
+    for (int b = len - 1; b >= 0; b--) {
+        unsigned carry = crc & top;
+        crc <<= 1;
+        if ((!carry) ^ (!((data >> b) & 1u))) crc ^= poly;
+    }
+    return crc;
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: 1024-point FHT (fft.c:78-1185), parallel over 64 lanes.  Input is written bit-reversed by
+// the caller (the swap list fft.c:85-1090 is the 10-bit reversal), so only the butterflies remain.
+TL_FN void tl_fht_pass_first(double *x, int lane)
+{   // fft.c:1092-1102: 256 groups of 4
+    for (int g = lane; g < 256; g += 64) {
+        double *fi = x + 4 * g;
+        double f1 = fi[0] - fi[1], f0 = fi[0] + fi[1], f3 = fi[2] - fi[3], f2 = fi[2] + fi[3];
+        fi[2] = f0 - f2; fi[0] = f0 + f2; fi[3] = f1 - f3; fi[1] = f1 + f3;
+    }
+}
+TL_FN void tl_fht_pass(double *x, int k, int twbase, const double (*TL_RESTRICT tw)[4], int lane)
+{   // fft.c:1104-1184: one pass = 128 independent 8-point butterflies
+    const double SQRT2 = 1.4142135623730951454746218587388284504414;
+    const int k1 = 1 << k, k2 = k1 << 1, k4 = k2 << 1, k3 = k2 + k1, kx = k1 >> 1;
+    for (int b = lane; b < 128; b += 64) {
+        int blk = b / kx, i = b - blk * kx;
+        double *base = x + blk * k4;
+        if (i == 0) {
+            double *fi = base, *gi = base + kx;
+            double f1 = fi[0] - fi[k1], f0 = fi[0] + fi[k1], f3 = fi[k2] - fi[k3], f2 = fi[k2] + fi[k3];
+            fi[k2] = f0 - f2; fi[0] = f0 + f2; fi[k3] = f1 - f3; fi[k1] = f1 + f3;
+            double g1 = gi[0] - gi[k1], g0 = gi[0] + gi[k1], g3 = SQRT2 * gi[k3], g2 = SQRT2 * gi[k2];
+            gi[k2] = g0 - g2; gi[0] = g0 + g2; gi[k3] = g1 - g3; gi[k1] = g1 + g3;
+        } else {
+            const double c1 = tw[twbase + i - 1][0], s1 = tw[twbase + i - 1][1];
+            const double c2 = tw[twbase + i - 1][2], s2 = tw[twbase + i - 1][3];
+            double *fi = base + i, *gi = base + k1 - i;
+            double a, b2, g0, f0, f1, g1, f2, g2, f3, g3;
+            b2 = s2 * fi[k1] - c2 * gi[k1]; a = c2 * fi[k1] + s2 * gi[k1];
+            f1 = fi[0] - a; f0 = fi[0] + a; g1 = gi[0] - b2; g0 = gi[0] + b2;
+            b2 = s2 * fi[k3] - c2 * gi[k3]; a = c2 * fi[k3] + s2 * gi[k3];
+            f3 = fi[k2] - a; f2 = fi[k2] + a; g3 = gi[k2] - b2; g2 = gi[k2] + b2;
+            b2 = s1 * f2 - c1 * g3; a = c1 * f2 + s1 * g3;
+            fi[k2] = f0 - a; fi[0] = f0 + a; gi[k3] = g1 - b2; gi[k1] = g1 + b2;
+            b2 = c1 * g2 - s1 * f3; a = s1 * g2 + c1 * f3;
+            gi[k2] = g0 - a; gi[0] = g0 + a; fi[k3] = f1 - b2; fi[k1] = f1 + b2;
+        }
+    }
+}
+
+// Hann window of samples [t-192, t+832) + FHT + energy (psycho_1.c:57-76,215-239, fft.c:1278-1293).
+// Leaves energy[0..512] in w.u.fft[0..512].
+TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, int ch)
+{
+    double *x = w.u.fft;
+    TL_LANES_BEGIN
+    for (int i = lane; i < 1024; i += 64) {
+        int r = 0;
+        for (int b = 0; b < 10; b++) r |= ((i >> b) & 1) << (9 - b);
+        // sample i of the analysis window = PCM index (TL_HIST - 192 + i) of [history | frame]
+        x[r] = ((double)w.pcm[ch][TL_HIST - 192 + i] / 32768) * T->hann[i];
+    }
+    TL_LANES_END
+    TL_LANES_BEGIN tl_fht_pass_first(x, lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_pass(x, 2, 0, T->fht_tw, lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_pass(x, 4, 1, T->fht_tw, lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_pass(x, 6, 8, T->fht_tw, lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_pass(x, 8, 39, T->fht_tw, lane); TL_LANES_END
+    TL_LANES_BEGIN
+    for (int i = lane; i <= 512; i += 64) {
+        double e;
+        if (i == 0 || i == 512) e = x[i] * x[i];
+        else { double a = x[i], b = x[1024 - i]; e = (a * a + b * b) / 2.0; }
+        x[i] = e;                     // position 1024-i is only ever read by this same lane
+    }
+    TL_LANES_END
+}
+
+// ------------------------------------------------------------------------------------------
+// psy model 1 (psycho_1.c:22-87, :215-581) for channel `ch`; result in w.smr[ch][0..sblimit).
+TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *TL_RESTRICT C, int ch)
+{
+    const double *energy = w.u.fft;
+    const double *db = T->dbtable;
+    tl_psy_spectrum(w, T, ch);
+
+    // power density spectrum + list reset (psycho_1.c:241-248); spike (psycho_1.c:252-257)
+    TL_LANES_BEGIN
+    for (int i = lane; i < 512; i += 64) {
+        double e = energy[i];
+        w.px[i] = e < 1E-20 ? -200.0 + TL_POWERNORM : 10 * tl_log10(e) + TL_POWERNORM;
+        w.pnext[i] = TL_STOP; w.ptype[i] = 0;
+    }
+    if (lane < 32) {
+        double sum = 1E-20;
+        for (int j = 0; j < 16; j++) sum += 1073741824 * energy[16 * lane + j];
+        w.spike[lane] = 10.0 * tl_log10(sum);
+    }
+    TL_LANES_END
+
+    // tonal candidates = local maxima 2..499, compacted in ascending order (psycho_1.c:274-284)
+    int ncand = 0;
+    for (int c = 0; c < 8; c++) {
+        PV(bool, isc);
+        TL_LANES_BEGIN
+        int i = 64 * c + lane;
+        L(isc) = (i >= 2 && i < 500) && (w.px[i] > w.px[i - 1] && w.px[i] >= w.px[i + 1]);
+        TL_LANES_END
+        uint64_t m = TL_BALLOT(isc);
+        TL_LANES_BEGIN
+        if ((m >> lane) & 1ull) {
+            int pos = ncand + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            w.cand[pos] = (int16_t)(64 * c + lane);
+        }
+        TL_LANES_END
+        ncand += __builtin_popcountll(m);
+    }
+    TL_LANES_BEGIN
+    for (int k = lane; k < ncand; k += 64) {
+        int i = w.cand[k];
+        w.ptype[i] = TL_T_TONE;
+        w.pnext[i] = (int16_t)(k + 1 < ncand ? w.cand[k + 1] : TL_LAST);
+    }
+    TL_LANES_END
+
+    // sequential tone confirmation (psycho_1.c:285-339); wave-uniform serial walk
+    int tone = TL_LAST, noise = 0;
+    {
+        int last = TL_LAST, last_but_one = TL_LAST;
+        int first = ncand ? w.cand[0] : TL_LAST;
+        while (first != TL_LAST && first != TL_STOP) {
+            int run;
+            if (first < 3 || first > 500) run = 0;
+            else if (first < 63) run = 2;
+            else if (first < 127) run = 3;
+            else if (first < 255) run = 6;
+            else run = 12;
+            double max = w.px[first] - 7;
+            bool ok = true;
+            for (int j = 2; j <= run; j++)
+                if (max < w.px[first - j] || max < w.px[first + j]) { ok = false; break; }
+            if (ok) {
+                int help = first;
+                if (tone == TL_LAST) tone = first;
+                while (w.pnext[help] != TL_LAST && (w.pnext[help] - first) <= run) help = w.pnext[help];
+                help = w.pnext[help];
+                w.pnext[first] = (int16_t)help;
+                if ((first - last) <= run) { if (last_but_one != TL_LAST) w.pnext[last_but_one] = (int16_t)first; }
+                if (first > 1 && first < 500) {
+                    double tmp = tl_add_db(db, w.px[first - 1], w.px[first + 1]);
+                    w.px[first] = tl_add_db(db, w.px[first], tmp);
+                }
+                for (int j = 1; j <= run; j++) {
+                    w.px[first - j] = w.px[first + j] = TL_DBMIN;
+                    w.pnext[first - j] = w.pnext[first + j] = TL_STOP;
+                    w.ptype[first - j] = w.ptype[first + j] = 0;
+                }
+                last_but_one = last; last = first; first = w.pnext[first];
+            } else {
+                w.ptype[first] = 0;
+                if (last != TL_LAST) w.pnext[last] = w.pnext[first];
+                int ll = first;
+                first = w.pnext[first];
+                w.pnext[ll] = TL_STOP;
+            }
+            TL_SYNC();
+        }
+    }
+
+    // noise components: one lane per critical band (psycho_1.c:356-376)
+    const int nbands = C->p1_ncb - 1;
+    TL_LANES_BEGIN
+    if (lane < nbands) {
+        const int lo = C->p1_cbound[lane], hi = C->p1_cbound[lane + 1];
+        double weight = 0.0, sum = TL_DBMIN;
+        for (int j = lo; j < hi; j++)
+            if (w.ptype[j] != TL_T_TONE && w.px[j] != TL_DBMIN) {
+                sum = tl_add_db(db, w.px[j], sum);
+                weight += 1073741824 * energy[j] * (double)(j - lo) / (double)(hi - lo);
+                w.px[j] = TL_DBMIN;
+            }
+        int centre;
+        if (sum <= TL_DBMIN) centre = (hi + lo) / 2;
+        else {
+            double index = weight * tl_pow10(-0.1 * sum);
+            centre = lo + (int)(index * (double)(hi - lo));
+        }
+        if (w.ptype[centre] == TL_T_TONE) { if (w.ptype[centre + 1] == TL_T_TONE) centre++; else centre--; }
+        w.nsum[lane] = sum; w.ncentre[lane] = (int16_t)centre;
+    }
+    TL_LANES_END
+    {   // link in band order (psycho_1.c:390-398)
+        int last = TL_LAST;
+        for (int i = 0; i < nbands; i++) {
+            int centre = w.ncentre[i];
+            if (last == TL_LAST) noise = centre;
+            else { w.pnext[centre] = TL_LAST; w.pnext[last] = (int16_t)centre; }
+            w.px[centre] = w.nsum[i]; w.ptype[centre] = TL_T_NOISE; last = centre;
+        }
+        TL_SYNC();
+    }
+
+    // decimation (psycho_1.c:409-470), then compaction of the surviving maskers
+    int ntone = 0, nnoise = 0;
+    {
+        const uint8_t *map = C->p1_map;
+        int i = tone, old = TL_STOP, guard = 0;
+        while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
+            if (w.px[i] < C->p1_hear[map[i]]) {
+                w.ptype[i] = 0; w.px[i] = TL_DBMIN;
+                if (old == TL_STOP) tone = w.pnext[i]; else w.pnext[old] = w.pnext[i];
+            } else old = i;
+            i = w.pnext[i];
+        }
+        i = noise; old = TL_STOP; guard = 0;
+        while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
+            if (w.px[i] < C->p1_hear[map[i]]) {
+                w.ptype[i] = 0; w.px[i] = TL_DBMIN;
+                if (old == TL_STOP) noise = w.pnext[i]; else w.pnext[old] = w.pnext[i];
+            } else old = i;
+            i = w.pnext[i];
+        }
+        i = tone; old = TL_STOP; guard = 0;
+        while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
+            int nx = w.pnext[i];
+            if (nx == TL_LAST) break;
+            if (C->p1_bark[map[nx]] - C->p1_bark[map[i]] < 0.5) {
+                if (w.px[nx] > w.px[i]) {
+                    if (old == TL_STOP) tone = nx; else w.pnext[old] = (int16_t)nx;
+                    w.ptype[i] = 0; w.px[i] = TL_DBMIN; i = nx;
+                } else {
+                    w.ptype[nx] = 0; w.px[nx] = TL_DBMIN;
+                    w.pnext[i] = w.pnext[nx]; old = i;
+                }
+            } else { old = i; i = nx; }
+        }
+        guard = 0;
+        for (int t = tone; t != TL_LAST && t != TL_STOP && ntone < 180 && guard++ < 600; t = w.pnext[t]) {
+            w.mk_x[ntone] = w.px[t]; w.mk_bark[ntone] = C->p1_bark[map[t]]; ntone++;
+        }
+        guard = 0;
+        for (int t = noise; t != TL_LAST && t != TL_STOP && ntone + nnoise < 200 && guard++ < 600; t = w.pnext[t]) {
+            w.mk_x[ntone + nnoise] = w.px[t]; w.mk_bark[ntone + nnoise] = C->p1_bark[map[t]]; nnoise++;
+        }
+        TL_SYNC();
+    }
+
+    // individual + global masking thresholds on the table lines (psycho_1.c:480-532)
+    const int sub = C->p1_sub;
+    TL_LANES_BEGIN
+    for (int k = 1 + lane; k < sub; k += 64) {
+        const double bk = C->p1_bark[k];
+        double x = TL_DBMIN;
+        for (int t = 0; t < ntone; t++) {
+            double dz = bk - w.mk_bark[t];
+            if (dz >= -3.0 && dz < 8.0) {
+                double px = w.mk_x[t];
+                double tmps = -1.525 - 0.275 * w.mk_bark[t] - 4.5 + px;
+                x = tl_add_db(db, x, tmps + tl_mask_vf(dz, px));
+            }
+        }
+        for (int t = ntone; t < ntone + nnoise; t++) {
+            double dz = bk - w.mk_bark[t];
+            if (dz >= -3.0 && dz < 8.0) {
+                double px = w.mk_x[t];
+                double tmps = -1.525 - 0.175 * w.mk_bark[t] - 0.5 + px;
+                x = tl_add_db(db, x, tmps + tl_mask_vf(dz, px));
+            }
+        }
+        if (C->br_per_ch < 96) x = tl_add_db(db, C->p1_hear[k], x);
+        else x = tl_add_db(db, C->p1_hear[k] - 12.0, x);
+        w.ltg[k] = x;
+    }
+    TL_LANES_END
+
+    // minimum per subband (psycho_1.c:541-559) and SMR (psycho_1.c:568-581)
+    TL_LANES_BEGIN
+    if (lane < C->sblimit) {
+        double m;
+        int n = C->p1_mm_n[lane], j0 = C->p1_mm_j0[lane];
+        if (n == 0) m = C->p1_hear[sub - 1];
+        else {
+            m = w.ltg[j0];
+            for (int j = j0 + 1; j < j0 + n; j++) if (m > w.ltg[j]) m = w.ltg[j];
+        }
+        double max = C->scale_db[w.minidx[ch][lane]];
+        if (w.spike[lane] > max) max = w.spike[lane];
+        w.smr[ch][lane] = max - m;
+    }
+    TL_LANES_END
+}
+
+// ------------------------------------------------------------------------------------------
+// psy model 3 (psycho_3.c:71-432) for channel `ch`; result in w.smr[ch][0..32).
+TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *TL_RESTRICT C, int ch)
+{
+    const double *energy = w.u.fft;
+    const double *db = T->dbtable;
+    const double *bark = C->p3_bark, *ath = C->p3_ath;
+    tl_psy_spectrum(w, T, ch);
+
+    // power[1..512] (psycho_3.c:152-160); power[0] is an uninitialised slot in the reference, pinned
+    // to 0.0 (oracle/mp2_oracle.c:psy3_run)
+    TL_LANES_BEGIN
+    for (int i = lane; i < 513; i += 64) {
+        double e = energy[i];
+        w.px[i] = i == 0 ? 0.0 : (e < 1E-20 ? -200.0 + TL_POWERNORM : 10 * tl_log10(e) + TL_POWERNORM);
+    }
+    TL_LANES_END
+    // Lsb (psycho_3.c:163-183; line 512 is skipped, see oracle) -> w.spike
+    TL_LANES_BEGIN
+    if (lane < 32) {
+        double xmax = TL_DBMIN;
+        for (int i = 16 * lane; i < 16 * lane + 16; i++) if (i >= 1 && xmax < w.px[i]) xmax = w.px[i];
+        double val = C->scale_db[w.minidx[ch][lane]];
+        w.spike[lane] = xmax > val ? xmax : val;
+    }
+    TL_LANES_END
+    // local maxima, compacted ascending (psycho_3.c:195-202); pnext doubles as tonelabel, ptype as noiselabel
+    int ncand = 0;
+    for (int c = 0; c < 8; c++) {
+        PV(bool, isc);
+        TL_LANES_BEGIN
+        int i = 64 * c + lane;
+        L(isc) = (i >= 2 && i < 500) && (w.px[i] > w.px[i - 1] && w.px[i] > w.px[i + 1]);
+        w.ptype[i] = 0;
+        if (c == 7 && lane == 0) w.ptype[512] = 0;
+        TL_LANES_END
+        uint64_t m = TL_BALLOT(isc);
+        TL_LANES_BEGIN
+        if ((m >> lane) & 1ull) {
+            int pos = ncand + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            w.cand[pos] = (int16_t)(64 * c + lane);
+        }
+        TL_LANES_END
+        ncand += __builtin_popcountll(m);
+    }
+    // sequential tone labelling with neighbour erasure (psycho_3.c:212-247)
+    int ntone = 0;
+    for (int q = 0; q < ncand; q++) {
+        int k = w.cand[q];
+        int sr = k < 63 ? 2 : k < 127 ? 3 : k < 255 ? 6 : 12;
+        double pk = w.px[k];
+        bool tonal = true;
+        for (int j = -sr; j <= sr; j++)
+            if ((j > 1 || j < -1) && (pk - w.px[k + j]) < 7.0) tonal = false;
+        if (tonal) {
+            double temp = tl_add_db(db, w.px[k - 1], pk);
+            double xt = tl_add_db(db, temp, w.px[k + 1]);
+            for (int j = -sr; j <= sr; j++) w.px[k + j] = TL_DBMIN;
+            if (!(xt < ath[k]) && ntone < 180) {               // decimation psycho_3.c:321-326
+                w.mk_x[ntone] = xt; w.mk_bark[ntone] = bark[k]; ntone++;
+            }
+            TL_SYNC();
+        }
+    }
+    // noise per critical band (psycho_3.c:264-304) + decimation (:313-320); one lane per band
+    const int nb = C->p3_cbands;
+    TL_LANES_BEGIN
+    if (lane < nb) {
+        const int lo = C->p3_cbidx[lane], hi = C->p3_cbidx[lane + 1];
+        double sum = TL_DBMIN, esum = 0, cw = 0;
+        for (int j = lo; j < hi; j++) {
+            double p = w.px[j];
+            if (p != TL_DBMIN) { sum = tl_add_db(db, p, sum); esum += energy[j]; cw += (j - lo) * energy[j]; }
+        }
+        // esum == 0: the reference indexes with (int)(0/0) and segfaults; defined as the band centre
+        int centre = (sum <= TL_DBMIN || esum == 0) ? (lo + hi) / 2 : lo + (int)(cw / esum);
+        w.nsum[lane] = sum; w.ncentre[lane] = (int16_t)centre;
+    }
+    TL_LANES_END
+    int nnoise = 0;
+    for (int i = 0; i < nb; i++) {          // ascending k order == band order (centres stay inside their band)
+        int k = w.ncentre[i];
+        double xn = w.nsum[i];
+        if (!(xn < ath[k]) && ntone + nnoise < 200) {
+            w.mk_x[ntone + nnoise] = xn; w.mk_bark[ntone + nnoise] = bark[k]; nnoise++;
+        }
+    }
+    TL_SYNC();
+    // thresholds on the 136 subsampled lines (psycho_3.c:339-406)
+    TL_LANES_BEGIN
+    for (int j = lane; j < 136; j += 64) {
+        const int line = C->p3_subset[j];
+        const double bj = bark[line];
+        double lt = TL_DBMIN, ln = TL_DBMIN;
+        for (int t = 0; t < ntone; t++) {
+            double dz = bj - w.mk_bark[t];
+            if (dz >= -3.0 && dz < 8.0) {
+                double x = w.mk_x[t];
+                double av = -1.525 - 0.275 * w.mk_bark[t] - 4.5 + x;
+                lt = tl_add_db(db, lt, av + tl_mask_vf(dz, x));
+            }
+        }
+        for (int t = ntone; t < ntone + nnoise; t++) {
+            double dz = bj - w.mk_bark[t];
+            if (dz >= -3.0 && dz < 8.0) {
+                double x = w.mk_x[t];
+                double av = -1.525 - 0.175 * w.mk_bark[t] - 0.5 + x;
+                ln = tl_add_db(db, ln, av + tl_mask_vf(dz, x));
+            }
+        }
+        double g = tl_add_db(db, ln, lt);
+        if (C->br_per_ch < 96) g = tl_add_db(db, ath[line], g);
+        else g = tl_add_db(db, ath[line] - 12.0, g);
+        w.ltg[j] = g;
+    }
+    TL_LANES_END
+    // minimum per subband + SMR (psycho_3.c:409-432)
+    TL_LANES_BEGIN
+    if (lane < 32) {
+        double m = 999999.9;
+        for (int j = 0; j < 136; j++)
+            if ((C->p3_subset[j] >> 4) == lane && m > w.ltg[j]) m = w.ltg[j];
+        w.smr[ch][lane] = w.spike[lane] - m;
+    }
+    TL_LANES_END
+}
+
+// ------------------------------------------------------------------------------------------
+// One frame of one stream.  lane = 2*sb + ch owns subband sb of channel ch.
+TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *TL_RESTRICT C,
+                           TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, TlTaps *taps)
+{
+    const int nch = C->nch, sblimit = C->sblimit;
+    PA(double, smp, 36);            // sb_sample[ch][gr][bl][sb] of this lane's (sb,ch), b = gr*12+bl
+    PA(int, scf, 3);
+
+    // ---- K1: polyphase filterbank (subband.c:201-310), 36 blocks of 32 samples ----
+    {
+        PA(double, cw, 16);         // this lane's 2x8 window taps: outputs i and i+32
+        PA(double, cm, 32);         // DCT row r = min(sb, 31-sb): even k then odd k
+        TL_LANES_BEGIN
+        const int i = lane >> 1, sb = lane >> 1, r = sb < 16 ? sb : 31 - sb;
+        for (int j = 0; j < 8; j++) { L(cw)[j] = T->enwindow[i + 64 * j]; L(cw)[8 + j] = T->enwindow[i + 32 + 64 * j]; }
+        for (int k = 0; k < 16; k++) { L(cm)[k] = T->dct[r][2 * k]; L(cm)[16 + k] = T->dct[r][2 * k + 1]; }
+        TL_LANES_END
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int b = 0; b < 36; b++) {
+            TL_LANES_BEGIN
+            const int c = lane & 1, i = lane >> 1;
+            if (c < nch) {
+                // X[k] = pcm[t0 + 31 - k], t0 = index of the block's first new sample
+                const int16_t *p = &w.pcm[c][TL_HIST + 32 * b + 31 - i];
+                double t0 = ((double)p[0] / 32768) * L(cw)[0];
+                double t1 = ((double)p[-32] / 32768) * L(cw)[8];
+                for (int j = 1; j < 8; j++) {
+                    t0 += ((double)p[-64 * j] / 32768) * L(cw)[j];
+                    t1 += ((double)p[-64 * j - 32] / 32768) * L(cw)[8 + j];
+                }
+                w.u.fb.y[c][i] = t0; w.u.fb.y[c][i + 32] = t1;
+            }
+            TL_LANES_END
+            TL_LANES_BEGIN
+            const int c = lane & 1, i = lane >> 1;
+            if (c < nch) {
+                const double *y = w.u.fb.y[c];
+                w.u.fb.yp[c][i] = i == 0 ? y[16] : (i <= 16 ? y[i + 16] + y[16 - i] : y[i + 16] - y[80 - i]);
+            }
+            TL_LANES_END
+            TL_LANES_BEGIN
+            const int c = lane & 1, sb = lane >> 1;
+            if (c < nch) {
+                const double *yp = w.u.fb.yp[c];
+                double s0 = 0.0, s1 = 0.0;
+                for (int k = 0; k < 16; k++) { s0 += L(cm)[k] * yp[2 * k]; s1 += L(cm)[16 + k] * yp[2 * k + 1]; }
+                L(smp)[b] = sb < 16 ? s0 + s1 : s0 - s1;
+            } else L(smp)[b] = 0.0;
+            TL_LANES_END
+        }
+    }
+
+    // ---- K2: scalefactors (encode_new.c:179-230) + find_sf_max (:260-277) ----
+    TL_LANES_BEGIN
+    const int c = lane & 1, sb = lane >> 1;
+    if (c < nch && sb < sblimit) {
+        unsigned lo = 63;
+        for (int gr = 0; gr < 3; gr++) {
+            double m = fabs(L(smp)[gr * 12 + 11]);
+            for (int j = 10; j >= 0; j--) { double t = fabs(L(smp)[gr * 12 + j]); if (t > m) m = t; }
+            unsigned idx = tl_sf_index(T->scalefactor, m);
+            L(scf)[gr] = (int)idx;
+            w.scf[c][gr][sb] = (uint8_t)idx;
+            if (idx < lo) lo = idx;
+        }
+        w.minidx[c][sb] = (uint8_t)lo;
+    } else {
+        L(scf)[0] = L(scf)[1] = L(scf)[2] = 0;
+        if (sb >= sblimit || c >= nch) { w.minidx[c][sb] = 63; w.scf[c][0][sb] = w.scf[c][1][sb] = w.scf[c][2][sb] = 0; }
+    }
+    TL_LANES_END
+
+    // joint stereo: scalefactors of .5*(L+R) (toolame.c:332-337, encode_new.c:237-246)
+    if (C->mode0 == 1) {
+        for (int gr = 0; gr < 3; gr++) {
+            PV(double, jm);
+            TL_LANES_BEGIN L(jm) = 0.0; TL_LANES_END
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int j = 11; j >= 0; j--) {
+                PV(double, other);
+#ifdef TL_EMULATE
+                for (int lane = 0; lane < 64; ++lane) other[lane] = smp[lane ^ 1][gr * 12 + j];
+#else
+                other = __shfl_xor(smp[gr * 12 + j], 1, 64);
+#endif
+                TL_LANES_BEGIN
+                double t = fabs(.5 * (L(smp)[gr * 12 + j] + L(other)));     // ch0 lane: .5*(L+R)
+                if (j == 11 || t > L(jm)) L(jm) = t;
+                TL_LANES_END
+            }
+            TL_LANES_BEGIN
+            const int c = lane & 1, sb = lane >> 1;
+            if (c == 0 && sb < sblimit) w.jscale[gr][sb] = (uint8_t)tl_sf_index(T->scalefactor, L(jm));
+            TL_LANES_END
+        }
+    }
+
+    if (taps) {
+        TL_LANES_BEGIN
+        const int c = lane & 1, sb = lane >> 1;
+        for (int b = 0; b < 36; b++) taps->sb_sample[c][b / 12][b % 12][sb] = L(smp)[b];
+        for (int gr = 0; gr < 3; gr++) { taps->scalar_pre[c][gr][sb] = w.scf[c][gr][sb]; if (c == 0) taps->j_scale[gr][sb] = C->mode0 == 1 && sb < sblimit ? w.jscale[gr][sb] : 0; }
+        taps->max_sc[c][sb] = (c < nch && sb < sblimit) ? T->scalefactor[w.minidx[c][sb]] : 1E-20;
+        TL_LANES_END
+    }
+
+    // ---- K3/K4: psychoacoustic model -> SMR (toolame.c:361-452) ----
+    if (C->psy == 0) {                                           // psycho_0.c:52-68
+        TL_LANES_BEGIN
+        const int c = lane & 1, sb = lane >> 1;
+        if (c < nch) {
+            int m = sb < sblimit ? (int)w.minidx[c][sb] : 0;     // scalar[] above sblimit stays 0 (toolame.c:132)
+            w.smr[c][sb] = 2.0 * (30.0 - m) - C->p0_athmin[sb];
+        }
+        TL_LANES_END
+    } else if (C->psy == 1) {
+        for (int ch = 0; ch < nch; ch++) tl_psy1(w, T, C, ch);
+    } else {
+        for (int ch = 0; ch < nch; ch++) tl_psy3(w, T, C, ch);
+    }
+
+    // ---- sf_transmission_pattern (encode_new.c:288-354, ISO Table C.4) ----
+    TL_LANES_BEGIN
+    const int c = lane & 1, sb = lane >> 1;
+    if (c < nch && sb < sblimit) {
+        int s0 = L(scf)[0], s1 = L(scf)[1], s2 = L(scf)[2];
+        int d0 = s0 - s1, d1 = s1 - s2;
+        int c0 = d0 <= -3 ? 0 : d0 < 0 ? 1 : d0 == 0 ? 2 : d0 < 3 ? 3 : 4;
+        int c1 = d1 <= -3 ? 0 : d1 < 0 ? 1 : d1 == 0 ? 2 : d1 < 3 ? 3 : 4;
+        // pattern table rows c0, columns c1, as 3 hex digits
+        const unsigned short pat[25] = {0x123, 0x122, 0x122, 0x133, 0x123, 0x113, 0x111, 0x111, 0x444, 0x113,
+                                        0x111, 0x111, 0x111, 0x333, 0x113, 0x222, 0x222, 0x222, 0x333, 0x123,
+                                        0x123, 0x122, 0x122, 0x133, 0x123};
+        unsigned p = pat[c0 * 5 + c1];
+        int sel;
+        switch (p) {
+        case 0x123: sel = 0; break;
+        case 0x122: sel = 3; s2 = s1; break;
+        case 0x133: sel = 3; s1 = s2; break;
+        case 0x113: sel = 1; s1 = s0; break;
+        case 0x111: sel = 2; s1 = s2 = s0; break;
+        case 0x222: sel = 2; s0 = s2 = s1; break;
+        case 0x333: sel = 2; s0 = s1 = s2; break;
+        default: sel = 2; if (s0 > s2) s0 = s2; s1 = s2 = s0; break;       // 0x444
+        }
+        L(scf)[0] = s0; L(scf)[1] = s1; L(scf)[2] = s2;
+        w.scf[c][0][sb] = (uint8_t)s0; w.scf[c][1][sb] = (uint8_t)s1; w.scf[c][2][sb] = (uint8_t)s2;
+        w.scfsi[c][sb] = (uint8_t)sel;
+    } else w.scfsi[c][sb] = 0;
+    w.balloc[c][sb] = 0;
+    TL_LANES_END
+
+    // ---- K5: bit allocation (encode_new.c:733-886, :634-705, :1061-1187) ----
+    const int lg_frame = C->frame_bytes;
+    int adb = lg_frame * 8 - (C->dab_ext * 8 + (xpad_len ? xpad_len : 2) * 8);     // toolame.c:292-301
+    int mode = C->mode0, mode_ext = C->mode_ext0, jsbound = C->jsbound0;
+    if (C->mode0 == 1) {
+        // try plain stereo, then jsbound 16, 12, 8, 4 (encode_new.c:803-819)
+        mode = 0; mode_ext = 0; jsbound = sblimit;
+        int tries = 0, try_ext = 4;
+        for (;;) {
+            PV(int, need);
+            TL_LANES_BEGIN
+            const int c = lane & 1, sb = lane >> 1;
+            int bitsn = 0;
+            if (sb < sblimit && c < (sb < jsbound ? nch : 1)) {
+                const int ln = C->line[sb];
+                const int maxAlloc = (1 << C->nbal[sb]) - 1;
+                int ba;
+                for (ba = 0; ba < maxAlloc - 1; ba++)
+                    if ((T->snr[T->step_index[ln][ba]] - w.smr[c][sb]) >= 0.0) break;
+                if (nch == 2 && sb >= jsbound)
+                    for (; ba < maxAlloc - 1; ba++)
+                        if ((T->snr[T->step_index[ln][ba]] - w.smr[1 - c][sb]) >= 0.0) break;
+                if (ba > 0) {
+                    const int q = T->step_index[ln][ba];
+                    const int sfs[4] = {3, 2, 1, 2};
+                    int smpb = 12 * T->group[q] * T->bits[q], sel = 2, sc = 6 * sfs[w.scfsi[c][sb]];
+                    if (nch == 2 && sb >= jsbound) { sel += 2; sc += 6 * sfs[w.scfsi[1 - c][sb]]; }
+                    bitsn = smpb + sel + sc;
+                }
+                bitsn += C->nbal[sb];                               // bbal share of this (sb,ch)
+            }
+            L(need) = bitsn;
+            TL_LANES_END
+            int rq = 32 + 16 + TL_WAVE_SUM_I32(need);
+            if (tries == 0) {
+                if (rq > adb) { mode = 1; } else break;
+            } else if (!(rq > adb && try_ext > 0)) { mode_ext = try_ext; break; }
+            const int jsb[4] = {4, 8, 12, 16};
+            --try_ext; jsbound = jsb[try_ext]; tries++;
+        }
+    }
+    int adb_left;
+    {   // a_bit_allocation_new (encode_new.c:1078-1187)
+        PV(double, mnr); PV(int, used); PV(int, ba); PV(int, nbits);
+        TL_LANES_BEGIN
+        const int c = lane & 1, sb = lane >> 1;
+        const bool live = c < nch && sb < sblimit;
+        L(mnr) = live ? T->snr[0] - w.smr[c][sb] : 0.0;
+        L(used) = live ? 0 : 2; L(ba) = 0;
+        L(nbits) = (sb < sblimit && c < (sb < jsbound ? nch : 1)) ? C->nbal[sb] : 0;
+        TL_LANES_END
+        const int bbal = TL_WAVE_SUM_I32(nbits);
+        int ad = adb - (bbal + 16 + 32);
+        int bspl = 0, bscf = 0, bsel = 0;
+        for (int guard = 0; guard < 2048; guard++) {
+            // maxmnr_new (encode_new.c:1061-1077): smallest mnr, first in (ch, sb) order
+            PV(uint64_t, key);
+            TL_LANES_BEGIN
+            uint64_t u = tl_d2u(L(mnr) + 0.0);
+            u = (u >> 63) ? ~u : (u | 0x8000000000000000ull);      // order-preserving map double -> u64
+            L(key) = (L(used) != 2 && 999999.0 > L(mnr)) ? u : ~0ull;
+            TL_LANES_END
+            const uint64_t kmin = TL_WAVE_MIN_U64(key);
+            if (kmin == ~0ull) break;
+            PV(bool, hit);
+            TL_LANES_BEGIN L(hit) = L(key) == kmin; TL_LANES_END
+            const uint64_t hm = TL_BALLOT(hit);
+            const uint64_t even = hm & 0x5555555555555555ull;       // ch 0 first, then ascending sb
+            const int wl = __builtin_ctzll(even ? even : hm);
+            const int min_ch = wl & 1, min_sb = wl >> 1, oth = 1 - min_ch;
+            // everything below is wave-uniform (one (ch,sb) cell changes per iteration)
+            const int ln = C->line[min_sb];
+            int cur_ba, cur_used;
+#ifdef TL_EMULATE
+            cur_ba = ba[wl]; cur_used = used[wl];
+#else
+            cur_ba = __shfl(ba, wl, 64); cur_used = __shfl(used, wl, 64);
+#endif
+            const int qn = T->step_index[ln][cur_ba + 1];
+            int increment = 12 * T->group[qn] * T->bits[qn];
+            int scale = 0, seli = 0;
+            if (cur_used) {
+                const int qc = T->step_index[ln][cur_ba];
+                increment -= 12 * T->group[qc] * T->bits[qc];
+            } else {
+                const int sfs[4] = {3, 2, 1, 2};
+                seli = 2; scale = 6 * sfs[w.scfsi[min_ch][min_sb]];
+                if (nch == 2 && min_sb >= jsbound) { seli += 2; scale += 6 * sfs[w.scfsi[oth][min_sb]]; }
+            }
+            int new_ba = cur_ba, new_used;
+            if (ad >= bspl + bscf + bsel + seli + scale + increment) {
+                new_ba = cur_ba + 1;
+                bspl += increment; bscf += scale; bsel += seli;
+                new_used = (new_ba >= (1 << C->nbal[min_sb]) - 1) ? 2 : 1;
+            } else new_used = 2;
+            const double snr_new = T->snr[T->step_index[ln][new_ba]];
+            const bool joint_pair = (min_sb >= jsbound && nch == 2);
+            TL_LANES_BEGIN
+            const int c = lane & 1, sb = lane >> 1;
+            if (lane == wl) {
+                L(ba) = new_ba; L(used) = new_used;
+                if (new_ba != cur_ba) L(mnr) = snr_new - w.smr[c][sb];
+            } else if (joint_pair && sb == min_sb && c == oth) {
+                L(ba) = new_ba; L(used) = new_used; L(mnr) = snr_new - w.smr[c][sb];
+            }
+            TL_LANES_END
+        }
+        adb_left = ad - (bspl + bscf + bsel);
+        TL_LANES_BEGIN
+        const int c = lane & 1, sb = lane >> 1;
+        w.balloc[c][sb] = (uint8_t)((c < nch && sb < sblimit) ? L(ba) : 0);
+        TL_LANES_END
+    }
+
+    // ---- K6: header, CRC, bit_alloc, scfsi, scalefactors, quantised samples -> LDS frame ----
+    uint32_t *frame = w.u.frame;
+    TL_LANES_BEGIN
+    for (int i = lane; i < TL_MAX_FRAME_WORDS; i += 64) frame[i] = 0;
+    TL_LANES_END
+    PV(int, f_ba); PV(int, f_sel); PV(int, f_scf); PV(int, f_smp);
+    PV(int, o_ba); PV(int, o_sel); PV(int, o_scf); PV(int, o_smp);
+    TL_LANES_BEGIN
+    const int c = lane & 1, sb = lane >> 1;
+    const bool live = c < nch && sb < sblimit;
+    const int ba = live ? w.balloc[c][sb] : 0;
+    const bool own = sb < sblimit && c < (sb < jsbound ? nch : 1);     // transmits bit_alloc + samples
+    const int sfs[4] = {3, 2, 1, 2};
+    L(f_ba) = own ? C->nbal[sb] : 0;
+    L(f_sel) = (live && ba) ? 2 : 0;
+    L(f_scf) = (live && ba) ? 6 * sfs[w.scfsi[c][sb]] : 0;
+    int q = (own && ba) ? T->step_index[C->line[sb]][ba] : 0;
+    L(f_smp) = (own && ba) ? (T->group[q] == 3 ? 3 * T->bits[q] : T->bits[q]) : 0;
+    TL_LANES_END
+    TL_WAVE_EXSCAN_I32(o_ba, f_ba); TL_WAVE_EXSCAN_I32(o_sel, f_sel);
+    TL_WAVE_EXSCAN_I32(o_scf, f_scf); TL_WAVE_EXSCAN_I32(o_smp, f_smp);
+    const int n_ba = TL_WAVE_SUM_I32(f_ba), n_sel = TL_WAVE_SUM_I32(f_sel);
+    const int n_scf = TL_WAVE_SUM_I32(f_scf), n_smp = TL_WAVE_SUM_I32(f_smp);
+    const int p_ba = 48, p_sel = p_ba + n_ba, p_scf = p_sel + n_sel, p_smp = p_scf + n_scf;
+
+    TL_LANES_BEGIN
+    const int c = lane & 1, sb = lane >> 1;
+    if (lane == 0) {     // write_header (encode_new.c:356-373)
+        uint32_t h = (0xfffu << 20) | ((uint32_t)C->version << 19) | (2u << 17) | (0u << 16)
+                   | ((uint32_t)C->br_idx << 12) | ((uint32_t)C->fs_idx << 10) | (0u << 9) | (0u << 8)
+                   | ((uint32_t)mode << 6) | ((uint32_t)mode_ext << 4);
+        TL_ATOMIC_OR(&frame[0], h);
+    }
+    const bool live = c < nch && sb < sblimit;
+    const int ba = live ? w.balloc[c][sb] : 0;
+    if (L(f_ba)) tl_put_bits(frame, p_ba + L(o_ba), (uint32_t)ba, L(f_ba));
+    if (L(f_sel)) {
+        tl_put_bits(frame, p_sel + L(o_sel), w.scfsi[c][sb], 2);
+        int pos = p_scf + L(o_scf);
+        switch (w.scfsi[c][sb]) {                                   // write_scalefactors (encode_new.c:428-443)
+        case 0: tl_put_bits(frame, pos, (uint32_t)L(scf)[0], 6); tl_put_bits(frame, pos + 6, (uint32_t)L(scf)[1], 6);
+                tl_put_bits(frame, pos + 12, (uint32_t)L(scf)[2], 6); break;
+        case 1: case 3: tl_put_bits(frame, pos, (uint32_t)L(scf)[0], 6); tl_put_bits(frame, pos + 6, (uint32_t)L(scf)[2], 6); break;
+        default: tl_put_bits(frame, pos, (uint32_t)L(scf)[0], 6); break;
+        }
+    }
+    TL_LANES_END
+
+    // quantise (encode_new.c:479-547) + write_samples_new (:560-598): 12 rounds of 3 samples
+    {
+        const bool js = (nch == 2);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int r = 0; r < 12; r++) {
+            const int gr = r >> 2, j0 = (r & 3) * 3;
+            PA(double, oth, 3);
+#ifdef TL_EMULATE
+            for (int lane = 0; lane < 64; ++lane) for (int x = 0; x < 3; x++) oth[lane][x] = smp[lane ^ 1][gr * 12 + j0 + x];
+#else
+            if (js) {
+#pragma unroll
+                for (int x = 0; x < 3; x++) oth[x] = __shfl_xor(smp[gr * 12 + j0 + x], 1, 64);
+            } else { oth[0] = oth[1] = oth[2] = 0.0; }
+#endif
+            TL_LANES_BEGIN
+            const int c = lane & 1, sb = lane >> 1;
+            const bool own = sb < sblimit && c < (sb < jsbound ? nch : 1);
+            const int ba = own ? w.balloc[c][sb] : 0;
+            unsigned v[3] = {0, 0, 0};
+            if (ba) {
+                const int q = T->step_index[C->line[sb]][ba];
+                const bool joint = js && sb >= jsbound;
+                const double sfv = joint ? T->scalefactor[w.jscale[gr][sb]] : T->scalefactor[L(scf)[gr]];
+                for (int x = 0; x < 3; x++) {
+                    double s = L(smp)[gr * 12 + j0 + x];
+                    if (joint) s = .5 * (s + L(oth)[x]);
+                    double d = s / sfv;
+                    d = d * T->qa[q] + T->qb[q];
+                    unsigned sig = 1;
+                    if (!(d >= 0)) { sig = 0; d += 1.0; }
+                    unsigned qv = (unsigned)(d * T->steps2n_f[q]);
+                    if (sig) qv |= (unsigned)T->steps2n[q];
+                    v[x] = qv;
+                }
+                const int nb = T->bits[q];
+                const int pos = p_smp + r * n_smp + L(o_smp);
+                if (T->group[q] == 3) {
+                    tl_put_bits(frame, pos, v[0], nb); tl_put_bits(frame, pos + nb, v[1], nb); tl_put_bits(frame, pos + 2 * nb, v[2], nb);
+                } else {
+                    unsigned y = (unsigned)T->steps[q];
+                    tl_put_bits(frame, pos, v[0] + v[1] * y + v[2] * y * y, nb);
+                }
+            }
+            if (taps) for (int x = 0; x < 3; x++) taps->subband[c][gr][j0 + x][sb] = (c < nch) ? v[x] : 0;
+            TL_LANES_END
+        }
+    }
+
+    // CRC-16 over header bits 16..31, bit_alloc and scfsi fields (crc.c:12-41); one lane, bit-serial
+    unsigned crc16 = 0xffff;
+    {
+        for (int p = 16; p < 32; p++) crc16 = tl_crc_upd(crc16, tl_get_bit(frame, p), 1, 0x8005, 0x8000);
+        for (int p = p_ba; p < p_scf; p++) crc16 = tl_crc_upd(crc16, tl_get_bit(frame, p), 1, 0x8005, 0x8000);
+        crc16 &= 0xffff;
+    }
+    // ScF-CRC (crc.c:58-97, toolame.c:527-542): lanes 0..dab_ext-1 each own one band group
+    const int tail = lg_frame - 2 - C->dab_ext;                     // byte offset of the first ScF-CRC byte
+    TL_LANES_BEGIN
+    if (lane == 0) tl_put_bits(frame, 32, crc16, 16);
+    if (lane < C->dab_ext) {
+        const int grp = C->dab_ext - 1 - lane;                      // transmission order: i = dab_ext-1 .. 0
+        const int f[5] = {0, 4, 8, 16, 30};
+        int first = f[grp], last = f[grp + 1] > sblimit ? sblimit : f[grp + 1];
+        unsigned c8 = 0;
+        for (int sb = first; sb < last; sb++)
+            for (int ch = 0; ch < nch; ch++)
+                if (w.balloc[ch][sb]) {
+                    const unsigned s0 = w.scf[ch][0][sb] >> 3, s1 = w.scf[ch][1][sb] >> 3, s2 = w.scf[ch][2][sb] >> 3;
+                    switch (w.scfsi[ch][sb]) {
+                    case 0: c8 = tl_crc_upd(c8, s0, 3, 0x1D, 0x80); c8 = tl_crc_upd(c8, s1, 3, 0x1D, 0x80); c8 = tl_crc_upd(c8, s2, 3, 0x1D, 0x80); break;
+                    case 1: case 3: c8 = tl_crc_upd(c8, s0, 3, 0x1D, 0x80); c8 = tl_crc_upd(c8, s2, 3, 0x1D, 0x80); break;
+                    default: c8 = tl_crc_upd(c8, s0, 3, 0x1D, 0x80); break;
+                    }
+                }
+        c8 &= 0xff;
+        tl_put_bits(frame, (tail + lane) * 8, c8, 8);
+        w.ncentre[lane] = (int16_t)c8;                               // reused as a 4-entry scratch
+    }
+    // X-PAD + F-PAD bytes (toolame.c:515-524,544-551): xpad[] holds xpad_len bytes in transmission order
+    if (xpad_len) {
+        const int xstart = lg_frame - C->dab_ext - xpad_len;        // X-PAD sits right before the ScF-CRC
+        for (int i = lane; i < xpad_len; i += 64) {
+            int bytepos = i < xpad_len - 2 ? xstart + i : lg_frame - 2 + (i - (xpad_len - 2));
+            tl_put_bits(frame, bytepos * 8, w.xpad[i], 8);
+        }
+    }
+    TL_LANES_END
+
+    if (taps) {
+        TL_LANES_BEGIN
+        const int c = lane & 1, sb = lane >> 1;
+        taps->smr[c][sb] = (c < nch) ? w.smr[c][sb] : 0.0;
+        taps->scfsi[c][sb] = w.scfsi[c][sb]; taps->bit_alloc[c][sb] = w.balloc[c][sb];
+        for (int gr = 0; gr < 3; gr++) taps->scalar[c][gr][sb] = w.scf[c][gr][sb];
+        if (lane == 0) { taps->adb_left = adb_left; taps->mode = mode; taps->mode_ext = mode_ext; taps->jsbound = jsbound; taps->crc16 = (int)crc16; }
+        if (lane < 4) taps->scfcrc[lane] = lane < C->dab_ext ? (uint8_t)w.ncentre[lane] : 0;
+        TL_LANES_END
+    }
+
+    // ---- emit: patch the previous frame's ScF-CRC slot with this frame's CRC and hand it out;
+    //      this frame becomes the pending one (toolame.c:527-542, "one frame in memory") ----
+    const int nwords = (lg_frame + 3) >> 2;
+    TL_LANES_BEGIN
+    for (int i = lane; i < nwords; i += 64) {
+        uint32_t prev = st->pending[i];
+        if (have_prev && out_prev) {
+            // overlay bytes [tail, tail+dab_ext) of the previous frame with this frame's ScF-CRC bytes
+            for (int k = 0; k < C->dab_ext; k++) {
+                int bp = tail + k;
+                if ((bp >> 2) == i) {
+                    int sh = 24 - 8 * (bp & 3);
+                    prev = (prev & ~(0xffu << sh)) | ((uint32_t)(w.ncentre[k] & 0xff) << sh);
+                }
+            }
+            uint32_t le = tl_bswap(prev);
+            int rem = lg_frame - 4 * i;
+            if (rem >= 4) ((uint32_t *)out_prev)[i] = le;
+            else for (int b = 0; b < rem; b++) out_prev[4 * i + b] = (uint8_t)(le >> (8 * b));
+        }
+        st->pending[i] = frame[i];
+    }
+    TL_LANES_END
+}
+
+// ------------------------------------------------------------------------------------------
+// A wave encodes `nframes` consecutive frames of stream `s`; state stays in LDS across frames.
+TL_FN void tl_encode_stream(TlWaveLds &w, const TlLaunch &A, int s)
+{
+    const TlTables *T = A.tables;
+    const TlConfig *C = &A.configs[A.stream_cfg[s]];
+    TlStreamState *st = &A.state[s];
+    const int nch = C->nch;
+    TL_LANES_BEGIN
+    for (int i = lane; i < 2 * TL_HIST; i += 64) w.pcm[i / TL_HIST][i % TL_HIST] = st->hist[i / TL_HIST][i % TL_HIST];
+    TL_LANES_END
+    int done = st->frames_done;
+    for (int f = 0; f < A.nframes; f++) {
+        const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
+        const int16_t *src = A.pcm + slot * 2304;
+        TL_LANES_BEGIN
+        // 1152 samples per channel = 576 dwords, coalesced 4-byte loads
+        for (int i = lane; i < 576 * nch; i += 64) {
+            uint32_t v = ((const uint32_t *)src)[i];
+            int ch = i / 576, k = (i % 576) * 2;
+            w.pcm[ch][TL_HIST + k] = (int16_t)(v & 0xffff);
+            w.pcm[ch][TL_HIST + k + 1] = (int16_t)(v >> 16);
+        }
+        TL_LANES_END
+        int xl = 0;
+        if (A.xpad_len) {
+            xl = A.xpad_len[slot];
+            if (xl < 2 || xl > TL_MAX_XPAD) xl = 0;
+            TL_LANES_BEGIN
+            for (int i = lane; i < xl; i += 64) w.xpad[i] = A.xpad[slot * TL_MAX_XPAD + i];
+            TL_LANES_END
+        }
+        tl_encode_frame(w, T, C, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, A.taps ? &A.taps[slot] : nullptr);
+        done++;
+        TL_LANES_BEGIN
+        for (int i = lane; i < TL_HIST * nch; i += 64) {
+            int ch = i / TL_HIST, k = i % TL_HIST;
+            w.pcm[ch][k] = w.pcm[ch][1152 + k];
+        }
+        TL_LANES_END
+    }
+    TL_LANES_BEGIN
+    for (int i = lane; i < 2 * TL_HIST; i += 64) st->hist[i / TL_HIST][i % TL_HIST] = w.pcm[i / TL_HIST][i % TL_HIST];
+    if (lane == 0) st->frames_done = done;
+    TL_LANES_END
+}

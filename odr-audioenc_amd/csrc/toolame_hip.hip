@@ -1,0 +1,372 @@
+// toolame_hip.hip -- gfx950 kernels + the C-ABI of include/toolame_batch.h.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see csrc/Makefile).
+// -ffp-contract=off is load-bearing: the reference is built -std=c99 (no FMA contraction,
+// Makefile.am:68) and every MAC chain / the quantiser d*a+b must round twice.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <deque>
+#include <vector>
+
+#include "../../include/toolame_batch.h"
+#include "mp2_host.h"
+#include "mp2_wave.h"
+
+static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
+
+#define TL_WAVES_PER_BLOCK 1
+
+// One wavefront per stream: block = TL_WAVES_PER_BLOCK independent waves, no
+// block-level barrier anywhere; each wave keeps its stream's working set in its own LDS slice.
+__global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK) tl_encode_kernel(TlLaunch A)
+{
+    __shared__ TlWaveLds lds[TL_WAVES_PER_BLOCK];
+    const int wave = (int)(threadIdx.x >> 6);
+    const int s = (int)blockIdx.x * TL_WAVES_PER_BLOCK + wave;
+    if (s >= A.nstreams) return;
+    tl_encode_stream(lds[wave], A, s);
+}
+
+// pending frame (big-endian words in the stream state) -> bytes
+__global__ void tl_flush_kernel(const TlStreamState *state, const TlConfig *configs, const int32_t *stream_cfg,
+                                uint8_t *out, int nstreams, int out_stride)
+{
+    const int s = (int)blockIdx.x;
+    if (s >= nstreams) return;
+    const int n = configs[stream_cfg[s]].frame_bytes;
+    const bool any = state[s].frames_done > 0;
+    for (int i = (int)threadIdx.x; i < out_stride; i += (int)blockDim.x)
+        out[(size_t)s * out_stride + i] = (any && i < n) ? (uint8_t)(state[s].pending[i >> 2] >> (24 - 8 * (i & 3))) : 0;
+}
+
+// ------------------------------------------------------------------------------------------
+struct tlb_batch {
+    int device = 0, nstreams = 0, out_stride = 0;
+    long frames = 0;
+    std::vector<TlConfig> h_configs;
+    std::vector<int32_t> h_stream_cfg;
+    TlTables *d_tables = nullptr;
+    TlConfig *d_configs = nullptr;
+    int32_t *d_stream_cfg = nullptr;
+    TlStreamState *d_state = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool timed = false;
+};
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "libtoolame-dab-hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    return TLB_ERR_HIP; } } while (0)
+
+extern "C" {
+
+int tlb_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int tlb_lds_bytes_per_stream(void) { return (int)sizeof(TlWaveLds); }
+const char *tlb_version(void) { return "odr-audioenc_amd 0.1 (gfx950, wave-per-stream, fp64)"; }
+
+void tlb_destroy(tlb_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->d_tables) (void)hipFree(b->d_tables);
+    if (b->d_configs) (void)hipFree(b->d_configs);
+    if (b->d_stream_cfg) (void)hipFree(b->d_stream_cfg);
+    if (b->d_state) (void)hipFree(b->d_state);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    delete b;
+}
+
+static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_stream_config *cfgs)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return TLB_ERR_NO_DEVICE;
+    b->device = device;
+    b->nstreams = nstreams;
+    b->h_stream_cfg.resize(nstreams);
+    // streams sharing the six knobs share one config record (keeps the tables L2/L1 resident)
+    std::vector<tlb_stream_config> uniq;
+    for (int s = 0; s < nstreams; s++) {
+        int found = -1;
+        for (size_t u = 0; u < uniq.size(); u++)
+            if (uniq[u].samplerate == cfgs[s].samplerate && uniq[u].mode == cfgs[s].mode && uniq[u].bitrate == cfgs[s].bitrate &&
+                uniq[u].psy_model == cfgs[s].psy_model && uniq[u].pad_len == cfgs[s].pad_len) { found = (int)u; break; }
+        if (found < 0) {
+            TlConfig c;
+            int rc = tl_build_config(&c, cfgs[s].samplerate, cfgs[s].mode, cfgs[s].bitrate, cfgs[s].psy_model, cfgs[s].pad_len);
+            if (rc) return rc;
+            uniq.push_back(cfgs[s]);
+            b->h_configs.push_back(c);
+            found = (int)uniq.size() - 1;
+        }
+        b->h_stream_cfg[s] = found;
+        if (b->h_configs[found].frame_bytes > b->out_stride) b->out_stride = b->h_configs[found].frame_bytes;
+    }
+    HIPCHK(hipSetDevice(device));
+    TlTables *ht = new TlTables;
+    tl_build_tables(ht);
+    hipError_t e = hipMalloc(&b->d_tables, sizeof(TlTables));
+    if (e == hipSuccess) e = hipMemcpy(b->d_tables, ht, sizeof(TlTables), hipMemcpyHostToDevice);
+    delete ht;
+    HIPCHK(e);
+    HIPCHK(hipMalloc(&b->d_configs, sizeof(TlConfig) * b->h_configs.size()));
+    HIPCHK(hipMemcpy(b->d_configs, b->h_configs.data(), sizeof(TlConfig) * b->h_configs.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&b->d_stream_cfg, sizeof(int32_t) * nstreams));
+    HIPCHK(hipMemcpy(b->d_stream_cfg, b->h_stream_cfg.data(), sizeof(int32_t) * nstreams, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&b->d_state, sizeof(TlStreamState) * (size_t)nstreams));
+    HIPCHK(hipMemset(b->d_state, 0, sizeof(TlStreamState) * (size_t)nstreams));
+    HIPCHK(hipEventCreate(&b->ev0));
+    HIPCHK(hipEventCreate(&b->ev1));
+    return TLB_OK;
+}
+
+tlb_batch *tlb_create(int device, int nstreams, const tlb_stream_config *cfgs, int *err)
+{
+    if (nstreams <= 0 || !cfgs) { if (err) *err = TLB_ERR_ARG; return nullptr; }
+    tlb_batch *b = new tlb_batch;
+    int rc = tlb_create_impl(b, device, nstreams, cfgs);
+    if (err) *err = rc;
+    if (rc) { tlb_destroy(b); return nullptr; }
+    return b;
+}
+
+int tlb_reset(tlb_batch *b)
+{
+    if (!b) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemset(b->d_state, 0, sizeof(TlStreamState) * (size_t)b->nstreams));
+    b->frames = 0;
+    return TLB_OK;
+}
+
+int tlb_nstreams(const tlb_batch *b) { return b ? b->nstreams : 0; }
+int tlb_frame_bytes(const tlb_batch *b, int s) { return (b && s >= 0 && s < b->nstreams) ? b->h_configs[b->h_stream_cfg[s]].frame_bytes : 0; }
+int tlb_out_stride(const tlb_batch *b) { return b ? b->out_stride : 0; }
+long tlb_frames_encoded(const tlb_batch *b) { return b ? b->frames : 0; }
+
+static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d_xpad, const int32_t *d_xpad_len,
+                      uint8_t *d_out, TlTaps *d_taps, hipStream_t st)
+{
+    if (!b || !d_pcm || !d_out || nframes <= 0) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    TlLaunch A;
+    memset(&A, 0, sizeof A);
+    A.tables = b->d_tables; A.configs = b->d_configs; A.stream_cfg = b->d_stream_cfg; A.state = b->d_state;
+    A.pcm = d_pcm; A.xpad = d_xpad_len ? d_xpad : nullptr; A.xpad_len = d_xpad ? d_xpad_len : nullptr;
+    A.out = d_out; A.taps = d_taps;
+    A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride;
+    const int blocks = (b->nstreams + TL_WAVES_PER_BLOCK - 1) / TL_WAVES_PER_BLOCK;
+    HIPCHK(hipEventRecord(b->ev0, st));
+    hipLaunchKernelGGL(tl_encode_kernel, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b->ev1, st));
+    b->last_stream = st; b->timed = true;
+    b->frames += nframes;
+    return TLB_OK;
+}
+
+int tlb_encode_device(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d_xpad, const int32_t *d_xpad_len,
+                      uint8_t *d_out, void *hip_stream)
+{
+    return tlb_launch(b, d_pcm, nframes, d_xpad, d_xpad_len, d_out, nullptr, (hipStream_t)hip_stream);
+}
+
+int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t *xpad, const int32_t *xpad_len,
+                    uint8_t *out, void *taps)
+{
+    if (!b || !pcm || !out || nframes <= 0) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    const size_t slots = (size_t)nframes * (size_t)b->nstreams;
+    int16_t *d_pcm = nullptr; uint8_t *d_xpad = nullptr; int32_t *d_xl = nullptr; uint8_t *d_out = nullptr; TlTaps *d_taps = nullptr;
+    int rc = TLB_OK;
+    hipError_t e = hipMalloc(&d_pcm, slots * 2304 * sizeof(int16_t));
+    if (e == hipSuccess) e = hipMalloc(&d_out, slots * (size_t)b->out_stride);
+    if (e == hipSuccess) e = hipMemset(d_out, 0, slots * (size_t)b->out_stride);
+    if (e == hipSuccess) e = hipMemcpy(d_pcm, pcm, slots * 2304 * sizeof(int16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && xpad && xpad_len) {
+        e = hipMalloc(&d_xpad, slots * TL_MAX_XPAD);
+        if (e == hipSuccess) e = hipMalloc(&d_xl, slots * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMemcpy(d_xpad, xpad, slots * TL_MAX_XPAD, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_xl, xpad_len, slots * sizeof(int32_t), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && taps) {
+        e = hipMalloc(&d_taps, slots * sizeof(TlTaps));
+        if (e == hipSuccess) e = hipMemset(d_taps, 0, slots * sizeof(TlTaps));
+    }
+    if (e == hipSuccess) {
+        rc = tlb_launch(b, d_pcm, nframes, d_xpad, d_xl, d_out, d_taps, nullptr);
+        if (rc == TLB_OK) e = hipDeviceSynchronize();
+        if (rc == TLB_OK && e == hipSuccess) e = hipMemcpy(out, d_out, slots * (size_t)b->out_stride, hipMemcpyDeviceToHost);
+        if (rc == TLB_OK && e == hipSuccess && taps) e = hipMemcpy(taps, d_taps, slots * sizeof(TlTaps), hipMemcpyDeviceToHost);
+    }
+    if (d_pcm) (void)hipFree(d_pcm);
+    if (d_out) (void)hipFree(d_out);
+    if (d_xpad) (void)hipFree(d_xpad);
+    if (d_xl) (void)hipFree(d_xl);
+    if (d_taps) (void)hipFree(d_taps);
+    if (e != hipSuccess) { fprintf(stderr, "libtoolame-dab-hip: %s\n", hipGetErrorString(e)); return TLB_ERR_HIP; }
+    return rc;
+}
+
+int tlb_flush_device(tlb_batch *b, uint8_t *d_out, void *hip_stream)
+{
+    if (!b || !d_out) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    hipLaunchKernelGGL(tl_flush_kernel, dim3(b->nstreams), dim3(128), 0, (hipStream_t)hip_stream, b->d_state, b->d_configs,
+                       b->d_stream_cfg, d_out, b->nstreams, b->out_stride);
+    HIPCHK(hipGetLastError());
+    return TLB_OK;
+}
+
+int tlb_flush_host(tlb_batch *b, uint8_t *out)
+{
+    if (!b || !out) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    uint8_t *d = nullptr;
+    const size_t n = (size_t)b->nstreams * (size_t)b->out_stride;
+    HIPCHK(hipMalloc(&d, n));
+    int rc = tlb_flush_device(b, d, nullptr);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d, n, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return TLB_ERR_HIP;
+    return rc;
+}
+
+float tlb_last_kernel_ms(tlb_batch *b)
+{
+    if (!b || !b->timed) return -1.0f;
+    if (hipSetDevice(b->device) != hipSuccess) return -1.0f;
+    if (hipEventSynchronize(b->ev1) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+// ------------------------------------------------------------------------------------------
+// legacy nine-function ABI: stream 0 of a private one-stream batch (libtoolame-dab/toolame.h:13-48)
+// ------------------------------------------------------------------------------------------
+namespace {
+struct Legacy {
+    bool inited = false;
+    long samplerate = 48000;       // the reference leaves the rate at its zero-initialised default until set
+    char mode = 's';
+    int kbps = 0;
+    int psy = 1;                   // DFLT_PSY, encoder.h:11
+    int pad_len = 0;
+    tlb_batch *batch = nullptr;
+    int lg_frame = 0, minimum = 4, fill = 0;     // emulated 4096-byte bit buffer (bitstream.c)
+    long frame_num = 0;
+    std::deque<unsigned char> fifo;              // final bytes not yet handed to the caller
+} g_legacy;
+
+const int kLegacyBuf = 4096;       // common.h BUFFER_SIZE
+
+int legacy_emit(unsigned char *out, size_t out_size, size_t n)
+{
+    size_t j = 0;
+    for (size_t i = 0; i < n; i++) {
+        unsigned char c = g_legacy.fifo.front();
+        g_legacy.fifo.pop_front();
+        if (j < out_size) out[j++] = c;
+        else if (j == out_size) { fprintf(stderr, "ERROR: libtoolame output buffer too small (%zu vs %zu)!\n", out_size, n); j = out_size + 1; }
+    }
+    return (int)(j > out_size ? out_size : j);
+}
+}  // namespace
+
+int toolame_init(void)
+{
+    if (g_legacy.batch) { tlb_destroy(g_legacy.batch); g_legacy.batch = nullptr; }
+    g_legacy = Legacy();
+    g_legacy.inited = true;
+    return 0;
+}
+int toolame_enable_byteswap(void) { return 0; }           // glopts.byteswap is never read on this path
+int toolame_set_channel_mode(const char mode)
+{
+    if (mode != 's' && mode != 'd' && mode != 'j' && mode != 'm') { fprintf(stderr, "libtoolame-dab: Bad mode %c\n", mode); return 1; }
+    g_legacy.mode = mode;
+    return 0;
+}
+int toolame_set_psy_model(int new_model)
+{
+    if (new_model < 0 || new_model > 3) { fprintf(stderr, "libtoolame-dab: Invalid PSY model %d\n", new_model); return 1; }
+    g_legacy.psy = new_model;
+    return 0;
+}
+int toolame_set_bitrate(int brate) { g_legacy.kbps = brate; return 0; }   // validated at the first frame (needs rate+mode)
+int toolame_set_samplerate(long sample_rate)
+{
+    switch (sample_rate) {
+    case 44100: case 48000: case 32000: case 24000: case 22050: case 16000: g_legacy.samplerate = sample_rate; return 0;
+    default: fprintf(stderr, "SmpFrqIndex: %ld is not a legal sample rate\n", sample_rate); return -1;
+    }
+}
+int toolame_set_pad(int pad_len)
+{
+    if (pad_len < 0) { fprintf(stderr, "Invalid XPAD length specified\n"); return 1; }
+    if (pad_len) g_legacy.pad_len = pad_len;
+    return 0;
+}
+
+int toolame_encode_frame(short buffer[2][1152], unsigned char *xpad_data, size_t xpad_len, unsigned char *output_buffer,
+                         size_t output_buffer_size)
+{
+    Legacy &g = g_legacy;
+    if (!g.batch) {
+        tlb_stream_config c = {g.samplerate, g.mode, g.kbps, g.psy, g.pad_len > TLB_MAX_XPAD ? TLB_MAX_XPAD : g.pad_len};
+        int err = 0;
+        g.batch = tlb_create(0, 1, &c, &err);
+        if (!g.batch) {
+            // the reference exit()s on an illegal bitrate (common.c:114); a missing GPU is equally fatal here
+            fprintf(stderr, "libtoolame-dab-hip: cannot create the GPU encoder (error %d)\n", err);
+            exit(-1);
+        }
+        g.lg_frame = tlb_frame_bytes(g.batch, 0);
+        g.minimum = g.lg_frame + 4;                        // toolame.c:298-300
+    }
+    unsigned char xrec[TLB_MAX_XPAD];
+    int32_t xl = 0;
+    memset(xrec, 0, sizeof xrec);
+    if (xpad_len >= 2 && xpad_data && xpad_len <= (size_t)TLB_MAX_XPAD && (int)xpad_len <= g.pad_len) {
+        xl = (int32_t)xpad_len;                            // bytes [dab_length-xpad_len, dab_length) in transmission order
+        memcpy(xrec, xpad_data + g.pad_len - (int)xpad_len, xpad_len);
+    }
+    std::vector<unsigned char> out((size_t)g.lg_frame);
+    if (tlb_encode_host(g.batch, &buffer[0][0], 1, xrec, &xl, out.data(), nullptr) != TLB_OK) return 0;
+    g.frame_num++;
+    if (g.frame_num > 1) g.fifo.insert(g.fifo.end(), out.begin(), out.end());   // frame n-1 is final now
+    // bitstream.c:46-71: when the 4096-byte buffer fills, everything but the newest `minimum` bytes is handed out
+    int written = 0;
+    if (g.fill + g.lg_frame >= kLegacyBuf) {
+        written = legacy_emit(output_buffer, output_buffer_size, (size_t)(kLegacyBuf - g.minimum));
+        g.fill = g.minimum + (g.fill + g.lg_frame - kLegacyBuf);
+    } else g.fill += g.lg_frame;
+    return written;
+}
+
+int toolame_finish(unsigned char *output_buffer, size_t output_buffer_size)
+{
+    Legacy &g = g_legacy;
+    if (!g.batch) return 0;
+    std::vector<unsigned char> last((size_t)tlb_out_stride(g.batch));
+    if (g.frame_num > 0 && tlb_flush_host(g.batch, last.data()) == TLB_OK)
+        g.fifo.insert(g.fifo.end(), last.begin(), last.begin() + g.lg_frame);   // the last frame keeps its own ScF-CRC
+    int n = legacy_emit(output_buffer, output_buffer_size, g.fifo.size());
+    tlb_destroy(g.batch);
+    g.batch = nullptr;
+    g.fill = 0; g.frame_num = 0;
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,203 @@
+"""ctypes binding of libtoolame_dab_hip.so (include/toolame_batch.h).
+
+Mirrors the reference's operator interface for this path: the six setters of
+libtoolame-dab/toolame.h:13-48 become the fields of StreamConfig (same names, same argument meaning,
+same validity rules), `Batch.encode()` is toolame_encode_frame() over N streams and F frames, and
+`Batch.flush()` is toolame_finish().  Errors surface as ToolameError with the library's code, where
+the reference returns non-zero or exit()s.
+"""
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libtoolame_dab_hip.so"
+MAX_XPAD = 200
+SAMPLES = 1152
+
+_ERR = {1: "illegal sample rate (48000/32000/24000/16000 Hz supported)", 2: "bad channel mode", 3: "invalid PSY model",
+        4: "illegal bitrate for this MPEG version", 5: "invalid XPAD length", 16: "no usable HIP device",
+        17: "HIP runtime error", 18: "bad argument"}
+
+
+class ToolameError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        super().__init__(f"libtoolame-dab-hip: {what or 'error'}: {_ERR.get(code, 'unknown')} (code {code})")
+
+
+@dataclass(frozen=True)
+class StreamConfig:
+    """toolame_set_samplerate / _channel_mode / _bitrate / _psy_model / _pad (toolame.c:174-262)."""
+    samplerate: int = 48000
+    mode: str = "j"          # odr-audioenc's default for two channels (src/odr-audioenc.cpp:697-709)
+    bitrate: int = 128
+    psy_model: int = 1
+    pad_len: int = 0
+
+
+class _CConfig(C.Structure):
+    _fields_ = [("samplerate", C.c_long), ("mode", C.c_char), ("bitrate", C.c_int), ("psy_model", C.c_int),
+                ("pad_len", C.c_int)]
+
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile csrc/ for gfx950 into libtoolame_dab_hip.so (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", str(PKG_DIR / "csrc")], capture_output=not verbose, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc build failed:\n" + (r.stdout or "") + (r.stderr or ""))
+    return LIB_PATH
+
+
+def load_library():
+    """Load the HIP library or raise -- there is no CPU fallback for the product path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ToolameError(16, f"{LIB_PATH} is missing (run __graft_entry__.build())")
+    L = C.CDLL(str(LIB_PATH))
+    L.tlb_create.restype = C.c_void_p
+    L.tlb_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+    L.tlb_destroy.argtypes = [C.c_void_p]
+    L.tlb_reset.argtypes = [C.c_void_p]
+    for f in ("tlb_nstreams", "tlb_out_stride"):
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.tlb_frame_bytes.argtypes = [C.c_void_p, C.c_int]
+    L.tlb_frames_encoded.argtypes = [C.c_void_p]
+    L.tlb_frames_encoded.restype = C.c_long
+    L.tlb_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tlb_encode_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tlb_flush_host.argtypes = [C.c_void_p, C.c_void_p]
+    L.tlb_flush_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tlb_last_kernel_ms.argtypes = [C.c_void_p]
+    L.tlb_last_kernel_ms.restype = C.c_float
+    L.tlb_version.restype = C.c_char_p
+    L.toolame_set_samplerate.argtypes = [C.c_long]
+    L.toolame_set_channel_mode.argtypes = [C.c_char]
+    L.toolame_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.toolame_finish.argtypes = [C.c_void_p, C.c_size_t]
+    _lib = L
+    return L
+
+
+def lds_bytes_per_stream():
+    return load_library().tlb_lds_bytes_per_stream()
+
+
+def legacy_api():
+    """The nine reference symbols (toolame_init ... toolame_encode_frame) as a ctypes library."""
+    return load_library()
+
+
+# mirror of TlTaps (csrc/mp2_types.h) for stage-level parity tests
+TAPS_DTYPE = np.dtype([
+    ("sb_sample", np.float64, (2, 3, 12, 32)), ("smr", np.float64, (2, 32)), ("max_sc", np.float64, (2, 32)),
+    ("subband", np.uint32, (2, 3, 12, 32)), ("scalar_pre", np.uint8, (2, 3, 32)), ("scalar", np.uint8, (2, 3, 32)),
+    ("j_scale", np.uint8, (3, 32)), ("scfsi", np.uint8, (2, 32)), ("bit_alloc", np.uint8, (2, 32)),
+    ("adb_left", np.int32), ("mode", np.int32), ("mode_ext", np.int32), ("jsbound", np.int32), ("crc16", np.int32),
+    ("scfcrc", np.uint8, (4,)), ("pad_", np.int32, (2,)),
+])
+
+
+class Batch:
+    """N independent DAB MP2 encoders on one MI355X (one wavefront per stream)."""
+
+    def __init__(self, configs, device=0):
+        self.L = load_library()
+        configs = list(configs)
+        if not configs:
+            raise ToolameError(18, "empty batch")
+        arr = (_CConfig * len(configs))()
+        for i, c in enumerate(configs):
+            arr[i].samplerate = c.samplerate
+            arr[i].mode = c.mode.encode()[:1]
+            arr[i].bitrate = c.bitrate
+            arr[i].psy_model = c.psy_model
+            arr[i].pad_len = c.pad_len
+        err = C.c_int(0)
+        self.h = self.L.tlb_create(device, len(configs), arr, C.byref(err))
+        if not self.h:
+            raise ToolameError(err.value, "tlb_create")
+        self.device = device
+        self.nstreams = len(configs)
+        self.configs = configs
+        self.frame_bytes = [self.L.tlb_frame_bytes(self.h, s) for s in range(self.nstreams)]
+        self.out_stride = self.L.tlb_out_stride(self.h)
+        self._first = True
+
+    # -- host-buffer path (tests, legacy-style callers) ------------------------------------
+    def encode(self, pcm, xpad=None, xpad_len=None, want_taps=False):
+        """pcm int16 [nframes, nstreams, 2, 1152] -> (per stream: bytes of the frames that became
+        final during this call, taps [nframes, nstreams] or None).  One frame of latency, see
+        include/toolame_batch.h."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        nf = pcm.shape[0]
+        if pcm.shape != (nf, self.nstreams, 2, SAMPLES):
+            raise ToolameError(18, f"pcm shape {pcm.shape}")
+        out = np.zeros((nf, self.nstreams, self.out_stride), dtype=np.uint8)
+        taps = np.zeros((nf, self.nstreams), dtype=TAPS_DTYPE) if want_taps else None
+        xp = xl = None
+        if xpad is not None:
+            xp = np.ascontiguousarray(xpad, dtype=np.uint8)
+            xl = np.ascontiguousarray(xpad_len, dtype=np.int32)
+            if xp.shape != (nf, self.nstreams, MAX_XPAD) or xl.shape != (nf, self.nstreams):
+                raise ToolameError(18, "xpad shape")
+        rc = self.L.tlb_encode_host(self.h, pcm.ctypes.data, nf, xp.ctypes.data if xp is not None else None,
+                                    xl.ctypes.data if xl is not None else None, out.ctypes.data,
+                                    taps.ctypes.data if taps is not None else None)
+        if rc:
+            raise ToolameError(rc, "tlb_encode_host")
+        first = 1 if self._first else 0
+        self._first = False
+        res = [b"".join(out[f, s, : self.frame_bytes[s]].tobytes() for f in range(first, nf)) for s in range(self.nstreams)]
+        return res, taps
+
+    def flush(self):
+        """toolame_finish(): the last (pending) frame of every stream, carrying its own ScF-CRC."""
+        out = np.zeros((self.nstreams, self.out_stride), dtype=np.uint8)
+        rc = self.L.tlb_flush_host(self.h, out.ctypes.data)
+        if rc:
+            raise ToolameError(rc, "tlb_flush_host")
+        if self._first:
+            return [b""] * self.nstreams
+        return [out[s, : self.frame_bytes[s]].tobytes() for s in range(self.nstreams)]
+
+    # -- device-resident path (bench, production) -------------------------------------------
+    def encode_device(self, d_pcm_ptr, nframes, d_out_ptr, d_xpad_ptr=None, d_xpad_len_ptr=None, stream=None):
+        rc = self.L.tlb_encode_device(self.h, d_pcm_ptr, nframes, d_xpad_ptr, d_xpad_len_ptr, d_out_ptr, stream)
+        if rc:
+            raise ToolameError(rc, "tlb_encode_device")
+        self._first = False
+
+    def flush_device(self, d_out_ptr, stream=None):
+        rc = self.L.tlb_flush_device(self.h, d_out_ptr, stream)
+        if rc:
+            raise ToolameError(rc, "tlb_flush_device")
+
+    def last_kernel_ms(self):
+        return float(self.L.tlb_last_kernel_ms(self.h))
+
+    def reset(self):
+        rc = self.L.tlb_reset(self.h)
+        if rc:
+            raise ToolameError(rc, "tlb_reset")
+        self._first = True
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.tlb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,69 @@
+// mp2_emu.cpp -- TEST-ONLY host emulation of the wave-per-stream HIP encoder.
+//
+// Compiles odr-audioenc_amd/csrc/mp2_wave.h with -DTL_EMULATE: every TL_LANES_BEGIN/END region
+// becomes a loop over 64 lanes, so the CPU test-suite executes the device algorithm (same source,
+// same arithmetic, same order) without a GPU.  This library is NOT part of the product: the C-ABI
+// library (libtoolame_dab_hip.so) never contains or loads it.
+#define TL_EMULATE 1
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../odr-audioenc_amd/csrc/mp2_host.h"
+#include "../../odr-audioenc_amd/csrc/mp2_wave.h"
+
+struct Emu {
+    TlTables tables;
+    std::vector<TlConfig> configs;
+    std::vector<int32_t> stream_cfg;
+    std::vector<TlStreamState> state;
+};
+
+extern "C" {
+void *emu_create(int nstreams, const long *fs, const char *mode, const int *kbps, const int *psy, const int *pad, int *err)
+{
+    Emu *e = new Emu;
+    tl_build_tables(&e->tables);
+    e->configs.resize(nstreams);
+    e->stream_cfg.resize(nstreams);
+    e->state.resize(nstreams);
+    memset(e->state.data(), 0, sizeof(TlStreamState) * nstreams);
+    for (int s = 0; s < nstreams; s++) {
+        int rc = tl_build_config(&e->configs[s], fs[s], mode[s], kbps[s], psy[s], pad[s]);
+        if (rc) { if (err) *err = rc; delete e; return nullptr; }
+        e->stream_cfg[s] = s;
+    }
+    if (err) *err = 0;
+    return e;
+}
+void emu_destroy(void *h) { delete (Emu *)h; }
+int emu_frame_bytes(void *h, int s) { return ((Emu *)h)->configs[s].frame_bytes; }
+
+int emu_encode(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, const int32_t *xpad_len, uint8_t *out,
+               int out_stride, TlTaps *taps)
+{
+    Emu *e = (Emu *)h;
+    TlLaunch A;
+    memset(&A, 0, sizeof A);
+    A.tables = &e->tables; A.configs = e->configs.data(); A.stream_cfg = e->stream_cfg.data();
+    A.state = e->state.data(); A.pcm = pcm; A.xpad = xpad; A.xpad_len = xpad_len; A.out = out; A.taps = taps;
+    A.nstreams = (int)e->state.size(); A.nframes = nframes; A.out_stride = out_stride;
+    static thread_local TlWaveLds w;
+    for (int s = 0; s < A.nstreams; s++) tl_encode_stream(w, A, s);
+    return 0;
+}
+int emu_pending(void *h, int s, uint8_t *out)
+{
+    Emu *e = (Emu *)h;
+    if (e->state[s].frames_done == 0) return 0;
+    int n = e->configs[s].frame_bytes;
+    for (int i = 0; i < n; i++) out[i] = (uint8_t)(e->state[s].pending[i >> 2] >> (24 - 8 * (i & 3)));
+    return n;
+}
+int emu_sizeof_taps(void) { return (int)sizeof(TlTaps); }
+int emu_sizeof_lds(void) { return (int)sizeof(TlWaveLds); }
+double emu_log10(double x) { return tl_log10(x); }
+double emu_pow10(double x) { return tl_pow10(x); }
+}
