@@ -986,7 +986,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     if (taps) {
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
-        taps->smr[c][sb] = (c < nch) ? w.smr[c][sb] : 0.0;
+        taps->smr[c][sb] = (c < nch && (C->psy != 1 || sb < sblimit)) ? w.smr[c][sb] : 0.0;   // psy 1 leaves sb >= sblimit unset
         taps->scfsi[c][sb] = w.scfsi[c][sb]; taps->bit_alloc[c][sb] = w.balloc[c][sb];
         for (int gr = 0; gr < 3; gr++) taps->scalar[c][gr][sb] = w.scf[c][gr][sb];
         if (lane == 0) { taps->adb_left = adb_left; taps->mode = mode; taps->mode_ext = mode_ext; taps->jsbound = jsbound; taps->crc16 = (int)crc16; }

