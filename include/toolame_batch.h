@@ -103,6 +103,9 @@ int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t
 int tlb_flush_host(tlb_batch *b, uint8_t *out);
 int tlb_flush_device(tlb_batch *b, uint8_t *d_out, void *hip_stream);
 
+/* Diagnostic only: per-stage cycle stamps [nframes][nstreams][32] (csrc/mp2_wave.h TL_STAMP), host buffers. */
+int tlb_encode_host_stamps(tlb_batch *b, const int16_t *pcm, int nframes, long long *stamps);
+
 /* Duration in milliseconds of the most recent tlb_encode_device()/tlb_encode_host() kernel, measured
  * with hipEvents on the launch stream (synchronises on that stream).  < 0 on error. */
 float tlb_last_kernel_ms(tlb_batch *b);

@@ -93,5 +93,6 @@ struct TlLaunch {
     const int32_t *xpad_len;          // [nframes][nstreams] or null
     uint8_t *out;                     // [nframes][nstreams][out_stride]: slot f holds frame (f-1); slot 0 = pending
     TlTaps *taps;                     // [nframes][nstreams] or null
+    long long *stamps;                // [nframes][nstreams][32] cycle stamps (diagnostic builds) or null
     int32_t nstreams, nframes, out_stride, pad_;
 };

@@ -80,6 +80,12 @@ TL_FN int tld_exscan_i32(int v) {
 #define TL_RESTRICT __restrict__
 #endif
 
+#ifdef TL_EMULATE
+#define TL_STAMP(sp, k) ((void)0)
+#else
+#define TL_STAMP(sp, k) do { if (sp) { long long t_ = (long long)__builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63u) == 0) (sp)[k] = t_; } } while (0)
+#endif
+
 #define TL_DBMIN (-200.0)
 #define TL_POWERNORM 90.3090
 #define TL_T_NOISE 10
@@ -234,11 +240,13 @@ TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, int ch)
 
 // ------------------------------------------------------------------------------------------
 // psy model 1 (psycho_1.c:22-87, :215-581) for channel `ch`; result in w.smr[ch][0..sblimit).
-TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *TL_RESTRICT C, int ch)
+TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *TL_RESTRICT C, int ch, long long *sp)
 {
     const double *energy = w.u.fft;
     const double *db = T->dbtable;
+    TL_STAMP(sp, 0);
     tl_psy_spectrum(w, T, ch);
+    TL_STAMP(sp, 1);
 
     // power density spectrum + list reset (psycho_1.c:241-248); spike (psycho_1.c:252-257)
     TL_LANES_BEGIN
@@ -279,6 +287,7 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
     }
     TL_LANES_END
 
+    TL_STAMP(sp, 2);
     // sequential tone confirmation (psycho_1.c:285-339); wave-uniform serial walk
     int tone = TL_LAST, noise = 0;
     {
@@ -323,6 +332,7 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
         }
     }
 
+    TL_STAMP(sp, 3);
     // noise components: one lane per critical band (psycho_1.c:356-376)
     const int nbands = C->p1_ncb - 1;
     TL_LANES_BEGIN
@@ -356,6 +366,7 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
         TL_SYNC();
     }
 
+    TL_STAMP(sp, 4);
     // decimation (psycho_1.c:409-470), then compaction of the surviving maskers
     int ntone = 0, nnoise = 0;
     {
@@ -401,6 +412,7 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
         TL_SYNC();
     }
 
+    TL_STAMP(sp, 5);
     // individual + global masking thresholds on the table lines (psycho_1.c:480-532)
     const int sub = C->p1_sub;
     TL_LANES_BEGIN
@@ -429,6 +441,7 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
     }
     TL_LANES_END
 
+    TL_STAMP(sp, 6);
     // minimum per subband (psycho_1.c:541-559) and SMR (psycho_1.c:568-581)
     TL_LANES_BEGIN
     if (lane < C->sblimit) {
@@ -448,7 +461,7 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
 
 // ------------------------------------------------------------------------------------------
 // psy model 3 (psycho_3.c:71-432) for channel `ch`; result in w.smr[ch][0..32).
-TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *TL_RESTRICT C, int ch)
+TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *TL_RESTRICT C, int ch, long long *sp)
 {
     const double *energy = w.u.fft;
     const double *db = T->dbtable;
@@ -576,12 +589,13 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
 // ------------------------------------------------------------------------------------------
 // One frame of one stream.  lane = 2*sb + ch owns subband sb of channel ch.
 TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *TL_RESTRICT C,
-                           TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, TlTaps *taps)
+                           TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, TlTaps *taps, long long *sp)
 {
     const int nch = C->nch, sblimit = C->sblimit;
     PA(double, smp, 36);            // sb_sample[ch][gr][bl][sb] of this lane's (sb,ch), b = gr*12+bl
     PA(int, scf, 3);
 
+    TL_STAMP(sp, 0);
     // ---- K1: polyphase filterbank (subband.c:201-310), 36 blocks of 32 samples ----
     {
         PA(double, cw, 16);         // this lane's 2x8 window taps: outputs i and i+32
@@ -628,6 +642,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         }
     }
 
+    TL_STAMP(sp, 1);
     // ---- K2: scalefactors (encode_new.c:179-230) + find_sf_max (:260-277) ----
     TL_LANES_BEGIN
     const int c = lane & 1, sb = lane >> 1;
@@ -684,6 +699,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         TL_LANES_END
     }
 
+    TL_STAMP(sp, 2);
     // ---- K3/K4: psychoacoustic model -> SMR (toolame.c:361-452) ----
     if (C->psy == 0) {                                           // psycho_0.c:52-68
         TL_LANES_BEGIN
@@ -694,11 +710,12 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         }
         TL_LANES_END
     } else if (C->psy == 1) {
-        for (int ch = 0; ch < nch; ch++) tl_psy1(w, T, C, ch);
+        for (int ch = 0; ch < nch; ch++) tl_psy1(w, T, C, ch, sp ? sp + 8 + 8 * ch : nullptr);
     } else {
-        for (int ch = 0; ch < nch; ch++) tl_psy3(w, T, C, ch);
+        for (int ch = 0; ch < nch; ch++) tl_psy3(w, T, C, ch, sp ? sp + 8 + 8 * ch : nullptr);
     }
 
+    TL_STAMP(sp, 3);
     // ---- sf_transmission_pattern (encode_new.c:288-354, ISO Table C.4) ----
     TL_LANES_BEGIN
     const int c = lane & 1, sb = lane >> 1;
@@ -844,6 +861,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         TL_LANES_END
     }
 
+    TL_STAMP(sp, 4);
     // ---- K6: header, CRC, bit_alloc, scfsi, scalefactors, quantised samples -> LDS frame ----
     uint32_t *frame = w.u.frame;
     TL_LANES_BEGIN
@@ -943,6 +961,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         }
     }
 
+    TL_STAMP(sp, 5);
     // CRC-16 over header bits 16..31, bit_alloc and scfsi fields (crc.c:12-41); one lane, bit-serial
     unsigned crc16 = 0xffff;
     {
@@ -994,6 +1013,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         TL_LANES_END
     }
 
+    TL_STAMP(sp, 6);
     // ---- emit: patch the previous frame's ScF-CRC slot with this frame's CRC and hand it out;
     //      this frame becomes the pending one (toolame.c:527-542, "one frame in memory") ----
     const int nwords = (lg_frame + 3) >> 2;
@@ -1017,6 +1037,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         st->pending[i] = frame[i];
     }
     TL_LANES_END
+    TL_STAMP(sp, 7);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1051,7 +1072,8 @@ TL_FN void tl_encode_stream(TlWaveLds &w, const TlLaunch &A, int s)
             for (int i = lane; i < xl; i += 64) w.xpad[i] = A.xpad[slot * TL_MAX_XPAD + i];
             TL_LANES_END
         }
-        tl_encode_frame(w, T, C, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, A.taps ? &A.taps[slot] : nullptr);
+        tl_encode_frame(w, T, C, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, A.taps ? &A.taps[slot] : nullptr,
+                        A.stamps ? A.stamps + slot * 32 : nullptr);
         done++;
         TL_LANES_BEGIN
         for (int i = lane; i < TL_HIST * nch; i += 64) {

@@ -154,7 +154,7 @@ int tlb_out_stride(const tlb_batch *b) { return b ? b->out_stride : 0; }
 long tlb_frames_encoded(const tlb_batch *b) { return b ? b->frames : 0; }
 
 static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d_xpad, const int32_t *d_xpad_len,
-                      uint8_t *d_out, TlTaps *d_taps, hipStream_t st)
+                      uint8_t *d_out, TlTaps *d_taps, hipStream_t st, long long *d_stamps = nullptr)
 {
     if (!b || !d_pcm || !d_out || nframes <= 0) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
@@ -162,7 +162,7 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
     memset(&A, 0, sizeof A);
     A.tables = b->d_tables; A.configs = b->d_configs; A.stream_cfg = b->d_stream_cfg; A.state = b->d_state;
     A.pcm = d_pcm; A.xpad = d_xpad_len ? d_xpad : nullptr; A.xpad_len = d_xpad ? d_xpad_len : nullptr;
-    A.out = d_out; A.taps = d_taps;
+    A.out = d_out; A.taps = d_taps; A.stamps = d_stamps;
     A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride;
     const int blocks = (b->nstreams + TL_WAVES_PER_BLOCK - 1) / TL_WAVES_PER_BLOCK;
     HIPCHK(hipEventRecord(b->ev0, st));
@@ -214,6 +214,25 @@ int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t
     if (d_xl) (void)hipFree(d_xl);
     if (d_taps) (void)hipFree(d_taps);
     if (e != hipSuccess) { fprintf(stderr, "libtoolame-dab-hip: %s\n", hipGetErrorString(e)); return TLB_ERR_HIP; }
+    return rc;
+}
+
+// Diagnostic: per-stage s_memtime stamps [nframes][nstreams][32] (see TL_STAMP in mp2_wave.h).
+int tlb_encode_host_stamps(tlb_batch *b, const int16_t *pcm, int nframes, long long *stamps)
+{
+    if (!b || !pcm || !stamps || nframes <= 0) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    const size_t slots = (size_t)nframes * (size_t)b->nstreams;
+    int16_t *d_pcm = nullptr; uint8_t *d_out = nullptr; long long *d_st = nullptr;
+    HIPCHK(hipMalloc(&d_pcm, slots * 2304 * sizeof(int16_t)));
+    HIPCHK(hipMalloc(&d_out, slots * (size_t)b->out_stride));
+    HIPCHK(hipMalloc(&d_st, slots * 32 * sizeof(long long)));
+    HIPCHK(hipMemset(d_st, 0, slots * 32 * sizeof(long long)));
+    HIPCHK(hipMemcpy(d_pcm, pcm, slots * 2304 * sizeof(int16_t), hipMemcpyHostToDevice));
+    int rc = tlb_launch(b, d_pcm, nframes, nullptr, nullptr, d_out, nullptr, nullptr, d_st);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(stamps, d_st, slots * 32 * sizeof(long long), hipMemcpyDeviceToHost));
+    (void)hipFree(d_pcm); (void)hipFree(d_out); (void)hipFree(d_st);
     return rc;
 }
 

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-stage share of a frame's cycles inside tl_encode_kernel (s_memtime stamps).
+Run on the GPU box: python tools/stage_profile.py [psy] [mode] [nstreams]"""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import odr_audioenc_amd as M
+from pcmgen import gen_pcm
+
+psy = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+mode = sys.argv[2] if len(sys.argv) > 2 else "s"
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+F = 4
+pcm = np.stack([gen_pcm(s, 0, 0, F) for s in range(S)], axis=1)
+b = M.Batch([M.StreamConfig(mode=mode, psy_model=psy)] * S)
+L = M.load_library()
+L.tlb_encode_host_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+st = np.zeros((F, S, 32), dtype=np.int64)
+assert L.tlb_encode_host_stamps(b.h, np.ascontiguousarray(pcm).ctypes.data, F, st.ctypes.data) == 0
+st = st[1:]                                   # skip the first (cold) frame
+names = ["filterbank", "scalefactors", "psy", "sfpattern+bitalloc", "quantise+pack", "crc+scfcrc+pad", "emit"]
+tot = (st[..., 7] - st[..., 0]).mean()
+print(f"psy {psy} mode {mode} {S} streams: {tot:.0f} cycles/frame/wave")
+for i, n in enumerate(names):
+    d = (st[..., i + 1] - st[..., i]).mean()
+    print(f"  {n:22s} {d:10.0f}  {100 * d / tot:5.1f}%")
+pn = ["spectrum(FHT)", "power+candidates", "tonal walk", "noise bands", "decimation", "threshold", "minmask+smr"]
+for ch in range(2):
+    base = 8 + 8 * ch
+    if st[..., base + 1].max() == 0:
+        continue
+    for i, n in enumerate(pn):
+        hi = st[..., base + i + 1] if i < 6 else None
+        if hi is None:
+            continue
+        d = (hi - st[..., base + i]).mean()
+        print(f"    ch{ch} {n:18s} {d:10.0f}  {100 * d / tot:5.1f}%")
