@@ -53,6 +53,13 @@ void tl_build_tables(TlTables *T)
         T->nbal_line[l] = TL_NBAL[l];
         for (int b = 0; b < 16; b++) T->step_index[l][b] = TL_STEP_INDEX[l * 16 + b];
     }
+    for (int l = 0; l < 9; l++)
+        for (int b = 0; b < 16; b++) {
+            const int q = TL_STEP_INDEX[l * 16 + b];
+            T->shared.snr_line[l][b] = T->snr[q];
+            T->shared.bits12_line[l][b] = (int16_t)(12 * TL_GROUP[q] * TL_BITS[q]);
+        }
+    for (int i = 0; i < 64; i++) T->shared.scalefactor[i] = T->scalefactor[i];
     // matrixing coefficients: cos scaled by 1e9, rounded half away from zero, scaled back (subband.c:125-137)
     for (int i = 0; i < 16; i++)
         for (int k = 0; k < 32; k++) {
@@ -67,6 +74,7 @@ void tl_build_tables(TlTables *T)
     for (int i = 0; i < 1000; i++) {
         double x = (double)i / 10.0;
         T->dbtable[i] = 10 * log10(1 + pow(10.0, x / 10.0)) - x;
+        T->shared.dbtable[i] = T->dbtable[i];
     }
     // Buneman recurrence of fft.c:1139-1149 unrolled into a table (passes k = 2,4,6,8)
     int n = 0;
@@ -191,6 +199,8 @@ int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, 
         for (; i < 6 * 16 + 1; i += 2) C->p3_subset[n++] = (int16_t)i;
         for (; i < 12 * 16 + 1; i += 4) C->p3_subset[n++] = (int16_t)i;
         for (; i < 32 * 16 + 1; i += 8) C->p3_subset[n++] = (int16_t)i;
+        for (int sb = 0; sb < 32; sb++) { C->p3_sb_j0[sb] = 0; C->p3_sb_n[sb] = 0; }
+        for (int j = 135; j >= 0; j--) { const int sb = C->p3_subset[j] >> 4; C->p3_sb_j0[sb] = (int16_t)j; C->p3_sb_n[sb]++; }
     }
     // ---- psy model 0 (psycho_0.c:36-50) ----
     {

@@ -12,6 +12,15 @@
 #define TL_HIST 480                  // filterbank history (512-32); psy-1/3 need the last 192
 #define TL_MAX_XPAD 200              // X-PAD + F-PAD bytes per frame handled on device
 
+// The part of the common tables that sits on dependent-load chains (dB sums, scalefactor search,
+// allocation loop): copied once per workgroup into LDS and shared by its waves.
+struct TlBlockShared {
+    double dbtable[1000];        // psycho_1.c:170-178
+    double scalefactor[64];      // encode_new.c:65-83
+    double snr_line[9][16];      // SNR[step_index[line][ba]]             (encode_new.c:16-27,96-100)
+    int16_t bits12_line[9][16];  // 12*group*bits of step_index[line][ba] (encode_new.c:1125-1133)
+};
+
 // Tables common to every config.  (ref: enwindow.h, subband.c:125-137, psycho_1.c:170-178,225-233,
 // fft.c:38-73,1139-1149, encode_new.c:16-100,448-462)
 struct TlTables {
@@ -31,6 +40,7 @@ struct TlTables {
     uint8_t step_index[9][16];
     uint8_t nbal_line[9];
     uint8_t pad_[3];
+    TlBlockShared shared;
 };
 
 // Per-config constants.  (ref: toolame.c:120-262, common.c:76-144, encode_new.c:104-125)
@@ -54,6 +64,7 @@ struct TlConfig {
     double p3_ath[520];
     int16_t p3_cbidx[36];
     int16_t p3_subset[136];
+    int16_t p3_sb_j0[32], p3_sb_n[32];   // rows of p3_subset that fall into each subband (psycho_3.c:415-420)
     // psy model 0 (psycho_0.c:36-50)
     double p0_athmin[32];
 };

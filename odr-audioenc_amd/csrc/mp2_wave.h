@@ -40,6 +40,7 @@ TL_FN void tlh_exscan_i32(int (&d)[64], const int (&v)[64]) { int s = 0; for (in
 #define TL_WAVE_SUM_I32(name) tlh_sum_i32(name)
 #define TL_WAVE_EXSCAN_I32(dst, src) tlh_exscan_i32(dst, src)
 #define TL_UNI_I(x) (x)
+#define TL_READLANE_I32(name, l) name[l]
 #define TL_RESTRICT
 #else
 #define TL_FN __device__ __forceinline__
@@ -55,10 +56,23 @@ TL_FN void tlh_exscan_i32(int (&d)[64], const int (&v)[64]) { int s = 0; for (in
 #define TL_OTHER(name, idx, src) tld_shfl_f64(name idx, src)
 #define TL_ATOMIC_OR(p, v) atomicOr((p), (v))
 TL_FN double tld_shfl_f64(double v, int src) { return __shfl(v, src, 64); }
+TL_FN uint32_t tld_min_u32(uint32_t v) {
+    // DPP reduction (gfx9): row_shr 1,2,4,8 -> row minimum in lane 15 of each row; row_bcast15 / row_bcast31
+    // carry it across rows; lane 63 holds the wave minimum.  Shifted-in lanes read the identity.
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x111, 0xf, 0xf, false); v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x112, 0xf, 0xf, false); v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x114, 0xf, 0xf, false); v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x118, 0xf, 0xf, false); v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x142, 0xa, 0xf, false); v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x143, 0xc, 0xf, false); v = t < v ? t : v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 TL_FN uint64_t tld_min_u64(uint64_t v) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) { uint64_t t = __shfl_xor((unsigned long long)v, o, 64); v = t < v ? t : v; }
-    return v;
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    const uint32_t mhi = tld_min_u32(hi);
+    const uint32_t mlo = tld_min_u32(hi == mhi ? lo : 0xffffffffu);
+    return ((uint64_t)mhi << 32) | mlo;
 }
 TL_FN int tld_sum_i32(int v) {
 #pragma unroll
@@ -77,6 +91,7 @@ TL_FN int tld_exscan_i32(int v) {
 #define TL_WAVE_SUM_I32(name) tld_sum_i32(name)
 #define TL_WAVE_EXSCAN_I32(dst, src) dst = tld_exscan_i32(src)
 #define TL_UNI_I(x) __builtin_amdgcn_readfirstlane(x)
+#define TL_READLANE_I32(name, l) __builtin_amdgcn_readlane(name, l)
 #define TL_RESTRICT __restrict__
 #endif
 
@@ -86,6 +101,14 @@ TL_FN int tld_exscan_i32(int v) {
 #define TL_STAMP(sp, k) do { if (sp) { long long t_ = (long long)__builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63u) == 0) (sp)[k] = t_; } } while (0)
 #endif
 
+#if defined(TL_EMULATE) && defined(TL_DEBUG_DUMP)
+#include <stdio.h>
+#include <stdlib.h>
+#define TL_DBG_DUMP(tag, ch, nt, nn, x, b) do { if (getenv("TL_DUMP")) { printf("%s ch%d ntone %d nnoise %d:", tag, ch, nt, nn); \
+    for (int i_ = 0; i_ < (nt) + (nn); i_++) printf(" (%.17g,%.6f)", (x)[i_], (b)[i_]); printf("\n"); } } while (0)
+#else
+#define TL_DBG_DUMP(tag, ch, nt, nn, x, b) ((void)0)
+#endif
 #define TL_DBMIN (-200.0)
 #define TL_POWERNORM 90.3090
 #define TL_T_NOISE 10
@@ -95,24 +118,28 @@ TL_FN int tld_exscan_i32(int v) {
 
 // ------------------------------------------------------------------------------------------
 // Per-wave LDS working set.
+#define TL_CAND_MAX 256              // local maxima with passing right side (<= 249)
+#define TL_TONE_MAX 96               // confirmed tones per channel-frame (hard bound ~75: erasure spacing)
+#define TL_MASKER_MAX 128            // tones + noise components after decimation
 struct TlWaveLds {
     int16_t pcm[2][TL_HIST + 1152];     // [history | this frame], planar
     union {
         struct { double y[2][64]; double yp[2][32]; } fb;     // filterbank stage
         double fft[1024];                                     // psy stage: FHT buffer, then energy[0..512]
-        double xch[12][64];                                   // joint-stereo sample exchange
         uint32_t frame[TL_MAX_FRAME_WORDS];                   // packing stage
     } u;
     double px[520];                     // psy: power spectrum in dB
     double ltg[136];                    // psy: thresholds on the subsampled lines
-    double mk_x[200];                   // psy: compacted maskers (tones first, then noise)
-    double mk_bark[200];
+    double mk_x[TL_MASKER_MAX];         // psy: compacted maskers (tones first, then noise)
+    double mk_bark[TL_MASKER_MAX];
+    double tone_x[TL_TONE_MAX];         // psy-1: summed level of each confirmed tone
     double smr[2][32];
     double spike[32];                   // psy-1 spike / psy-3 Lsb
     double nsum[32];                    // psy noise sums per critical band
-    int16_t pnext[520];                 // psy-1 linked list
-    int16_t cand[520];                  // compacted candidate list
-    int16_t mk_idx[200];
+    uint32_t cinfo[TL_CAND_MAX];        // tone candidates (line | left-fail mask << 10)
+    int16_t conf_c[TL_TONE_MAX];        // confirmed tones: line | variant << 12 | erased << 13
+    int16_t conf_nxt[TL_TONE_MAX];      // psy-1: chain links between confirmed tones
+    int16_t tlist[TL_TONE_MAX];         // psy-1: chain order
     int16_t ncentre[32];
     uint8_t ptype[520];
     uint8_t scf[2][3][32];
@@ -122,6 +149,7 @@ struct TlWaveLds {
     uint8_t minidx[2][32];
     uint8_t xpad[TL_MAX_XPAD];
 };
+
 
 // ------------------------------------------------------------------------------------------
 TL_FN double tl_add_db(const double *TL_RESTRICT dbtable, double a, double b)
@@ -239,21 +267,32 @@ TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, int ch)
 }
 
 // ------------------------------------------------------------------------------------------
+// Candidate record used by the tone labelling of psy 1 and psy 3: bits 0-8 line index,
+// bits 10.. = "left neighbour j fails" for j = 2.. (bit 10 + j - 2).  Only candidates whose RIGHT
+// neighbours pass are recorded: the right side of a candidate is never touched by an earlier tone
+// (the erasure reach of every earlier tone ends below the candidate), so that half of the test can be
+// decided in parallel from the original spectrum; the left half depends on which earlier candidates
+// were confirmed and is resolved by a short wave-uniform walk over the records.
+
+TL_FN int tl_run_psy1(int c) { return (c < 3 || c > 500) ? 0 : c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 12; }   // psycho_1.c:289-298
+TL_FN int tl_run_psy3(int c) { return c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 12; }                            // psycho_3.c:212-215
+
 // psy model 1 (psycho_1.c:22-87, :215-581) for channel `ch`; result in w.smr[ch][0..sblimit).
-TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *TL_RESTRICT C, int ch, long long *sp)
+TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+                   const TlConfig *TL_RESTRICT C, int ch, long long *sp)
 {
     const double *energy = w.u.fft;
-    const double *db = T->dbtable;
+    const double *db = B->dbtable;
     TL_STAMP(sp, 0);
     tl_psy_spectrum(w, T, ch);
     TL_STAMP(sp, 1);
 
-    // power density spectrum + list reset (psycho_1.c:241-248); spike (psycho_1.c:252-257)
+    // power density spectrum (psycho_1.c:241-248); spike (psycho_1.c:252-257)
     TL_LANES_BEGIN
     for (int i = lane; i < 512; i += 64) {
         double e = energy[i];
         w.px[i] = e < 1E-20 ? -200.0 + TL_POWERNORM : 10 * tl_log10(e) + TL_POWERNORM;
-        w.pnext[i] = TL_STOP; w.ptype[i] = 0;
+        w.ptype[i] = 0;
     }
     if (lane < 32) {
         double sum = 1E-20;
@@ -262,78 +301,104 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
     }
     TL_LANES_END
 
-    // tonal candidates = local maxima 2..499, compacted in ascending order (psycho_1.c:274-284)
+    // ---- tonal components (psycho_1.c:267-340) ----
+    // (1) local maxima 2..499 whose right-hand neighbours pass the 7 dB test, compacted ascending
     int ncand = 0;
-    for (int c = 0; c < 8; c++) {
-        PV(bool, isc);
+    for (int c8 = 0; c8 < 8; c8++) {
+        PV(bool, isc); PV(uint32_t, rec);
         TL_LANES_BEGIN
-        int i = 64 * c + lane;
-        L(isc) = (i >= 2 && i < 500) && (w.px[i] > w.px[i - 1] && w.px[i] >= w.px[i + 1]);
-        TL_LANES_END
-        uint64_t m = TL_BALLOT(isc);
-        TL_LANES_BEGIN
-        if ((m >> lane) & 1ull) {
-            int pos = ncand + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-            w.cand[pos] = (int16_t)(64 * c + lane);
+        const int i = 64 * c8 + lane;
+        bool cnd = (i >= 2 && i < 500) && (w.px[i] > w.px[i - 1] && w.px[i] >= w.px[i + 1]);
+        uint32_t r = 0;
+        if (cnd) {
+            const int run = tl_run_psy1(i);
+            const double max = w.px[i] - 7;
+            for (int j = 2; j <= run; j++) {
+                if (max < w.px[i + j]) cnd = false;
+                if (max < w.px[i - j]) r |= 1u << (10 + j - 2);
+            }
+            r |= (uint32_t)i;
         }
+        L(isc) = cnd; L(rec) = r;
+        TL_LANES_END
+        const uint64_t m = TL_BALLOT(isc);
+        TL_LANES_BEGIN
+        if ((m >> lane) & 1ull) w.cinfo[ncand + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = L(rec);
         TL_LANES_END
         ncand += __builtin_popcountll(m);
     }
+    TL_STAMP(sp, 2);
+    // (2) wave-uniform walk: which candidates become tones.  State of the reference's list walk that
+    //     matters: the last confirmed tone (`last`), its erasure reach R = last + run(last), and the
+    //     chain bookkeeping (last_but_one relinking, psycho_1.c:313-316).
+    int nconf = 0;
+    {
+        int last = -1, run_last = 0, R = -1, last_var = 0;
+        for (int k = 0; k < ncand; k++) {
+            const uint32_t info = w.cinfo[k];
+            const int c = (int)(info & 511u);
+            if (last >= 0 && c - last <= run_last) continue;          // unlinked by the help loop, psycho_1.c:309-312
+            const int run = tl_run_psy1(c);
+            bool ok = true;
+            if (last < 0) { if (info >> 10) ok = false; }
+            else {
+                // neighbours c-j <= R were erased to DBMIN by `last` (they pass), except `last` itself,
+                // which carries its summed level; neighbours above R (or below last-run_last) are original
+                uint32_t orig = 0;
+                for (int j = 2; j <= run; j++) { const int q = c - j; if (q > R || q < last - run_last) orig |= 1u << (j - 2); }
+                if ((info >> 10) & orig) ok = false;
+                if (ok && c - last >= 2 && c - last <= run) {
+                    const double xl = tl_add_db(db, w.px[last], tl_add_db(db, last_var ? TL_DBMIN : w.px[last - 1], w.px[last + 1]));
+                    if (w.px[c] - 7 < xl) ok = false;
+                }
+            }
+            if (!ok) continue;                                        // rejected: only unlinked, psycho_1.c:330-338
+            // confirmed.  Its left neighbour c-1 was erased iff it is exactly the end of `last`'s reach.
+            const int var = (last >= 0 && run_last >= 1 && c - 1 == R) ? 1 : 0;
+            if (nconf < TL_TONE_MAX) {
+                const int i = nconf++;
+                w.conf_c[i] = (int16_t)(c | (var << 12));
+                w.conf_nxt[i] = TL_LAST;
+                if (i > 0) {
+                    if (c - last <= run) {                            // erases the previous tone, psycho_1.c:313-316,322-326
+                        w.conf_nxt[i - 1] = TL_STOP;
+                        w.conf_c[i - 1] = (int16_t)(w.conf_c[i - 1] | (1 << 13));
+                        if (i >= 2) w.conf_nxt[i - 2] = (int16_t)i;
+                    } else w.conf_nxt[i - 1] = (int16_t)i;
+                }
+            }
+            last = c; run_last = run; R = c + run; last_var = var;
+        }
+        TL_SYNC();
+    }
+    // (3) levels of the confirmed tones from the still-original spectrum (psycho_1.c:317-321)
     TL_LANES_BEGIN
-    for (int k = lane; k < ncand; k += 64) {
-        int i = w.cand[k];
-        w.ptype[i] = TL_T_TONE;
-        w.pnext[i] = (int16_t)(k + 1 < ncand ? w.cand[k + 1] : TL_LAST);
+    for (int i = lane; i < nconf; i += 64) {
+        const int cc = w.conf_c[i], c = cc & 511, var = (cc >> 12) & 1;
+        w.tone_x[i] = tl_add_db(db, w.px[c], tl_add_db(db, var ? TL_DBMIN : w.px[c - 1], w.px[c + 1]));
     }
     TL_LANES_END
-
-    TL_STAMP(sp, 2);
-    // sequential tone confirmation (psycho_1.c:285-339); wave-uniform serial walk
-    int tone = TL_LAST, noise = 0;
-    {
-        int last = TL_LAST, last_but_one = TL_LAST;
-        int first = ncand ? w.cand[0] : TL_LAST;
-        while (first != TL_LAST && first != TL_STOP) {
-            int run;
-            if (first < 3 || first > 500) run = 0;
-            else if (first < 63) run = 2;
-            else if (first < 127) run = 3;
-            else if (first < 255) run = 6;
-            else run = 12;
-            double max = w.px[first] - 7;
-            bool ok = true;
-            for (int j = 2; j <= run; j++)
-                if (max < w.px[first - j] || max < w.px[first + j]) { ok = false; break; }
-            if (ok) {
-                int help = first;
-                if (tone == TL_LAST) tone = first;
-                while (w.pnext[help] != TL_LAST && (w.pnext[help] - first) <= run) help = w.pnext[help];
-                help = w.pnext[help];
-                w.pnext[first] = (int16_t)help;
-                if ((first - last) <= run) { if (last_but_one != TL_LAST) w.pnext[last_but_one] = (int16_t)first; }
-                if (first > 1 && first < 500) {
-                    double tmp = tl_add_db(db, w.px[first - 1], w.px[first + 1]);
-                    w.px[first] = tl_add_db(db, w.px[first], tmp);
-                }
-                for (int j = 1; j <= run; j++) {
-                    w.px[first - j] = w.px[first + j] = TL_DBMIN;
-                    w.pnext[first - j] = w.pnext[first + j] = TL_STOP;
-                    w.ptype[first - j] = w.ptype[first + j] = 0;
-                }
-                last_but_one = last; last = first; first = w.pnext[first];
-            } else {
-                w.ptype[first] = 0;
-                if (last != TL_LAST) w.pnext[last] = w.pnext[first];
-                int ll = first;
-                first = w.pnext[first];
-                w.pnext[ll] = TL_STOP;
-            }
-            TL_SYNC();
-        }
+    TL_LANES_BEGIN
+    for (int i = lane; i < nconf; i += 64) { const int c = w.conf_c[i] & 511; w.px[c] = w.tone_x[i]; w.ptype[c] = TL_T_TONE; }
+    TL_LANES_END
+    // (4) erasures (psycho_1.c:322-326); a tone erased by its successor ends up DBMIN / not TONE
+    TL_LANES_BEGIN
+    for (int i = lane; i < nconf; i += 64) {
+        const int c = w.conf_c[i] & 511, run = tl_run_psy1(c);
+        for (int j = 1; j <= run; j++) { w.px[c - j] = TL_DBMIN; w.px[c + j] = TL_DBMIN; w.ptype[c - j] = 0; w.ptype[c + j] = 0; }
     }
-
+    TL_LANES_END
+    // (5) the tone list in chain order (psycho_1.c list head `*tone`): walk the links, then decimate
+    //     in parallel (psycho_1.c:416-428): drop erased tones and tones below the threshold in quiet
+    int nlist = 0;
+    {
+        int i = nconf ? 0 : TL_LAST, guard = 0;
+        while (i != TL_LAST && i != TL_STOP && guard++ < TL_TONE_MAX) { w.tlist[nlist++] = (int16_t)i; i = w.conf_nxt[i]; }
+        TL_SYNC();
+    }
     TL_STAMP(sp, 3);
-    // noise components: one lane per critical band (psycho_1.c:356-376)
+
+    // ---- noise components: one lane per critical band (psycho_1.c:356-376) ----
     const int nbands = C->p1_ncb - 1;
     TL_LANES_BEGIN
     if (lane < nbands) {
@@ -351,69 +416,152 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
             double index = weight * tl_pow10(-0.1 * sum);
             centre = lo + (int)(index * (double)(hi - lo));
         }
+        centre = centre < 1 ? 1 : centre > 510 ? 510 : centre;     // out-of-range only on non-finite input (UB in the reference)
         if (w.ptype[centre] == TL_T_TONE) { if (w.ptype[centre + 1] == TL_T_TONE) centre++; else centre--; }
         w.nsum[lane] = sum; w.ncentre[lane] = (int16_t)centre;
     }
     TL_LANES_END
-    {   // link in band order (psycho_1.c:390-398)
-        int last = TL_LAST;
-        for (int i = 0; i < nbands; i++) {
-            int centre = w.ncentre[i];
-            if (last == TL_LAST) noise = centre;
-            else { w.pnext[centre] = TL_LAST; w.pnext[last] = (int16_t)centre; }
-            w.px[centre] = w.nsum[i]; w.ptype[centre] = TL_T_NOISE; last = centre;
-        }
-        TL_SYNC();
-    }
-
-    TL_STAMP(sp, 4);
-    // decimation (psycho_1.c:409-470), then compaction of the surviving maskers
+    // The reference keeps tones and noise components in ONE linked list field (power[].next).  The two
+    // chains only interact when the head of the tone chain is a tone that was erased by its successor
+    // (psycho_1.c:313-316 with last_but_one == LAST): its line is no longer TONE, so a noise centre may
+    // land on it and splice the noise chain into the tone chain.  That (rare) case is replayed pointer by
+    // pointer below; otherwise the chains are independent and are processed in parallel.
+    const bool dead_head = nconf > 0 && ((w.conf_c[0] >> 13) & 1);
+    const uint8_t *map = C->p1_map;
     int ntone = 0, nnoise = 0;
-    {
-        const uint8_t *map = C->p1_map;
-        int i = tone, old = TL_STOP, guard = 0;
-        while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
-            if (w.px[i] < C->p1_hear[map[i]]) {
-                w.ptype[i] = 0; w.px[i] = TL_DBMIN;
-                if (old == TL_STOP) tone = w.pnext[i]; else w.pnext[old] = w.pnext[i];
-            } else old = i;
-            i = w.pnext[i];
+    if (dead_head) {
+        int16_t *pnext = (int16_t *)w.cinfo;                // candidate records are dead by now
+        TL_LANES_BEGIN
+        for (int i = lane; i < 512; i += 64) pnext[i] = TL_STOP;
+        TL_LANES_END
+        TL_LANES_BEGIN
+        for (int i = lane; i < nconf; i += 64) {
+            const int nx = w.conf_nxt[i];
+            pnext[w.conf_c[i] & 511] = (int16_t)(nx >= 0 ? (w.conf_c[nx] & 511) : nx);
         }
-        i = noise; old = TL_STOP; guard = 0;
-        while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
-            if (w.px[i] < C->p1_hear[map[i]]) {
-                w.ptype[i] = 0; w.px[i] = TL_DBMIN;
-                if (old == TL_STOP) noise = w.pnext[i]; else w.pnext[old] = w.pnext[i];
-            } else old = i;
-            i = w.pnext[i];
+        TL_LANES_END
+        int tone = w.conf_c[0] & 511, noise = 0;
+        {   // noise chain in band order (psycho_1.c:390-398)
+            int last = TL_LAST;
+            for (int i = 0; i < nbands; i++) {
+                const int centre = w.ncentre[i];
+                if (last == TL_LAST) noise = centre;
+                else { pnext[centre] = TL_LAST; pnext[last] = (int16_t)centre; }
+                w.px[centre] = w.nsum[i]; w.ptype[centre] = TL_T_NOISE; last = centre;
+            }
         }
-        i = tone; old = TL_STOP; guard = 0;
-        while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
-            int nx = w.pnext[i];
-            if (nx == TL_LAST) break;
-            if (C->p1_bark[map[nx]] - C->p1_bark[map[i]] < 0.5) {
-                if (w.px[nx] > w.px[i]) {
-                    if (old == TL_STOP) tone = nx; else w.pnext[old] = (int16_t)nx;
-                    w.ptype[i] = 0; w.px[i] = TL_DBMIN; i = nx;
-                } else {
-                    w.ptype[nx] = 0; w.px[nx] = TL_DBMIN;
-                    w.pnext[i] = w.pnext[nx]; old = i;
-                }
-            } else { old = i; i = nx; }
-        }
-        guard = 0;
-        for (int t = tone; t != TL_LAST && t != TL_STOP && ntone < 180 && guard++ < 600; t = w.pnext[t]) {
-            w.mk_x[ntone] = w.px[t]; w.mk_bark[ntone] = C->p1_bark[map[t]]; ntone++;
-        }
-        guard = 0;
-        for (int t = noise; t != TL_LAST && t != TL_STOP && ntone + nnoise < 200 && guard++ < 600; t = w.pnext[t]) {
-            w.mk_x[ntone + nnoise] = w.px[t]; w.mk_bark[ntone + nnoise] = C->p1_bark[map[t]]; nnoise++;
+        {   // psycho_1.c:409-470 verbatim on the shared links
+            int i = tone, old = TL_STOP, guard = 0;
+            while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
+                if (w.px[i] < C->p1_hear[map[i]]) {
+                    w.ptype[i] = 0; w.px[i] = TL_DBMIN;
+                    if (old == TL_STOP) tone = pnext[i]; else pnext[old] = pnext[i];
+                } else old = i;
+                i = pnext[i];
+            }
+            i = noise; old = TL_STOP; guard = 0;
+            while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
+                if (w.px[i] < C->p1_hear[map[i]]) {
+                    w.ptype[i] = 0; w.px[i] = TL_DBMIN;
+                    if (old == TL_STOP) noise = pnext[i]; else pnext[old] = pnext[i];
+                } else old = i;
+                i = pnext[i];
+            }
+            i = tone; old = TL_STOP; guard = 0;
+            while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
+                const int nx = pnext[i];
+                if (nx == TL_LAST) break;
+                if (nx == TL_STOP) break;                     // (the reference would index power[-100]; never reached in practice)
+                if (C->p1_bark[map[nx]] - C->p1_bark[map[i]] < 0.5) {
+                    if (w.px[nx] > w.px[i]) {
+                        if (old == TL_STOP) tone = nx; else pnext[old] = (int16_t)nx;
+                        w.ptype[i] = 0; w.px[i] = TL_DBMIN; i = nx;
+                    } else {
+                        w.ptype[nx] = 0; w.px[nx] = TL_DBMIN;
+                        pnext[i] = pnext[nx]; old = i;
+                    }
+                } else { old = i; i = nx; }
+            }
+            guard = 0;
+            for (int t = tone; t != TL_LAST && t != TL_STOP && ntone < TL_MASKER_MAX - 32 && guard++ < 600; t = pnext[t]) {
+                w.mk_x[ntone] = w.px[t]; w.mk_bark[ntone] = C->p1_bark[map[t]]; ntone++;
+            }
+            guard = 0;
+            for (int t = noise; t != TL_LAST && t != TL_STOP && ntone + nnoise < TL_MASKER_MAX && guard++ < 600; t = pnext[t]) {
+                w.mk_x[ntone + nnoise] = w.px[t]; w.mk_bark[ntone + nnoise] = C->p1_bark[map[t]]; nnoise++;
+            }
         }
         TL_SYNC();
-    }
+    } else {
+    // band order: a later band overwrites an earlier one that chose the same line (psycho_1.c:390-398)
+    for (int i = 0; i < nbands; i++) { const int centre = w.ncentre[i]; w.px[centre] = w.nsum[i]; w.ptype[centre] = TL_T_NOISE; }
+    TL_SYNC();
+    TL_STAMP(sp, 4);
 
+    // ---- decimation (psycho_1.c:409-470) ----
+    {
+        // tones: keep if not erased and not below the threshold in quiet (order preserved)
+        for (int base = 0; base < nlist; base += 64) {
+            PV(bool, keep); PV(double, kx); PV(double, kb);
+            TL_LANES_BEGIN
+            bool kp = false; double x = 0, bk = 0;
+            if (base + lane < nlist) {
+                const int cc = w.conf_c[w.tlist[base + lane]], c = cc & 511;
+                x = w.px[c]; bk = C->p1_bark[map[c]];
+                kp = !((cc >> 13) & 1) && !(x < C->p1_hear[map[c]]);
+            }
+            L(keep) = kp; L(kx) = x; L(kb) = bk;
+            TL_LANES_END
+            const uint64_t m = TL_BALLOT(keep);
+            TL_LANES_BEGIN
+            if ((m >> lane) & 1ull) {
+                const int pos = ntone + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                w.mk_x[pos] = L(kx); w.mk_bark[pos] = L(kb);
+            }
+            TL_LANES_END
+            ntone += __builtin_popcountll(m);
+        }
+        // tones closer than 0.5 bark: keep the stronger (psycho_1.c:443-469), sequential over the survivors
+        {
+            int n = 0;                    // compacted in place: entries [0,n) are final, `i` is the current survivor
+            if (ntone > 0) {
+                double xi = w.mk_x[0], bi = w.mk_bark[0];
+                for (int q = 1; q < ntone; q++) {
+                    const double xn = w.mk_x[q], bn = w.mk_bark[q];
+                    if (bn - bi < 0.5) {
+                        if (xn > xi) { xi = xn; bi = bn; }           // drop i, continue from next
+                    } else { w.mk_x[n] = xi; w.mk_bark[n] = bi; n++; xi = xn; bi = bn; }
+                }
+                w.mk_x[n] = xi; w.mk_bark[n] = bi; n++;
+            }
+            ntone = n;
+            TL_SYNC();
+        }
+        // noise: band order, keep if not below the threshold in quiet (psycho_1.c:429-442)
+        PV(bool, keepn); PV(double, nx); PV(double, nb);
+        TL_LANES_BEGIN
+        bool kp = false; double x = 0, bk = 0;
+        if (lane < nbands) {
+            const int c = w.ncentre[lane];
+            x = w.px[c]; bk = C->p1_bark[map[c]];
+            kp = !(x < C->p1_hear[map[c]]);
+        }
+        L(keepn) = kp; L(nx) = x; L(nb) = bk;
+        TL_LANES_END
+        const uint64_t mn = TL_BALLOT(keepn);
+        TL_LANES_BEGIN
+        if ((mn >> lane) & 1ull) {
+            const int pos = ntone + __builtin_popcountll(mn & ((1ull << lane) - 1ull));
+            w.mk_x[pos] = L(nx); w.mk_bark[pos] = L(nb);
+        }
+        TL_LANES_END
+        nnoise = __builtin_popcountll(mn);
+    }
+    }
     TL_STAMP(sp, 5);
-    // individual + global masking thresholds on the table lines (psycho_1.c:480-532)
+
+    TL_DBG_DUMP("psy1", ch, ntone, nnoise, w.mk_x, w.mk_bark);
+    // ---- individual + global masking thresholds on the table lines (psycho_1.c:480-532) ----
     const int sub = C->p1_sub;
     TL_LANES_BEGIN
     for (int k = 1 + lane; k < sub; k += 64) {
@@ -440,9 +588,9 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
         w.ltg[k] = x;
     }
     TL_LANES_END
-
     TL_STAMP(sp, 6);
-    // minimum per subband (psycho_1.c:541-559) and SMR (psycho_1.c:568-581)
+
+    // ---- minimum per subband (psycho_1.c:541-559) and SMR (psycho_1.c:568-581) ----
     TL_LANES_BEGIN
     if (lane < C->sblimit) {
         double m;
@@ -461,12 +609,15 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
 
 // ------------------------------------------------------------------------------------------
 // psy model 3 (psycho_3.c:71-432) for channel `ch`; result in w.smr[ch][0..32).
-TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *TL_RESTRICT C, int ch, long long *sp)
+TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+                   const TlConfig *TL_RESTRICT C, int ch, long long *sp)
 {
     const double *energy = w.u.fft;
-    const double *db = T->dbtable;
+    const double *db = B->dbtable;
     const double *bark = C->p3_bark, *ath = C->p3_ath;
+    TL_STAMP(sp, 0);
     tl_psy_spectrum(w, T, ch);
+    TL_STAMP(sp, 1);
 
     // power[1..512] (psycho_3.c:152-160); power[0] is an uninitialised slot in the reference, pinned
     // to 0.0 (oracle/mp2_oracle.c:psy3_run)
@@ -485,47 +636,90 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
         w.spike[lane] = xmax > val ? xmax : val;
     }
     TL_LANES_END
-    // local maxima, compacted ascending (psycho_3.c:195-202); pnext doubles as tonelabel, ptype as noiselabel
+    // ---- tone labelling (psycho_3.c:186-247) ----
+    // (1) local maxima 2..499 whose right-hand neighbours are >= 7 dB down, compacted ascending
     int ncand = 0;
-    for (int c = 0; c < 8; c++) {
-        PV(bool, isc);
+    for (int c8 = 0; c8 < 8; c8++) {
+        PV(bool, isc); PV(uint32_t, rec);
         TL_LANES_BEGIN
-        int i = 64 * c + lane;
-        L(isc) = (i >= 2 && i < 500) && (w.px[i] > w.px[i - 1] && w.px[i] > w.px[i + 1]);
-        w.ptype[i] = 0;
-        if (c == 7 && lane == 0) w.ptype[512] = 0;
-        TL_LANES_END
-        uint64_t m = TL_BALLOT(isc);
-        TL_LANES_BEGIN
-        if ((m >> lane) & 1ull) {
-            int pos = ncand + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-            w.cand[pos] = (int16_t)(64 * c + lane);
+        const int i = 64 * c8 + lane;
+        bool cnd = (i >= 2 && i < 500) && (w.px[i] > w.px[i - 1] && w.px[i] > w.px[i + 1]);
+        uint32_t r = 0;
+        if (cnd) {
+            const int sr = tl_run_psy3(i);
+            const double pk = w.px[i];
+            for (int j = 2; j <= sr; j++) {
+                if ((pk - w.px[i + j]) < 7.0) cnd = false;
+                if ((pk - w.px[i - j]) < 7.0) r |= 1u << (10 + j - 2);
+            }
+            r |= (uint32_t)i;
         }
+        L(isc) = cnd; L(rec) = r;
+        TL_LANES_END
+        const uint64_t m = TL_BALLOT(isc);
+        TL_LANES_BEGIN
+        if ((m >> lane) & 1ull) w.cinfo[ncand + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = L(rec);
         TL_LANES_END
         ncand += __builtin_popcountll(m);
     }
-    // sequential tone labelling with neighbour erasure (psycho_3.c:212-247)
-    int ntone = 0;
-    for (int q = 0; q < ncand; q++) {
-        int k = w.cand[q];
-        int sr = k < 63 ? 2 : k < 127 ? 3 : k < 255 ? 6 : 12;
-        double pk = w.px[k];
-        bool tonal = true;
-        for (int j = -sr; j <= sr; j++)
-            if ((j > 1 || j < -1) && (pk - w.px[k + j]) < 7.0) tonal = false;
-        if (tonal) {
-            double temp = tl_add_db(db, w.px[k - 1], pk);
-            double xt = tl_add_db(db, temp, w.px[k + 1]);
-            for (int j = -sr; j <= sr; j++) w.px[k + j] = TL_DBMIN;
-            if (!(xt < ath[k]) && ntone < 180) {               // decimation psycho_3.c:321-326
-                w.mk_x[ntone] = xt; w.mk_bark[ntone] = bark[k]; ntone++;
-            }
-            TL_SYNC();
+    TL_STAMP(sp, 2);
+    // (2) wave-uniform walk.  A confirmed tone k erases lines k-sr..k+sr (itself included) to DBMIN
+    //     (psycho_3.c:243-244); a later maximum inside that reach R has power DBMIN and always fails,
+    //     one above R sees erased left neighbours (always >= 7 dB down) and original ones beyond.
+    int nconf = 0;
+    {
+        int R = -1;
+        for (int q = 0; q < ncand; q++) {
+            const uint32_t info = w.cinfo[q];
+            const int k = (int)(info & 511u);
+            if (k <= R) continue;
+            const int sr = tl_run_psy3(k);
+            uint32_t orig = 0;
+            for (int j = 2; j <= sr; j++) if (k - j > R) orig |= 1u << (j - 2);
+            if ((info >> 10) & orig) continue;
+            if (nconf < TL_TONE_MAX) w.conf_c[nconf++] = (int16_t)(k | ((k - 1 <= R) ? (1 << 12) : 0));
+            R = k + sr;
         }
+        TL_SYNC();
     }
-    // noise per critical band (psycho_3.c:264-304) + decimation (:313-320); one lane per band
-    const int nb = C->p3_cbands;
+    // (3) tone levels from the still-original spectrum (psycho_3.c:238-239), decimation against the
+    //     threshold in quiet (:321-326), compaction in ascending line order
+    int ntone = 0;
+    for (int base = 0; base < nconf; base += 64) {
+        PV(bool, keep); PV(double, kx); PV(double, kb);
+        TL_LANES_BEGIN
+        bool kp = false; double x = 0, bk = 0;
+        if (base + lane < nconf) {
+            const int cc = w.conf_c[base + lane], k = cc & 511;
+            const double temp = tl_add_db(db, (cc >> 12) & 1 ? TL_DBMIN : w.px[k - 1], w.px[k]);
+            x = tl_add_db(db, temp, w.px[k + 1]);
+            bk = bark[k];
+            kp = !(x < ath[k]);
+        }
+        L(keep) = kp; L(kx) = x; L(kb) = bk;
+        TL_LANES_END
+        const uint64_t m = TL_BALLOT(keep);
+        TL_LANES_BEGIN
+        if ((m >> lane) & 1ull) {
+            const int pos = ntone + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            w.mk_x[pos] = L(kx); w.mk_bark[pos] = L(kb);
+        }
+        TL_LANES_END
+        ntone += __builtin_popcountll(m);
+    }
+    // (4) erasures
     TL_LANES_BEGIN
+    for (int i = lane; i < nconf; i += 64) {
+        const int k = w.conf_c[i] & 511, sr = tl_run_psy3(k);
+        for (int j = -sr; j <= sr; j++) w.px[k + j] = TL_DBMIN;
+    }
+    TL_LANES_END
+    TL_STAMP(sp, 3);
+    // ---- noise per critical band (psycho_3.c:264-304) + decimation (:313-320); one lane per band ----
+    const int nb = C->p3_cbands;
+    PV(bool, keepn); PV(double, nx); PV(double, nbk);
+    TL_LANES_BEGIN
+    bool kp = false; double xn = 0, bk = 0;
     if (lane < nb) {
         const int lo = C->p3_cbidx[lane], hi = C->p3_cbidx[lane + 1];
         double sum = TL_DBMIN, esum = 0, cw = 0;
@@ -535,19 +729,23 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
         }
         // esum == 0: the reference indexes with (int)(0/0) and segfaults; defined as the band centre
         int centre = (sum <= TL_DBMIN || esum == 0) ? (lo + hi) / 2 : lo + (int)(cw / esum);
-        w.nsum[lane] = sum; w.ncentre[lane] = (int16_t)centre;
+        centre = centre < 1 ? 1 : centre > 512 ? 512 : centre;
+        xn = sum; bk = bark[centre];
+        kp = !(xn < ath[centre]);
+    }
+    L(keepn) = kp; L(nx) = xn; L(nbk) = bk;
+    TL_LANES_END
+    const uint64_t mn = TL_BALLOT(keepn);       // ascending line order == band order (centres stay in their band)
+    TL_LANES_BEGIN
+    if ((mn >> lane) & 1ull) {
+        const int pos = ntone + __builtin_popcountll(mn & ((1ull << lane) - 1ull));
+        w.mk_x[pos] = L(nx); w.mk_bark[pos] = L(nbk);
     }
     TL_LANES_END
-    int nnoise = 0;
-    for (int i = 0; i < nb; i++) {          // ascending k order == band order (centres stay inside their band)
-        int k = w.ncentre[i];
-        double xn = w.nsum[i];
-        if (!(xn < ath[k]) && ntone + nnoise < 200) {
-            w.mk_x[ntone + nnoise] = xn; w.mk_bark[ntone + nnoise] = bark[k]; nnoise++;
-        }
-    }
-    TL_SYNC();
-    // thresholds on the 136 subsampled lines (psycho_3.c:339-406)
+    const int nnoise = __builtin_popcountll(mn);
+    TL_STAMP(sp, 4);
+    TL_STAMP(sp, 5);
+    // ---- thresholds on the 136 subsampled lines (psycho_3.c:339-406) ----
     TL_LANES_BEGIN
     for (int j = lane; j < 136; j += 64) {
         const int line = C->p3_subset[j];
@@ -575,12 +773,13 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
         w.ltg[j] = g;
     }
     TL_LANES_END
-    // minimum per subband + SMR (psycho_3.c:409-432)
+    TL_STAMP(sp, 6);
+    // ---- minimum per subband + SMR (psycho_3.c:409-432); subset rows of subband sb are contiguous ----
     TL_LANES_BEGIN
     if (lane < 32) {
         double m = 999999.9;
-        for (int j = 0; j < 136; j++)
-            if ((C->p3_subset[j] >> 4) == lane && m > w.ltg[j]) m = w.ltg[j];
+        const int j0 = C->p3_sb_j0[lane], n = C->p3_sb_n[lane];
+        for (int j = j0; j < j0 + n; j++) if (m > w.ltg[j]) m = w.ltg[j];
         w.smr[ch][lane] = w.spike[lane] - m;
     }
     TL_LANES_END
@@ -588,7 +787,8 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *
 
 // ------------------------------------------------------------------------------------------
 // One frame of one stream.  lane = 2*sb + ch owns subband sb of channel ch.
-TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlConfig *TL_RESTRICT C,
+TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+                           const TlConfig *TL_RESTRICT C,
                            TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, TlTaps *taps, long long *sp)
 {
     const int nch = C->nch, sblimit = C->sblimit;
@@ -651,7 +851,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         for (int gr = 0; gr < 3; gr++) {
             double m = fabs(L(smp)[gr * 12 + 11]);
             for (int j = 10; j >= 0; j--) { double t = fabs(L(smp)[gr * 12 + j]); if (t > m) m = t; }
-            unsigned idx = tl_sf_index(T->scalefactor, m);
+            unsigned idx = tl_sf_index(B->scalefactor, m);
             L(scf)[gr] = (int)idx;
             w.scf[c][gr][sb] = (uint8_t)idx;
             if (idx < lo) lo = idx;
@@ -685,7 +885,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             }
             TL_LANES_BEGIN
             const int c = lane & 1, sb = lane >> 1;
-            if (c == 0 && sb < sblimit) w.jscale[gr][sb] = (uint8_t)tl_sf_index(T->scalefactor, L(jm));
+            if (c == 0 && sb < sblimit) w.jscale[gr][sb] = (uint8_t)tl_sf_index(B->scalefactor, L(jm));
             TL_LANES_END
         }
     }
@@ -695,7 +895,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         const int c = lane & 1, sb = lane >> 1;
         for (int b = 0; b < 36; b++) taps->sb_sample[c][b / 12][b % 12][sb] = L(smp)[b];
         for (int gr = 0; gr < 3; gr++) { taps->scalar_pre[c][gr][sb] = w.scf[c][gr][sb]; if (c == 0) taps->j_scale[gr][sb] = C->mode0 == 1 && sb < sblimit ? w.jscale[gr][sb] : 0; }
-        taps->max_sc[c][sb] = (c < nch && sb < sblimit) ? T->scalefactor[w.minidx[c][sb]] : 1E-20;
+        taps->max_sc[c][sb] = (c < nch && sb < sblimit) ? B->scalefactor[w.minidx[c][sb]] : 1E-20;
         TL_LANES_END
     }
 
@@ -710,9 +910,9 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         }
         TL_LANES_END
     } else if (C->psy == 1) {
-        for (int ch = 0; ch < nch; ch++) tl_psy1(w, T, C, ch, sp ? sp + 8 + 8 * ch : nullptr);
+        for (int ch = 0; ch < nch; ch++) tl_psy1(w, T, B, C, ch, sp ? sp + 8 + 8 * ch : nullptr);
     } else {
-        for (int ch = 0; ch < nch; ch++) tl_psy3(w, T, C, ch, sp ? sp + 8 + 8 * ch : nullptr);
+        for (int ch = 0; ch < nch; ch++) tl_psy3(w, T, B, C, ch, sp ? sp + 8 + 8 * ch : nullptr);
     }
 
     TL_STAMP(sp, 3);
@@ -751,6 +951,19 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     const int lg_frame = C->frame_bytes;
     int adb = lg_frame * 8 - (C->dab_ext * 8 + (xpad_len ? xpad_len : 2) * 8);     // toolame.c:292-301
     int mode = C->mode0, mode_ext = C->mode_ext0, jsbound = C->jsbound0;
+    // per-lane constants of the allocation loops
+    PV(int, a_ln); PV(int, a_nbal); PV(int, a_sfs); PV(int, a_sfs_o); PV(double, a_smr); PV(double, a_smr_o);
+    TL_LANES_BEGIN
+    const int c = lane & 1, sb = lane >> 1;
+    const bool live = c < nch && sb < sblimit;
+    const int sfs[4] = {3, 2, 1, 2};
+    L(a_ln) = live ? C->line[sb] : 0;
+    L(a_nbal) = live ? C->nbal[sb] : 0;
+    L(a_sfs) = live ? 6 * sfs[w.scfsi[c][sb]] : 0;
+    L(a_sfs_o) = (live && nch == 2) ? 6 * sfs[w.scfsi[1 - c][sb]] : 0;
+    L(a_smr) = live ? w.smr[c][sb] : 0.0;
+    L(a_smr_o) = (live && nch == 2) ? w.smr[1 - c][sb] : 0.0;
+    TL_LANES_END
     if (C->mode0 == 1) {
         // try plain stereo, then jsbound 16, 12, 8, 4 (encode_new.c:803-819)
         mode = 0; mode_ext = 0; jsbound = sblimit;
@@ -761,22 +974,20 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             const int c = lane & 1, sb = lane >> 1;
             int bitsn = 0;
             if (sb < sblimit && c < (sb < jsbound ? nch : 1)) {
-                const int ln = C->line[sb];
-                const int maxAlloc = (1 << C->nbal[sb]) - 1;
+                const int ln = L(a_ln);
+                const int maxAlloc = (1 << L(a_nbal)) - 1;
                 int ba;
                 for (ba = 0; ba < maxAlloc - 1; ba++)
-                    if ((T->snr[T->step_index[ln][ba]] - w.smr[c][sb]) >= 0.0) break;
+                    if ((B->snr_line[ln][ba] - L(a_smr)) >= 0.0) break;
                 if (nch == 2 && sb >= jsbound)
                     for (; ba < maxAlloc - 1; ba++)
-                        if ((T->snr[T->step_index[ln][ba]] - w.smr[1 - c][sb]) >= 0.0) break;
+                        if ((B->snr_line[ln][ba] - L(a_smr_o)) >= 0.0) break;
                 if (ba > 0) {
-                    const int q = T->step_index[ln][ba];
-                    const int sfs[4] = {3, 2, 1, 2};
-                    int smpb = 12 * T->group[q] * T->bits[q], sel = 2, sc = 6 * sfs[w.scfsi[c][sb]];
-                    if (nch == 2 && sb >= jsbound) { sel += 2; sc += 6 * sfs[w.scfsi[1 - c][sb]]; }
-                    bitsn = smpb + sel + sc;
+                    int sel = 2, sc = L(a_sfs);
+                    if (nch == 2 && sb >= jsbound) { sel += 2; sc += L(a_sfs_o); }
+                    bitsn = B->bits12_line[ln][ba] + sel + sc;
                 }
-                bitsn += C->nbal[sb];                               // bbal share of this (sb,ch)
+                bitsn += L(a_nbal);                                 // bbal share of this (sb,ch)
             }
             L(need) = bitsn;
             TL_LANES_END
@@ -789,18 +1000,21 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         }
     }
     int adb_left;
-    {   // a_bit_allocation_new (encode_new.c:1078-1187)
-        PV(double, mnr); PV(int, used); PV(int, ba); PV(int, nbits);
+    {   // a_bit_allocation_new (encode_new.c:1078-1187).  Every lane carries its cell's mnr / used / ba and
+        // the price of its next step; one wave arg-min + one uniform comparison per iteration.
+        PV(double, mnr); PV(int, used); PV(int, ba); PV(int, nbits); PV(int, cost);
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
         const bool live = c < nch && sb < sblimit;
-        L(mnr) = live ? T->snr[0] - w.smr[c][sb] : 0.0;
+        L(mnr) = live ? B->snr_line[L(a_ln)][0] - L(a_smr) : 0.0;
         L(used) = live ? 0 : 2; L(ba) = 0;
-        L(nbits) = (sb < sblimit && c < (sb < jsbound ? nch : 1)) ? C->nbal[sb] : 0;
+        L(nbits) = (sb < sblimit && c < (sb < jsbound ? nch : 1)) ? L(a_nbal) : 0;
+        // first step of a cell: samples + scfsi + scalefactors (both channels above jsbound), :1139-1147
+        L(cost) = live ? B->bits12_line[L(a_ln)][1] + 2 + L(a_sfs) + ((nch == 2 && sb >= jsbound) ? 2 + L(a_sfs_o) : 0) : 0;
         TL_LANES_END
         const int bbal = TL_WAVE_SUM_I32(nbits);
-        int ad = adb - (bbal + 16 + 32);
-        int bspl = 0, bscf = 0, bsel = 0;
+        const int ad = adb - (bbal + 16 + 32);
+        int spent = 0;                                              // bspl + bscf + bsel
         for (int guard = 0; guard < 2048; guard++) {
             // maxmnr_new (encode_new.c:1061-1077): smallest mnr, first in (ch, sb) order
             PV(uint64_t, key);
@@ -816,45 +1030,24 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             const uint64_t hm = TL_BALLOT(hit);
             const uint64_t even = hm & 0x5555555555555555ull;       // ch 0 first, then ascending sb
             const int wl = __builtin_ctzll(even ? even : hm);
-            const int min_ch = wl & 1, min_sb = wl >> 1, oth = 1 - min_ch;
-            // everything below is wave-uniform (one (ch,sb) cell changes per iteration)
-            const int ln = C->line[min_sb];
-            int cur_ba, cur_used;
-#ifdef TL_EMULATE
-            cur_ba = ba[wl]; cur_used = used[wl];
-#else
-            cur_ba = __shfl(ba, wl, 64); cur_used = __shfl(used, wl, 64);
-#endif
-            const int qn = T->step_index[ln][cur_ba + 1];
-            int increment = 12 * T->group[qn] * T->bits[qn];
-            int scale = 0, seli = 0;
-            if (cur_used) {
-                const int qc = T->step_index[ln][cur_ba];
-                increment -= 12 * T->group[qc] * T->bits[qc];
-            } else {
-                const int sfs[4] = {3, 2, 1, 2};
-                seli = 2; scale = 6 * sfs[w.scfsi[min_ch][min_sb]];
-                if (nch == 2 && min_sb >= jsbound) { seli += 2; scale += 6 * sfs[w.scfsi[oth][min_sb]]; }
-            }
-            int new_ba = cur_ba, new_used;
-            if (ad >= bspl + bscf + bsel + seli + scale + increment) {
-                new_ba = cur_ba + 1;
-                bspl += increment; bscf += scale; bsel += seli;
-                new_used = (new_ba >= (1 << C->nbal[min_sb]) - 1) ? 2 : 1;
-            } else new_used = 2;
-            const double snr_new = T->snr[T->step_index[ln][new_ba]];
+            const int min_sb = wl >> 1;
+            const int wcost = TL_READLANE_I32(cost, wl);
+            const bool fits = ad >= spent + wcost;
+            if (fits) spent += wcost;
             const bool joint_pair = (min_sb >= jsbound && nch == 2);
             TL_LANES_BEGIN
-            const int c = lane & 1, sb = lane >> 1;
-            if (lane == wl) {
-                L(ba) = new_ba; L(used) = new_used;
-                if (new_ba != cur_ba) L(mnr) = snr_new - w.smr[c][sb];
-            } else if (joint_pair && sb == min_sb && c == oth) {
-                L(ba) = new_ba; L(used) = new_used; L(mnr) = snr_new - w.smr[c][sb];
+            if (lane == wl || (joint_pair && (lane ^ 1) == wl)) {
+                if (fits) {
+                    const int nba = L(ba) + 1;
+                    L(ba) = nba;
+                    L(mnr) = B->snr_line[L(a_ln)][nba] - L(a_smr);
+                    L(used) = (nba >= (1 << L(a_nbal)) - 1) ? 2 : 1;
+                    L(cost) = B->bits12_line[L(a_ln)][(nba + 1) & 15] - B->bits12_line[L(a_ln)][nba];
+                } else L(used) = 2;
             }
             TL_LANES_END
         }
-        adb_left = ad - (bspl + bscf + bsel);
+        adb_left = ad - spent;
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
         w.balloc[c][sb] = (uint8_t)((c < nch && sb < sblimit) ? L(ba) : 0);
@@ -935,7 +1128,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             if (ba) {
                 const int q = T->step_index[C->line[sb]][ba];
                 const bool joint = js && sb >= jsbound;
-                const double sfv = joint ? T->scalefactor[w.jscale[gr][sb]] : T->scalefactor[L(scf)[gr]];
+                const double sfv = joint ? B->scalefactor[w.jscale[gr][sb]] : B->scalefactor[L(scf)[gr]];
                 for (int x = 0; x < 3; x++) {
                     double s = L(smp)[gr * 12 + j0 + x];
                     if (joint) s = .5 * (s + L(oth)[x]);
@@ -965,9 +1158,18 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     // CRC-16 over header bits 16..31, bit_alloc and scfsi fields (crc.c:12-41); one lane, bit-serial
     unsigned crc16 = 0xffff;
     {
-        for (int p = 16; p < 32; p++) crc16 = tl_crc_upd(crc16, tl_get_bit(frame, p), 1, 0x8005, 0x8000);
-        for (int p = p_ba; p < p_scf; p++) crc16 = tl_crc_upd(crc16, tl_get_bit(frame, p), 1, 0x8005, 0x8000);
-        crc16 &= 0xffff;
+        // bits [16,32) of word 0, then bits [48, p_scf); one LDS read per 32-bit word
+        const int lastw = (p_scf - 1) >> 5;
+        for (int wi = 0; wi <= lastw; wi++) {
+            const uint32_t wv = (uint32_t)TL_UNI_I((int)frame[wi]);
+            const int lo = wi == 0 ? 16 : wi == 1 ? 16 : 0;                  // skip header bits 0..15 and the CRC field 32..47
+            const int hi = (wi == lastw) ? ((p_scf - 1) & 31) + 1 : 32;
+            for (int bit = lo; bit < hi; bit++) {
+                const unsigned d = (wv >> (31 - bit)) & 1u;
+                const unsigned fb = ((crc16 >> 15) ^ d) & 1u;
+                crc16 = ((crc16 << 1) & 0xffffu) ^ (fb ? 0x8005u : 0u);
+            }
+        }
     }
     // ScF-CRC (crc.c:58-97, toolame.c:527-542): lanes 0..dab_ext-1 each own one band group
     const int tail = lg_frame - 2 - C->dab_ext;                     // byte offset of the first ScF-CRC byte
@@ -1042,7 +1244,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
 
 // ------------------------------------------------------------------------------------------
 // A wave encodes `nframes` consecutive frames of stream `s`; state stays in LDS across frames.
-TL_FN void tl_encode_stream(TlWaveLds &w, const TlLaunch &A, int s)
+TL_FN void tl_encode_stream(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const TlLaunch &A, int s)
 {
     const TlTables *T = A.tables;
     const TlConfig *C = &A.configs[A.stream_cfg[s]];
@@ -1072,7 +1274,7 @@ TL_FN void tl_encode_stream(TlWaveLds &w, const TlLaunch &A, int s)
             for (int i = lane; i < xl; i += 64) w.xpad[i] = A.xpad[slot * TL_MAX_XPAD + i];
             TL_LANES_END
         }
-        tl_encode_frame(w, T, C, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, A.taps ? &A.taps[slot] : nullptr,
+        tl_encode_frame(w, T, B, C, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, A.taps ? &A.taps[slot] : nullptr,
                         A.stamps ? A.stamps + slot * 32 : nullptr);
         done++;
         TL_LANES_BEGIN

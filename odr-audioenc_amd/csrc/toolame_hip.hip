@@ -17,17 +17,25 @@
 
 static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 
-#define TL_WAVES_PER_BLOCK 1
+#define TL_WAVES_PER_BLOCK 4
 
 // One wavefront per stream: block = TL_WAVES_PER_BLOCK independent waves, no
 // block-level barrier anywhere; each wave keeps its stream's working set in its own LDS slice.
 __global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK) tl_encode_kernel(TlLaunch A)
 {
+    __shared__ TlBlockShared shared;                 // tables on dependent-load chains, one copy per workgroup
     __shared__ TlWaveLds lds[TL_WAVES_PER_BLOCK];
+    static_assert(sizeof(TlBlockShared) % 8 == 0, "copied as doubles");
+    {
+        const double *src = (const double *)&A.tables->shared;
+        double *dst = (double *)&shared;
+        for (int i = (int)threadIdx.x; i < (int)(sizeof(TlBlockShared) / 8); i += 64 * TL_WAVES_PER_BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();                                 // the only workgroup barrier: the waves are independent from here on
     const int wave = (int)(threadIdx.x >> 6);
     const int s = (int)blockIdx.x * TL_WAVES_PER_BLOCK + wave;
     if (s >= A.nstreams) return;
-    tl_encode_stream(lds[wave], A, s);
+    tl_encode_stream(lds[wave], &shared, A, s);
 }
 
 // pending frame (big-endian words in the stream state) -> bytes

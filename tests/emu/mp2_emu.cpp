@@ -51,7 +51,7 @@ int emu_encode(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, co
     A.state = e->state.data(); A.pcm = pcm; A.xpad = xpad; A.xpad_len = xpad_len; A.out = out; A.taps = taps;
     A.nstreams = (int)e->state.size(); A.nframes = nframes; A.out_stride = out_stride;
     static thread_local TlWaveLds w;
-    for (int s = 0; s < A.nstreams; s++) tl_encode_stream(w, A, s);
+    for (int s = 0; s < A.nstreams; s++) tl_encode_stream(w, &e->tables.shared, A, s);
     return 0;
 }
 int emu_pending(void *h, int s, uint8_t *out)
