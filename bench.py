@@ -94,27 +94,22 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import odr_audioenc_amd as M
+    import odr_audioenc_amd.shard as shard
     from pcmgen import gen_pcm
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, local_rank, world, dist = shard.init_from_env("nccl")      # "nccl" is RCCL on ROCm
 
     S, F = args.streams, args.frames_per_step
     # stream i of rank r uses seed r*S + i; two alternating PCM buffers = frames [0,F) and [F,2F)
     t0 = time.time()
     host = np.empty((2 * F, S, 2, 1152), dtype=np.int16)
-    for s in range(S):
-        host[:, s] = gen_pcm(rank * S + s, 0, 0, 2 * F)
+    for k, sid in enumerate(shard.weak_stream_ids(rank, S)):
+        host[:, k] = gen_pcm(sid, 0, 0, 2 * F)
     pcm = [torch.from_numpy(host[:F].copy()).cuda(), torch.from_numpy(host[F:].copy()).cuda()]
     del host
     batch = M.Batch([M.StreamConfig(samplerate=FS, mode=args.mode, bitrate=KBPS, psy_model=args.psy)] * S, device=local_rank)
@@ -124,29 +119,20 @@ def main():
     def step(i):
         batch.encode_device(pcm[i & 1].data_ptr(), F, out.data_ptr(), stream=stream.cuda_stream)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for i in range(args.warmup):
         step(i)
-    barrier()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t_start = time.perf_counter()
-    for i in range(args.steps):
-        evs[i][0].record(stream)
-        step(args.warmup + i)
-        evs[i][1].record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t_start
+
+    def timed():
+        for i in range(args.steps):
+            evs[i][0].record(stream)
+            step(args.warmup + i)
+            evs[i][1].record(stream)
+
+    # barrier + synchronize on both sides, MAX over ranks (shard.timed_region)
+    elapsed = shard.timed_region(dist, timed, device_sync=torch.cuda.synchronize, device="cuda")
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     last_ms = batch.last_kernel_ms()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # sanity: the frames are real frames (sync word + right length), never timed
     chk = out[1, :4].cpu().numpy()
@@ -156,6 +142,16 @@ def main():
         frames = world * S * F * args.steps
         value = frames / elapsed
         algo_bytes_per_launch = ALGO_BYTES_PER_FRAME * S * F
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh); only
+        # quoted when the committed measurement was taken on this very workload
+        traffic = None
+        try:
+            pm = json.load(open(ROOT / "profiles" / "pmc_traffic_latest.json"))
+            wl = pm["workload"]
+            if (wl["streams"], wl["frames_per_step"], wl["psy"], wl["mode"]) == (S, F, args.psy, args.mode):
+                traffic = pm["hbm_bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            pass
         achieved = algo_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         res = {
             "metric": "real-time stereo DAB MP2 streams sustained (frames/s) @128 kbps/48 kHz",
@@ -167,7 +163,7 @@ def main():
                        "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
             "realtime_streams": round(value / (FS / 1152.0), 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "tl_encode_kernel", "kernel_ms": round(kernel_ms, 4), "last_kernel_ms_hip_events": round(last_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch,
                          "note": "the path is fp64-VALU/LDS-latency bound, not HBM bound (SURVEY F9): compulsory traffic is "
@@ -180,7 +176,7 @@ def main():
         elif world > 1:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,73 @@
+"""Multi-GPU sharding of the encode path: streams are independent, so the unit of
+sharding is the stream and there is NO data-path collective.  One process per GPU; torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests) carries only the barrier
+and two scalars per measurement window (max elapsed time, total frames)."""
+import os
+import time
+
+
+def init_from_env(backend=None):
+    """-> (rank, local_rank, world, dist or None).  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return rank, local_rank, world, None
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if not dist.is_initialized():
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world, dist
+
+
+def strong_range(rank, world, total_streams):
+    """contiguous block [lo, hi) of `total_streams` owned by `rank` (strong scaling split)."""
+    return rank * total_streams // world, (rank + 1) * total_streams // world
+
+
+def weak_stream_ids(rank, streams_per_rank):
+    """global stream ids (= PCM seeds) of a rank when every rank owns `streams_per_rank` streams."""
+    return range(rank * streams_per_rank, (rank + 1) * streams_per_rank)
+
+
+def barrier(dist, device_sync=None):
+    if device_sync:
+        device_sync()
+    if dist is not None:
+        dist.barrier()
+    if device_sync:
+        device_sync()
+
+
+def timed_region(dist, fn, device_sync=None, device="cpu"):
+    """barrier + sync, run fn(), barrier + sync; returns MAX over ranks of the elapsed seconds."""
+    barrier(dist, device_sync)
+    t0 = time.perf_counter()
+    fn()
+    barrier(dist, device_sync)
+    elapsed = time.perf_counter() - t0
+    return reduce_max(dist, elapsed, device)
+
+
+def reduce_max(dist, value, device="cpu"):
+    if dist is None:
+        return float(value)
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def reduce_sum(dist, value, device="cpu"):
+    if dist is None:
+        return int(value)
+    import torch
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
