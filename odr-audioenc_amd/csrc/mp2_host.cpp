@@ -169,6 +169,9 @@ int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, 
         }
         for (int i = 1; i < C->p1_sub; i++)
             for (int j = C->p1_line[i - 1]; j <= C->p1_line[i]; j++) C->p1_map[j] = (uint8_t)i;
+        memset(C->p1_lineband, 255, sizeof C->p1_lineband);
+        for (int b = 0; b + 1 < C->p1_ncb; b++)
+            for (int j = C->p1_cbound[b]; j < C->p1_cbound[b + 1]; j++) C->p1_lineband[j] = (uint8_t)b;
         // resolve the sequential minimum-mask walk (psycho_1.c:541-559) into per-subband row ranges
         int j = 1;
         for (int sb = 0; sb < C->sblimit; sb++) {

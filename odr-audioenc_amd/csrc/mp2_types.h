@@ -57,6 +57,7 @@ struct TlConfig {
     double p1_bark[136];
     double p1_hear[136];
     uint8_t p1_map[520];
+    uint8_t p1_lineband[520];    // critical band of each FFT line (index into p1_cbound), 255 outside the bands
     int16_t p1_mm_j0[32];        // minimum-mask walk (psycho_1.c:541-559) resolved per subband:
     int16_t p1_mm_n[32];         //   first table row, number of rows (0 => use hear[sub-1])
     // psy model 3 (psycho_3.c:434-512)

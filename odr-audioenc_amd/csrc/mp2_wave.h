@@ -119,24 +119,23 @@ TL_FN int tld_exscan_i32(int v) {
 // ------------------------------------------------------------------------------------------
 // Per-wave LDS working set.
 #define TL_CAND_MAX 256              // local maxima with passing right side (<= 249)
+#define TL_FB_BATCH 3                // filterbank blocks per LDS round trip (36 = 12 x 3)
 #define TL_TONE_MAX 96               // confirmed tones per channel-frame (hard bound ~75: erasure spacing)
 #define TL_MASKER_MAX 128            // tones + noise components after decimation
 struct TlWaveLds {
-    int16_t pcm[2][TL_HIST + 1152];     // [history | this frame], planar
+    // Stage-exclusive 8 KB: [PCM history | frame] + filterbank scratch  ->  FHT buffer / energy (and, once the
+    // energies are dead, the masker lists and thresholds)  ->  the frame being packed.
     union {
-        struct { double y[2][64]; double yp[2][32]; } fb;     // filterbank stage
-        double fft[1024];                                     // psy stage: FHT buffer, then energy[0..512]
-        uint32_t frame[TL_MAX_FRAME_WORDS];                   // packing stage
+        struct { int16_t pcm[2][TL_HIST + 1152]; double yp[TL_FB_BATCH][2][32]; } fbk;
+        double fft[1024];
+        uint32_t frame[TL_MAX_FRAME_WORDS];
     } u;
     double px[520];                     // psy: power spectrum in dB
-    double ltg[136];                    // psy: thresholds on the subsampled lines
-    double mk_x[TL_MASKER_MAX];         // psy: compacted maskers (tones first, then noise)
-    double mk_bark[TL_MASKER_MAX];
-    double tone_x[TL_TONE_MAX];         // psy-1: summed level of each confirmed tone
+    double tone_x[TL_TONE_MAX];         // psy: summed level of each confirmed tone
     double smr[2][32];
     double spike[32];                   // psy-1 spike / psy-3 Lsb
     double nsum[32];                    // psy noise sums per critical band
-    uint32_t cinfo[TL_CAND_MAX];        // tone candidates (line | left-fail mask << 10)
+    uint32_t cinfo[TL_CAND_MAX];        // tone candidates (line | left-fail mask << 10); psy-1 slow path: links
     int16_t conf_c[TL_TONE_MAX];        // confirmed tones: line | variant << 12 | erased << 13
     int16_t conf_nxt[TL_TONE_MAX];      // psy-1: chain links between confirmed tones
     int16_t tlist[TL_TONE_MAX];         // psy-1: chain order
@@ -149,6 +148,11 @@ struct TlWaveLds {
     uint8_t minidx[2][32];
     uint8_t xpad[TL_MAX_XPAD];
 };
+// masker lists / thresholds live in the low half of the FHT buffer once the energies are no longer needed
+#define TL_MK_X(w) ((w).u.fft)                         /* [TL_MASKER_MAX] */
+#define TL_MK_BARK(w) ((w).u.fft + TL_MASKER_MAX)      /* [TL_MASKER_MAX] */
+#define TL_LTG(w) ((w).u.fft + 2 * TL_MASKER_MAX)      /* [136] */
+
 
 
 // ------------------------------------------------------------------------------------------
@@ -240,15 +244,20 @@ TL_FN void tl_fht_pass(double *x, int k, int twbase, const double (*TL_RESTRICT 
 
 // Hann window of samples [t-192, t+832) + FHT + energy (psycho_1.c:57-76,215-239, fft.c:1278-1293).
 // Leaves energy[0..512] in w.u.fft[0..512].
-TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, int ch)
+// A stream's PCM as the kernel sees it in HBM: this frame (planar [2][1152]) and the 480 samples per
+// channel that precede it (the stream state on the first frame of a launch, the previous input frame after).
+struct TlPcmView { const int16_t *cur; const int16_t *hist; int hist_stride; };
+
+TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPcmView &pv, int ch)
 {
     double *x = w.u.fft;
     TL_LANES_BEGIN
     for (int i = lane; i < 1024; i += 64) {
         int r = 0;
         for (int b = 0; b < 10; b++) r |= ((i >> b) & 1) << (9 - b);
-        // sample i of the analysis window = PCM index (TL_HIST - 192 + i) of [history | frame]
-        x[r] = ((double)w.pcm[ch][TL_HIST - 192 + i] / 32768) * T->hann[i];
+        // sample i of the analysis window: the last 192 samples of the history, then the first 832 of the frame
+        const int16_t v = i < 192 ? pv.hist[ch * pv.hist_stride + (TL_HIST - 192) + i] : pv.cur[ch * 1152 + (i - 192)];
+        x[r] = ((double)v / 32768) * T->hann[i];
     }
     TL_LANES_END
     TL_LANES_BEGIN tl_fht_pass_first(x, lane); TL_LANES_END
@@ -279,12 +288,12 @@ TL_FN int tl_run_psy3(int c) { return c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 1
 
 // psy model 1 (psycho_1.c:22-87, :215-581) for channel `ch`; result in w.smr[ch][0..sblimit).
 TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
-                   const TlConfig *TL_RESTRICT C, int ch, long long *sp)
+                   const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
 {
     const double *energy = w.u.fft;
     const double *db = B->dbtable;
     TL_STAMP(sp, 0);
-    tl_psy_spectrum(w, T, ch);
+    tl_psy_spectrum(w, T, pv, ch);
     TL_STAMP(sp, 1);
 
     // power density spectrum (psycho_1.c:241-248); spike (psycho_1.c:252-257)
@@ -398,18 +407,33 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     }
     TL_STAMP(sp, 3);
 
-    // ---- noise components: one lane per critical band (psycho_1.c:356-376) ----
+    // ---- noise components (psycho_1.c:356-376) ----
+    // the per-line weight terms are independent: computed line-parallel in place of the (now unneeded) energies
     const int nbands = C->p1_ncb - 1;
+    {
+        double *term = w.u.fft;
+        const int first = C->p1_cbound[0], end = C->p1_cbound[nbands];
+        TL_LANES_BEGIN
+        for (int j = first + lane; j < end; j += 64) {
+            const int bnd = C->p1_lineband[j];
+            const int lo = C->p1_cbound[bnd], hi = C->p1_cbound[bnd + 1];
+            term[j] = 1073741824 * energy[j] * (double)(j - lo) / (double)(hi - lo);
+        }
+        TL_LANES_END
+    }
+    // one lane per critical band: the dB-sum chain and the weight sum, both in ascending line order
     TL_LANES_BEGIN
     if (lane < nbands) {
+        const double *term = w.u.fft;
         const int lo = C->p1_cbound[lane], hi = C->p1_cbound[lane + 1];
         double weight = 0.0, sum = TL_DBMIN;
-        for (int j = lo; j < hi; j++)
-            if (w.ptype[j] != TL_T_TONE && w.px[j] != TL_DBMIN) {
-                sum = tl_add_db(db, w.px[j], sum);
-                weight += 1073741824 * energy[j] * (double)(j - lo) / (double)(hi - lo);
-                w.px[j] = TL_DBMIN;
+        for (int j = lo; j < hi; j++) {
+            const double p = w.px[j];
+            if (w.ptype[j] != TL_T_TONE && p != TL_DBMIN) {
+                sum = tl_add_db(db, p, sum);
+                weight += term[j];
             }
+        }
         int centre;
         if (sum <= TL_DBMIN) centre = (hi + lo) / 2;
         else {
@@ -421,15 +445,21 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         w.nsum[lane] = sum; w.ncentre[lane] = (int16_t)centre;
     }
     TL_LANES_END
+    // every non-tonal line inside the bands is consumed (set to DBMIN) by its band, psycho_1.c:363
+    TL_LANES_BEGIN
+    for (int j = C->p1_cbound[0] + lane; j < C->p1_cbound[nbands]; j += 64) if (w.ptype[j] != TL_T_TONE) w.px[j] = TL_DBMIN;
+    TL_LANES_END
     // The reference keeps tones and noise components in ONE linked list field (power[].next).  The two
     // chains only interact when the head of the tone chain is a tone that was erased by its successor
     // (psycho_1.c:313-316 with last_but_one == LAST): its line is no longer TONE, so a noise centre may
     // land on it and splice the noise chain into the tone chain.  That (rare) case is replayed pointer by
     // pointer below; otherwise the chains are independent and are processed in parallel.
+    TL_STAMP(sp, 4);
     const bool dead_head = nconf > 0 && ((w.conf_c[0] >> 13) & 1);
     const uint8_t *map = C->p1_map;
     int ntone = 0, nnoise = 0;
     if (dead_head) {
+        TL_DBG_DUMP("deadhead", ch, 0, 0, w.px, w.px);
         int16_t *pnext = (int16_t *)w.cinfo;                // candidate records are dead by now
         TL_LANES_BEGIN
         for (int i = lane; i < 512; i += 64) pnext[i] = TL_STOP;
@@ -484,11 +514,11 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
             }
             guard = 0;
             for (int t = tone; t != TL_LAST && t != TL_STOP && ntone < TL_MASKER_MAX - 32 && guard++ < 600; t = pnext[t]) {
-                w.mk_x[ntone] = w.px[t]; w.mk_bark[ntone] = C->p1_bark[map[t]]; ntone++;
+                TL_MK_X(w)[ntone] = w.px[t]; TL_MK_BARK(w)[ntone] = C->p1_bark[map[t]]; ntone++;
             }
             guard = 0;
             for (int t = noise; t != TL_LAST && t != TL_STOP && ntone + nnoise < TL_MASKER_MAX && guard++ < 600; t = pnext[t]) {
-                w.mk_x[ntone + nnoise] = w.px[t]; w.mk_bark[ntone + nnoise] = C->p1_bark[map[t]]; nnoise++;
+                TL_MK_X(w)[ntone + nnoise] = w.px[t]; TL_MK_BARK(w)[ntone + nnoise] = C->p1_bark[map[t]]; nnoise++;
             }
         }
         TL_SYNC();
@@ -496,7 +526,6 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     // band order: a later band overwrites an earlier one that chose the same line (psycho_1.c:390-398)
     for (int i = 0; i < nbands; i++) { const int centre = w.ncentre[i]; w.px[centre] = w.nsum[i]; w.ptype[centre] = TL_T_NOISE; }
     TL_SYNC();
-    TL_STAMP(sp, 4);
 
     // ---- decimation (psycho_1.c:409-470) ----
     {
@@ -516,7 +545,7 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
             TL_LANES_BEGIN
             if ((m >> lane) & 1ull) {
                 const int pos = ntone + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                w.mk_x[pos] = L(kx); w.mk_bark[pos] = L(kb);
+                TL_MK_X(w)[pos] = L(kx); TL_MK_BARK(w)[pos] = L(kb);
             }
             TL_LANES_END
             ntone += __builtin_popcountll(m);
@@ -525,14 +554,14 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         {
             int n = 0;                    // compacted in place: entries [0,n) are final, `i` is the current survivor
             if (ntone > 0) {
-                double xi = w.mk_x[0], bi = w.mk_bark[0];
+                double xi = TL_MK_X(w)[0], bi = TL_MK_BARK(w)[0];
                 for (int q = 1; q < ntone; q++) {
-                    const double xn = w.mk_x[q], bn = w.mk_bark[q];
+                    const double xn = TL_MK_X(w)[q], bn = TL_MK_BARK(w)[q];
                     if (bn - bi < 0.5) {
                         if (xn > xi) { xi = xn; bi = bn; }           // drop i, continue from next
-                    } else { w.mk_x[n] = xi; w.mk_bark[n] = bi; n++; xi = xn; bi = bn; }
+                    } else { TL_MK_X(w)[n] = xi; TL_MK_BARK(w)[n] = bi; n++; xi = xn; bi = bn; }
                 }
-                w.mk_x[n] = xi; w.mk_bark[n] = bi; n++;
+                TL_MK_X(w)[n] = xi; TL_MK_BARK(w)[n] = bi; n++;
             }
             ntone = n;
             TL_SYNC();
@@ -552,7 +581,7 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         TL_LANES_BEGIN
         if ((mn >> lane) & 1ull) {
             const int pos = ntone + __builtin_popcountll(mn & ((1ull << lane) - 1ull));
-            w.mk_x[pos] = L(nx); w.mk_bark[pos] = L(nb);
+            TL_MK_X(w)[pos] = L(nx); TL_MK_BARK(w)[pos] = L(nb);
         }
         TL_LANES_END
         nnoise = __builtin_popcountll(mn);
@@ -560,7 +589,7 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     }
     TL_STAMP(sp, 5);
 
-    TL_DBG_DUMP("psy1", ch, ntone, nnoise, w.mk_x, w.mk_bark);
+    TL_DBG_DUMP("psy1", ch, ntone, nnoise, TL_MK_X(w), TL_MK_BARK(w));
     // ---- individual + global masking thresholds on the table lines (psycho_1.c:480-532) ----
     const int sub = C->p1_sub;
     TL_LANES_BEGIN
@@ -568,24 +597,24 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         const double bk = C->p1_bark[k];
         double x = TL_DBMIN;
         for (int t = 0; t < ntone; t++) {
-            double dz = bk - w.mk_bark[t];
+            double dz = bk - TL_MK_BARK(w)[t];
             if (dz >= -3.0 && dz < 8.0) {
-                double px = w.mk_x[t];
-                double tmps = -1.525 - 0.275 * w.mk_bark[t] - 4.5 + px;
+                double px = TL_MK_X(w)[t];
+                double tmps = -1.525 - 0.275 * TL_MK_BARK(w)[t] - 4.5 + px;
                 x = tl_add_db(db, x, tmps + tl_mask_vf(dz, px));
             }
         }
         for (int t = ntone; t < ntone + nnoise; t++) {
-            double dz = bk - w.mk_bark[t];
+            double dz = bk - TL_MK_BARK(w)[t];
             if (dz >= -3.0 && dz < 8.0) {
-                double px = w.mk_x[t];
-                double tmps = -1.525 - 0.175 * w.mk_bark[t] - 0.5 + px;
+                double px = TL_MK_X(w)[t];
+                double tmps = -1.525 - 0.175 * TL_MK_BARK(w)[t] - 0.5 + px;
                 x = tl_add_db(db, x, tmps + tl_mask_vf(dz, px));
             }
         }
         if (C->br_per_ch < 96) x = tl_add_db(db, C->p1_hear[k], x);
         else x = tl_add_db(db, C->p1_hear[k] - 12.0, x);
-        w.ltg[k] = x;
+        TL_LTG(w)[k] = x;
     }
     TL_LANES_END
     TL_STAMP(sp, 6);
@@ -597,8 +626,8 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         int n = C->p1_mm_n[lane], j0 = C->p1_mm_j0[lane];
         if (n == 0) m = C->p1_hear[sub - 1];
         else {
-            m = w.ltg[j0];
-            for (int j = j0 + 1; j < j0 + n; j++) if (m > w.ltg[j]) m = w.ltg[j];
+            m = TL_LTG(w)[j0];
+            for (int j = j0 + 1; j < j0 + n; j++) if (m > TL_LTG(w)[j]) m = TL_LTG(w)[j];
         }
         double max = C->scale_db[w.minidx[ch][lane]];
         if (w.spike[lane] > max) max = w.spike[lane];
@@ -610,13 +639,13 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
 // ------------------------------------------------------------------------------------------
 // psy model 3 (psycho_3.c:71-432) for channel `ch`; result in w.smr[ch][0..32).
 TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
-                   const TlConfig *TL_RESTRICT C, int ch, long long *sp)
+                   const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
 {
     const double *energy = w.u.fft;
     const double *db = B->dbtable;
     const double *bark = C->p3_bark, *ath = C->p3_ath;
     TL_STAMP(sp, 0);
-    tl_psy_spectrum(w, T, ch);
+    tl_psy_spectrum(w, T, pv, ch);
     TL_STAMP(sp, 1);
 
     // power[1..512] (psycho_3.c:152-160); power[0] is an uninitialised slot in the reference, pinned
@@ -682,31 +711,15 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         }
         TL_SYNC();
     }
-    // (3) tone levels from the still-original spectrum (psycho_3.c:238-239), decimation against the
-    //     threshold in quiet (:321-326), compaction in ascending line order
-    int ntone = 0;
-    for (int base = 0; base < nconf; base += 64) {
-        PV(bool, keep); PV(double, kx); PV(double, kb);
-        TL_LANES_BEGIN
-        bool kp = false; double x = 0, bk = 0;
-        if (base + lane < nconf) {
-            const int cc = w.conf_c[base + lane], k = cc & 511;
-            const double temp = tl_add_db(db, (cc >> 12) & 1 ? TL_DBMIN : w.px[k - 1], w.px[k]);
-            x = tl_add_db(db, temp, w.px[k + 1]);
-            bk = bark[k];
-            kp = !(x < ath[k]);
-        }
-        L(keep) = kp; L(kx) = x; L(kb) = bk;
-        TL_LANES_END
-        const uint64_t m = TL_BALLOT(keep);
-        TL_LANES_BEGIN
-        if ((m >> lane) & 1ull) {
-            const int pos = ntone + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-            w.mk_x[pos] = L(kx); w.mk_bark[pos] = L(kb);
-        }
-        TL_LANES_END
-        ntone += __builtin_popcountll(m);
+    // (3) tone levels from the still-original spectrum (psycho_3.c:238-239); kept aside until the energies
+    //     are dead (the masker lists share the FHT buffer)
+    TL_LANES_BEGIN
+    for (int i = lane; i < nconf; i += 64) {
+        const int cc = w.conf_c[i], k = cc & 511;
+        const double temp = tl_add_db(db, (cc >> 12) & 1 ? TL_DBMIN : w.px[k - 1], w.px[k]);
+        w.tone_x[i] = tl_add_db(db, temp, w.px[k + 1]);
     }
+    TL_LANES_END
     // (4) erasures
     TL_LANES_BEGIN
     for (int i = lane; i < nconf; i += 64) {
@@ -736,10 +749,32 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     L(keepn) = kp; L(nx) = xn; L(nbk) = bk;
     TL_LANES_END
     const uint64_t mn = TL_BALLOT(keepn);       // ascending line order == band order (centres stay in their band)
+    // tones: decimation against the threshold in quiet (psycho_3.c:321-326), compaction in ascending line order
+    int ntone = 0;
+    for (int base = 0; base < nconf; base += 64) {
+        PV(bool, keep); PV(double, kx); PV(double, kb);
+        TL_LANES_BEGIN
+        bool kp2 = false; double x = 0, bk2 = 0;
+        if (base + lane < nconf) {
+            const int k = w.conf_c[base + lane] & 511;
+            x = w.tone_x[base + lane]; bk2 = bark[k];
+            kp2 = !(x < ath[k]);
+        }
+        L(keep) = kp2; L(kx) = x; L(kb) = bk2;
+        TL_LANES_END
+        const uint64_t m = TL_BALLOT(keep);
+        TL_LANES_BEGIN
+        if ((m >> lane) & 1ull) {
+            const int pos = ntone + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            TL_MK_X(w)[pos] = L(kx); TL_MK_BARK(w)[pos] = L(kb);
+        }
+        TL_LANES_END
+        ntone += __builtin_popcountll(m);
+    }
     TL_LANES_BEGIN
     if ((mn >> lane) & 1ull) {
         const int pos = ntone + __builtin_popcountll(mn & ((1ull << lane) - 1ull));
-        w.mk_x[pos] = L(nx); w.mk_bark[pos] = L(nbk);
+        TL_MK_X(w)[pos] = L(nx); TL_MK_BARK(w)[pos] = L(nbk);
     }
     TL_LANES_END
     const int nnoise = __builtin_popcountll(mn);
@@ -752,25 +787,25 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         const double bj = bark[line];
         double lt = TL_DBMIN, ln = TL_DBMIN;
         for (int t = 0; t < ntone; t++) {
-            double dz = bj - w.mk_bark[t];
+            double dz = bj - TL_MK_BARK(w)[t];
             if (dz >= -3.0 && dz < 8.0) {
-                double x = w.mk_x[t];
-                double av = -1.525 - 0.275 * w.mk_bark[t] - 4.5 + x;
+                double x = TL_MK_X(w)[t];
+                double av = -1.525 - 0.275 * TL_MK_BARK(w)[t] - 4.5 + x;
                 lt = tl_add_db(db, lt, av + tl_mask_vf(dz, x));
             }
         }
         for (int t = ntone; t < ntone + nnoise; t++) {
-            double dz = bj - w.mk_bark[t];
+            double dz = bj - TL_MK_BARK(w)[t];
             if (dz >= -3.0 && dz < 8.0) {
-                double x = w.mk_x[t];
-                double av = -1.525 - 0.175 * w.mk_bark[t] - 0.5 + x;
+                double x = TL_MK_X(w)[t];
+                double av = -1.525 - 0.175 * TL_MK_BARK(w)[t] - 0.5 + x;
                 ln = tl_add_db(db, ln, av + tl_mask_vf(dz, x));
             }
         }
         double g = tl_add_db(db, ln, lt);
         if (C->br_per_ch < 96) g = tl_add_db(db, ath[line], g);
         else g = tl_add_db(db, ath[line] - 12.0, g);
-        w.ltg[j] = g;
+        TL_LTG(w)[j] = g;
     }
     TL_LANES_END
     TL_STAMP(sp, 6);
@@ -779,7 +814,7 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     if (lane < 32) {
         double m = 999999.9;
         const int j0 = C->p3_sb_j0[lane], n = C->p3_sb_n[lane];
-        for (int j = j0; j < j0 + n; j++) if (m > w.ltg[j]) m = w.ltg[j];
+        for (int j = j0; j < j0 + n; j++) if (m > TL_LTG(w)[j]) m = TL_LTG(w)[j];
         w.smr[ch][lane] = w.spike[lane] - m;
     }
     TL_LANES_END
@@ -788,7 +823,7 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
 // ------------------------------------------------------------------------------------------
 // One frame of one stream.  lane = 2*sb + ch owns subband sb of channel ch.
 TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
-                           const TlConfig *TL_RESTRICT C,
+                           const TlConfig *TL_RESTRICT C, const TlPcmView &pv,
                            TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, TlTaps *taps, long long *sp)
 {
     const int nch = C->nch, sblimit = C->sblimit;
@@ -797,47 +832,71 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
 
     TL_STAMP(sp, 0);
     // ---- K1: polyphase filterbank (subband.c:201-310), 36 blocks of 32 samples ----
+    // Window stage: lane (ch,i) owns yprime[i] and computes exactly the two window outputs it is made of
+    // (yprime[0]=y[16]; yprime[i]=y[i+16]+y[16-i], i<=16; y[i+16]-y[80-i], i>=17 -- every y is used by one
+    // yprime only, so nothing is computed twice), each as the reference's ascending 8-tap chain.
+    // Matrixing stage: lane (ch,sb) owns the even-k chain s0 (sb<16) or the odd-k chain s1 (sb>=16) of row
+    // min(sb,31-sb); the two halves swap values (a move, not a re-association): s[i]=s0+s1, s[31-i]=s0-s1.
     {
-        PA(double, cw, 16);         // this lane's 2x8 window taps: outputs i and i+32
-        PA(double, cm, 32);         // DCT row r = min(sb, 31-sb): even k then odd k
+        PA(double, ca, 8); PA(double, cb, 8); PA(double, cm, 16);
         TL_LANES_BEGIN
-        const int i = lane >> 1, sb = lane >> 1, r = sb < 16 ? sb : 31 - sb;
-        for (int j = 0; j < 8; j++) { L(cw)[j] = T->enwindow[i + 64 * j]; L(cw)[8 + j] = T->enwindow[i + 32 + 64 * j]; }
-        for (int k = 0; k < 16; k++) { L(cm)[k] = T->dct[r][2 * k]; L(cm)[16 + k] = T->dct[r][2 * k + 1]; }
+        const int i = lane >> 1, sb = lane >> 1, r = sb < 16 ? sb : 31 - sb, par = sb < 16 ? 0 : 1;
+        const int ya = i == 0 ? 16 : i + 16, yb = i == 0 ? 16 : (i <= 16 ? 16 - i : 80 - i);
+        for (int j = 0; j < 8; j++) { L(ca)[j] = T->enwindow[ya + 64 * j]; L(cb)[j] = T->enwindow[yb + 64 * j]; }
+        for (int k = 0; k < 16; k++) L(cm)[k] = T->dct[r][2 * k + par];
         TL_LANES_END
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int b = 0; b < 36; b++) {
+        for (int b0 = 0; b0 < 36; b0 += TL_FB_BATCH) {
             TL_LANES_BEGIN
             const int c = lane & 1, i = lane >> 1;
             if (c < nch) {
-                // X[k] = pcm[t0 + 31 - k], t0 = index of the block's first new sample
-                const int16_t *p = &w.pcm[c][TL_HIST + 32 * b + 31 - i];
-                double t0 = ((double)p[0] / 32768) * L(cw)[0];
-                double t1 = ((double)p[-32] / 32768) * L(cw)[8];
-                for (int j = 1; j < 8; j++) {
-                    t0 += ((double)p[-64 * j] / 32768) * L(cw)[j];
-                    t1 += ((double)p[-64 * j - 32] / 32768) * L(cw)[8 + j];
+                const int ya = i == 0 ? 16 : i + 16, yb = i == 0 ? 16 : (i <= 16 ? 16 - i : 80 - i);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                for (int bb = 0; bb < TL_FB_BATCH; bb++) {
+                    // X[k] = pcm[t0 + 31 - k], t0 = index of the block's first new sample
+                    const int16_t *pa = &w.u.fbk.pcm[c][TL_HIST + 32 * (b0 + bb) + 31 - ya];
+                    const int16_t *pb = &w.u.fbk.pcm[c][TL_HIST + 32 * (b0 + bb) + 31 - yb];
+                    double ta = ((double)pa[0] / 32768) * L(ca)[0];
+                    double tb = ((double)pb[0] / 32768) * L(cb)[0];
+                    for (int j = 1; j < 8; j++) {
+                        ta += ((double)pa[-64 * j] / 32768) * L(ca)[j];
+                        tb += ((double)pb[-64 * j] / 32768) * L(cb)[j];
+                    }
+                    w.u.fbk.yp[bb][c][i] = i == 0 ? ta : (i <= 16 ? ta + tb : ta - tb);
                 }
-                w.u.fb.y[c][i] = t0; w.u.fb.y[c][i + 32] = t1;
             }
             TL_LANES_END
+            PA(double, part, TL_FB_BATCH);
             TL_LANES_BEGIN
-            const int c = lane & 1, i = lane >> 1;
-            if (c < nch) {
-                const double *y = w.u.fb.y[c];
-                w.u.fb.yp[c][i] = i == 0 ? y[16] : (i <= 16 ? y[i + 16] + y[16 - i] : y[i + 16] - y[80 - i]);
+            const int c = lane & 1, sb = lane >> 1, par = sb < 16 ? 0 : 1;
+            for (int bb = 0; bb < TL_FB_BATCH; bb++) {
+                double acc = 0.0;
+                if (c < nch) {
+                    const double *yp = w.u.fbk.yp[bb][c];
+                    for (int k = 0; k < 16; k++) acc += L(cm)[k] * yp[2 * k + par];
+                }
+                L(part)[bb] = acc;
             }
             TL_LANES_END
+            PA(double, oth, TL_FB_BATCH);
+#ifdef TL_EMULATE
+            for (int lane = 0; lane < 64; ++lane)
+                for (int bb = 0; bb < TL_FB_BATCH; bb++) oth[lane][bb] = part[2 * (31 - (lane >> 1)) + (lane & 1)][bb];
+#else
+            {
+                const int lane_ = (int)(threadIdx.x & 63u), partner = 2 * (31 - (lane_ >> 1)) + (lane_ & 1);
+#pragma unroll
+                for (int bb = 0; bb < TL_FB_BATCH; bb++) oth[bb] = __shfl(part[bb], partner, 64);
+            }
+#endif
             TL_LANES_BEGIN
             const int c = lane & 1, sb = lane >> 1;
-            if (c < nch) {
-                const double *yp = w.u.fb.yp[c];
-                double s0 = 0.0, s1 = 0.0;
-                for (int k = 0; k < 16; k++) { s0 += L(cm)[k] * yp[2 * k]; s1 += L(cm)[16 + k] * yp[2 * k + 1]; }
-                L(smp)[b] = sb < 16 ? s0 + s1 : s0 - s1;
-            } else L(smp)[b] = 0.0;
+            for (int bb = 0; bb < TL_FB_BATCH; bb++)
+                L(smp)[b0 + bb] = c < nch ? (sb < 16 ? L(part)[bb] + L(oth)[bb] : L(oth)[bb] - L(part)[bb]) : 0.0;
             TL_LANES_END
         }
     }
@@ -910,9 +969,9 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         }
         TL_LANES_END
     } else if (C->psy == 1) {
-        for (int ch = 0; ch < nch; ch++) tl_psy1(w, T, B, C, ch, sp ? sp + 8 + 8 * ch : nullptr);
+        for (int ch = 0; ch < nch; ch++) tl_psy1(w, T, B, C, pv, ch, sp ? sp + 8 + 8 * ch : nullptr);
     } else {
-        for (int ch = 0; ch < nch; ch++) tl_psy3(w, T, B, C, ch, sp ? sp + 8 + 8 * ch : nullptr);
+        for (int ch = 0; ch < nch; ch++) tl_psy3(w, T, B, C, pv, ch, sp ? sp + 8 + 8 * ch : nullptr);
     }
 
     TL_STAMP(sp, 3);
@@ -1105,7 +1164,20 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
 
     // quantise (encode_new.c:479-547) + write_samples_new (:560-598): 12 rounds of 3 samples
     {
-        const bool js = (nch == 2);
+        const bool any_joint = (nch == 2) && jsbound < sblimit;      // joint-coded subbands exist in this frame
+        // per-lane constants of the frame: quantiser class and its coefficients, the three scalefactors
+        PV(int, q_ba); PV(int, q_nb); PV(int, q_grp); PV(int, q_s2n); PV(int, q_steps);
+        PV(double, q_a); PV(double, q_b); PV(double, q_s2nf); PA(double, q_sf, 3);
+        TL_LANES_BEGIN
+        const int c = lane & 1, sb = lane >> 1;
+        const bool own = sb < sblimit && c < (sb < jsbound ? nch : 1);
+        const int ba = own ? w.balloc[c][sb] : 0;
+        const int q = ba ? T->step_index[C->line[sb]][ba] : 0;
+        const bool joint = any_joint && sb >= jsbound;
+        L(q_ba) = ba; L(q_nb) = T->bits[q]; L(q_grp) = T->group[q]; L(q_s2n) = T->steps2n[q]; L(q_steps) = T->steps[q];
+        L(q_a) = T->qa[q]; L(q_b) = T->qb[q]; L(q_s2nf) = T->steps2n_f[q];
+        for (int gr = 0; gr < 3; gr++) L(q_sf)[gr] = B->scalefactor[joint ? w.jscale[gr][sb] : L(scf)[gr]];
+        TL_LANES_END
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
@@ -1115,37 +1187,34 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
 #ifdef TL_EMULATE
             for (int lane = 0; lane < 64; ++lane) for (int x = 0; x < 3; x++) oth[lane][x] = smp[lane ^ 1][gr * 12 + j0 + x];
 #else
-            if (js) {
+            if (any_joint) {
 #pragma unroll
                 for (int x = 0; x < 3; x++) oth[x] = __shfl_xor(smp[gr * 12 + j0 + x], 1, 64);
             } else { oth[0] = oth[1] = oth[2] = 0.0; }
 #endif
             TL_LANES_BEGIN
             const int c = lane & 1, sb = lane >> 1;
-            const bool own = sb < sblimit && c < (sb < jsbound ? nch : 1);
-            const int ba = own ? w.balloc[c][sb] : 0;
             unsigned v[3] = {0, 0, 0};
-            if (ba) {
-                const int q = T->step_index[C->line[sb]][ba];
-                const bool joint = js && sb >= jsbound;
-                const double sfv = joint ? B->scalefactor[w.jscale[gr][sb]] : B->scalefactor[L(scf)[gr]];
+            if (L(q_ba)) {
+                const bool joint = any_joint && sb >= jsbound;
+                const double sfv = L(q_sf)[gr];
                 for (int x = 0; x < 3; x++) {
                     double s = L(smp)[gr * 12 + j0 + x];
                     if (joint) s = .5 * (s + L(oth)[x]);
                     double d = s / sfv;
-                    d = d * T->qa[q] + T->qb[q];
+                    d = d * L(q_a) + L(q_b);
                     unsigned sig = 1;
                     if (!(d >= 0)) { sig = 0; d += 1.0; }
-                    unsigned qv = (unsigned)(d * T->steps2n_f[q]);
-                    if (sig) qv |= (unsigned)T->steps2n[q];
+                    unsigned qv = (unsigned)(d * L(q_s2nf));
+                    if (sig) qv |= (unsigned)L(q_s2n);
                     v[x] = qv;
                 }
-                const int nb = T->bits[q];
+                const int nb = L(q_nb);
                 const int pos = p_smp + r * n_smp + L(o_smp);
-                if (T->group[q] == 3) {
+                if (L(q_grp) == 3) {
                     tl_put_bits(frame, pos, v[0], nb); tl_put_bits(frame, pos + nb, v[1], nb); tl_put_bits(frame, pos + 2 * nb, v[2], nb);
                 } else {
-                    unsigned y = (unsigned)T->steps[q];
+                    unsigned y = (unsigned)L(q_steps);
                     tl_put_bits(frame, pos, v[0] + v[1] * y + v[2] * y * y, nb);
                 }
             }
@@ -1171,25 +1240,33 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             }
         }
     }
-    // ScF-CRC (crc.c:58-97, toolame.c:527-542): lanes 0..dab_ext-1 each own one band group
+    // ScF-CRC (crc.c:58-97, toolame.c:527-542).  Every (sb,ch) lane packs the 3 MSBs of the scalefactors it
+    // transmits (crc.c:83-96); lanes 0..dab_ext-1 then fold the records of their band group in (sb,ch) order.
     const int tail = lg_frame - 2 - C->dab_ext;                     // byte offset of the first ScF-CRC byte
     TL_LANES_BEGIN
+    const int c = lane & 1, sb = lane >> 1;
+    uint32_t rec = 0;
+    if (c < nch && sb < sblimit && w.balloc[c][sb]) {
+        const uint32_t s0 = (uint32_t)L(scf)[0] >> 3, s1 = (uint32_t)L(scf)[1] >> 3, s2 = (uint32_t)L(scf)[2] >> 3;
+        switch (w.scfsi[c][sb]) {
+        case 0: rec = (9u << 16) | (s0 << 6) | (s1 << 3) | s2; break;
+        case 1: case 3: rec = (6u << 16) | (s0 << 3) | s2; break;
+        default: rec = (3u << 16) | s0; break;
+        }
+    }
+    w.cinfo[lane] = rec;
     if (lane == 0) tl_put_bits(frame, 32, crc16, 16);
+    TL_LANES_END
+    TL_LANES_BEGIN
     if (lane < C->dab_ext) {
         const int grp = C->dab_ext - 1 - lane;                      // transmission order: i = dab_ext-1 .. 0
         const int f[5] = {0, 4, 8, 16, 30};
         int first = f[grp], last = f[grp + 1] > sblimit ? sblimit : f[grp + 1];
         unsigned c8 = 0;
-        for (int sb = first; sb < last; sb++)
-            for (int ch = 0; ch < nch; ch++)
-                if (w.balloc[ch][sb]) {
-                    const unsigned s0 = w.scf[ch][0][sb] >> 3, s1 = w.scf[ch][1][sb] >> 3, s2 = w.scf[ch][2][sb] >> 3;
-                    switch (w.scfsi[ch][sb]) {
-                    case 0: c8 = tl_crc_upd(c8, s0, 3, 0x1D, 0x80); c8 = tl_crc_upd(c8, s1, 3, 0x1D, 0x80); c8 = tl_crc_upd(c8, s2, 3, 0x1D, 0x80); break;
-                    case 1: case 3: c8 = tl_crc_upd(c8, s0, 3, 0x1D, 0x80); c8 = tl_crc_upd(c8, s2, 3, 0x1D, 0x80); break;
-                    default: c8 = tl_crc_upd(c8, s0, 3, 0x1D, 0x80); break;
-                    }
-                }
+        for (int l = 2 * first; l < 2 * last; l++) {
+            const uint32_t rec = w.cinfo[l];
+            c8 = tl_crc_upd(c8, rec & 0xffffu, (int)(rec >> 16), 0x1D, 0x80);
+        }
         c8 &= 0xff;
         tl_put_bits(frame, (tail + lane) * 8, c8, 8);
         w.ncentre[lane] = (int16_t)c8;                               // reused as a 4-entry scratch
@@ -1250,20 +1327,26 @@ TL_FN void tl_encode_stream(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, co
     const TlConfig *C = &A.configs[A.stream_cfg[s]];
     TlStreamState *st = &A.state[s];
     const int nch = C->nch;
-    TL_LANES_BEGIN
-    for (int i = lane; i < 2 * TL_HIST; i += 64) w.pcm[i / TL_HIST][i % TL_HIST] = st->hist[i / TL_HIST][i % TL_HIST];
-    TL_LANES_END
     int done = st->frames_done;
     for (int f = 0; f < A.nframes; f++) {
         const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
-        const int16_t *src = A.pcm + slot * 2304;
+        TlPcmView pv;
+        pv.cur = A.pcm + slot * 2304;
+        if (f == 0) { pv.hist = &st->hist[0][0]; pv.hist_stride = TL_HIST; }
+        else { pv.hist = A.pcm + (slot - (size_t)A.nstreams) * 2304 + (1152 - TL_HIST); pv.hist_stride = 1152; }
         TL_LANES_BEGIN
-        // 1152 samples per channel = 576 dwords, coalesced 4-byte loads
+        // [history | frame] -> LDS: 240 + 576 dwords per channel, coalesced 4-byte loads
+        for (int i = lane; i < (TL_HIST / 2) * nch; i += 64) {
+            const int ch = i / (TL_HIST / 2), k = (i % (TL_HIST / 2)) * 2;
+            const uint32_t v = *(const uint32_t *)(pv.hist + ch * pv.hist_stride + k);
+            w.u.fbk.pcm[ch][k] = (int16_t)(v & 0xffff);
+            w.u.fbk.pcm[ch][k + 1] = (int16_t)(v >> 16);
+        }
         for (int i = lane; i < 576 * nch; i += 64) {
-            uint32_t v = ((const uint32_t *)src)[i];
-            int ch = i / 576, k = (i % 576) * 2;
-            w.pcm[ch][TL_HIST + k] = (int16_t)(v & 0xffff);
-            w.pcm[ch][TL_HIST + k + 1] = (int16_t)(v >> 16);
+            const uint32_t v = ((const uint32_t *)pv.cur)[i];
+            const int ch = i / 576, k = (i % 576) * 2;
+            w.u.fbk.pcm[ch][TL_HIST + k] = (int16_t)(v & 0xffff);
+            w.u.fbk.pcm[ch][TL_HIST + k + 1] = (int16_t)(v >> 16);
         }
         TL_LANES_END
         int xl = 0;
@@ -1274,18 +1357,19 @@ TL_FN void tl_encode_stream(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, co
             for (int i = lane; i < xl; i += 64) w.xpad[i] = A.xpad[slot * TL_MAX_XPAD + i];
             TL_LANES_END
         }
-        tl_encode_frame(w, T, B, C, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, A.taps ? &A.taps[slot] : nullptr,
+        tl_encode_frame(w, T, B, C, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, A.taps ? &A.taps[slot] : nullptr,
                         A.stamps ? A.stamps + slot * 32 : nullptr);
         done++;
+    }
+    // the last 480 samples per channel of the last input frame become the stream's history
+    {
+        const int16_t *last = A.pcm + ((size_t)(A.nframes - 1) * (size_t)A.nstreams + (size_t)s) * 2304;
         TL_LANES_BEGIN
-        for (int i = lane; i < TL_HIST * nch; i += 64) {
-            int ch = i / TL_HIST, k = i % TL_HIST;
-            w.pcm[ch][k] = w.pcm[ch][1152 + k];
+        for (int i = lane; i < (TL_HIST / 2) * 2; i += 64) {
+            const int ch = i / (TL_HIST / 2), k = (i % (TL_HIST / 2)) * 2;
+            *(uint32_t *)&st->hist[ch][k] = ch < nch ? *(const uint32_t *)(last + ch * 1152 + (1152 - TL_HIST) + k) : 0u;
         }
+        if (lane == 0) st->frames_done = done;
         TL_LANES_END
     }
-    TL_LANES_BEGIN
-    for (int i = lane; i < 2 * TL_HIST; i += 64) st->hist[i / TL_HIST][i % TL_HIST] = w.pcm[i / TL_HIST][i % TL_HIST];
-    if (lane == 0) st->frames_done = done;
-    TL_LANES_END
 }

@@ -21,7 +21,7 @@ static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 
 // One wavefront per stream: block = TL_WAVES_PER_BLOCK independent waves, no
 // block-level barrier anywhere; each wave keeps its stream's working set in its own LDS slice.
-__global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK) tl_encode_kernel(TlLaunch A)
+__global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK, 2) tl_encode_kernel(TlLaunch A)
 {
     __shared__ TlBlockShared shared;                 // tables on dependent-load chains, one copy per workgroup
     __shared__ TlWaveLds lds[TL_WAVES_PER_BLOCK];
