@@ -157,20 +157,25 @@ struct TlWaveLds {
 
 // ------------------------------------------------------------------------------------------
 TL_FN double tl_add_db(const double *TL_RESTRICT dbtable, double a, double b)
-{   // psycho_1.c:180-205 == psycho_3.c:44-69
-    double fdiff = 10.0 * (a - b);
-    if (fdiff > 990.0) return a;
-    if (fdiff < -990.0) return b;
+{   // psycho_1.c:180-205 == psycho_3.c:44-69, written without branches (every lane of a wave walks its own
+    // chain): one table read, then selects.  Inside |fdiff| <= 990 the index is the reference's (int)fdiff.
+    const double fdiff = 10.0 * (a - b);
     int idiff = (int)fdiff;
-    if (idiff >= 0) return a + dbtable[idiff];
-    return b + dbtable[-idiff];
+    idiff = idiff > 999 ? 999 : (idiff < -999 ? -999 : idiff);
+    const double t = dbtable[idiff >= 0 ? idiff : -idiff];
+    double r = idiff >= 0 ? a + t : b + t;
+    r = fdiff < -990.0 ? b : r;
+    r = fdiff > 990.0 ? a : r;
+    return r;
 }
 TL_FN double tl_mask_vf(double dz, double x)
-{   // psycho_1.c:494-503 == psycho_3.c:359-369
-    if (dz < -1) return 17 * (dz + 1) - (0.4 * x + 6);
-    if (dz < 0) return (0.4 * x + 6) * dz;
-    if (dz < 1) return -17 * dz;
-    return -(dz - 1) * (17 - 0.15 * x) - 17;
+{   // psycho_1.c:494-503 == psycho_3.c:359-369 (same four expressions, selected instead of branched)
+    const double g = 0.4 * x + 6;
+    const double v0 = 17 * (dz + 1) - g;
+    const double v1 = g * dz;
+    const double v2 = -17 * dz;
+    const double v3 = -(dz - 1) * (17 - 0.15 * x) - 17;
+    return dz < -1 ? v0 : (dz < 0 ? v1 : (dz < 1 ? v2 : v3));
 }
 TL_FN unsigned tl_sf_index(const double *TL_RESTRICT sf, double cur_max)
 {   // encode_new.c:208-218
@@ -592,31 +597,29 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     TL_DBG_DUMP("psy1", ch, ntone, nnoise, TL_MK_X(w), TL_MK_BARK(w));
     // ---- individual + global masking thresholds on the table lines (psycho_1.c:480-532) ----
     const int sub = C->p1_sub;
-    TL_LANES_BEGIN
-    for (int k = 1 + lane; k < sub; k += 64) {
-        const double bk = C->p1_bark[k];
-        double x = TL_DBMIN;
-        for (int t = 0; t < ntone; t++) {
-            double dz = bk - TL_MK_BARK(w)[t];
-            if (dz >= -3.0 && dz < 8.0) {
-                double px = TL_MK_X(w)[t];
-                double tmps = -1.525 - 0.275 * TL_MK_BARK(w)[t] - 4.5 + px;
-                x = tl_add_db(db, x, tmps + tl_mask_vf(dz, px));
+    // each lane folds the maskers into (up to) two table lines at once: two independent dB-sum chains
+    for (int base = 1; base < sub; base += 128) {       // 126..132 lines: one full pass + a 4-line tail at most
+        TL_LANES_BEGIN
+        const int k0 = base + lane, k1 = base + 64 + lane;
+        const bool h0 = k0 < sub, h1 = k1 < sub;
+        if (h0) {
+            const double bk0 = C->p1_bark[k0], bk1 = C->p1_bark[h1 ? k1 : k0];
+            double x0 = TL_DBMIN, x1 = TL_DBMIN;
+            for (int t = 0; t < ntone + nnoise; t++) {
+                const double mb = TL_MK_BARK(w)[t], px = TL_MK_X(w)[t];
+                // tonal: -1.525 - 0.275*bark - 4.5 + x ; noise: -1.525 - 0.175*bark - 0.5 + x   (psycho_1.c:493,512)
+                const double tmps = t < ntone ? -1.525 - 0.275 * mb - 4.5 + px : -1.525 - 0.175 * mb - 0.5 + px;
+                const double dz0 = bk0 - mb, dz1 = bk1 - mb;
+                const double n0 = tl_add_db(db, x0, tmps + tl_mask_vf(dz0, px));
+                const double n1 = tl_add_db(db, x1, tmps + tl_mask_vf(dz1, px));
+                x0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : x0;
+                x1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : x1;
             }
+            TL_LTG(w)[k0] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k0] : C->p1_hear[k0] - 12.0, x0);
+            if (h1) TL_LTG(w)[k1] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k1] : C->p1_hear[k1] - 12.0, x1);
         }
-        for (int t = ntone; t < ntone + nnoise; t++) {
-            double dz = bk - TL_MK_BARK(w)[t];
-            if (dz >= -3.0 && dz < 8.0) {
-                double px = TL_MK_X(w)[t];
-                double tmps = -1.525 - 0.175 * TL_MK_BARK(w)[t] - 0.5 + px;
-                x = tl_add_db(db, x, tmps + tl_mask_vf(dz, px));
-            }
-        }
-        if (C->br_per_ch < 96) x = tl_add_db(db, C->p1_hear[k], x);
-        else x = tl_add_db(db, C->p1_hear[k] - 12.0, x);
-        TL_LTG(w)[k] = x;
+        TL_LANES_END
     }
-    TL_LANES_END
     TL_STAMP(sp, 6);
 
     // ---- minimum per subband (psycho_1.c:541-559) and SMR (psycho_1.c:568-581) ----
@@ -781,33 +784,43 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     TL_STAMP(sp, 4);
     TL_STAMP(sp, 5);
     // ---- thresholds on the 136 subsampled lines (psycho_3.c:339-406) ----
-    TL_LANES_BEGIN
-    for (int j = lane; j < 136; j += 64) {
-        const int line = C->p3_subset[j];
-        const double bj = bark[line];
-        double lt = TL_DBMIN, ln = TL_DBMIN;
-        for (int t = 0; t < ntone; t++) {
-            double dz = bj - TL_MK_BARK(w)[t];
-            if (dz >= -3.0 && dz < 8.0) {
-                double x = TL_MK_X(w)[t];
-                double av = -1.525 - 0.275 * TL_MK_BARK(w)[t] - 4.5 + x;
-                lt = tl_add_db(db, lt, av + tl_mask_vf(dz, x));
+    for (int base = 0; base < 136; base += 128) {       // 136 lines: one full pass + an 8-line tail
+        TL_LANES_BEGIN
+        const int j0 = base + lane, j1 = base + 64 + lane;
+        const bool h0 = j0 < 136, h1 = j1 < 136;
+        if (h0) {
+            const int line0 = C->p3_subset[j0], line1 = C->p3_subset[h1 ? j1 : j0];
+            const double b0 = bark[line0], b1 = bark[line1];
+            double lt0 = TL_DBMIN, ln0 = TL_DBMIN, lt1 = TL_DBMIN, ln1 = TL_DBMIN;
+            for (int t = 0; t < ntone; t++) {
+                const double mb = TL_MK_BARK(w)[t], x = TL_MK_X(w)[t];
+                const double av = -1.525 - 0.275 * mb - 4.5 + x;
+                const double dz0 = b0 - mb, dz1 = b1 - mb;
+                const double n0 = tl_add_db(db, lt0, av + tl_mask_vf(dz0, x));
+                const double n1 = tl_add_db(db, lt1, av + tl_mask_vf(dz1, x));
+                lt0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : lt0;
+                lt1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : lt1;
+            }
+            for (int t = ntone; t < ntone + nnoise; t++) {
+                const double mb = TL_MK_BARK(w)[t], x = TL_MK_X(w)[t];
+                const double av = -1.525 - 0.175 * mb - 0.5 + x;
+                const double dz0 = b0 - mb, dz1 = b1 - mb;
+                const double n0 = tl_add_db(db, ln0, av + tl_mask_vf(dz0, x));
+                const double n1 = tl_add_db(db, ln1, av + tl_mask_vf(dz1, x));
+                ln0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : ln0;
+                ln1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : ln1;
+            }
+            {
+                const double g = tl_add_db(db, ln0, lt0);
+                TL_LTG(w)[j0] = tl_add_db(db, C->br_per_ch < 96 ? ath[line0] : ath[line0] - 12.0, g);
+            }
+            if (h1) {
+                const double g = tl_add_db(db, ln1, lt1);
+                TL_LTG(w)[j1] = tl_add_db(db, C->br_per_ch < 96 ? ath[line1] : ath[line1] - 12.0, g);
             }
         }
-        for (int t = ntone; t < ntone + nnoise; t++) {
-            double dz = bj - TL_MK_BARK(w)[t];
-            if (dz >= -3.0 && dz < 8.0) {
-                double x = TL_MK_X(w)[t];
-                double av = -1.525 - 0.175 * TL_MK_BARK(w)[t] - 0.5 + x;
-                ln = tl_add_db(db, ln, av + tl_mask_vf(dz, x));
-            }
-        }
-        double g = tl_add_db(db, ln, lt);
-        if (C->br_per_ch < 96) g = tl_add_db(db, ath[line], g);
-        else g = tl_add_db(db, ath[line] - 12.0, g);
-        TL_LTG(w)[j] = g;
+        TL_LANES_END
     }
-    TL_LANES_END
     TL_STAMP(sp, 6);
     // ---- minimum per subband + SMR (psycho_3.c:409-432); subset rows of subband sb are contiguous ----
     TL_LANES_BEGIN
