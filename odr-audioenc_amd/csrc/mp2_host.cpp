@@ -92,6 +92,76 @@ void tl_build_tables(TlTables *T)
     }
 }
 
+int tl_psy2_slot(long samplerate)
+{   // one table set per distinct rate the device path supports
+    switch (samplerate) { case 48000: return 0; case 32000: return 1; case 24000: return 2; default: return 3; }
+}
+
+void tl_build_psy2_tables(TlPsy2Tables *P, long samplerate)
+{   // psycho_2_init, psycho_2.c:259-420
+    static const double crit_band[27] = {0, 100, 200, 300, 400, 510, 630, 770, 920, 1080, 1270, 1480, 1720, 2000, 2320,
+                                         2700, 3150, 3700, 4400, 5300, 6400, 7700, 9500, 12000, 15500, 25000, 30000};
+    static const double bmax[27] = {20.0, 20.0, 20.0, 20.0, 20.0, 17.0, 15.0, 10.0, 7.0, 4.4, 4.5, 4.5, 4.5, 4.5,
+                                    4.5, 4.5, 4.5, 4.5, 4.5, 4.5, 4.5, 4.5, 4.5, 4.5, 3.5, 3.5, 3.5};
+    const double LN_TO_LOG10 = 0.2302585093;                      // common.h:30
+    memset(P, 0, sizeof *P);
+    const double sfreq = (double)samplerate;
+    int sfreq_idx;                                                // psycho_2.c:287-303
+    switch (samplerate) { case 32000: case 16000: sfreq_idx = 0; break; case 44100: case 22050: sfreq_idx = 1; break; default: sfreq_idx = 2; break; }
+    for (int j = 0; j < 513; j++) P->absthr[j] = (double)TL_PSY2_ABSTHR_E2[sfreq_idx * 513 + j] / 100.0;
+    for (int i = 0; i < 1024; i++) P->window[i] = 0.5 * (1 - cos(2.0 * kRefPi * (i - 0.5) / 1024));
+    double fthr[513], cbval[64] = {0}, rnorm[64] = {0}, s[64][64];
+    int partition[513], numlines[64] = {0};
+    const double freq_mult = sfreq / 1024;
+    for (int i = 0; i < 513; i++) {
+        const double t = i * freq_mult;
+        int j = 1;
+        while (t > crit_band[j]) j++;
+        fthr[i] = j - 1 + (t - crit_band[j - 1]) / (crit_band[j] - crit_band[j - 1]);
+    }
+    partition[0] = 0;
+    double cnt = 1, bval_lo = fthr[0];
+    cbval[0] = fthr[0];
+    int i;
+    for (i = 1; i < 513; i++) {
+        if ((fthr[i] - bval_lo) > 0.33) {
+            partition[i] = partition[i - 1] + 1;
+            cbval[partition[i - 1]] = cbval[partition[i - 1]] / cnt;
+            cbval[partition[i]] = fthr[i];
+            bval_lo = fthr[i];
+            numlines[partition[i - 1]] = (int)cnt;
+            cnt = 1;
+        } else {
+            partition[i] = partition[i - 1];
+            cbval[partition[i]] += fthr[i];
+            cnt++;
+        }
+    }
+    numlines[partition[i - 1]] = (int)cnt;
+    cbval[partition[i - 1]] = cbval[partition[i - 1]] / cnt;
+    P->npart = partition[512] + 1;
+    for (int j = 0; j < 64; j++)
+        for (int k = 0; k < 64; k++) {
+            double t1 = (cbval[k] - cbval[j]) * 1.05, t2, t3;
+            if (t1 >= 0.5 && t1 <= 2.5) { t2 = t1 - 0.5; t2 = 8.0 * (t2 * t2 - 2.0 * t2); } else t2 = 0;
+            t1 += 0.474;
+            t3 = 15.811389 + 7.5 * t1 - 17.5 * sqrt(1.0 + t1 * t1);
+            s[k][j] = t3 <= -100 ? 0 : exp((t2 + t3) * LN_TO_LOG10);
+        }
+    for (int j = 0; j < 64; j++) {
+        const double t1 = 15.5 + cbval[j];
+        P->tmn[j] = t1 > 24.5 ? t1 : 24.5;
+        rnorm[j] = 0;
+        for (int k = 0; k < 64; k++) rnorm[j] += s[j][k];
+        P->bmaxk[j] = bmax[(int)(cbval[j] + 0.5)];
+        P->den[j] = (rnorm[j] && numlines[j]) ? rnorm[j] * numlines[j] : 0.0;
+        for (int k = 0; k < 64; k++) P->s_t[k][j] = s[j][k];
+        P->part_lo[j] = P->part_hi[j] = 0;
+    }
+    for (int j = 512; j >= 0; j--) { P->partition[j] = (uint8_t)partition[j]; P->part_lo[partition[j]] = (int16_t)j; }
+    for (int j = 0; j < 513; j++) P->part_hi[partition[j]] = (int16_t)(j + 1);
+}
+
 int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, int pad_len)
 {
     memset(C, 0, sizeof *C);
@@ -104,8 +174,9 @@ int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, 
     // (src/odr-audioenc.cpp:560-563 accepts 24000/48000 only) -- rejected by the device path.
     default: return TL_ERR_SAMPLERATE;
     }
-    if (psy < 0 || psy > 3 || psy == 2) return TL_ERR_PSY;       // psy 2 (and the 4 extension): next round
+    if (psy < 0 || psy > 3) return TL_ERR_PSY;                   // toolame.c:204-207
     C->psy = psy;
+    C->psy2_tab = tl_psy2_slot(samplerate);
     switch (mode) {                                               // toolame.c:174-200
     case 's': C->mode0 = 0; C->mode_ext0 = 0; break;
     case 'd': C->mode0 = 2; C->mode_ext0 = 0; break;

@@ -19,4 +19,7 @@ enum {
 };
 
 void tl_build_tables(TlTables *T);
+// psy-2 tables for a sample rate (48000/32000/24000/16000); returns the table slot 0..2 used as TlConfig::psy2_tab
+int tl_psy2_slot(long samplerate);
+void tl_build_psy2_tables(TlPsy2Tables *P, long samplerate);
 int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, int pad_len);

@@ -47,7 +47,7 @@ struct TlTables {
 struct TlConfig {
     int32_t version, fs_idx, br_idx, kbps, nch, mode0, mode_ext0, tab, sblimit, jsbound0;
     int32_t dab_ext, dab_length, psy, frame_bytes, br_per_ch;
-    int32_t p1_ncb, p1_sub, p3_cbands;
+    int32_t p1_ncb, p1_sub, p3_cbands, psy2_tab;
     uint8_t line[32];            // alloc-table line per subband (255 above sblimit)
     uint8_t nbal[32];            // bits of the bit_alloc field per subband
     double scale_db[64];         // 20*log10(scalefactor[i]*32768) - 10   (psycho_1.c:575, psycho_3.c:180)
@@ -68,6 +68,23 @@ struct TlConfig {
     int16_t p3_sb_j0[32], p3_sb_n[32];   // rows of p3_subset that fall into each subband (psycho_3.c:415-420)
     // psy model 0 (psycho_0.c:36-50)
     double p0_athmin[32];
+};
+
+// psy model 2 tables; they depend on the sample rate only (psycho_2.c:259-420, absthr.h).
+struct TlPsy2Tables {
+    double window[1024];         // 0.5*(1-cos(2*PI*(i-0.5)/1024)), psycho_2.c:318-319
+    double absthr[513];
+    double s_t[64][64];          // spreading function TRANSPOSED: s_t[k][j] = s[j][k]  (coalesced by partition j)
+    double tmn[64], bmaxk[64];   // tone-masking-noise, bmax[(int)(cbval+0.5)]
+    double den[64];              // rnorm[j]*numlines[j]; 0 => nb[j] = 0  (psycho_2.c:200-204)
+    int16_t part_lo[64], part_hi[64];   // FFT lines [lo,hi) of each partition (empty partitions: lo = hi)
+    uint8_t partition[520];
+    int32_t npart, pad_;
+};
+// psy model 2 prediction state per stream: r and phi of the two previous 576-sample passes (psycho_2.c:300-306)
+struct TlPsy2State {
+    double r[2][2][513];
+    double phi[2][2][513];
 };
 
 // Per-stream state that persists across launches.
@@ -106,5 +123,7 @@ struct TlLaunch {
     uint8_t *out;                     // [nframes][nstreams][out_stride]: slot f holds frame (f-1); slot 0 = pending
     TlTaps *taps;                     // [nframes][nstreams] or null
     long long *stamps;                // [nframes][nstreams][32] cycle stamps (diagnostic builds) or null
+    const TlPsy2Tables *psy2_tables;  // [*] indexed by TlConfig::psy2_tab, or null when no stream uses psy 2
+    TlPsy2State *psy2_state;          // [nstreams] or null
     int32_t nstreams, nframes, out_stride, pad_;
 };

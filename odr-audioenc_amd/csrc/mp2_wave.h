@@ -17,6 +17,7 @@
 #pragma once
 #include "mp2_types.h"
 #include "tl_math.h"
+#include <math.h>
 
 // ------------------------------------------------------------------------------------------
 #ifdef TL_EMULATE
@@ -834,10 +835,120 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
 }
 
 // ------------------------------------------------------------------------------------------
+// psy model 2 (psycho_2.c:52-254, psycho_2_fft fft.c:1230-1275) for channel `ch`; result in w.smr[ch][0..32).
+// Two 576-sample passes per frame; a pass needs the 480 samples before its 544 new ones -- the stream's
+// PCM history on pass 0, samples 96..575 of the frame on pass 1 (the reference's savebuf shift by 576).
+// Line-parallel: FFT, unpredictability (sincos/atan2/sqrt per line), thresholds; partition-parallel:
+// grouping, spreading, SNR.  Every sum is one lane's sequential chain in the reference's order.
+TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_RESTRICT P,
+                   TlPsy2State *TL_RESTRICT S, const TlPcmView &pv, int ch)
+{
+    double *x = w.u.fft;
+    double *cw = w.px;                       // c[] (unpredictability), then fthr[]
+    double *ge = w.u.fft + 520, *gc = ge + 64, *ecb = gc + 64, *nb = ecb + 64;   // dead upper half of the FHT buffer
+    PV(double, snr0);
+    for (int pass = 0; pass < 2; pass++) {
+        TL_LANES_BEGIN
+        for (int i = lane; i < 1024; i += 64) {
+            int r = 0;
+            for (int b = 0; b < 10; b++) r |= ((i >> b) & 1) << (9 - b);
+            int16_t v;
+            if (pass == 0) v = i < TL_HIST ? pv.hist[ch * pv.hist_stride + i] : pv.cur[ch * 1152 + (i - TL_HIST)];
+            else v = pv.cur[ch * 1152 + 96 + i];
+            x[r] = P->window[i] * (double)v;                         // psycho_2.c:84-92
+        }
+        TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass_first(x, lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass(x, 2, 0, T->fht_tw, lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass(x, 4, 1, T->fht_tw, lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass(x, 6, 8, T->fht_tw, lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass(x, 8, 39, T->fht_tw, lane); TL_LANES_END
+        // energy + phase (fft.c:1246-1275), unpredictability (psycho_2.c:119-140); ages: new = 1-pass, old = pass
+        const int nw = 1 - pass, old = pass;
+        TL_LANES_BEGIN
+        for (int j = lane; j <= 512; j += 64) {
+            double e, phi;
+            if (j == 0) { e = x[0] * x[0]; phi = 0.0; }
+            else if (j == 512) { e = x[512] * x[512]; phi = tl_atan2(0.0, x[512]); }
+            else {
+                const double a = x[j], b = x[1024 - j];
+                e = (a * a + b * b) / 2.0;
+                if (e < 0.0005) { e = 0.0005; phi = 0; }
+                else phi = tl_atan2(-a, b) + 3.14159265358979 / 4;
+            }
+            const double r_prime = 2.0 * S->r[ch][old][j] - S->r[ch][nw][j];
+            const double phi_prime = 2.0 * S->phi[ch][old][j] - S->phi[ch][nw][j];
+            const double rn = sqrt(e);
+            S->r[ch][nw][j] = rn; S->phi[ch][nw][j] = phi;
+            double sp, cp, spp, cpp;
+            tl_sincos(phi, &sp, &cp);
+            tl_sincos(phi_prime, &spp, &cpp);
+            const double t1 = rn * cp - r_prime * cpp;
+            const double t2 = rn * sp - r_prime * spp;
+            const double t3 = rn + fabs(r_prime);
+            cw[j] = t3 != 0 ? sqrt(t1 * t1 + t2 * t2) / t3 : 0;
+            x[j] = e;                                               // x[1024-j] belongs to this lane only
+        }
+        TL_LANES_END
+        const double *energy = x;
+        // grouped energy / weighted unpredictability per partition (psycho_2.c:146-155)
+        TL_LANES_BEGIN
+        {
+            double e = 0, c = 0;
+            if (lane < P->npart)
+                for (int j = P->part_lo[lane]; j < P->part_hi[lane]; j++) { e += energy[j]; c += energy[j] * cw[j]; }
+            ge[lane] = e; gc[lane] = c;
+        }
+        TL_LANES_END
+        // spreading (psycho_2.c:161-175), required SNR (:181-193), permissible noise (:200-204)
+        TL_LANES_BEGIN
+        {
+            double e = 0, c = 0;
+            for (int k = 0; k < 64; k++) {
+                const double sv = P->s_t[k][lane];
+                if (sv != 0.0) { e += sv * ge[k]; c += sv * gc[k]; }
+            }
+            double cb = e != 0 ? c / e : 0;
+            if (cb < .05) cb = 0.05; else if (cb > .5) cb = 0.5;
+            const double tb = -0.434294482 * tl_log(cb) - 0.301029996;
+            double bc = P->tmn[lane] * tb + 5.5 * (1.0 - tb);
+            bc = bc > P->bmaxk[lane] ? bc : P->bmaxk[lane];
+            bc = tl_exp(-bc * 0.2302585093);
+            ecb[lane] = e;
+            nb[lane] = P->den[lane] != 0 ? e * bc / P->den[lane] : 0;
+        }
+        TL_LANES_END
+        // threshold per line (psycho_2.c:205-224): c[] is dead, reuse it for fthr[]
+        TL_LANES_BEGIN
+        for (int j = lane; j <= 512; j += 64) {
+            const double t = nb[P->partition[j]], a = P->absthr[j];
+            cw[j] = t > a ? t : a;
+        }
+        TL_LANES_END
+        // 32 subbands (psycho_2.c:227-246)
+        TL_LANES_BEGIN
+        if (lane < 32) {
+            const int j = 16 * lane;
+            double minthres = lane < 13 ? 60802371420160.0 : 0.0, sum_energy = 0.0;
+            for (int k = 0; k < 17; k++) {
+                if (lane < 13) { if (minthres > cw[j + k]) minthres = cw[j + k]; }
+                else minthres += cw[j + k];
+                sum_energy += energy[j + k];
+            }
+            double snr = lane < 13 ? sum_energy / (minthres * 17.0) : sum_energy / minthres;
+            snr = 4.342944819 * tl_log(snr);
+            if (pass == 0) L(snr0) = snr;
+            else w.smr[ch][lane] = L(snr0) > snr ? L(snr0) : snr;
+        }
+        TL_LANES_END
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // One frame of one stream.  lane = 2*sb + ch owns subband sb of channel ch.
 TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
-                           const TlConfig *TL_RESTRICT C, const TlPcmView &pv,
-                           TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, TlTaps *taps, long long *sp)
+                           const TlConfig *TL_RESTRICT C, const TlPsy2Tables *TL_RESTRICT P2, TlPsy2State *TL_RESTRICT S2,
+                           const TlPcmView &pv, TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, TlTaps *taps, long long *sp)
 {
     const int nch = C->nch, sblimit = C->sblimit;
     PA(double, smp, 36);            // sb_sample[ch][gr][bl][sb] of this lane's (sb,ch), b = gr*12+bl
@@ -981,6 +1092,8 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             w.smr[c][sb] = 2.0 * (30.0 - m) - C->p0_athmin[sb];
         }
         TL_LANES_END
+    } else if (C->psy == 2) {
+        for (int ch = 0; ch < nch; ch++) tl_psy2(w, T, P2, S2, pv, ch);
     } else if (C->psy == 1) {
         for (int ch = 0; ch < nch; ch++) tl_psy1(w, T, B, C, pv, ch, sp ? sp + 8 + 8 * ch : nullptr);
     } else {
@@ -1370,7 +1483,7 @@ TL_FN void tl_encode_stream(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, co
             for (int i = lane; i < xl; i += 64) w.xpad[i] = A.xpad[slot * TL_MAX_XPAD + i];
             TL_LANES_END
         }
-        tl_encode_frame(w, T, B, C, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, A.taps ? &A.taps[slot] : nullptr,
+        tl_encode_frame(w, T, B, C, A.psy2_tables ? &A.psy2_tables[C->psy2_tab] : nullptr, A.psy2_state ? &A.psy2_state[s] : nullptr, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, A.taps ? &A.taps[slot] : nullptr,
                         A.stamps ? A.stamps + slot * 32 : nullptr);
         done++;
     }

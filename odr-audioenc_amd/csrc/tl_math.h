@@ -115,3 +115,169 @@ TL_HD double tl_pow10(double x)
     if (ex >= 0x7ff) return yv * tl_u2d(0x7fe0000000000000ull) * 2.0;
     return tl_u2d((u & 0x800fffffffffffffull) | ((uint64_t)ex << 52));
 }
+
+// ------------------------------------------------------------------------------------------
+// natural log, exp, sin, cos, atan2 for psy model 2 (psycho_2.c:127-133,184,192,235,245, fft.c:1258-1263).
+// Same construction as above: fdlibm kernels restated with IEEE + - * / only.
+
+TL_HD double tl_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t u = tl_d2u(x);
+    int32_t hx = (int32_t)(u >> 32);
+    int k = 0;
+    if (hx < 0x00100000) {
+        if ((u << 1) == 0) return -1.0 / 0.0 * 1.0;
+        if (hx < 0) return (x - x) / (x - x);
+        k -= 54; x *= 18014398509481984.0; u = tl_d2u(x); hx = (int32_t)(u >> 32);
+    }
+    if (hx >= 0x7ff00000) return x + x;
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    int32_t i = (hx + 0x95f64) & 0x100000;
+    x = tl_u2d(((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32) | (u & 0xffffffffull));
+    k += (i >> 20);
+    const double f = x - 1.0, dk = (double)k;
+    const double s = f / (2.0 + f), z = s * s, w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1, hfsq = 0.5 * f * f;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+TL_HD double tl_exp(double x)
+{
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x > 709.0) return 1.0 / 0.0 * 1.0;
+    if (x < -745.0) return 0.0;
+    const double t = x * invln2;
+    const int k = (int)(t + (t >= 0 ? 0.5 : -0.5));
+    const double hi = x - k * ln2HI, lo = k * ln2LO;
+    const double r = hi - lo;
+    const double tt = r * r;
+    const double c = r - tt * (P1 + tt * (P2 + tt * (P3 + tt * (P4 + tt * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    if (k == 0) return y;
+    uint64_t u = tl_d2u(y);
+    const int ex = (int)((u >> 52) & 0x7ff) + k;
+    if (ex <= 0) return y * tl_u2d((uint64_t)(k + 1023 + 200) << 52) * tl_u2d((uint64_t)(1023 - 200) << 52);
+    return tl_u2d((u & 0x800fffffffffffffull) | ((uint64_t)ex << 52));
+}
+
+// reduce x to r = y0 + y1 in [-pi/4, pi/4], return the quadrant (|x| < ~1e5: two/three-term Cody-Waite)
+TL_HD int tl_rem_pio2(double x, double *y0, double *y1)
+{
+    const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11,
+                 pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21,
+                 pio2_3 = 2.02226624871116645580e-21, pio2_3t = 8.47842766036889956997e-32;
+    const double t0 = x * invpio2;
+    const int n = (int)(t0 + (t0 >= 0 ? 0.5 : -0.5));
+    const double fn = (double)n;
+    double r = x - fn * pio2_1, w = fn * pio2_1t;
+    double y = r - w;
+    const int ex = (int)((tl_d2u(x) >> 52) & 0x7ff);
+    int ey = (int)((tl_d2u(y) >> 52) & 0x7ff);
+    if (ex - ey > 16) {                       // cancellation: second iteration
+        double t = r;
+        w = fn * pio2_2; r = t - w; w = fn * pio2_2t - ((t - r) - w);
+        y = r - w;
+        ey = (int)((tl_d2u(y) >> 52) & 0x7ff);
+        if (ex - ey > 49) {                   // third iteration
+            t = r;
+            w = fn * pio2_3; r = t - w; w = fn * pio2_3t - ((t - r) - w);
+            y = r - w;
+        }
+    }
+    *y0 = y; *y1 = (r - y) - w;
+    return n;
+}
+TL_HD double tl_ksin(double x, double y, int iy)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = x * x, v = z * x, r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    if (iy == 0) return x + v * (S1 + z * r);
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+TL_HD double tl_kcos(double x, double y)
+{
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = x * x;
+    const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const int32_t ix = (int32_t)(tl_d2u(x) >> 32) & 0x7fffffff;
+    if (ix < 0x3FD33333) return 1.0 - (0.5 * z - (z * r - x * y));
+    const double qx = ix > 0x3fe90000 ? 0.28125 : tl_u2d((uint64_t)(uint32_t)(ix - 0x00200000) << 32);
+    const double hz = 0.5 * z - qx, a = 1.0 - qx;
+    return a - (hz - (z * r - x * y));
+}
+TL_HD void tl_sincos(double x, double *sn, double *cs)
+{
+    const int32_t ix = (int32_t)(tl_d2u(x) >> 32) & 0x7fffffff;
+    double y0 = x, y1 = 0.0;
+    int n = 0;
+    if (ix > 0x3fe921fb) n = tl_rem_pio2(x, &y0, &y1);
+    const double s = tl_ksin(y0, y1, ix > 0x3fe921fb), c = tl_kcos(y0, y1);
+    switch (n & 3) {
+    case 0: *sn = s; *cs = c; break;
+    case 1: *sn = c; *cs = -s; break;
+    case 2: *sn = -s; *cs = -c; break;
+    default: *sn = -c; *cs = s; break;
+    }
+}
+
+TL_HD double tl_atan(double x)
+{
+    const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01, aT2 = 1.42857142725034663711e-01,
+                 aT3 = -1.11111104054623557880e-01, aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
+                 aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02, aT8 = 4.97687799461593236017e-02,
+                 aT9 = -3.65315727442169155270e-02, aT10 = 1.62858201153657823623e-02;
+    const int32_t hx = (int32_t)(tl_d2u(x) >> 32), ix = hx & 0x7fffffff;
+    int id;
+    double hi = 0, lo = 0;
+    if (ix >= 0x44100000) { const double r = 1.57079632679489655800e+00 + 6.12323399573676603587e-17; return hx > 0 ? r : -r; }
+    if (ix < 0x3fdc0000) { if (ix < 0x3e400000) return x; id = -1; }
+    else {
+        x = x < 0 ? -x : x;
+        if (ix < 0x3ff30000) {
+            if (ix < 0x3fe60000) { id = 0; x = (2.0 * x - 1.0) / (2.0 + x); hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
+            else { id = 1; x = (x - 1.0) / (x + 1.0); hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
+        } else {
+            if (ix < 0x40038000) { id = 2; x = (x - 1.5) / (1.0 + 1.5 * x); hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
+            else { id = 3; x = -1.0 / x; hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
+        }
+    }
+    const double z = x * x, w = z * z;
+    const double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0) return x - x * (s1 + s2);
+    const double zz = hi - ((x * (s1 + s2) - lo) - x);
+    return hx < 0 ? -zz : zz;
+}
+TL_HD double tl_atan2(double y, double x)
+{
+    const double pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16, pi_o_2 = 1.5707963267948965580E+00;
+    const uint64_t ux = tl_d2u(x), uy = tl_d2u(y);
+    const int32_t hx = (int32_t)(ux >> 32), hy = (int32_t)(uy >> 32), ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if ((uy << 1) == 0) {                                   // y = +-0
+        switch (m) { case 0: case 1: return y; case 2: return pi; default: return -pi; }
+    }
+    if ((ux << 1) == 0) return hy < 0 ? -pi_o_2 : pi_o_2;  // x = +-0
+    const int k = (iy - ix) >> 20;
+    double z;
+    if (k > 60) z = pi_o_2 + 0.5 * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0;
+    else { double q = y / x; z = tl_atan(q < 0 ? -q : q); }
+    switch (m) {
+    case 0: return z;
+    case 1: return -z;
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}

@@ -60,6 +60,8 @@ struct tlb_batch {
     TlConfig *d_configs = nullptr;
     int32_t *d_stream_cfg = nullptr;
     TlStreamState *d_state = nullptr;
+    TlPsy2Tables *d_psy2_tables = nullptr;     // 4 slots (tl_psy2_slot), only when a stream uses psy 2
+    TlPsy2State *d_psy2_state = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
     bool timed = false;
@@ -88,6 +90,8 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_configs) (void)hipFree(b->d_configs);
     if (b->d_stream_cfg) (void)hipFree(b->d_stream_cfg);
     if (b->d_state) (void)hipFree(b->d_state);
+    if (b->d_psy2_tables) (void)hipFree(b->d_psy2_tables);
+    if (b->d_psy2_state) (void)hipFree(b->d_psy2_state);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     delete b;
@@ -131,6 +135,17 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
     HIPCHK(hipMemcpy(b->d_stream_cfg, b->h_stream_cfg.data(), sizeof(int32_t) * nstreams, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&b->d_state, sizeof(TlStreamState) * (size_t)nstreams));
     HIPCHK(hipMemset(b->d_state, 0, sizeof(TlStreamState) * (size_t)nstreams));
+    bool any2 = false;
+    for (auto &c : b->h_configs) any2 |= c.psy == 2;
+    if (any2) {
+        const long rates[4] = {48000, 32000, 24000, 16000};
+        std::vector<TlPsy2Tables> ht2(4);
+        for (int i = 0; i < 4; i++) tl_build_psy2_tables(&ht2[tl_psy2_slot(rates[i])], rates[i]);
+        HIPCHK(hipMalloc(&b->d_psy2_tables, sizeof(TlPsy2Tables) * 4));
+        HIPCHK(hipMemcpy(b->d_psy2_tables, ht2.data(), sizeof(TlPsy2Tables) * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc(&b->d_psy2_state, sizeof(TlPsy2State) * (size_t)nstreams));
+        HIPCHK(hipMemset(b->d_psy2_state, 0, sizeof(TlPsy2State) * (size_t)nstreams));
+    }
     HIPCHK(hipEventCreate(&b->ev0));
     HIPCHK(hipEventCreate(&b->ev1));
     return TLB_OK;
@@ -152,6 +167,7 @@ int tlb_reset(tlb_batch *b)
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(b->d_state, 0, sizeof(TlStreamState) * (size_t)b->nstreams));
+    if (b->d_psy2_state) HIPCHK(hipMemset(b->d_psy2_state, 0, sizeof(TlPsy2State) * (size_t)b->nstreams));
     b->frames = 0;
     return TLB_OK;
 }
@@ -171,6 +187,7 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
     A.tables = b->d_tables; A.configs = b->d_configs; A.stream_cfg = b->d_stream_cfg; A.state = b->d_state;
     A.pcm = d_pcm; A.xpad = d_xpad_len ? d_xpad : nullptr; A.xpad_len = d_xpad ? d_xpad_len : nullptr;
     A.out = d_out; A.taps = d_taps; A.stamps = d_stamps;
+    A.psy2_tables = b->d_psy2_tables; A.psy2_state = b->d_psy2_state;
     A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride;
     const int blocks = (b->nstreams + TL_WAVES_PER_BLOCK - 1) / TL_WAVES_PER_BLOCK;
     HIPCHK(hipEventRecord(b->ev0, st));

@@ -263,7 +263,7 @@ mp2o_enc *mp2o_create(long samplerate, char mode, int kbps, int psy, int pad_len
     case 16000: e->version = 0; e->fs_idx = 2; break;
     default: free(e); return NULL;
     }
-    if (psy < 0 || psy > 4) { free(e); return NULL; }      /* ABI range is 0..3, toolame.c:202-210; 4 = extension */
+    if (psy < 0 || psy > 3) { free(e); return NULL; }      /* toolame.c:202-210 */
     e->psy = psy;
     /* toolame_set_channel_mode, toolame.c:174-200 */
     switch (mode) {
@@ -305,7 +305,7 @@ mp2o_enc *mp2o_create(long samplerate, char mode, int kbps, int psy, int pad_len
     psy1_init(e);
     psy3_init(e);
     psy0_init(e);
-    if (psy == 2 || psy == 4) psy2_init(e);
+    if (psy == 2) psy2_init(e);
     return e;
 }
 
@@ -902,7 +902,7 @@ int mp2o_encode_frame(mp2o_enc *e, const short pcm[2][1152], const unsigned char
     case 0: psy0_run(e, T->scalar, T->smr); break;
     case 1: for (int ch = 0; ch < nch; ch++) psy1_run(e, pcm[ch], ch, T->max_sc[ch], T->smr[ch]); break;
     case 3: for (int ch = 0; ch < nch; ch++) psy3_run(e, pcm[ch], ch, T->max_sc[ch], T->smr[ch]); break;
-    case 2: case 4: for (int ch = 0; ch < nch; ch++) psy2_run(e, pcm[ch], ch, T->smr[ch]); break;
+    case 2: for (int ch = 0; ch < nch; ch++) psy2_run(e, pcm[ch], ch, T->smr[ch]); break;
     }
 
     sf_pattern(e, T->scalar, T->scfsi);

@@ -44,8 +44,7 @@ typedef struct {
 } mp2o_taps;
 
 /* Configure like odr-audioenc does (src/odr-audioenc.cpp:687-722): init, samplerate, psy, mode,
- * bitrate, pad.  mode in {'s','d','j','m'}; psy in {0,1,2,3} through the ABI-visible range, 4
- * accepted here as an extension value.  Returns NULL for an illegal configuration. */
+ * bitrate, pad.  mode in {'s','d','j','m'}; psy in {0,1,2,3} (the ABI-visible range).  Returns NULL for an illegal configuration. */
 mp2o_enc *mp2o_create(long samplerate, char mode, int bitrate_kbps, int psy, int pad_len);
 void mp2o_destroy(mp2o_enc *e);
 

@@ -19,6 +19,8 @@ struct Emu {
     std::vector<TlConfig> configs;
     std::vector<int32_t> stream_cfg;
     std::vector<TlStreamState> state;
+    std::vector<TlPsy2Tables> psy2_tables;
+    std::vector<TlPsy2State> psy2_state;
 };
 
 extern "C" {
@@ -35,6 +37,15 @@ void *emu_create(int nstreams, const long *fs, const char *mode, const int *kbps
         if (rc) { if (err) *err = rc; delete e; return nullptr; }
         e->stream_cfg[s] = s;
     }
+    bool any2 = false;
+    for (auto &c : e->configs) any2 |= c.psy == 2;
+    if (any2) {
+        const long rates[4] = {48000, 32000, 24000, 16000};
+        e->psy2_tables.resize(4);
+        for (int i = 0; i < 4; i++) tl_build_psy2_tables(&e->psy2_tables[tl_psy2_slot(rates[i])], rates[i]);
+        e->psy2_state.resize(nstreams);
+        memset(e->psy2_state.data(), 0, sizeof(TlPsy2State) * nstreams);
+    }
     if (err) *err = 0;
     return e;
 }
@@ -49,6 +60,8 @@ int emu_encode(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, co
     memset(&A, 0, sizeof A);
     A.tables = &e->tables; A.configs = e->configs.data(); A.stream_cfg = e->stream_cfg.data();
     A.state = e->state.data(); A.pcm = pcm; A.xpad = xpad; A.xpad_len = xpad_len; A.out = out; A.taps = taps;
+    A.psy2_tables = e->psy2_tables.empty() ? nullptr : e->psy2_tables.data();
+    A.psy2_state = e->psy2_state.empty() ? nullptr : e->psy2_state.data();
     A.nstreams = (int)e->state.size(); A.nframes = nframes; A.out_stride = out_stride;
     static thread_local TlWaveLds w;
     for (int s = 0; s < A.nstreams; s++) tl_encode_stream(w, &e->tables.shared, A, s);

@@ -34,11 +34,11 @@ CONFIGS = [  # (samplerate, mode, kbps)
 
 def cases():
     out = []
-    for psy in (0, 1, 3):
+    for psy in (0, 1, 2, 3):
         for i, (fs, mode, kbps) in enumerate(CONFIGS):
             out.append(dict(name=f"p{psy}_{fs // 1000}k_{mode}_{kbps}_k0", samplerate=fs, mode=mode, kbps=kbps,
                             psy=psy, kind=0, seed=100 + i, pad_len=0))
-    for psy in (1, 3):
+    for psy in (1, 2, 3):
         for mode in ("s", "j"):
             for kind in range(1, 8):
                 if psy == 3 and kind in (1, 3):

@@ -92,9 +92,10 @@ def test_device_equals_host_emulation_bitwise(M):
     """Same kernel source, two compilers: gfx950 vs the lane-loop emulation. Everything bit-identical,
     including SMR (shared deterministic log10/pow10)."""
     cfgs = [dict(psy=1, mode="j"), dict(psy=3, mode="s"), dict(psy=1, mode="m", kbps=64, samplerate=32000),
-            dict(psy=3, mode="j", kbps=192), dict(psy=0, mode="d"), dict(psy=3, mode="m", kbps=64, samplerate=24000)]
+            dict(psy=3, mode="j", kbps=192), dict(psy=0, mode="d"), dict(psy=3, mode="m", kbps=64, samplerate=24000),
+            dict(psy=2, mode="j"), dict(psy=2, mode="s", kbps=192, samplerate=32000)]
     nframes = 6
-    pcm = np.stack([gen_pcm(50 + s, [0, 7, 4, 5, 2, 6][s], 0, nframes) for s in range(len(cfgs))], axis=1)
+    pcm = np.stack([gen_pcm(50 + s, [0, 7, 4, 5, 2, 6, 0, 7][s], 0, nframes) for s in range(len(cfgs))], axis=1)
     e = E.EmuBatch(cfgs)
     eg, et = e.encode(pcm, want_taps=True)
     b = M.Batch([M.StreamConfig(samplerate=c.get("samplerate", 48000), mode=c["mode"], bitrate=c.get("kbps", 128),
@@ -109,7 +110,7 @@ def test_device_equals_host_emulation_bitwise(M):
     e.close()
 
 
-@pytest.mark.parametrize("psy,mode,nstreams,nframes", [(1, "j", 96, 12), (3, "s", 96, 12), (1, "s", 64, 24)])
+@pytest.mark.parametrize("psy,mode,nstreams,nframes", [(1, "j", 96, 12), (3, "s", 96, 12), (1, "s", 64, 24), (2, "j", 64, 12)])
 def test_many_streams_vs_oracle(M, psy, mode, nstreams, nframes):
     """stream i uses seed i; frames fed in ragged chunks (1, 2, 5, rest) to exercise the
     state hand-over between launches."""

@@ -36,7 +36,7 @@ def test_oracle_matches_reference_golden(path):
         assert np.array_equal(t["scfsi"][:nch, :sbl], g["scfsi"][i][:nch, :sbl]), ("scfsi", i)
         assert np.array_equal(t["bit_alloc"][:nch], g["bit_alloc"][i][:nch]), ("bit_alloc", i)
         assert np.array_equal(_bits(t["max_sc"][:nch]), _bits(g["max_sc"][i][:nch])), ("max_sc", i)
-        nsmr = 32 if psy in (0, 3) else sbl          # psy 1 writes only sblimit entries
+        nsmr = sbl if psy == 1 else 32               # psy 1 writes only sblimit entries
         assert np.array_equal(_bits(t["smr"][:nch, :nsmr]), _bits(g["smr"][i][:nch, :nsmr])), ("smr", i)
         assert (t["mode"], t["mode_ext"]) == (int(g["mode"][i]), int(g["mode_ext"][i])), ("mode", i)
         if chr(mode) == "j":
