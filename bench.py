@@ -164,7 +164,7 @@ def main():
             "realtime_streams": round(value / (FS / 1152.0), 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "tl_encode_kernel", "kernel_ms": round(kernel_ms, 4), "last_kernel_ms_hip_events": round(last_ms, 4),
+                         "kernel": f"tl_encode_kernel<{args.psy}>", "kernel_ms": round(kernel_ms, 4), "last_kernel_ms_hip_events": round(last_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch,
                          "note": "the path is fp64-VALU/LDS-latency bound, not HBM bound (SURVEY F9): compulsory traffic is "
                                  "4992 B per 0.35 MFLOP frame"},

@@ -116,6 +116,7 @@ struct TlLaunch {
     const TlTables *tables;
     const TlConfig *configs;          // [nconfigs]
     const int32_t *stream_cfg;        // [nstreams] -> config index
+    const int32_t *stream_list;       // [nlist] stream ids handled by this launch (the streams of one psy model)
     TlStreamState *state;             // [nstreams]
     const int16_t *pcm;               // [nframes][nstreams][2][1152]
     const uint8_t *xpad;              // [nframes][nstreams][TL_MAX_XPAD] or null
@@ -125,5 +126,5 @@ struct TlLaunch {
     long long *stamps;                // [nframes][nstreams][32] cycle stamps (diagnostic builds) or null
     const TlPsy2Tables *psy2_tables;  // [*] indexed by TlConfig::psy2_tab, or null when no stream uses psy 2
     TlPsy2State *psy2_state;          // [nstreams] or null
-    int32_t nstreams, nframes, out_stride, pad_;
+    int32_t nstreams, nframes, out_stride, nlist;
 };

@@ -945,7 +945,9 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
 }
 
 // ------------------------------------------------------------------------------------------
-// One frame of one stream.  lane = 2*sb + ch owns subband sb of channel ch.
+// One frame of one stream.  lane = 2*sb + ch owns subband sb of channel ch.  PSY (the psy model) is a compile-time
+// parameter: one kernel per model keeps each kernel's code and register footprint to what that model needs.
+template <int PSY>
 TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
                            const TlConfig *TL_RESTRICT C, const TlPsy2Tables *TL_RESTRICT P2, TlPsy2State *TL_RESTRICT S2,
                            const TlPcmView &pv, TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, TlTaps *taps, long long *sp)
@@ -1084,7 +1086,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
 
     TL_STAMP(sp, 2);
     // ---- K3/K4: psychoacoustic model -> SMR (toolame.c:361-452) ----
-    if (C->psy == 0) {                                           // psycho_0.c:52-68
+    if constexpr (PSY == 0) {                                    // psycho_0.c:52-68
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
         if (c < nch) {
@@ -1092,9 +1094,9 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             w.smr[c][sb] = 2.0 * (30.0 - m) - C->p0_athmin[sb];
         }
         TL_LANES_END
-    } else if (C->psy == 2) {
+    } else if constexpr (PSY == 2) {
         for (int ch = 0; ch < nch; ch++) tl_psy2(w, T, P2, S2, pv, ch);
-    } else if (C->psy == 1) {
+    } else if constexpr (PSY == 1) {
         for (int ch = 0; ch < nch; ch++) tl_psy1(w, T, B, C, pv, ch, sp ? sp + 8 + 8 * ch : nullptr);
     } else {
         for (int ch = 0; ch < nch; ch++) tl_psy3(w, T, B, C, pv, ch, sp ? sp + 8 + 8 * ch : nullptr);
@@ -1410,7 +1412,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     if (taps) {
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
-        taps->smr[c][sb] = (c < nch && (C->psy != 1 || sb < sblimit)) ? w.smr[c][sb] : 0.0;   // psy 1 leaves sb >= sblimit unset
+        taps->smr[c][sb] = (c < nch && (PSY != 1 || sb < sblimit)) ? w.smr[c][sb] : 0.0;   // psy 1 leaves sb >= sblimit unset
         taps->scfsi[c][sb] = w.scfsi[c][sb]; taps->bit_alloc[c][sb] = w.balloc[c][sb];
         for (int gr = 0; gr < 3; gr++) taps->scalar[c][gr][sb] = w.scf[c][gr][sb];
         if (lane == 0) { taps->adb_left = adb_left; taps->mode = mode; taps->mode_ext = mode_ext; taps->jsbound = jsbound; taps->crc16 = (int)crc16; }
@@ -1447,6 +1449,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
 
 // ------------------------------------------------------------------------------------------
 // A wave encodes `nframes` consecutive frames of stream `s`; state stays in LDS across frames.
+template <int PSY>
 TL_FN void tl_encode_stream(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const TlLaunch &A, int s)
 {
     const TlTables *T = A.tables;
@@ -1483,7 +1486,7 @@ TL_FN void tl_encode_stream(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, co
             for (int i = lane; i < xl; i += 64) w.xpad[i] = A.xpad[slot * TL_MAX_XPAD + i];
             TL_LANES_END
         }
-        tl_encode_frame(w, T, B, C, A.psy2_tables ? &A.psy2_tables[C->psy2_tab] : nullptr, A.psy2_state ? &A.psy2_state[s] : nullptr, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, A.taps ? &A.taps[slot] : nullptr,
+        tl_encode_frame<PSY>(w, T, B, C, A.psy2_tables ? &A.psy2_tables[C->psy2_tab] : nullptr, A.psy2_state ? &A.psy2_state[s] : nullptr, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, A.taps ? &A.taps[slot] : nullptr,
                         A.stamps ? A.stamps + slot * 32 : nullptr);
         done++;
     }

@@ -20,7 +20,9 @@ static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 #define TL_WAVES_PER_BLOCK 4
 
 // One wavefront per stream: block = TL_WAVES_PER_BLOCK independent waves, no
-// block-level barrier anywhere; each wave keeps its stream's working set in its own LDS slice.
+// block-level barrier after the table copy; each wave keeps its stream's working set in its own LDS slice.
+// One kernel per psy model (template), launched over the streams that use it (A.stream_list).
+template <int PSY>
 __global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK, 2) tl_encode_kernel(TlLaunch A)
 {
     __shared__ TlBlockShared shared;                 // tables on dependent-load chains, one copy per workgroup
@@ -33,9 +35,9 @@ __global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK, 2) tl_encode_kernel(T
     }
     __syncthreads();                                 // the only workgroup barrier: the waves are independent from here on
     const int wave = (int)(threadIdx.x >> 6);
-    const int s = (int)blockIdx.x * TL_WAVES_PER_BLOCK + wave;
-    if (s >= A.nstreams) return;
-    tl_encode_stream(lds[wave], &shared, A, s);
+    const int k = (int)blockIdx.x * TL_WAVES_PER_BLOCK + wave;
+    if (k >= A.nlist) return;
+    tl_encode_stream<PSY>(lds[wave], &shared, A, A.stream_list[k]);
 }
 
 // pending frame (big-endian words in the stream state) -> bytes
@@ -60,6 +62,8 @@ struct tlb_batch {
     TlConfig *d_configs = nullptr;
     int32_t *d_stream_cfg = nullptr;
     TlStreamState *d_state = nullptr;
+    int32_t *d_list[4] = {nullptr, nullptr, nullptr, nullptr};   // stream ids per psy model
+    int n_list[4] = {0, 0, 0, 0};
     TlPsy2Tables *d_psy2_tables = nullptr;     // 4 slots (tl_psy2_slot), only when a stream uses psy 2
     TlPsy2State *d_psy2_state = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -90,6 +94,7 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_configs) (void)hipFree(b->d_configs);
     if (b->d_stream_cfg) (void)hipFree(b->d_stream_cfg);
     if (b->d_state) (void)hipFree(b->d_state);
+    for (int p = 0; p < 4; p++) if (b->d_list[p]) (void)hipFree(b->d_list[p]);
     if (b->d_psy2_tables) (void)hipFree(b->d_psy2_tables);
     if (b->d_psy2_state) (void)hipFree(b->d_psy2_state);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -135,6 +140,14 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
     HIPCHK(hipMemcpy(b->d_stream_cfg, b->h_stream_cfg.data(), sizeof(int32_t) * nstreams, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&b->d_state, sizeof(TlStreamState) * (size_t)nstreams));
     HIPCHK(hipMemset(b->d_state, 0, sizeof(TlStreamState) * (size_t)nstreams));
+    for (int p = 0; p < 4; p++) {
+        std::vector<int32_t> ids;
+        for (int s2 = 0; s2 < nstreams; s2++) if (b->h_configs[b->h_stream_cfg[s2]].psy == p) ids.push_back(s2);
+        b->n_list[p] = (int)ids.size();
+        if (ids.empty()) continue;
+        HIPCHK(hipMalloc(&b->d_list[p], sizeof(int32_t) * ids.size()));
+        HIPCHK(hipMemcpy(b->d_list[p], ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice));
+    }
     bool any2 = false;
     for (auto &c : b->h_configs) any2 |= c.psy == 2;
     if (any2) {
@@ -189,10 +202,19 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
     A.out = d_out; A.taps = d_taps; A.stamps = d_stamps;
     A.psy2_tables = b->d_psy2_tables; A.psy2_state = b->d_psy2_state;
     A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride;
-    const int blocks = (b->nstreams + TL_WAVES_PER_BLOCK - 1) / TL_WAVES_PER_BLOCK;
     HIPCHK(hipEventRecord(b->ev0, st));
-    hipLaunchKernelGGL(tl_encode_kernel, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);
-    HIPCHK(hipGetLastError());
+    for (int p = 0; p < 4; p++) {
+        if (!b->n_list[p]) continue;
+        A.stream_list = b->d_list[p]; A.nlist = b->n_list[p];
+        const int blocks = (b->n_list[p] + TL_WAVES_PER_BLOCK - 1) / TL_WAVES_PER_BLOCK;
+        switch (p) {
+        case 0: hipLaunchKernelGGL(tl_encode_kernel<0>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A); break;
+        case 1: hipLaunchKernelGGL(tl_encode_kernel<1>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A); break;
+        case 2: hipLaunchKernelGGL(tl_encode_kernel<2>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A); break;
+        default: hipLaunchKernelGGL(tl_encode_kernel<3>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A); break;
+        }
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(b->ev1, st));
     b->last_stream = st; b->timed = true;
     b->frames += nframes;

@@ -64,7 +64,13 @@ int emu_encode(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, co
     A.psy2_state = e->psy2_state.empty() ? nullptr : e->psy2_state.data();
     A.nstreams = (int)e->state.size(); A.nframes = nframes; A.out_stride = out_stride;
     static thread_local TlWaveLds w;
-    for (int s = 0; s < A.nstreams; s++) tl_encode_stream(w, &e->tables.shared, A, s);
+    for (int s = 0; s < A.nstreams; s++)
+        switch (e->configs[e->stream_cfg[s]].psy) {
+        case 0: tl_encode_stream<0>(w, &e->tables.shared, A, s); break;
+        case 1: tl_encode_stream<1>(w, &e->tables.shared, A, s); break;
+        case 2: tl_encode_stream<2>(w, &e->tables.shared, A, s); break;
+        default: tl_encode_stream<3>(w, &e->tables.shared, A, s); break;
+        }
     return 0;
 }
 int emu_pending(void *h, int s, uint8_t *out)
