@@ -67,6 +67,9 @@ void tl_build_tables(TlTables *T)
             if (f >= 0) modf(f + 0.5, &ip); else modf(f - 0.5, &ip);
             T->dct[i][k] = ip * 1e-9;
         }
+    for (int r = 0; r < 16; r++)
+        for (int k = 0; k < 16; k++)
+            for (int par = 0; par < 2; par++) T->shared.dct_t[k][par][r] = T->dct[r][2 * k + par];
     // Hann window with the sqrt(8/3)/N normalisation (psycho_1.c:225-233, psycho_3.c:135-141)
     const double sqrt_8_over_3 = pow(8.0 / 3.0, 0.5);
     for (int i = 0; i < 1024; i++) T->hann[i] = sqrt_8_over_3 * 0.5 * (1 - cos(2.0 * kRefPi * i / 1024)) / 1024;

@@ -57,6 +57,13 @@ TL_FN void tlh_exscan_i32(int (&d)[64], const int (&v)[64]) { int s = 0; for (in
 #define TL_OTHER(name, idx, src) tld_shfl_f64(name idx, src)
 #define TL_ATOMIC_OR(p, v) atomicOr((p), (v))
 TL_FN double tld_shfl_f64(double v, int src) { return __shfl(v, src, 64); }
+TL_FN double tld_swap1_f64(double v) {
+    // value of lane^1 (the other channel of the same subband): DPP quad_perm [1,0,3,2], no LDS crossbar
+    const uint64_t u = tl_d2u(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, 0xB1, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), 0xB1, 0xf, 0xf, true);
+    return tl_u2d(((uint64_t)hi << 32) | lo);
+}
 TL_FN uint32_t tld_min_u32(uint32_t v) {
     // DPP reduction (gfx9): row_shr 1,2,4,8 -> row minimum in lane 15 of each row; row_bcast15 / row_bcast31
     // carry it across rows; lane 63 holds the wave minimum.  Shifted-in lanes read the identity.
@@ -75,18 +82,19 @@ TL_FN uint64_t tld_min_u64(uint64_t v) {
     const uint32_t mlo = tld_min_u32(hi == mhi ? lo : 0xffffffffu);
     return ((uint64_t)mhi << 32) | mlo;
 }
-TL_FN int tld_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+TL_FN int tld_incl_scan_i32(int v) {
+    // inclusive prefix sum over the 64 lanes with DPP only (no ds_bpermute, no per-lane address registers):
+    // Hillis-Steele inside each row of 16 (row_shr 1,2,4,8), then row_bcast15 / row_bcast31 across rows.
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return v;
 }
-TL_FN int tld_exscan_i32(int v) {
-    const int lane = (int)(threadIdx.x & 63u);
-    int s = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(s, o, 64); if (lane >= o) s += t; }
-    return s - v;
-}
+TL_FN int tld_sum_i32(int v) { return __builtin_amdgcn_readlane(tld_incl_scan_i32(v), 63); }
+TL_FN int tld_exscan_i32(int v) { return tld_incl_scan_i32(v) - v; }
 #define TL_BALLOT(name) ((uint64_t)__ballot(name))
 #define TL_WAVE_MIN_U64(name) tld_min_u64(name)
 #define TL_WAVE_SUM_I32(name) tld_sum_i32(name)
@@ -121,7 +129,7 @@ TL_FN int tld_exscan_i32(int v) {
 // Per-wave LDS working set.
 #define TL_CAND_MAX 256              // local maxima with passing right side (<= 249)
 #define TL_FB_BATCH 3                // filterbank blocks per LDS round trip (36 = 12 x 3)
-#define TL_TONE_MAX 96               // confirmed tones per channel-frame (hard bound ~75: erasure spacing)
+#define TL_TONE_MAX 80               // confirmed tones per channel-frame (hard bound ~75: erasure spacing)
 #define TL_MASKER_MAX 128            // tones + noise components after decimation
 struct TlWaveLds {
     // Stage-exclusive 8 KB: [PCM history | frame] + filterbank scratch  ->  FHT buffer / energy (and, once the
@@ -964,12 +972,11 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     // Matrixing stage: lane (ch,sb) owns the even-k chain s0 (sb<16) or the odd-k chain s1 (sb>=16) of row
     // min(sb,31-sb); the two halves swap values (a move, not a re-association): s[i]=s0+s1, s[31-i]=s0-s1.
     {
-        PA(double, ca, 8); PA(double, cb, 8); PA(double, cm, 16);
+        PA(double, ca, 8); PA(double, cb, 8);
         TL_LANES_BEGIN
-        const int i = lane >> 1, sb = lane >> 1, r = sb < 16 ? sb : 31 - sb, par = sb < 16 ? 0 : 1;
+        const int i = lane >> 1;
         const int ya = i == 0 ? 16 : i + 16, yb = i == 0 ? 16 : (i <= 16 ? 16 - i : 80 - i);
         for (int j = 0; j < 8; j++) { L(ca)[j] = T->enwindow[ya + 64 * j]; L(cb)[j] = T->enwindow[yb + 64 * j]; }
-        for (int k = 0; k < 16; k++) L(cm)[k] = T->dct[r][2 * k + par];
         TL_LANES_END
 #ifndef TL_EMULATE
 #pragma unroll
@@ -998,15 +1005,15 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             TL_LANES_END
             PA(double, part, TL_FB_BATCH);
             TL_LANES_BEGIN
-            const int c = lane & 1, sb = lane >> 1, par = sb < 16 ? 0 : 1;
-            for (int bb = 0; bb < TL_FB_BATCH; bb++) {
-                double acc = 0.0;
-                if (c < nch) {
-                    const double *yp = w.u.fbk.yp[bb][c];
-                    for (int k = 0; k < 16; k++) acc += L(cm)[k] * yp[2 * k + par];
+            const int c = lane & 1, sb = lane >> 1, par = sb < 16 ? 0 : 1, r = sb < 16 ? sb : 31 - sb;
+            double acc[TL_FB_BATCH];
+            for (int bb = 0; bb < TL_FB_BATCH; bb++) acc[bb] = 0.0;
+            if (c < nch)
+                for (int k = 0; k < 16; k++) {
+                    const double m = B->dct_t[k][par][r];               // shared LDS copy, conflict-free per k
+                    for (int bb = 0; bb < TL_FB_BATCH; bb++) acc[bb] += m * w.u.fbk.yp[bb][c][2 * k + par];
                 }
-                L(part)[bb] = acc;
-            }
+            for (int bb = 0; bb < TL_FB_BATCH; bb++) L(part)[bb] = acc[bb];
             TL_LANES_END
             PA(double, oth, TL_FB_BATCH);
 #ifdef TL_EMULATE
@@ -1061,7 +1068,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
 #ifdef TL_EMULATE
                 for (int lane = 0; lane < 64; ++lane) other[lane] = smp[lane ^ 1][gr * 12 + j];
 #else
-                other = __shfl_xor(smp[gr * 12 + j], 1, 64);
+                other = tld_swap1_f64(smp[gr * 12 + j]);
 #endif
                 TL_LANES_BEGIN
                 double t = fabs(.5 * (L(smp)[gr * 12 + j] + L(other)));     // ch0 lane: .5*(L+R)
@@ -1317,7 +1324,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
 #else
             if (any_joint) {
 #pragma unroll
-                for (int x = 0; x < 3; x++) oth[x] = __shfl_xor(smp[gr * 12 + j0 + x], 1, 64);
+                for (int x = 0; x < 3; x++) oth[x] = tld_swap1_f64(smp[gr * 12 + j0 + x]);
             } else { oth[0] = oth[1] = oth[2] = 0.0; }
 #endif
             TL_LANES_BEGIN

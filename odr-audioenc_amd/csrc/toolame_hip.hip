@@ -34,10 +34,12 @@ __global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK, 2) tl_encode_kernel(T
         for (int i = (int)threadIdx.x; i < (int)(sizeof(TlBlockShared) / 8); i += 64 * TL_WAVES_PER_BLOCK) dst[i] = src[i];
     }
     __syncthreads();                                 // the only workgroup barrier: the waves are independent from here on
-    const int wave = (int)(threadIdx.x >> 6);
+    // wave-uniform by construction; say so, or every pointer derived from the stream id lives in VGPRs
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int k = (int)blockIdx.x * TL_WAVES_PER_BLOCK + wave;
     if (k >= A.nlist) return;
-    tl_encode_stream<PSY>(lds[wave], &shared, A, A.stream_list[k]);
+    const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
+    tl_encode_stream<PSY>(lds[wave], &shared, A, s);
 }
 
 // pending frame (big-endian words in the stream state) -> bytes
