@@ -60,6 +60,10 @@ void tl_build_tables(TlTables *T)
             T->shared.bits12_line[l][b] = (int16_t)(12 * TL_GROUP[q] * TL_BITS[q]);
         }
     for (int i = 0; i < 64; i++) T->shared.scalefactor[i] = T->scalefactor[i];
+    {   // powers of x modulo the CRC-16 polynomial 0x8005 (CRC16_POLYNOMIAL, common.h:45)
+        unsigned v = 1;
+        for (int e = 0; e < 384; e++) { T->crc_xpow[e] = (uint16_t)v; v <<= 1; if (v & 0x10000u) v = (v ^ 0x18005u) & 0xffffu; }
+    }
     // matrixing coefficients: cos scaled by 1e9, rounded half away from zero, scaled back (subband.c:125-137)
     for (int i = 0; i < 16; i++)
         for (int k = 0; k < 32; k++) {

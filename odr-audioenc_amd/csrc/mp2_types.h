@@ -41,6 +41,7 @@ struct TlTables {
     uint8_t step_index[9][16];
     uint8_t nbal_line[9];
     uint8_t pad_[3];
+    uint16_t crc_xpow[384];      // x^e mod (x^16+x^15+x^2+1), e = 0..383: lets lanes fold CRC-16 chunks in parallel (crc.c:43-56)
     TlBlockShared shared;
 };
 

@@ -35,10 +35,12 @@
 TL_FN uint64_t tlh_ballot(const bool (&p)[64]) { uint64_t m = 0; for (int i = 0; i < 64; i++) if (p[i]) m |= 1ull << i; return m; }
 TL_FN uint64_t tlh_min_u64(const uint64_t (&v)[64]) { uint64_t m = v[0]; for (int i = 1; i < 64; i++) if (v[i] < m) m = v[i]; return m; }
 TL_FN int tlh_sum_i32(const int (&v)[64]) { int s = 0; for (int i = 0; i < 64; i++) s += v[i]; return s; }
+TL_FN uint32_t tlh_xor_u32(const uint32_t (&v)[64]) { uint32_t s = 0; for (int i = 0; i < 64; i++) s ^= v[i]; return s; }
 TL_FN void tlh_exscan_i32(int (&d)[64], const int (&v)[64]) { int s = 0; for (int i = 0; i < 64; i++) { d[i] = s; s += v[i]; } }
 #define TL_BALLOT(name) tlh_ballot(name)
 #define TL_WAVE_MIN_U64(name) tlh_min_u64(name)
 #define TL_WAVE_SUM_I32(name) tlh_sum_i32(name)
+#define TL_WAVE_XOR_U32(name) tlh_xor_u32(name)
 #define TL_WAVE_EXSCAN_I32(dst, src) tlh_exscan_i32(dst, src)
 #define TL_UNI_I(x) (x)
 #define TL_READLANE_I32(name, l) name[l]
@@ -93,11 +95,22 @@ TL_FN int tld_incl_scan_i32(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return v;
 }
+TL_FN uint32_t tld_xor_u32(uint32_t x) {
+    int v = (int)x;
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
 TL_FN int tld_sum_i32(int v) { return __builtin_amdgcn_readlane(tld_incl_scan_i32(v), 63); }
 TL_FN int tld_exscan_i32(int v) { return tld_incl_scan_i32(v) - v; }
 #define TL_BALLOT(name) ((uint64_t)__ballot(name))
 #define TL_WAVE_MIN_U64(name) tld_min_u64(name)
 #define TL_WAVE_SUM_I32(name) tld_sum_i32(name)
+#define TL_WAVE_XOR_U32(name) tld_xor_u32(name)
 #define TL_WAVE_EXSCAN_I32(dst, src) dst = tld_exscan_i32(src)
 #define TL_UNI_I(x) __builtin_amdgcn_readfirstlane(x)
 #define TL_READLANE_I32(name, l) __builtin_amdgcn_readlane(name, l)
@@ -441,12 +454,17 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         const double *term = w.u.fft;
         const int lo = C->p1_cbound[lane], hi = C->p1_cbound[lane + 1];
         double weight = 0.0, sum = TL_DBMIN;
+        // operands of line j+1 are fetched while the dB-sum chain works on line j (index hi stays inside the arrays)
+        double p = w.px[lo], tm = term[lo];
+        int ty = w.ptype[lo];
         for (int j = lo; j < hi; j++) {
-            const double p = w.px[j];
-            if (w.ptype[j] != TL_T_TONE && p != TL_DBMIN) {
+            const double pn = w.px[j + 1], tmn = term[j + 1];
+            const int tyn = w.ptype[j + 1];
+            if (ty != TL_T_TONE && p != TL_DBMIN) {
                 sum = tl_add_db(db, p, sum);
-                weight += term[j];
+                weight += tm;
             }
+            p = pn; tm = tmn; ty = tyn;
         }
         int centre;
         if (sum <= TL_DBMIN) centre = (hi + lo) / 2;
@@ -748,9 +766,11 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     if (lane < nb) {
         const int lo = C->p3_cbidx[lane], hi = C->p3_cbidx[lane + 1];
         double sum = TL_DBMIN, esum = 0, cw = 0;
+        double p = w.px[lo], en = energy[lo];
         for (int j = lo; j < hi; j++) {
-            double p = w.px[j];
-            if (p != TL_DBMIN) { sum = tl_add_db(db, p, sum); esum += energy[j]; cw += (j - lo) * energy[j]; }
+            const double pn = w.px[j + 1], enn = energy[j + 1];      // fetched one line ahead of the chain
+            if (p != TL_DBMIN) { sum = tl_add_db(db, p, sum); esum += en; cw += (j - lo) * en; }
+            p = pn; en = enn;
         }
         // esum == 0: the reference indexes with (int)(0/0) and segfaults; defined as the band centre
         int centre = (sum <= TL_DBMIN || esum == 0) ? (lo + hi) / 2 : lo + (int)(cw / esum);
@@ -976,7 +996,9 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         TL_LANES_BEGIN
         const int i = lane >> 1;
         const int ya = i == 0 ? 16 : i + 16, yb = i == 0 ? 16 : (i <= 16 ? 16 - i : 80 - i);
-        for (int j = 0; j < 8; j++) { L(ca)[j] = T->enwindow[ya + 64 * j]; L(cb)[j] = T->enwindow[yb + 64 * j]; }
+        // the reference scales the sample, (pcm/32768)*C (subband.c:233,249); scaling the coefficient instead is the
+        // same real product rounded once (2^-15 is exact, nothing underflows), so the bits are identical
+        for (int j = 0; j < 8; j++) { L(ca)[j] = T->enwindow[ya + 64 * j] / 32768; L(cb)[j] = T->enwindow[yb + 64 * j] / 32768; }
         TL_LANES_END
 #ifndef TL_EMULATE
 #pragma unroll
@@ -993,11 +1015,11 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
                     // X[k] = pcm[t0 + 31 - k], t0 = index of the block's first new sample
                     const int16_t *pa = &w.u.fbk.pcm[c][TL_HIST + 32 * (b0 + bb) + 31 - ya];
                     const int16_t *pb = &w.u.fbk.pcm[c][TL_HIST + 32 * (b0 + bb) + 31 - yb];
-                    double ta = ((double)pa[0] / 32768) * L(ca)[0];
-                    double tb = ((double)pb[0] / 32768) * L(cb)[0];
+                    double ta = (double)pa[0] * L(ca)[0];
+                    double tb = (double)pb[0] * L(cb)[0];
                     for (int j = 1; j < 8; j++) {
-                        ta += ((double)pa[-64 * j] / 32768) * L(ca)[j];
-                        tb += ((double)pb[-64 * j] / 32768) * L(cb)[j];
+                        ta += (double)pa[-64 * j] * L(ca)[j];
+                        tb += (double)pb[-64 * j] * L(cb)[j];
                     }
                     w.u.fbk.yp[bb][c][i] = i == 0 ? ta : (i <= 16 ? ta + tb : ta - tb);
                 }
@@ -1197,6 +1219,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     {   // a_bit_allocation_new (encode_new.c:1078-1187).  Every lane carries its cell's mnr / used / ba and
         // the price of its next step; one wave arg-min + one uniform comparison per iteration.
         PV(double, mnr); PV(int, used); PV(int, ba); PV(int, nbits); PV(int, cost);
+        PV(double, mnr_nx); PV(int, cost_nx);                       // values of the NEXT step, fetched one win ahead
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
         const bool live = c < nch && sb < sblimit;
@@ -1205,6 +1228,8 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         L(nbits) = (sb < sblimit && c < (sb < jsbound ? nch : 1)) ? L(a_nbal) : 0;
         // first step of a cell: samples + scfsi + scalefactors (both channels above jsbound), :1139-1147
         L(cost) = live ? B->bits12_line[L(a_ln)][1] + 2 + L(a_sfs) + ((nch == 2 && sb >= jsbound) ? 2 + L(a_sfs_o) : 0) : 0;
+        L(mnr_nx) = live ? B->snr_line[L(a_ln)][1] - L(a_smr) : 0.0;
+        L(cost_nx) = live ? B->bits12_line[L(a_ln)][2] - B->bits12_line[L(a_ln)][1] : 0;
         TL_LANES_END
         const int bbal = TL_WAVE_SUM_I32(nbits);
         const int ad = adb - (bbal + 16 + 32);
@@ -1234,9 +1259,11 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
                 if (fits) {
                     const int nba = L(ba) + 1;
                     L(ba) = nba;
-                    L(mnr) = B->snr_line[L(a_ln)][nba] - L(a_smr);
+                    L(mnr) = L(mnr_nx);                              // == snr_line[ln][nba] - smr
+                    L(cost) = L(cost_nx);                            // == bits12[nba+1] - bits12[nba]
                     L(used) = (nba >= (1 << L(a_nbal)) - 1) ? 2 : 1;
-                    L(cost) = B->bits12_line[L(a_ln)][(nba + 1) & 15] - B->bits12_line[L(a_ln)][nba];
+                    L(mnr_nx) = B->snr_line[L(a_ln)][(nba + 1) & 15] - L(a_smr);
+                    L(cost_nx) = B->bits12_line[L(a_ln)][(nba + 2) & 15] - B->bits12_line[L(a_ln)][(nba + 1) & 15];
                 } else L(used) = 2;
             }
             TL_LANES_END
@@ -1360,20 +1387,30 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
 
     TL_STAMP(sp, 5);
     // CRC-16 over header bits 16..31, bit_alloc and scfsi fields (crc.c:12-41); one lane, bit-serial
-    unsigned crc16 = 0xffff;
+    // Protected message = frame bits [16,32) then [48,p_scf).  The CRC register update is linear over GF(2), so
+    // lane L folds message bits [32L,32L+32) on its own (lane 0 also carries the 0xffff preset) and the chunks
+    // are combined as sum_L R_L * x^(bits after chunk L) mod P, with x^e mod P from a table; one XOR-reduce.
+    unsigned crc16;
     {
-        // bits [16,32) of word 0, then bits [48, p_scf); one LDS read per 32-bit word
-        const int lastw = (p_scf - 1) >> 5;
-        for (int wi = 0; wi <= lastw; wi++) {
-            const uint32_t wv = (uint32_t)TL_UNI_I((int)frame[wi]);
-            const int lo = wi == 0 ? 16 : wi == 1 ? 16 : 0;                  // skip header bits 0..15 and the CRC field 32..47
-            const int hi = (wi == lastw) ? ((p_scf - 1) & 31) + 1 : 32;
-            for (int bit = lo; bit < hi; bit++) {
-                const unsigned d = (wv >> (31 - bit)) & 1u;
-                const unsigned fb = ((crc16 >> 15) ^ d) & 1u;
-                crc16 = ((crc16 << 1) & 0xffffu) ^ (fb ? 0x8005u : 0u);
+        const int n = 16 + (p_scf - 48);
+        PV(uint32_t, part);
+        TL_LANES_BEGIN
+        uint32_t acc = 0;
+        if (32 * lane < n) {
+            const uint32_t chunk = lane == 0 ? ((frame[0] & 0xffffu) << 16) | (frame[1] & 0xffffu) : frame[lane + 1];
+            const int cnt = n - 32 * lane < 32 ? n - 32 * lane : 32;
+            unsigned r = lane == 0 ? 0xffffu : 0u;
+            for (int bit = 0; bit < cnt; bit++) {
+                const unsigned d = (chunk >> (31 - bit)) & 1u;
+                const unsigned fb = ((r >> 15) ^ d) & 1u;
+                r = ((r << 1) & 0xffffu) ^ (fb ? 0x8005u : 0u);
             }
+            const int after = n - 32 * lane - cnt;
+            for (int b16 = 0; b16 < 16; b16++) if ((r >> b16) & 1u) acc ^= T->crc_xpow[b16 + after];
         }
+        L(part) = acc;
+        TL_LANES_END
+        crc16 = TL_WAVE_XOR_U32(part) & 0xffffu;
     }
     // ScF-CRC (crc.c:58-97, toolame.c:527-542).  Every (sb,ch) lane packs the 3 MSBs of the scalefactors it
     // transmits (crc.c:83-96); lanes 0..dab_ext-1 then fold the records of their band group in (sb,ch) order.
