@@ -6,8 +6,8 @@
 // ulp, so the device path carries its own implementation built ONLY from IEEE-754 + - * / and
 // integer operations (no FMA contraction: the translation unit is compiled -ffp-contract=off).
 // The same source compiled for the host gives bit-identical results, which is what lets the CPU
-// test-suite check the device algorithm exactly.  Accuracy: < 1 ulp (log10), < 1 ulp (pow10) --
-// measured against glibc in tests/test_tl_math.py; the residual last-ulp differences against
+// test-suite check the device algorithm exactly.  Accuracy: within 2 ulp (log10) / 1 ulp (pow10, log, exp,
+// sin, cos, atan2) of glibc -- tests/test_emu_parity.py; the residual last-ulp differences against
 // glibc only matter when a dB value lands within 1 ulp of a decision threshold.
 //
 // Algorithm: the classic fdlibm/FreeBSD msun kernels (k_log.h + e_log10.c hi/lo recombination,
