@@ -103,6 +103,18 @@ int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t
 int tlb_flush_host(tlb_batch *b, uint8_t *out);
 int tlb_flush_device(tlb_batch *b, uint8_t *d_out, void *hip_stream);
 
+/* Caller-side per-frame glue folded into the batch: what AudioEnc::run() does between the input
+ * queue and toolame_encode_frame() -- linear gain with the reference's double-multiply-and-truncate and the positive
+ * peak level per channel (src/odr-audioenc.cpp:1030-1051), de-interleaving into `short[2][1152]` (:1139-1152).
+ *   d_interleaved int16 [nframes][nstreams][2304]: s16le L R L R ... (mono streams: 1152 samples, rest ignored)
+ *   d_pcm         int16 [nframes][nstreams][2][1152]  -- exactly what tlb_encode_device() takes
+ *   d_peaks       int16 [nframes][nstreams][2]  (max(0, samples) of the "left"/"right" slots; the caller's silence
+ *                 detection is `max(peaks) == 0`, odr-audioenc.cpp:1064)
+ * tlb_set_gain_db(stream = -1) sets every stream; gain 0 dB leaves samples untouched like the reference. */
+int tlb_set_gain_db(tlb_batch *b, int stream, double gain_db);
+int tlb_ingest_device(tlb_batch *b, const int16_t *d_interleaved, int nframes, int16_t *d_pcm, int16_t *d_peaks, void *hip_stream);
+int tlb_ingest_host(tlb_batch *b, const int16_t *interleaved, int nframes, int16_t *pcm, int16_t *peaks);
+
 /* Diagnostic only: per-stage cycle stamps [nframes][nstreams][32] (csrc/mp2_wave.h TL_STAMP), host buffers. */
 int tlb_encode_host_stamps(tlb_batch *b, const int16_t *pcm, int nframes, long long *stamps);
 

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 #include <deque>
@@ -42,6 +43,55 @@ __global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK, 2) tl_encode_kernel(T
     tl_encode_stream<PSY>(lds[wave], &shared, A, s);
 }
 
+// Ingest glue of the caller (src/odr-audioenc.cpp:1030-1051 gain + peak, :1139-1152
+// de-interleave): interleaved s16le -> planar [2][1152], optional linear gain with the reference's
+// double-multiply-and-truncate, positive peak per channel.  Pure streaming kernel: 16 B loads, 8 B stores.
+// in  [nframes][nstreams][2304] int16 (L R L R ...; mono streams use the first 1152 values)
+// out [nframes][nstreams][2][1152] int16, peaks [nframes][nstreams][2] int16
+__global__ void __launch_bounds__(256) tl_ingest_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out,
+                                                       int16_t *__restrict__ peaks, const double *__restrict__ gain,
+                                                       const TlConfig *configs, const int32_t *stream_cfg, int nstreams)
+{
+    const size_t slot = blockIdx.x;
+    const int s = (int)(slot % (size_t)nstreams);
+    const int nch = configs[stream_cfg[s]].nch;
+    const double g = gain[s];
+    const int16_t *src = in + slot * 2304;
+    int16_t *dst = out + slot * 2304;
+    int pk0 = 0, pk1 = 0;
+    // the level loop of the reference always walks the buffer as L/R pairs, also in mono (odr-audioenc.cpp:1034-1051)
+    const int nquads = nch == 2 ? 288 : 144;                    // 16 bytes = 4 L/R pairs per step
+    for (int q = (int)threadIdx.x; q < nquads; q += 256) {
+        const uint4 v = ((const uint4 *)src)[q];
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+        int16_t l[4], r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int a = (int16_t)(w4[k] & 0xffff), b = (int16_t)(w4[k] >> 16);
+            if (g != 1.0) { a = (int16_t)(int)((double)a * g); b = (int16_t)(int)((double)b * g); }
+            l[k] = (int16_t)a; r[k] = (int16_t)b;
+            pk0 = a > pk0 ? a : pk0; pk1 = b > pk1 ? b : pk1;
+        }
+        if (nch == 2) {
+            ((uint2 *)dst)[q] = make_uint2((uint16_t)l[0] | ((uint32_t)(uint16_t)l[1] << 16), (uint16_t)l[2] | ((uint32_t)(uint16_t)l[3] << 16));
+            ((uint2 *)(dst + 1152))[q] = make_uint2((uint16_t)r[0] | ((uint32_t)(uint16_t)r[1] << 16), (uint16_t)r[2] | ((uint32_t)(uint16_t)r[3] << 16));
+        } else {                                                 // mono: consecutive samples, channel 0 only
+            ((uint4 *)dst)[q] = make_uint4((uint16_t)l[0] | ((uint32_t)(uint16_t)r[0] << 16), (uint16_t)l[1] | ((uint32_t)(uint16_t)r[1] << 16),
+                                           (uint16_t)l[2] | ((uint32_t)(uint16_t)r[2] << 16), (uint16_t)l[3] | ((uint32_t)(uint16_t)r[3] << 16));
+        }
+    }
+    if (nch == 1) for (int q = (int)threadIdx.x; q < 288; q += 256) ((uint2 *)(dst + 1152))[q] = make_uint2(0u, 0u);
+    __shared__ int red[2][4];
+    for (int o = 32; o; o >>= 1) { int t0 = __shfl_xor(pk0, o, 64), t1 = __shfl_xor(pk1, o, 64); pk0 = t0 > pk0 ? t0 : pk0; pk1 = t1 > pk1 ? t1 : pk1; }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = pk0; red[1][threadIdx.x >> 6] = pk1; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        int m = red[threadIdx.x][0];
+        for (int k = 1; k < 4; k++) m = red[threadIdx.x][k] > m ? red[threadIdx.x][k] : m;
+        peaks[slot * 2 + threadIdx.x] = (int16_t)m;
+    }
+}
+
 // pending frame (big-endian words in the stream state) -> bytes
 __global__ void tl_flush_kernel(const TlStreamState *state, const TlConfig *configs, const int32_t *stream_cfg,
                                 uint8_t *out, int nstreams, int out_stride)
@@ -64,6 +114,8 @@ struct tlb_batch {
     TlConfig *d_configs = nullptr;
     int32_t *d_stream_cfg = nullptr;
     TlStreamState *d_state = nullptr;
+    double *d_gain = nullptr;                    // linear gain per stream (ingest kernel)
+    std::vector<double> h_gain;
     int32_t *d_list[4] = {nullptr, nullptr, nullptr, nullptr};   // stream ids per psy model
     int n_list[4] = {0, 0, 0, 0};
     TlPsy2Tables *d_psy2_tables = nullptr;     // 4 slots (tl_psy2_slot), only when a stream uses psy 2
@@ -96,6 +148,7 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_configs) (void)hipFree(b->d_configs);
     if (b->d_stream_cfg) (void)hipFree(b->d_stream_cfg);
     if (b->d_state) (void)hipFree(b->d_state);
+    if (b->d_gain) (void)hipFree(b->d_gain);
     for (int p = 0; p < 4; p++) if (b->d_list[p]) (void)hipFree(b->d_list[p]);
     if (b->d_psy2_tables) (void)hipFree(b->d_psy2_tables);
     if (b->d_psy2_state) (void)hipFree(b->d_psy2_state);
@@ -142,6 +195,9 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
     HIPCHK(hipMemcpy(b->d_stream_cfg, b->h_stream_cfg.data(), sizeof(int32_t) * nstreams, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&b->d_state, sizeof(TlStreamState) * (size_t)nstreams));
     HIPCHK(hipMemset(b->d_state, 0, sizeof(TlStreamState) * (size_t)nstreams));
+    b->h_gain.assign((size_t)nstreams, 1.0);
+    HIPCHK(hipMalloc(&b->d_gain, sizeof(double) * (size_t)nstreams));
+    HIPCHK(hipMemcpy(b->d_gain, b->h_gain.data(), sizeof(double) * (size_t)nstreams, hipMemcpyHostToDevice));
     for (int p = 0; p < 4; p++) {
         std::vector<int32_t> ids;
         for (int s2 = 0; s2 < nstreams; s2++) if (b->h_configs[b->h_stream_cfg[s2]].psy == p) ids.push_back(s2);
@@ -282,6 +338,44 @@ int tlb_encode_host_stamps(tlb_batch *b, const int16_t *pcm, int nframes, long l
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(stamps, d_st, slots * 32 * sizeof(long long), hipMemcpyDeviceToHost));
     (void)hipFree(d_pcm); (void)hipFree(d_out); (void)hipFree(d_st);
+    return rc;
+}
+
+int tlb_set_gain_db(tlb_batch *b, int stream, double gain_db)
+{   // const double linear_gain_correction = pow(10.0, gain_dB / 20.0);  (src/odr-audioenc.cpp:1032)
+    if (!b || stream < -1 || stream >= b->nstreams) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    const double g = pow(10.0, gain_db / 20.0);
+    for (int s2 = 0; s2 < b->nstreams; s2++) if (stream < 0 || s2 == stream) b->h_gain[(size_t)s2] = g;
+    HIPCHK(hipMemcpy(b->d_gain, b->h_gain.data(), sizeof(double) * (size_t)b->nstreams, hipMemcpyHostToDevice));
+    return TLB_OK;
+}
+
+int tlb_ingest_device(tlb_batch *b, const int16_t *d_interleaved, int nframes, int16_t *d_pcm, int16_t *d_peaks, void *hip_stream)
+{
+    if (!b || !d_interleaved || !d_pcm || !d_peaks || nframes <= 0) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    hipLaunchKernelGGL(tl_ingest_kernel, dim3((unsigned)((size_t)nframes * (size_t)b->nstreams)), dim3(256), 0, (hipStream_t)hip_stream,
+                       d_interleaved, d_pcm, d_peaks, b->d_gain, b->d_configs, b->d_stream_cfg, b->nstreams);
+    HIPCHK(hipGetLastError());
+    return TLB_OK;
+}
+
+int tlb_ingest_host(tlb_batch *b, const int16_t *interleaved, int nframes, int16_t *pcm, int16_t *peaks)
+{
+    if (!b || !interleaved || !pcm || !peaks || nframes <= 0) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    const size_t slots = (size_t)nframes * (size_t)b->nstreams;
+    int16_t *d_in = nullptr, *d_out = nullptr, *d_pk = nullptr;
+    HIPCHK(hipMalloc(&d_in, slots * 2304 * 2));
+    HIPCHK(hipMalloc(&d_out, slots * 2304 * 2));
+    HIPCHK(hipMalloc(&d_pk, slots * 2 * 2));
+    HIPCHK(hipMemcpy(d_in, interleaved, slots * 2304 * 2, hipMemcpyHostToDevice));
+    int rc = tlb_ingest_device(b, d_in, nframes, d_out, d_pk, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(pcm, d_out, slots * 2304 * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(peaks, d_pk, slots * 2 * 2, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_pk);
     return rc;
 }
 

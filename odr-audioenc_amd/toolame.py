@@ -80,6 +80,9 @@ def load_library():
     L.tlb_last_kernel_ms.argtypes = [C.c_void_p]
     L.tlb_last_kernel_ms.restype = C.c_float
     L.tlb_version.restype = C.c_char_p
+    L.tlb_set_gain_db.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.tlb_ingest_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tlb_ingest_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.toolame_set_samplerate.argtypes = [C.c_long]
     L.toolame_set_channel_mode.argtypes = [C.c_char]
     L.toolame_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -181,6 +184,30 @@ class Batch:
         rc = self.L.tlb_flush_device(self.h, d_out_ptr, stream)
         if rc:
             raise ToolameError(rc, "tlb_flush_device")
+
+    # -- caller-side glue (gain, peak, de-interleave; src/odr-audioenc.cpp:1030-1051,1139-1152) ----
+    def set_gain_db(self, gain_db, stream=-1):
+        rc = self.L.tlb_set_gain_db(self.h, stream, float(gain_db))
+        if rc:
+            raise ToolameError(rc, "tlb_set_gain_db")
+
+    def ingest(self, interleaved):
+        """int16 [nframes, nstreams, 2304] interleaved s16le -> (planar [nframes, nstreams, 2, 1152], peaks [.., 2])"""
+        a = np.ascontiguousarray(interleaved, dtype=np.int16)
+        nf = a.shape[0]
+        if a.shape != (nf, self.nstreams, 2 * SAMPLES):
+            raise ToolameError(18, f"interleaved shape {a.shape}")
+        pcm = np.zeros((nf, self.nstreams, 2, SAMPLES), dtype=np.int16)
+        peaks = np.zeros((nf, self.nstreams, 2), dtype=np.int16)
+        rc = self.L.tlb_ingest_host(self.h, a.ctypes.data, nf, pcm.ctypes.data, peaks.ctypes.data)
+        if rc:
+            raise ToolameError(rc, "tlb_ingest_host")
+        return pcm, peaks
+
+    def ingest_device(self, d_in_ptr, nframes, d_pcm_ptr, d_peaks_ptr, stream=None):
+        rc = self.L.tlb_ingest_device(self.h, d_in_ptr, nframes, d_pcm_ptr, d_peaks_ptr, stream)
+        if rc:
+            raise ToolameError(rc, "tlb_ingest_device")
 
     def last_kernel_ms(self):
         return float(self.L.tlb_last_kernel_ms(self.h))

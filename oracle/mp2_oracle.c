@@ -1046,6 +1046,27 @@ int mp2o_get_table(const mp2o_enc *e, const char *name, double *out, int n)
     return len;
 }
 
+/* caller-side glue of AudioEnc::run(): gain + positive peak (src/odr-audioenc.cpp:1030-1051) and de-interleave
+   (:1139-1152).  `in` = 2304 int16 (s16le, L R L R ...; mono: 1152 samples).  gain_db as given to -g. */
+void mp2o_ingest(const short *in, int nch, double gain_db, short out[2][1152], short peaks[2])
+{
+    const double g = pow(10.0, gain_db / 20.0);
+    short buf[2304];
+    const int n = nch == 2 ? 2304 : 1152;
+    short pl = 0, pr = 0;
+    memcpy(buf, in, (size_t)n * sizeof(short));
+    for (int i = 0; i < n; i += 2) {                /* the level loop walks L/R pairs also in mono */
+        short l = buf[i], r = buf[i + 1];
+        if (g != 1.0) { l = (short)(int)(l * g); r = (short)(int)(r * g); buf[i] = l; buf[i + 1] = r; }
+        if (l > pl) pl = l;
+        if (r > pr) pr = r;
+    }
+    peaks[0] = pl; peaks[1] = pr;
+    memset(out, 0, 2 * 1152 * sizeof(short));
+    if (nch == 1) memcpy(out[0], buf, 1152 * sizeof(short));
+    else for (int i = 0; i < 1152; i++) { out[0][i] = buf[2 * i]; out[1][i] = buf[2 * i + 1]; }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* integer-only PCM generator (mirrored in tests/pcmgen.py)                                    */
 static uint32_t mix32(uint32_t x)

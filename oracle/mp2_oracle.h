@@ -78,6 +78,9 @@ void mp2o_debug_set_p3_power0(double v);
  * 6 low-level (+-1 LSB) noise.  Fills planar pcm[2][1152] for frame index `frame` of stream `seed`. */
 void mp2o_gen_pcm(uint32_t seed, int kind, int frame, short pcm[2][1152]);
 
+/* Caller-side glue (gain, positive peak, de-interleave): src/odr-audioenc.cpp:1030-1051,1139-1152. */
+void mp2o_ingest(const short *in, int nch, double gain_db, short out[2][1152], short peaks[2]);
+
 /* cpu_baseline helper: encode `nframes` frames of stream `seed` (kind 0) and return the number of
  * output bytes (all frames + finish); used only for timing. */
 long mp2o_bench_stream(long samplerate, char mode, int kbps, int psy, uint32_t seed, int nframes);

@@ -182,3 +182,35 @@ def test_errors(M):
                dict(pad_len=-1)):
         with pytest.raises(M.ToolameError):
             M.Batch([M.StreamConfig(**kw)])
+
+
+def test_ingest_gain_peak_deinterleave(M):
+    """the caller's gain / peak / de-interleave glue as a device pre-kernel, against the oracle
+    (src/odr-audioenc.cpp:1030-1051,1139-1152), then straight into the encoder."""
+    rng = np.random.default_rng(3)
+    cfgs = [M.StreamConfig(mode="j"), M.StreamConfig(mode="m", bitrate=64), M.StreamConfig(mode="s"), M.StreamConfig(mode="m", bitrate=64)]
+    gains = [0.0, -6.0, 3.5, 20.0]                       # +20 dB overflows int16: the reference wraps, so do we
+    nf = 3
+    raw = rng.integers(-32768, 32768, size=(nf, len(cfgs), 2304), dtype=np.int16)
+    raw[0, 0, :8] = [32767, -32768, 0, 1, -1, 12345, -12345, 2]
+    raw[2, 2] = 0                                        # digital silence -> peaks 0 (the caller's silence test)
+    b = M.Batch(cfgs)
+    for s, g in enumerate(gains):
+        b.set_gain_db(g, s)
+    pcm, peaks = b.ingest(raw)
+    L = O.lib()
+    for f in range(nf):
+        for s, c in enumerate(cfgs):
+            out = np.zeros((2, 1152), dtype=np.int16)
+            pk = np.zeros(2, dtype=np.int16)
+            src = np.ascontiguousarray(raw[f, s])
+            L.mp2o_ingest(src.ctypes.data, 1 if c.mode == "m" else 2, gains[s], out.ctypes.data, pk.ctypes.data)
+            assert np.array_equal(pcm[f, s], out), (f, s)
+            assert np.array_equal(peaks[f, s], pk), (f, s)
+    assert tuple(peaks[2, 2]) == (0, 0)
+    got, _ = b.encode(pcm)
+    tail = b.flush()
+    for s, c in enumerate(cfgs):
+        ref, _ = O.oracle_stream(pcm[:, s], mode=c.mode, kbps=c.bitrate, psy=c.psy_model)
+        assert got[s] + tail[s] == ref
+    b.close()
