@@ -115,6 +115,17 @@ int tlb_set_gain_db(tlb_batch *b, int stream, double gain_db);
 int tlb_ingest_device(tlb_batch *b, const int16_t *d_interleaved, int nframes, int16_t *d_pcm, int16_t *d_peaks, void *hip_stream);
 int tlb_ingest_host(tlb_batch *b, const int16_t *interleaved, int nframes, int16_t *pcm, int16_t *peaks);
 
+/* Egress framing of the step after the path (ZeroMQ part): one ODR-DabMux ZMQ message per frame,
+ * `struct zmq_frame_header_t` (src/Outputs.h:76-89: u16 version = 1, u16 encoder = ZMQ_ENCODER_MPEG_L2 = 2, u32 datasize,
+ * i16 audiolevel_left, i16 audiolevel_right, packed, little-endian) followed by the frame (Outputs.cpp:101-138).
+ *   d_frames uint8 [nframes][nstreams][tlb_out_stride()]   (tlb_encode_device output)
+ *   d_peaks  int16 [nframes][nstreams][2] or NULL (levels 0)  (tlb_ingest_device output)
+ *   d_msgs   uint8 [nframes][nstreams][tlb_zmq_msg_stride()]; message length of a stream = 12 + tlb_frame_bytes()
+ * Sockets, CURVE and EDI packetisation stay with the caller (out of scope). */
+int tlb_zmq_msg_stride(const tlb_batch *b);
+int tlb_zmq_frame_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_peaks, int nframes, uint8_t *d_msgs, void *hip_stream);
+int tlb_zmq_frame_host(tlb_batch *b, const uint8_t *frames, const int16_t *peaks, int nframes, uint8_t *msgs);
+
 /* Diagnostic only: per-stage cycle stamps [nframes][nstreams][32] (csrc/mp2_wave.h TL_STAMP), host buffers. */
 int tlb_encode_host_stamps(tlb_batch *b, const int16_t *pcm, int nframes, long long *stamps);
 

@@ -92,6 +92,26 @@ __global__ void __launch_bounds__(256) tl_ingest_kernel(const int16_t *__restric
     }
 }
 
+// ZeroMQ wire format of the step after the path (src/Outputs.h:76-99, Outputs.cpp:101-138):
+// packed header {u16 version=1, u16 encoder=2 (MPEG L2), u32 datasize, i16 level_left, i16 level_right} + frame bytes.
+// msgs [nslots][msg_stride]; one block per slot.
+__global__ void tl_zmq_frame_kernel(const uint8_t *__restrict__ frames, const int16_t *__restrict__ peaks, uint8_t *__restrict__ msgs,
+                                    const TlConfig *configs, const int32_t *stream_cfg, int nstreams, int out_stride, int msg_stride)
+{
+    const size_t slot = blockIdx.x;
+    const int s = (int)(slot % (size_t)nstreams);
+    const int n = configs[stream_cfg[s]].frame_bytes;
+    uint8_t *m = msgs + slot * (size_t)msg_stride;
+    if (threadIdx.x < 3) {
+        const int pl = peaks ? peaks[slot * 2] : 0, pr = peaks ? peaks[slot * 2 + 1] : 0;
+        const uint32_t w = threadIdx.x == 0 ? (1u | (2u << 16)) : threadIdx.x == 1 ? (uint32_t)n
+                                            : ((uint32_t)(uint16_t)pl | ((uint32_t)(uint16_t)pr << 16));
+        ((uint32_t *)m)[threadIdx.x] = w;
+    }
+    const uint32_t *src = (const uint32_t *)(frames + slot * (size_t)out_stride);
+    for (int i = (int)threadIdx.x; i < (n >> 2); i += (int)blockDim.x) ((uint32_t *)m)[3 + i] = src[i];
+}
+
 // pending frame (big-endian words in the stream state) -> bytes
 __global__ void tl_flush_kernel(const TlStreamState *state, const TlConfig *configs, const int32_t *stream_cfg,
                                 uint8_t *out, int nstreams, int out_stride)
@@ -376,6 +396,36 @@ int tlb_ingest_host(tlb_batch *b, const int16_t *interleaved, int nframes, int16
     HIPCHK(hipMemcpy(pcm, d_out, slots * 2304 * 2, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(peaks, d_pk, slots * 2 * 2, hipMemcpyDeviceToHost));
     (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_pk);
+    return rc;
+}
+
+int tlb_zmq_msg_stride(const tlb_batch *b) { return b ? 12 + b->out_stride : 0; }
+
+int tlb_zmq_frame_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_peaks, int nframes, uint8_t *d_msgs, void *hip_stream)
+{
+    if (!b || !d_frames || !d_msgs || nframes <= 0) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    hipLaunchKernelGGL(tl_zmq_frame_kernel, dim3((unsigned)((size_t)nframes * (size_t)b->nstreams)), dim3(128), 0, (hipStream_t)hip_stream,
+                       d_frames, d_peaks, d_msgs, b->d_configs, b->d_stream_cfg, b->nstreams, b->out_stride, 12 + b->out_stride);
+    HIPCHK(hipGetLastError());
+    return TLB_OK;
+}
+
+int tlb_zmq_frame_host(tlb_batch *b, const uint8_t *frames, const int16_t *peaks, int nframes, uint8_t *msgs)
+{
+    if (!b || !frames || !msgs || nframes <= 0) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    const size_t slots = (size_t)nframes * (size_t)b->nstreams, ms = 12 + (size_t)b->out_stride;
+    uint8_t *d_f = nullptr, *d_m = nullptr; int16_t *d_p = nullptr;
+    HIPCHK(hipMalloc(&d_f, slots * (size_t)b->out_stride));
+    HIPCHK(hipMalloc(&d_m, slots * ms));
+    HIPCHK(hipMemset(d_m, 0, slots * ms));
+    HIPCHK(hipMemcpy(d_f, frames, slots * (size_t)b->out_stride, hipMemcpyHostToDevice));
+    if (peaks) { HIPCHK(hipMalloc(&d_p, slots * 4)); HIPCHK(hipMemcpy(d_p, peaks, slots * 4, hipMemcpyHostToDevice)); }
+    int rc = tlb_zmq_frame_device(b, d_f, d_p, nframes, d_m, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(msgs, d_m, slots * ms, hipMemcpyDeviceToHost));
+    (void)hipFree(d_f); (void)hipFree(d_m); if (d_p) (void)hipFree(d_p);
     return rc;
 }
 

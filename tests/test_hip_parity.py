@@ -214,3 +214,28 @@ def test_ingest_gain_peak_deinterleave(M):
         ref, _ = O.oracle_stream(pcm[:, s], mode=c.mode, kbps=c.bitrate, psy=c.psy_model)
         assert got[s] + tail[s] == ref
     b.close()
+
+
+def test_zmq_frame_header(M):
+    """SURVEY 8f N2 (ZeroMQ part): struct zmq_frame_header_t + frame, src/Outputs.h:76-89, Outputs.cpp:101-138."""
+    import ctypes as C
+    import struct
+    cfgs = [M.StreamConfig(mode="j"), M.StreamConfig(mode="s", bitrate=192), M.StreamConfig(mode="m", bitrate=64)]
+    b = M.Batch(cfgs)
+    L = M.load_library()
+    L.tlb_zmq_msg_stride.argtypes = [C.c_void_p]
+    L.tlb_zmq_frame_host.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
+    nf = 2
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, size=(nf, 3, b.out_stride), dtype=np.uint8)
+    peaks = rng.integers(-5, 32768, size=(nf, 3, 2)).astype(np.int16)
+    ms = L.tlb_zmq_msg_stride(b.h)
+    assert ms == 12 + b.out_stride
+    msgs = np.zeros((nf, 3, ms), dtype=np.uint8)
+    assert L.tlb_zmq_frame_host(b.h, frames.ctypes.data, peaks.ctypes.data, nf, msgs.ctypes.data) == 0
+    for f in range(nf):
+        for s in range(3):
+            n = b.frame_bytes[s]
+            want = struct.pack("<HHIhh", 1, 2, n, int(peaks[f, s, 0]), int(peaks[f, s, 1])) + frames[f, s, :n].tobytes()
+            assert msgs[f, s, :12 + n].tobytes() == want, (f, s)
+    b.close()
