@@ -147,7 +147,7 @@ TL_FN int tld_exscan_i32(int v) { return tld_incl_scan_i32(v) - v; }
 struct TlWaveLds {
     // Stage-exclusive 8 KB: [PCM history | frame] + filterbank scratch  ->  FHT buffer / energy (and, once the
     // energies are dead, the masker lists and thresholds)  ->  the frame being packed.
-    union {
+    union alignas(16) {
         struct { int16_t pcm[2][TL_HIST + 1152]; double yp[TL_FB_BATCH][2][32]; } fbk;
         double fft[1024];
         uint32_t frame[TL_MAX_FRAME_WORDS];
@@ -162,6 +162,7 @@ struct TlWaveLds {
     int16_t conf_nxt[TL_TONE_MAX];      // psy-1: chain links between confirmed tones
     int16_t tlist[TL_TONE_MAX];         // psy-1: chain order
     int16_t ncentre[32];
+    int16_t bandoff[32];                // psy-1: first compacted entry of each critical band
     uint8_t ptype[520];
     uint8_t scf[2][3][32];
     uint8_t jscale[3][32];
@@ -174,6 +175,9 @@ struct TlWaveLds {
 #define TL_MK_X(w) ((w).u.fft)                         /* [TL_MASKER_MAX] */
 #define TL_MK_BARK(w) ((w).u.fft + TL_MASKER_MAX)      /* [TL_MASKER_MAX] */
 #define TL_LTG(w) ((w).u.fft + 2 * TL_MASKER_MAX)      /* [136] */
+// per-masker constants of the threshold loops, computed once per masker instead of once per (masker, line)
+struct alignas(16) TlMasker { double bark, av, g, ns; };   // av = level term (psycho_1.c:493,512), g = 0.4x+6, ns = -(17-0.15x)
+#define TL_MK4(w) ((TlMasker *)((w).u.fft + 2 * TL_MASKER_MAX + 136))   /* [TL_MASKER_MAX], ends at fft[904] */
 
 
 
@@ -190,14 +194,30 @@ TL_FN double tl_add_db(const double *TL_RESTRICT dbtable, double a, double b)
     r = fdiff > 990.0 ? a : r;
     return r;
 }
-TL_FN double tl_mask_vf(double dz, double x)
-{   // psycho_1.c:494-503 == psycho_3.c:359-369 (same four expressions, selected instead of branched)
-    const double g = 0.4 * x + 6;
-    const double v0 = 17 * (dz + 1) - g;
-    const double v1 = g * dz;
-    const double v2 = -17 * dz;
-    const double v3 = -(dz - 1) * (17 - 0.15 * x) - 17;
-    return dz < -1 ? v0 : (dz < 0 ? v1 : (dz < 1 ? v2 : v3));
+TL_FN uint64_t tl_mnr_key(double mnr)
+{   // order-preserving map double -> u64 for the allocation arg-min; ~0 = never chosen (encode_new.c:1068: small = 999999.0)
+    uint64_t u = tl_d2u(mnr + 0.0);
+    u = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+    return 999999.0 > mnr ? u : ~0ull;
+}
+TL_FN double tl_mask_vf(double dz, double g, double ns)
+{   // psycho_1.c:494-503 == psycho_3.c:359-369 with g = 0.4*x + 6 and ns = -(17 - 0.15*x):
+    //   dz < -1: 17*(dz+1) - g     dz < 0: g*dz     dz < 1: -17*dz     else: -(dz-1)*(17-0.15x) - 17
+    // all four are A*(dz+B) - C with the same roundings (adding -0.0 / subtracting +0.0 changes no bit, negating a
+    // factor only flips the product's sign), so the operands are selected and one expression is evaluated.
+    const bool c0 = dz < -1, c1 = dz < 0, c2 = dz < 1;
+    const double A = c0 ? 17.0 : (c1 ? g : (c2 ? -17.0 : ns));
+    const double Bc = c0 ? 1.0 : (c2 ? -0.0 : -1.0);
+    const double Cc = c0 ? g : (c2 ? 0.0 : 17.0);
+    return A * (dz + Bc) - Cc;
+}
+TL_FN void tl_masker_consts(TlMasker *TL_RESTRICT mk, const double *TL_RESTRICT mx, const double *TL_RESTRICT mbk, int t, bool tonal)
+{
+    const double x = mx[t], mb = mbk[t];
+    mk[t].bark = mb;
+    mk[t].av = tonal ? -1.525 - 0.275 * mb - 4.5 + x : -1.525 - 0.175 * mb - 0.5 + x;
+    mk[t].g = 0.4 * x + 6;
+    mk[t].ns = -(17 - 0.15 * x);
 }
 TL_FN unsigned tl_sf_index(const double *TL_RESTRICT sf, double cur_max)
 {   // encode_new.c:208-218
@@ -435,36 +455,57 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     TL_STAMP(sp, 3);
 
     // ---- noise components (psycho_1.c:356-376) ----
-    // the per-line weight terms are independent: computed line-parallel in place of the (now unneeded) energies
+    // Line-parallel preparation: the lines a band will actually sum (not tonal, not erased) are compacted in
+    // ascending order together with their weight terms, so the sequential part is a bare dB-sum chain.
+    // vt[] overwrites the energies in place (a compacted position is always below its line), vp[] uses the dead
+    // upper half of the FHT buffer.
     const int nbands = C->p1_ncb - 1;
     {
-        double *term = w.u.fft;
+        double *vt = w.u.fft, *vp = w.u.fft + 520;
         const int first = C->p1_cbound[0], end = C->p1_cbound[nbands];
-        TL_LANES_BEGIN
-        for (int j = first + lane; j < end; j += 64) {
-            const int bnd = C->p1_lineband[j];
-            const int lo = C->p1_cbound[bnd], hi = C->p1_cbound[bnd + 1];
-            term[j] = 1073741824 * energy[j] * (double)(j - lo) / (double)(hi - lo);
+        int nvalid = 0;
+        for (int base = first; base < end; base += 64) {
+            PV(bool, ok); PV(double, tv); PV(double, pvv);
+            TL_LANES_BEGIN
+            const int j = base + lane;
+            bool v = false; double t = 0, p = 0;
+            if (j < end) {
+                const int bnd = C->p1_lineband[j];
+                const int lo = C->p1_cbound[bnd], hi = C->p1_cbound[bnd + 1];
+                p = w.px[j];
+                v = w.ptype[j] != TL_T_TONE && p != TL_DBMIN;
+                t = 1073741824 * energy[j] * (double)(j - lo) / (double)(hi - lo);
+            }
+            L(ok) = v; L(tv) = t; L(pvv) = p;
+            TL_LANES_END
+            const uint64_t m = TL_BALLOT(ok);
+            TL_LANES_BEGIN
+            const int j = base + lane;
+            const int pos = nvalid + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (j < end) {
+                const int bnd = C->p1_lineband[j];
+                if (j == C->p1_cbound[bnd]) w.bandoff[bnd] = (int16_t)pos;     // first line of its band
+            }
+            if (L(ok)) { vt[pos] = L(tv); vp[pos] = L(pvv); }
+            TL_LANES_END
+            nvalid += __builtin_popcountll(m);
         }
-        TL_LANES_END
+        w.bandoff[nbands] = (int16_t)nvalid;
+        TL_SYNC();
     }
     // one lane per critical band: the dB-sum chain and the weight sum, both in ascending line order
     TL_LANES_BEGIN
     if (lane < nbands) {
-        const double *term = w.u.fft;
+        const double *vt = w.u.fft, *vp = w.u.fft + 520;
         const int lo = C->p1_cbound[lane], hi = C->p1_cbound[lane + 1];
+        const int i0 = w.bandoff[lane], i1 = w.bandoff[lane + 1];
         double weight = 0.0, sum = TL_DBMIN;
-        // operands of line j+1 are fetched while the dB-sum chain works on line j (index hi stays inside the arrays)
-        double p = w.px[lo], tm = term[lo];
-        int ty = w.ptype[lo];
-        for (int j = lo; j < hi; j++) {
-            const double pn = w.px[j + 1], tmn = term[j + 1];
-            const int tyn = w.ptype[j + 1];
-            if (ty != TL_T_TONE && p != TL_DBMIN) {
-                sum = tl_add_db(db, p, sum);
-                weight += tm;
-            }
-            p = pn; tm = tmn; ty = tyn;
+        double p = vp[i0], tm = vt[i0];                             // operands are fetched one entry ahead of the chain
+        for (int i = i0; i < i1; i++) {
+            const double pn = vp[i + 1], tmn = vt[i + 1];
+            sum = tl_add_db(db, p, sum);
+            weight += tm;
+            p = pn; tm = tmn;
         }
         int centre;
         if (sum <= TL_DBMIN) centre = (hi + lo) / 2;
@@ -624,6 +665,9 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     TL_DBG_DUMP("psy1", ch, ntone, nnoise, TL_MK_X(w), TL_MK_BARK(w));
     // ---- individual + global masking thresholds on the table lines (psycho_1.c:480-532) ----
     const int sub = C->p1_sub;
+    TL_LANES_BEGIN
+    for (int t = lane; t < ntone + nnoise; t += 64) tl_masker_consts(TL_MK4(w), TL_MK_X(w), TL_MK_BARK(w), t, t < ntone);
+    TL_LANES_END
     // each lane folds the maskers into (up to) two table lines at once: two independent dB-sum chains
     for (int base = 1; base < sub; base += 128) {       // 126..132 lines: one full pass + a 4-line tail at most
         TL_LANES_BEGIN
@@ -632,13 +676,12 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         if (h0) {
             const double bk0 = C->p1_bark[k0], bk1 = C->p1_bark[h1 ? k1 : k0];
             double x0 = TL_DBMIN, x1 = TL_DBMIN;
+            const TlMasker *mk = TL_MK4(w);
             for (int t = 0; t < ntone + nnoise; t++) {
-                const double mb = TL_MK_BARK(w)[t], px = TL_MK_X(w)[t];
-                // tonal: -1.525 - 0.275*bark - 4.5 + x ; noise: -1.525 - 0.175*bark - 0.5 + x   (psycho_1.c:493,512)
-                const double tmps = t < ntone ? -1.525 - 0.275 * mb - 4.5 + px : -1.525 - 0.175 * mb - 0.5 + px;
+                const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
                 const double dz0 = bk0 - mb, dz1 = bk1 - mb;
-                const double n0 = tl_add_db(db, x0, tmps + tl_mask_vf(dz0, px));
-                const double n1 = tl_add_db(db, x1, tmps + tl_mask_vf(dz1, px));
+                const double n0 = tl_add_db(db, x0, av + tl_mask_vf(dz0, g, ns));
+                const double n1 = tl_add_db(db, x1, av + tl_mask_vf(dz1, g, ns));
                 x0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : x0;
                 x1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : x1;
             }
@@ -813,6 +856,9 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     TL_STAMP(sp, 4);
     TL_STAMP(sp, 5);
     // ---- thresholds on the 136 subsampled lines (psycho_3.c:339-406) ----
+    TL_LANES_BEGIN
+    for (int t = lane; t < ntone + nnoise; t += 64) tl_masker_consts(TL_MK4(w), TL_MK_X(w), TL_MK_BARK(w), t, t < ntone);
+    TL_LANES_END
     for (int base = 0; base < 136; base += 128) {       // 136 lines: one full pass + an 8-line tail
         TL_LANES_BEGIN
         const int j0 = base + lane, j1 = base + 64 + lane;
@@ -821,21 +867,20 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
             const int line0 = C->p3_subset[j0], line1 = C->p3_subset[h1 ? j1 : j0];
             const double b0 = bark[line0], b1 = bark[line1];
             double lt0 = TL_DBMIN, ln0 = TL_DBMIN, lt1 = TL_DBMIN, ln1 = TL_DBMIN;
+            const TlMasker *mk = TL_MK4(w);
             for (int t = 0; t < ntone; t++) {
-                const double mb = TL_MK_BARK(w)[t], x = TL_MK_X(w)[t];
-                const double av = -1.525 - 0.275 * mb - 4.5 + x;
+                const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
                 const double dz0 = b0 - mb, dz1 = b1 - mb;
-                const double n0 = tl_add_db(db, lt0, av + tl_mask_vf(dz0, x));
-                const double n1 = tl_add_db(db, lt1, av + tl_mask_vf(dz1, x));
+                const double n0 = tl_add_db(db, lt0, av + tl_mask_vf(dz0, g, ns));
+                const double n1 = tl_add_db(db, lt1, av + tl_mask_vf(dz1, g, ns));
                 lt0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : lt0;
                 lt1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : lt1;
             }
             for (int t = ntone; t < ntone + nnoise; t++) {
-                const double mb = TL_MK_BARK(w)[t], x = TL_MK_X(w)[t];
-                const double av = -1.525 - 0.175 * mb - 0.5 + x;
+                const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
                 const double dz0 = b0 - mb, dz1 = b1 - mb;
-                const double n0 = tl_add_db(db, ln0, av + tl_mask_vf(dz0, x));
-                const double n1 = tl_add_db(db, ln1, av + tl_mask_vf(dz1, x));
+                const double n0 = tl_add_db(db, ln0, av + tl_mask_vf(dz0, g, ns));
+                const double n1 = tl_add_db(db, ln1, av + tl_mask_vf(dz1, g, ns));
                 ln0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : ln0;
                 ln1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : ln1;
             }
@@ -1216,15 +1261,18 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         }
     }
     int adb_left;
-    {   // a_bit_allocation_new (encode_new.c:1078-1187).  Every lane carries its cell's mnr / used / ba and
-        // the price of its next step; one wave arg-min + one uniform comparison per iteration.
-        PV(double, mnr); PV(int, used); PV(int, ba); PV(int, nbits); PV(int, cost);
+    {   // a_bit_allocation_new (encode_new.c:1078-1187).  Every lane carries its cell's order-preserving mnr key,
+        // its ba and the price of its next step; one wave arg-min per iteration.
+        // The reference marks a cell used=2 when its next step does not fit.  The bits left only shrink and a
+        // cell's price only changes when it wins, so a cell that does not fit now never fits later: such cells
+        // are left out of the arg-min right away (same result, no iterations spent on refusals).
+        PV(uint64_t, ukey); PV(int, ba); PV(int, nbits); PV(int, cost);
         PV(double, mnr_nx); PV(int, cost_nx);                       // values of the NEXT step, fetched one win ahead
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
         const bool live = c < nch && sb < sblimit;
-        L(mnr) = live ? B->snr_line[L(a_ln)][0] - L(a_smr) : 0.0;
-        L(used) = live ? 0 : 2; L(ba) = 0;
+        L(ukey) = live ? tl_mnr_key(B->snr_line[L(a_ln)][0] - L(a_smr)) : ~0ull;
+        L(ba) = 0;
         L(nbits) = (sb < sblimit && c < (sb < jsbound ? nch : 1)) ? L(a_nbal) : 0;
         // first step of a cell: samples + scfsi + scalefactors (both channels above jsbound), :1139-1147
         L(cost) = live ? B->bits12_line[L(a_ln)][1] + 2 + L(a_sfs) + ((nch == 2 && sb >= jsbound) ? 2 + L(a_sfs_o) : 0) : 0;
@@ -1238,9 +1286,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             // maxmnr_new (encode_new.c:1061-1077): smallest mnr, first in (ch, sb) order
             PV(uint64_t, key);
             TL_LANES_BEGIN
-            uint64_t u = tl_d2u(L(mnr) + 0.0);
-            u = (u >> 63) ? ~u : (u | 0x8000000000000000ull);      // order-preserving map double -> u64
-            L(key) = (L(used) != 2 && 999999.0 > L(mnr)) ? u : ~0ull;
+            L(key) = L(cost) <= ad - spent ? L(ukey) : ~0ull;
             TL_LANES_END
             const uint64_t kmin = TL_WAVE_MIN_U64(key);
             if (kmin == ~0ull) break;
@@ -1250,21 +1296,16 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             const uint64_t even = hm & 0x5555555555555555ull;       // ch 0 first, then ascending sb
             const int wl = __builtin_ctzll(even ? even : hm);
             const int min_sb = wl >> 1;
-            const int wcost = TL_READLANE_I32(cost, wl);
-            const bool fits = ad >= spent + wcost;
-            if (fits) spent += wcost;
+            spent += TL_READLANE_I32(cost, wl);
             const bool joint_pair = (min_sb >= jsbound && nch == 2);
             TL_LANES_BEGIN
             if (lane == wl || (joint_pair && (lane ^ 1) == wl)) {
-                if (fits) {
-                    const int nba = L(ba) + 1;
-                    L(ba) = nba;
-                    L(mnr) = L(mnr_nx);                              // == snr_line[ln][nba] - smr
-                    L(cost) = L(cost_nx);                            // == bits12[nba+1] - bits12[nba]
-                    L(used) = (nba >= (1 << L(a_nbal)) - 1) ? 2 : 1;
-                    L(mnr_nx) = B->snr_line[L(a_ln)][(nba + 1) & 15] - L(a_smr);
-                    L(cost_nx) = B->bits12_line[L(a_ln)][(nba + 2) & 15] - B->bits12_line[L(a_ln)][(nba + 1) & 15];
-                } else L(used) = 2;
+                const int nba = L(ba) + 1;
+                L(ba) = nba;
+                L(ukey) = (nba >= (1 << L(a_nbal)) - 1) ? ~0ull : tl_mnr_key(L(mnr_nx));   // == snr_line[ln][nba] - smr
+                L(cost) = L(cost_nx);                                // == bits12[nba+1] - bits12[nba]
+                L(mnr_nx) = B->snr_line[L(a_ln)][(nba + 1) & 15] - L(a_smr);
+                L(cost_nx) = B->bits12_line[L(a_ln)][(nba + 2) & 15] - B->bits12_line[L(a_ln)][(nba + 1) & 15];
             }
             TL_LANES_END
         }
