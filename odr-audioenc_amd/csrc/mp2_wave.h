@@ -45,6 +45,7 @@ TL_FN void tlh_exscan_i32(int (&d)[64], const int (&v)[64]) { int s = 0; for (in
 #define TL_UNI_I(x) (x)
 #define TL_READLANE_I32(name, l) name[l]
 #define TL_RESTRICT
+#define TL_SELECT(c, a, b) ((c) ? (a) : (b))
 #else
 #define TL_FN __device__ __forceinline__
 #define TL_LANES_BEGIN { const int lane = (int)(threadIdx.x & 63u);
@@ -115,6 +116,7 @@ TL_FN int tld_exscan_i32(int v) { return tld_incl_scan_i32(v) - v; }
 #define TL_UNI_I(x) __builtin_amdgcn_readfirstlane(x)
 #define TL_READLANE_I32(name, l) __builtin_amdgcn_readlane(name, l)
 #define TL_RESTRICT __restrict__
+#define TL_SELECT(c, a, b) (__builtin_unpredictable(c) ? (a) : (b))      /* a v_cndmask, never a divergent branch */
 #endif
 
 #ifdef TL_EMULATE
@@ -206,9 +208,9 @@ TL_FN double tl_mask_vf(double dz, double g, double ns)
     // all four are A*(dz+B) - C with the same roundings (adding -0.0 / subtracting +0.0 changes no bit, negating a
     // factor only flips the product's sign), so the operands are selected and one expression is evaluated.
     const bool c0 = dz < -1, c1 = dz < 0, c2 = dz < 1;
-    const double A = c0 ? 17.0 : (c1 ? g : (c2 ? -17.0 : ns));
-    const double Bc = c0 ? 1.0 : (c2 ? -0.0 : -1.0);
-    const double Cc = c0 ? g : (c2 ? 0.0 : 17.0);
+    double A = TL_SELECT(c2, -17.0, ns), Bc = TL_SELECT(c2, -0.0, -1.0), Cc = TL_SELECT(c2, 0.0, 17.0);
+    A = TL_SELECT(c1, g, A);
+    A = TL_SELECT(c0, 17.0, A); Bc = TL_SELECT(c0, 1.0, Bc); Cc = TL_SELECT(c0, g, Cc);
     return A * (dz + Bc) - Cc;
 }
 TL_FN void tl_masker_consts(TlMasker *TL_RESTRICT mk, const double *TL_RESTRICT mx, const double *TL_RESTRICT mbk, int t, bool tonal)
