@@ -83,6 +83,7 @@ void tl_build_tables(TlTables *T)
         T->dbtable[i] = 10 * log10(1 + pow(10.0, x / 10.0)) - x;
         T->shared.dbtable[i] = T->dbtable[i];
     }
+    T->shared.dbtable[1000] = -0.0; T->shared.dbtable[1001] = -0.0;
     // Buneman recurrence of fft.c:1139-1149 unrolled into a table (passes k = 2,4,6,8)
     int n = 0;
     for (int k = 2; k <= 8; k += 2) {

@@ -15,7 +15,7 @@
 // The part of the common tables that sits on dependent-load chains (dB sums, scalefactor search,
 // allocation loop): copied once per workgroup into LDS and shared by its waves.
 struct TlBlockShared {
-    double dbtable[1000];        // psycho_1.c:170-178
+    double dbtable[1002];        // psycho_1.c:170-178; [1000] = -0.0: the addend when the levels are > 99 dB apart
     double scalefactor[64];      // encode_new.c:65-83
     double snr_line[9][16];      // SNR[step_index[line][ba]]             (encode_new.c:16-27,96-100)
     int16_t bits12_line[9][16];  // 12*group*bits of step_index[line][ba] (encode_new.c:1125-1133)

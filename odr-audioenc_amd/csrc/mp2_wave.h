@@ -186,15 +186,15 @@ struct alignas(16) TlMasker { double bark, av, g, ns; };   // av = level term (p
 // ------------------------------------------------------------------------------------------
 TL_FN double tl_add_db(const double *TL_RESTRICT dbtable, double a, double b)
 {   // psycho_1.c:180-205 == psycho_3.c:44-69, written without branches (every lane of a wave walks its own
-    // chain): one table read, then selects.  Inside |fdiff| <= 990 the index is the reference's (int)fdiff.
+    // chain) and with nothing but the final add behind the table read.  Inside |fdiff| <= 990 the index is the
+    // reference's (int)fdiff; beyond it the reference returns the larger operand unchanged, which is
+    // operand + table[1000] with table[1000] = -0.0.
     const double fdiff = 10.0 * (a - b);
-    int idiff = (int)fdiff;
-    idiff = idiff > 999 ? 999 : (idiff < -999 ? -999 : idiff);
-    const double t = dbtable[idiff >= 0 ? idiff : -idiff];
-    double r = idiff >= 0 ? a + t : b + t;
-    r = fdiff < -990.0 ? b : r;
-    r = fdiff > 990.0 ? a : r;
-    return r;
+    const int idiff = (int)fdiff;
+    const int mag = idiff >= 0 ? idiff : -idiff;
+    const int idx = TL_SELECT(__builtin_fabs(fdiff) > 990.0, 1000, mag);
+    const double base = TL_SELECT(idiff >= 0, a, b);
+    return base + dbtable[idx];
 }
 TL_FN uint64_t tl_mnr_key(double mnr)
 {   // order-preserving map double -> u64 for the allocation arg-min; ~0 = never chosen (encode_new.c:1068: small = 999999.0)
@@ -502,13 +502,16 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         const int lo = C->p1_cbound[lane], hi = C->p1_cbound[lane + 1];
         const int i0 = w.bandoff[lane], i1 = w.bandoff[lane + 1];
         double weight = 0.0, sum = TL_DBMIN;
-        double p = vp[i0], tm = vt[i0];                             // operands are fetched one entry ahead of the chain
-        for (int i = i0; i < i1; i++) {
-            const double pn = vp[i + 1], tmn = vt[i + 1];
-            sum = tl_add_db(db, p, sum);
-            weight += tm;
-            p = pn; tm = tmn;
+        int i = i0;
+        for (; i + 4 <= i1; i += 4) {                               // operands of four steps in flight per LDS round trip
+            const double p0 = vp[i], p1 = vp[i + 1], p2 = vp[i + 2], p3 = vp[i + 3];
+            const double t0 = vt[i], t1 = vt[i + 1], t2 = vt[i + 2], t3 = vt[i + 3];
+            sum = tl_add_db(db, p0, sum); weight += t0;
+            sum = tl_add_db(db, p1, sum); weight += t1;
+            sum = tl_add_db(db, p2, sum); weight += t2;
+            sum = tl_add_db(db, p3, sum); weight += t3;
         }
+        for (; i < i1; i++) { sum = tl_add_db(db, vp[i], sum); weight += vt[i]; }
         int centre;
         if (sum <= TL_DBMIN) centre = (hi + lo) / 2;
         else {
