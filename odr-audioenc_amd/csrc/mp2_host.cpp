@@ -276,6 +276,9 @@ int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, 
         cb++;
         C->p3_cbidx[cb] = 513;
         C->p3_cbands = cb;
+        memset(C->p3_lineband, 255, sizeof C->p3_lineband);
+        for (int b = 0; b < cb; b++)
+            for (int j = C->p3_cbidx[b]; j < C->p3_cbidx[b + 1]; j++) C->p3_lineband[j] = (uint8_t)b;
         int n = 0, i = 1;
         for (; i < 3 * 16 + 1; i++) C->p3_subset[n++] = (int16_t)i;
         for (; i < 6 * 16 + 1; i += 2) C->p3_subset[n++] = (int16_t)i;

@@ -67,6 +67,7 @@ struct TlConfig {
     double p3_ath[520];
     int16_t p3_cbidx[36];
     int16_t p3_subset[136];
+    uint8_t p3_lineband[520];    // critical band of each FFT line (index into p3_cbidx)
     int16_t p3_sb_j0[32], p3_sb_n[32];   // rows of p3_subset that fall into each subband (psycho_3.c:415-420)
     // psy model 0 (psycho_0.c:36-50)
     double p0_athmin[32];

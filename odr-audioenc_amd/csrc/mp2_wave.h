@@ -164,7 +164,7 @@ struct TlWaveLds {
     int16_t conf_nxt[TL_TONE_MAX];      // psy-1: chain links between confirmed tones
     int16_t tlist[TL_TONE_MAX];         // psy-1: chain order
     int16_t ncentre[32];
-    int16_t bandoff[32];                // psy-1: first compacted entry of each critical band
+    int16_t bandoff[40];                // psy-1/3: first compacted entry of each critical band
     uint8_t ptype[520];
     uint8_t scf[2][3][32];
     uint8_t jscale[3][32];
@@ -335,6 +335,41 @@ TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
 TL_FN int tl_run_psy1(int c) { return (c < 3 || c > 500) ? 0 : c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 12; }   // psycho_1.c:289-298
 TL_FN int tl_run_psy3(int c) { return c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 12; }                            // psycho_3.c:212-215
 
+// Tone candidates of one 64-line chunk: local maxima 2..499 whose right-hand neighbours (distance 2..run) pass the
+// 7 dB test; the left-hand failures are recorded as a bit mask for the walk that follows (psycho_1.c:267-300,
+// psycho_3.c:186-236).  RMAX is the largest run inside the chunk, so the neighbour reads are straight-line code
+// and overlap; PSY3 selects psycho_3's strict maximum and its (peak - neighbour) < 7 form of the test.
+template <int RMAX, bool PSY3>
+TL_FN void tl_cand_chunk(TlWaveLds &w, int c8, int &ncand)
+{
+    PV(bool, isc); PV(uint32_t, rec);
+    TL_LANES_BEGIN
+    const int i = 64 * c8 + lane;
+    const bool inr = i >= 2 && i < 500;
+    const int ii = inr ? i : 16;
+    const double pk = w.px[ii], l1 = w.px[ii - 1], r1 = w.px[ii + 1];
+    bool cnd = inr && pk > l1 && (PSY3 ? pk > r1 : pk >= r1);
+    const int run = PSY3 ? tl_run_psy3(ii) : tl_run_psy1(ii);
+    const double max = pk - 7;
+    uint32_t r = (uint32_t)i;
+#pragma unroll
+    for (int j = 2; j <= RMAX; j++) {
+        const double a = w.px[ii + j], b = w.px[ii - j < 0 ? 0 : ii - j];
+        const bool in = j <= run;
+        const bool fa = PSY3 ? (pk - a) < 7.0 : max < a;
+        const bool fb = PSY3 ? (pk - b) < 7.0 : max < b;
+        cnd = cnd && !(in && fa);
+        r |= (in && fb) ? 1u << (10 + j - 2) : 0u;
+    }
+    L(isc) = cnd; L(rec) = r;
+    TL_LANES_END
+    const uint64_t m = TL_BALLOT(isc);
+    TL_LANES_BEGIN
+    if ((m >> lane) & 1ull) w.cinfo[ncand + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = L(rec);
+    TL_LANES_END
+    ncand += __builtin_popcountll(m);
+}
+
 // psy model 1 (psycho_1.c:22-87, :215-581) for channel `ch`; result in w.smr[ch][0..sblimit).
 TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
                    const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
@@ -362,29 +397,9 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     // ---- tonal components (psycho_1.c:267-340) ----
     // (1) local maxima 2..499 whose right-hand neighbours pass the 7 dB test, compacted ascending
     int ncand = 0;
-    for (int c8 = 0; c8 < 8; c8++) {
-        PV(bool, isc); PV(uint32_t, rec);
-        TL_LANES_BEGIN
-        const int i = 64 * c8 + lane;
-        bool cnd = (i >= 2 && i < 500) && (w.px[i] > w.px[i - 1] && w.px[i] >= w.px[i + 1]);
-        uint32_t r = 0;
-        if (cnd) {
-            const int run = tl_run_psy1(i);
-            const double max = w.px[i] - 7;
-            for (int j = 2; j <= run; j++) {
-                if (max < w.px[i + j]) cnd = false;
-                if (max < w.px[i - j]) r |= 1u << (10 + j - 2);
-            }
-            r |= (uint32_t)i;
-        }
-        L(isc) = cnd; L(rec) = r;
-        TL_LANES_END
-        const uint64_t m = TL_BALLOT(isc);
-        TL_LANES_BEGIN
-        if ((m >> lane) & 1ull) w.cinfo[ncand + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = L(rec);
-        TL_LANES_END
-        ncand += __builtin_popcountll(m);
-    }
+    tl_cand_chunk<3, false>(w, 0, ncand);                           // lines < 64: run <= 3
+    for (int c8 = 1; c8 < 3; c8++) tl_cand_chunk<6, false>(w, c8, ncand);     // < 192: run <= 6
+    for (int c8 = 3; c8 < 8; c8++) tl_cand_chunk<12, false>(w, c8, ncand);
     TL_STAMP(sp, 2);
     // (2) wave-uniform walk: which candidates become tones.  State of the reference's list walk that
     //     matters: the last confirmed tone (`last`), its erasure reach R = last + run(last), and the
@@ -392,8 +407,11 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     int nconf = 0;
     {
         int last = -1, run_last = 0, R = -1, last_var = 0;
-        for (int k = 0; k < ncand; k++) {
-            const uint32_t info = w.cinfo[k];
+        for (int kb = 0; kb < ncand; kb += 64) {                        // 64 records per LDS round trip, then lane reads
+        PV(int, crec);
+        TL_LANES_BEGIN L(crec) = (int)w.cinfo[kb + lane < TL_CAND_MAX ? kb + lane : 0]; TL_LANES_END
+        for (int k = kb; k < ncand && k < kb + 64; k++) {
+            const uint32_t info = (uint32_t)TL_READLANE_I32(crec, k - kb);
             const int c = (int)(info & 511u);
             if (last >= 0 && c - last <= run_last) continue;          // unlinked by the help loop, psycho_1.c:309-312
             const int run = tl_run_psy1(c);
@@ -427,6 +445,7 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
             }
             last = c; run_last = run; R = c + run; last_var = var;
         }
+        }
         TL_SYNC();
     }
     // (3) levels of the confirmed tones from the still-original spectrum (psycho_1.c:317-321)
@@ -450,8 +469,13 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     //     in parallel (psycho_1.c:416-428): drop erased tones and tones below the threshold in quiet
     int nlist = 0;
     {
+        PV(int, nx0); PV(int, nx1);                                   // the links in registers: the walk reads lanes, not LDS
+        TL_LANES_BEGIN L(nx0) = w.conf_nxt[lane]; L(nx1) = w.conf_nxt[64 + lane < TL_TONE_MAX ? 64 + lane : 0]; TL_LANES_END
         int i = nconf ? 0 : TL_LAST, guard = 0;
-        while (i != TL_LAST && i != TL_STOP && guard++ < TL_TONE_MAX) { w.tlist[nlist++] = (int16_t)i; i = w.conf_nxt[i]; }
+        while (i != TL_LAST && i != TL_STOP && guard++ < TL_TONE_MAX) {
+            w.tlist[nlist++] = (int16_t)i;
+            i = i < 64 ? TL_READLANE_I32(nx0, i) : TL_READLANE_I32(nx1, i - 64);
+        }
         TL_SYNC();
     }
     TL_STAMP(sp, 3);
@@ -746,29 +770,9 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     // ---- tone labelling (psycho_3.c:186-247) ----
     // (1) local maxima 2..499 whose right-hand neighbours are >= 7 dB down, compacted ascending
     int ncand = 0;
-    for (int c8 = 0; c8 < 8; c8++) {
-        PV(bool, isc); PV(uint32_t, rec);
-        TL_LANES_BEGIN
-        const int i = 64 * c8 + lane;
-        bool cnd = (i >= 2 && i < 500) && (w.px[i] > w.px[i - 1] && w.px[i] > w.px[i + 1]);
-        uint32_t r = 0;
-        if (cnd) {
-            const int sr = tl_run_psy3(i);
-            const double pk = w.px[i];
-            for (int j = 2; j <= sr; j++) {
-                if ((pk - w.px[i + j]) < 7.0) cnd = false;
-                if ((pk - w.px[i - j]) < 7.0) r |= 1u << (10 + j - 2);
-            }
-            r |= (uint32_t)i;
-        }
-        L(isc) = cnd; L(rec) = r;
-        TL_LANES_END
-        const uint64_t m = TL_BALLOT(isc);
-        TL_LANES_BEGIN
-        if ((m >> lane) & 1ull) w.cinfo[ncand + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = L(rec);
-        TL_LANES_END
-        ncand += __builtin_popcountll(m);
-    }
+    tl_cand_chunk<3, true>(w, 0, ncand);                            // lines < 64: run <= 3
+    for (int c8 = 1; c8 < 3; c8++) tl_cand_chunk<6, true>(w, c8, ncand);      // < 192: run <= 6
+    for (int c8 = 3; c8 < 8; c8++) tl_cand_chunk<12, true>(w, c8, ncand);
     TL_STAMP(sp, 2);
     // (2) wave-uniform walk.  A confirmed tone k erases lines k-sr..k+sr (itself included) to DBMIN
     //     (psycho_3.c:243-244); a later maximum inside that reach R has power DBMIN and always fails,
@@ -776,8 +780,11 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     int nconf = 0;
     {
         int R = -1;
-        for (int q = 0; q < ncand; q++) {
-            const uint32_t info = w.cinfo[q];
+        for (int kb = 0; kb < ncand; kb += 64) {                        // 64 records per LDS round trip, then lane reads
+        PV(int, crec);
+        TL_LANES_BEGIN L(crec) = (int)w.cinfo[kb + lane < TL_CAND_MAX ? kb + lane : 0]; TL_LANES_END
+        for (int q = kb; q < ncand && q < kb + 64; q++) {
+            const uint32_t info = (uint32_t)TL_READLANE_I32(crec, q - kb);
             const int k = (int)(info & 511u);
             if (k <= R) continue;
             const int sr = tl_run_psy3(k);
@@ -786,6 +793,7 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
             if ((info >> 10) & orig) continue;
             if (nconf < TL_TONE_MAX) w.conf_c[nconf++] = (int16_t)(k | ((k - 1 <= R) ? (1 << 12) : 0));
             R = k + sr;
+        }
         }
         TL_SYNC();
     }
@@ -808,18 +816,62 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     TL_STAMP(sp, 3);
     // ---- noise per critical band (psycho_3.c:264-304) + decimation (:313-320); one lane per band ----
     const int nb = C->p3_cbands;
+    // Line-parallel preparation as in psy 1: the lines that are summed (not erased) are compacted in ascending
+    // order -- levels in place in px[], energies in place in the FHT buffer (a compacted position is always below
+    // its line), the centre-of-gravity terms (j-lo)*e in the buffer's upper half -- so the per-band part is three
+    // bare chains.  energy[512] shares its slot with the first centre term and is read up front.
+    {
+        double *ve = w.u.fft, *vc = w.u.fft + 512, *vp = w.px;
+        const int first = C->p3_cbidx[0], end = C->p3_cbidx[nb];
+        PV(double, e512);
+        TL_LANES_BEGIN L(e512) = energy[512]; TL_LANES_END
+        int nvalid = 0;
+        for (int base = first; base < end; base += 64) {
+            PV(bool, ok); PV(double, ev); PV(double, cv); PV(double, pvv); PV(int, bnd);
+            TL_LANES_BEGIN
+            const int j = base + lane;
+            bool v = false; double e = 0, c = 0, p = 0; int bd = -1;
+            if (j < end) {
+                const int b0 = C->p3_lineband[j];
+                const int lo = C->p3_cbidx[b0];
+                p = w.px[j];
+                v = p != TL_DBMIN;
+                e = j == 512 ? L(e512) : energy[j];
+                c = (j - lo) * e;
+                bd = j == lo ? b0 : -1;
+            }
+            L(ok) = v; L(ev) = e; L(cv) = c; L(pvv) = p; L(bnd) = bd;
+            TL_LANES_END
+            const uint64_t m = TL_BALLOT(ok);
+            TL_LANES_BEGIN
+            const int pos = nvalid + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (L(bnd) >= 0) w.bandoff[L(bnd)] = (int16_t)pos;     // first line of its band
+            if (L(ok)) { ve[pos] = L(ev); vc[pos] = L(cv); vp[pos] = L(pvv); }
+            TL_LANES_END
+            nvalid += __builtin_popcountll(m);
+        }
+        w.bandoff[nb] = (int16_t)nvalid;
+        TL_SYNC();
+    }
     PV(bool, keepn); PV(double, nx); PV(double, nbk);
     TL_LANES_BEGIN
     bool kp = false; double xn = 0, bk = 0;
     if (lane < nb) {
+        const double *ve = w.u.fft, *vc = w.u.fft + 512, *vp = w.px;
         const int lo = C->p3_cbidx[lane], hi = C->p3_cbidx[lane + 1];
+        const int i0 = w.bandoff[lane], i1 = w.bandoff[lane + 1];
         double sum = TL_DBMIN, esum = 0, cw = 0;
-        double p = w.px[lo], en = energy[lo];
-        for (int j = lo; j < hi; j++) {
-            const double pn = w.px[j + 1], enn = energy[j + 1];      // fetched one line ahead of the chain
-            if (p != TL_DBMIN) { sum = tl_add_db(db, p, sum); esum += en; cw += (j - lo) * en; }
-            p = pn; en = enn;
+        int i = i0;
+        for (; i + 4 <= i1; i += 4) {                               // operands of four steps in flight per LDS round trip
+            const double p0 = vp[i], p1 = vp[i + 1], p2 = vp[i + 2], p3 = vp[i + 3];
+            const double e0 = ve[i], e1 = ve[i + 1], e2 = ve[i + 2], e3 = ve[i + 3];
+            const double c0 = vc[i], c1 = vc[i + 1], c2 = vc[i + 2], c3 = vc[i + 3];
+            sum = tl_add_db(db, p0, sum); esum += e0; cw += c0;
+            sum = tl_add_db(db, p1, sum); esum += e1; cw += c1;
+            sum = tl_add_db(db, p2, sum); esum += e2; cw += c2;
+            sum = tl_add_db(db, p3, sum); esum += e3; cw += c3;
         }
+        for (; i < i1; i++) { sum = tl_add_db(db, vp[i], sum); esum += ve[i]; cw += vc[i]; }
         // esum == 0: the reference indexes with (int)(0/0) and segfaults; defined as the band centre
         int centre = (sum <= TL_DBMIN || esum == 0) ? (lo + hi) / 2 : lo + (int)(cw / esum);
         centre = centre < 1 ? 1 : centre > 512 ? 512 : centre;
@@ -864,42 +916,60 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     TL_LANES_BEGIN
     for (int t = lane; t < ntone + nnoise; t += 64) tl_masker_consts(TL_MK4(w), TL_MK_X(w), TL_MK_BARK(w), t, t < ntone);
     TL_LANES_END
-    for (int base = 0; base < 136; base += 128) {       // 136 lines: one full pass + an 8-line tail
-        TL_LANES_BEGIN
-        const int j0 = base + lane, j1 = base + 64 + lane;
-        const bool h0 = j0 < 136, h1 = j1 < 136;
-        if (h0) {
-            const int line0 = C->p3_subset[j0], line1 = C->p3_subset[h1 ? j1 : j0];
-            const double b0 = bark[line0], b1 = bark[line1];
-            double lt0 = TL_DBMIN, ln0 = TL_DBMIN, lt1 = TL_DBMIN, ln1 = TL_DBMIN;
-            const TlMasker *mk = TL_MK4(w);
-            for (int t = 0; t < ntone; t++) {
-                const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
-                const double dz0 = b0 - mb, dz1 = b1 - mb;
-                const double n0 = tl_add_db(db, lt0, av + tl_mask_vf(dz0, g, ns));
-                const double n1 = tl_add_db(db, lt1, av + tl_mask_vf(dz1, g, ns));
-                lt0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : lt0;
-                lt1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : lt1;
-            }
-            for (int t = ntone; t < ntone + nnoise; t++) {
-                const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
-                const double dz0 = b0 - mb, dz1 = b1 - mb;
-                const double n0 = tl_add_db(db, ln0, av + tl_mask_vf(dz0, g, ns));
-                const double n1 = tl_add_db(db, ln1, av + tl_mask_vf(dz1, g, ns));
-                ln0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : ln0;
-                ln1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : ln1;
-            }
-            {
-                const double g = tl_add_db(db, ln0, lt0);
-                TL_LTG(w)[j0] = tl_add_db(db, C->br_per_ch < 96 ? ath[line0] : ath[line0] - 12.0, g);
-            }
-            if (h1) {
-                const double g = tl_add_db(db, ln1, lt1);
-                TL_LTG(w)[j1] = tl_add_db(db, C->br_per_ch < 96 ? ath[line1] : ath[line1] - 12.0, g);
-            }
+    // lines 0..127: every lane folds the maskers into two lines (two independent dB-sum chains at a time)
+    TL_LANES_BEGIN
+    {
+        const int j0 = lane, j1 = 64 + lane;
+        const int line0 = C->p3_subset[j0], line1 = C->p3_subset[j1];
+        const double b0 = bark[line0], b1 = bark[line1];
+        double lt0 = TL_DBMIN, ln0 = TL_DBMIN, lt1 = TL_DBMIN, ln1 = TL_DBMIN;
+        const TlMasker *mk = TL_MK4(w);
+        for (int t = 0; t < ntone; t++) {
+            const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
+            const double dz0 = b0 - mb, dz1 = b1 - mb;
+            const double n0 = tl_add_db(db, lt0, av + tl_mask_vf(dz0, g, ns));
+            const double n1 = tl_add_db(db, lt1, av + tl_mask_vf(dz1, g, ns));
+            lt0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : lt0;
+            lt1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : lt1;
         }
-        TL_LANES_END
+        for (int t = ntone; t < ntone + nnoise; t++) {
+            const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
+            const double dz0 = b0 - mb, dz1 = b1 - mb;
+            const double n0 = tl_add_db(db, ln0, av + tl_mask_vf(dz0, g, ns));
+            const double n1 = tl_add_db(db, ln1, av + tl_mask_vf(dz1, g, ns));
+            ln0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : ln0;
+            ln1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : ln1;
+        }
+        const double g0 = tl_add_db(db, ln0, lt0), g1 = tl_add_db(db, ln1, lt1);
+        TL_LTG(w)[j0] = tl_add_db(db, C->br_per_ch < 96 ? ath[line0] : ath[line0] - 12.0, g0);
+        TL_LTG(w)[j1] = tl_add_db(db, C->br_per_ch < 96 ? ath[line1] : ath[line1] - 12.0, g1);
     }
+    TL_LANES_END
+    // lines 128..135: the tone sum and the noise sum of a line are independent chains (psycho_3.c:350-395), so
+    // lanes 0..7 run the tone chains and lanes 8..15 the noise chains of the eight lines side by side
+    TL_LANES_BEGIN
+    if (lane < 16) {
+        const int j = 128 + (lane & 7), line = C->p3_subset[j];
+        const double bj = bark[line];
+        const TlMasker *mk = TL_MK4(w);
+        const int t0 = lane < 8 ? 0 : ntone, t1 = lane < 8 ? ntone : ntone + nnoise;
+        double acc = TL_DBMIN;
+        for (int t = t0; t < t1; t++) {
+            const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
+            const double dz = bj - mb;
+            const double n = tl_add_db(db, acc, av + tl_mask_vf(dz, g, ns));
+            acc = (dz >= -3.0 && dz < 8.0) ? n : acc;
+        }
+        w.nsum[lane] = acc;
+    }
+    TL_LANES_END
+    TL_LANES_BEGIN
+    if (lane < 8) {
+        const int j = 128 + lane, line = C->p3_subset[j];
+        const double g = tl_add_db(db, w.nsum[8 + lane], w.nsum[lane]);
+        TL_LTG(w)[j] = tl_add_db(db, C->br_per_ch < 96 ? ath[line] : ath[line] - 12.0, g);
+    }
+    TL_LANES_END
     TL_STAMP(sp, 6);
     // ---- minimum per subband + SMR (psycho_3.c:409-432); subset rows of subband sb are contiguous ----
     TL_LANES_BEGIN
