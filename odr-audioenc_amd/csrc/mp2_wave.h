@@ -46,6 +46,7 @@ TL_FN void tlh_exscan_i32(int (&d)[64], const int (&v)[64]) { int s = 0; for (in
 #define TL_READLANE_I32(name, l) name[l]
 #define TL_RESTRICT
 #define TL_SELECT(c, a, b) ((c) ? (a) : (b))
+#define TL_LAUNDER(p) ((void)0)
 #else
 #define TL_FN __device__ __forceinline__
 #define TL_LANES_BEGIN { const int lane = (int)(threadIdx.x & 63u);
@@ -117,6 +118,7 @@ TL_FN int tld_exscan_i32(int v) { return tld_incl_scan_i32(v) - v; }
 #define TL_READLANE_I32(name, l) __builtin_amdgcn_readlane(name, l)
 #define TL_RESTRICT __restrict__
 #define TL_SELECT(c, a, b) (__builtin_unpredictable(c) ? (a) : (b))      /* a v_cndmask, never a divergent branch */
+#define TL_LAUNDER(p) asm volatile("" : "+s"(p))       /* keeps loads through p inside the frame loop (no hoisting into long-lived VGPRs) */
 #endif
 
 #ifdef TL_EMULATE
@@ -297,23 +299,47 @@ TL_FN void tl_fht_pass(double *x, int k, int twbase, const double (*TL_RESTRICT 
 // channel that precede it (the stream state on the first frame of a launch, the previous input frame after).
 struct TlPcmView { const int16_t *cur; const int16_t *hist; int hist_stride; };
 
-TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPcmView &pv, int ch)
+TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPcmView &pv, int ch, long long *sp)
 {
     double *x = w.u.fft;
+    long long *sq = (sp && ch == 0) ? sp + 16 : nullptr;      // channel 0's pass-by-pass stamps: slots 24..30 of the frame's record
+    TL_STAMP(sq, 0);
     TL_LANES_BEGIN
-    for (int i = lane; i < 1024; i += 64) {
-        int r = 0;
-        for (int b = 0; b < 10; b++) r |= ((i >> b) & 1) << (9 - b);
-        // sample i of the analysis window: the last 192 samples of the history, then the first 832 of the frame
-        const int16_t v = i < 192 ? pv.hist[ch * pv.hist_stride + (TL_HIST - 192) + i] : pv.cur[ch * 1152 + (i - 192)];
-        x[r] = ((double)v / 32768) * T->hann[i];
+    {
+        // sample i = lane + 64*it of the analysis window: the last 192 samples of the history (it < 3), then the
+        // first 832 of the frame.  The loads are issued in batches ahead of their use; the bit-reversed slot of i
+        // is rev6(lane) << 4 | rev4(it).
+        const int16_t *hs = pv.hist + ch * pv.hist_stride + (TL_HIST - 192) + lane;
+        const int16_t *cs = pv.cur + ch * 1152 - 192 + lane;
+        const double *hann = T->hann;
+        TL_LAUNDER(hann);
+        int r6 = 0;
+        for (int b = 0; b < 6; b++) r6 |= ((lane >> b) & 1) << (5 - b);
+#pragma unroll
+        for (int half = 0; half < 16; half += 8) {                  // eight loads in flight (sixteen would spill)
+            int16_t v[8]; double h[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const int it = half + q; v[q] = it < 3 ? hs[64 * it] : cs[64 * it]; h[q] = hann[lane + 64 * it]; }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int it = half + q;
+                const int r4 = ((it & 1) << 3) | ((it & 2) << 1) | ((it & 4) >> 1) | ((it & 8) >> 3);
+                x[(r6 << 4) | r4] = ((double)v[q] / 32768) * h[q];
+            }
+        }
     }
     TL_LANES_END
+    TL_STAMP(sq, 1);
     TL_LANES_BEGIN tl_fht_pass_first(x, lane); TL_LANES_END
+    TL_STAMP(sq, 2);
     TL_LANES_BEGIN tl_fht_pass(x, 2, 0, T->fht_tw, lane); TL_LANES_END
+    TL_STAMP(sq, 3);
     TL_LANES_BEGIN tl_fht_pass(x, 4, 1, T->fht_tw, lane); TL_LANES_END
+    TL_STAMP(sq, 4);
     TL_LANES_BEGIN tl_fht_pass(x, 6, 8, T->fht_tw, lane); TL_LANES_END
+    TL_STAMP(sq, 5);
     TL_LANES_BEGIN tl_fht_pass(x, 8, 39, T->fht_tw, lane); TL_LANES_END
+    TL_STAMP(sq, 6);
     TL_LANES_BEGIN
     for (int i = lane; i <= 512; i += 64) {
         double e;
@@ -377,7 +403,7 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     const double *energy = w.u.fft;
     const double *db = B->dbtable;
     TL_STAMP(sp, 0);
-    tl_psy_spectrum(w, T, pv, ch);
+    tl_psy_spectrum(w, T, pv, ch, sp);
     TL_STAMP(sp, 1);
 
     // power density spectrum (psycho_1.c:241-248); spike (psycho_1.c:252-257)
@@ -747,7 +773,7 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     const double *db = B->dbtable;
     const double *bark = C->p3_bark, *ath = C->p3_ath;
     TL_STAMP(sp, 0);
-    tl_psy_spectrum(w, T, pv, ch);
+    tl_psy_spectrum(w, T, pv, ch, sp);
     TL_STAMP(sp, 1);
 
     // power[1..512] (psycho_3.c:152-160); power[0] is an uninitialised slot in the reference, pinned
@@ -1113,12 +1139,27 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     // min(sb,31-sb); the two halves swap values (a move, not a re-association): s[i]=s0+s1, s[31-i]=s0-s1.
     {
         PA(double, ca, 8); PA(double, cb, 8);
+        const double *enw = T->enwindow;
+        TL_LAUNDER(enw);                // re-read per frame: 32 VGPRs of coefficients must not stay live through the other stages
         TL_LANES_BEGIN
         const int i = lane >> 1;
         const int ya = i == 0 ? 16 : i + 16, yb = i == 0 ? 16 : (i <= 16 ? 16 - i : 80 - i);
         // the reference scales the sample, (pcm/32768)*C (subband.c:233,249); scaling the coefficient instead is the
         // same real product rounded once (2^-15 is exact, nothing underflows), so the bits are identical
-        for (int j = 0; j < 8; j++) { L(ca)[j] = T->enwindow[ya + 64 * j] / 32768; L(cb)[j] = T->enwindow[yb + 64 * j] / 32768; }
+        for (int j = 0; j < 8; j++) { L(ca)[j] = enw[ya + 64 * j] / 32768; L(cb)[j] = enw[yb + 64 * j] / 32768; }
+        TL_LANES_END
+        // Window taps as a rolling register file: tap j of block b is tap j+1 of block b+2 (the window advances 32
+        // samples per block, the taps are 64 apart), so each block reads two new samples per lane from LDS instead of
+        // sixteen (kept as integers: sixteen more doubles would not fit the register file).  Slot of (b, j): [b & 1][((b >> 1) - j) & 7].
+        PA(int, xa, 16); PA(int, xb, 16);
+        TL_LANES_BEGIN
+        const int c = lane & 1, i = lane >> 1;
+        const int ya = i == 0 ? 16 : i + 16, yb = i == 0 ? 16 : (i <= 16 ? 16 - i : 80 - i);
+        for (int b = 0; b < 2; b++)
+            for (int j = 1; j < 8; j++) {
+                L(xa)[8 * b + ((0 - j) & 7)] = c < nch ? w.u.fbk.pcm[c][TL_HIST + 32 * b + 31 - ya - 64 * j] : 0;
+                L(xb)[8 * b + ((0 - j) & 7)] = c < nch ? w.u.fbk.pcm[c][TL_HIST + 32 * b + 31 - yb - 64 * j] : 0;
+            }
         TL_LANES_END
 #ifndef TL_EMULATE
 #pragma unroll
@@ -1133,13 +1174,14 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
 #endif
                 for (int bb = 0; bb < TL_FB_BATCH; bb++) {
                     // X[k] = pcm[t0 + 31 - k], t0 = index of the block's first new sample
-                    const int16_t *pa = &w.u.fbk.pcm[c][TL_HIST + 32 * (b0 + bb) + 31 - ya];
-                    const int16_t *pb = &w.u.fbk.pcm[c][TL_HIST + 32 * (b0 + bb) + 31 - yb];
-                    double ta = (double)pa[0] * L(ca)[0];
-                    double tb = (double)pb[0] * L(cb)[0];
+                    const int b = b0 + bb, q = 8 * (b & 1), h = b >> 1;
+                    L(xa)[q + (h & 7)] = w.u.fbk.pcm[c][TL_HIST + 32 * b + 31 - ya];
+                    L(xb)[q + (h & 7)] = w.u.fbk.pcm[c][TL_HIST + 32 * b + 31 - yb];
+                    double ta = (double)L(xa)[q + (h & 7)] * L(ca)[0];
+                    double tb = (double)L(xb)[q + (h & 7)] * L(cb)[0];
                     for (int j = 1; j < 8; j++) {
-                        ta += (double)pa[-64 * j] * L(ca)[j];
-                        tb += (double)pb[-64 * j] * L(cb)[j];
+                        ta += (double)L(xa)[q + ((h - j) & 7)] * L(ca)[j];
+                        tb += (double)L(xb)[q + ((h - j) & 7)] * L(cb)[j];
                     }
                     w.u.fbk.yp[bb][c][i] = i == 0 ? ta : (i <= 16 ? ta + tb : ta - tb);
                 }

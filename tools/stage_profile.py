@@ -40,3 +40,8 @@ for ch in range(2):
             continue
         d = (hi - st[..., base + i]).mean()
         print(f"    ch{ch} {n:18s} {d:10.0f}  {100 * d / tot:5.1f}%")
+if st[..., 25].max() > 0:
+    fn = ["window+scatter", "first pass", "pass k=2", "pass k=4", "pass k=6", "pass k=8"]
+    for i, n in enumerate(fn):
+        d = (st[..., 25 + i] - st[..., 24 + i]).mean()
+        print(f"      ch0 FHT {n:16s} {d:8.0f}  {100 * d / tot:5.1f}%")
