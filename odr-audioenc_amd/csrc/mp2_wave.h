@@ -49,7 +49,7 @@ TL_FN void tlh_exscan_i32(int (&d)[64], const int (&v)[64]) { int s = 0; for (in
 #define TL_LAUNDER(p) ((void)0)
 #else
 #define TL_FN __device__ __forceinline__
-#define TL_LANES_BEGIN { const int lane = (int)(threadIdx.x & 63u);
+#define TL_LANES_BEGIN { int lane_ = (int)(threadIdx.x & 63u); asm volatile("" : "+v"(lane_)); __builtin_assume(lane_ >= 0 && lane_ < 64); const int lane = lane_;
 #define TL_LANES_END } TL_SYNC();
 #define TL_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -192,10 +192,10 @@ TL_FN double tl_add_db(const double *TL_RESTRICT dbtable, double a, double b)
     // reference's (int)fdiff; beyond it the reference returns the larger operand unchanged, which is
     // operand + table[1000] with table[1000] = -0.0.
     const double fdiff = 10.0 * (a - b);
-    const int idiff = (int)fdiff;
-    const int mag = idiff >= 0 ? idiff : -idiff;
-    const int idx = TL_SELECT(__builtin_fabs(fdiff) > 990.0, 1000, mag);
-    const double base = TL_SELECT(idiff >= 0, a, b);
+    const double af = __builtin_fabs(fdiff);
+    const int mag = (int)af;                                        // == |(int)fdiff|: truncation is symmetric
+    const int idx = TL_SELECT(af > 990.0, 1000, mag);
+    const double base = TL_SELECT(fdiff > -1.0, a, b);              // (int)fdiff >= 0
     return base + dbtable[idx];
 }
 TL_FN uint64_t tl_mnr_key(double mnr)
