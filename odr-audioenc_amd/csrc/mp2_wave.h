@@ -1665,19 +1665,27 @@ TL_FN void tl_encode_stream(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, co
         pv.cur = A.pcm + slot * 2304;
         if (f == 0) { pv.hist = &st->hist[0][0]; pv.hist_stride = TL_HIST; }
         else { pv.hist = A.pcm + (slot - (size_t)A.nstreams) * 2304 + (1152 - TL_HIST); pv.hist_stride = 1152; }
+        TL_STAMP(A.stamps ? A.stamps + slot * 32 : nullptr, 31);        // frame begin, before the PCM staging
         TL_LANES_BEGIN
-        // [history | frame] -> LDS: 240 + 576 dwords per channel, coalesced 4-byte loads
-        for (int i = lane; i < (TL_HIST / 2) * nch; i += 64) {
-            const int ch = i / (TL_HIST / 2), k = (i % (TL_HIST / 2)) * 2;
-            const uint32_t v = *(const uint32_t *)(pv.hist + ch * pv.hist_stride + k);
-            w.u.fbk.pcm[ch][k] = (int16_t)(v & 0xffff);
-            w.u.fbk.pcm[ch][k + 1] = (int16_t)(v >> 16);
-        }
-        for (int i = lane; i < 576 * nch; i += 64) {
-            const uint32_t v = ((const uint32_t *)pv.cur)[i];
-            const int ch = i / 576, k = (i % 576) * 2;
-            w.u.fbk.pcm[ch][TL_HIST + k] = (int16_t)(v & 0xffff);
-            w.u.fbk.pcm[ch][TL_HIST + k + 1] = (int16_t)(v >> 16);
+        {
+            // [history | frame] -> LDS in 8-byte pieces, 120 + 288 per channel.  All of a lane's loads are issued
+            // before the first LDS write so the HBM latency is paid once per frame, not once per piece.
+            constexpr int HP = TL_HIST / 4, CP = 1152 / 4, PER = HP + CP;      // pieces per channel
+            constexpr int NIT = (2 * PER + 63) / 64;
+            uint64_t v[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int i = lane + 64 * it, ch = i >= PER ? 1 : 0, k = i - ch * PER;
+                v[it] = 0;
+                if (i < PER * nch)
+                    v[it] = k < HP ? *(const uint64_t *)(pv.hist + ch * pv.hist_stride + 4 * k)
+                                   : *(const uint64_t *)(pv.cur + ch * 1152 + 4 * (k - HP));
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int i = lane + 64 * it, ch = i >= PER ? 1 : 0, k = i - ch * PER;
+                if (i < PER * nch) *(uint64_t *)&w.u.fbk.pcm[ch][4 * k] = v[it];
+            }
         }
         TL_LANES_END
         int xl = 0;

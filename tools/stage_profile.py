@@ -45,3 +45,9 @@ if st[..., 25].max() > 0:
     for i, n in enumerate(fn):
         d = (st[..., 25 + i] - st[..., 24 + i]).mean()
         print(f"      ch0 FHT {n:16s} {d:8.0f}  {100 * d / tot:5.1f}%")
+if st[..., 31].max() > 0:
+    d = (st[..., 0] - st[..., 31]).mean()
+    print(f"  PCM staging before stamp 0: {d:8.0f}  {100 * d / tot:5.1f}% (not in the total above)")
+    if st.shape[0] > 1:
+        g = (st[1:, :, 31] - st[:-1, :, 7]).mean()
+        print(f"  gap between frames (emit end -> next frame begin): {g:8.0f}")
