@@ -251,6 +251,10 @@ int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, 
         memset(C->p1_lineband, 255, sizeof C->p1_lineband);
         for (int b = 0; b + 1 < C->p1_ncb; b++)
             for (int j = C->p1_cbound[b]; j < C->p1_cbound[b + 1]; j++) C->p1_lineband[j] = (uint8_t)b;
+        memset(C->p1_lineinfo, 0, sizeof C->p1_lineinfo);
+        for (int b = 0; b + 1 < C->p1_ncb; b++)
+            for (int j = C->p1_cbound[b]; j < C->p1_cbound[b + 1] && j < 512; j++)
+                C->p1_lineinfo[j] = (uint32_t)b | ((uint32_t)C->p1_cbound[b] << 8) | ((uint32_t)C->p1_cbound[b + 1] << 20);
         // resolve the sequential minimum-mask walk (psycho_1.c:541-559) into per-subband row ranges
         int j = 1;
         for (int sb = 0; sb < C->sblimit; sb++) {
@@ -279,6 +283,10 @@ int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, 
         memset(C->p3_lineband, 255, sizeof C->p3_lineband);
         for (int b = 0; b < cb; b++)
             for (int j = C->p3_cbidx[b]; j < C->p3_cbidx[b + 1]; j++) C->p3_lineband[j] = (uint8_t)b;
+        memset(C->p3_lineinfo, 0, sizeof C->p3_lineinfo);
+        for (int b = 0; b < cb; b++)
+            for (int j = C->p3_cbidx[b]; j < C->p3_cbidx[b + 1]; j++)
+                C->p3_lineinfo[j] = (uint32_t)b | ((uint32_t)C->p3_cbidx[b] << 8) | ((uint32_t)C->p3_cbidx[b + 1] << 20);
         int n = 0, i = 1;
         for (; i < 3 * 16 + 1; i++) C->p3_subset[n++] = (int16_t)i;
         for (; i < 6 * 16 + 1; i += 2) C->p3_subset[n++] = (int16_t)i;

@@ -60,6 +60,7 @@ struct TlConfig {
     double p1_hear[136];
     uint8_t p1_map[520];
     uint8_t p1_lineband[520];    // critical band of each FFT line (index into p1_cbound), 255 outside the bands
+    uint32_t p1_lineinfo[512];   // per FFT line inside the bands: band | lo << 8 | hi << 20 (lo/hi = first line of the band / of the next); 0 outside
     int16_t p1_mm_j0[32];        // minimum-mask walk (psycho_1.c:541-559) resolved per subband:
     int16_t p1_mm_n[32];         //   first table row, number of rows (0 => use hear[sub-1])
     // psy model 3 (psycho_3.c:434-512)
@@ -68,6 +69,7 @@ struct TlConfig {
     int16_t p3_cbidx[36];
     int16_t p3_subset[136];
     uint8_t p3_lineband[520];    // critical band of each FFT line (index into p3_cbidx)
+    uint32_t p3_lineinfo[520];   // band | lo << 8 | hi << 20 per FFT line, as for psy 1
     int16_t p3_sb_j0[32], p3_sb_n[32];   // rows of p3_subset that fall into each subband (psycho_3.c:415-420)
     // psy model 0 (psycho_0.c:36-50)
     double p0_athmin[32];

@@ -514,30 +514,28 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     const int nbands = C->p1_ncb - 1;
     {
         double *vt = w.u.fft, *vp = w.u.fft + 520;
-        const int first = C->p1_cbound[0], end = C->p1_cbound[nbands];
         int nvalid = 0;
-        for (int base = first; base < end; base += 64) {
-            PV(bool, ok); PV(double, tv); PV(double, pvv);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int base = 0; base < 512; base += 64) {                // straight-line: the table reads of all chunks overlap
+            PV(bool, ok); PV(double, tv); PV(double, pvv); PV(int, bnd);
             TL_LANES_BEGIN
             const int j = base + lane;
+            const uint32_t info = C->p1_lineinfo[j];
+            const int lo = (int)((info >> 8) & 0xfffu), hi = (int)(info >> 20);
             bool v = false; double t = 0, p = 0;
-            if (j < end) {
-                const int bnd = C->p1_lineband[j];
-                const int lo = C->p1_cbound[bnd], hi = C->p1_cbound[bnd + 1];
+            if (info) {                                             // line inside the bands
                 p = w.px[j];
                 v = w.ptype[j] != TL_T_TONE && p != TL_DBMIN;
                 t = 1073741824 * energy[j] * (double)(j - lo) / (double)(hi - lo);
             }
-            L(ok) = v; L(tv) = t; L(pvv) = p;
+            L(ok) = v; L(tv) = t; L(pvv) = p; L(bnd) = (info && j == lo) ? (int)(info & 0xffu) : -1;
             TL_LANES_END
             const uint64_t m = TL_BALLOT(ok);
             TL_LANES_BEGIN
-            const int j = base + lane;
             const int pos = nvalid + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-            if (j < end) {
-                const int bnd = C->p1_lineband[j];
-                if (j == C->p1_cbound[bnd]) w.bandoff[bnd] = (int16_t)pos;     // first line of its band
-            }
+            if (L(bnd) >= 0) w.bandoff[L(bnd)] = (int16_t)pos;     // first line of its band
             if (L(ok)) { vt[pos] = L(tv); vp[pos] = L(pvv); }
             TL_LANES_END
             nvalid += __builtin_popcountll(m);
@@ -848,25 +846,26 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     // bare chains.  energy[512] shares its slot with the first centre term and is read up front.
     {
         double *ve = w.u.fft, *vc = w.u.fft + 512, *vp = w.px;
-        const int first = C->p3_cbidx[0], end = C->p3_cbidx[nb];
         PV(double, e512);
         TL_LANES_BEGIN L(e512) = energy[512]; TL_LANES_END
         int nvalid = 0;
-        for (int base = first; base < end; base += 64) {
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int base = 0; base < 576; base += 64) {                // lines 1..512; straight-line so the table reads overlap
             PV(bool, ok); PV(double, ev); PV(double, cv); PV(double, pvv); PV(int, bnd);
             TL_LANES_BEGIN
             const int j = base + lane;
-            bool v = false; double e = 0, c = 0, p = 0; int bd = -1;
-            if (j < end) {
-                const int b0 = C->p3_lineband[j];
-                const int lo = C->p3_cbidx[b0];
+            const uint32_t info = j < 520 ? C->p3_lineinfo[j] : 0u;
+            const int lo = (int)((info >> 8) & 0xfffu);
+            bool v = false; double e = 0, c = 0, p = 0;
+            if (info) {
                 p = w.px[j];
                 v = p != TL_DBMIN;
                 e = j == 512 ? L(e512) : energy[j];
                 c = (j - lo) * e;
-                bd = j == lo ? b0 : -1;
             }
-            L(ok) = v; L(ev) = e; L(cv) = c; L(pvv) = p; L(bnd) = bd;
+            L(ok) = v; L(ev) = e; L(cv) = c; L(pvv) = p; L(bnd) = (info && j == lo) ? (int)(info & 0xffu) : -1;
             TL_LANES_END
             const uint64_t m = TL_BALLOT(ok);
             TL_LANES_BEGIN
