@@ -251,6 +251,7 @@ int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, 
         memset(C->p1_lineband, 255, sizeof C->p1_lineband);
         for (int b = 0; b + 1 < C->p1_ncb; b++)
             for (int j = C->p1_cbound[b]; j < C->p1_cbound[b + 1]; j++) C->p1_lineband[j] = (uint8_t)b;
+        for (int j = 0; j < 512; j++) { C->p1_lbark[j] = C->p1_bark[C->p1_map[j]]; C->p1_lhear[j] = C->p1_hear[C->p1_map[j]]; }
         memset(C->p1_lineinfo, 0, sizeof C->p1_lineinfo);
         for (int b = 0; b + 1 < C->p1_ncb; b++)
             for (int j = C->p1_cbound[b]; j < C->p1_cbound[b + 1] && j < 512; j++)

@@ -37,7 +37,17 @@ TL_FN uint64_t tlh_min_u64(const uint64_t (&v)[64]) { uint64_t m = v[0]; for (in
 TL_FN int tlh_sum_i32(const int (&v)[64]) { int s = 0; for (int i = 0; i < 64; i++) s += v[i]; return s; }
 TL_FN uint32_t tlh_xor_u32(const uint32_t (&v)[64]) { uint32_t s = 0; for (int i = 0; i < 64; i++) s ^= v[i]; return s; }
 TL_FN void tlh_exscan_i32(int (&d)[64], const int (&v)[64]) { int s = 0; for (int i = 0; i < 64; i++) { d[i] = s; s += v[i]; } }
+TL_FN int tlh_argmin_u64(const uint64_t (&v)[64])
+{   // lane of the smallest key, ties: channel-0 lanes (even) first, then ascending; -1 when every key is ~0
+    const uint64_t m = tlh_min_u64(v);
+    if (m == ~0ull) return -1;
+    for (int i = 0; i < 64; i += 2) if (v[i] == m) return i;
+    for (int i = 1; i < 64; i += 2) if (v[i] == m) return i;
+    return -1;
+}
 #define TL_BALLOT(name) tlh_ballot(name)
+#define TL_SWAP1_U64(dst, src) do { for (int l_ = 0; l_ < 64; l_++) dst[l_] = src[l_ ^ 1]; } while (0)
+#define TL_WAVE_ARGMIN_U64(name) tlh_argmin_u64(name)
 #define TL_WAVE_MIN_U64(name) tlh_min_u64(name)
 #define TL_WAVE_SUM_I32(name) tlh_sum_i32(name)
 #define TL_WAVE_XOR_U32(name) tlh_xor_u32(name)
@@ -109,7 +119,22 @@ TL_FN uint32_t tld_xor_u32(uint32_t x) {
 }
 TL_FN int tld_sum_i32(int v) { return __builtin_amdgcn_readlane(tld_incl_scan_i32(v), 63); }
 TL_FN int tld_exscan_i32(int v) { return tld_incl_scan_i32(v) - v; }
+TL_FN int tld_argmin_u64(uint64_t v)
+{   // as tlh_argmin_u64.  The low words are only reduced when several lanes share the smallest high word.
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    const uint32_t mhi = tld_min_u32(hi);
+    uint64_t m = (uint64_t)__ballot(hi == mhi);
+    if (__builtin_popcountll(m) > 1) {
+        const uint32_t mlo = tld_min_u32(hi == mhi ? lo : 0xffffffffu);
+        if ((mhi & mlo) == 0xffffffffu) return -1;
+        m = (uint64_t)__ballot(hi == mhi && lo == mlo);
+    } else if (mhi == 0xffffffffu && (uint32_t)__builtin_amdgcn_readlane((int)lo, __builtin_ctzll(m)) == 0xffffffffu) return -1;
+    const uint64_t even = m & 0x5555555555555555ull;
+    return __builtin_ctzll(even ? even : m);
+}
 #define TL_BALLOT(name) ((uint64_t)__ballot(name))
+#define TL_SWAP1_U64(dst, src) dst = tl_d2u(tld_swap1_f64(tl_u2d(src)))
+#define TL_WAVE_ARGMIN_U64(name) tld_argmin_u64(name)
 #define TL_WAVE_MIN_U64(name) tld_min_u64(name)
 #define TL_WAVE_SUM_I32(name) tld_sum_i32(name)
 #define TL_WAVE_XOR_U32(name) tld_xor_u32(name)
@@ -662,8 +687,8 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
             bool kp = false; double x = 0, bk = 0;
             if (base + lane < nlist) {
                 const int cc = w.conf_c[w.tlist[base + lane]], c = cc & 511;
-                x = w.px[c]; bk = C->p1_bark[map[c]];
-                kp = !((cc >> 13) & 1) && !(x < C->p1_hear[map[c]]);
+                x = w.px[c]; bk = C->p1_lbark[c];
+                kp = !((cc >> 13) & 1) && !(x < C->p1_lhear[c]);
             }
             L(keep) = kp; L(kx) = x; L(kb) = bk;
             TL_LANES_END
@@ -698,8 +723,8 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         bool kp = false; double x = 0, bk = 0;
         if (lane < nbands) {
             const int c = w.ncentre[lane];
-            x = w.px[c]; bk = C->p1_bark[map[c]];
-            kp = !(x < C->p1_hear[map[c]]);
+            x = w.px[c]; bk = C->p1_lbark[c];
+            kp = !(x < C->p1_lhear[c]);
         }
         L(keepn) = kp; L(nx) = x; L(nb) = bk;
         TL_LANES_END
@@ -1382,35 +1407,71 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         // The reference marks a cell used=2 when its next step does not fit.  The bits left only shrink and a
         // cell's price only changes when it wins, so a cell that does not fit now never fits later: such cells
         // are left out of the arg-min right away (same result, no iterations spent on refusals).
-        PV(uint64_t, ukey); PV(int, ba); PV(int, nbits); PV(int, cost);
-        PV(double, mnr_nx); PV(int, cost_nx);                       // values of the NEXT step, fetched one win ahead
+        //
+        // A cell's mnr only grows with its allocation (the SNR column of an allocation line is increasing), so the
+        // greedy order is the merge of the cells' ascending key lists.  Every cell therefore carries the key and the
+        // price of its next step AND of the step after it; with M = the smallest second key in the wave, the cells
+        // whose next key is below M are exactly the greedy order's next events (no second step can come before
+        // them).  If together they still fit, they are all taken in one round; the one-at-a-time loop takes over
+        // when a round no longer fits (or is empty), so the refusal rule above is applied event by event.
+        PV(uint64_t, ukey); PV(uint64_t, ukey2); PV(int, ba); PV(int, nbits); PV(int, cost); PV(int, cost2);
+        PV(int, jpair);                                             // lane belongs to a joint-coded pair (steps with its partner)
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
         const bool live = c < nch && sb < sblimit;
+        const int maxa = (1 << L(a_nbal)) - 1;
         L(ukey) = live ? tl_mnr_key(B->snr_line[L(a_ln)][0] - L(a_smr)) : ~0ull;
+        L(ukey2) = (live && 1 < maxa) ? tl_mnr_key(B->snr_line[L(a_ln)][1] - L(a_smr)) : ~0ull;
         L(ba) = 0;
         L(nbits) = (sb < sblimit && c < (sb < jsbound ? nch : 1)) ? L(a_nbal) : 0;
         // first step of a cell: samples + scfsi + scalefactors (both channels above jsbound), :1139-1147
         L(cost) = live ? B->bits12_line[L(a_ln)][1] + 2 + L(a_sfs) + ((nch == 2 && sb >= jsbound) ? 2 + L(a_sfs_o) : 0) : 0;
-        L(mnr_nx) = live ? B->snr_line[L(a_ln)][1] - L(a_smr) : 0.0;
-        L(cost_nx) = live ? B->bits12_line[L(a_ln)][2] - B->bits12_line[L(a_ln)][1] : 0;
+        L(cost2) = live ? B->bits12_line[L(a_ln)][2] - B->bits12_line[L(a_ln)][1] : 0;
+        L(jpair) = (live && nch == 2 && sb >= jsbound) ? 1 : 0;
         TL_LANES_END
         const int bbal = TL_WAVE_SUM_I32(nbits);
         const int ad = adb - (bbal + 16 + 32);
         int spent = 0;                                              // bspl + bscf + bsel
-        for (int guard = 0; guard < 2048; guard++) {
+        const bool any_pair = nch == 2 && jsbound < sblimit;
+        for (;;) {                                                  // rounds
+            PV(uint64_t, keff); PV(uint64_t, k2eff);
+            TL_LANES_BEGIN L(keff) = L(ukey); L(k2eff) = L(ukey2); TL_LANES_END
+            if (any_pair) {                                         // a pair acts at the smaller of its two keys
+                PV(uint64_t, ok1); PV(uint64_t, ok2);
+                TL_SWAP1_U64(ok1, ukey); TL_SWAP1_U64(ok2, ukey2);
+                TL_LANES_BEGIN
+                if (L(jpair)) { if (L(ok1) < L(keff)) L(keff) = L(ok1); if (L(ok2) < L(k2eff)) L(k2eff) = L(ok2); }
+                TL_LANES_END
+            }
+            const uint64_t M = TL_WAVE_MIN_U64(k2eff);
+            PV(bool, inb); PV(int, bcost);
+            TL_LANES_BEGIN
+            L(inb) = L(keff) < M;
+            L(bcost) = (L(inb) && !(L(jpair) && (lane & 1))) ? L(cost) : 0;     // a pair pays once
+            TL_LANES_END
+            if (TL_BALLOT(inb) == 0ull) break;
+            const int csum = TL_WAVE_SUM_I32(bcost);
+            if (csum > ad - spent) break;
+            spent += csum;
+            TL_LANES_BEGIN
+            if (L(inb)) {
+                const int nba = L(ba) + 1;
+                L(ba) = nba;
+                L(ukey) = L(ukey2);
+                L(cost) = L(cost2);
+                L(ukey2) = (nba + 1 >= (1 << L(a_nbal)) - 1) ? ~0ull : tl_mnr_key(B->snr_line[L(a_ln)][(nba + 1) & 15] - L(a_smr));
+                L(cost2) = B->bits12_line[L(a_ln)][(nba + 2) & 15] - B->bits12_line[L(a_ln)][(nba + 1) & 15];
+            }
+            TL_LANES_END
+        }
+        for (;;) {                                                  // one event at a time
             // maxmnr_new (encode_new.c:1061-1077): smallest mnr, first in (ch, sb) order
             PV(uint64_t, key);
             TL_LANES_BEGIN
             L(key) = L(cost) <= ad - spent ? L(ukey) : ~0ull;
             TL_LANES_END
-            const uint64_t kmin = TL_WAVE_MIN_U64(key);
-            if (kmin == ~0ull) break;
-            PV(bool, hit);
-            TL_LANES_BEGIN L(hit) = L(key) == kmin; TL_LANES_END
-            const uint64_t hm = TL_BALLOT(hit);
-            const uint64_t even = hm & 0x5555555555555555ull;       // ch 0 first, then ascending sb
-            const int wl = __builtin_ctzll(even ? even : hm);
+            const int wl = TL_WAVE_ARGMIN_U64(key);                  // ch 0 first, then ascending sb
+            if (wl < 0) break;
             const int min_sb = wl >> 1;
             spent += TL_READLANE_I32(cost, wl);
             const bool joint_pair = (min_sb >= jsbound && nch == 2);
@@ -1418,10 +1479,10 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             if (lane == wl || (joint_pair && (lane ^ 1) == wl)) {
                 const int nba = L(ba) + 1;
                 L(ba) = nba;
-                L(ukey) = (nba >= (1 << L(a_nbal)) - 1) ? ~0ull : tl_mnr_key(L(mnr_nx));   // == snr_line[ln][nba] - smr
-                L(cost) = L(cost_nx);                                // == bits12[nba+1] - bits12[nba]
-                L(mnr_nx) = B->snr_line[L(a_ln)][(nba + 1) & 15] - L(a_smr);
-                L(cost_nx) = B->bits12_line[L(a_ln)][(nba + 2) & 15] - B->bits12_line[L(a_ln)][(nba + 1) & 15];
+                L(ukey) = L(ukey2);
+                L(cost) = L(cost2);
+                L(ukey2) = (nba + 1 >= (1 << L(a_nbal)) - 1) ? ~0ull : tl_mnr_key(B->snr_line[L(a_ln)][(nba + 1) & 15] - L(a_smr));
+                L(cost2) = B->bits12_line[L(a_ln)][(nba + 2) & 15] - B->bits12_line[L(a_ln)][(nba + 1) & 15];
             }
             TL_LANES_END
         }
@@ -1556,14 +1617,18 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         if (32 * lane < n) {
             const uint32_t chunk = lane == 0 ? ((frame[0] & 0xffffu) << 16) | (frame[1] & 0xffffu) : frame[lane + 1];
             const int cnt = n - 32 * lane < 32 ? n - 32 * lane : 32;
+            const int after = n - 32 * lane - cnt;
+            unsigned xp = T->crc_xpow[after];                        // x^after mod P: the only table read, issued ahead of the bit loop
             unsigned r = lane == 0 ? 0xffffu : 0u;
             for (int bit = 0; bit < cnt; bit++) {
                 const unsigned d = (chunk >> (31 - bit)) & 1u;
                 const unsigned fb = ((r >> 15) ^ d) & 1u;
                 r = ((r << 1) & 0xffffu) ^ (fb ? 0x8005u : 0u);
             }
-            const int after = n - 32 * lane - cnt;
-            for (int b16 = 0; b16 < 16; b16++) if ((r >> b16) & 1u) acc ^= T->crc_xpow[b16 + after];
+            for (int b16 = 0; b16 < 16; b16++) {                    // acc = r(x) * x^after mod P, shift-and-add in GF(2)
+                acc ^= ((r >> b16) & 1u) ? xp : 0u;
+                xp = ((xp << 1) & 0xffffu) ^ ((xp & 0x8000u) ? 0x8005u : 0u);
+            }
         }
         L(part) = acc;
         TL_LANES_END
