@@ -1449,10 +1449,37 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             L(inb) = L(keff) < M;
             L(bcost) = (L(inb) && !(L(jpair) && (lane & 1))) ? L(cost) : 0;     // a pair pays once
             TL_LANES_END
-            if (TL_BALLOT(inb) == 0ull) break;
+            const uint64_t bm = TL_BALLOT(inb);
+            if (bm == 0ull) break;
             const int csum = TL_WAVE_SUM_I32(bcost);
-            if (csum > ad - spent) break;
-            spent += csum;
+            bool last_round = false;
+            if (csum > ad - spent) {
+                // The round does not fit as a whole: admit its events up to the first refusal.  Each cell adds up the
+                // prices of the round's events that come no later than its own (equal keys count as earlier, which can
+                // only shorten the admitted prefix); the prefix sums grow along the greedy order, so the cells whose
+                // sum still fits are exactly a prefix of it.  The event-by-event loop below deals with the rest.
+                PV(int, pre); PV(int, kh); PV(int, kl);
+                TL_LANES_BEGIN L(pre) = L(cost); L(kh) = (int)(uint32_t)(L(keff) >> 32); L(kl) = (int)(uint32_t)L(keff); TL_LANES_END
+                uint64_t pm = bm;
+                while (pm) {
+                    const int j = __builtin_ctzll(pm);
+                    pm &= pm - 1;
+                    const int cj = TL_READLANE_I32(bcost, j);
+                    if (cj == 0) continue;                          // the non-paying lane of a pair
+                    const uint64_t kj = ((uint64_t)(uint32_t)TL_READLANE_I32(kh, j) << 32) | (uint32_t)TL_READLANE_I32(kl, j);
+                    TL_LANES_BEGIN
+                    const int own = L(jpair) ? (lane & ~1) : lane;
+                    if (j != own && kj <= L(keff)) L(pre) += cj;
+                    TL_LANES_END
+                }
+                TL_LANES_BEGIN
+                L(inb) = L(inb) && L(pre) <= ad - spent;
+                L(bcost) = L(inb) ? L(bcost) : 0;
+                TL_LANES_END
+                if (TL_BALLOT(inb) == 0ull) break;
+                spent += TL_WAVE_SUM_I32(bcost);
+                last_round = true;
+            } else spent += csum;
             TL_LANES_BEGIN
             if (L(inb)) {
                 const int nba = L(ba) + 1;
@@ -1463,6 +1490,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
                 L(cost2) = B->bits12_line[L(a_ln)][(nba + 2) & 15] - B->bits12_line[L(a_ln)][(nba + 1) & 15];
             }
             TL_LANES_END
+            if (last_round) break;
         }
         for (;;) {                                                  // one event at a time
             // maxmnr_new (encode_new.c:1061-1077): smallest mnr, first in (ch, sb) order
