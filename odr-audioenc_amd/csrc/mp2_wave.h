@@ -45,6 +45,9 @@ TL_FN int tlh_argmin_u64(const uint64_t (&v)[64])
     for (int i = 1; i < 64; i += 2) if (v[i] == m) return i;
     return -1;
 }
+TL_FN void tlh_row16_max_f64(double (&d)[64], const double (&v)[64])
+{ for (int r = 0; r < 4; r++) { double m = v[16 * r]; for (int i = 1; i < 16; i++) if (m < v[16 * r + i]) m = v[16 * r + i]; for (int i = 0; i < 16; i++) d[16 * r + i] = m; } }
+#define TL_ROW16_MAX_F64(dst, src) tlh_row16_max_f64(dst, src)      /* valid in lane 15 of each row of 16 (all lanes here) */
 #define TL_BALLOT(name) tlh_ballot(name)
 #define TL_SWAP1_U64(dst, src) do { for (int l_ = 0; l_ < 64; l_++) dst[l_] = src[l_ ^ 1]; } while (0)
 #define TL_WAVE_ARGMIN_U64(name) tlh_argmin_u64(name)
@@ -132,6 +135,26 @@ TL_FN int tld_argmin_u64(uint64_t v)
     const uint64_t even = m & 0x5555555555555555ull;
     return __builtin_ctzll(even ? even : m);
 }
+TL_FN double tld_row16_max_f64(double v)
+{   // maximum over each row of 16 lanes, valid in the row's lane 15 (row_shr 1,2,4,8; shifted-in lanes keep their own value)
+#pragma unroll
+    for (int sh = 1; sh <= 8; sh <<= 1) {
+        const uint64_t u = tl_d2u(v);
+        const int ctl = 0x110 | sh;
+        uint32_t lo, hi;
+        switch (sh) {
+        case 1: lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)u, (int)(uint32_t)u, 0x111, 0xf, 0xf, false); hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(u >> 32), (int)(uint32_t)(u >> 32), 0x111, 0xf, 0xf, false); break;
+        case 2: lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)u, (int)(uint32_t)u, 0x112, 0xf, 0xf, false); hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(u >> 32), (int)(uint32_t)(u >> 32), 0x112, 0xf, 0xf, false); break;
+        case 4: lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)u, (int)(uint32_t)u, 0x114, 0xf, 0xf, false); hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(u >> 32), (int)(uint32_t)(u >> 32), 0x114, 0xf, 0xf, false); break;
+        default: lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)u, (int)(uint32_t)u, 0x118, 0xf, 0xf, false); hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(u >> 32), (int)(uint32_t)(u >> 32), 0x118, 0xf, 0xf, false); break;
+        }
+        (void)ctl;
+        const double o = tl_u2d(((uint64_t)hi << 32) | lo);
+        v = v < o ? o : v;
+    }
+    return v;
+}
+#define TL_ROW16_MAX_F64(dst, src) dst = tld_row16_max_f64(src)
 #define TL_BALLOT(name) ((uint64_t)__ballot(name))
 #define TL_SWAP1_U64(dst, src) dst = tl_d2u(tld_swap1_f64(tl_u2d(src)))
 #define TL_WAVE_ARGMIN_U64(name) tld_argmin_u64(name)
@@ -432,16 +455,22 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     TL_STAMP(sp, 1);
 
     // power density spectrum (psycho_1.c:241-248); spike (psycho_1.c:252-257)
+    // The spike sums read 16 consecutive energies per lane; a copy with row stride 17 in the (free) upper half of the
+    // buffer keeps those reads off each other's LDS banks.  Only subbands below sblimit (<= 30) are ever used.
+    double *espk = w.u.fft + 513;
     TL_LANES_BEGIN
     for (int i = lane; i < 512; i += 64) {
         double e = energy[i];
-        w.px[i] = e < 1E-20 ? -200.0 + TL_POWERNORM : 10 * tl_log10(e) + TL_POWERNORM;
+        w.px[i] = e < 1E-20 ? -200.0 + TL_POWERNORM : 10 * tl_log10_pn(e) + TL_POWERNORM;
         w.ptype[i] = 0;
+        if (i < 480) espk[17 * (i >> 4) + (i & 15)] = 1073741824 * e;
     }
-    if (lane < 32) {
+    TL_LANES_END
+    TL_LANES_BEGIN
+    if (lane < 30) {
         double sum = 1E-20;
-        for (int j = 0; j < 16; j++) sum += 1073741824 * energy[16 * lane + j];
-        w.spike[lane] = 10.0 * tl_log10(sum);
+        for (int j = 0; j < 16; j++) sum += espk[17 * lane + j];
+        w.spike[lane] = 10.0 * tl_log10_pn(sum);
     }
     TL_LANES_END
 
@@ -801,20 +830,32 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
 
     // power[1..512] (psycho_3.c:152-160); power[0] is an uninitialised slot in the reference, pinned
     // to 0.0 (oracle/mp2_oracle.c:psy3_run)
-    TL_LANES_BEGIN
-    for (int i = lane; i < 513; i += 64) {
-        double e = energy[i];
-        w.px[i] = i == 0 ? 0.0 : (e < 1E-20 ? -200.0 + TL_POWERNORM : 10 * tl_log10(e) + TL_POWERNORM);
+    // and Lsb (psycho_3.c:163-183; line 512 is skipped, see oracle) -> w.spike.  A subband's 16 lines sit in one row of
+    // 16 lanes, so its maximum is a row reduction of the values just computed (no strided re-read of px).
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int it = 0; it < 8; it++) {
+        PV(double, pxv); PV(double, pxm);
+        TL_LANES_BEGIN
+        const int i = lane + 64 * it;
+        const double e = energy[i];
+        const double v = e < 1E-20 ? -200.0 + TL_POWERNORM : 10 * tl_log10_pn(e) + TL_POWERNORM;
+        w.px[i] = i == 0 ? 0.0 : v;
+        L(pxv) = i == 0 ? TL_DBMIN : v;
+        TL_LANES_END
+        TL_ROW16_MAX_F64(pxm, pxv);
+        TL_LANES_BEGIN
+        if ((lane & 15) == 15) {
+            const int sb = (lane + 64 * it) >> 4;
+            const double xmax = TL_DBMIN < L(pxm) ? L(pxm) : TL_DBMIN;
+            const double val = C->scale_db[w.minidx[ch][sb]];
+            w.spike[sb] = xmax > val ? xmax : val;
+        }
+        TL_LANES_END
     }
-    TL_LANES_END
-    // Lsb (psycho_3.c:163-183; line 512 is skipped, see oracle) -> w.spike
     TL_LANES_BEGIN
-    if (lane < 32) {
-        double xmax = TL_DBMIN;
-        for (int i = 16 * lane; i < 16 * lane + 16; i++) if (i >= 1 && xmax < w.px[i]) xmax = w.px[i];
-        double val = C->scale_db[w.minidx[ch][lane]];
-        w.spike[lane] = xmax > val ? xmax : val;
-    }
+    if (lane == 0) { const double e = energy[512]; w.px[512] = e < 1E-20 ? -200.0 + TL_POWERNORM : 10 * tl_log10_pn(e) + TL_POWERNORM; }
     TL_LANES_END
     // ---- tone labelling (psycho_3.c:186-247) ----
     // (1) local maxima 2..499 whose right-hand neighbours are >= 7 dB down, compacted ascending

@@ -79,6 +79,48 @@ TL_HD double tl_log10(double x)
     return val_lo + val_hi;
 }
 
+// log10(x) for positive NORMAL finite x only, straight-line (no branches): the same operations as tl_log10 on
+// that domain, so the same bits.  The encoder's spectra are clamped at 1e-20 before the call; for any other input
+// the result is unspecified (and discarded by the caller's select), never a trap.
+TL_HD double tl_log10_pn(double x)
+{
+    const double ivln10hi = 4.34294481878168880939e-01, ivln10lo = 2.50829467116452752298e-11;
+    const double log10_2hi = 3.01029995663611771306e-01, log10_2lo = 3.69423907715893078616e-13;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t u = tl_d2u(x);
+    const bool one = u == 0x3ff0000000000000ull;
+    int32_t hx = (int32_t)(u >> 32);
+    int k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int32_t i = (hx + 0x95f64) & 0x100000;
+    u = ((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32) | (u & 0xffffffffull);
+    x = tl_u2d(u);
+    k += (i >> 20);
+    const double y = (double)k;
+    const double f = x - 1.0;
+    const double hfsq = 0.5 * f * f;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double r = s * (hfsq + (t2 + t1));
+    double hi = f - hfsq;
+    hi = tl_u2d(tl_d2u(hi) & 0xffffffff00000000ull);
+    const double lo = (f - hi) - hfsq + r;
+    double val_hi = hi * ivln10hi;
+    const double y2 = y * log10_2hi;
+    double val_lo = y * log10_2lo + (lo + hi) * ivln10lo + lo * ivln10hi;
+    const double ww = y2 + val_hi;
+    val_lo += (y2 - ww) + val_hi;
+    val_hi = ww;
+    const double res = val_lo + val_hi;
+    return one ? 0.0 : res;
+}
+
 // 10^x for |x| < 300.
 TL_HD double tl_pow10(double x)
 {

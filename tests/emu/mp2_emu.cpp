@@ -84,5 +84,6 @@ int emu_pending(void *h, int s, uint8_t *out)
 int emu_sizeof_taps(void) { return (int)sizeof(TlTaps); }
 int emu_sizeof_lds(void) { return (int)sizeof(TlWaveLds); }
 double emu_log10(double x) { return tl_log10(x); }
+double emu_log10_pn(double x) { return tl_log10_pn(x); }
 double emu_pow10(double x) { return tl_pow10(x); }
 }

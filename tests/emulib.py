@@ -34,6 +34,8 @@ def lib():
         L.emu_pending.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_log10.restype = C.c_double
         L.emu_log10.argtypes = [C.c_double]
+        L.emu_log10_pn.restype = C.c_double
+        L.emu_log10_pn.argtypes = [C.c_double]
         L.emu_pow10.restype = C.c_double
         L.emu_pow10.argtypes = [C.c_double]
         assert L.emu_sizeof_taps() == TAPS_DTYPE.itemsize, (L.emu_sizeof_taps(), TAPS_DTYPE.itemsize)

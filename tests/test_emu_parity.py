@@ -84,6 +84,9 @@ def test_emulated_log10_pow10_accuracy():
         a, b = L.emu_log10(float(x)), math.log10(float(x))
         worst = max(worst, abs(int(np.float64(a).view(np.int64)) - int(np.float64(b).view(np.int64))))
     assert worst <= 2
+    # the straight-line variant used on clamped spectra is the same function on positive normals, bit for bit
+    for x in np.concatenate([10 ** rng.uniform(-20, 12, 20000), 1 + rng.uniform(-0.1, 0.1, 5000), [1.0, 1e-20, 0.5, 2.0]]):
+        assert np.float64(L.emu_log10_pn(float(x))).view(np.int64) == np.float64(L.emu_log10(float(x))).view(np.int64)
     worst = 0
     for x in rng.uniform(-20, 25, 20000):
         a, b = L.emu_pow10(float(x)), math.pow(10.0, float(x))
