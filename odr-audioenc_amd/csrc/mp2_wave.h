@@ -311,33 +311,36 @@ TL_FN void tl_fht_pass_first(double *x, int lane)
         fi[2] = f0 - f2; fi[0] = f0 + f2; fi[3] = f1 - f3; fi[1] = f1 + f3;
     }
 }
-TL_FN void tl_fht_pass(double *x, int k, int twbase, const double (*TL_RESTRICT tw)[4], int lane)
-{   // fft.c:1104-1184: one pass = 128 independent 8-point butterflies
+template <int K>
+TL_FN void tl_fht_pass(double *x, int twbase, const double (*TL_RESTRICT tw)[4], int lane)
+{   // fft.c:1104-1184: one pass = 128 independent 8-point butterflies: per block of 4*k1 points one with trivial /
+    // sqrt(2) twiddles (i = 0) and kx-1 general ones.  The general ones are dealt densely to the lanes and the
+    // trivial ones follow in their own step, so a wave never runs both code paths for one batch of butterflies.
     const double SQRT2 = 1.4142135623730951454746218587388284504414;
-    const int k1 = 1 << k, k2 = k1 << 1, k4 = k2 << 1, k3 = k2 + k1, kx = k1 >> 1;
-    for (int b = lane; b < 128; b += 64) {
-        int blk = b / kx, i = b - blk * kx;
+    constexpr int k1 = 1 << K, k2 = k1 << 1, k4 = k2 << 1, k3 = k2 + k1, kx = k1 >> 1;
+    constexpr int NBLK = 128 / kx, NGEN = 128 - NBLK;
+    for (int g = lane; g < NGEN; g += 64) {
+        const int blk = g / (kx - 1), i = 1 + (g - blk * (kx - 1));
         double *base = x + blk * k4;
-        if (i == 0) {
-            double *fi = base, *gi = base + kx;
-            double f1 = fi[0] - fi[k1], f0 = fi[0] + fi[k1], f3 = fi[k2] - fi[k3], f2 = fi[k2] + fi[k3];
-            fi[k2] = f0 - f2; fi[0] = f0 + f2; fi[k3] = f1 - f3; fi[k1] = f1 + f3;
-            double g1 = gi[0] - gi[k1], g0 = gi[0] + gi[k1], g3 = SQRT2 * gi[k3], g2 = SQRT2 * gi[k2];
-            gi[k2] = g0 - g2; gi[0] = g0 + g2; gi[k3] = g1 - g3; gi[k1] = g1 + g3;
-        } else {
-            const double c1 = tw[twbase + i - 1][0], s1 = tw[twbase + i - 1][1];
-            const double c2 = tw[twbase + i - 1][2], s2 = tw[twbase + i - 1][3];
-            double *fi = base + i, *gi = base + k1 - i;
-            double a, b2, g0, f0, f1, g1, f2, g2, f3, g3;
-            b2 = s2 * fi[k1] - c2 * gi[k1]; a = c2 * fi[k1] + s2 * gi[k1];
-            f1 = fi[0] - a; f0 = fi[0] + a; g1 = gi[0] - b2; g0 = gi[0] + b2;
-            b2 = s2 * fi[k3] - c2 * gi[k3]; a = c2 * fi[k3] + s2 * gi[k3];
-            f3 = fi[k2] - a; f2 = fi[k2] + a; g3 = gi[k2] - b2; g2 = gi[k2] + b2;
-            b2 = s1 * f2 - c1 * g3; a = c1 * f2 + s1 * g3;
-            fi[k2] = f0 - a; fi[0] = f0 + a; gi[k3] = g1 - b2; gi[k1] = g1 + b2;
-            b2 = c1 * g2 - s1 * f3; a = s1 * g2 + c1 * f3;
-            gi[k2] = g0 - a; gi[0] = g0 + a; fi[k3] = f1 - b2; fi[k1] = f1 + b2;
-        }
+        const double c1 = tw[twbase + i - 1][0], s1 = tw[twbase + i - 1][1];
+        const double c2 = tw[twbase + i - 1][2], s2 = tw[twbase + i - 1][3];
+        double *fi = base + i, *gi = base + k1 - i;
+        double a, b2, g0, f0, f1, g1, f2, g2, f3, g3;
+        b2 = s2 * fi[k1] - c2 * gi[k1]; a = c2 * fi[k1] + s2 * gi[k1];
+        f1 = fi[0] - a; f0 = fi[0] + a; g1 = gi[0] - b2; g0 = gi[0] + b2;
+        b2 = s2 * fi[k3] - c2 * gi[k3]; a = c2 * fi[k3] + s2 * gi[k3];
+        f3 = fi[k2] - a; f2 = fi[k2] + a; g3 = gi[k2] - b2; g2 = gi[k2] + b2;
+        b2 = s1 * f2 - c1 * g3; a = c1 * f2 + s1 * g3;
+        fi[k2] = f0 - a; fi[0] = f0 + a; gi[k3] = g1 - b2; gi[k1] = g1 + b2;
+        b2 = c1 * g2 - s1 * f3; a = s1 * g2 + c1 * f3;
+        gi[k2] = g0 - a; gi[0] = g0 + a; fi[k3] = f1 - b2; fi[k1] = f1 + b2;
+    }
+    if (lane < NBLK) {
+        double *fi = x + lane * k4, *gi = fi + kx;
+        double f1 = fi[0] - fi[k1], f0 = fi[0] + fi[k1], f3 = fi[k2] - fi[k3], f2 = fi[k2] + fi[k3];
+        fi[k2] = f0 - f2; fi[0] = f0 + f2; fi[k3] = f1 - f3; fi[k1] = f1 + f3;
+        double g1 = gi[0] - gi[k1], g0 = gi[0] + gi[k1], g3 = SQRT2 * gi[k3], g2 = SQRT2 * gi[k2];
+        gi[k2] = g0 - g2; gi[0] = g0 + g2; gi[k3] = g1 - g3; gi[k1] = g1 + g3;
     }
 }
 
@@ -380,13 +383,13 @@ TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     TL_STAMP(sq, 1);
     TL_LANES_BEGIN tl_fht_pass_first(x, lane); TL_LANES_END
     TL_STAMP(sq, 2);
-    TL_LANES_BEGIN tl_fht_pass(x, 2, 0, T->fht_tw, lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_pass<2>(x, 0, T->fht_tw, lane); TL_LANES_END
     TL_STAMP(sq, 3);
-    TL_LANES_BEGIN tl_fht_pass(x, 4, 1, T->fht_tw, lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_pass<4>(x, 1, T->fht_tw, lane); TL_LANES_END
     TL_STAMP(sq, 4);
-    TL_LANES_BEGIN tl_fht_pass(x, 6, 8, T->fht_tw, lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_pass<6>(x, 8, T->fht_tw, lane); TL_LANES_END
     TL_STAMP(sq, 5);
-    TL_LANES_BEGIN tl_fht_pass(x, 8, 39, T->fht_tw, lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_pass<8>(x, 39, T->fht_tw, lane); TL_LANES_END
     TL_STAMP(sq, 6);
     TL_LANES_BEGIN
     for (int i = lane; i <= 512; i += 64) {
@@ -1098,10 +1101,10 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
         }
         TL_LANES_END
         TL_LANES_BEGIN tl_fht_pass_first(x, lane); TL_LANES_END
-        TL_LANES_BEGIN tl_fht_pass(x, 2, 0, T->fht_tw, lane); TL_LANES_END
-        TL_LANES_BEGIN tl_fht_pass(x, 4, 1, T->fht_tw, lane); TL_LANES_END
-        TL_LANES_BEGIN tl_fht_pass(x, 6, 8, T->fht_tw, lane); TL_LANES_END
-        TL_LANES_BEGIN tl_fht_pass(x, 8, 39, T->fht_tw, lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass<2>(x, 0, T->fht_tw, lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass<4>(x, 1, T->fht_tw, lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass<6>(x, 8, T->fht_tw, lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass<8>(x, 39, T->fht_tw, lane); TL_LANES_END
         // energy + phase (fft.c:1246-1275), unpredictability (psycho_2.c:119-140); ages: new = 1-pass, old = pass
         const int nw = 1 - pass, old = pass;
         TL_LANES_BEGIN
