@@ -311,19 +311,34 @@ TL_FN void tl_fht_pass_first(double *x, int lane)
         fi[2] = f0 - f2; fi[0] = f0 + f2; fi[3] = f1 - f3; fi[1] = f1 + f3;
     }
 }
+// Twiddles (c1,s1,c2,s2) of the (up to) two general butterflies a lane runs in pass K; fetched one pass ahead.
 template <int K>
-TL_FN void tl_fht_pass(double *x, int twbase, const double (*TL_RESTRICT tw)[4], int lane)
+TL_FN void tl_fht_twiddles(double (&t)[8], int twbase, const double (*TL_RESTRICT tw)[4], int lane)
+{
+    constexpr int kx = (1 << K) >> 1, NGEN = 128 - 128 / kx;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int g = lane + 64 * it, gg = g < NGEN ? g : 0;
+        const int blk = gg / (kx - 1), i = 1 + (gg - blk * (kx - 1));
+#pragma unroll
+        for (int q = 0; q < 4; q++) t[4 * it + q] = tw[twbase + i - 1][q];
+    }
+}
+template <int K>
+TL_FN void tl_fht_pass(double *x, const double (&t)[8], int lane)
 {   // fft.c:1104-1184: one pass = 128 independent 8-point butterflies: per block of 4*k1 points one with trivial /
     // sqrt(2) twiddles (i = 0) and kx-1 general ones.  The general ones are dealt densely to the lanes and the
     // trivial ones follow in their own step, so a wave never runs both code paths for one batch of butterflies.
     const double SQRT2 = 1.4142135623730951454746218587388284504414;
     constexpr int k1 = 1 << K, k2 = k1 << 1, k4 = k2 << 1, k3 = k2 + k1, kx = k1 >> 1;
     constexpr int NBLK = 128 / kx, NGEN = 128 - NBLK;
-    for (int g = lane; g < NGEN; g += 64) {
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int g = lane + 64 * it;
+        if (g >= NGEN) break;
         const int blk = g / (kx - 1), i = 1 + (g - blk * (kx - 1));
         double *base = x + blk * k4;
-        const double c1 = tw[twbase + i - 1][0], s1 = tw[twbase + i - 1][1];
-        const double c2 = tw[twbase + i - 1][2], s2 = tw[twbase + i - 1][3];
+        const double c1 = t[4 * it], s1 = t[4 * it + 1], c2 = t[4 * it + 2], s2 = t[4 * it + 3];
         double *fi = base + i, *gi = base + k1 - i;
         double a, b2, g0, f0, f1, g1, f2, g2, f3, g3;
         b2 = s2 * fi[k1] - c2 * gi[k1]; a = c2 * fi[k1] + s2 * gi[k1];
@@ -381,15 +396,20 @@ TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     }
     TL_LANES_END
     TL_STAMP(sq, 1);
-    TL_LANES_BEGIN tl_fht_pass_first(x, lane); TL_LANES_END
+    // twiddles travel one pass ahead of their use (twa: k=2 then k=8, twc: k=4, twb: k=6)
+    PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
+    TL_LANES_BEGIN
+    tl_fht_twiddles<2>(L(twa), 0, T->fht_tw, lane); tl_fht_twiddles<4>(L(twc), 1, T->fht_tw, lane);
+    tl_fht_pass_first(x, lane);
+    TL_LANES_END
     TL_STAMP(sq, 2);
-    TL_LANES_BEGIN tl_fht_pass<2>(x, 0, T->fht_tw, lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_twiddles<6>(L(twb), 8, T->fht_tw, lane); tl_fht_pass<2>(x, L(twa), lane); TL_LANES_END
     TL_STAMP(sq, 3);
-    TL_LANES_BEGIN tl_fht_pass<4>(x, 1, T->fht_tw, lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), 39, T->fht_tw, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
     TL_STAMP(sq, 4);
-    TL_LANES_BEGIN tl_fht_pass<6>(x, 8, T->fht_tw, lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
     TL_STAMP(sq, 5);
-    TL_LANES_BEGIN tl_fht_pass<8>(x, 39, T->fht_tw, lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_pass<8>(x, L(twa), lane); TL_LANES_END
     TL_STAMP(sq, 6);
     TL_LANES_BEGIN
     for (int i = lane; i <= 512; i += 64) {
@@ -1100,11 +1120,15 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
             x[r] = P->window[i] * (double)v;                         // psycho_2.c:84-92
         }
         TL_LANES_END
-        TL_LANES_BEGIN tl_fht_pass_first(x, lane); TL_LANES_END
-        TL_LANES_BEGIN tl_fht_pass<2>(x, 0, T->fht_tw, lane); TL_LANES_END
-        TL_LANES_BEGIN tl_fht_pass<4>(x, 1, T->fht_tw, lane); TL_LANES_END
-        TL_LANES_BEGIN tl_fht_pass<6>(x, 8, T->fht_tw, lane); TL_LANES_END
-        TL_LANES_BEGIN tl_fht_pass<8>(x, 39, T->fht_tw, lane); TL_LANES_END
+        PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
+        TL_LANES_BEGIN
+        tl_fht_twiddles<2>(L(twa), 0, T->fht_tw, lane); tl_fht_twiddles<4>(L(twc), 1, T->fht_tw, lane);
+        tl_fht_pass_first(x, lane);
+        TL_LANES_END
+        TL_LANES_BEGIN tl_fht_twiddles<6>(L(twb), 8, T->fht_tw, lane); tl_fht_pass<2>(x, L(twa), lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), 39, T->fht_tw, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass<8>(x, L(twa), lane); TL_LANES_END
         // energy + phase (fft.c:1246-1275), unpredictability (psycho_2.c:119-140); ages: new = 1-pass, old = pass
         const int nw = 1 - pass, old = pass;
         TL_LANES_BEGIN
