@@ -523,8 +523,11 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
             else {
                 // neighbours c-j <= R were erased to DBMIN by `last` (they pass), except `last` itself,
                 // which carries its summed level; neighbours above R (or below last-run_last) are original
-                uint32_t orig = 0;
-                for (int j = 2; j <= run; j++) { const int q = c - j; if (q > R || q < last - run_last) orig |= 1u << (j - 2); }
+                // bit j-2 set for j in [2, run] with c-j > R (j <= c-R-1) or c-j < last-run_last (j >= c-last+run_last+1)
+                const int hi_j = run < c - R - 1 ? run : c - R - 1;
+                const int lo_j = c - last + run_last + 1 > 2 ? c - last + run_last + 1 : 2;
+                uint32_t orig = hi_j >= 2 ? (1u << (hi_j - 1)) - 1u : 0u;
+                if (lo_j <= run) orig |= ((1u << (run - 1)) - 1u) & ~((1u << (lo_j - 2)) - 1u);
                 if ((info >> 10) & orig) ok = false;
                 if (ok && c - last >= 2 && c - last <= run) {
                     const double xl = tl_add_db(db, w.px[last], tl_add_db(db, last_var ? TL_DBMIN : w.px[last - 1], w.px[last + 1]));
@@ -798,22 +801,38 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     TL_LANES_BEGIN
     for (int t = lane; t < ntone + nnoise; t += 64) tl_masker_consts(TL_MK4(w), TL_MK_X(w), TL_MK_BARK(w), t, t < ntone);
     TL_LANES_END
-    // each lane folds the maskers into (up to) two table lines at once: two independent dB-sum chains
+    // Each lane folds the maskers into two ADJACENT table lines at once (two independent dB-sum chains).  A masker only
+    // reaches lines with -3 <= dz < 8 bark, so a lane first finds the first and last masker (tones, then noise, in list
+    // order) that reaches either of its lines and walks only that span; the per-line range test stays in the walk, so
+    // nothing depends on the lists being sorted.
     for (int base = 1; base < sub; base += 128) {       // 126..132 lines: one full pass + a 4-line tail at most
         TL_LANES_BEGIN
-        const int k0 = base + lane, k1 = base + 64 + lane;
+        const int k0 = base + 2 * lane, k1 = k0 + 1;
         const bool h0 = k0 < sub, h1 = k1 < sub;
         if (h0) {
             const double bk0 = C->p1_bark[k0], bk1 = C->p1_bark[h1 ? k1 : k0];
-            double x0 = TL_DBMIN, x1 = TL_DBMIN;
+            const double blo = (bk0 < bk1 ? bk0 : bk1) - 8.0, bhi = (bk0 < bk1 ? bk1 : bk0) + 3.0;
             const TlMasker *mk = TL_MK4(w);
-            for (int t = 0; t < ntone + nnoise; t++) {
-                const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
-                const double dz0 = bk0 - mb, dz1 = bk1 - mb;
-                const double n0 = tl_add_db(db, x0, av + tl_mask_vf(dz0, g, ns));
-                const double n1 = tl_add_db(db, x1, av + tl_mask_vf(dz1, g, ns));
-                x0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : x0;
-                x1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : x1;
+            const int nm = ntone + nnoise;
+            int a0 = nm, a1 = -1, b0 = nm, b1 = -1;                 // spans inside the tone part and inside the noise part
+            for (int t = 0; t < nm; t++) {
+                const double mb = mk[t].bark;
+                const bool r = mb > blo && mb <= bhi;               // superset of both lines' (-3 <= dz < 8)
+                const bool rt = r && t < ntone, rn = r && t >= ntone;
+                a0 = (rt && t < a0) ? t : a0; a1 = rt ? t : a1;
+                b0 = (rn && t < b0) ? t : b0; b1 = rn ? t : b1;
+            }
+            double x0 = TL_DBMIN, x1 = TL_DBMIN;
+            for (int part = 0; part < 2; part++) {
+                const int t_first = part ? b0 : a0, t_last = part ? b1 : a1;
+                for (int t = t_first; t <= t_last; t++) {
+                    const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
+                    const double dz0 = bk0 - mb, dz1 = bk1 - mb;
+                    const double n0 = tl_add_db(db, x0, av + tl_mask_vf(dz0, g, ns));
+                    const double n1 = tl_add_db(db, x1, av + tl_mask_vf(dz1, g, ns));
+                    x0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : x0;
+                    x1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : x1;
+                }
             }
             TL_LTG(w)[k0] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k0] : C->p1_hear[k0] - 12.0, x0);
             if (h1) TL_LTG(w)[k1] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k1] : C->p1_hear[k1] - 12.0, x1);
@@ -901,8 +920,8 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
             const int k = (int)(info & 511u);
             if (k <= R) continue;
             const int sr = tl_run_psy3(k);
-            uint32_t orig = 0;
-            for (int j = 2; j <= sr; j++) if (k - j > R) orig |= 1u << (j - 2);
+            const int hi_j = sr < k - R - 1 ? sr : k - R - 1;         // bit j-2 set for j in [2, sr] with k-j > R
+            const uint32_t orig = hi_j >= 2 ? (1u << (hi_j - 1)) - 1u : 0u;
             if ((info >> 10) & orig) continue;
             if (nconf < TL_TONE_MAX) w.conf_c[nconf++] = (int16_t)(k | ((k - 1 <= R) ? (1 << 12) : 0));
             R = k + sr;
