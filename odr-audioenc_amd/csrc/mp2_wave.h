@@ -48,6 +48,8 @@ TL_FN int tlh_argmin_u64(const uint64_t (&v)[64])
 TL_FN void tlh_row16_max_f64(double (&d)[64], const double (&v)[64])
 { for (int r = 0; r < 4; r++) { double m = v[16 * r]; for (int i = 1; i < 16; i++) if (m < v[16 * r + i]) m = v[16 * r + i]; for (int i = 0; i < 16; i++) d[16 * r + i] = m; } }
 #define TL_ROW16_MAX_F64(dst, src) tlh_row16_max_f64(dst, src)      /* valid in lane 15 of each row of 16 (all lanes here) */
+TL_FN void tlh_incl_xscan_u32(uint32_t (&d)[64], const uint32_t (&v)[64]) { uint32_t x = 0; for (int i = 0; i < 64; i++) { x ^= v[i]; d[i] = x; } }
+#define TL_WAVE_INCL_XSCAN_U32(dst, src) tlh_incl_xscan_u32(dst, src)
 #define TL_BALLOT(name) tlh_ballot(name)
 #define TL_SWAP1_U64(dst, src) do { for (int l_ = 0; l_ < 64; l_++) dst[l_] = src[l_ ^ 1]; } while (0)
 #define TL_WAVE_ARGMIN_U64(name) tlh_argmin_u64(name)
@@ -155,6 +157,18 @@ TL_FN double tld_row16_max_f64(double v)
     return v;
 }
 #define TL_ROW16_MAX_F64(dst, src) dst = tld_row16_max_f64(src)
+TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
+{   // inclusive XOR prefix over the 64 lanes, same DPP ladder as the integer sum scan
+    int v = (int)x;
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v ^= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return (uint32_t)v;
+}
+#define TL_WAVE_INCL_XSCAN_U32(dst, src) dst = tld_incl_xscan_u32(src)
 #define TL_BALLOT(name) ((uint64_t)__ballot(name))
 #define TL_SWAP1_U64(dst, src) dst = tl_d2u(tld_swap1_f64(tl_u2d(src)))
 #define TL_WAVE_ARGMIN_U64(name) tld_argmin_u64(name)
@@ -1750,8 +1764,9 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         crc16 = TL_WAVE_XOR_U32(part) & 0xffffu;
     }
     // ScF-CRC (crc.c:58-97, toolame.c:527-542).  Every (sb,ch) lane packs the 3 MSBs of the scalefactors it
-    // transmits (crc.c:83-96); lanes 0..dab_ext-1 then fold the records of their band group in (sb,ch) order.
+    // transmits (crc.c:83-96) and folds it on its own; the band groups are combined below.
     const int tail = lg_frame - 2 - C->dab_ext;                     // byte offset of the first ScF-CRC byte
+    PV(int, rlen); PV(uint32_t, rcrc);
     TL_LANES_BEGIN
     const int c = lane & 1, sb = lane >> 1;
     uint32_t rec = 0;
@@ -1763,23 +1778,60 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         default: rec = (3u << 16) | s0; break;
         }
     }
-    w.cinfo[lane] = rec;
     if (lane == 0) tl_put_bits(frame, 32, crc16, 16);
+    // this record's own remainder R = rec(x) * x^8 mod P (crc.c:99-113 with crc = 0), bit-serial over <= 9 bits
+    unsigned r8 = 0;
+    const int len = (int)(rec >> 16);
+    for (int b = 8; b >= 0; b--)
+        if (b < len) { const unsigned fb = ((r8 >> 7) ^ (rec >> b)) & 1u; r8 = ((r8 << 1) & 0xffu) ^ (fb ? 0x1Du : 0u); }
+    L(rlen) = len; L(rcrc) = r8;
     TL_LANES_END
-    TL_LANES_BEGIN
-    if (lane < C->dab_ext) {
-        const int grp = C->dab_ext - 1 - lane;                      // transmission order: i = dab_ext-1 .. 0
+    // The CRC register update is linear over GF(2): the CRC of a band group (records concatenated in (sb,ch) order, crc.c:58-97)
+    // is the XOR of R_l * x^(bits after record l) mod P.  Bits-after from a prefix sum of the lengths, x^e from a table,
+    // one XOR scan, then the four group values are differences of that scan at the group boundaries.
+    {
+        PV(int, lex);
+        TL_WAVE_EXSCAN_I32(lex, rlen);
         const int f[5] = {0, 4, 8, 16, 30};
-        int first = f[grp], last = f[grp + 1] > sblimit ? sblimit : f[grp + 1];
-        unsigned c8 = 0;
-        for (int l = 2 * first; l < 2 * last; l++) {
-            const uint32_t rec = w.cinfo[l];
-            c8 = tl_crc_upd(c8, rec & 0xffffu, (int)(rec >> 16), 0x1D, 0x80);
+        int gend[4], gfirst[4], glast[4];
+        for (int g = 0; g < 4; g++) {
+            gfirst[g] = f[g]; glast[g] = f[g + 1] > sblimit ? sblimit : f[g + 1];
+            const int e = 2 * glast[g];
+            gend[g] = (g < C->dab_ext && glast[g] > gfirst[g]) ? TL_READLANE_I32(lex, e) : 0;      // e <= 60
         }
-        c8 &= 0xff;
-        tl_put_bits(frame, (tail + lane) * 8, c8, 8);
-        w.ncentre[lane] = (int16_t)c8;                               // reused as a 4-entry scratch
+        PV(uint32_t, part); PV(uint32_t, pscan);
+        TL_LANES_BEGIN
+        const int sb = lane >> 1;
+        const int g = sb < 4 ? 0 : sb < 8 ? 1 : sb < 16 ? 2 : 3;
+        const int after = (g == 0 ? gend[0] : g == 1 ? gend[1] : g == 2 ? gend[2] : gend[3]) - L(lex) - L(rlen);
+        unsigned xp = T->crc8_xpow[after & 255];
+        unsigned acc = 0;
+        const unsigned r8 = L(rcrc);
+        for (int b = 0; b < 8; b++) {                                // acc = R * x^after mod P, shift-and-add in GF(2)
+            acc ^= ((r8 >> b) & 1u) ? xp : 0u;
+            xp = ((xp << 1) & 0xffu) ^ ((xp & 0x80u) ? 0x1Du : 0u);
+        }
+        L(part) = (L(rlen) && sb < sblimit) ? acc : 0u;
+        TL_LANES_END
+        TL_WAVE_INCL_XSCAN_U32(pscan, part);
+        unsigned c8g[4];
+        for (int g = 0; g < 4; g++) {
+            c8g[g] = 0;
+            if (g < C->dab_ext && glast[g] > gfirst[g]) {
+                c8g[g] = (unsigned)TL_READLANE_I32(pscan, 2 * glast[g] - 1);
+                if (gfirst[g] > 0) c8g[g] ^= (unsigned)TL_READLANE_I32(pscan, 2 * gfirst[g] - 1);
+            }
+        }
+        TL_LANES_BEGIN
+        if (lane < C->dab_ext) {
+            const int grp = C->dab_ext - 1 - lane;                  // transmission order: i = dab_ext-1 .. 0
+            const unsigned c8 = (grp == 0 ? c8g[0] : grp == 1 ? c8g[1] : grp == 2 ? c8g[2] : c8g[3]) & 0xffu;
+            tl_put_bits(frame, (tail + lane) * 8, c8, 8);
+            w.ncentre[lane] = (int16_t)c8;                           // reused as a 4-entry scratch
+        }
+        TL_LANES_END
     }
+    TL_LANES_BEGIN
     // X-PAD + F-PAD bytes (toolame.c:515-524,544-551): xpad[] holds xpad_len bytes in transmission order
     if (xpad_len) {
         const int xstart = lg_frame - C->dab_ext - xpad_len;        // X-PAD sits right before the ScF-CRC
