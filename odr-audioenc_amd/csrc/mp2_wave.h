@@ -18,6 +18,7 @@
 #include "mp2_types.h"
 #include "tl_math.h"
 #include <math.h>
+#include <stddef.h>
 
 // ------------------------------------------------------------------------------------------
 #ifdef TL_EMULATE
@@ -207,14 +208,14 @@ TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
 // ------------------------------------------------------------------------------------------
 // Per-wave LDS working set.
 #define TL_CAND_MAX 256              // local maxima with passing right side (<= 249)
-#define TL_FB_BATCH 3                // filterbank blocks per LDS round trip (36 = 12 x 3)
+#define TL_FB_BATCH 9                // filterbank blocks per LDS round trip (36 = 4 x 9); the window outputs go through the (idle) psy arrays px[] + tone_x[]
 #define TL_TONE_MAX 80               // confirmed tones per channel-frame (hard bound ~75: erasure spacing)
 #define TL_MASKER_MAX 128            // tones + noise components after decimation
 struct TlWaveLds {
     // Stage-exclusive 8 KB: [PCM history | frame] + filterbank scratch  ->  FHT buffer / energy (and, once the
     // energies are dead, the masker lists and thresholds)  ->  the frame being packed.
     union alignas(16) {
-        struct { int16_t pcm[2][TL_HIST + 1152]; double yp[TL_FB_BATCH][2][32]; } fbk;
+        struct { int16_t pcm[2][TL_HIST + 1152]; } fbk;
         double fft[1024];
         uint32_t frame[TL_MAX_FRAME_WORDS];
     } u;
@@ -1286,6 +1287,8 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
                 L(xb)[8 * b + ((0 - j) & 7)] = c < nch ? w.u.fbk.pcm[c][TL_HIST + 32 * b + 31 - yb - 64 * j] : 0;
             }
         TL_LANES_END
+        double (*yp)[2][32] = (double (*)[2][32])w.px;              // [TL_FB_BATCH][2][32] window outputs of the batch
+        static_assert(offsetof(TlWaveLds, tone_x) == offsetof(TlWaveLds, px) + sizeof(w.px) && sizeof(double) * TL_FB_BATCH * 64 <= sizeof(w.px) + sizeof(w.tone_x), "filterbank scratch");
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
@@ -1308,7 +1311,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
                         ta += (double)L(xa)[q + ((h - j) & 7)] * L(ca)[j];
                         tb += (double)L(xb)[q + ((h - j) & 7)] * L(cb)[j];
                     }
-                    w.u.fbk.yp[bb][c][i] = i == 0 ? ta : (i <= 16 ? ta + tb : ta - tb);
+                    yp[bb][c][i] = i == 0 ? ta : (i <= 16 ? ta + tb : ta - tb);
                 }
             }
             TL_LANES_END
@@ -1320,7 +1323,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             if (c < nch)
                 for (int k = 0; k < 16; k++) {
                     const double m = B->dct_t[k][par][r];               // shared LDS copy, conflict-free per k
-                    for (int bb = 0; bb < TL_FB_BATCH; bb++) acc[bb] += m * w.u.fbk.yp[bb][c][2 * k + par];
+                    for (int bb = 0; bb < TL_FB_BATCH; bb++) acc[bb] += m * yp[bb][c][2 * k + par];
                 }
             for (int bb = 0; bb < TL_FB_BATCH; bb++) L(part)[bb] = acc[bb];
             TL_LANES_END
