@@ -208,7 +208,7 @@ TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
 // ------------------------------------------------------------------------------------------
 // Per-wave LDS working set.
 #define TL_CAND_MAX 256              // local maxima with passing right side (<= 249)
-#define TL_FB_BATCH 9                // filterbank blocks per LDS round trip (36 = 4 x 9); the window outputs go through the (idle) psy arrays px[] + tone_x[]
+#define TL_FB_BATCH 12               // filterbank blocks per LDS round trip (36 = 3 x 12); the window outputs go through the (idle) psy arrays px[] .. cinfo[]
 #define TL_TONE_MAX 80               // confirmed tones per channel-frame (hard bound ~75: erasure spacing)
 #define TL_MASKER_MAX 128            // tones + noise components after decimation
 struct TlWaveLds {
@@ -1288,7 +1288,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             }
         TL_LANES_END
         double (*yp)[2][32] = (double (*)[2][32])w.px;              // [TL_FB_BATCH][2][32] window outputs of the batch
-        static_assert(offsetof(TlWaveLds, tone_x) == offsetof(TlWaveLds, px) + sizeof(w.px) && sizeof(double) * TL_FB_BATCH * 64 <= sizeof(w.px) + sizeof(w.tone_x), "filterbank scratch");
+        static_assert(offsetof(TlWaveLds, cinfo) + sizeof(w.cinfo) - offsetof(TlWaveLds, px) >= sizeof(double) * TL_FB_BATCH * 64, "filterbank scratch");
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
