@@ -121,10 +121,37 @@ int tlb_ingest_host(tlb_batch *b, const int16_t *interleaved, int nframes, int16
  *   d_frames uint8 [nframes][nstreams][tlb_out_stride()]   (tlb_encode_device output)
  *   d_peaks  int16 [nframes][nstreams][2] or NULL (levels 0)  (tlb_ingest_device output)
  *   d_msgs   uint8 [nframes][nstreams][tlb_zmq_msg_stride()]; message length of a stream = 12 + tlb_frame_bytes()
- * Sockets, CURVE and EDI packetisation stay with the caller (out of scope). */
+ * Sockets and CURVE stay with the caller (out of scope). */
 int tlb_zmq_msg_stride(const tlb_batch *b);
 int tlb_zmq_frame_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_peaks, int nframes, uint8_t *d_msgs, void *hip_stream);
 int tlb_zmq_frame_host(tlb_batch *b, const uint8_t *frames, const int16_t *peaks, int nframes, uint8_t *msgs);
+
+/* Egress framing, EDI part: the AF packet an EDI/TCP destination receives for one frame --
+ * what EDI::write_frame builds (src/Outputs.cpp:194-261): TAG items *ptr("DSTI"), dsti, ss0001 (the frame), ODRa (audio
+ * levels) and, every ten seconds, ODRv (version string + uptime) (contrib/edioutput/TagItems.cpp), wrapped by
+ * AFPacketiser::Assemble (contrib/edioutput/AFPacket.cpp:46-94: "AF", LEN, SEQ, AR, PT 'T', payload, CRC-16/CCITT).
+ * `tlb_edi_state` is the per-stream sender state (EDI::m_timestamp/m_edi_time/m_send_version_at_time/m_num_seconds_sent/
+ * m_tist, AFPacketiser::m_seq, TagDSTI::dlfc); the call advances it by nframes.  tlb_edi_state_init() is the first-call
+ * branch of write_frame (Outputs.cpp:200-212) with the wall clock and the TAI-UTC offset passed in by the caller.
+ *   d_frames  uint8 [nframes][nstreams][tlb_out_stride()]       (tlb_encode_device output)
+ *   d_levels  int16 [nframes][nstreams][2] or NULL (levels 0)   (tlb_ingest_device peaks)
+ *   d_state   tlb_edi_state [nstreams]
+ *   d_pkts    uint8 [nframes][nstreams][tlb_edi_af_stride()], d_pkt_len int32 [nframes][nstreams] = bytes used
+ * `version` is host memory (<= 64 bytes).  PFT fragmentation / Reed-Solomon (the UDP transport layer,
+ * contrib/edioutput/PFT.cpp) and the sockets stay with the caller. */
+typedef struct tlb_edi_state {
+    int64_t edi_time, send_version_at_time;
+    uint32_t timestamp, num_seconds_sent;
+    int32_t tai_utc_offset;
+    uint16_t seq, dlfc;
+    uint8_t tist, pad_[7];
+} tlb_edi_state;
+void tlb_edi_state_init(tlb_edi_state *st, long long now_s, unsigned delay_ms, int tist, int tai_utc_offset);
+int tlb_edi_af_stride(const tlb_batch *b, int version_len);
+int tlb_edi_af_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_levels, int nframes, tlb_edi_state *d_state,
+                      const char *version, int version_len, uint8_t *d_pkts, int32_t *d_pkt_len, void *hip_stream);
+int tlb_edi_af_host(tlb_batch *b, const uint8_t *frames, const int16_t *levels, int nframes, tlb_edi_state *state,
+                    const char *version, int version_len, uint8_t *pkts, int32_t *pkt_len);
 
 /* Diagnostic only: per-stage cycle stamps [nframes][nstreams][32] (csrc/mp2_wave.h TL_STAMP), host buffers. */
 int tlb_encode_host_stamps(tlb_batch *b, const int16_t *pcm, int nframes, long long *stamps);

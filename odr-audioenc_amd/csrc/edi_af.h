@@ -1,0 +1,169 @@
+// edi_af.h -- EDI "AF packet" of one encoded frame: the TAG packet that
+// src/Outputs.cpp:194-261 (EDI::write_frame) assembles -- *ptr("DSTI"), dsti, ss0001, ODRa and, every
+// ten seconds, ODRv (contrib/edioutput/TagItems.cpp:38-66,202-263,304-356,381-441) -- wrapped by
+// contrib/edioutput/AFPacket.cpp:46-94 (SYNC "AF", LEN, SEQ, AR = CRC flag | version 1.0, PT 'T', payload,
+// CRC-16/CCITT with init 0xffff and final inversion, contrib/crc.c:247-255).
+// This is what an EDI/TCP destination receives (PFT fragmentation + Reed-Solomon, used for UDP, is a further
+// layer and not built here).
+//
+// Written in the same lane-SPMD style as mp2_wave.h (include it first): compiled by hipcc for gfx950 and, with
+// -DTL_EMULATE, as a lane loop for the CPU tests.  One wavefront builds the packets of one stream, frame by frame,
+// because the sender state (timestamp, sequence and frame counters, version cadence) advances per frame.
+#pragma once
+#include <stdint.h>
+
+// Sender state of one stream: EDI members of src/Outputs.h:150-164 + AFPacketiser::m_seq + TagDSTI::dlfc.
+struct TlEdiState {
+    int64_t edi_time;                // m_edi_time (POSIX seconds)
+    int64_t send_version_at_time;    // m_send_version_at_time
+    uint32_t timestamp;              // m_timestamp (level-2 units of 1/16384000 s, 24 bits used on the wire)
+    uint32_t num_seconds_sent;       // m_num_seconds_sent
+    int32_t tai_utc_offset;          // ClockTAI offset handed to TagDSTI::set_edi_time
+    uint16_t seq;                    // AFPacketiser::m_seq
+    uint16_t dlfc;                   // TagDSTI::dlfc, modulo 5000
+    uint8_t tist;                    // m_tist -> atstf
+    uint8_t pad_[7];
+};
+
+struct TlEdiArgs {
+    const uint8_t *frames;           // [nframes][nstreams][out_stride] whole frames (tlb_encode_* output)
+    const int16_t *levels;           // [nframes][nstreams][2] audio levels (tlb_ingest_* peaks) or null -> 0
+    TlEdiState *state;               // [nstreams], advanced by nframes
+    const uint8_t *version;          // ODRv version string (not terminated)
+    const uint16_t *xpow8;           // x^(8k) mod (x^16+x^12+x^5+1), k = 0..TL_EDI_XPOW-1
+    const int32_t *frame_bytes;      // [nstreams]
+    uint8_t *pkts;                   // [nframes][nstreams][pkt_stride]
+    int32_t *pkt_len;                // [nframes][nstreams]
+    int32_t nstreams, nframes, out_stride, pkt_stride, version_len;
+};
+#define TL_EDI_XPOW 2048             // longest AF packet: 10 + 16 + 18 + 11 + 1728 + 12 + 12 + version < 2048 bytes
+#define TL_EDI_MAX_VERSION 64
+
+// everything that is the same for all bytes of one packet
+struct TlEdiFrame {
+    const uint8_t *payload; const uint8_t *version;
+    uint32_t n, vlen, taglen, seconds, tsta, uptime;
+    uint16_t seq, dsti_hdr; int16_t left, right;
+    uint8_t atstf, utco, with_version;
+};
+
+// byte `pos` of the AF packet before the CRC (pos < 10 + taglen)
+TL_FN uint8_t tl_edi_byte(const TlEdiFrame &F, uint32_t pos)
+{
+    if (pos < 10) {                                                  // AFPacket.cpp:55-71
+        switch (pos) {
+        case 0: return 'A'; case 1: return 'F';
+        case 2: return (uint8_t)(F.taglen >> 24); case 3: return (uint8_t)(F.taglen >> 16);
+        case 4: return (uint8_t)(F.taglen >> 8); case 5: return (uint8_t)F.taglen;
+        case 6: return (uint8_t)(F.seq >> 8); case 7: return (uint8_t)F.seq;
+        case 8: return 0x80 | 0x10; default: return 'T';
+        }
+    }
+    uint32_t p = pos - 10;
+    if (p < 16) {                                                    // TagStarPTR("DSTI"), TagItems.cpp:46-66
+        const uint8_t t[16] = {'*', 'p', 't', 'r', 0, 0, 0, 0x40, 'D', 'S', 'T', 'I', 0, 0, 0, 0};
+        return t[p];
+    }
+    p -= 16;
+    const uint32_t dsti_len = 2u + (F.atstf ? 8u : 0u);
+    if (p < 8 + dsti_len) {                                          // TagDSTI, TagItems.cpp:202-263 (stihf = rfadf = 0)
+        const uint32_t bits = dsti_len * 8;
+        switch (p) {
+        case 0: return 'd'; case 1: return 's'; case 2: return 't'; case 3: return 'i';
+        case 4: return (uint8_t)(bits >> 24); case 5: return (uint8_t)(bits >> 16); case 6: return (uint8_t)(bits >> 8); case 7: return (uint8_t)bits;
+        case 8: return (uint8_t)(F.dsti_hdr >> 8); case 9: return (uint8_t)F.dsti_hdr;
+        case 10: return F.utco;
+        case 11: return (uint8_t)(F.seconds >> 24); case 12: return (uint8_t)(F.seconds >> 16);
+        case 13: return (uint8_t)(F.seconds >> 8); case 14: return (uint8_t)F.seconds;
+        case 15: return (uint8_t)(F.tsta >> 16); case 16: return (uint8_t)(F.tsta >> 8); default: return (uint8_t)F.tsta;
+        }
+    }
+    p -= 8 + dsti_len;
+    if (p < 11 + F.n) {                                              // TagSSm id 1, TagItems.cpp:304-356 (istc = 0)
+        const uint32_t bits = (3 + F.n) * 8;
+        if (p >= 11) return F.payload[p - 11];
+        switch (p) {
+        case 0: return 's'; case 1: return 's'; case 2: return 0; case 3: return 1;
+        case 4: return (uint8_t)(bits >> 24); case 5: return (uint8_t)(bits >> 16); case 6: return (uint8_t)(bits >> 8); case 7: return (uint8_t)bits;
+        default: return 0;
+        }
+    }
+    p -= 11 + F.n;
+    if (p < 12) {                                                    // TagODRAudioLevels, TagItems.cpp:421-441
+        switch (p) {
+        case 0: return 'O'; case 1: return 'D'; case 2: return 'R'; case 3: return 'a';
+        case 4: case 5: case 6: return 0; case 7: return 0x20;
+        case 8: return (uint8_t)((uint16_t)F.left >> 8); case 9: return (uint8_t)F.left;
+        case 10: return (uint8_t)((uint16_t)F.right >> 8); default: return (uint8_t)F.right;
+        }
+    }
+    p -= 12;
+    {                                                                // TagODRVersion, TagItems.cpp:387-413
+        const uint32_t bits = (F.vlen + 4) * 8;
+        if (p < 4) { const uint8_t t[4] = {'O', 'D', 'R', 'v'}; return t[p]; }
+        if (p < 8) return (uint8_t)(bits >> (8 * (7 - p)));
+        if (p < 8 + F.vlen) return F.version[p - 8];
+        return (uint8_t)(F.uptime >> (8 * (3 - (p - 8 - F.vlen))));
+    }
+}
+
+// AF packets of `A.nframes` consecutive frames of stream s.
+TL_FN void tl_edi_af_stream(const TlEdiArgs &A, int s)
+{
+    TlEdiState st = A.state[s];
+    const uint32_t n = (uint32_t)A.frame_bytes[s];
+    for (int f = 0; f < A.nframes; f++) {
+        const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
+        // ---- sender state, Outputs.cpp:214-257 ----
+        st.timestamp += 24u << 14;                                   // 24 ms at timestamp level 2
+        if (st.timestamp > 0xf9FFffu) { st.timestamp -= 0xfa0000u; st.edi_time += 1; st.num_seconds_sent++; }
+        TlEdiFrame F;
+        F.payload = A.frames + slot * (size_t)A.out_stride;
+        F.version = A.version; F.vlen = (uint32_t)A.version_len; F.n = n;
+        F.atstf = st.tist ? 1 : 0;
+        F.utco = (uint8_t)(st.tai_utc_offset - 32);                  // TagDSTI::set_edi_time, TagItems.cpp:265-274
+        F.seconds = (uint32_t)(st.edi_time - 946684800 + F.utco);
+        F.tsta = st.timestamp & 0xffffffu;
+        F.dsti_hdr = (uint16_t)((st.dlfc % 250) | ((st.dlfc / 250) << 8) | (F.atstf << 14));
+        st.dlfc = (uint16_t)((st.dlfc + 1) % 5000);
+        F.left = A.levels ? A.levels[slot * 2] : 0; F.right = A.levels ? A.levels[slot * 2 + 1] : 0;
+        F.with_version = 0;
+        if (st.send_version_at_time < st.edi_time) { st.send_version_at_time += 10; F.with_version = 1; }
+        F.uptime = st.num_seconds_sent;
+        F.seq = st.seq; st.seq = (uint16_t)(st.seq + 1);
+        F.taglen = 16 + (10 + (F.atstf ? 8 : 0)) + (11 + n) + 12 + (F.with_version ? 12 + F.vlen : 0);
+        const uint32_t body = 10 + F.taglen;                         // bytes covered by the CRC
+        uint8_t *pkt = A.pkts + slot * (size_t)A.pkt_stride;
+
+        // ---- bytes + CRC.  The CRC register update is linear over GF(2): lane l folds bytes [l*C, l*C+C) on its own
+        //      (lane 0 carries the 0xffff preset) and the chunk remainders are combined as sum r_l * x^(8*bytes after). ----
+        const uint32_t C = (body + 63) / 64;
+        PV(uint32_t, part);
+        TL_LANES_BEGIN
+        for (uint32_t pos = (uint32_t)lane; pos < body; pos += 64) pkt[pos] = tl_edi_byte(F, pos);
+        uint32_t acc = 0;
+        const uint32_t p0 = (uint32_t)lane * C;
+        if (p0 < body) {
+            const uint32_t p1 = p0 + C < body ? p0 + C : body;
+            uint32_t r = lane == 0 ? 0xffffu : 0u;
+            for (uint32_t pos = p0; pos < p1; pos++) {
+                r ^= (uint32_t)tl_edi_byte(F, pos) << 8;
+                for (int b = 0; b < 8; b++) r = ((r << 1) & 0xffffu) ^ ((r & 0x8000u) ? 0x1021u : 0u);
+            }
+            uint32_t xp = A.xpow8[body - p1];
+            for (int b = 0; b < 16; b++) {                           // acc = r * x^(8*(body-p1)) mod P
+                acc ^= ((r >> b) & 1u) ? xp : 0u;
+                xp = ((xp << 1) & 0xffffu) ^ ((xp & 0x8000u) ? 0x1021u : 0u);
+            }
+        }
+        L(part) = acc;
+        TL_LANES_END
+        const uint32_t crc = (TL_WAVE_XOR_U32(part) ^ 0xffffu) & 0xffffu;
+        TL_LANES_BEGIN
+        if (lane == 0) { pkt[body] = (uint8_t)(crc >> 8); pkt[body + 1] = (uint8_t)crc; A.pkt_len[slot] = (int32_t)(body + 2); }
+        TL_LANES_END
+    }
+    TL_LANES_BEGIN
+    if (lane == 0) A.state[s] = st;
+    TL_LANES_END
+}

@@ -63,6 +63,11 @@ void tl_build_tables(TlTables *T)
     {   // powers of x modulo the CRC-16 polynomial 0x8005 (CRC16_POLYNOMIAL, common.h:45)
         unsigned v = 1;
         for (int e = 0; e < 384; e++) { T->crc_xpow[e] = (uint16_t)v; v <<= 1; if (v & 0x10000u) v = (v ^ 0x18005u) & 0xffffu; }
+        unsigned ve = 1;
+        for (int k = 0; k < 2048; k++) {
+            T->edi_xpow8[k] = (uint16_t)ve;
+            for (int b = 0; b < 8; b++) { ve <<= 1; if (ve & 0x10000u) ve = (ve ^ 0x11021u) & 0xffffu; }
+        }
         unsigned v8 = 1;
         for (int e = 0; e < 256; e++) { T->crc8_xpow[e] = (uint8_t)v8; v8 <<= 1; if (v8 & 0x100u) v8 = (v8 ^ 0x11Du) & 0xffu; }
     }

@@ -15,6 +15,7 @@
 #include "../../include/toolame_batch.h"
 #include "mp2_host.h"
 #include "mp2_wave.h"
+#include "edi_af.h"
 
 static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 
@@ -112,6 +113,15 @@ __global__ void tl_zmq_frame_kernel(const uint8_t *__restrict__ frames, const in
     for (int i = (int)threadIdx.x; i < (n >> 2); i += (int)blockDim.x) ((uint32_t *)m)[3 + i] = src[i];
 }
 
+// EDI AF packets of the step after the path (EDI part; csrc/edi_af.h): one wavefront per stream,
+// frames in order because the sender state advances per frame.
+__global__ void __launch_bounds__(256) tl_edi_af_kernel(TlEdiArgs A)
+{
+    const int s = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (s >= A.nstreams) return;
+    tl_edi_af_stream(A, s);
+}
+
 // pending frame (big-endian words in the stream state) -> bytes
 __global__ void tl_flush_kernel(const TlStreamState *state, const TlConfig *configs, const int32_t *stream_cfg,
                                 uint8_t *out, int nstreams, int out_stride)
@@ -140,6 +150,8 @@ struct tlb_batch {
     int n_list[4] = {0, 0, 0, 0};
     TlPsy2Tables *d_psy2_tables = nullptr;     // 4 slots (tl_psy2_slot), only when a stream uses psy 2
     TlPsy2State *d_psy2_state = nullptr;
+    uint8_t *d_edi_version = nullptr;            // EDI: ODRv string and per-stream frame sizes (allocated on first use)
+    int32_t *d_frame_bytes = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
     bool timed = false;
@@ -169,6 +181,8 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_stream_cfg) (void)hipFree(b->d_stream_cfg);
     if (b->d_state) (void)hipFree(b->d_state);
     if (b->d_gain) (void)hipFree(b->d_gain);
+    if (b->d_edi_version) (void)hipFree(b->d_edi_version);
+    if (b->d_frame_bytes) (void)hipFree(b->d_frame_bytes);
     for (int p = 0; p < 4; p++) if (b->d_list[p]) (void)hipFree(b->d_list[p]);
     if (b->d_psy2_tables) (void)hipFree(b->d_psy2_tables);
     if (b->d_psy2_state) (void)hipFree(b->d_psy2_state);
@@ -426,6 +440,78 @@ int tlb_zmq_frame_host(tlb_batch *b, const uint8_t *frames, const int16_t *peaks
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(msgs, d_m, slots * ms, hipMemcpyDeviceToHost));
     (void)hipFree(d_f); (void)hipFree(d_m); if (d_p) (void)hipFree(d_p);
+    return rc;
+}
+
+// ---- EDI AF packets (include/toolame_batch.h) ----
+static_assert(sizeof(tlb_edi_state) == sizeof(TlEdiState), "tlb_edi_state mirrors TlEdiState");
+
+void tlb_edi_state_init(tlb_edi_state *st, long long now_s, unsigned delay_ms, int tist, int tai_utc_offset)
+{   // the first-call branch of EDI::write_frame (src/Outputs.cpp:200-212)
+    if (!st) return;
+    memset(st, 0, sizeof *st);
+    st->edi_time = now_s + delay_ms / 1000;
+    st->send_version_at_time = st->edi_time;
+    for (int sub_ms = (int)(delay_ms % 1000); sub_ms > 0; sub_ms -= 24) st->timestamp += 24u << 14;
+    st->tist = tist ? 1 : 0;
+    st->tai_utc_offset = tai_utc_offset;
+}
+
+int tlb_edi_af_stride(const tlb_batch *b, int version_len)
+{
+    if (!b || version_len < 0 || version_len > TL_EDI_MAX_VERSION) return 0;
+    return (10 + 16 + 18 + 11 + b->out_stride + 12 + 12 + version_len + 2 + 3) & ~3;
+}
+
+int tlb_edi_af_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_levels, int nframes, tlb_edi_state *d_state,
+                      const char *version, int version_len, uint8_t *d_pkts, int32_t *d_pkt_len, void *hip_stream)
+{
+    if (!b || !d_frames || !d_state || !d_pkts || !d_pkt_len || nframes <= 0 || version_len < 0 || version_len > TL_EDI_MAX_VERSION ||
+        (version_len && !version)) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (!b->d_edi_version) {
+        HIPCHK(hipMalloc(&b->d_edi_version, TL_EDI_MAX_VERSION));
+        HIPCHK(hipMalloc(&b->d_frame_bytes, sizeof(int32_t) * (size_t)b->nstreams));
+        std::vector<int32_t> fb((size_t)b->nstreams);
+        for (int s = 0; s < b->nstreams; s++) fb[(size_t)s] = b->h_configs[b->h_stream_cfg[s]].frame_bytes;
+        HIPCHK(hipMemcpy(b->d_frame_bytes, fb.data(), sizeof(int32_t) * fb.size(), hipMemcpyHostToDevice));
+    }
+    if (version_len) HIPCHK(hipMemcpyAsync(b->d_edi_version, version, (size_t)version_len, hipMemcpyHostToDevice, st));
+    TlEdiArgs A;
+    A.frames = d_frames; A.levels = d_levels; A.state = (TlEdiState *)d_state; A.version = b->d_edi_version;
+    A.xpow8 = b->d_tables->edi_xpow8; A.frame_bytes = b->d_frame_bytes; A.pkts = d_pkts; A.pkt_len = d_pkt_len;
+    A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride;
+    A.pkt_stride = tlb_edi_af_stride(b, version_len); A.version_len = version_len;
+    hipLaunchKernelGGL(tl_edi_af_kernel, dim3((unsigned)((b->nstreams + 3) / 4)), dim3(256), 0, st, A);
+    HIPCHK(hipGetLastError());
+    return TLB_OK;
+}
+
+int tlb_edi_af_host(tlb_batch *b, const uint8_t *frames, const int16_t *levels, int nframes, tlb_edi_state *state,
+                    const char *version, int version_len, uint8_t *pkts, int32_t *pkt_len)
+{
+    if (!b || !frames || !state || !pkts || !pkt_len || nframes <= 0) return TLB_ERR_ARG;
+    const int stride = tlb_edi_af_stride(b, version_len);
+    if (!stride) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    const size_t slots = (size_t)nframes * (size_t)b->nstreams;
+    uint8_t *d_f = nullptr, *d_p = nullptr; int16_t *d_l = nullptr; tlb_edi_state *d_s = nullptr; int32_t *d_n = nullptr;
+    HIPCHK(hipMalloc(&d_f, slots * (size_t)b->out_stride));
+    HIPCHK(hipMalloc(&d_p, slots * (size_t)stride));
+    HIPCHK(hipMalloc(&d_s, sizeof(tlb_edi_state) * (size_t)b->nstreams));
+    HIPCHK(hipMalloc(&d_n, sizeof(int32_t) * slots));
+    HIPCHK(hipMemset(d_p, 0, slots * (size_t)stride));
+    HIPCHK(hipMemcpy(d_f, frames, slots * (size_t)b->out_stride, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_s, state, sizeof(tlb_edi_state) * (size_t)b->nstreams, hipMemcpyHostToDevice));
+    if (levels) { HIPCHK(hipMalloc(&d_l, slots * 4)); HIPCHK(hipMemcpy(d_l, levels, slots * 4, hipMemcpyHostToDevice)); }
+    int rc = tlb_edi_af_device(b, d_f, d_l, nframes, d_s, version, version_len, d_p, d_n, nullptr);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(pkts, d_p, slots * (size_t)stride, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(pkt_len, d_n, sizeof(int32_t) * slots, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(state, d_s, sizeof(tlb_edi_state) * (size_t)b->nstreams, hipMemcpyDeviceToHost);
+    (void)hipFree(d_f); (void)hipFree(d_p); (void)hipFree(d_s); (void)hipFree(d_n); if (d_l) (void)hipFree(d_l);
+    if (e != hipSuccess) return TLB_ERR_HIP;
     return rc;
 }
 

@@ -83,6 +83,11 @@ def load_library():
     L.tlb_set_gain_db.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.tlb_ingest_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tlb_ingest_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.tlb_edi_state_init.argtypes = [C.c_void_p, C.c_longlong, C.c_uint, C.c_int, C.c_int]
+    L.tlb_edi_state_init.restype = None
+    L.tlb_edi_af_stride.argtypes = [C.c_void_p, C.c_int]
+    L.tlb_edi_af_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tlb_edi_af_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]
     L.toolame_set_samplerate.argtypes = [C.c_long]
     L.toolame_set_channel_mode.argtypes = [C.c_char]
     L.toolame_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -98,6 +103,21 @@ def lds_bytes_per_stream():
 def legacy_api():
     """The nine reference symbols (toolame_init ... toolame_encode_frame) as a ctypes library."""
     return load_library()
+
+
+# mirror of tlb_edi_state (include/toolame_batch.h): the per-stream EDI sender state
+EDI_STATE_DTYPE = np.dtype([("edi_time", np.int64), ("send_version_at_time", np.int64), ("timestamp", np.uint32),
+                            ("num_seconds_sent", np.uint32), ("tai_utc_offset", np.int32), ("seq", np.uint16), ("dlfc", np.uint16),
+                            ("tist", np.uint8), ("pad_", np.uint8, (7,))])
+
+
+def edi_state_init(nstreams, now_s, delay_ms=0, tist=False, tai_utc_offset=37):
+    """per-stream EDI sender state as EDI::write_frame sets it up on its first call (src/Outputs.cpp:200-212)"""
+    st = np.zeros(nstreams, dtype=EDI_STATE_DTYPE)
+    L = load_library()
+    for s in range(nstreams):
+        L.tlb_edi_state_init(st[s:s + 1].ctypes.data, int(now_s), int(delay_ms), 1 if tist else 0, int(tai_utc_offset))
+    return st
 
 
 # mirror of TlTaps (csrc/mp2_types.h) for stage-level parity tests
@@ -208,6 +228,25 @@ class Batch:
         rc = self.L.tlb_ingest_device(self.h, d_in_ptr, nframes, d_pcm_ptr, d_peaks_ptr, stream)
         if rc:
             raise ToolameError(rc, "tlb_ingest_device")
+
+    def edi_af(self, frames, levels, state, version=b""):
+        """frames uint8 [nframes, nstreams, out_stride] (encode() layout), levels int16 [nframes, nstreams, 2] or None,
+        state = edi_state_init(...) (advanced in place) -> (packets uint8 [nframes, nstreams, stride], lengths int32)"""
+        f = np.ascontiguousarray(frames, dtype=np.uint8)
+        nf = f.shape[0]
+        if f.shape != (nf, self.nstreams, self.out_stride) or state.dtype != EDI_STATE_DTYPE or state.shape != (self.nstreams,):
+            raise ToolameError(18, f"frames {f.shape} / state {state.shape}")
+        lv = np.ascontiguousarray(levels, dtype=np.int16) if levels is not None else None
+        ps = self.L.tlb_edi_af_stride(self.h, len(version))
+        if ps <= 0:
+            raise ToolameError(18, "version string too long")
+        pkts = np.zeros((nf, self.nstreams, ps), dtype=np.uint8)
+        plen = np.zeros((nf, self.nstreams), dtype=np.int32)
+        rc = self.L.tlb_edi_af_host(self.h, f.ctypes.data, lv.ctypes.data if lv is not None else None, nf, state.ctypes.data,
+                                    bytes(version), len(version), pkts.ctypes.data, plen.ctypes.data)
+        if rc:
+            raise ToolameError(rc, "tlb_edi_af_host")
+        return pkts, plen
 
     def last_kernel_ms(self):
         return float(self.L.tlb_last_kernel_ms(self.h))

@@ -13,6 +13,7 @@
 
 #include "../../odr-audioenc_amd/csrc/mp2_host.h"
 #include "../../odr-audioenc_amd/csrc/mp2_wave.h"
+#include "../../odr-audioenc_amd/csrc/edi_af.h"
 
 struct Emu {
     TlTables tables;
@@ -81,6 +82,23 @@ int emu_pending(void *h, int s, uint8_t *out)
     for (int i = 0; i < n; i++) out[i] = (uint8_t)(e->state[s].pending[i >> 2] >> (24 - 8 * (i & 3)));
     return n;
 }
+// EDI AF packets (csrc/edi_af.h) of nframes frames of nstreams streams, emulated wave per stream.
+// frames [nframes][nstreams][out_stride], levels [nframes][nstreams][2] or null, state [nstreams] (advanced),
+// pkts [nframes][nstreams][pkt_stride], pkt_len [nframes][nstreams]
+int emu_edi_af(const uint8_t *frames, const int16_t *levels, int nframes, int nstreams, int out_stride, const int32_t *frame_bytes,
+               TlEdiState *state, const uint8_t *version, int version_len, uint8_t *pkts, int pkt_stride, int32_t *pkt_len)
+{
+    static TlTables T;
+    static bool built = false;
+    if (!built) { tl_build_tables(&T); built = true; }
+    TlEdiArgs A;
+    A.frames = frames; A.levels = levels; A.state = state; A.version = version; A.xpow8 = T.edi_xpow8; A.frame_bytes = frame_bytes;
+    A.pkts = pkts; A.pkt_len = pkt_len; A.nstreams = nstreams; A.nframes = nframes; A.out_stride = out_stride;
+    A.pkt_stride = pkt_stride; A.version_len = version_len;
+    for (int s = 0; s < nstreams; s++) tl_edi_af_stream(A, s);
+    return 0;
+}
+int emu_sizeof_edi_state(void) { return (int)sizeof(TlEdiState); }
 int emu_sizeof_taps(void) { return (int)sizeof(TlTaps); }
 int emu_sizeof_lds(void) { return (int)sizeof(TlWaveLds); }
 double emu_log10(double x) { return tl_log10(x); }

@@ -3,6 +3,8 @@ golden vectors of the real reference and against the oracle, on a real MI355X.  
 bytes and every integer tap; fp64 filterbank taps compared as raw bits; SMR within 1e-9 dB (the
 device carries its own log10, see csrc/tl_math.h) and bit-exact against the host emulation of
 the same kernel source."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -239,3 +241,31 @@ def test_zmq_frame_header(M):
             want = struct.pack("<HHIhh", 1, 2, n, int(peaks[f, s, 0]), int(peaks[f, s, 1])) + frames[f, s, :n].tobytes()
             assert msgs[f, s, :12 + n].tobytes() == want, (f, s)
     b.close()
+
+
+def test_edi_af_packets(M):
+    """SURVEY 8f N2 (EDI part): AF packets through the C-ABI equal the golden vectors made with the reference's own
+    TagItems/TagPacket/AFPacket classes (tests/golden/make_golden_edi.py), sender state included."""
+    import edilib as E
+    g = np.load(Path(__file__).resolve().parent / "golden" / "edi_cases.npz")
+    kb = {96: 32, 288: 96, 384: 128, 576: 192}                  # frame bytes -> kbps at 48 kHz
+    for name, *_ in E.CASES:
+        frames, levels, fb, st = E.case_inputs(name)
+        b = M.Batch([M.StreamConfig(mode="s" if n > 96 else "m", bitrate=kb[int(n)]) for n in fb])
+        assert list(b.frame_bytes) == [int(n) for n in fb] and b.out_stride == frames.shape[2]
+        state = st.astype(M.EDI_STATE_DTYPE)
+        pkts, plen = b.edi_af(frames, levels, state, E.VERSION)
+        assert (plen == g[name + "_len"]).all(), name
+        assert (pkts[:16] == g[name + "_head"]).all(), name
+        assert E.digest(pkts, plen) == bytes(g[name + "_sha"]).hex(), name
+        assert state.tobytes() == g[name + "_state"].tobytes(), name
+        # two calls of half the frames == one call (the state carries everything)
+        half = frames.shape[0] // 2
+        state2 = st.astype(M.EDI_STATE_DTYPE)
+        p1, l1 = b.edi_af(frames[:half], levels[:half] if levels is not None else None, state2, E.VERSION)
+        p2, l2 = b.edi_af(frames[half:], levels[half:] if levels is not None else None, state2, E.VERSION)
+        assert (np.concatenate([p1, p2]) == pkts).all() and (np.concatenate([l1, l2]) == plen).all(), name
+        b.close()
+    # tlb_edi_state_init == the first-call branch of EDI::write_frame
+    for now, delay, tist in ((1700000000, 250, 1), (1600000123, 0, 0), (1751234567, 1015, 1)):
+        assert M.edi_state_init(2, now, delay, tist, 37).tobytes() == E.init_state(2, now, delay, tist, 37).astype(M.EDI_STATE_DTYPE).tobytes()
