@@ -744,9 +744,19 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         }
         TL_SYNC();
     } else {
-    // band order: a later band overwrites an earlier one that chose the same line (psycho_1.c:390-398)
-    for (int i = 0; i < nbands; i++) { const int centre = w.ncentre[i]; w.px[centre] = w.nsum[i]; w.ptype[centre] = TL_T_NOISE; }
-    TL_SYNC();
+    // band order: a later band overwrites an earlier one that chose the same line (psycho_1.c:390-398).  Which bands are
+    // overwritten is settled from registers (lane reads, no LDS round trips); the survivors then write side by side.
+    {
+        PV(int, ncen); PV(bool, over);
+        TL_LANES_BEGIN L(ncen) = lane < nbands ? (int)w.ncentre[lane] : -1 - lane; L(over) = false; TL_LANES_END
+        for (int b = 1; b < nbands; b++) {
+            const int cb = TL_READLANE_I32(ncen, b);
+            TL_LANES_BEGIN if (lane < b && L(ncen) == cb) L(over) = true; TL_LANES_END
+        }
+        TL_LANES_BEGIN
+        if (lane < nbands) { if (!L(over)) w.px[L(ncen)] = w.nsum[lane]; w.ptype[L(ncen)] = TL_T_NOISE; }
+        TL_LANES_END
+    }
 
     // ---- decimation (psycho_1.c:409-470) ----
     {
@@ -771,10 +781,18 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
             TL_LANES_END
             ntone += __builtin_popcountll(m);
         }
-        // tones closer than 0.5 bark: keep the stronger (psycho_1.c:443-469), sequential over the survivors
+        // tones closer than 0.5 bark: keep the stronger (psycho_1.c:443-469).  The walk compares each tone with the current
+        // survivor; as long as no two NEIGHBOURS of the list are that close the survivor is always the previous tone and
+        // nothing is merged, which one line-parallel comparison settles.  Only otherwise the sequential walk runs.
         {
-            int n = 0;                    // compacted in place: entries [0,n) are final, `i` is the current survivor
-            if (ntone > 0) {
+            PV(bool, closep);
+            TL_LANES_BEGIN
+            bool cl = false;
+            for (int q = 1 + lane; q < ntone; q += 64) cl = cl || (TL_MK_BARK(w)[q] - TL_MK_BARK(w)[q - 1] < 0.5);
+            L(closep) = cl;
+            TL_LANES_END
+            if (TL_BALLOT(closep) != 0ull) {
+                int n = 0;                // compacted in place: entries [0,n) are final, (xi,bi) is the current survivor
                 double xi = TL_MK_X(w)[0], bi = TL_MK_BARK(w)[0];
                 for (int q = 1; q < ntone; q++) {
                     const double xn = TL_MK_X(w)[q], bn = TL_MK_BARK(w)[q];
@@ -783,9 +801,9 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
                     } else { TL_MK_X(w)[n] = xi; TL_MK_BARK(w)[n] = bi; n++; xi = xn; bi = bn; }
                 }
                 TL_MK_X(w)[n] = xi; TL_MK_BARK(w)[n] = bi; n++;
+                ntone = n;
+                TL_SYNC();
             }
-            ntone = n;
-            TL_SYNC();
         }
         // noise: band order, keep if not below the threshold in quiet (psycho_1.c:429-442)
         PV(bool, keepn); PV(double, nx); PV(double, nb);
