@@ -7,10 +7,12 @@
 // layer and not built here).
 //
 // Written in the same lane-SPMD style as mp2_wave.h (include it first): compiled by hipcc for gfx950 and, with
-// -DTL_EMULATE, as a lane loop for the CPU tests.  One wavefront builds the packets of one stream, frame by frame,
-// because the sender state (timestamp, sequence and frame counters, version cadence) advances per frame.
+// -DTL_EMULATE, as a lane loop for the CPU tests.  One wavefront builds one packet; the sender state (timestamp,
+// sequence and frame counters, version cadence) advances per frame, which is a few integer operations, so the wave of
+// frame f simply replays f+1 advances from the state at the start of the call.
 #pragma once
 #include <stdint.h>
+#include <string.h>
 
 // Sender state of one stream: EDI members of src/Outputs.h:150-164 + AFPacketiser::m_seq + TagDSTI::dlfc.
 struct TlEdiState {
@@ -28,7 +30,8 @@ struct TlEdiState {
 struct TlEdiArgs {
     const uint8_t *frames;           // [nframes][nstreams][out_stride] whole frames (tlb_encode_* output)
     const int16_t *levels;           // [nframes][nstreams][2] audio levels (tlb_ingest_* peaks) or null -> 0
-    TlEdiState *state;               // [nstreams], advanced by nframes
+    const TlEdiState *state;         // [nstreams] sender state before the first frame of this call
+    TlEdiState *state_out;           // [nstreams] state after the last frame (a different array: every packet reads `state`)
     const uint8_t *version;          // ODRv version string (not terminated)
     const uint16_t *xpow8;           // x^(8k) mod (x^16+x^12+x^5+1), k = 0..TL_EDI_XPOW-1
     const int32_t *frame_bytes;      // [nstreams]
@@ -45,6 +48,7 @@ struct TlEdiFrame {
     uint32_t n, vlen, taglen, seconds, tsta, uptime;
     uint16_t seq, dsti_hdr; int16_t left, right;
     uint8_t atstf, utco, with_version;
+    uint32_t pay_lo;                 // packet offset of the first frame byte
 };
 
 // byte `pos` of the AF packet before the CRC (pos < 10 + taglen)
@@ -107,16 +111,23 @@ TL_FN uint8_t tl_edi_byte(const TlEdiFrame &F, uint32_t pos)
     }
 }
 
-// AF packets of `A.nframes` consecutive frames of stream s.
-TL_FN void tl_edi_af_stream(const TlEdiArgs &A, int s)
+// AF packet of frame f (0-based within this call) of stream s.
+TL_FN void tl_edi_af_packet(const TlEdiArgs &A, int s, int f)
 {
     TlEdiState st = A.state[s];
     const uint32_t n = (uint32_t)A.frame_bytes[s];
-    for (int f = 0; f < A.nframes; f++) {
+    {
         const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
-        // ---- sender state, Outputs.cpp:214-257 ----
-        st.timestamp += 24u << 14;                                   // 24 ms at timestamp level 2
-        if (st.timestamp > 0xf9FFffu) { st.timestamp -= 0xfa0000u; st.edi_time += 1; st.num_seconds_sent++; }
+        // ---- sender state, Outputs.cpp:214-257; frames 0..f-1 only advance it ----
+        uint16_t dlfc = 0, seq = 0; uint8_t with_version = 0;
+        for (int k = 0; k <= f; k++) {
+            st.timestamp += 24u << 14;                               // 24 ms at timestamp level 2
+            if (st.timestamp > 0xf9FFffu) { st.timestamp -= 0xfa0000u; st.edi_time += 1; st.num_seconds_sent++; }
+            dlfc = st.dlfc; st.dlfc = (uint16_t)((st.dlfc + 1) % 5000);
+            with_version = 0;
+            if (st.send_version_at_time < st.edi_time) { st.send_version_at_time += 10; with_version = 1; }
+            seq = st.seq; st.seq = (uint16_t)(st.seq + 1);
+        }
         TlEdiFrame F;
         F.payload = A.frames + slot * (size_t)A.out_stride;
         F.version = A.version; F.vlen = (uint32_t)A.version_len; F.n = n;
@@ -124,32 +135,50 @@ TL_FN void tl_edi_af_stream(const TlEdiArgs &A, int s)
         F.utco = (uint8_t)(st.tai_utc_offset - 32);                  // TagDSTI::set_edi_time, TagItems.cpp:265-274
         F.seconds = (uint32_t)(st.edi_time - 946684800 + F.utco);
         F.tsta = st.timestamp & 0xffffffu;
-        F.dsti_hdr = (uint16_t)((st.dlfc % 250) | ((st.dlfc / 250) << 8) | (F.atstf << 14));
-        st.dlfc = (uint16_t)((st.dlfc + 1) % 5000);
+        F.dsti_hdr = (uint16_t)((dlfc % 250) | ((dlfc / 250) << 8) | (F.atstf << 14));
         F.left = A.levels ? A.levels[slot * 2] : 0; F.right = A.levels ? A.levels[slot * 2 + 1] : 0;
-        F.with_version = 0;
-        if (st.send_version_at_time < st.edi_time) { st.send_version_at_time += 10; F.with_version = 1; }
+        F.with_version = with_version;
         F.uptime = st.num_seconds_sent;
-        F.seq = st.seq; st.seq = (uint16_t)(st.seq + 1);
+        F.seq = seq;
         F.taglen = 16 + (10 + (F.atstf ? 8 : 0)) + (11 + n) + 12 + (F.with_version ? 12 + F.vlen : 0);
+        F.pay_lo = 10 + 16 + (10 + (F.atstf ? 8 : 0)) + 11;
         const uint32_t body = 10 + F.taglen;                         // bytes covered by the CRC
         uint8_t *pkt = A.pkts + slot * (size_t)A.pkt_stride;
 
-        // ---- bytes + CRC.  The CRC register update is linear over GF(2): lane l folds bytes [l*C, l*C+C) on its own
-        //      (lane 0 carries the 0xffff preset) and the chunk remainders are combined as sum r_l * x^(8*bytes after). ----
-        const uint32_t C = (body + 63) / 64;
-        PV(uint32_t, part);
+        // ---- bytes + CRC.  Lane l owns bytes [l*C, l*C+C), C a multiple of 4 (<= 32): it builds them once as up to eight
+        //      words and folds them into its own CRC remainder (lane 0 carries the 0xffff preset).  The register update is
+        //      linear over GF(2), so the remainders combine as sum r_l * x^(8 * bytes after the chunk) mod P; the two CRC
+        //      bytes are then patched into the word(s) that hold them and every lane stores whole words. ----
+        const uint32_t C = 4 * ((body + 2 + 255) / 256);
+        PV(uint32_t, part); PA(uint32_t, wd, 8);
         TL_LANES_BEGIN
-        for (uint32_t pos = (uint32_t)lane; pos < body; pos += 64) pkt[pos] = tl_edi_byte(F, pos);
         uint32_t acc = 0;
         const uint32_t p0 = (uint32_t)lane * C;
+        uint32_t r = lane == 0 ? 0xffffu : 0u;
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (uint32_t wi = 0; wi < 8; wi++) {
+            uint32_t word = 0;
+            if (4 * wi < C) {
+                const uint32_t q = p0 + 4 * wi;
+                const bool inside = q >= F.pay_lo && q + 4 <= F.pay_lo + F.n;      // four frame bytes: one (unaligned) word load
+                uint32_t pw = 0;
+                if (inside) memcpy(&pw, F.payload + (q - F.pay_lo), 4);
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t pos = q + k;
+                    if (pos < body) {
+                        const uint32_t by = inside ? (pw >> (8 * k)) & 0xffu : tl_edi_byte(F, pos);
+                        r ^= by << 8;
+                        for (int b = 0; b < 8; b++) r = ((r << 1) & 0xffffu) ^ ((r & 0x8000u) ? 0x1021u : 0u);
+                        word |= by << (8 * k);
+                    }
+                }
+            }
+            L(wd)[wi] = word;
+        }
         if (p0 < body) {
             const uint32_t p1 = p0 + C < body ? p0 + C : body;
-            uint32_t r = lane == 0 ? 0xffffu : 0u;
-            for (uint32_t pos = p0; pos < p1; pos++) {
-                r ^= (uint32_t)tl_edi_byte(F, pos) << 8;
-                for (int b = 0; b < 8; b++) r = ((r << 1) & 0xffffu) ^ ((r & 0x8000u) ? 0x1021u : 0u);
-            }
             uint32_t xp = A.xpow8[body - p1];
             for (int b = 0; b < 16; b++) {                           // acc = r * x^(8*(body-p1)) mod P
                 acc ^= ((r >> b) & 1u) ? xp : 0u;
@@ -160,10 +189,25 @@ TL_FN void tl_edi_af_stream(const TlEdiArgs &A, int s)
         TL_LANES_END
         const uint32_t crc = (TL_WAVE_XOR_U32(part) ^ 0xffffu) & 0xffffu;
         TL_LANES_BEGIN
-        if (lane == 0) { pkt[body] = (uint8_t)(crc >> 8); pkt[body + 1] = (uint8_t)crc; A.pkt_len[slot] = (int32_t)(body + 2); }
+        const uint32_t p0 = (uint32_t)lane * C;
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (uint32_t wi = 0; wi < 8; wi++) {
+            const uint32_t q = p0 + 4 * wi;
+            if (4 * wi < C && q < body + 2) {
+                uint32_t word = L(wd)[wi];
+                if (body >= q && body < q + 4) word |= (crc >> 8) << (8 * (body - q));
+                if (body + 1 >= q && body + 1 < q + 4) word |= (crc & 0xffu) << (8 * (body + 1 - q));
+                *(uint32_t *)(pkt + q) = word;                        // pkt_stride and C are multiples of 4
+            }
+        }
+        if (lane == 0) A.pkt_len[slot] = (int32_t)(body + 2);
         TL_LANES_END
     }
-    TL_LANES_BEGIN
-    if (lane == 0) A.state[s] = st;
-    TL_LANES_END
+    if (f == A.nframes - 1) {
+        TL_LANES_BEGIN
+        if (lane == 0) A.state_out[s] = st;
+        TL_LANES_END
+    }
 }

@@ -113,13 +113,13 @@ __global__ void tl_zmq_frame_kernel(const uint8_t *__restrict__ frames, const in
     for (int i = (int)threadIdx.x; i < (n >> 2); i += (int)blockDim.x) ((uint32_t *)m)[3 + i] = src[i];
 }
 
-// EDI AF packets of the step after the path (EDI part; csrc/edi_af.h): one wavefront per stream,
-// frames in order because the sender state advances per frame.
+// EDI AF packets of the step after the path (EDI part; csrc/edi_af.h): one wavefront per packet,
+// blockIdx.y = frame of the call, four streams per workgroup.
 __global__ void __launch_bounds__(256) tl_edi_af_kernel(TlEdiArgs A)
 {
     const int s = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (s >= A.nstreams) return;
-    tl_edi_af_stream(A, s);
+    tl_edi_af_packet(A, s, (int)blockIdx.y);
 }
 
 // pending frame (big-endian words in the stream state) -> bytes
@@ -152,6 +152,7 @@ struct tlb_batch {
     TlPsy2State *d_psy2_state = nullptr;
     uint8_t *d_edi_version = nullptr;            // EDI: ODRv string and per-stream frame sizes (allocated on first use)
     int32_t *d_frame_bytes = nullptr;
+    TlEdiState *d_edi_state_tmp = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
     bool timed = false;
@@ -183,6 +184,7 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_gain) (void)hipFree(b->d_gain);
     if (b->d_edi_version) (void)hipFree(b->d_edi_version);
     if (b->d_frame_bytes) (void)hipFree(b->d_frame_bytes);
+    if (b->d_edi_state_tmp) (void)hipFree(b->d_edi_state_tmp);
     for (int p = 0; p < 4; p++) if (b->d_list[p]) (void)hipFree(b->d_list[p]);
     if (b->d_psy2_tables) (void)hipFree(b->d_psy2_tables);
     if (b->d_psy2_state) (void)hipFree(b->d_psy2_state);
@@ -466,25 +468,27 @@ int tlb_edi_af_stride(const tlb_batch *b, int version_len)
 int tlb_edi_af_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_levels, int nframes, tlb_edi_state *d_state,
                       const char *version, int version_len, uint8_t *d_pkts, int32_t *d_pkt_len, void *hip_stream)
 {
-    if (!b || !d_frames || !d_state || !d_pkts || !d_pkt_len || nframes <= 0 || version_len < 0 || version_len > TL_EDI_MAX_VERSION ||
+    if (!b || !d_frames || !d_state || !d_pkts || !d_pkt_len || nframes <= 0 || nframes > 65535 || version_len < 0 || version_len > TL_EDI_MAX_VERSION ||
         (version_len && !version)) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
     hipStream_t st = (hipStream_t)hip_stream;
     if (!b->d_edi_version) {
         HIPCHK(hipMalloc(&b->d_edi_version, TL_EDI_MAX_VERSION));
         HIPCHK(hipMalloc(&b->d_frame_bytes, sizeof(int32_t) * (size_t)b->nstreams));
+        HIPCHK(hipMalloc(&b->d_edi_state_tmp, sizeof(TlEdiState) * (size_t)b->nstreams));
         std::vector<int32_t> fb((size_t)b->nstreams);
         for (int s = 0; s < b->nstreams; s++) fb[(size_t)s] = b->h_configs[b->h_stream_cfg[s]].frame_bytes;
         HIPCHK(hipMemcpy(b->d_frame_bytes, fb.data(), sizeof(int32_t) * fb.size(), hipMemcpyHostToDevice));
     }
     if (version_len) HIPCHK(hipMemcpyAsync(b->d_edi_version, version, (size_t)version_len, hipMemcpyHostToDevice, st));
     TlEdiArgs A;
-    A.frames = d_frames; A.levels = d_levels; A.state = (TlEdiState *)d_state; A.version = b->d_edi_version;
+    A.frames = d_frames; A.levels = d_levels; A.state = (const TlEdiState *)d_state; A.state_out = b->d_edi_state_tmp; A.version = b->d_edi_version;
     A.xpow8 = b->d_tables->edi_xpow8; A.frame_bytes = b->d_frame_bytes; A.pkts = d_pkts; A.pkt_len = d_pkt_len;
     A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride;
     A.pkt_stride = tlb_edi_af_stride(b, version_len); A.version_len = version_len;
-    hipLaunchKernelGGL(tl_edi_af_kernel, dim3((unsigned)((b->nstreams + 3) / 4)), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(tl_edi_af_kernel, dim3((unsigned)((b->nstreams + 3) / 4), (unsigned)nframes), dim3(256), 0, st, A);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(d_state, b->d_edi_state_tmp, sizeof(TlEdiState) * (size_t)b->nstreams, hipMemcpyDeviceToDevice, st));
     return TLB_OK;
 }
 

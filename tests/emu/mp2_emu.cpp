@@ -92,10 +92,13 @@ int emu_edi_af(const uint8_t *frames, const int16_t *levels, int nframes, int ns
     static bool built = false;
     if (!built) { tl_build_tables(&T); built = true; }
     TlEdiArgs A;
-    A.frames = frames; A.levels = levels; A.state = state; A.version = version; A.xpow8 = T.edi_xpow8; A.frame_bytes = frame_bytes;
+    std::vector<TlEdiState> next((size_t)nstreams);
+    A.frames = frames; A.levels = levels; A.state = state; A.state_out = next.data(); A.version = version; A.xpow8 = T.edi_xpow8; A.frame_bytes = frame_bytes;
     A.pkts = pkts; A.pkt_len = pkt_len; A.nstreams = nstreams; A.nframes = nframes; A.out_stride = out_stride;
     A.pkt_stride = pkt_stride; A.version_len = version_len;
-    for (int s = 0; s < nstreams; s++) tl_edi_af_stream(A, s);
+    for (int f = 0; f < nframes; f++)
+        for (int s = 0; s < nstreams; s++) tl_edi_af_packet(A, s, f);
+    memcpy(state, next.data(), sizeof(TlEdiState) * (size_t)nstreams);
     return 0;
 }
 int emu_sizeof_edi_state(void) { return (int)sizeof(TlEdiState); }
