@@ -610,14 +610,21 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     {
         double *vt = w.u.fft, *vp = w.u.fft + 520;
         int nvalid = 0;
+        PA(uint32_t, linfo, 8);                                     // the table reads of all eight chunks in one batch
+        TL_LANES_BEGIN
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int base = 0; base < 512; base += 64) {                // straight-line: the table reads of all chunks overlap
+        for (int c8 = 0; c8 < 8; c8++) L(linfo)[c8] = C->p1_lineinfo[64 * c8 + lane];
+        TL_LANES_END
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int base = 0; base < 512; base += 64) {
             PV(bool, ok); PV(double, tv); PV(double, pvv); PV(int, bnd);
             TL_LANES_BEGIN
             const int j = base + lane;
-            const uint32_t info = C->p1_lineinfo[j];
+            const uint32_t info = L(linfo)[base >> 6];
             const int lo = (int)((info >> 8) & 0xfffu), hi = (int)(info >> 20);
             bool v = false; double t = 0, p = 0;
             if (info) {                                             // line inside the bands
@@ -990,14 +997,21 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         PV(double, e512);
         TL_LANES_BEGIN L(e512) = energy[512]; TL_LANES_END
         int nvalid = 0;
+        PA(uint32_t, linfo, 9);                                     // the table reads of all nine chunks in one batch
+        TL_LANES_BEGIN
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int base = 0; base < 576; base += 64) {                // lines 1..512; straight-line so the table reads overlap
+        for (int c8 = 0; c8 < 9; c8++) L(linfo)[c8] = 64 * c8 + lane < 520 ? C->p3_lineinfo[64 * c8 + lane] : 0u;
+        TL_LANES_END
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int base = 0; base < 576; base += 64) {                // lines 1..512
             PV(bool, ok); PV(double, ev); PV(double, cv); PV(double, pvv); PV(int, bnd);
             TL_LANES_BEGIN
             const int j = base + lane;
-            const uint32_t info = j < 520 ? C->p3_lineinfo[j] : 0u;
+            const uint32_t info = L(linfo)[base >> 6];
             const int lo = (int)((info >> 8) & 0xfffu);
             bool v = false; double e = 0, c = 0, p = 0;
             if (info) {
