@@ -58,6 +58,7 @@ void tl_build_tables(TlTables *T)
             const int q = TL_STEP_INDEX[l * 16 + b];
             T->shared.snr_line[l][b] = T->snr[q];
             T->shared.bits12_line[l][b] = (int16_t)(12 * TL_GROUP[q] * TL_BITS[q]);
+            T->shared.qinfo_line[l][b] = (uint16_t)(q | (TL_BITS[q] << 5) | ((TL_GROUP[q] == 3 ? 1 : 0) << 10));
         }
     for (int i = 0; i < 64; i++) T->shared.scalefactor[i] = T->scalefactor[i];
     {   // powers of x modulo the CRC-16 polynomial 0x8005 (CRC16_POLYNOMIAL, common.h:45)

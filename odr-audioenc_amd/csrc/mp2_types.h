@@ -19,6 +19,7 @@ struct TlBlockShared {
     double scalefactor[64];      // encode_new.c:65-83
     double snr_line[9][16];      // SNR[step_index[line][ba]]             (encode_new.c:16-27,96-100)
     int16_t bits12_line[9][16];  // 12*group*bits of step_index[line][ba] (encode_new.c:1125-1133)
+    uint16_t qinfo_line[9][16];  // quantiser class of (line, ba): step_index | bits << 5 | (group == 3) << 10 (encode_new.c:16-100)
     double dct_t[16][2][16];     // matrixing coefficients m[r][2k+par] stored [k][par][r]: one k = 32 consecutive doubles
 };
 

@@ -1671,11 +1671,10 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     const int ba = live ? w.balloc[c][sb] : 0;
     const bool own = sb < sblimit && c < (sb < jsbound ? nch : 1);     // transmits bit_alloc + samples
     const int sfs[4] = {3, 2, 1, 2};
-    L(f_ba) = own ? C->nbal[sb] : 0;
+    L(f_ba) = own ? L(a_nbal) : 0;
     L(f_sel) = (live && ba) ? 2 : 0;
     L(f_scf) = (live && ba) ? 6 * sfs[w.scfsi[c][sb]] : 0;
-    int q = (own && ba) ? T->step_index[C->line[sb]][ba] : 0;
-    L(f_smp) = (own && ba) ? (T->group[q] == 3 ? 3 * T->bits[q] : T->bits[q]) : 0;
+    L(f_smp) = (own && ba) ? B->bits12_line[L(a_ln)][ba] / 12 : 0;     // group * bits of the cell's quantiser class
     TL_LANES_END
     TL_WAVE_EXSCAN_I32(o_ba, f_ba); TL_WAVE_EXSCAN_I32(o_sel, f_sel);
     TL_WAVE_EXSCAN_I32(o_scf, f_scf); TL_WAVE_EXSCAN_I32(o_smp, f_smp);
@@ -1716,9 +1715,10 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         const int c = lane & 1, sb = lane >> 1;
         const bool own = sb < sblimit && c < (sb < jsbound ? nch : 1);
         const int ba = own ? w.balloc[c][sb] : 0;
-        const int q = ba ? T->step_index[C->line[sb]][ba] : 0;
+        const unsigned qi = ba ? B->qinfo_line[L(a_ln)][ba] : 0u;   // class, bits and grouping from the shared LDS copy
+        const int q = (int)(qi & 31u);
         const bool joint = any_joint && sb >= jsbound;
-        L(q_ba) = ba; L(q_nb) = T->bits[q]; L(q_grp) = T->group[q]; L(q_s2n) = T->steps2n[q]; L(q_steps) = T->steps[q];
+        L(q_ba) = ba; L(q_nb) = (int)((qi >> 5) & 31u); L(q_grp) = ((qi >> 10) & 1u) ? 3 : 1; L(q_s2n) = T->steps2n[q]; L(q_steps) = T->steps[q];
         L(q_a) = T->qa[q]; L(q_b) = T->qb[q]; L(q_s2nf) = T->steps2n_f[q];
         for (int gr = 0; gr < 3; gr++) L(q_sf)[gr] = B->scalefactor[joint ? w.jscale[gr][sb] : L(scf)[gr]];
         TL_LANES_END
