@@ -1169,21 +1169,46 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
 // Line-parallel: FFT, unpredictability (sincos/atan2/sqrt per line), thresholds; partition-parallel:
 // grouping, spreading, SNR.  Every sum is one lane's sequential chain in the reference's order.
 TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_RESTRICT P,
-                   TlPsy2State *TL_RESTRICT S, const TlPcmView &pv, int ch)
+                   TlPsy2State *TL_RESTRICT S, const TlPcmView &pv, int ch, long long *sp)
 {
     double *x = w.u.fft;
     double *cw = w.px;                       // c[] (unpredictability), then fthr[]
     double *ge = w.u.fft + 520, *gc = ge + 64, *ecb = gc + 64, *nb = ecb + 64;   // dead upper half of the FHT buffer
     PV(double, snr0);
     for (int pass = 0; pass < 2; pass++) {
+        long long *sq = pass == 0 ? sp : nullptr;                  // stage stamps of the first pass
+        TL_STAMP(sq, 0);
         TL_LANES_BEGIN
-        for (int i = lane; i < 1024; i += 64) {
-            int r = 0;
-            for (int b = 0; b < 10; b++) r |= ((i >> b) & 1) << (9 - b);
-            int16_t v;
-            if (pass == 0) v = i < TL_HIST ? pv.hist[ch * pv.hist_stride + i] : pv.cur[ch * 1152 + (i - TL_HIST)];
-            else v = pv.cur[ch * 1152 + 96 + i];
-            x[r] = P->window[i] * (double)v;                         // psycho_2.c:84-92
+        {
+            // sample i = lane + 64*it of the pass's 1024-sample window (psycho_2.c:84-92); loads in batches of eight ahead
+            // of their use; the bit-reversed slot of i is rev6(lane) << 4 | rev4(it)
+            const double *win = P->window;
+            TL_LAUNDER(win);
+            int r6 = 0;
+            for (int b = 0; b < 6; b++) r6 |= ((lane >> b) & 1) << (5 - b);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int half = 0; half < 16; half += 8) {
+                int16_t v[8]; double h[8];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                for (int q = 0; q < 8; q++) {
+                    const int i = lane + 64 * (half + q);
+                    if (pass == 0) v[q] = i < TL_HIST ? pv.hist[ch * pv.hist_stride + i] : pv.cur[ch * 1152 + (i - TL_HIST)];
+                    else v[q] = pv.cur[ch * 1152 + 96 + i];
+                    h[q] = win[i];
+                }
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                for (int q = 0; q < 8; q++) {
+                    const int it = half + q;
+                    const int r4 = ((it & 1) << 3) | ((it & 2) << 1) | ((it & 4) >> 1) | ((it & 8) >> 3);
+                    x[(r6 << 4) | r4] = h[q] * (double)v[q];
+                }
+            }
         }
         TL_LANES_END
         PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
@@ -1195,33 +1220,42 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
         TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), 39, T->fht_tw, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
         TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
         TL_LANES_BEGIN tl_fht_pass<8>(x, L(twa), lane); TL_LANES_END
+        TL_STAMP(sq, 1);
         // energy + phase (fft.c:1246-1275), unpredictability (psycho_2.c:119-140); ages: new = 1-pass, old = pass
         const int nw = 1 - pass, old = pass;
         TL_LANES_BEGIN
-        for (int j = lane; j <= 512; j += 64) {
-            double e, phi;
-            if (j == 0) { e = x[0] * x[0]; phi = 0.0; }
-            else if (j == 512) { e = x[512] * x[512]; phi = tl_atan2(0.0, x[512]); }
-            else {
-                const double a = x[j], b = x[1024 - j];
-                e = (a * a + b * b) / 2.0;
-                if (e < 0.0005) { e = 0.0005; phi = 0; }
-                else phi = tl_atan2(-a, b) + 3.14159265358979 / 4;
+        {
+            // the prediction state of the line handled next is fetched while the current line's transcendentals run
+            double r_o = S->r[ch][old][lane], r_n = S->r[ch][nw][lane], p_o = S->phi[ch][old][lane], p_n = S->phi[ch][nw][lane];
+            for (int j = lane; j <= 512; j += 64) {
+                const int jn = j + 64 <= 512 ? j + 64 : j;
+                const double r_o2 = S->r[ch][old][jn], r_n2 = S->r[ch][nw][jn], p_o2 = S->phi[ch][old][jn], p_n2 = S->phi[ch][nw][jn];
+                double e, phi;
+                if (j == 0) { e = x[0] * x[0]; phi = 0.0; }
+                else if (j == 512) { e = x[512] * x[512]; phi = tl_atan2(0.0, x[512]); }
+                else {
+                    const double a = x[j], b = x[1024 - j];
+                    e = (a * a + b * b) / 2.0;
+                    if (e < 0.0005) { e = 0.0005; phi = 0; }
+                    else phi = tl_atan2(-a, b) + 3.14159265358979 / 4;
+                }
+                const double r_prime = 2.0 * r_o - r_n;
+                const double phi_prime = 2.0 * p_o - p_n;
+                const double rn = sqrt(e);
+                S->r[ch][nw][j] = rn; S->phi[ch][nw][j] = phi;
+                double sp, cp, spp, cpp;
+                tl_sincos(phi, &sp, &cp);
+                tl_sincos(phi_prime, &spp, &cpp);
+                const double t1 = rn * cp - r_prime * cpp;
+                const double t2 = rn * sp - r_prime * spp;
+                const double t3 = rn + fabs(r_prime);
+                cw[j] = t3 != 0 ? sqrt(t1 * t1 + t2 * t2) / t3 : 0;
+                x[j] = e;                                           // x[1024-j] belongs to this lane only
+                r_o = r_o2; r_n = r_n2; p_o = p_o2; p_n = p_n2;
             }
-            const double r_prime = 2.0 * S->r[ch][old][j] - S->r[ch][nw][j];
-            const double phi_prime = 2.0 * S->phi[ch][old][j] - S->phi[ch][nw][j];
-            const double rn = sqrt(e);
-            S->r[ch][nw][j] = rn; S->phi[ch][nw][j] = phi;
-            double sp, cp, spp, cpp;
-            tl_sincos(phi, &sp, &cp);
-            tl_sincos(phi_prime, &spp, &cpp);
-            const double t1 = rn * cp - r_prime * cpp;
-            const double t2 = rn * sp - r_prime * spp;
-            const double t3 = rn + fabs(r_prime);
-            cw[j] = t3 != 0 ? sqrt(t1 * t1 + t2 * t2) / t3 : 0;
-            x[j] = e;                                               // x[1024-j] belongs to this lane only
         }
         TL_LANES_END
+        TL_STAMP(sq, 2);
         const double *energy = x;
         // grouped energy / weighted unpredictability per partition (psycho_2.c:146-155)
         TL_LANES_BEGIN
@@ -1232,13 +1266,26 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
             ge[lane] = e; gc[lane] = c;
         }
         TL_LANES_END
+        TL_STAMP(sq, 3);
         // spreading (psycho_2.c:161-175), required SNR (:181-193), permissible noise (:200-204)
         TL_LANES_BEGIN
         {
             double e = 0, c = 0;
-            for (int k = 0; k < 64; k++) {
-                const double sv = P->s_t[k][lane];
-                if (sv != 0.0) { e += sv * ge[k]; c += sv * gc[k]; }
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int k0 = 0; k0 < 64; k0 += 16) {                   // sixteen coefficient loads in flight per round trip
+                double sv[16];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                for (int q = 0; q < 16; q++) sv[q] = P->s_t[k0 + q][lane];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                // the reference skips zero coefficients (psycho_2.c:165); adding their +-0 products leaves the sums unchanged
+                // bit for bit (finite operands, sums start at +0), so the test is dropped instead of branching 64 times
+                for (int q = 0; q < 16; q++) { e += sv[q] * ge[k0 + q]; c += sv[q] * gc[k0 + q]; }
             }
             double cb = e != 0 ? c / e : 0;
             if (cb < .05) cb = 0.05; else if (cb > .5) cb = 0.5;
@@ -1250,6 +1297,7 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
             nb[lane] = P->den[lane] != 0 ? e * bc / P->den[lane] : 0;
         }
         TL_LANES_END
+        TL_STAMP(sq, 4);
         // threshold per line (psycho_2.c:205-224): c[] is dead, reuse it for fthr[]
         TL_LANES_BEGIN
         for (int j = lane; j <= 512; j += 64) {
@@ -1257,6 +1305,7 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
             cw[j] = t > a ? t : a;
         }
         TL_LANES_END
+        TL_STAMP(sq, 5);
         // 32 subbands (psycho_2.c:227-246)
         TL_LANES_BEGIN
         if (lane < 32) {
@@ -1273,6 +1322,7 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
             else w.smr[ch][lane] = L(snr0) > snr ? L(snr0) : snr;
         }
         TL_LANES_END
+        TL_STAMP(sq, 6);
     }
 }
 
@@ -1446,7 +1496,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         }
         TL_LANES_END
     } else if constexpr (PSY == 2) {
-        for (int ch = 0; ch < nch; ch++) tl_psy2(w, T, P2, S2, pv, ch);
+        for (int ch = 0; ch < nch; ch++) tl_psy2(w, T, P2, S2, pv, ch, sp ? sp + 8 + 8 * ch : nullptr);
     } else if constexpr (PSY == 1) {
         for (int ch = 0; ch < nch; ch++) tl_psy1(w, T, B, C, pv, ch, sp ? sp + 8 + 8 * ch : nullptr);
     } else {

@@ -30,6 +30,8 @@ for i, n in enumerate(names):
     d = (st[..., i + 1] - st[..., i]).mean()
     print(f"  {n:22s} {d:10.0f}  {100 * d / tot:5.1f}%")
 pn = ["spectrum(FHT)", "power+candidates", "tonal walk", "noise bands", "decimation", "threshold", "minmask+smr"]
+if psy == 2:      # stamps of the first of the two 576-sample passes
+    pn = ["window+FHT", "energy/phase/unpred.", "partitions", "spreading+SNR", "line thresholds", "subbands", "-"]
 for ch in range(2):
     base = 8 + 8 * ch
     if st[..., base + 1].max() == 0:
