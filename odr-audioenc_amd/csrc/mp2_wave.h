@@ -914,6 +914,9 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     // to 0.0 (oracle/mp2_oracle.c:psy3_run)
     // and Lsb (psycho_3.c:163-183; line 512 is skipped, see oracle) -> w.spike.  A subband's 16 lines sit in one row of
     // 16 lanes, so its maximum is a row reduction of the values just computed (no strided re-read of px).
+    TL_LANES_BEGIN
+    if (lane < 32) w.nsum[lane] = C->scale_db[w.minidx[ch][lane]];    // one table round trip for all subbands (nsum is free here)
+    TL_LANES_END
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
@@ -931,7 +934,7 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         if ((lane & 15) == 15) {
             const int sb = (lane + 64 * it) >> 4;
             const double xmax = TL_DBMIN < L(pxm) ? L(pxm) : TL_DBMIN;
-            const double val = C->scale_db[w.minidx[ch][sb]];
+            const double val = w.nsum[sb];
             w.spike[sb] = xmax > val ? xmax : val;
         }
         TL_LANES_END
