@@ -130,6 +130,37 @@ def test_many_streams_vs_oracle(M, psy, mode, nstreams, nframes):
     b.close()
 
 
+def test_configuration_sweep_vs_oracle(M):
+    """Every legal (sample rate, mode, bitrate) x psy model as ONE mixed batch, a different signal per stream, against the
+    oracle byte for byte (SURVEY 8d cfg5 generalised: mixed configurations share a launch)."""
+    rates = {48000: [(m, k) for m in "sjdm" for k in ((64, 96, 128, 160, 192, 256, 384) if m != "m" else (32, 48, 64, 96, 128, 192))],
+             32000: [("s", 128), ("j", 192), ("m", 64), ("m", 96), ("d", 256)],
+             24000: [("s", 64), ("j", 96), ("m", 32), ("m", 64), ("s", 128)],
+             16000: [("m", 24), ("s", 48), ("j", 64)]}
+    nframes, cfgs, pcms, refs = 5, [], [], []
+    n = 0
+    for fs, lst in rates.items():
+        for mode, kbps in lst:
+            for psy in (0, 1, 2, 3):
+                kind = (0, 3, 5, 7)[n % 4] if psy != 3 else (0, 5)[n % 2]      # psy 3 + silence-like kinds crash the reference
+                pcm = gen_pcm(31 + n, kind, 0, nframes)
+                n += 1
+                try:
+                    ref, _ = O.oracle_stream(pcm, samplerate=fs, mode=mode, kbps=kbps, psy=psy)
+                except Exception:
+                    continue                                                   # combination the reference rejects
+                cfgs.append(M.StreamConfig(samplerate=fs, mode=mode, bitrate=kbps, psy_model=psy))
+                pcms.append(pcm)
+                refs.append(ref)
+    assert len(cfgs) > 120
+    b = M.Batch(cfgs)
+    got, _ = b.encode(np.stack(pcms, axis=1))
+    tail = b.flush()
+    bad = [(c.samplerate, c.mode, c.bitrate, c.psy_model) for c, g, t, r in zip(cfgs, got, tail, refs) if g + t != r]
+    assert not bad, bad
+    b.close()
+
+
 def test_full_size_properties(M):
     """BASELINE configs[1] size (4096 streams, psy 1): size-independent properties instead of a full
     oracle run -- identical inputs give identical frames, every frame starts with the sync header,
