@@ -137,8 +137,7 @@ int tlb_zmq_frame_host(tlb_batch *b, const uint8_t *frames, const int16_t *peaks
  *   d_levels  int16 [nframes][nstreams][2] or NULL (levels 0)   (tlb_ingest_device peaks)
  *   d_state   tlb_edi_state [nstreams]
  *   d_pkts    uint8 [nframes][nstreams][tlb_edi_af_stride()], d_pkt_len int32 [nframes][nstreams] = bytes used
- * `version` is host memory (<= 64 bytes).  PFT fragmentation / Reed-Solomon (the UDP transport layer,
- * contrib/edioutput/PFT.cpp) and the sockets stay with the caller. */
+ * `version` is host memory (<= 64 bytes).  The PFT layer for UDP destinations is tlb_edi_pft_* below; sockets stay with the caller. */
 typedef struct tlb_edi_state {
     int64_t edi_time, send_version_at_time;
     uint32_t timestamp, num_seconds_sent;
@@ -152,6 +151,25 @@ int tlb_edi_af_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_le
                       const char *version, int version_len, uint8_t *d_pkts, int32_t *d_pkt_len, void *hip_stream);
 int tlb_edi_af_host(tlb_batch *b, const uint8_t *frames, const int16_t *levels, int nframes, tlb_edi_state *state,
                     const char *version, int version_len, uint8_t *pkts, int32_t *pkt_len);
+
+/* EDI protection, fragmentation and transport layer (ETSI TS 102 821 clause 7): what
+ * edi::PFT::Assemble (contrib/edioutput/PFT.cpp:234-320, with Protect :75-139 and ProtectAndFragment :141-232) makes of an
+ * AF packet for UDP destinations -- Reed-Solomon RS(255,207) per chunk (fec = m > 0: m fragments may be lost), interleaved
+ * fragments, PF header ("PF", Pseq, Findex, Fcount, FEC|Addr|Plen, [RSk, RSz], [Source, Dest], CRC-16) + payload.
+ * fec = 0: fragmentation only (1400-byte slices), as the reference's default configuration (EDIConfig.h:69-70).
+ *   d_af      uint8 [nframes][nstreams][af_stride], d_af_len int32 [nframes][nstreams]     (tlb_edi_af_device output)
+ *   d_pseq    uint16 [nstreams]: PFT::m_pseq per stream, advanced by nframes
+ *   d_frags   uint8 [nframes][nstreams][max_frags][frag_stride], d_frag_len int32 [nframes][nstreams][max_frags],
+ *   d_nfrag   int32 [nframes][nstreams];  max_frags / frag_stride at least what tlb_edi_pft_shape() reports for this af_stride
+ *   (every AF packet length up to af_stride is covered; at most 10 chunks per packet, i.e. chunk_len >= af_stride / 10)
+ * chunk_len is edi::configuration_t::chunk_len (<= 207), transport/addr_source/dest_port the optional address header. */
+int tlb_edi_pft_shape(const tlb_batch *b, int af_stride, int fec, int chunk_len, int transport, int *max_frags, int *frag_stride);
+int tlb_edi_pft_device(tlb_batch *b, const uint8_t *d_af, const int32_t *d_af_len, int nframes, int af_stride, uint16_t *d_pseq,
+                       int fec, int chunk_len, int transport, int addr_source, int dest_port,
+                       uint8_t *d_frags, int32_t *d_frag_len, int32_t *d_nfrag, int max_frags, int frag_stride, void *hip_stream);
+int tlb_edi_pft_host(tlb_batch *b, const uint8_t *af, const int32_t *af_len, int nframes, int af_stride, uint16_t *pseq,
+                     int fec, int chunk_len, int transport, int addr_source, int dest_port,
+                     uint8_t *frags, int32_t *frag_len, int32_t *nfrag, int max_frags, int frag_stride);
 
 /* Diagnostic only: per-stage cycle stamps [nframes][nstreams][32] (csrc/mp2_wave.h TL_STAMP), host buffers. */
 int tlb_encode_host_stamps(tlb_batch *b, const int16_t *pcm, int nframes, long long *stamps);

@@ -64,6 +64,30 @@ void tl_build_tables(TlTables *T)
     {   // powers of x modulo the CRC-16 polynomial 0x8005 (CRC16_POLYNOMIAL, common.h:45)
         unsigned v = 1;
         for (int e = 0; e < 384; e++) { T->crc_xpow[e] = (uint16_t)v; v <<= 1; if (v & 0x10000u) v = (v ^ 0x18005u) & 0xffffu; }
+        {   // Reed-Solomon RS(255,207) of the EDI PFT layer: GF(2^8) with x^8+x^4+x^3+x^2+1, generator polynomial with roots
+            // alpha^1..alpha^48 (contrib/edioutput/PFT.cpp:100-107: gfPoly 0x11d, firstRoot 1; contrib/fec/init_rs.h).
+            uint8_t *lg = T->rs_log, *ex = T->rs_exp;
+            unsigned sr = 1;
+            lg[0] = 255;
+            for (int i = 0; i < 255; i++) { lg[sr] = (uint8_t)i; ex[i] = (uint8_t)sr; sr <<= 1; if (sr & 0x100u) sr ^= 0x11du; }
+            for (int i = 255; i < 512; i++) ex[i] = ex[i - 255];
+            uint8_t gen[49];                                         // generator polynomial, gen[48] = 1 (coefficient form)
+            gen[0] = 1;
+            for (int i = 0, root = 1; i < 48; i++, root++) {
+                gen[i + 1] = 1;
+                for (int j = i; j > 0; j--) gen[j] = (uint8_t)(gen[j - 1] ^ (gen[j] ? ex[lg[gen[j]] + root] : 0));
+                gen[0] = ex[lg[gen[0]] + root];
+            }
+            for (int u = 0; u < 207; u++) {                          // systematic encoder (LFSR division) on the unit chunk e_u
+                uint8_t par[48] = {0};
+                for (int i = 0; i < 207; i++) {
+                    const uint8_t fb = (uint8_t)((i == u ? 1 : 0) ^ par[0]);
+                    for (int j = 0; j < 47; j++) par[j] = (uint8_t)(par[j + 1] ^ ((fb && gen[47 - j]) ? ex[lg[fb] + lg[gen[47 - j]]] : 0));
+                    par[47] = (uint8_t)((fb && gen[0]) ? ex[lg[fb] + lg[gen[0]]] : 0);
+                }
+                for (int j = 0; j < 48; j++) T->rs_mlog[u][j] = par[j] ? lg[par[j]] : 255;
+            }
+        }
         unsigned ve = 1;
         for (int k = 0; k < 2048; k++) {
             T->edi_xpow8[k] = (uint16_t)ve;

@@ -16,6 +16,7 @@
 #include "mp2_host.h"
 #include "mp2_wave.h"
 #include "edi_af.h"
+#include "edi_pft.h"
 
 static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 
@@ -122,6 +123,23 @@ __global__ void __launch_bounds__(256) tl_edi_af_kernel(TlEdiArgs A)
     tl_edi_af_packet(A, s, (int)blockIdx.y);
 }
 
+// EDI PFT layer (csrc/edi_pft.h): one wavefront per AF packet, blockIdx.y = frame of the call.  The Reed-Solomon tables
+// (11 KB) are copied into LDS once per workgroup: the encoder's look-ups are dependent and must not go to global memory.
+__global__ void __launch_bounds__(256) tl_edi_pft_kernel(TlPftArgs A, const TlTables *T)
+{
+    __shared__ uint8_t s_log[256], s_exp[512], s_mlog[207 * TL_PFT_PARITY];
+    __shared__ TlPftScratch scratch[4];
+    for (int i = (int)threadIdx.x; i < 256; i += 256) s_log[i] = T->rs_log[i];
+    for (int i = (int)threadIdx.x; i < 512; i += 256) s_exp[i] = T->rs_exp[i];
+    for (int i = (int)threadIdx.x; i < 207 * TL_PFT_PARITY; i += 256) s_mlog[i] = (&T->rs_mlog[0][0])[i];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int s = (int)blockIdx.x * 4 + wave;
+    if (s >= A.nstreams) return;
+    const TlPftTables R = {s_log, s_exp, s_mlog};
+    tl_edi_pft_packet(A, R, s, (int)blockIdx.y, scratch[wave]);
+}
+
 // pending frame (big-endian words in the stream state) -> bytes
 __global__ void tl_flush_kernel(const TlStreamState *state, const TlConfig *configs, const int32_t *stream_cfg,
                                 uint8_t *out, int nstreams, int out_stride)
@@ -153,6 +171,7 @@ struct tlb_batch {
     uint8_t *d_edi_version = nullptr;            // EDI: ODRv string and per-stream frame sizes (allocated on first use)
     int32_t *d_frame_bytes = nullptr;
     TlEdiState *d_edi_state_tmp = nullptr;
+    uint16_t *d_pseq_tmp = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
     bool timed = false;
@@ -185,6 +204,7 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_edi_version) (void)hipFree(b->d_edi_version);
     if (b->d_frame_bytes) (void)hipFree(b->d_frame_bytes);
     if (b->d_edi_state_tmp) (void)hipFree(b->d_edi_state_tmp);
+    if (b->d_pseq_tmp) (void)hipFree(b->d_pseq_tmp);
     for (int p = 0; p < 4; p++) if (b->d_list[p]) (void)hipFree(b->d_list[p]);
     if (b->d_psy2_tables) (void)hipFree(b->d_psy2_tables);
     if (b->d_psy2_state) (void)hipFree(b->d_psy2_state);
@@ -515,6 +535,84 @@ int tlb_edi_af_host(tlb_batch *b, const uint8_t *frames, const int16_t *levels, 
     if (e == hipSuccess) e = hipMemcpy(pkt_len, d_n, sizeof(int32_t) * slots, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(state, d_s, sizeof(tlb_edi_state) * (size_t)b->nstreams, hipMemcpyDeviceToHost);
     (void)hipFree(d_f); (void)hipFree(d_p); (void)hipFree(d_s); (void)hipFree(d_n); if (d_l) (void)hipFree(d_l);
+    if (e != hipSuccess) return TLB_ERR_HIP;
+    return rc;
+}
+
+// ---- EDI PFT layer (include/toolame_batch.h) ----
+static int pft_shape(int max_af_len, int fec, int chunk_len, int transport, int *max_frags, int *frag_stride)
+{   // largest fragment count and fragment size over every AF packet length the batch can produce (PFT.cpp:166-176,199-209)
+    if (fec < 0 || fec > 5 || chunk_len < 1 || chunk_len > 207 || max_af_len < 1) return TLB_ERR_ARG;
+    int mf = 0, ms = 0;
+    for (int l = 1; l <= max_af_len; l++) {
+        int nfr, fsz;
+        if (fec > 0) {
+            const int c = (l + chunk_len - 1) / chunk_len, k = (l + c - 1) / c, total = c * (k + 48), smax = (c * 48) / (fec + 1);
+            nfr = (total + smax - 1) / smax; fsz = (total + nfr - 1) / nfr;
+            if (c > TL_PFT_MAX_CHUNKS) return TLB_ERR_ARG;
+        } else { nfr = (l + 1399) / 1400; fsz = (l + nfr - 1) / nfr; }
+        if (nfr > mf) mf = nfr;
+        if (fsz > ms) ms = fsz;
+    }
+    *max_frags = mf;
+    *frag_stride = (12 + (fec > 0 ? 2 : 0) + (transport ? 4 : 0) + 2 + ms + 3) & ~3;
+    return TLB_OK;
+}
+
+int tlb_edi_pft_shape(const tlb_batch *b, int af_stride, int fec, int chunk_len, int transport, int *max_frags, int *frag_stride)
+{
+    if (!b || !max_frags || !frag_stride) return TLB_ERR_ARG;
+    return pft_shape(af_stride, fec, chunk_len, transport, max_frags, frag_stride);
+}
+
+int tlb_edi_pft_device(tlb_batch *b, const uint8_t *d_af, const int32_t *d_af_len, int nframes, int af_stride, uint16_t *d_pseq,
+                       int fec, int chunk_len, int transport, int addr_source, int dest_port,
+                       uint8_t *d_frags, int32_t *d_frag_len, int32_t *d_nfrag, int max_frags, int frag_stride, void *hip_stream)
+{
+    if (!b || !d_af || !d_af_len || !d_pseq || !d_frags || !d_frag_len || !d_nfrag || nframes <= 0 || nframes > 65535 || af_stride <= 0 || af_stride > 2048 || (af_stride & 3)) return TLB_ERR_ARG;
+    int mf = 0, fs = 0;
+    if (int rc = pft_shape(af_stride, fec, chunk_len, transport, &mf, &fs)) return rc;
+    if (max_frags < mf || frag_stride < fs) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (!b->d_pseq_tmp) HIPCHK(hipMalloc(&b->d_pseq_tmp, sizeof(uint16_t) * (size_t)b->nstreams));
+    TlPftArgs A;
+    A.af = d_af; A.af_len = d_af_len; A.pseq = d_pseq; A.pseq_out = b->d_pseq_tmp;
+    A.frags = d_frags; A.frag_len = d_frag_len; A.nfrag = d_nfrag;
+    A.nstreams = b->nstreams; A.nframes = nframes; A.af_stride = af_stride; A.max_frags = max_frags; A.frag_stride = frag_stride;
+    A.fec = fec; A.chunk_len = chunk_len; A.transport = transport ? 1 : 0; A.addr_source = addr_source; A.dest_port = dest_port;
+    hipLaunchKernelGGL(tl_edi_pft_kernel, dim3((unsigned)((b->nstreams + 3) / 4), (unsigned)nframes), dim3(256), 0, st, A, (const TlTables *)b->d_tables);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(d_pseq, b->d_pseq_tmp, sizeof(uint16_t) * (size_t)b->nstreams, hipMemcpyDeviceToDevice, st));
+    return TLB_OK;
+}
+
+int tlb_edi_pft_host(tlb_batch *b, const uint8_t *af, const int32_t *af_len, int nframes, int af_stride, uint16_t *pseq,
+                     int fec, int chunk_len, int transport, int addr_source, int dest_port,
+                     uint8_t *frags, int32_t *frag_len, int32_t *nfrag, int max_frags, int frag_stride)
+{
+    if (!b || !af || !af_len || !pseq || !frags || !frag_len || !nfrag || nframes <= 0 || af_stride <= 0 || max_frags <= 0 || frag_stride <= 0) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    const size_t slots = (size_t)nframes * (size_t)b->nstreams;
+    uint8_t *d_a = nullptr, *d_f = nullptr; int32_t *d_l = nullptr, *d_fl = nullptr, *d_n = nullptr; uint16_t *d_p = nullptr;
+    HIPCHK(hipMalloc(&d_a, slots * (size_t)af_stride));
+    HIPCHK(hipMalloc(&d_l, slots * 4));
+    HIPCHK(hipMalloc(&d_f, slots * (size_t)max_frags * (size_t)frag_stride));
+    HIPCHK(hipMalloc(&d_fl, slots * (size_t)max_frags * 4));
+    HIPCHK(hipMalloc(&d_n, slots * 4));
+    HIPCHK(hipMalloc(&d_p, sizeof(uint16_t) * (size_t)b->nstreams));
+    HIPCHK(hipMemset(d_f, 0, slots * (size_t)max_frags * (size_t)frag_stride));
+    HIPCHK(hipMemset(d_fl, 0, slots * (size_t)max_frags * 4));
+    HIPCHK(hipMemcpy(d_a, af, slots * (size_t)af_stride, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_l, af_len, slots * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_p, pseq, sizeof(uint16_t) * (size_t)b->nstreams, hipMemcpyHostToDevice));
+    int rc = tlb_edi_pft_device(b, d_a, d_l, nframes, af_stride, d_p, fec, chunk_len, transport, addr_source, dest_port, d_f, d_fl, d_n, max_frags, frag_stride, nullptr);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(frags, d_f, slots * (size_t)max_frags * (size_t)frag_stride, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(frag_len, d_fl, slots * (size_t)max_frags * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(nfrag, d_n, slots * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(pseq, d_p, sizeof(uint16_t) * (size_t)b->nstreams, hipMemcpyDeviceToHost);
+    (void)hipFree(d_a); (void)hipFree(d_l); (void)hipFree(d_f); (void)hipFree(d_fl); (void)hipFree(d_n); (void)hipFree(d_p);
     if (e != hipSuccess) return TLB_ERR_HIP;
     return rc;
 }

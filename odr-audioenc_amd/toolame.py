@@ -88,6 +88,9 @@ def load_library():
     L.tlb_edi_af_stride.argtypes = [C.c_void_p, C.c_int]
     L.tlb_edi_af_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tlb_edi_af_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.tlb_edi_pft_shape.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.tlb_edi_pft_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int] * 2
+    L.tlb_edi_pft_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int] * 2 + [C.c_void_p]
     L.toolame_set_samplerate.argtypes = [C.c_long]
     L.toolame_set_channel_mode.argtypes = [C.c_char]
     L.toolame_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -247,6 +250,27 @@ class Batch:
         if rc:
             raise ToolameError(rc, "tlb_edi_af_host")
         return pkts, plen
+
+    def edi_pft(self, af, af_len, pseq, fec=0, chunk_len=207, transport=False, addr_source=0, dest_port=0):
+        """AF packets (edi_af() output) -> PFT fragments.  pseq uint16 [nstreams] is advanced in place.
+        Returns (fragments uint8 [nframes, nstreams, max_frags, frag_stride], lengths int32 [.., max_frags], counts int32 [nframes, nstreams])"""
+        a = np.ascontiguousarray(af, dtype=np.uint8)
+        nf, ns, stride = a.shape
+        al = np.ascontiguousarray(af_len, dtype=np.int32)
+        if ns != self.nstreams or al.shape != (nf, ns) or pseq.dtype != np.uint16 or pseq.shape != (ns,):
+            raise ToolameError(18, "edi_pft argument shapes")
+        mf, fs = C.c_int(0), C.c_int(0)
+        rc = self.L.tlb_edi_pft_shape(self.h, stride, fec, chunk_len, 1 if transport else 0, C.byref(mf), C.byref(fs))
+        if rc:
+            raise ToolameError(rc, "tlb_edi_pft_shape")
+        frags = np.zeros((nf, ns, mf.value, fs.value), dtype=np.uint8)
+        flen = np.zeros((nf, ns, mf.value), dtype=np.int32)
+        nfrag = np.zeros((nf, ns), dtype=np.int32)
+        rc = self.L.tlb_edi_pft_host(self.h, a.ctypes.data, al.ctypes.data, nf, stride, pseq.ctypes.data, fec, chunk_len, 1 if transport else 0,
+                                     addr_source, dest_port, frags.ctypes.data, flen.ctypes.data, nfrag.ctypes.data, mf.value, fs.value)
+        if rc:
+            raise ToolameError(rc, "tlb_edi_pft_host")
+        return frags, flen, nfrag
 
     def last_kernel_ms(self):
         return float(self.L.tlb_last_kernel_ms(self.h))

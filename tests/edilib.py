@@ -128,3 +128,103 @@ def case_inputs(name):
                 levels = ((k * 7919 + 13) % 32768).astype(np.int16).reshape(nf, len(fbs), 2)
             return frames, levels, np.array(fbs, dtype=np.int32), st
     raise KeyError(name)
+
+
+# ---- PFT layer (csrc/edi_pft.h) ----
+def pft_shape(max_af_len, fec, chunk_len, transport):
+    """largest fragment count / 4-byte-rounded fragment slot over all AF lengths up to max_af_len (PFT.cpp:166-176,199-209)"""
+    mf = ms = 0
+    for l in range(1, max_af_len + 1):
+        if fec > 0:
+            c = -(-l // chunk_len); k = -(-l // c); total = c * (k + 48); smax = (c * 48) // (fec + 1)
+            nfr = -(-total // smax); fsz = -(-total // nfr)
+        else:
+            nfr = -(-l // 1400); fsz = -(-l // nfr)
+        mf, ms = max(mf, nfr), max(ms, fsz)
+    return mf, (12 + (2 if fec > 0 else 0) + (4 if transport else 0) + 2 + ms + 3) & ~3
+
+
+def emu_pft(af, af_len, pseq, fec, chunk_len=207, transport=0, addr_source=0, dest_port=0):
+    import emulib as E
+    L = E.lib()
+    nf, ns, stride = af.shape
+    mf, fs = pft_shape(stride, fec, chunk_len, transport)
+    frags = np.zeros((nf, ns, mf, fs), dtype=np.uint8)
+    flen = np.zeros((nf, ns, mf), dtype=np.int32)
+    nfrag = np.zeros((nf, ns), dtype=np.int32)
+    ps = np.ascontiguousarray(pseq, dtype=np.uint16).copy()
+    al = np.ascontiguousarray(af_len, dtype=np.int32)
+    L.emu_edi_pft.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p] * 4 + [C.c_int] * 2
+    assert L.emu_edi_pft(af.ctypes.data, al.ctypes.data, nf, ns, stride, fec, chunk_len, transport, addr_source, dest_port,
+                         ps.ctypes.data, frags.ctypes.data, flen.ctypes.data, nfrag.ctypes.data, mf, fs) == 0
+    return frags, flen, nfrag, ps
+
+
+def pft_ref_lib():
+    p = ROOT / "oracle" / "_ref" / "libpft_ref.so"
+    if not p.exists() and Path("/root/reference").exists():
+        subprocess.run(["make", "-s", "-C", str(ROOT / "oracle"), "_ref/libpft_ref.so"], check=True)
+    if not p.exists():
+        return None
+    L = C.CDLL(str(p))
+    L.pftref_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_int, C.c_uint, C.c_uint, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    return L
+
+
+def ref_pft(af, af_len, pseq, fec, chunk_len=207, transport=0, addr_source=0, dest_port=0):
+    """reference Reed-Solomon + CRC code under a statement-by-statement restatement of PFT.cpp (oracle/pft_ref_driver.cpp)"""
+    L = pft_ref_lib()
+    nf, ns, stride = af.shape
+    mf, fs = pft_shape(stride, fec, chunk_len, transport)
+    frags = np.zeros((nf, ns, mf, fs), dtype=np.uint8)
+    flen = np.zeros((nf, ns, mf), dtype=np.int32)
+    nfrag = np.zeros((nf, ns), dtype=np.int32)
+    ps = np.ascontiguousarray(pseq, dtype=np.uint16).copy()
+    for s in range(ns):
+        a = np.ascontiguousarray(af[:, s, :]); al = np.ascontiguousarray(af_len[:, s], dtype=np.int32)
+        fr = np.zeros((nf, mf, fs), dtype=np.uint8); fl = np.zeros((nf, mf), dtype=np.int32); nn = np.zeros(nf, dtype=np.int32)
+        one = ps[s:s + 1].copy()
+        assert L.pftref_stream(a.ctypes.data, al.ctypes.data, nf, stride, fec, chunk_len, transport, addr_source, dest_port,
+                               one.ctypes.data, fr.ctypes.data, fl.ctypes.data, nn.ctypes.data, mf, fs) == 0
+        frags[:, s], flen[:, s], nfrag[:, s], ps[s] = fr, fl, nn, one[0]
+    return frags, flen, nfrag, ps
+
+
+def pft_digest(frags, flen, nfrag):
+    h = hashlib.sha256()
+    for f in range(frags.shape[0]):
+        for s in range(frags.shape[1]):
+            h.update(int(nfrag[f, s]).to_bytes(4, "little"))
+            for i in range(nfrag[f, s]):
+                h.update(frags[f, s, i, : flen[f, s, i]].tobytes())
+    return h.hexdigest()
+
+
+# (name, AF case it builds on, frames used, fec, chunk_len, transport, addr_source, dest_port, start pseq)
+PFT_CASES = [
+    ("fec2", "tist_wrap", 40, 2, 207, 0, 0, 0, 65530),
+    ("fec0_plain", "plain", 20, 0, 207, 0, 0, 0, 7),
+    ("fec5_addr_k100", "long_version_cadence", 60, 5, 100, 1, 0x1234, 12000, 0),
+    ("fec1_big", "big", 6, 1, 207, 1, 1, 65535, 100),
+    ("fec0_big", "big", 6, 0, 207, 0, 0, 0, 100),
+]
+
+
+def pft_case_inputs(name):
+    """AF packets for a PFT case: the emulated AF layer's output for the named AF case ('big' = 1728-byte frames)"""
+    for c in PFT_CASES:
+        if c[0] == name:
+            _, afcase, nf, fec, k, tr, src, dst, pseq0 = c
+            if afcase == "big":
+                fbs = [1728, 1152]
+                frames = payload(nf, 2, 1728, fbs, seed=99)
+                st = init_state(2, 1712345678, 0, 1, 37)
+                levels, fb = None, np.array(fbs, dtype=np.int32)
+            else:
+                frames, levels, fb, st = case_inputs(afcase)
+                frames, levels = frames[:nf], (levels[:nf] if levels is not None else None)
+            pkts, plen, _ = emu_af(frames, levels, fb, st)
+            pseq = np.full(len(fb), pseq0, dtype=np.uint16)
+            return pkts, plen, pseq, dict(fec=fec, chunk_len=k, transport=tr, addr_source=src, dest_port=dst)
+    raise KeyError(name)

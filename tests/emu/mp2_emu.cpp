@@ -14,6 +14,7 @@
 #include "../../odr-audioenc_amd/csrc/mp2_host.h"
 #include "../../odr-audioenc_amd/csrc/mp2_wave.h"
 #include "../../odr-audioenc_amd/csrc/edi_af.h"
+#include "../../odr-audioenc_amd/csrc/edi_pft.h"
 
 struct Emu {
     TlTables tables;
@@ -102,6 +103,26 @@ int emu_edi_af(const uint8_t *frames, const int16_t *levels, int nframes, int ns
     return 0;
 }
 int emu_sizeof_edi_state(void) { return (int)sizeof(TlEdiState); }
+// EDI PFT fragments (csrc/edi_pft.h) of nframes AF packets of nstreams streams, emulated wave per packet.
+int emu_edi_pft(const uint8_t *af, const int32_t *af_len, int nframes, int nstreams, int af_stride, int fec, int chunk_len, int transport,
+                int addr_source, int dest_port, uint16_t *pseq, uint8_t *frags, int32_t *frag_len, int32_t *nfrag, int max_frags, int frag_stride)
+{
+    static TlTables T;
+    static bool built = false;
+    if (!built) { tl_build_tables(&T); built = true; }
+    std::vector<uint16_t> next((size_t)nstreams);
+    TlPftArgs A;
+    A.af = af; A.af_len = af_len; A.pseq = pseq; A.pseq_out = next.data();
+    A.frags = frags; A.frag_len = frag_len; A.nfrag = nfrag;
+    A.nstreams = nstreams; A.nframes = nframes; A.af_stride = af_stride; A.max_frags = max_frags; A.frag_stride = frag_stride;
+    A.fec = fec; A.chunk_len = chunk_len; A.transport = transport; A.addr_source = addr_source; A.dest_port = dest_port;
+    static TlPftScratch W;
+    const TlPftTables R = {T.rs_log, T.rs_exp, &T.rs_mlog[0][0]};
+    for (int f = 0; f < nframes; f++)
+        for (int s = 0; s < nstreams; s++) tl_edi_pft_packet(A, R, s, f, W);
+    memcpy(pseq, next.data(), sizeof(uint16_t) * (size_t)nstreams);
+    return 0;
+}
 int emu_sizeof_taps(void) { return (int)sizeof(TlTaps); }
 int emu_sizeof_lds(void) { return (int)sizeof(TlWaveLds); }
 double emu_log10(double x) { return tl_log10(x); }

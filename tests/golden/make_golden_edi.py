@@ -21,3 +21,16 @@ for name, *_ in E.CASES:
     out[name + "_state"] = st2
     print(name, pkts.shape, plen.min(), plen.max(), E.digest(pkts, plen)[:16])
 np.savez_compressed(Path(__file__).resolve().parent / "edi_cases.npz", **out)
+
+# ---- PFT layer: reference Reed-Solomon/CRC code under the restated PFT.cpp logic (oracle/pft_ref_driver.cpp) ----
+pft = {}
+for name, *_ in E.PFT_CASES:
+    af, af_len, pseq, kw = E.pft_case_inputs(name)
+    frags, flen, nfrag, ps = E.ref_pft(af, af_len, pseq, **kw)
+    pft[name + "_head"] = frags[:2]
+    pft[name + "_len"] = flen
+    pft[name + "_n"] = nfrag
+    pft[name + "_pseq"] = ps
+    pft[name + "_sha"] = np.frombuffer(bytes.fromhex(E.pft_digest(frags, flen, nfrag)), dtype=np.uint8)
+    print(name, frags.shape, int(nfrag.min()), int(nfrag.max()), E.pft_digest(frags, flen, nfrag)[:16])
+np.savez_compressed(Path(__file__).resolve().parent / "edi_pft_cases.npz", **pft)

@@ -300,3 +300,25 @@ def test_edi_af_packets(M):
     # tlb_edi_state_init == the first-call branch of EDI::write_frame
     for now, delay, tist in ((1700000000, 250, 1), (1600000123, 0, 0), (1751234567, 1015, 1)):
         assert M.edi_state_init(2, now, delay, tist, 37).tobytes() == E.init_state(2, now, delay, tist, 37).astype(M.EDI_STATE_DTYPE).tobytes()
+
+
+def test_edi_pft_fragments(M):
+    """SURVEY 8f N2 (PFT part): fragments through the C-ABI equal the golden vectors (reference Reed-Solomon + CRC code under
+    the restated PFT.cpp logic, tests/golden/make_golden_edi.py); Pseq carried across calls."""
+    import edilib as E
+    g = np.load(Path(__file__).resolve().parent / "golden" / "edi_pft_cases.npz")
+    for name, *_ in E.PFT_CASES:
+        af, af_len, pseq, kw = E.pft_case_inputs(name)
+        b = M.Batch([M.StreamConfig()] * af.shape[1])               # the PFT layer only needs the stream count
+        ps = pseq.copy()
+        frags, flen, nfrag = b.edi_pft(af, af_len, ps, **kw)
+        assert (nfrag == g[name + "_n"]).all() and (flen == g[name + "_len"]).all(), name
+        assert (frags[:2] == g[name + "_head"]).all(), name
+        assert E.pft_digest(frags, flen, nfrag) == bytes(g[name + "_sha"]).hex(), name
+        assert (ps == g[name + "_pseq"]).all(), name
+        half = af.shape[0] // 2
+        ps2 = pseq.copy()
+        f1, l1, n1 = b.edi_pft(af[:half], af_len[:half], ps2, **kw)
+        f2, l2, n2 = b.edi_pft(af[half:], af_len[half:], ps2, **kw)
+        assert (np.concatenate([f1, f2]) == frags).all() and (np.concatenate([n1, n2]) == nfrag).all() and (ps2 == ps).all(), name
+        b.close()

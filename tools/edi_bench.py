@@ -33,3 +33,23 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / N
 print(f"EDI AF packets: {S} streams x {F} frames in {dt * 1e3:.3f} ms = {S * F / dt / 1e6:.1f} M packets/s "
       f"({int(plen[0, 0])} B each, {S * F * int(plen[0, 0]) / dt / 1e9:.1f} GB/s written)")
+
+# PFT layer on the AF packets just built
+import ctypes as C
+for fec in (0, 2):
+    mf, fs = C.c_int(0), C.c_int(0)
+    assert L.tlb_edi_pft_shape(b.h, ps, fec, 207, 0, C.byref(mf), C.byref(fs)) == 0
+    frags = torch.zeros((F, S, mf.value, fs.value), dtype=torch.uint8, device=dev)
+    flen = torch.zeros((F, S, mf.value), dtype=torch.int32, device=dev)
+    nfr = torch.zeros((F, S), dtype=torch.int32, device=dev)
+    pseq = torch.zeros((S,), dtype=torch.int16, device=dev)
+    args = (b.h, pkts.data_ptr(), plen.data_ptr(), F, ps, pseq.data_ptr(), fec, 207, 0, 0, 0, frags.data_ptr(), flen.data_ptr(), nfr.data_ptr(), mf.value, fs.value, None)
+    for _ in range(3):
+        assert L.tlb_edi_pft_device(*args) == 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(N):
+        L.tlb_edi_pft_device(*args)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / N
+    print(f"EDI PFT fec={fec}: {S * F} AF packets -> {int(nfr[0, 0])} fragment(s) each in {dt * 1e3:.3f} ms = {S * F / dt / 1e6:.1f} M packets/s")
