@@ -114,6 +114,11 @@ int tlb_flush_device(tlb_batch *b, uint8_t *d_out, void *hip_stream);
 int tlb_set_gain_db(tlb_batch *b, int stream, double gain_db);
 int tlb_ingest_device(tlb_batch *b, const int16_t *d_interleaved, int nframes, int16_t *d_pcm, int16_t *d_peaks, void *hip_stream);
 int tlb_ingest_host(tlb_batch *b, const int16_t *interleaved, int nframes, int16_t *pcm, int16_t *peaks);
+/* The caller's silence accounting (src/odr-audioenc.cpp:1053-1079): per stream, a frame with both peaks 0 adds its duration
+ * in whole milliseconds (24 at 48 kHz, 36 at 32 kHz, 48 at 24 kHz) to d_silence_ms[stream], any other frame resets it to 0.
+ * The decision itself (`measured_silence_ms > 1000 * silence_timeout` -> stop the stream) stays with the caller. */
+int tlb_silence_device(tlb_batch *b, const int16_t *d_peaks, int nframes, uint32_t *d_silence_ms, void *hip_stream);
+int tlb_silence_host(tlb_batch *b, const int16_t *peaks, int nframes, uint32_t *silence_ms);
 
 /* Egress framing of the step after the path (ZeroMQ part): one ODR-DabMux ZMQ message per frame,
  * `struct zmq_frame_header_t` (src/Outputs.h:76-89: u16 version = 1, u16 encoder = ZMQ_ENCODER_MPEG_L2 = 2, u32 datasize,

@@ -94,6 +94,27 @@ __global__ void __launch_bounds__(256) tl_ingest_kernel(const int16_t *__restric
     }
 }
 
+// Silence accounting of the caller (src/odr-audioenc.cpp:1053-1079): a frame whose peaks are both 0
+// adds its duration (integer milliseconds, as the reference computes it) to the stream's counter, any other frame resets it.
+// One thread per stream, frames in order.
+__global__ void tl_silence_kernel(const int16_t *__restrict__ peaks, uint32_t *__restrict__ silence_ms, const TlConfig *configs,
+                                  const int32_t *stream_cfg, int nstreams, int nframes)
+{
+    const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (s >= nstreams) return;
+    const TlConfig &c = configs[stream_cfg[s]];
+    const long fs_hz[2][3] = {{22050, 24000, 16000}, {44100, 48000, 32000}};
+    const unsigned long rate = (unsigned long)fs_hz[c.version][c.fs_idx], nch = (unsigned long)c.nch;
+    const uint32_t frame_ms = (uint32_t)(1000ul * (1152ul * 2ul * nch) / (2ul * nch * rate));
+    uint32_t ms = silence_ms[s];
+    for (int f = 0; f < nframes; f++) {
+        const size_t slot = (size_t)f * (size_t)nstreams + (size_t)s;
+        const int pl = peaks[slot * 2], pr = peaks[slot * 2 + 1];
+        ms = (pl > pr ? pl : pr) == 0 ? ms + frame_ms : 0u;
+    }
+    silence_ms[s] = ms;
+}
+
 // ZeroMQ wire format of the step after the path (src/Outputs.h:76-99, Outputs.cpp:101-138):
 // packed header {u16 version=1, u16 encoder=2 (MPEG L2), u32 datasize, i16 level_left, i16 level_right} + frame bytes.
 // msgs [nslots][msg_stride]; one block per slot.
@@ -432,6 +453,34 @@ int tlb_ingest_host(tlb_batch *b, const int16_t *interleaved, int nframes, int16
     HIPCHK(hipMemcpy(pcm, d_out, slots * 2304 * 2, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(peaks, d_pk, slots * 2 * 2, hipMemcpyDeviceToHost));
     (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_pk);
+    return rc;
+}
+
+int tlb_silence_device(tlb_batch *b, const int16_t *d_peaks, int nframes, uint32_t *d_silence_ms, void *hip_stream)
+{
+    if (!b || !d_peaks || !d_silence_ms || nframes <= 0) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    hipLaunchKernelGGL(tl_silence_kernel, dim3((unsigned)((b->nstreams + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream,
+                       d_peaks, d_silence_ms, b->d_configs, b->d_stream_cfg, b->nstreams, nframes);
+    HIPCHK(hipGetLastError());
+    return TLB_OK;
+}
+
+int tlb_silence_host(tlb_batch *b, const int16_t *peaks, int nframes, uint32_t *silence_ms)
+{
+    if (!b || !peaks || !silence_ms || nframes <= 0) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    const size_t slots = (size_t)nframes * (size_t)b->nstreams;
+    int16_t *d_p = nullptr; uint32_t *d_m = nullptr;
+    HIPCHK(hipMalloc(&d_p, slots * 4));
+    HIPCHK(hipMalloc(&d_m, sizeof(uint32_t) * (size_t)b->nstreams));
+    HIPCHK(hipMemcpy(d_p, peaks, slots * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_m, silence_ms, sizeof(uint32_t) * (size_t)b->nstreams, hipMemcpyHostToDevice));
+    int rc = tlb_silence_device(b, d_p, nframes, d_m, nullptr);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(silence_ms, d_m, sizeof(uint32_t) * (size_t)b->nstreams, hipMemcpyDeviceToHost);
+    (void)hipFree(d_p); (void)hipFree(d_m);
+    if (e != hipSuccess) return TLB_ERR_HIP;
     return rc;
 }
 

@@ -1067,6 +1067,18 @@ void mp2o_ingest(const short *in, int nch, double gain_db, short out[2][1152], s
     else for (int i = 0; i < 1152; i++) { out[0][i] = buf[2 * i]; out[1][i] = buf[2 * i + 1]; }
 }
 
+/* silence accounting of AudioEnc::run() (src/odr-audioenc.cpp:1053-1079) for one frame of 1152 samples per channel:
+   returns the updated measured_silence_ms; the caller aborts when it exceeds 1000*silence_timeout. */
+unsigned mp2o_silence_ms(unsigned measured_silence_ms, const short peaks[2], int nch, long samplerate)
+{
+    const unsigned read_bytes = 1152u * 2u * (unsigned)nch;
+    if ((peaks[0] > peaks[1] ? peaks[0] : peaks[1]) == 0) {
+        const unsigned frame_time_msec = (unsigned)(1000ul * read_bytes / (2ul * (unsigned long)nch * (unsigned long)samplerate));
+        return measured_silence_ms + frame_time_msec;
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* integer-only PCM generator (mirrored in tests/pcmgen.py)                                    */
 static uint32_t mix32(uint32_t x)

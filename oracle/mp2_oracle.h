@@ -79,6 +79,7 @@ void mp2o_debug_set_p3_power0(double v);
 void mp2o_gen_pcm(uint32_t seed, int kind, int frame, short pcm[2][1152]);
 
 /* Caller-side glue (gain, positive peak, de-interleave): src/odr-audioenc.cpp:1030-1051,1139-1152. */
+unsigned mp2o_silence_ms(unsigned measured_silence_ms, const short peaks[2], int nch, long samplerate);
 void mp2o_ingest(const short *in, int nch, double gain_db, short out[2][1152], short peaks[2]);
 
 /* cpu_baseline helper: encode `nframes` frames of stream `seed` (kind 0) and return the number of

@@ -62,6 +62,8 @@ def lib():
         L.mp2o_fht1024.argtypes = [C.c_void_p]
         L.mp2o_filterbank_block.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.mp2o_ingest.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        L.mp2o_silence_ms.argtypes = [C.c_uint, C.c_void_p, C.c_int, C.c_long]
+        L.mp2o_silence_ms.restype = C.c_uint
         L.mp2o_bench_stream.argtypes = [C.c_long, C.c_char, C.c_int, C.c_int, C.c_uint32, C.c_int]
         L.mp2o_bench_stream.restype = C.c_long
         _lib = L

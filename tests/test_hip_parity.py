@@ -241,6 +241,19 @@ def test_ingest_gain_peak_deinterleave(M):
             assert np.array_equal(pcm[f, s], out), (f, s)
             assert np.array_equal(peaks[f, s], pk), (f, s)
     assert tuple(peaks[2, 2]) == (0, 0)
+    # silence accounting of the caller (odr-audioenc.cpp:1053-1079) on these peaks plus a silent tail, against the oracle
+    import ctypes as C
+    pk2 = np.concatenate([peaks, np.zeros((5, len(cfgs), 2), dtype=np.int16)])
+    pk2[5, 1] = (0, 3)                                     # one non-silent frame in the tail of stream 1 resets its counter
+    ms = np.array([7, 0, 100, 0], dtype=np.uint32)
+    want = ms.copy()
+    for f in range(pk2.shape[0]):
+        for s, c in enumerate(cfgs):
+            want[s] = L.mp2o_silence_ms(int(want[s]), np.ascontiguousarray(pk2[f, s]).ctypes.data, 1 if c.mode == "m" else 2, c.samplerate)
+    HL = M.load_library()
+    HL.tlb_silence_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    assert HL.tlb_silence_host(b.h, np.ascontiguousarray(pk2).ctypes.data, pk2.shape[0], ms.ctypes.data) == 0
+    assert np.array_equal(ms, want) and ms[2] == 24 * 6 and ms[1] == 24 * 2, (ms, want)
     got, _ = b.encode(pcm)
     tail = b.flush()
     for s, c in enumerate(cfgs):
