@@ -164,7 +164,7 @@ def main():
             "realtime_streams": round(value / (FS / 1152.0), 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": f"tl_encode_kernel<{args.psy}>", "kernel_ms": round(kernel_ms, 4), "last_kernel_ms_hip_events": round(last_ms, 4),
+                         "kernel": f"tl_encode_kernel<{2 if args.psy == 4 else args.psy}>", "kernel_ms": round(kernel_ms, 4), "last_kernel_ms_hip_events": round(last_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch,
                          "secondary_fp64": {"achieved_tflops": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 1e12, 3), "peak_tflops": 78.6,
                                             "frac": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 78.6e12, 5),

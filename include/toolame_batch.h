@@ -63,7 +63,8 @@ typedef struct {
     long samplerate;               /* 48000, 32000, 24000, 16000 */
     char mode;                     /* 's' stereo, 'j' joint stereo, 'd' dual channel, 'm' mono */
     int bitrate;                   /* kbps; 0 = the reference default (192 / 160) */
-    int psy_model;                 /* 0, 1, 2, 3 (toolame.c:202-210) */
+    int psy_model;                 /* 0, 1, 2, 3 (toolame.c:202-210); 4 = psycho_4.c, an extension of this API only: the
+                                      reference implements it (toolame.c:384-391) but its setter refuses it */
     int pad_len;                   /* toolame_set_pad(): upper bound of xpad_len, 0..TLB_MAX_XPAD */
 } tlb_stream_config;
 

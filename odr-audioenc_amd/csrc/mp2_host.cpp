@@ -202,6 +202,52 @@ void tl_build_psy2_tables(TlPsy2Tables *P, long samplerate)
     for (int j = 0; j < 513; j++) P->part_hi[partition[j]] = (int16_t)(j + 1);
 }
 
+void tl_build_psy4_tables(TlPsy2Tables *P, long samplerate)
+{   // psycho_4_init, psycho_4.c:330-413 (+ psycho_4_spreading_function :418-458), mapped onto the psy-2 table record: the
+    // per-frame code of psycho_4 (:123-327, non-NEWATAN build) performs the same operations as psycho_2's on these tables.
+    static const double minval[27] = {0.0, 20.0, 20.0, 20.0, 20.0, 20.0, 17.0, 15.0, 10.0, 7.0, 4.4, 4.5, 4.5, 4.5, 4.5, 4.5, 4.5, 4.5,
+                                      4.5, 4.5, 4.5, 4.5, 4.5, 4.5, 4.5, 4.5, 3.5};      // psycho_4.c:62-76
+    const double LN_TO_LOG10 = 0.2302585093;                      // common.h:30
+    memset(P, 0, sizeof *P);
+    const double sfreq = (double)samplerate;
+    for (int i = 0; i < 1024; i++) P->window[i] = 0.5 * (1 - cos(2.0 * kRefPi * (i - 0.5) / 1024));
+    double bark[513], cbval[64] = {0}, rnorm[64] = {0}, s[64][64];
+    int partition[513], numlines[64] = {0};
+    for (int i = 0; i < 513; i++) {
+        const double freq = i * sfreq / 1024;
+        bark[i] = freq2bark(freq);
+        P->absthr[i] = pow(10.0, (ath_db(freq, 0) + 0 /* glopts.athlevel, toolame.c:41 */ + 41.837375) * 0.1);   // ATH_energy, ath.c:49-66
+    }
+    int partition_count = 0, cbase = 0;
+    for (int i = 0; i < 513; i++) {
+        if ((bark[i] - bark[cbase]) > 0.33) { cbase = i; partition_count++; }
+        partition[i] = partition_count;
+        numlines[partition_count]++;
+    }
+    for (int i = 0; i < 513; i++) cbval[partition[i]] += bark[i];
+    for (int i = 0; i < 64; i++) cbval[i] = numlines[i] != 0 ? cbval[i] / numlines[i] : 0;
+    for (int i = 0; i < 64; i++)
+        for (int j = 0; j < 64; j++) {
+            double tempx = 1.05 * (cbval[i] - cbval[j]), x, tempy;
+            if (tempx >= 0.5 && tempx <= 2.5) { const double temp = tempx - 0.5; x = 8.0 * (temp * temp - 2.0 * temp); } else x = 0.0;
+            tempx += 0.474;
+            tempy = 15.811389 + 7.5 * tempx - 17.5 * sqrt(1.0 + tempx * tempx);
+            s[i][j] = tempy <= -60.0 ? 0.0 : exp((x + tempy) * LN_TO_LOG10);
+            rnorm[i] += s[i][j];
+        }
+    P->npart = partition_count + 1;
+    for (int j = 0; j < 64; j++) {
+        const double t1 = 15.5 + cbval[j];
+        P->tmn[j] = t1 > 24.5 ? t1 : 24.5;
+        P->bmaxk[j] = minval[(int)cbval[j]];
+        P->den[j] = (rnorm[j] && numlines[j]) ? rnorm[j] * numlines[j] : 0.0;
+        for (int k = 0; k < 64; k++) P->s_t[k][j] = s[j][k];
+        P->part_lo[j] = P->part_hi[j] = 0;
+    }
+    for (int j = 512; j >= 0; j--) { P->partition[j] = (uint8_t)partition[j]; P->part_lo[partition[j]] = (int16_t)j; }
+    for (int j = 0; j < 513; j++) P->part_hi[partition[j]] = (int16_t)(j + 1);
+}
+
 int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, int pad_len)
 {
     memset(C, 0, sizeof *C);
@@ -214,9 +260,11 @@ int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, 
     // (src/odr-audioenc.cpp:560-563 accepts 24000/48000 only) -- rejected by the device path.
     default: return TL_ERR_SAMPLERATE;
     }
-    if (psy < 0 || psy > 3) return TL_ERR_PSY;                   // toolame.c:204-207
+    // toolame.c:204-207 accepts 0..3; model 4 (psycho_4.c, unreachable through the reference's setter) is an extension of
+    // the batched API only -- the legacy toolame_set_psy_model() shim keeps rejecting it
+    if (psy < 0 || psy > 4) return TL_ERR_PSY;
     C->psy = psy;
-    C->psy2_tab = tl_psy2_slot(samplerate);
+    C->psy2_tab = tl_psy2_slot(samplerate) + (psy == 4 ? 4 : 0);   // slots 0..3: psy 2, 4..7: psy 4
     switch (mode) {                                               // toolame.c:174-200
     case 's': C->mode0 = 0; C->mode_ext0 = 0; break;
     case 'd': C->mode0 = 2; C->mode_ext0 = 0; break;

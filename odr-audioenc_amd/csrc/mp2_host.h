@@ -22,4 +22,5 @@ void tl_build_tables(TlTables *T);
 // psy-2 tables for a sample rate (48000/32000/24000/16000); returns the table slot 0..2 used as TlConfig::psy2_tab
 int tl_psy2_slot(long samplerate);
 void tl_build_psy2_tables(TlPsy2Tables *P, long samplerate);
+void tl_build_psy4_tables(TlPsy2Tables *P, long samplerate);   // psy model 4 mapped onto the psy-2 record
 int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, int pad_len);

@@ -277,20 +277,24 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
     HIPCHK(hipMemcpy(b->d_gain, b->h_gain.data(), sizeof(double) * (size_t)nstreams, hipMemcpyHostToDevice));
     for (int p = 0; p < 4; p++) {
         std::vector<int32_t> ids;
-        for (int s2 = 0; s2 < nstreams; s2++) if (b->h_configs[b->h_stream_cfg[s2]].psy == p) ids.push_back(s2);
+        // kernel p serves psy model p; model 4 runs the psy-2 kernel on its own tables (mp2_host.cpp: tl_build_psy4_tables)
+        for (int s2 = 0; s2 < nstreams; s2++) { const int m = b->h_configs[b->h_stream_cfg[s2]].psy; if ((m == 4 ? 2 : m) == p) ids.push_back(s2); }
         b->n_list[p] = (int)ids.size();
         if (ids.empty()) continue;
         HIPCHK(hipMalloc(&b->d_list[p], sizeof(int32_t) * ids.size()));
         HIPCHK(hipMemcpy(b->d_list[p], ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice));
     }
     bool any2 = false;
-    for (auto &c : b->h_configs) any2 |= c.psy == 2;
+    for (auto &c : b->h_configs) any2 |= c.psy == 2 || c.psy == 4;
     if (any2) {
         const long rates[4] = {48000, 32000, 24000, 16000};
-        std::vector<TlPsy2Tables> ht2(4);
-        for (int i = 0; i < 4; i++) tl_build_psy2_tables(&ht2[tl_psy2_slot(rates[i])], rates[i]);
-        HIPCHK(hipMalloc(&b->d_psy2_tables, sizeof(TlPsy2Tables) * 4));
-        HIPCHK(hipMemcpy(b->d_psy2_tables, ht2.data(), sizeof(TlPsy2Tables) * 4, hipMemcpyHostToDevice));
+        std::vector<TlPsy2Tables> ht2(8);                            // slots 0..3: psy 2 per rate, 4..7: psy 4 per rate
+        for (int i = 0; i < 4; i++) {
+            tl_build_psy2_tables(&ht2[tl_psy2_slot(rates[i])], rates[i]);
+            tl_build_psy4_tables(&ht2[4 + tl_psy2_slot(rates[i])], rates[i]);
+        }
+        HIPCHK(hipMalloc(&b->d_psy2_tables, sizeof(TlPsy2Tables) * 8));
+        HIPCHK(hipMemcpy(b->d_psy2_tables, ht2.data(), sizeof(TlPsy2Tables) * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMalloc(&b->d_psy2_state, sizeof(TlPsy2State) * (size_t)nstreams));
         HIPCHK(hipMemset(b->d_psy2_state, 0, sizeof(TlPsy2State) * (size_t)nstreams));
     }

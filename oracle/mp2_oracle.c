@@ -246,6 +246,8 @@ static void psy0_init(mp2o_enc *e)                /* psycho_0.c:36-50 */
 
 static void psy2_init(mp2o_enc *e);
 static void psy2_run(mp2o_enc *e, const short *pcm, int ch, double *smr);
+static void psy4_init(mp2o_enc *e);
+static void psy4_run(mp2o_enc *e, const short *pcm, int ch, double *smr);
 
 /* ------------------------------------------------------------------------------------------ */
 mp2o_enc *mp2o_create(long samplerate, char mode, int kbps, int psy, int pad_len)
@@ -263,7 +265,9 @@ mp2o_enc *mp2o_create(long samplerate, char mode, int kbps, int psy, int pad_len
     case 16000: e->version = 0; e->fs_idx = 2; break;
     default: free(e); return NULL;
     }
-    if (psy < 0 || psy > 3) { free(e); return NULL; }      /* toolame.c:202-210 */
+    /* toolame.c:202-210 accepts 0..3; 4 (psycho_4, reachable in the reference only by writing `model`) is kept for the
+       batched API's extension and its golden vectors */
+    if (psy < 0 || psy > 4) { free(e); return NULL; }
     e->psy = psy;
     /* toolame_set_channel_mode, toolame.c:174-200 */
     switch (mode) {
@@ -306,6 +310,7 @@ mp2o_enc *mp2o_create(long samplerate, char mode, int kbps, int psy, int pad_len
     psy3_init(e);
     psy0_init(e);
     if (psy == 2) psy2_init(e);
+    if (psy == 4) psy4_init(e);
     return e;
 }
 
@@ -903,6 +908,7 @@ int mp2o_encode_frame(mp2o_enc *e, const short pcm[2][1152], const unsigned char
     case 1: for (int ch = 0; ch < nch; ch++) psy1_run(e, pcm[ch], ch, T->max_sc[ch], T->smr[ch]); break;
     case 3: for (int ch = 0; ch < nch; ch++) psy3_run(e, pcm[ch], ch, T->max_sc[ch], T->smr[ch]); break;
     case 2: for (int ch = 0; ch < nch; ch++) psy2_run(e, pcm[ch], ch, T->smr[ch]); break;
+    case 4: for (int ch = 0; ch < nch; ch++) psy4_run(e, pcm[ch], ch, T->smr[ch]); break;        /* toolame.c:384-391 */
     }
 
     sf_pattern(e, T->scalar, T->scfsi);
@@ -1025,6 +1031,7 @@ static void psy2_init(mp2o_enc *e) { (void)e; }
 static void psy2_run(mp2o_enc *e, const short *pcm, int ch, double *smr)
 { (void)e; (void)pcm; (void)ch; for (int i = 0; i < 32; i++) smr[i] = 0; }
 #endif
+#include "mp2_oracle_psy4.inc"
 
 /* table taps for tests/test_oracle_golden.py::test_tables */
 int mp2o_get_table(const mp2o_enc *e, const char *name, double *out, int n)

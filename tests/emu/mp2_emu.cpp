@@ -40,11 +40,14 @@ void *emu_create(int nstreams, const long *fs, const char *mode, const int *kbps
         e->stream_cfg[s] = s;
     }
     bool any2 = false;
-    for (auto &c : e->configs) any2 |= c.psy == 2;
+    for (auto &c : e->configs) any2 |= c.psy == 2 || c.psy == 4;
     if (any2) {
         const long rates[4] = {48000, 32000, 24000, 16000};
-        e->psy2_tables.resize(4);
-        for (int i = 0; i < 4; i++) tl_build_psy2_tables(&e->psy2_tables[tl_psy2_slot(rates[i])], rates[i]);
+        e->psy2_tables.resize(8);
+        for (int i = 0; i < 4; i++) {
+            tl_build_psy2_tables(&e->psy2_tables[tl_psy2_slot(rates[i])], rates[i]);
+            tl_build_psy4_tables(&e->psy2_tables[4 + tl_psy2_slot(rates[i])], rates[i]);
+        }
         e->psy2_state.resize(nstreams);
         memset(e->psy2_state.data(), 0, sizeof(TlPsy2State) * nstreams);
     }
@@ -70,7 +73,7 @@ int emu_encode(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, co
         switch (e->configs[e->stream_cfg[s]].psy) {
         case 0: tl_encode_stream<0>(w, &e->tables.shared, A, s); break;
         case 1: tl_encode_stream<1>(w, &e->tables.shared, A, s); break;
-        case 2: tl_encode_stream<2>(w, &e->tables.shared, A, s); break;
+        case 2: case 4: tl_encode_stream<2>(w, &e->tables.shared, A, s); break;     // model 4: the psy-2 code on its own tables
         default: tl_encode_stream<3>(w, &e->tables.shared, A, s); break;
         }
     return 0;

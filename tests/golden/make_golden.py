@@ -34,11 +34,11 @@ CONFIGS = [  # (samplerate, mode, kbps)
 
 def cases():
     out = []
-    for psy in (0, 1, 2, 3):
+    for psy in (0, 1, 2, 3, 4):      # 4 = psycho_4, selected by writing the reference's `model` (see tests/oraclelib.py)
         for i, (fs, mode, kbps) in enumerate(CONFIGS):
             out.append(dict(name=f"p{psy}_{fs // 1000}k_{mode}_{kbps}_k0", samplerate=fs, mode=mode, kbps=kbps,
                             psy=psy, kind=0, seed=100 + i, pad_len=0))
-    for psy in (1, 2, 3):
+    for psy in (1, 2, 3, 4):
         for mode in ("s", "j"):
             for kind in range(1, 8):
                 if psy == 3 and kind in (1, 3):
@@ -98,6 +98,8 @@ def main():
     make_tables()
     total = 0
     for case in cases():
+        if "--only-missing" in sys.argv and (HERE / (case["name"] + ".npz")).exists():
+            continue
         pcm = gen_pcm(case["seed"], case["kind"], 0, NFRAMES)
         xp = xpads_for(case)
         ref = O.reference_stream(pcm, samplerate=case["samplerate"], mode=case["mode"], kbps=case["kbps"],

@@ -156,9 +156,11 @@ L.toolame_set_samplerate.argtypes = [C.c_long]
 L.toolame_set_channel_mode.argtypes = [C.c_char]
 L.toolame_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
 L.toolame_finish.argtypes = [C.c_void_p, C.c_size_t]
-rc = [L.toolame_init(), L.toolame_set_samplerate(cfg['samplerate']), L.toolame_set_psy_model(cfg['psy']),
+rc = [L.toolame_init(), L.toolame_set_samplerate(cfg['samplerate']), L.toolame_set_psy_model(min(cfg['psy'], 3)),
       L.toolame_set_channel_mode(cfg['mode'].encode()[0:1]), L.toolame_set_bitrate(cfg['kbps']),
       L.toolame_set_pad(cfg['pad_len'])]
+if cfg['psy'] > 3:   # the setter refuses model 4 (toolame.c:204-207); the file-scope `model` is exposed by oracle/Makefile
+    C.c_int.in_dll(L, 'tlref_model').value = cfg['psy']
 def tap(name, ctype, shape, deref=False):
     n = int(np.prod(shape))
     if deref:

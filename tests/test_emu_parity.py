@@ -95,6 +95,6 @@ def test_emulated_log10_pow10_accuracy():
 
 
 def test_emulated_illegal_configs():
-    for kw in (dict(samplerate=44100), dict(kbps=100), dict(mode="x"), dict(psy=5), dict(psy=4), dict(pad_len=-1), dict(pad_len=999)):
+    for kw in (dict(samplerate=44100), dict(kbps=100), dict(mode="x"), dict(psy=5), dict(psy=-1), dict(pad_len=-1), dict(pad_len=999)):
         with pytest.raises(ValueError):
             E.EmuBatch([kw])

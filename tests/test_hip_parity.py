@@ -141,7 +141,7 @@ def test_configuration_sweep_vs_oracle(M):
     n = 0
     for fs, lst in rates.items():
         for mode, kbps in lst:
-            for psy in (0, 1, 2, 3):
+            for psy in (0, 1, 2, 3, 4):
                 kind = (0, 3, 5, 7)[n % 4] if psy != 3 else (0, 5)[n % 2]      # psy 3 + silence-like kinds crash the reference
                 pcm = gen_pcm(31 + n, kind, 0, nframes)
                 n += 1
@@ -152,7 +152,7 @@ def test_configuration_sweep_vs_oracle(M):
                 cfgs.append(M.StreamConfig(samplerate=fs, mode=mode, bitrate=kbps, psy_model=psy))
                 pcms.append(pcm)
                 refs.append(ref)
-    assert len(cfgs) > 120
+    assert len(cfgs) > 150
     b = M.Batch(cfgs)
     got, _ = b.encode(np.stack(pcms, axis=1))
     tail = b.flush()
