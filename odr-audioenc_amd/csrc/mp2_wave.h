@@ -523,8 +523,10 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     //     matters: the last confirmed tone (`last`), its erasure reach R = last + run(last), and the
     //     chain bookkeeping (last_but_one relinking, psycho_1.c:313-316).
     int nconf = 0;
+    bool any_erased;                                                  // a confirmed tone erased its predecessor: the chain order is not 0..nconf-1
     {
         int last = -1, run_last = 0, R = -1, last_var = 0;
+        any_erased = false;
         for (int kb = 0; kb < ncand; kb += 64) {                        // 64 records per LDS round trip, then lane reads
         PV(int, crec);
         TL_LANES_BEGIN L(crec) = (int)w.cinfo[kb + lane < TL_CAND_MAX ? kb + lane : 0]; TL_LANES_END
@@ -558,6 +560,7 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
                 w.conf_nxt[i] = TL_LAST;
                 if (i > 0) {
                     if (c - last <= run) {                            // erases the previous tone, psycho_1.c:313-316,322-326
+                        any_erased = true;
                         w.conf_nxt[i - 1] = TL_STOP;
                         w.conf_c[i - 1] = (int16_t)(w.conf_c[i - 1] | (1 << 13));
                         if (i >= 2) w.conf_nxt[i - 2] = (int16_t)i;
@@ -589,7 +592,12 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     // (5) the tone list in chain order (psycho_1.c list head `*tone`): walk the links, then decimate
     //     in parallel (psycho_1.c:416-428): drop erased tones and tones below the threshold in quiet
     int nlist = 0;
-    {
+    if (!any_erased) {                                                // every link points to the next tone: the chain is 0..nconf-1
+        nlist = nconf;
+        TL_LANES_BEGIN
+        for (int i = lane; i < nconf; i += 64) w.tlist[i] = (int16_t)i;
+        TL_LANES_END
+    } else {
         PV(int, nx0); PV(int, nx1);                                   // the links in registers: the walk reads lanes, not LDS
         TL_LANES_BEGIN L(nx0) = w.conf_nxt[lane]; L(nx1) = w.conf_nxt[64 + lane < TL_TONE_MAX ? 64 + lane : 0]; TL_LANES_END
         int i = nconf ? 0 : TL_LAST, guard = 0;
