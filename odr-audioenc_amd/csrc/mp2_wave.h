@@ -681,10 +681,6 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         w.nsum[lane] = sum; w.ncentre[lane] = (int16_t)centre;
     }
     TL_LANES_END
-    // every non-tonal line inside the bands is consumed (set to DBMIN) by its band, psycho_1.c:363
-    TL_LANES_BEGIN
-    for (int j = C->p1_cbound[0] + lane; j < C->p1_cbound[nbands]; j += 64) if (w.ptype[j] != TL_T_TONE) w.px[j] = TL_DBMIN;
-    TL_LANES_END
     // The reference keeps tones and noise components in ONE linked list field (power[].next).  The two
     // chains only interact when the head of the tone chain is a tone that was erased by its successor
     // (psycho_1.c:313-316 with last_but_one == LAST): its line is no longer TONE, so a noise centre may
@@ -695,6 +691,10 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     const uint8_t *map = C->p1_map;
     int ntone = 0, nnoise = 0;
     if (dead_head) {
+        // every non-tonal line inside the bands is consumed (set to DBMIN) by its band, psycho_1.c:363 (the replay reads power[])
+        TL_LANES_BEGIN
+        for (int j = C->p1_cbound[0] + lane; j < C->p1_cbound[nbands]; j += 64) if (w.ptype[j] != TL_T_TONE) w.px[j] = TL_DBMIN;
+        TL_LANES_END
         TL_DBG_DUMP("deadhead", ch, 0, 0, w.px, w.px);
         int16_t *pnext = (int16_t *)w.cinfo;                // candidate records are dead by now
         TL_LANES_BEGIN
@@ -759,33 +759,49 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         }
         TL_SYNC();
     } else {
-    // band order: a later band overwrites an earlier one that chose the same line (psycho_1.c:390-398).  Which bands are
-    // overwritten is settled from registers (lane reads, no LDS round trips); the survivors then write side by side.
-    {
-        PV(int, ncen); PV(bool, over);
-        TL_LANES_BEGIN L(ncen) = lane < nbands ? (int)w.ncentre[lane] : -1 - lane; L(over) = false; TL_LANES_END
-        for (int b = 1; b < nbands; b++) {
-            const int cb = TL_READLANE_I32(ncen, b);
-            TL_LANES_BEGIN if (lane < b && L(ncen) == cb) L(over) = true; TL_LANES_END
-        }
-        TL_LANES_BEGIN
-        if (lane < nbands) { if (!L(over)) w.px[L(ncen)] = w.nsum[lane]; w.ptype[L(ncen)] = TL_T_NOISE; }
-        TL_LANES_END
+    // The reference now writes every band's sum to power[centre] in band order -- a later band overwrites an earlier one
+    // that chose the same line, and (through the centre+1 rule above) a centre may even land on a tone's line
+    // (psycho_1.c:390-398) -- and the decimation reads the levels back from power[].  The same values without the array:
+    // a band's level is the sum of the LAST band with its centre, a tone's level is its own unless a band centre sits on
+    // its line.  (Lane reads, no LDS round trips.)
+    PV(int, ncen); PV(double, nlev); PV(int, nsh); PV(int, nsl); PV(bool, ontone);
+    TL_LANES_BEGIN
+    L(ncen) = lane < nbands ? (int)w.ncentre[lane] : -1 - lane;
+    const double v = lane < nbands ? w.nsum[lane] : 0.0;
+    L(nlev) = v; L(nsh) = (int)(uint32_t)(tl_d2u(v) >> 32); L(nsl) = (int)(uint32_t)tl_d2u(v);
+    L(ontone) = lane < nbands && w.ptype[L(ncen)] == TL_T_TONE;
+    TL_LANES_END
+    const bool centre_on_tone = TL_BALLOT(ontone) != 0ull;            // only then can a tone's level be replaced (rare)
+    for (int b = 1; b < nbands; b++) {
+        const int cb = TL_READLANE_I32(ncen, b);
+        const double vb = tl_u2d(((uint64_t)(uint32_t)TL_READLANE_I32(nsh, b) << 32) | (uint32_t)TL_READLANE_I32(nsl, b));
+        TL_LANES_BEGIN if (lane < b && L(ncen) == cb) L(nlev) = vb; TL_LANES_END
     }
 
     // ---- decimation (psycho_1.c:409-470) ----
     {
         // tones: keep if not erased and not below the threshold in quiet (order preserved)
         for (int base = 0; base < nlist; base += 64) {
-            PV(bool, keep); PV(double, kx); PV(double, kb);
+            PV(bool, keep); PV(double, kx); PV(double, kb); PV(int, tline);
             TL_LANES_BEGIN
-            bool kp = false; double x = 0, bk = 0;
+            double x = 0; int c = -1000 - lane;
+            if (base + lane < nlist) { const int ti = w.tlist[base + lane]; c = w.conf_c[ti] & 511; x = w.tone_x[ti]; }
+            L(kx) = x; L(tline) = c;
+            TL_LANES_END
+            if (centre_on_tone)
+                for (int b = 0; b < nbands; b++) {                  // a band centre on the tone's line replaces its level
+                    const int cb = TL_READLANE_I32(ncen, b);
+                    const double vb = tl_u2d(((uint64_t)(uint32_t)TL_READLANE_I32(nsh, b) << 32) | (uint32_t)TL_READLANE_I32(nsl, b));
+                    TL_LANES_BEGIN if (L(tline) == cb) L(kx) = vb; TL_LANES_END
+                }
+            TL_LANES_BEGIN
+            bool kp = false; double bk = 0;
             if (base + lane < nlist) {
                 const int cc = w.conf_c[w.tlist[base + lane]], c = cc & 511;
-                x = w.px[c]; bk = C->p1_lbark[c];
-                kp = !((cc >> 13) & 1) && !(x < C->p1_lhear[c]);
+                bk = C->p1_lbark[c];
+                kp = !((cc >> 13) & 1) && !(L(kx) < C->p1_lhear[c]);
             }
-            L(keep) = kp; L(kx) = x; L(kb) = bk;
+            L(keep) = kp; L(kb) = bk;
             TL_LANES_END
             const uint64_t m = TL_BALLOT(keep);
             TL_LANES_BEGIN
@@ -825,8 +841,8 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         TL_LANES_BEGIN
         bool kp = false; double x = 0, bk = 0;
         if (lane < nbands) {
-            const int c = w.ncentre[lane];
-            x = w.px[c]; bk = C->p1_lbark[c];
+            const int c = L(ncen);
+            x = L(nlev); bk = C->p1_lbark[c];
             kp = !(x < C->p1_lhear[c]);
         }
         L(keepn) = kp; L(nx) = x; L(nb) = bk;
