@@ -482,9 +482,17 @@ TL_FN void tl_cand_chunk(TlWaveLds &w, int c8, int &ncand)
     ncand += __builtin_popcountll(m);
 }
 
-// psy model 1 (psycho_1.c:22-87, :215-581) for channel `ch`; result in w.smr[ch][0..sblimit).
-TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
-                   const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
+// psy model 1 (psycho_1.c:22-87, :215-581); result in w.smr[ch][0..sblimit).
+//
+// Per channel the model is a FRONT (spectrum, power, tone labelling, compaction of the lines each critical band sums),
+// the per-band dB-sum CHAINS (sequential by definition: up to 164 dependent table look-ups in the widest band, on 27
+// lanes) and a BACK (band centres, decimation, thresholds, SMR).  For two channels the chains of both run side by side
+// on the two halves of the wave (tl_psy1_stereo): channel 0's front results wait in registers while channel 1's front
+// uses the LDS arrays.
+struct TlPsy1Ch { int nconf, nlist; bool dead_head; };
+
+TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+                             const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
 {
     const double *energy = w.u.fft;
     const double *db = B->dbtable;
@@ -653,13 +661,51 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         w.bandoff[nbands] = (int16_t)nvalid;
         TL_SYNC();
     }
-    // one lane per critical band: the dB-sum chain and the weight sum, both in ascending line order
+    TlPsy1Ch r;
+    r.nconf = nconf; r.nlist = nlist;
+    // The reference keeps tones and noise components in ONE linked list field (power[].next).  The two chains only interact
+    // when the head of the tone chain is a tone that was erased by its successor (psycho_1.c:313-316 with last_but_one ==
+    // LAST): its line is no longer TONE, so a noise centre may land on it and splice the noise chain into the tone chain.
+    // That (rare) case is replayed pointer by pointer (tl_psy1_deadhead); otherwise the chains are independent.
+    r.dead_head = nconf > 0 && ((w.conf_c[0] >> 13) & 1);
+    return r;
+}
+
+// weight sums of the bands (psycho_1.c:364-366), ascending line order; lane b < nbands owns band b.  Only used where the
+// weights cannot ride along with the dB-sum chain (channel 0 of a stereo frame, whose terms leave LDS before its chain runs).
+TL_FN void tl_psy1_weights(TlWaveLds &w, int nbands, PARG(double, wt))
+{
     TL_LANES_BEGIN
+    double weight = 0.0;
+    if (lane < nbands) {
+        const double *vt = w.u.fft;
+        const int i0 = w.bandoff[lane], i1 = w.bandoff[lane + 1];
+        int i = i0;
+        for (; i + 16 <= i1; i += 16) {                             // sixteen operands per LDS round trip, summed in order
+            double t[16];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 16; q++) t[q] = vt[i + q];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 16; q++) weight += t[q];
+        }
+        for (; i < i1; i++) weight += vt[i];
+    }
+    L(wt) = weight;
+    TL_LANES_END
+}
+
+// dB sums and weight sums of the bands of ONE channel (levels at fft+520, weight terms at fft): lane b < nbands
+TL_FN void tl_psy1_chain(TlWaveLds &w, const double *TL_RESTRICT db, int nbands, PARG(double, bsum), PARG(double, wt))
+{
+    TL_LANES_BEGIN
+    double sum = TL_DBMIN, weight = 0.0;
     if (lane < nbands) {
         const double *vt = w.u.fft, *vp = w.u.fft + 520;
-        const int lo = C->p1_cbound[lane], hi = C->p1_cbound[lane + 1];
         const int i0 = w.bandoff[lane], i1 = w.bandoff[lane + 1];
-        double weight = 0.0, sum = TL_DBMIN;
         int i = i0;
         for (; i + 4 <= i1; i += 4) {                               // operands of four steps in flight per LDS round trip
             const double p0 = vp[i], p1 = vp[i + 1], p2 = vp[i + 2], p3 = vp[i + 3];
@@ -670,6 +716,46 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
             sum = tl_add_db(db, p3, sum); weight += t3;
         }
         for (; i < i1; i++) { sum = tl_add_db(db, vp[i], sum); weight += vt[i]; }
+    }
+    L(bsum) = sum; L(wt) = weight;
+    TL_LANES_END
+}
+
+// dB sums of BOTH channels at once: lanes 0..31 walk channel 0's bands (levels parked in px[], ranges in r0/r1), lanes 32..63
+// channel 1's (levels at fft+520, weight terms at fft, ranges from bandoff[]).  Result: lane b holds channel 0's sum, lane
+// 32+b channel 1's sum and weight (wt2; lanes < 32 get 0).
+TL_FN void tl_psy1_chain2(TlWaveLds &w, const double *TL_RESTRICT db, int nbands, PARG(int, r0), PARG(int, r1), PARG(double, bsum), PARG(double, wt2))
+{
+    TL_LANES_BEGIN
+    double sum = TL_DBMIN, weight = 0.0;
+    const int band = lane & 31;
+    if (band < nbands) {
+        const bool second = lane >= 32;
+        const double *vp = second ? w.u.fft + 520 : w.px;
+        const double *vt = w.u.fft;
+        const int i0 = second ? (int)w.bandoff[band] : L(r0), i1 = second ? (int)w.bandoff[band + 1] : L(r1);
+        int i = i0;
+        for (; i + 4 <= i1; i += 4) {
+            const double p0 = vp[i], p1 = vp[i + 1], p2 = vp[i + 2], p3 = vp[i + 3];
+            const double t0 = vt[i], t1 = vt[i + 1], t2 = vt[i + 2], t3 = vt[i + 3];   // channel 1's terms; lanes < 32 ignore their sum
+            sum = tl_add_db(db, p0, sum); weight += t0;
+            sum = tl_add_db(db, p1, sum); weight += t1;
+            sum = tl_add_db(db, p2, sum); weight += t2;
+            sum = tl_add_db(db, p3, sum); weight += t3;
+        }
+        for (; i < i1; i++) { sum = tl_add_db(db, vp[i], sum); weight += vt[i]; }
+    }
+    L(bsum) = sum; L(wt2) = lane >= 32 ? weight : 0.0;
+    TL_LANES_END
+}
+
+// band centres (psycho_1.c:367-388) from the sums and weights of lanes b < nbands; needs ptype[] of the channel
+TL_FN void tl_psy1_centres(TlWaveLds &w, const TlConfig *TL_RESTRICT C, int nbands, PARG(double, bsum), PARG(double, wt))
+{
+    TL_LANES_BEGIN
+    if (lane < nbands) {
+        const int lo = C->p1_cbound[lane], hi = C->p1_cbound[lane + 1];
+        const double sum = L(bsum), weight = L(wt);
         int centre;
         if (sum <= TL_DBMIN) centre = (hi + lo) / 2;
         else {
@@ -681,84 +767,83 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         w.nsum[lane] = sum; w.ncentre[lane] = (int16_t)centre;
     }
     TL_LANES_END
-    // The reference keeps tones and noise components in ONE linked list field (power[].next).  The two
-    // chains only interact when the head of the tone chain is a tone that was erased by its successor
-    // (psycho_1.c:313-316 with last_but_one == LAST): its line is no longer TONE, so a noise centre may
-    // land on it and splice the noise chain into the tone chain.  That (rare) case is replayed pointer by
-    // pointer below; otherwise the chains are independent and are processed in parallel.
-    TL_STAMP(sp, 4);
-    const bool dead_head = nconf > 0 && ((w.conf_c[0] >> 13) & 1);
-    const uint8_t *map = C->p1_map;
+}
+
+// individual + global masking thresholds, minimum per subband, SMR (psycho_1.c:480-581) from the masker lists
+TL_FN void tl_psy1_thresholds(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const TlConfig *TL_RESTRICT C, int ch, int ntone, int nnoise, long long *sp)
+{
+    const double *db = B->dbtable;
+    TL_STAMP(sp, 5);
+
+    TL_DBG_DUMP("psy1", ch, ntone, nnoise, TL_MK_X(w), TL_MK_BARK(w));
+    // ---- individual + global masking thresholds on the table lines (psycho_1.c:480-532) ----
+    const int sub = C->p1_sub;
+    TL_LANES_BEGIN
+    for (int t = lane; t < ntone + nnoise; t += 64) tl_masker_consts(TL_MK4(w), TL_MK_X(w), TL_MK_BARK(w), t, t < ntone);
+    TL_LANES_END
+    // Each lane folds the maskers into two ADJACENT table lines at once (two independent dB-sum chains).  A masker only
+    // reaches lines with -3 <= dz < 8 bark, so a lane first finds the first and last masker (tones, then noise, in list
+    // order) that reaches either of its lines and walks only that span; the per-line range test stays in the walk, so
+    // nothing depends on the lists being sorted.
+    for (int base = 1; base < sub; base += 128) {       // 126..132 lines: one full pass + a 4-line tail at most
+        TL_LANES_BEGIN
+        const int k0 = base + 2 * lane, k1 = k0 + 1;
+        const bool h0 = k0 < sub, h1 = k1 < sub;
+        if (h0) {
+            const double bk0 = C->p1_bark[k0], bk1 = C->p1_bark[h1 ? k1 : k0];
+            const double blo = (bk0 < bk1 ? bk0 : bk1) - 8.0, bhi = (bk0 < bk1 ? bk1 : bk0) + 3.0;
+            const TlMasker *mk = TL_MK4(w);
+            const int nm = ntone + nnoise;
+            int a0 = nm, a1 = -1, b0 = nm, b1 = -1;                 // spans inside the tone part and inside the noise part
+            for (int t = 0; t < nm; t++) {
+                const double mb = mk[t].bark;
+                const bool r = mb > blo && mb <= bhi;               // superset of both lines' (-3 <= dz < 8)
+                const bool rt = r && t < ntone, rn = r && t >= ntone;
+                a0 = (rt && t < a0) ? t : a0; a1 = rt ? t : a1;
+                b0 = (rn && t < b0) ? t : b0; b1 = rn ? t : b1;
+            }
+            double x0 = TL_DBMIN, x1 = TL_DBMIN;
+            for (int part = 0; part < 2; part++) {
+                const int t_first = part ? b0 : a0, t_last = part ? b1 : a1;
+                for (int t = t_first; t <= t_last; t++) {
+                    const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
+                    const double dz0 = bk0 - mb, dz1 = bk1 - mb;
+                    const double n0 = tl_add_db(db, x0, av + tl_mask_vf(dz0, g, ns));
+                    const double n1 = tl_add_db(db, x1, av + tl_mask_vf(dz1, g, ns));
+                    x0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : x0;
+                    x1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : x1;
+                }
+            }
+            TL_LTG(w)[k0] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k0] : C->p1_hear[k0] - 12.0, x0);
+            if (h1) TL_LTG(w)[k1] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k1] : C->p1_hear[k1] - 12.0, x1);
+        }
+        TL_LANES_END
+    }
+    TL_STAMP(sp, 6);
+
+    // ---- minimum per subband (psycho_1.c:541-559) and SMR (psycho_1.c:568-581) ----
+    TL_LANES_BEGIN
+    if (lane < C->sblimit) {
+        double m;
+        int n = C->p1_mm_n[lane], j0 = C->p1_mm_j0[lane];
+        if (n == 0) m = C->p1_hear[sub - 1];
+        else {
+            m = TL_LTG(w)[j0];
+            for (int j = j0 + 1; j < j0 + n; j++) if (m > TL_LTG(w)[j]) m = TL_LTG(w)[j];
+        }
+        double max = C->scale_db[w.minidx[ch][lane]];
+        if (w.spike[lane] > max) max = w.spike[lane];
+        w.smr[ch][lane] = max - m;
+    }
+    TL_LANES_END
+}
+
+// band levels, decimation (psycho_1.c:390-470) and everything after; the regular (not dead-head) case
+TL_FN void tl_psy1_back(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, long long *sp)
+{
+    const int nbands = C->p1_ncb - 1, nlist = st.nlist;
     int ntone = 0, nnoise = 0;
-    if (dead_head) {
-        // every non-tonal line inside the bands is consumed (set to DBMIN) by its band, psycho_1.c:363 (the replay reads power[])
-        TL_LANES_BEGIN
-        for (int j = C->p1_cbound[0] + lane; j < C->p1_cbound[nbands]; j += 64) if (w.ptype[j] != TL_T_TONE) w.px[j] = TL_DBMIN;
-        TL_LANES_END
-        TL_DBG_DUMP("deadhead", ch, 0, 0, w.px, w.px);
-        int16_t *pnext = (int16_t *)w.cinfo;                // candidate records are dead by now
-        TL_LANES_BEGIN
-        for (int i = lane; i < 512; i += 64) pnext[i] = TL_STOP;
-        TL_LANES_END
-        TL_LANES_BEGIN
-        for (int i = lane; i < nconf; i += 64) {
-            const int nx = w.conf_nxt[i];
-            pnext[w.conf_c[i] & 511] = (int16_t)(nx >= 0 ? (w.conf_c[nx] & 511) : nx);
-        }
-        TL_LANES_END
-        int tone = w.conf_c[0] & 511, noise = 0;
-        {   // noise chain in band order (psycho_1.c:390-398)
-            int last = TL_LAST;
-            for (int i = 0; i < nbands; i++) {
-                const int centre = w.ncentre[i];
-                if (last == TL_LAST) noise = centre;
-                else { pnext[centre] = TL_LAST; pnext[last] = (int16_t)centre; }
-                w.px[centre] = w.nsum[i]; w.ptype[centre] = TL_T_NOISE; last = centre;
-            }
-        }
-        {   // psycho_1.c:409-470 verbatim on the shared links
-            int i = tone, old = TL_STOP, guard = 0;
-            while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
-                if (w.px[i] < C->p1_hear[map[i]]) {
-                    w.ptype[i] = 0; w.px[i] = TL_DBMIN;
-                    if (old == TL_STOP) tone = pnext[i]; else pnext[old] = pnext[i];
-                } else old = i;
-                i = pnext[i];
-            }
-            i = noise; old = TL_STOP; guard = 0;
-            while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
-                if (w.px[i] < C->p1_hear[map[i]]) {
-                    w.ptype[i] = 0; w.px[i] = TL_DBMIN;
-                    if (old == TL_STOP) noise = pnext[i]; else pnext[old] = pnext[i];
-                } else old = i;
-                i = pnext[i];
-            }
-            i = tone; old = TL_STOP; guard = 0;
-            while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
-                const int nx = pnext[i];
-                if (nx == TL_LAST) break;
-                if (nx == TL_STOP) break;                     // (the reference would index power[-100]; never reached in practice)
-                if (C->p1_bark[map[nx]] - C->p1_bark[map[i]] < 0.5) {
-                    if (w.px[nx] > w.px[i]) {
-                        if (old == TL_STOP) tone = nx; else pnext[old] = (int16_t)nx;
-                        w.ptype[i] = 0; w.px[i] = TL_DBMIN; i = nx;
-                    } else {
-                        w.ptype[nx] = 0; w.px[nx] = TL_DBMIN;
-                        pnext[i] = pnext[nx]; old = i;
-                    }
-                } else { old = i; i = nx; }
-            }
-            guard = 0;
-            for (int t = tone; t != TL_LAST && t != TL_STOP && ntone < TL_MASKER_MAX - 32 && guard++ < 600; t = pnext[t]) {
-                TL_MK_X(w)[ntone] = w.px[t]; TL_MK_BARK(w)[ntone] = C->p1_bark[map[t]]; ntone++;
-            }
-            guard = 0;
-            for (int t = noise; t != TL_LAST && t != TL_STOP && ntone + nnoise < TL_MASKER_MAX && guard++ < 600; t = pnext[t]) {
-                TL_MK_X(w)[ntone + nnoise] = w.px[t]; TL_MK_BARK(w)[ntone + nnoise] = C->p1_bark[map[t]]; nnoise++;
-            }
-        }
-        TL_SYNC();
-    } else {
+    TL_STAMP(sp, 4);
     // The reference now writes every band's sum to power[centre] in band order -- a later band overwrites an earlier one
     // that chose the same line, and (through the centre+1 rule above) a centre may even land on a tone's line
     // (psycho_1.c:390-398) -- and the decimation reads the levels back from power[].  The same values without the array:
@@ -856,70 +941,195 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         TL_LANES_END
         nnoise = __builtin_popcountll(mn);
     }
-    }
-    TL_STAMP(sp, 5);
+    tl_psy1_thresholds(w, B, C, ch, ntone, nnoise, sp);
+}
 
-    TL_DBG_DUMP("psy1", ch, ntone, nnoise, TL_MK_X(w), TL_MK_BARK(w));
-    // ---- individual + global masking thresholds on the table lines (psycho_1.c:480-532) ----
-    const int sub = C->p1_sub;
-    TL_LANES_BEGIN
-    for (int t = lane; t < ntone + nnoise; t += 64) tl_masker_consts(TL_MK4(w), TL_MK_X(w), TL_MK_BARK(w), t, t < ntone);
-    TL_LANES_END
-    // Each lane folds the maskers into two ADJACENT table lines at once (two independent dB-sum chains).  A masker only
-    // reaches lines with -3 <= dz < 8 bark, so a lane first finds the first and last masker (tones, then noise, in list
-    // order) that reaches either of its lines and walks only that span; the per-line range test stays in the walk, so
-    // nothing depends on the lists being sorted.
-    for (int base = 1; base < sub; base += 128) {       // 126..132 lines: one full pass + a 4-line tail at most
+// the dead-head replay (see tl_psy1_front): works on power[] (px) and the shared links like the reference
+TL_FN void tl_psy1_deadhead(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, long long *sp)
+{
+    const int nbands = C->p1_ncb - 1, nconf = st.nconf;
+    const uint8_t *map = C->p1_map;
+    int ntone = 0, nnoise = 0;
+    TL_STAMP(sp, 4);
+    {
+        // every non-tonal line inside the bands is consumed (set to DBMIN) by its band, psycho_1.c:363 (the replay reads power[])
         TL_LANES_BEGIN
-        const int k0 = base + 2 * lane, k1 = k0 + 1;
-        const bool h0 = k0 < sub, h1 = k1 < sub;
-        if (h0) {
-            const double bk0 = C->p1_bark[k0], bk1 = C->p1_bark[h1 ? k1 : k0];
-            const double blo = (bk0 < bk1 ? bk0 : bk1) - 8.0, bhi = (bk0 < bk1 ? bk1 : bk0) + 3.0;
-            const TlMasker *mk = TL_MK4(w);
-            const int nm = ntone + nnoise;
-            int a0 = nm, a1 = -1, b0 = nm, b1 = -1;                 // spans inside the tone part and inside the noise part
-            for (int t = 0; t < nm; t++) {
-                const double mb = mk[t].bark;
-                const bool r = mb > blo && mb <= bhi;               // superset of both lines' (-3 <= dz < 8)
-                const bool rt = r && t < ntone, rn = r && t >= ntone;
-                a0 = (rt && t < a0) ? t : a0; a1 = rt ? t : a1;
-                b0 = (rn && t < b0) ? t : b0; b1 = rn ? t : b1;
-            }
-            double x0 = TL_DBMIN, x1 = TL_DBMIN;
-            for (int part = 0; part < 2; part++) {
-                const int t_first = part ? b0 : a0, t_last = part ? b1 : a1;
-                for (int t = t_first; t <= t_last; t++) {
-                    const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
-                    const double dz0 = bk0 - mb, dz1 = bk1 - mb;
-                    const double n0 = tl_add_db(db, x0, av + tl_mask_vf(dz0, g, ns));
-                    const double n1 = tl_add_db(db, x1, av + tl_mask_vf(dz1, g, ns));
-                    x0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : x0;
-                    x1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : x1;
-                }
-            }
-            TL_LTG(w)[k0] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k0] : C->p1_hear[k0] - 12.0, x0);
-            if (h1) TL_LTG(w)[k1] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k1] : C->p1_hear[k1] - 12.0, x1);
+        for (int j = C->p1_cbound[0] + lane; j < C->p1_cbound[nbands]; j += 64) if (w.ptype[j] != TL_T_TONE) w.px[j] = TL_DBMIN;
+        TL_LANES_END
+        TL_DBG_DUMP("deadhead", ch, 0, 0, w.px, w.px);
+        int16_t *pnext = (int16_t *)w.cinfo;                // candidate records are dead by now
+        TL_LANES_BEGIN
+        for (int i = lane; i < 512; i += 64) pnext[i] = TL_STOP;
+        TL_LANES_END
+        TL_LANES_BEGIN
+        for (int i = lane; i < nconf; i += 64) {
+            const int nx = w.conf_nxt[i];
+            pnext[w.conf_c[i] & 511] = (int16_t)(nx >= 0 ? (w.conf_c[nx] & 511) : nx);
         }
         TL_LANES_END
-    }
-    TL_STAMP(sp, 6);
-
-    // ---- minimum per subband (psycho_1.c:541-559) and SMR (psycho_1.c:568-581) ----
-    TL_LANES_BEGIN
-    if (lane < C->sblimit) {
-        double m;
-        int n = C->p1_mm_n[lane], j0 = C->p1_mm_j0[lane];
-        if (n == 0) m = C->p1_hear[sub - 1];
-        else {
-            m = TL_LTG(w)[j0];
-            for (int j = j0 + 1; j < j0 + n; j++) if (m > TL_LTG(w)[j]) m = TL_LTG(w)[j];
+        int tone = w.conf_c[0] & 511, noise = 0;
+        {   // noise chain in band order (psycho_1.c:390-398)
+            int last = TL_LAST;
+            for (int i = 0; i < nbands; i++) {
+                const int centre = w.ncentre[i];
+                if (last == TL_LAST) noise = centre;
+                else { pnext[centre] = TL_LAST; pnext[last] = (int16_t)centre; }
+                w.px[centre] = w.nsum[i]; w.ptype[centre] = TL_T_NOISE; last = centre;
+            }
         }
-        double max = C->scale_db[w.minidx[ch][lane]];
-        if (w.spike[lane] > max) max = w.spike[lane];
-        w.smr[ch][lane] = max - m;
+        {   // psycho_1.c:409-470 verbatim on the shared links
+            int i = tone, old = TL_STOP, guard = 0;
+            while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
+                if (w.px[i] < C->p1_hear[map[i]]) {
+                    w.ptype[i] = 0; w.px[i] = TL_DBMIN;
+                    if (old == TL_STOP) tone = pnext[i]; else pnext[old] = pnext[i];
+                } else old = i;
+                i = pnext[i];
+            }
+            i = noise; old = TL_STOP; guard = 0;
+            while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
+                if (w.px[i] < C->p1_hear[map[i]]) {
+                    w.ptype[i] = 0; w.px[i] = TL_DBMIN;
+                    if (old == TL_STOP) noise = pnext[i]; else pnext[old] = pnext[i];
+                } else old = i;
+                i = pnext[i];
+            }
+            i = tone; old = TL_STOP; guard = 0;
+            while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
+                const int nx = pnext[i];
+                if (nx == TL_LAST) break;
+                if (nx == TL_STOP) break;                     // (the reference would index power[-100]; never reached in practice)
+                if (C->p1_bark[map[nx]] - C->p1_bark[map[i]] < 0.5) {
+                    if (w.px[nx] > w.px[i]) {
+                        if (old == TL_STOP) tone = nx; else pnext[old] = (int16_t)nx;
+                        w.ptype[i] = 0; w.px[i] = TL_DBMIN; i = nx;
+                    } else {
+                        w.ptype[nx] = 0; w.px[nx] = TL_DBMIN;
+                        pnext[i] = pnext[nx]; old = i;
+                    }
+                } else { old = i; i = nx; }
+            }
+            guard = 0;
+            for (int t = tone; t != TL_LAST && t != TL_STOP && ntone < TL_MASKER_MAX - 32 && guard++ < 600; t = pnext[t]) {
+                TL_MK_X(w)[ntone] = w.px[t]; TL_MK_BARK(w)[ntone] = C->p1_bark[map[t]]; ntone++;
+            }
+            guard = 0;
+            for (int t = noise; t != TL_LAST && t != TL_STOP && ntone + nnoise < TL_MASKER_MAX && guard++ < 600; t = pnext[t]) {
+                TL_MK_X(w)[ntone + nnoise] = w.px[t]; TL_MK_BARK(w)[ntone + nnoise] = C->p1_bark[map[t]]; nnoise++;
+            }
+        }
+        TL_SYNC();
     }
+    tl_psy1_thresholds(w, B, C, ch, ntone, nnoise, sp);
+}
+
+// one channel start to end (mono streams; stereo streams when a dead-head case forces the plain order)
+TL_FN void tl_psy1_finish(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, long long *sp)
+{
+    const int nbands = C->p1_ncb - 1;
+    PV(double, wt); PV(double, bsum);
+    tl_psy1_chain(w, B->dbtable, nbands, bsum, wt);
+    tl_psy1_centres(w, C, nbands, bsum, wt);
+    if (st.dead_head) tl_psy1_deadhead(w, B, C, ch, st, sp); else tl_psy1_back(w, B, C, ch, st, sp);
+}
+TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+                   const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
+{
+    const TlPsy1Ch st = tl_psy1_front(w, T, B, C, pv, ch, sp);
+    tl_psy1_finish(w, B, C, ch, st, sp);
+}
+
+// Both channels of a stereo frame.  Order: front(0) -> park channel 0's front results in registers -> front(1) -> the dB-sum
+// chains of both channels side by side -> back(1) -> channel 0's results return to the LDS arrays -> back(0).
+// Parked: the compacted levels (<= 466 doubles: 8 per lane), the tone records (conf_c, tlist, tone_x), the spike levels, the
+// band ranges and the weight sums.  ptype[] is not parked: after the tone labelling a line is TONE exactly if it is the line
+// of a confirmed tone that was not erased by its successor, so it is rebuilt from conf_c.  A dead-head channel (see
+// tl_psy1_front) falls back to the plain per-channel order, which needs that channel's power[] array intact.
+TL_FN void tl_psy1_stereo(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+                          const TlConfig *TL_RESTRICT C, const TlPcmView &pv, long long *sp)
+{
+    const int nbands = C->p1_ncb - 1;
+    long long *sp0 = sp ? sp + 8 : nullptr, *sp1 = sp ? sp + 16 : nullptr;
+    const TlPsy1Ch s0 = tl_psy1_front(w, T, B, C, pv, 0, sp0);
+    if (s0.dead_head) {                                               // plain order for both channels
+        tl_psy1_finish(w, B, C, 0, s0, sp0);
+        tl_psy1(w, T, B, C, pv, 1, sp1);
+        return;
+    }
+    // ---- park channel 0 ----
+    PV(double, wt0); PV(int, r0); PV(int, r1);
+    PA(double, pvp, 8); PV(int, pcc); PV(int, ptl); PV(double, ptx0); PV(double, ptx1); PV(double, pspk);
+    tl_psy1_weights(w, nbands, wt0);
+    TL_LANES_BEGIN
+    L(r0) = lane < nbands ? (int)w.bandoff[lane] : 0; L(r1) = lane < nbands ? (int)w.bandoff[lane + 1] : 0;
+    const double *vp = w.u.fft + 520;
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int k = 0; k < 8; k++) L(pvp)[k] = lane + 64 * k < 504 ? vp[lane + 64 * k] : 0.0;
+    const int hi = 64 + lane < TL_TONE_MAX ? 64 + lane : 0;
+    L(pcc) = (int)((uint32_t)(uint16_t)w.conf_c[lane] | ((uint32_t)(uint16_t)w.conf_c[hi] << 16));
+    L(ptl) = (int)((uint32_t)(uint16_t)w.tlist[lane] | ((uint32_t)(uint16_t)w.tlist[hi] << 16));
+    L(ptx0) = w.tone_x[lane]; L(ptx1) = w.tone_x[hi];
+    L(pspk) = w.spike[lane & 31];
     TL_LANES_END
+    // ---- channel 1's front; a dead-head channel 1 is finished in the plain order first ----
+    const TlPsy1Ch s1 = tl_psy1_front(w, T, B, C, pv, 1, sp1);
+    PV(double, bsum); PV(double, wt1);
+    if (s1.dead_head) {
+        tl_psy1_finish(w, B, C, 1, s1, sp1);
+        TL_LANES_BEGIN
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int k = 0; k < 8; k++) if (lane + 64 * k < 504) w.u.fft[520 + lane + 64 * k] = L(pvp)[k];
+        if (lane <= nbands) w.bandoff[lane] = (int16_t)(lane < nbands ? L(r0) : 0);
+        TL_LANES_END
+        // bandoff[nbands] = end of the last band
+        {
+            const int last_end = TL_READLANE_I32(r1, nbands - 1);
+            TL_LANES_BEGIN if (lane == 0) w.bandoff[nbands] = (int16_t)last_end; TL_LANES_END
+        }
+        PV(double, wdummy);
+        // the weight terms are gone; tl_psy1_chain's weight output is ignored (the parked sums are used)
+        TL_LANES_BEGIN
+        for (int i = lane; i < 504; i += 64) w.u.fft[i] = 0.0;
+        TL_LANES_END
+        tl_psy1_chain(w, B->dbtable, nbands, bsum, wdummy);
+    } else {
+        // ---- both chains ----
+        TL_LANES_BEGIN
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int k = 0; k < 8; k++) if (lane + 64 * k < 504) w.px[lane + 64 * k] = L(pvp)[k];     // channel 1's power[] is no longer needed
+        TL_LANES_END
+        PV(double, wt2);
+        TL_STAMP(sp1, 4);
+        tl_psy1_chain2(w, B->dbtable, nbands, r0, r1, bsum, wt2);
+        // ---- back(1): its sums and weights move from lanes 32+b to lanes b ----
+        PV(double, bsum1);
+#ifdef TL_EMULATE
+        for (int lane = 0; lane < 64; ++lane) { bsum1[lane] = bsum[(lane + 32) & 63]; wt1[lane] = wt2[(lane + 32) & 63]; }
+#else
+        bsum1 = __shfl(bsum, (int)((threadIdx.x + 32u) & 63u), 64); wt1 = __shfl(wt2, (int)((threadIdx.x + 32u) & 63u), 64);
+#endif
+        tl_psy1_centres(w, C, nbands, bsum1, wt1);
+        tl_psy1_back(w, B, C, 1, s1, sp1);
+    }
+    // ---- channel 0 returns to the LDS arrays ----
+    TL_LANES_BEGIN
+    for (int i = lane; i < 520; i += 64) w.ptype[i] = 0;
+    const int hi = 64 + lane < TL_TONE_MAX ? 64 + lane : 0;
+    w.conf_c[lane] = (int16_t)(L(pcc) & 0xffff); w.tlist[lane] = (int16_t)(L(ptl) & 0xffff); w.tone_x[lane] = L(ptx0);
+    if (64 + lane < TL_TONE_MAX) { w.conf_c[hi] = (int16_t)((uint32_t)L(pcc) >> 16); w.tlist[hi] = (int16_t)((uint32_t)L(ptl) >> 16); w.tone_x[hi] = L(ptx1); }
+    if (lane < 32) w.spike[lane] = L(pspk);
+    TL_LANES_END
+    TL_LANES_BEGIN
+    for (int i = lane; i < s0.nconf; i += 64) { const int cc = w.conf_c[i]; if (!((cc >> 13) & 1)) w.ptype[cc & 511] = TL_T_TONE; }
+    TL_LANES_END
+    tl_psy1_centres(w, C, nbands, bsum, wt0);
+    tl_psy1_back(w, B, C, 0, s0, sp0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1525,7 +1735,8 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     } else if constexpr (PSY == 2) {
         for (int ch = 0; ch < nch; ch++) tl_psy2(w, T, P2, S2, pv, ch, sp ? sp + 8 + 8 * ch : nullptr);
     } else if constexpr (PSY == 1) {
-        for (int ch = 0; ch < nch; ch++) tl_psy1(w, T, B, C, pv, ch, sp ? sp + 8 + 8 * ch : nullptr);
+        if (nch == 2) tl_psy1_stereo(w, T, B, C, pv, sp);
+        else tl_psy1(w, T, B, C, pv, 0, sp ? sp + 8 : nullptr);
     } else {
         for (int ch = 0; ch < nch; ch++) tl_psy3(w, T, B, C, pv, ch, sp ? sp + 8 + 8 * ch : nullptr);
     }
