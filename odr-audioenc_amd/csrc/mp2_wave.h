@@ -1134,7 +1134,7 @@ TL_FN void tl_psy1_stereo(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlB
 
 // ------------------------------------------------------------------------------------------
 // psy model 3 (psycho_3.c:71-432) for channel `ch`; result in w.smr[ch][0..32).
-TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+TL_FN int tl_psy3_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
                    const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
 {
     const double *energy = w.u.fft;
@@ -1270,14 +1270,44 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         w.bandoff[nb] = (int16_t)nvalid;
         TL_SYNC();
     }
-    PV(bool, keepn); PV(double, nx); PV(double, nbk);
+    return nconf;
+}
+
+// energy sum and centre-of-gravity sum of the bands (psycho_3.c:283-289), ascending line order; lane b < nb.  Used on their own
+// for stereo frames, where only the levels take part in the shared dB-sum chain.
+TL_FN void tl_psy3_moments(TlWaveLds &w, int nb, PARG(double, es), PARG(double, cg))
+{
     TL_LANES_BEGIN
-    bool kp = false; double xn = 0, bk = 0;
+    double esum = 0, cw = 0;
+    if (lane < nb) {
+        const double *ve = w.u.fft, *vc = w.u.fft + 512;
+        const int i0 = w.bandoff[lane], i1 = w.bandoff[lane + 1];
+        int i = i0;
+        for (; i + 8 <= i1; i += 8) {                               // operands of eight steps per LDS round trip, summed in order
+            double e[8], c[8];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 8; q++) { e[q] = ve[i + q]; c[q] = vc[i + q]; }
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 8; q++) { esum += e[q]; cw += c[q]; }
+        }
+        for (; i < i1; i++) { esum += ve[i]; cw += vc[i]; }
+    }
+    L(es) = esum; L(cg) = cw;
+    TL_LANES_END
+}
+
+// dB sums, energy sums and centre-of-gravity sums of the bands of ONE channel: lane b < nb
+TL_FN void tl_psy3_chain(TlWaveLds &w, const double *TL_RESTRICT db, int nb, PARG(double, bsum), PARG(double, es), PARG(double, cg))
+{
+    TL_LANES_BEGIN
+    double sum = TL_DBMIN, esum = 0, cw = 0;
     if (lane < nb) {
         const double *ve = w.u.fft, *vc = w.u.fft + 512, *vp = w.px;
-        const int lo = C->p3_cbidx[lane], hi = C->p3_cbidx[lane + 1];
         const int i0 = w.bandoff[lane], i1 = w.bandoff[lane + 1];
-        double sum = TL_DBMIN, esum = 0, cw = 0;
         int i = i0;
         for (; i + 4 <= i1; i += 4) {                               // operands of four steps in flight per LDS round trip
             const double p0 = vp[i], p1 = vp[i + 1], p2 = vp[i + 2], p3 = vp[i + 3];
@@ -1289,6 +1319,46 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
             sum = tl_add_db(db, p3, sum); esum += e3; cw += c3;
         }
         for (; i < i1; i++) { sum = tl_add_db(db, vp[i], sum); esum += ve[i]; cw += vc[i]; }
+    }
+    L(bsum) = sum; L(es) = esum; L(cg) = cw;
+    TL_LANES_END
+}
+
+// dB sums of BOTH channels at once: lanes 0..31 walk channel 0's bands (levels parked at fft[], ranges in r0/r1), lanes 32..63
+// channel 1's (levels in px[], ranges from bandoff[]).  Lane b holds channel 0's sum, lane 32+b channel 1's.
+TL_FN void tl_psy3_chain2(TlWaveLds &w, const double *TL_RESTRICT db, int nb, PARG(int, r0), PARG(int, r1), PARG(double, bsum))
+{
+    TL_LANES_BEGIN
+    double sum = TL_DBMIN;
+    const int band = lane & 31;
+    if (band < nb) {
+        const bool second = lane >= 32;
+        const double *vp = second ? w.px : w.u.fft;
+        const int i0 = second ? (int)w.bandoff[band] : L(r0), i1 = second ? (int)w.bandoff[band + 1] : L(r1);
+        int i = i0;
+        for (; i + 4 <= i1; i += 4) {
+            const double p0 = vp[i], p1 = vp[i + 1], p2 = vp[i + 2], p3 = vp[i + 3];
+            sum = tl_add_db(db, p0, sum); sum = tl_add_db(db, p1, sum); sum = tl_add_db(db, p2, sum); sum = tl_add_db(db, p3, sum);
+        }
+        for (; i < i1; i++) sum = tl_add_db(db, vp[i], sum);
+    }
+    L(bsum) = sum;
+    TL_LANES_END
+}
+
+// band centres, decimation, thresholds, SMR (psycho_3.c:290-432) from the sums of lanes b < nb
+TL_FN void tl_psy3_back(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const TlConfig *TL_RESTRICT C, int ch, int nconf,
+                        PARG(double, bsum), PARG(double, es), PARG(double, cg), long long *sp)
+{
+    const double *db = B->dbtable;
+    const double *bark = C->p3_bark, *ath = C->p3_ath;
+    const int nb = C->p3_cbands;
+    PV(bool, keepn); PV(double, nx); PV(double, nbk);
+    TL_LANES_BEGIN
+    bool kp = false; double xn = 0, bk = 0;
+    if (lane < nb) {
+        const int lo = C->p3_cbidx[lane], hi = C->p3_cbidx[lane + 1];
+        const double sum = L(bsum), esum = L(es), cw = L(cg);
         // esum == 0: the reference indexes with (int)(0/0) and segfaults; defined as the band centre
         int centre = (sum <= TL_DBMIN || esum == 0) ? (lo + hi) / 2 : lo + (int)(cw / esum);
         centre = centre < 1 ? 1 : centre > 512 ? 512 : centre;
@@ -1397,6 +1467,63 @@ TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         w.smr[ch][lane] = w.spike[lane] - m;
     }
     TL_LANES_END
+}
+
+
+TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+                   const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
+{
+    const int nconf = tl_psy3_front(w, T, B, C, pv, ch, sp);
+    PV(double, bsum); PV(double, es); PV(double, cg);
+    tl_psy3_chain(w, B->dbtable, C->p3_cbands, bsum, es, cg);
+    tl_psy3_back(w, B, C, ch, nconf, bsum, es, cg, sp);
+}
+
+// Both channels of a stereo frame, organised like tl_psy1_stereo: front(0) -> channel 0's compacted levels, tone records, Lsb
+// and band moments wait in registers -> front(1) -> both dB-sum chains side by side -> back(1) -> back(0).
+TL_FN void tl_psy3_stereo(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+                          const TlConfig *TL_RESTRICT C, const TlPcmView &pv, long long *sp)
+{
+    const int nb = C->p3_cbands;
+    long long *sp0 = sp ? sp + 8 : nullptr, *sp1 = sp ? sp + 16 : nullptr;
+    const int nconf0 = tl_psy3_front(w, T, B, C, pv, 0, sp0);
+    PV(double, es0); PV(double, cg0); PV(int, r0); PV(int, r1);
+    PA(double, pvp, 8); PV(int, pcc); PV(double, ptx0); PV(double, ptx1); PV(double, pspk);
+    tl_psy3_moments(w, nb, es0, cg0);
+    TL_LANES_BEGIN
+    L(r0) = lane < nb ? (int)w.bandoff[lane] : 0; L(r1) = lane < nb ? (int)w.bandoff[lane + 1] : 0;
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int k = 0; k < 8; k++) L(pvp)[k] = w.px[lane + 64 * k];
+    const int hi = 64 + lane < TL_TONE_MAX ? 64 + lane : 0;
+    L(pcc) = (int)((uint32_t)(uint16_t)w.conf_c[lane] | ((uint32_t)(uint16_t)w.conf_c[hi] << 16));
+    L(ptx0) = w.tone_x[lane]; L(ptx1) = w.tone_x[hi];
+    L(pspk) = w.spike[lane & 31];
+    TL_LANES_END
+    const int nconf1 = tl_psy3_front(w, T, B, C, pv, 1, sp1);
+    PV(double, es1); PV(double, cg1); PV(double, bsum); PV(double, bsum1);
+    tl_psy3_moments(w, nb, es1, cg1);
+    TL_LANES_BEGIN
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int k = 0; k < 8; k++) w.u.fft[lane + 64 * k] = L(pvp)[k];   // channel 1's energies and centre terms are summed: the buffer is free
+    TL_LANES_END
+    tl_psy3_chain2(w, B->dbtable, nb, r0, r1, bsum);
+#ifdef TL_EMULATE
+    for (int lane = 0; lane < 64; ++lane) bsum1[lane] = bsum[(lane + 32) & 63];
+#else
+    bsum1 = __shfl(bsum, (int)((threadIdx.x + 32u) & 63u), 64);
+#endif
+    tl_psy3_back(w, B, C, 1, nconf1, bsum1, es1, cg1, sp1);
+    TL_LANES_BEGIN
+    const int hi = 64 + lane < TL_TONE_MAX ? 64 + lane : 0;
+    w.conf_c[lane] = (int16_t)(L(pcc) & 0xffff); w.tone_x[lane] = L(ptx0);
+    if (64 + lane < TL_TONE_MAX) { w.conf_c[hi] = (int16_t)((uint32_t)L(pcc) >> 16); w.tone_x[hi] = L(ptx1); }
+    if (lane < 32) w.spike[lane] = L(pspk);
+    TL_LANES_END
+    tl_psy3_back(w, B, C, 0, nconf0, bsum, es0, cg0, sp0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1738,7 +1865,8 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         if (nch == 2) tl_psy1_stereo(w, T, B, C, pv, sp);
         else tl_psy1(w, T, B, C, pv, 0, sp ? sp + 8 : nullptr);
     } else {
-        for (int ch = 0; ch < nch; ch++) tl_psy3(w, T, B, C, pv, ch, sp ? sp + 8 + 8 * ch : nullptr);
+        if (nch == 2) tl_psy3_stereo(w, T, B, C, pv, sp);
+        else tl_psy3(w, T, B, C, pv, 0, sp ? sp + 8 : nullptr);
     }
 
     TL_STAMP(sp, 3);
