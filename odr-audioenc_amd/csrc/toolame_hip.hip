@@ -202,6 +202,10 @@ struct tlb_batch {
     fprintf(stderr, "libtoolame-dab-hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
     return TLB_ERR_HIP; } } while (0)
 
+// device scratch of the *_host convenience entry points: released on every exit path
+struct DevFree { std::vector<void *> v; ~DevFree() { for (void *p : v) (void)hipFree(p); } };
+#define DEVALLOC(ptr, bytes) do { HIPCHK(hipMalloc(&(ptr), (bytes))); guard_.v.push_back((void *)(ptr)); } while (0)
+
 extern "C" {
 
 int tlb_device_count(void)
@@ -369,6 +373,7 @@ int tlb_encode_device(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
 int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t *xpad, const int32_t *xpad_len,
                     uint8_t *out, void *taps)
 {
+    DevFree guard_;
     if (!b || !pcm || !out || nframes <= 0) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
     const size_t slots = (size_t)nframes * (size_t)b->nstreams;
@@ -394,11 +399,7 @@ int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t
         if (rc == TLB_OK && e == hipSuccess) e = hipMemcpy(out, d_out, slots * (size_t)b->out_stride, hipMemcpyDeviceToHost);
         if (rc == TLB_OK && e == hipSuccess && taps) e = hipMemcpy(taps, d_taps, slots * sizeof(TlTaps), hipMemcpyDeviceToHost);
     }
-    if (d_pcm) (void)hipFree(d_pcm);
-    if (d_out) (void)hipFree(d_out);
-    if (d_xpad) (void)hipFree(d_xpad);
-    if (d_xl) (void)hipFree(d_xl);
-    if (d_taps) (void)hipFree(d_taps);
+    for (void *p : {(void *)d_pcm, (void *)d_xpad, (void *)d_xl, (void *)d_out, (void *)d_taps}) if (p) guard_.v.push_back(p);
     if (e != hipSuccess) { fprintf(stderr, "libtoolame-dab-hip: %s\n", hipGetErrorString(e)); return TLB_ERR_HIP; }
     return rc;
 }
@@ -406,19 +407,20 @@ int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t
 // Diagnostic: per-stage s_memtime stamps [nframes][nstreams][32] (see TL_STAMP in mp2_wave.h).
 int tlb_encode_host_stamps(tlb_batch *b, const int16_t *pcm, int nframes, long long *stamps)
 {
+    DevFree guard_;
     if (!b || !pcm || !stamps || nframes <= 0) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
     const size_t slots = (size_t)nframes * (size_t)b->nstreams;
     int16_t *d_pcm = nullptr; uint8_t *d_out = nullptr; long long *d_st = nullptr;
-    HIPCHK(hipMalloc(&d_pcm, slots * 2304 * sizeof(int16_t)));
-    HIPCHK(hipMalloc(&d_out, slots * (size_t)b->out_stride));
-    HIPCHK(hipMalloc(&d_st, slots * 32 * sizeof(long long)));
+    DEVALLOC(d_pcm, slots * 2304 * sizeof(int16_t));
+    DEVALLOC(d_out, slots * (size_t)b->out_stride);
+    DEVALLOC(d_st, slots * 32 * sizeof(long long));
     HIPCHK(hipMemset(d_st, 0, slots * 32 * sizeof(long long)));
     HIPCHK(hipMemcpy(d_pcm, pcm, slots * 2304 * sizeof(int16_t), hipMemcpyHostToDevice));
     int rc = tlb_launch(b, d_pcm, nframes, nullptr, nullptr, d_out, nullptr, nullptr, d_st);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(stamps, d_st, slots * 32 * sizeof(long long), hipMemcpyDeviceToHost));
-    (void)hipFree(d_pcm); (void)hipFree(d_out); (void)hipFree(d_st);
+
     return rc;
 }
 
@@ -444,19 +446,20 @@ int tlb_ingest_device(tlb_batch *b, const int16_t *d_interleaved, int nframes, i
 
 int tlb_ingest_host(tlb_batch *b, const int16_t *interleaved, int nframes, int16_t *pcm, int16_t *peaks)
 {
+    DevFree guard_;
     if (!b || !interleaved || !pcm || !peaks || nframes <= 0) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
     const size_t slots = (size_t)nframes * (size_t)b->nstreams;
     int16_t *d_in = nullptr, *d_out = nullptr, *d_pk = nullptr;
-    HIPCHK(hipMalloc(&d_in, slots * 2304 * 2));
-    HIPCHK(hipMalloc(&d_out, slots * 2304 * 2));
-    HIPCHK(hipMalloc(&d_pk, slots * 2 * 2));
+    DEVALLOC(d_in, slots * 2304 * 2);
+    DEVALLOC(d_out, slots * 2304 * 2);
+    DEVALLOC(d_pk, slots * 2 * 2);
     HIPCHK(hipMemcpy(d_in, interleaved, slots * 2304 * 2, hipMemcpyHostToDevice));
     int rc = tlb_ingest_device(b, d_in, nframes, d_out, d_pk, nullptr);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(pcm, d_out, slots * 2304 * 2, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(peaks, d_pk, slots * 2 * 2, hipMemcpyDeviceToHost));
-    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_pk);
+
     return rc;
 }
 
@@ -472,18 +475,19 @@ int tlb_silence_device(tlb_batch *b, const int16_t *d_peaks, int nframes, uint32
 
 int tlb_silence_host(tlb_batch *b, const int16_t *peaks, int nframes, uint32_t *silence_ms)
 {
+    DevFree guard_;
     if (!b || !peaks || !silence_ms || nframes <= 0) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
     const size_t slots = (size_t)nframes * (size_t)b->nstreams;
     int16_t *d_p = nullptr; uint32_t *d_m = nullptr;
-    HIPCHK(hipMalloc(&d_p, slots * 4));
-    HIPCHK(hipMalloc(&d_m, sizeof(uint32_t) * (size_t)b->nstreams));
+    DEVALLOC(d_p, slots * 4);
+    DEVALLOC(d_m, sizeof(uint32_t) * (size_t)b->nstreams);
     HIPCHK(hipMemcpy(d_p, peaks, slots * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_m, silence_ms, sizeof(uint32_t) * (size_t)b->nstreams, hipMemcpyHostToDevice));
     int rc = tlb_silence_device(b, d_p, nframes, d_m, nullptr);
     hipError_t e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(silence_ms, d_m, sizeof(uint32_t) * (size_t)b->nstreams, hipMemcpyDeviceToHost);
-    (void)hipFree(d_p); (void)hipFree(d_m);
+
     if (e != hipSuccess) return TLB_ERR_HIP;
     return rc;
 }
@@ -502,19 +506,20 @@ int tlb_zmq_frame_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d
 
 int tlb_zmq_frame_host(tlb_batch *b, const uint8_t *frames, const int16_t *peaks, int nframes, uint8_t *msgs)
 {
+    DevFree guard_;
     if (!b || !frames || !msgs || nframes <= 0) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
     const size_t slots = (size_t)nframes * (size_t)b->nstreams, ms = 12 + (size_t)b->out_stride;
     uint8_t *d_f = nullptr, *d_m = nullptr; int16_t *d_p = nullptr;
-    HIPCHK(hipMalloc(&d_f, slots * (size_t)b->out_stride));
-    HIPCHK(hipMalloc(&d_m, slots * ms));
+    DEVALLOC(d_f, slots * (size_t)b->out_stride);
+    DEVALLOC(d_m, slots * ms);
     HIPCHK(hipMemset(d_m, 0, slots * ms));
     HIPCHK(hipMemcpy(d_f, frames, slots * (size_t)b->out_stride, hipMemcpyHostToDevice));
-    if (peaks) { HIPCHK(hipMalloc(&d_p, slots * 4)); HIPCHK(hipMemcpy(d_p, peaks, slots * 4, hipMemcpyHostToDevice)); }
+    if (peaks) { DEVALLOC(d_p, slots * 4); HIPCHK(hipMemcpy(d_p, peaks, slots * 4, hipMemcpyHostToDevice)); }
     int rc = tlb_zmq_frame_device(b, d_f, d_p, nframes, d_m, nullptr);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(msgs, d_m, slots * ms, hipMemcpyDeviceToHost));
-    (void)hipFree(d_f); (void)hipFree(d_m); if (d_p) (void)hipFree(d_p);
+
     return rc;
 }
 
@@ -568,26 +573,27 @@ int tlb_edi_af_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_le
 int tlb_edi_af_host(tlb_batch *b, const uint8_t *frames, const int16_t *levels, int nframes, tlb_edi_state *state,
                     const char *version, int version_len, uint8_t *pkts, int32_t *pkt_len)
 {
+    DevFree guard_;
     if (!b || !frames || !state || !pkts || !pkt_len || nframes <= 0) return TLB_ERR_ARG;
     const int stride = tlb_edi_af_stride(b, version_len);
     if (!stride) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
     const size_t slots = (size_t)nframes * (size_t)b->nstreams;
     uint8_t *d_f = nullptr, *d_p = nullptr; int16_t *d_l = nullptr; tlb_edi_state *d_s = nullptr; int32_t *d_n = nullptr;
-    HIPCHK(hipMalloc(&d_f, slots * (size_t)b->out_stride));
-    HIPCHK(hipMalloc(&d_p, slots * (size_t)stride));
-    HIPCHK(hipMalloc(&d_s, sizeof(tlb_edi_state) * (size_t)b->nstreams));
-    HIPCHK(hipMalloc(&d_n, sizeof(int32_t) * slots));
+    DEVALLOC(d_f, slots * (size_t)b->out_stride);
+    DEVALLOC(d_p, slots * (size_t)stride);
+    DEVALLOC(d_s, sizeof(tlb_edi_state) * (size_t)b->nstreams);
+    DEVALLOC(d_n, sizeof(int32_t) * slots);
     HIPCHK(hipMemset(d_p, 0, slots * (size_t)stride));
     HIPCHK(hipMemcpy(d_f, frames, slots * (size_t)b->out_stride, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_s, state, sizeof(tlb_edi_state) * (size_t)b->nstreams, hipMemcpyHostToDevice));
-    if (levels) { HIPCHK(hipMalloc(&d_l, slots * 4)); HIPCHK(hipMemcpy(d_l, levels, slots * 4, hipMemcpyHostToDevice)); }
+    if (levels) { DEVALLOC(d_l, slots * 4); HIPCHK(hipMemcpy(d_l, levels, slots * 4, hipMemcpyHostToDevice)); }
     int rc = tlb_edi_af_device(b, d_f, d_l, nframes, d_s, version, version_len, d_p, d_n, nullptr);
     hipError_t e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(pkts, d_p, slots * (size_t)stride, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(pkt_len, d_n, sizeof(int32_t) * slots, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(state, d_s, sizeof(tlb_edi_state) * (size_t)b->nstreams, hipMemcpyDeviceToHost);
-    (void)hipFree(d_f); (void)hipFree(d_p); (void)hipFree(d_s); (void)hipFree(d_n); if (d_l) (void)hipFree(d_l);
+
     if (e != hipSuccess) return TLB_ERR_HIP;
     return rc;
 }
@@ -644,16 +650,17 @@ int tlb_edi_pft_host(tlb_batch *b, const uint8_t *af, const int32_t *af_len, int
                      int fec, int chunk_len, int transport, int addr_source, int dest_port,
                      uint8_t *frags, int32_t *frag_len, int32_t *nfrag, int max_frags, int frag_stride)
 {
+    DevFree guard_;
     if (!b || !af || !af_len || !pseq || !frags || !frag_len || !nfrag || nframes <= 0 || af_stride <= 0 || max_frags <= 0 || frag_stride <= 0) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
     const size_t slots = (size_t)nframes * (size_t)b->nstreams;
     uint8_t *d_a = nullptr, *d_f = nullptr; int32_t *d_l = nullptr, *d_fl = nullptr, *d_n = nullptr; uint16_t *d_p = nullptr;
-    HIPCHK(hipMalloc(&d_a, slots * (size_t)af_stride));
-    HIPCHK(hipMalloc(&d_l, slots * 4));
-    HIPCHK(hipMalloc(&d_f, slots * (size_t)max_frags * (size_t)frag_stride));
-    HIPCHK(hipMalloc(&d_fl, slots * (size_t)max_frags * 4));
-    HIPCHK(hipMalloc(&d_n, slots * 4));
-    HIPCHK(hipMalloc(&d_p, sizeof(uint16_t) * (size_t)b->nstreams));
+    DEVALLOC(d_a, slots * (size_t)af_stride);
+    DEVALLOC(d_l, slots * 4);
+    DEVALLOC(d_f, slots * (size_t)max_frags * (size_t)frag_stride);
+    DEVALLOC(d_fl, slots * (size_t)max_frags * 4);
+    DEVALLOC(d_n, slots * 4);
+    DEVALLOC(d_p, sizeof(uint16_t) * (size_t)b->nstreams);
     HIPCHK(hipMemset(d_f, 0, slots * (size_t)max_frags * (size_t)frag_stride));
     HIPCHK(hipMemset(d_fl, 0, slots * (size_t)max_frags * 4));
     HIPCHK(hipMemcpy(d_a, af, slots * (size_t)af_stride, hipMemcpyHostToDevice));
@@ -665,7 +672,7 @@ int tlb_edi_pft_host(tlb_batch *b, const uint8_t *af, const int32_t *af_len, int
     if (e == hipSuccess) e = hipMemcpy(frag_len, d_fl, slots * (size_t)max_frags * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(nfrag, d_n, slots * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(pseq, d_p, sizeof(uint16_t) * (size_t)b->nstreams, hipMemcpyDeviceToHost);
-    (void)hipFree(d_a); (void)hipFree(d_l); (void)hipFree(d_f); (void)hipFree(d_fl); (void)hipFree(d_n); (void)hipFree(d_p);
+
     if (e != hipSuccess) return TLB_ERR_HIP;
     return rc;
 }
@@ -682,15 +689,16 @@ int tlb_flush_device(tlb_batch *b, uint8_t *d_out, void *hip_stream)
 
 int tlb_flush_host(tlb_batch *b, uint8_t *out)
 {
+    DevFree guard_;
     if (!b || !out) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
     uint8_t *d = nullptr;
     const size_t n = (size_t)b->nstreams * (size_t)b->out_stride;
-    HIPCHK(hipMalloc(&d, n));
+    DEVALLOC(d, n);
     int rc = tlb_flush_device(b, d, nullptr);
     hipError_t e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(out, d, n, hipMemcpyDeviceToHost);
-    (void)hipFree(d);
+
     if (e != hipSuccess) return TLB_ERR_HIP;
     return rc;
 }
