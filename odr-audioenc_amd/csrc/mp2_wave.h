@@ -316,15 +316,53 @@ TL_FN unsigned tl_crc_upd(unsigned crc, unsigned data, int len, unsigned poly, u
 }
 
 // ------------------------------------------------------------------------------------------
-// K3: 1024-point FHT (fft.c:78-1185), parallel over 64 lanes.  Input is written bit-reversed by
-// the caller (the swap list fft.c:85-1090 is the 10-bit reversal), so only the butterflies remain.
-TL_FN void tl_fht_pass_first(double *x, int lane)
-{   // fft.c:1092-1102: 256 groups of 4
-    for (int g = lane; g < 256; g += 64) {
-        double *fi = x + 4 * g;
-        double f1 = fi[0] - fi[1], f0 = fi[0] + fi[1], f3 = fi[2] - fi[3], f2 = fi[2] + fi[3];
-        fi[2] = f0 - f2; fi[0] = f0 + f2; fi[3] = f1 - f3; fi[1] = f1 + f3;
+// K3: 1024-point FHT (fft.c:78-1185), parallel over 64 lanes.  The swap list of fft.c:85-1090 is the 10-bit reversal.
+//
+// Head in registers: lane L loads the windowed samples i = L + 64*it (it = 0..15); their bit-reversed slots are
+// 16*rev6(L) + rev4(it) -- exactly one block of 16 consecutive points, the unit the first pass (groups of four,
+// fft.c:1092-1102) and the k=2 pass (fft.c:1104-1184 with k1=4) work on.  So the lane runs both passes on its own sixteen
+// values without touching LDS and stores the block once (tl_fht_head / tl_fht_store).
+// Layout: logical index i lives at i ^ (i >> 5) (a permutation inside each group of 32 doubles).  With it the stored
+// blocks, the k=4/6/8 butterflies and the energy reads spread over the LDS banks (at most ~3 lanes per bank instead of
+// up to 32); index fields that do not share bits pass through the map separately: FX(a|b) = FX(a) ^ FX(b).
+#define TL_FX(i) ((i) ^ ((i) >> 5))
+TL_FN void tl_fht_head(double (&e)[16], const double (*TL_RESTRICT tw)[4])
+{
+    const double SQRT2 = 1.4142135623730951454746218587388284504414;
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int g = 0; g < 16; g += 4) {                               // fft.c:1092-1102
+        const double f1 = e[g] - e[g + 1], f0 = e[g] + e[g + 1], f3 = e[g + 2] - e[g + 3], f2 = e[g + 2] + e[g + 3];
+        e[g + 2] = f0 - f2; e[g] = f0 + f2; e[g + 3] = f1 - f3; e[g + 1] = f1 + f3;
     }
+    {   // k=2 pass, i = 0: fi = block, gi = block + 2 (k1 = 4, k2 = 8, k3 = 12)
+        const double f1 = e[0] - e[4], f0 = e[0] + e[4], f3 = e[8] - e[12], f2 = e[8] + e[12];
+        e[8] = f0 - f2; e[0] = f0 + f2; e[12] = f1 - f3; e[4] = f1 + f3;
+        const double g1 = e[2] - e[6], g0 = e[2] + e[6], g3 = SQRT2 * e[14], g2 = SQRT2 * e[10];
+        e[10] = g0 - g2; e[2] = g0 + g2; e[14] = g1 - g3; e[6] = g1 + g3;
+    }
+    {   // k=2 pass, i = 1: fi = block + 1, gi = block + 3; one twiddle set for every block
+        const double c1 = tw[0][0], s1 = tw[0][1], c2 = tw[0][2], s2 = tw[0][3];
+        double a, b2, g0, f0, f1, g1, f2, g2, f3, g3;
+        b2 = s2 * e[5] - c2 * e[7]; a = c2 * e[5] + s2 * e[7];
+        f1 = e[1] - a; f0 = e[1] + a; g1 = e[3] - b2; g0 = e[3] + b2;
+        b2 = s2 * e[13] - c2 * e[15]; a = c2 * e[13] + s2 * e[15];
+        f3 = e[9] - a; f2 = e[9] + a; g3 = e[11] - b2; g2 = e[11] + b2;
+        b2 = s1 * f2 - c1 * g3; a = c1 * f2 + s1 * g3;
+        e[9] = f0 - a; e[1] = f0 + a; e[15] = g1 - b2; e[7] = g1 + b2;
+        b2 = c1 * g2 - s1 * f3; a = s1 * g2 + c1 * f3;
+        e[11] = g0 - a; e[3] = g0 + a; e[13] = f1 - b2; e[5] = f1 + b2;
+    }
+}
+TL_FN int tl_rev6(int lane) { int r = 0; for (int b = 0; b < 6; b++) r |= ((lane >> b) & 1) << (5 - b); return r; }
+TL_FN void tl_fht_store(double *x, int lane, const double (&e)[16])
+{
+    const int l = tl_rev6(lane), base = (16 * l) ^ (l >> 1);         // FX(16*l + t) = base ^ t for t < 16
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int t = 0; t < 16; t++) x[base ^ t] = e[t];
 }
 // Twiddles (c1,s1,c2,s2) of the (up to) two general butterflies a lane runs in pass K; fetched one pass ahead.
 template <int K>
@@ -344,33 +382,39 @@ TL_FN void tl_fht_pass(double *x, const double (&t)[8], int lane)
 {   // fft.c:1104-1184: one pass = 128 independent 8-point butterflies: per block of 4*k1 points one with trivial /
     // sqrt(2) twiddles (i = 0) and kx-1 general ones.  The general ones are dealt densely to the lanes and the
     // trivial ones follow in their own step, so a wave never runs both code paths for one batch of butterflies.
+    // Addresses: block, i (or k1-i) and q*k1 occupy disjoint bit fields, so each goes through TL_FX on its own.
     const double SQRT2 = 1.4142135623730951454746218587388284504414;
     constexpr int k1 = 1 << K, k2 = k1 << 1, k4 = k2 << 1, k3 = k2 + k1, kx = k1 >> 1;
     constexpr int NBLK = 128 / kx, NGEN = 128 - NBLK;
+    constexpr int q1 = TL_FX(k1), q2 = TL_FX(k2), q3 = TL_FX(k3);
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         const int g = lane + 64 * it;
         if (g >= NGEN) break;
         const int blk = g / (kx - 1), i = 1 + (g - blk * (kx - 1));
-        double *base = x + blk * k4;
+        const int pb = TL_FX(blk * k4);
         const double c1 = t[4 * it], s1 = t[4 * it + 1], c2 = t[4 * it + 2], s2 = t[4 * it + 3];
-        double *fi = base + i, *gi = base + k1 - i;
+        const int F = pb ^ TL_FX(i), G = pb ^ TL_FX(k1 - i);
+        double *f0p = x + F, *f1p = x + (F ^ q1), *f2p = x + (F ^ q2), *f3p = x + (F ^ q3);
+        double *g0p = x + G, *g1p = x + (G ^ q1), *g2p = x + (G ^ q2), *g3p = x + (G ^ q3);
         double a, b2, g0, f0, f1, g1, f2, g2, f3, g3;
-        b2 = s2 * fi[k1] - c2 * gi[k1]; a = c2 * fi[k1] + s2 * gi[k1];
-        f1 = fi[0] - a; f0 = fi[0] + a; g1 = gi[0] - b2; g0 = gi[0] + b2;
-        b2 = s2 * fi[k3] - c2 * gi[k3]; a = c2 * fi[k3] + s2 * gi[k3];
-        f3 = fi[k2] - a; f2 = fi[k2] + a; g3 = gi[k2] - b2; g2 = gi[k2] + b2;
+        b2 = s2 * *f1p - c2 * *g1p; a = c2 * *f1p + s2 * *g1p;
+        f1 = *f0p - a; f0 = *f0p + a; g1 = *g0p - b2; g0 = *g0p + b2;
+        b2 = s2 * *f3p - c2 * *g3p; a = c2 * *f3p + s2 * *g3p;
+        f3 = *f2p - a; f2 = *f2p + a; g3 = *g2p - b2; g2 = *g2p + b2;
         b2 = s1 * f2 - c1 * g3; a = c1 * f2 + s1 * g3;
-        fi[k2] = f0 - a; fi[0] = f0 + a; gi[k3] = g1 - b2; gi[k1] = g1 + b2;
+        *f2p = f0 - a; *f0p = f0 + a; *g3p = g1 - b2; *g1p = g1 + b2;
         b2 = c1 * g2 - s1 * f3; a = s1 * g2 + c1 * f3;
-        gi[k2] = g0 - a; gi[0] = g0 + a; fi[k3] = f1 - b2; fi[k1] = f1 + b2;
+        *g2p = g0 - a; *g0p = g0 + a; *f3p = f1 - b2; *f1p = f1 + b2;
     }
     if (lane < NBLK) {
-        double *fi = x + lane * k4, *gi = fi + kx;
-        double f1 = fi[0] - fi[k1], f0 = fi[0] + fi[k1], f3 = fi[k2] - fi[k3], f2 = fi[k2] + fi[k3];
-        fi[k2] = f0 - f2; fi[0] = f0 + f2; fi[k3] = f1 - f3; fi[k1] = f1 + f3;
-        double g1 = gi[0] - gi[k1], g0 = gi[0] + gi[k1], g3 = SQRT2 * gi[k3], g2 = SQRT2 * gi[k2];
-        gi[k2] = g0 - g2; gi[0] = g0 + g2; gi[k3] = g1 - g3; gi[k1] = g1 + g3;
+        const int F = TL_FX(lane * k4), G = F ^ TL_FX(kx);
+        double *f0p = x + F, *f1p = x + (F ^ q1), *f2p = x + (F ^ q2), *f3p = x + (F ^ q3);
+        double *g0p = x + G, *g1p = x + (G ^ q1), *g2p = x + (G ^ q2), *g3p = x + (G ^ q3);
+        double f1 = *f0p - *f1p, f0 = *f0p + *f1p, f3 = *f2p - *f3p, f2 = *f2p + *f3p;
+        *f2p = f0 - f2; *f0p = f0 + f2; *f3p = f1 - f3; *f1p = f1 + f3;
+        double g1 = *g0p - *g1p, g0 = *g0p + *g1p, g3 = SQRT2 * *g3p, g2 = SQRT2 * *g2p;
+        *g2p = g0 - g2; *g0p = g0 + g2; *g3p = g1 - g3; *g1p = g1 + g3;
     }
 }
 
@@ -385,40 +429,44 @@ TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     double *x = w.u.fft;
     long long *sq = (sp && ch == 0) ? sp + 16 : nullptr;      // channel 0's pass-by-pass stamps: slots 24..30 of the frame's record
     TL_STAMP(sq, 0);
+    // twiddles travel one pass ahead of their use (twc: k=4, twb: k=6, twa: k=8)
+    PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
     TL_LANES_BEGIN
     {
         // sample i = lane + 64*it of the analysis window: the last 192 samples of the history (it < 3), then the
-        // first 832 of the frame.  The loads are issued in batches ahead of their use; the bit-reversed slot of i
-        // is rev6(lane) << 4 | rev4(it).
+        // first 832 of the frame.  The loads are issued in batches ahead of their use.  Slot of i inside the lane's block
+        // of sixteen: rev4(it).
         const int16_t *hs = pv.hist + ch * pv.hist_stride + (TL_HIST - 192) + lane;
         const int16_t *cs = pv.cur + ch * 1152 - 192 + lane;
         const double *hann = T->hann;
         TL_LAUNDER(hann);
-        int r6 = 0;
-        for (int b = 0; b < 6; b++) r6 |= ((lane >> b) & 1) << (5 - b);
+        tl_fht_twiddles<4>(L(twc), 1, T->fht_tw, lane);
+        double e[16];
+#ifndef TL_EMULATE
 #pragma unroll
+#endif
         for (int half = 0; half < 16; half += 8) {                  // eight loads in flight (sixteen would spill)
             int16_t v[8]; double h[8];
+#ifndef TL_EMULATE
 #pragma unroll
+#endif
             for (int q = 0; q < 8; q++) { const int it = half + q; v[q] = it < 3 ? hs[64 * it] : cs[64 * it]; h[q] = hann[lane + 64 * it]; }
+#ifndef TL_EMULATE
 #pragma unroll
+#endif
             for (int q = 0; q < 8; q++) {
                 const int it = half + q;
                 const int r4 = ((it & 1) << 3) | ((it & 2) << 1) | ((it & 4) >> 1) | ((it & 8) >> 3);
-                x[(r6 << 4) | r4] = ((double)v[q] / 32768) * h[q];
+                e[r4] = ((double)v[q] / 32768) * h[q];
             }
         }
+        tl_fht_twiddles<6>(L(twb), 8, T->fht_tw, lane);
+        tl_fht_head(e, T->fht_tw);
+        tl_fht_store(x, lane, e);
     }
     TL_LANES_END
     TL_STAMP(sq, 1);
-    // twiddles travel one pass ahead of their use (twa: k=2 then k=8, twc: k=4, twb: k=6)
-    PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
-    TL_LANES_BEGIN
-    tl_fht_twiddles<2>(L(twa), 0, T->fht_tw, lane); tl_fht_twiddles<4>(L(twc), 1, T->fht_tw, lane);
-    tl_fht_pass_first(x, lane);
-    TL_LANES_END
     TL_STAMP(sq, 2);
-    TL_LANES_BEGIN tl_fht_twiddles<6>(L(twb), 8, T->fht_tw, lane); tl_fht_pass<2>(x, L(twa), lane); TL_LANES_END
     TL_STAMP(sq, 3);
     TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), 39, T->fht_tw, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
     TL_STAMP(sq, 4);
@@ -426,13 +474,21 @@ TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     TL_STAMP(sq, 5);
     TL_LANES_BEGIN tl_fht_pass<8>(x, L(twa), lane); TL_LANES_END
     TL_STAMP(sq, 6);
-    TL_LANES_BEGIN
-    for (int i = lane; i <= 512; i += 64) {
+    // energies (fft.c:1278-1293), 64 lines at a time: read through the layout map, write in natural order.  The writes of
+    // one step touch lines [64*it, 64*it+63], whose slots hold nothing a later step still reads.
+    for (int it = 0; it < 8; it++) {
+        PV(double, ev);
+        TL_LANES_BEGIN
+        const int i = lane + 64 * it;
         double e;
-        if (i == 0 || i == 512) e = x[i] * x[i];
-        else { double a = x[i], b = x[1024 - i]; e = (a * a + b * b) / 2.0; }
-        x[i] = e;                     // position 1024-i is only ever read by this same lane
+        if (i == 0) e = x[0] * x[0];
+        else { const double a = x[TL_FX(i)], b = x[TL_FX(1024 - i)]; e = (a * a + b * b) / 2.0; }
+        L(ev) = e;
+        TL_LANES_END
+        TL_LANES_BEGIN x[lane + 64 * it] = L(ev); TL_LANES_END
     }
+    TL_LANES_BEGIN
+    if (lane == 0) { const double v = x[TL_FX(512)]; x[512] = v * v; }
     TL_LANES_END
 }
 
@@ -1542,14 +1598,15 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
     for (int pass = 0; pass < 2; pass++) {
         long long *sq = pass == 0 ? sp : nullptr;                  // stage stamps of the first pass
         TL_STAMP(sq, 0);
+        PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
         TL_LANES_BEGIN
         {
             // sample i = lane + 64*it of the pass's 1024-sample window (psycho_2.c:84-92); loads in batches of eight ahead
-            // of their use; the bit-reversed slot of i is rev6(lane) << 4 | rev4(it)
+            // of their use; slot of i inside the lane's block of sixteen: rev4(it) (see tl_fht_head)
             const double *win = P->window;
             TL_LAUNDER(win);
-            int r6 = 0;
-            for (int b = 0; b < 6; b++) r6 |= ((lane >> b) & 1) << (5 - b);
+            tl_fht_twiddles<4>(L(twc), 1, T->fht_tw, lane);
+            double e[16];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
@@ -1570,41 +1627,50 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
                 for (int q = 0; q < 8; q++) {
                     const int it = half + q;
                     const int r4 = ((it & 1) << 3) | ((it & 2) << 1) | ((it & 4) >> 1) | ((it & 8) >> 3);
-                    x[(r6 << 4) | r4] = h[q] * (double)v[q];
+                    e[r4] = h[q] * (double)v[q];
                 }
             }
+            tl_fht_twiddles<6>(L(twb), 8, T->fht_tw, lane);
+            tl_fht_head(e, T->fht_tw);
+            tl_fht_store(x, lane, e);
         }
         TL_LANES_END
-        PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
-        TL_LANES_BEGIN
-        tl_fht_twiddles<2>(L(twa), 0, T->fht_tw, lane); tl_fht_twiddles<4>(L(twc), 1, T->fht_tw, lane);
-        tl_fht_pass_first(x, lane);
-        TL_LANES_END
-        TL_LANES_BEGIN tl_fht_twiddles<6>(L(twb), 8, T->fht_tw, lane); tl_fht_pass<2>(x, L(twa), lane); TL_LANES_END
         TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), 39, T->fht_tw, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
         TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
         TL_LANES_BEGIN tl_fht_pass<8>(x, L(twa), lane); TL_LANES_END
         TL_STAMP(sq, 1);
-        // energy + phase (fft.c:1246-1275), unpredictability (psycho_2.c:119-140); ages: new = 1-pass, old = pass
+        // energy + phase (fft.c:1246-1275), unpredictability (psycho_2.c:119-140); ages: new = 1-pass, old = pass.
+        // 64 lines per step: the transform is read through the layout map first, then the step's energies are written in
+        // natural order (their slots hold nothing a later step reads).  The prediction state of the line handled next
+        // is fetched while the current line's transcendentals run.
         const int nw = 1 - pass, old = pass;
+        PV(double, r_o); PV(double, r_n); PV(double, p_o); PV(double, p_n);
         TL_LANES_BEGIN
-        {
-            // the prediction state of the line handled next is fetched while the current line's transcendentals run
-            double r_o = S->r[ch][old][lane], r_n = S->r[ch][nw][lane], p_o = S->phi[ch][old][lane], p_n = S->phi[ch][nw][lane];
-            for (int j = lane; j <= 512; j += 64) {
+        L(r_o) = S->r[ch][old][lane]; L(r_n) = S->r[ch][nw][lane]; L(p_o) = S->phi[ch][old][lane]; L(p_n) = S->phi[ch][nw][lane];
+        TL_LANES_END
+        for (int it = 0; it < 9; it++) {
+            PV(double, xa); PV(double, xb);
+            TL_LANES_BEGIN
+            const int j = lane + 64 * it;
+            L(xa) = j <= 512 ? x[TL_FX(j)] : 0.0;
+            L(xb) = (j >= 1 && j < 512) ? x[TL_FX(1024 - j)] : 0.0;
+            TL_LANES_END
+            TL_LANES_BEGIN
+            const int j = lane + 64 * it;
+            if (j <= 512) {
                 const int jn = j + 64 <= 512 ? j + 64 : j;
                 const double r_o2 = S->r[ch][old][jn], r_n2 = S->r[ch][nw][jn], p_o2 = S->phi[ch][old][jn], p_n2 = S->phi[ch][nw][jn];
                 double e, phi;
-                if (j == 0) { e = x[0] * x[0]; phi = 0.0; }
-                else if (j == 512) { e = x[512] * x[512]; phi = tl_atan2(0.0, x[512]); }
+                if (j == 0) { e = L(xa) * L(xa); phi = 0.0; }
+                else if (j == 512) { e = L(xa) * L(xa); phi = tl_atan2(0.0, L(xa)); }
                 else {
-                    const double a = x[j], b = x[1024 - j];
+                    const double a = L(xa), b = L(xb);
                     e = (a * a + b * b) / 2.0;
                     if (e < 0.0005) { e = 0.0005; phi = 0; }
                     else phi = tl_atan2(-a, b) + 3.14159265358979 / 4;
                 }
-                const double r_prime = 2.0 * r_o - r_n;
-                const double phi_prime = 2.0 * p_o - p_n;
+                const double r_prime = 2.0 * L(r_o) - L(r_n);
+                const double phi_prime = 2.0 * L(p_o) - L(p_n);
                 const double rn = sqrt(e);
                 S->r[ch][nw][j] = rn; S->phi[ch][nw][j] = phi;
                 double sp, cp, spp, cpp;
@@ -1614,11 +1680,11 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
                 const double t2 = rn * sp - r_prime * spp;
                 const double t3 = rn + fabs(r_prime);
                 cw[j] = t3 != 0 ? sqrt(t1 * t1 + t2 * t2) / t3 : 0;
-                x[j] = e;                                           // x[1024-j] belongs to this lane only
-                r_o = r_o2; r_n = r_n2; p_o = p_o2; p_n = p_n2;
+                x[j] = e;
+                L(r_o) = r_o2; L(r_n) = r_n2; L(p_o) = p_o2; L(p_n) = p_n2;
             }
+            TL_LANES_END
         }
-        TL_LANES_END
         TL_STAMP(sq, 2);
         const double *energy = x;
         // grouped energy / weighted unpredictability per partition (psycho_2.c:146-155)
