@@ -472,24 +472,66 @@ TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     TL_STAMP(sq, 4);
     TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
     TL_STAMP(sq, 5);
-    TL_LANES_BEGIN tl_fht_pass<8>(x, L(twa), lane); TL_LANES_END
-    TL_STAMP(sq, 6);
-    // energies (fft.c:1278-1293), 64 lines at a time: read through the layout map, write in natural order.  The writes of
-    // one step touch lines [64*it, 64*it+63], whose slots hold nothing a later step still reads.
-    for (int it = 0; it < 8; it++) {
-        PV(double, ev);
+    // Last pass (k=8) and energies (fft.c:1278-1293) in one go: the eight outputs of a k=8 butterfly are x[i+256q] and
+    // x[256-i+256q], and line j pairs with 1024-j -- so butterfly i holds both members of the pairs of lines i, 256-i, 256+i
+    // and 512-i (the trivial butterfly: lines 0, 128, 256, 384, 512).  The transform is never written back: every input is
+    // read first (the energies go to natural positions, which are other lanes' inputs), then each lane squares its own pairs.
+    {
+        constexpr int k1 = 256, kx = 128;
+        constexpr int q1 = TL_FX(256), q2 = TL_FX(512), q3 = TL_FX(768);
+        PA(double, fv, 8); PA(double, gv, 8);
         TL_LANES_BEGIN
-        const int i = lane + 64 * it;
-        double e;
-        if (i == 0) e = x[0] * x[0];
-        else { const double a = x[TL_FX(i)], b = x[TL_FX(1024 - i)]; e = (a * a + b * b) / 2.0; }
-        L(ev) = e;
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int it = 0; it < 2; it++) {
+            const int g = lane + 64 * it;                            // general butterflies i = 1 + g (g < 127); g = 127: the trivial one
+            const int F = g < 127 ? TL_FX(1 + g) : 0, G = g < 127 ? TL_FX(k1 - 1 - g) : TL_FX(kx);
+            L(fv)[4 * it] = x[F]; L(fv)[4 * it + 1] = x[F ^ q1]; L(fv)[4 * it + 2] = x[F ^ q2]; L(fv)[4 * it + 3] = x[F ^ q3];
+            L(gv)[4 * it] = x[G]; L(gv)[4 * it + 1] = x[G ^ q1]; L(gv)[4 * it + 2] = x[G ^ q2]; L(gv)[4 * it + 3] = x[G ^ q3];
+        }
         TL_LANES_END
-        TL_LANES_BEGIN x[lane + 64 * it] = L(ev); TL_LANES_END
+        TL_LANES_BEGIN
+        const double SQRT2 = 1.4142135623730951454746218587388284504414;
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int it = 0; it < 2; it++) {
+            const int g = lane + 64 * it;
+            const double fi0 = L(fv)[4 * it], fi1 = L(fv)[4 * it + 1], fi2 = L(fv)[4 * it + 2], fi3 = L(fv)[4 * it + 3];
+            const double gi0 = L(gv)[4 * it], gi1 = L(gv)[4 * it + 1], gi2 = L(gv)[4 * it + 2], gi3 = L(gv)[4 * it + 3];
+            if (g < 127) {
+                const int i = 1 + g;
+                const double c1 = L(twa)[4 * it], s1 = L(twa)[4 * it + 1], c2 = L(twa)[4 * it + 2], s2 = L(twa)[4 * it + 3];
+                double a, b2, g0, f0, f1, g1, f2, g2, f3, g3;
+                b2 = s2 * fi1 - c2 * gi1; a = c2 * fi1 + s2 * gi1;
+                f1 = fi0 - a; f0 = fi0 + a; g1 = gi0 - b2; g0 = gi0 + b2;
+                b2 = s2 * fi3 - c2 * gi3; a = c2 * fi3 + s2 * gi3;
+                f3 = fi2 - a; f2 = fi2 + a; g3 = gi2 - b2; g2 = gi2 + b2;
+                b2 = s1 * f2 - c1 * g3; a = c1 * f2 + s1 * g3;
+                const double o_f2 = f0 - a, o_f0 = f0 + a, o_g3 = g1 - b2, o_g1 = g1 + b2;     // x[i+512], x[i], x[1024-i], x[512-i]
+                b2 = c1 * g2 - s1 * f3; a = s1 * g2 + c1 * f3;
+                const double o_g2 = g0 - a, o_g0 = g0 + a, o_f3 = f1 - b2, o_f1 = f1 + b2;     // x[768-i], x[256-i], x[i+768], x[i+256]
+                // E[j] = (x[j]^2 + x[1024-j]^2) / 2 with a = x[j] first, as in the reference
+                x[i] = (o_f0 * o_f0 + o_g3 * o_g3) / 2.0;
+                x[256 - i] = (o_g0 * o_g0 + o_f3 * o_f3) / 2.0;
+                x[256 + i] = (o_f1 * o_f1 + o_g2 * o_g2) / 2.0;
+                x[512 - i] = (o_g1 * o_g1 + o_f2 * o_f2) / 2.0;
+            } else if (g == 127) {
+                double f1 = fi0 - fi1, f0 = fi0 + fi1, f3 = fi2 - fi3, f2 = fi2 + fi3;
+                const double o_f2 = f0 - f2, o_f0 = f0 + f2, o_f3 = f1 - f3, o_f1 = f1 + f3;     // x[512], x[0], x[768], x[256]
+                double g1 = gi0 - gi1, g0 = gi0 + gi1, g3 = SQRT2 * gi3, g2 = SQRT2 * gi2;
+                const double o_g2 = g0 - g2, o_g0 = g0 + g2, o_g3 = g1 - g3, o_g1 = g1 + g3;     // x[640], x[128], x[896], x[384]
+                x[0] = o_f0 * o_f0;
+                x[512] = o_f2 * o_f2;
+                x[256] = (o_f1 * o_f1 + o_f3 * o_f3) / 2.0;
+                x[128] = (o_g0 * o_g0 + o_g3 * o_g3) / 2.0;
+                x[384] = (o_g1 * o_g1 + o_g2 * o_g2) / 2.0;
+            }
+        }
+        TL_LANES_END
     }
-    TL_LANES_BEGIN
-    if (lane == 0) { const double v = x[TL_FX(512)]; x[512] = v * v; }
-    TL_LANES_END
+    TL_STAMP(sq, 6);
 }
 
 // ------------------------------------------------------------------------------------------
