@@ -70,13 +70,29 @@ else:
 print(n / dt)
 """ % (FS, PSY, MODE, KBPS, FS, MODE, KBPS, PSY)
     kind = "reference" if ref_so.exists() else "port"
+    cmd = [sys.executable, "-c", child, str(ref_so) if ref_so.exists() else "", str(ora_so)]
     try:
-        r = subprocess.run([sys.executable, "-c", child, str(ref_so) if ref_so.exists() else "", str(ora_so), str(nframes)],
-                           capture_output=True, text=True, timeout=120)
+        r = subprocess.run(cmd + [str(nframes)], capture_output=True, text=True, timeout=120)
         fps = float(r.stdout.strip().splitlines()[-1])
     except Exception as ex:  # noqa: BLE001
         return {"value": None, "unit": "frames/s", "cores": 1, "kind": kind, "sample": f"failed: {ex}"}
-    return {"value": round(fps, 1), "unit": "frames/s", "cores": 1, "kind": kind,
+    # SURVEY 8(d): also the whole host -- one independent encoder process per core (the reference is a process-global
+    # singleton), half the sample each, rates summed
+    allc = None
+    try:
+        ncpu = min(len(os.sched_getaffinity(0)), 32)
+        procs = [subprocess.Popen(cmd + [str(nframes // 2)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                 for _ in range(ncpu)]
+        rates = [float(p_.communicate(timeout=180)[0].strip().splitlines()[-1]) for p_ in procs]
+        model = ""
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+        allc = {"value": round(sum(rates), 1), "cores": ncpu, "cpu": model}
+    except Exception as ex:  # noqa: BLE001
+        allc = {"value": None, "error": str(ex)}
+    return {"value": round(fps, 1), "unit": "frames/s", "cores": 1, "kind": kind, "all_cores": allc,
             "sample": f"{nframes} frames of one stream (seed 0, tones+noise), {FS} Hz mode '{MODE}' {KBPS} kbps psy {PSY}, "
                       f"{'libtoolame-dab compiled from the reference sources' if kind == 'reference' else 'oracle/mp2_oracle.c'}, gcc -O2, 1 thread"}
 

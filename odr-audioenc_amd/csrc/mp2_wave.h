@@ -286,6 +286,20 @@ TL_FN void tl_masker_consts(TlMasker *TL_RESTRICT mk, const double *TL_RESTRICT 
     mk[t].g = 0.4 * x + 6;
     mk[t].ns = -(17 - 0.15 * x);
 }
+// s / d given r = RN(1/d): two residual corrections with fused multiply-adds.  After the first, q is a faithful
+// quotient (error ~2u^2 before its rounding); for a faithful q and the correctly rounded reciprocal the second yields the
+// correctly rounded quotient (Markstein's theorem; its one exception, a divisor whose significand is all ones, does not
+// occur among the scalefactors -- tests/test_emu_parity.py checks the table and 10^7 quotients incl. near-midpoint ones).
+// No scaling: the encoder's operands are far from the exponent limits.  A zero dividend may come out as +0 where the
+// division gives -0; the quantiser adds a non-zero constant next, so no bit depends on it.
+TL_FN double tl_div_by(double s, double d, double r)
+{
+    double q = s * r;
+    double e = __builtin_fma(-q, d, s);
+    q = __builtin_fma(e, r, q);
+    e = __builtin_fma(-q, d, s);
+    return __builtin_fma(e, r, q);
+}
 TL_FN unsigned tl_sf_index(const double *TL_RESTRICT sf, double cur_max)
 {   // encode_new.c:208-218
     unsigned i = 32;
@@ -1841,8 +1855,8 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
                 L(xb)[8 * b + ((0 - j) & 7)] = c < nch ? w.u.fbk.pcm[c][TL_HIST + 32 * b + 31 - yb - 64 * j] : 0;
             }
         TL_LANES_END
-        double (*yp)[2][32] = (double (*)[2][32])w.px;              // [TL_FB_BATCH][2][32] window outputs of the batch
-        static_assert(offsetof(TlWaveLds, cinfo) + sizeof(w.cinfo) - offsetof(TlWaveLds, px) >= sizeof(double) * TL_FB_BATCH * 64, "filterbank scratch");
+        double (*yp)[2][34] = (double (*)[2][34])w.px;              // [TL_FB_BATCH][2][32 (+2: the four addresses a matrixing read touches sit on different banks)]
+        static_assert(offsetof(TlWaveLds, cinfo) + sizeof(w.cinfo) - offsetof(TlWaveLds, px) >= sizeof(double) * TL_FB_BATCH * 68, "filterbank scratch");
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
@@ -2234,7 +2248,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         const bool any_joint = (nch == 2) && jsbound < sblimit;      // joint-coded subbands exist in this frame
         // per-lane constants of the frame: quantiser class and its coefficients, the three scalefactors
         PV(int, q_ba); PV(int, q_nb); PV(int, q_grp); PV(int, q_s2n); PV(int, q_steps);
-        PV(double, q_a); PV(double, q_b); PV(double, q_s2nf); PA(double, q_sf, 3);
+        PV(double, q_a); PV(double, q_b); PV(double, q_s2nf); PA(double, q_sf, 3); PA(double, q_rsf, 3);
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
         const bool own = sb < sblimit && c < (sb < jsbound ? nch : 1);
@@ -2244,7 +2258,10 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         const bool joint = any_joint && sb >= jsbound;
         L(q_ba) = ba; L(q_nb) = (int)((qi >> 5) & 31u); L(q_grp) = ((qi >> 10) & 1u) ? 3 : 1; L(q_s2n) = T->steps2n[q]; L(q_steps) = T->steps[q];
         L(q_a) = T->qa[q]; L(q_b) = T->qb[q]; L(q_s2nf) = T->steps2n_f[q];
-        for (int gr = 0; gr < 3; gr++) L(q_sf)[gr] = B->scalefactor[joint ? w.jscale[gr][sb] : L(scf)[gr]];
+        for (int gr = 0; gr < 3; gr++) {
+            L(q_sf)[gr] = B->scalefactor[joint ? w.jscale[gr][sb] : L(scf)[gr]];
+            L(q_rsf)[gr] = 1.0 / L(q_sf)[gr];                          // one division per granule instead of twelve
+        }
         TL_LANES_END
 #ifndef TL_EMULATE
 #pragma unroll
@@ -2265,11 +2282,11 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             unsigned v[3] = {0, 0, 0};
             if (L(q_ba)) {
                 const bool joint = any_joint && sb >= jsbound;
-                const double sfv = L(q_sf)[gr];
+                const double sfv = L(q_sf)[gr], rsf = L(q_rsf)[gr];
                 for (int x = 0; x < 3; x++) {
                     double s = L(smp)[gr * 12 + j0 + x];
                     if (joint) s = .5 * (s + L(oth)[x]);
-                    double d = s / sfv;
+                    double d = tl_div_by(s, sfv, rsf);                   // == s / sfv (encode_new.c:507,511)
                     d = d * L(q_a) + L(q_b);
                     unsigned sig = 1;
                     if (!(d >= 0)) { sig = 0; d += 1.0; }

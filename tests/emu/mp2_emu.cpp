@@ -131,4 +131,16 @@ int emu_sizeof_lds(void) { return (int)sizeof(TlWaveLds); }
 double emu_log10(double x) { return tl_log10(x); }
 double emu_log10_pn(double x) { return tl_log10_pn(x); }
 double emu_pow10(double x) { return tl_pow10(x); }
+void emu_scalefactors(double *out) { static TlTables T; tl_build_tables(&T); for (int i = 0; i < 64; i++) out[i] = T.scalefactor[i]; }
+// tl_div_by against the division it replaces; returns the number of mismatching quotients among n (s[i], d[i]) pairs
+long emu_div_by_check(const double *s, const double *d, long n)
+{
+    long bad = 0;
+    for (long i = 0; i < n; i++) {
+        const double q = tl_div_by(s[i], d[i], 1.0 / d[i]), t = s[i] / d[i];
+        uint64_t a, b; memcpy(&a, &q, 8); memcpy(&b, &t, 8);
+        if (a != b && !(t == 0.0 && q == 0.0)) bad++;
+    }
+    return bad;
+}
 }

@@ -1,6 +1,8 @@
 """Host logic: the wave-per-stream kernel source (csrc/mp2_wave.h) executed by the lane-loop
 emulation (tests/emu) against the oracle and the golden vectors -- bit-exact bytes, integer taps and
 fp64 filterbank taps; SMR within 1e-9 dB (device log10 vs glibc).  CPU only."""
+import math
+
 import numpy as np
 import pytest
 
@@ -92,6 +94,66 @@ def test_emulated_log10_pow10_accuracy():
         a, b = L.emu_pow10(float(x)), math.pow(10.0, float(x))
         worst = max(worst, abs(int(np.float64(a).view(np.int64)) - int(np.float64(b).view(np.int64))))
     assert worst <= 1
+
+
+def test_quantiser_division():
+    """tl_div_by (reciprocal + two fused corrections) == IEEE division for every scalefactor divisor: random dividends over
+    the subband-sample range, dividends that put the quotient next to a representable number, and dividends that put it
+    next to a rounding midpoint (the hard cases of any division algorithm)."""
+    import ctypes as C
+    L = E.lib()
+    L.emu_div_by_check.restype = C.c_long
+    L.emu_div_by_check.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+    tab = (C.c_double * 64)()
+    L.emu_scalefactors(tab)                                         # the encoder's own table (encode_new.c:65-83)
+    sf = np.array(tab)
+    assert sf[0] == 2.0 and sf[63] == 1e-20
+    # Markstein's exception: no divisor has an all-ones significand
+    assert not np.any((sf.view(np.uint64) & np.uint64((1 << 52) - 1)) == np.uint64((1 << 52) - 1))
+    rng = np.random.default_rng(7)
+    n = 100000
+
+    def hardest(d):
+        """Dividends whose quotient by d lies within ~2^-106 (relative) of a rounding midpoint: S * 2^53 = (2M+1) * D + t
+        for small t, solved for the odd 2M+1 modulo a power of two (D = integer significand of d)."""
+        m, e = math.frexp(d)
+        D = int(m * (1 << 53))
+        z = (D & -D).bit_length() - 1
+        Dp, mod = D >> z, 1 << (53 - z)
+        inv = pow(Dp, -1, mod)
+        out = []
+        for tp in range(-15, 16, 2):
+            r = (-tp * inv) % mod
+            for k in range(0, 1 << z if z < 6 else 64):
+                o = r + k * mod
+                if not (o & 1):
+                    continue
+                o |= 1 << 53                                        # 2M+1 in [2^53, 2^54)
+                num = o * D + (tp << z)
+                if num % (1 << 53):
+                    continue
+                S = num >> 53
+                while S >= (1 << 53) and not (S & 1):
+                    S >>= 1
+                if (1 << 52) <= S < (1 << 53):
+                    out.append(math.ldexp(float(S), -52))
+        return out
+
+    nhard = 0
+    for d in sf:
+        s_rand = rng.uniform(-2.5, 2.5, n) * 10.0 ** rng.uniform(-12, 0, n)
+        q = rng.uniform(0.5, 4.0, n) * rng.choice([-1.0, 1.0], n)
+        near_rep = np.nextafter(q * d, rng.choice([-np.inf, np.inf], n))      # quotient within an ulp of q
+        half = (np.nextafter(np.abs(q), np.inf) - np.abs(q)) / 2
+        mid = (np.abs(q).astype(np.longdouble) + half.astype(np.longdouble)) * np.sign(q).astype(np.longdouble)
+        near_mid = (mid * np.longdouble(d)).astype(np.float64)              # quotient within an ulp-fraction of a midpoint
+        hard = np.array(hardest(float(d)), dtype=np.float64)
+        nhard += len(hard)
+        s_all = np.ascontiguousarray(np.concatenate([s_rand, q * d, near_rep, near_mid, np.nextafter(near_mid, np.inf),
+                                                     np.nextafter(near_mid, -np.inf), hard, -hard]))
+        d_all = np.full(s_all.shape, d)
+        assert L.emu_div_by_check(s_all.ctypes.data, d_all.ctypes.data, len(s_all)) == 0
+    assert nhard > 300
 
 
 def test_emulated_illegal_configs():
