@@ -336,6 +336,10 @@ int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, 
         for (int b = 0; b + 1 < C->p1_ncb; b++)
             for (int j = C->p1_cbound[b]; j < C->p1_cbound[b + 1] && j < 512; j++)
                 C->p1_lineinfo[j] = (uint32_t)b | ((uint32_t)C->p1_cbound[b] << 8) | ((uint32_t)C->p1_cbound[b + 1] << 20);
+        for (int j = 0; j < 512; j++) {
+            const uint32_t info = C->p1_lineinfo[j];
+            C->p1_linerw[j] = info ? 1.0 / (double)((int)(info >> 20) - (int)((info >> 8) & 0xfffu)) : 0.0;
+        }
         // resolve the sequential minimum-mask walk (psycho_1.c:541-559) into per-subband row ranges
         int j = 1;
         for (int sb = 0; sb < C->sblimit; sb++) {

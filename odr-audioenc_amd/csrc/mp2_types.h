@@ -67,6 +67,7 @@ struct TlConfig {
     uint8_t p1_lineband[520];    // critical band of each FFT line (index into p1_cbound), 255 outside the bands
     double p1_lbark[512], p1_lhear[512];   // p1_bark / p1_hear of the table row each FFT line maps to (one load instead of two dependent ones)
     uint32_t p1_lineinfo[512];   // per FFT line inside the bands: band | lo << 8 | hi << 20 (lo/hi = first line of the band / of the next); 0 outside
+    double p1_linerw[512];       // 1 / (hi - lo) of the line's band, correctly rounded (the weight division, psycho_1.c:364-366, as tl_div_by); 0 outside
     int16_t p1_mm_j0[32];        // minimum-mask walk (psycho_1.c:541-559) resolved per subband:
     int16_t p1_mm_n[32];         //   first table row, number of rows (0 => use hear[sub-1])
     // psy model 3 (psycho_3.c:434-512)

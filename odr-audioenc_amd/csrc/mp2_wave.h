@@ -289,7 +289,8 @@ TL_FN void tl_masker_consts(TlMasker *TL_RESTRICT mk, const double *TL_RESTRICT 
 // s / d given r = RN(1/d): two residual corrections with fused multiply-adds.  After the first, q is a faithful
 // quotient (error ~2u^2 before its rounding); for a faithful q and the correctly rounded reciprocal the second yields the
 // correctly rounded quotient (Markstein's theorem; its one exception, a divisor whose significand is all ones, does not
-// occur among the scalefactors -- tests/test_emu_parity.py checks the table and 10^7 quotients incl. near-midpoint ones).
+// occur among the divisors used: scalefactors and critical-band widths -- tests/test_emu_parity.py checks them and
+// 10^8 quotients incl. the hardest near-midpoint ones).
 // No scaling: the encoder's operands are far from the exponent limits.  A zero dividend may come out as +0 where the
 // division gives -0; the quantiser adds a non-zero constant next, so no bit depends on it.
 TL_FN double tl_div_by(double s, double d, double r)
@@ -738,12 +739,12 @@ TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const 
     {
         double *vt = w.u.fft, *vp = w.u.fft + 520;
         int nvalid = 0;
-        PA(uint32_t, linfo, 8);                                     // the table reads of all eight chunks in one batch
+        PA(uint32_t, linfo, 8); PA(double, lrw, 8);                 // the table reads of all eight chunks in one batch
         TL_LANES_BEGIN
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int c8 = 0; c8 < 8; c8++) L(linfo)[c8] = C->p1_lineinfo[64 * c8 + lane];
+        for (int c8 = 0; c8 < 8; c8++) { L(linfo)[c8] = C->p1_lineinfo[64 * c8 + lane]; L(lrw)[c8] = C->p1_linerw[64 * c8 + lane]; }
         TL_LANES_END
 #ifndef TL_EMULATE
 #pragma unroll
@@ -758,7 +759,7 @@ TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const 
             if (info) {                                             // line inside the bands
                 p = w.px[j];
                 v = w.ptype[j] != TL_T_TONE && p != TL_DBMIN;
-                t = 1073741824 * energy[j] * (double)(j - lo) / (double)(hi - lo);
+                t = tl_div_by(1073741824 * energy[j] * (double)(j - lo), (double)(hi - lo), L(lrw)[base >> 6]);   // == num / (hi - lo)
             }
             L(ok) = v; L(tv) = t; L(pvv) = p; L(bnd) = (info && j == lo) ? (int)(info & 0xffu) : -1;
             TL_LANES_END
