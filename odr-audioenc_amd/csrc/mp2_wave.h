@@ -243,7 +243,7 @@ struct TlWaveLds {
 #define TL_MK_BARK(w) ((w).u.fft + TL_MASKER_MAX)      /* [TL_MASKER_MAX] */
 #define TL_LTG(w) ((w).u.fft + 2 * TL_MASKER_MAX)      /* [136] */
 // per-masker constants of the threshold loops, computed once per masker instead of once per (masker, line)
-struct alignas(16) TlMasker { double bark, av, g, ns; };   // av = level term (psycho_1.c:493,512), g = 0.4x+6, ns = -(17-0.15x)
+struct alignas(16) TlMasker { double bark, av, g, n; };    // av = level term (psycho_1.c:493,512), g = 0.4x+6, n = 17-0.15x
 #define TL_MK4(w) ((TlMasker *)((w).u.fft + 2 * TL_MASKER_MAX + 136))   /* [TL_MASKER_MAX], ends at fft[904] */
 
 
@@ -267,16 +267,26 @@ TL_FN uint64_t tl_mnr_key(double mnr)
     u = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
     return 999999.0 > mnr ? u : ~0ull;
 }
-TL_FN double tl_mask_vf(double dz, double g, double ns)
-{   // psycho_1.c:494-503 == psycho_3.c:359-369 with g = 0.4*x + 6 and ns = -(17 - 0.15*x):
-    //   dz < -1: 17*(dz+1) - g     dz < 0: g*dz     dz < 1: -17*dz     else: -(dz-1)*(17-0.15x) - 17
-    // all four are A*(dz+B) - C with the same roundings (adding -0.0 / subtracting +0.0 changes no bit, negating a
-    // factor only flips the product's sign), so the operands are selected and one expression is evaluated.
-    const bool c0 = dz < -1, c1 = dz < 0, c2 = dz < 1;
-    double A = TL_SELECT(c2, -17.0, ns), Bc = TL_SELECT(c2, -0.0, -1.0), Cc = TL_SELECT(c2, 0.0, 17.0);
-    A = TL_SELECT(c1, g, A);
-    A = TL_SELECT(c0, 17.0, A); Bc = TL_SELECT(c0, 1.0, Bc); Cc = TL_SELECT(c0, g, Cc);
-    return A * (dz + Bc) - Cc;
+// One step of a threshold chain: x (+) the masking of one masker at distance dz bark, if it reaches the line at all
+// (psycho_1.c:489-517 == psycho_3.c:352-394).  The reference's masking function
+//   dz < -1: 17*(dz+1) - g     dz < 0: g*dz     dz < 1: -17*dz     else: -(dz-1)*n - 17        (g = 0.4x+6, n = 17-0.15x)
+// is, with a = |dz|,  -(A*(a - B) + C):  inside |dz| < 1  A = (dz<0 ? g : 17), B = C = 0;  outside  A = (dz<0 ? 17 : n), B = 1,
+// C = (dz<0 ? g : 17) -- the same roundings (negating an operand or a result changes no rounding; adding or subtracting a
+// zero changes no bit; at dz = -1 and dz = 1 both neighbouring pieces give the same value), and level + vf = level - (...).
+// C is the inside A times B (a product with 0.0 or 1.0 is exact): 64-bit selects cost two instructions, a product one.
+// A masker out of reach (dz outside [-3, 8)) enters the dB sum as a level below -65536 dB, which leaves the sum as it
+// is (|difference| > 99 dB: the reference returns the larger operand, tl_add_db adds its -0.0 entry).
+TL_FN double tl_mask_step(const double *TL_RESTRICT db, double x, double dz, double av, double g, double n)
+{
+    const double ad = __builtin_fabs(dz);
+    const bool s = dz < 0.0, o = ad >= 1.0;
+    const double G = TL_SELECT(s, g, 17.0), H = TL_SELECT(s, 17.0, n);
+    const double A = TL_SELECT(o, H, G), Bc = TL_SELECT(o, 1.0, 0.0);
+    const double term = av - (A * (ad - Bc) + G * Bc);
+    const bool in = dz >= -3.0 && dz < 8.0;
+    const uint64_t tu = tl_d2u(term);
+    const uint32_t hi = TL_SELECT(in, (uint32_t)(tu >> 32), 0xC0F00000u);
+    return tl_add_db(db, x, tl_u2d(((uint64_t)hi << 32) | (tu & 0xffffffffull)));
 }
 TL_FN void tl_masker_consts(TlMasker *TL_RESTRICT mk, const double *TL_RESTRICT mx, const double *TL_RESTRICT mbk, int t, bool tonal)
 {
@@ -284,7 +294,7 @@ TL_FN void tl_masker_consts(TlMasker *TL_RESTRICT mk, const double *TL_RESTRICT 
     mk[t].bark = mb;
     mk[t].av = tonal ? -1.525 - 0.275 * mb - 4.5 + x : -1.525 - 0.175 * mb - 0.5 + x;
     mk[t].g = 0.4 * x + 6;
-    mk[t].ns = -(17 - 0.15 * x);
+    mk[t].n = 17 - 0.15 * x;
 }
 // s / d given r = RN(1/d): two residual corrections with fused multiply-adds.  After the first, q is a faithful
 // quotient (error ~2u^2 before its rounding); for a faithful q and the correctly rounded reciprocal the second yields the
@@ -908,23 +918,35 @@ TL_FN void tl_psy1_thresholds(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, 
             const TlMasker *mk = TL_MK4(w);
             const int nm = ntone + nnoise;
             int a0 = nm, a1 = -1, b0 = nm, b1 = -1;                 // spans inside the tone part and inside the noise part
-            for (int t = 0; t < nm; t++) {
-                const double mb = mk[t].bark;
-                const bool r = mb > blo && mb <= bhi;               // superset of both lines' (-3 <= dz < 8)
-                const bool rt = r && t < ntone, rn = r && t >= ntone;
-                a0 = (rt && t < a0) ? t : a0; a1 = rt ? t : a1;
-                b0 = (rn && t < b0) ? t : b0; b1 = rn ? t : b1;
+            for (int tb = 0; tb < nm; tb += 32) {                   // 32 maskers -> one hit mask, eight barks per LDS round trip
+                uint32_t m = 0;
+                for (int t8 = 0; t8 < 32 && tb + t8 < nm; t8 += 8) {
+                    double mb[8];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                    for (int q = 0; q < 8; q++) mb[q] = mk[tb + t8 + q].bark;      // entries past nm (< TL_MASKER_MAX) are masked below
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                    for (int q = 0; q < 8; q++) m |= (mb[q] > blo && mb[q] <= bhi) ? 1u << (t8 + q) : 0u;      // superset of both lines' (-3 <= dz < 8)
+                }
+                const int left = nm - tb, tleft = ntone - tb;
+                m &= left >= 32 ? ~0u : (1u << left) - 1u;
+                const uint32_t tmask = tleft >= 32 ? ~0u : tleft <= 0 ? 0u : (1u << tleft) - 1u;
+                const uint32_t mt = m & tmask, mn = m & ~tmask;
+                const int ft = tb + __builtin_ctz(mt | 0x80000000u), lt = tb + 31 - __builtin_clz(mt | 1u);
+                const int fn = tb + __builtin_ctz(mn | 0x80000000u), ln = tb + 31 - __builtin_clz(mn | 1u);
+                a0 = (mt && ft < a0) ? ft : a0; a1 = mt ? lt : a1;
+                b0 = (mn && fn < b0) ? fn : b0; b1 = mn ? ln : b1;
             }
             double x0 = TL_DBMIN, x1 = TL_DBMIN;
             for (int part = 0; part < 2; part++) {
                 const int t_first = part ? b0 : a0, t_last = part ? b1 : a1;
                 for (int t = t_first; t <= t_last; t++) {
-                    const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
-                    const double dz0 = bk0 - mb, dz1 = bk1 - mb;
-                    const double n0 = tl_add_db(db, x0, av + tl_mask_vf(dz0, g, ns));
-                    const double n1 = tl_add_db(db, x1, av + tl_mask_vf(dz1, g, ns));
-                    x0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : x0;
-                    x1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : x1;
+                    const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, n = mk[t].n;
+                    x0 = tl_mask_step(db, x0, bk0 - mb, av, g, n);
+                    x1 = tl_mask_step(db, x1, bk1 - mb, av, g, n);
                 }
             }
             TL_LTG(w)[k0] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k0] : C->p1_hear[k0] - 12.0, x0);
@@ -1525,20 +1547,14 @@ TL_FN void tl_psy3_back(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const 
         double lt0 = TL_DBMIN, ln0 = TL_DBMIN, lt1 = TL_DBMIN, ln1 = TL_DBMIN;
         const TlMasker *mk = TL_MK4(w);
         for (int t = 0; t < ntone; t++) {
-            const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
-            const double dz0 = b0 - mb, dz1 = b1 - mb;
-            const double n0 = tl_add_db(db, lt0, av + tl_mask_vf(dz0, g, ns));
-            const double n1 = tl_add_db(db, lt1, av + tl_mask_vf(dz1, g, ns));
-            lt0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : lt0;
-            lt1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : lt1;
+            const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, n = mk[t].n;
+            lt0 = tl_mask_step(db, lt0, b0 - mb, av, g, n);
+            lt1 = tl_mask_step(db, lt1, b1 - mb, av, g, n);
         }
         for (int t = ntone; t < ntone + nnoise; t++) {
-            const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
-            const double dz0 = b0 - mb, dz1 = b1 - mb;
-            const double n0 = tl_add_db(db, ln0, av + tl_mask_vf(dz0, g, ns));
-            const double n1 = tl_add_db(db, ln1, av + tl_mask_vf(dz1, g, ns));
-            ln0 = (dz0 >= -3.0 && dz0 < 8.0) ? n0 : ln0;
-            ln1 = (dz1 >= -3.0 && dz1 < 8.0) ? n1 : ln1;
+            const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, n = mk[t].n;
+            ln0 = tl_mask_step(db, ln0, b0 - mb, av, g, n);
+            ln1 = tl_mask_step(db, ln1, b1 - mb, av, g, n);
         }
         const double g0 = tl_add_db(db, ln0, lt0), g1 = tl_add_db(db, ln1, lt1);
         TL_LTG(w)[j0] = tl_add_db(db, C->br_per_ch < 96 ? ath[line0] : ath[line0] - 12.0, g0);
@@ -1555,10 +1571,8 @@ TL_FN void tl_psy3_back(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const 
         const int t0 = lane < 8 ? 0 : ntone, t1 = lane < 8 ? ntone : ntone + nnoise;
         double acc = TL_DBMIN;
         for (int t = t0; t < t1; t++) {
-            const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, ns = mk[t].ns;
-            const double dz = bj - mb;
-            const double n = tl_add_db(db, acc, av + tl_mask_vf(dz, g, ns));
-            acc = (dz >= -3.0 && dz < 8.0) ? n : acc;
+            const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, n = mk[t].n;
+            acc = tl_mask_step(db, acc, bj - mb, av, g, n);
         }
         w.nsum[lane] = acc;
     }
