@@ -63,6 +63,7 @@ TL_FN void tlh_incl_xscan_u32(uint32_t (&d)[64], const uint32_t (&v)[64]) { uint
 #define TL_RESTRICT
 #define TL_SELECT(c, a, b) ((c) ? (a) : (b))
 #define TL_LAUNDER(p) ((void)0)
+#define TL_KEEP(x) ((void)0)
 #else
 #define TL_FN __device__ __forceinline__
 #define TL_LANES_BEGIN { int lane_ = (int)(threadIdx.x & 63u); asm volatile("" : "+v"(lane_)); __builtin_assume(lane_ >= 0 && lane_ < 64); const int lane = lane_;
@@ -181,6 +182,7 @@ TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
 #define TL_READLANE_I32(name, l) __builtin_amdgcn_readlane(name, l)
 #define TL_RESTRICT __restrict__
 #define TL_SELECT(c, a, b) (__builtin_unpredictable(c) ? (a) : (b))      /* a v_cndmask, never a divergent branch */
+#define TL_KEEP(x) asm volatile("" : : "v"(x))             /* x is computed (a load: issued) here, not sunk into a later branch */
 #define TL_LAUNDER(p) asm volatile("" : "+s"(p))       /* keeps loads through p inside the frame loop (no hoisting into long-lived VGPRs) */
 #endif
 
@@ -582,17 +584,23 @@ TL_FN void tl_cand_chunk(TlWaveLds &w, int c8, int &ncand)
     const int i = 64 * c8 + lane;
     const bool inr = i >= 2 && i < 500;
     const int ii = inr ? i : 16;
-    const double pk = w.px[ii], l1 = w.px[ii - 1], r1 = w.px[ii + 1];
-    bool cnd = inr && pk > l1 && (PSY3 ? pk > r1 : pk >= r1);
+    // every neighbour is read before the first test (TL_KEEP: otherwise the compiler reads each one only if the
+    // tests so far passed -- a chain of dependent LDS round trips)
+    double a[RMAX + 1], b[RMAX + 1];
+    const double pk = w.px[ii];
+#pragma unroll
+    for (int j = 1; j <= RMAX; j++) { a[j] = w.px[ii + j]; b[j] = w.px[ii - j < 0 ? 0 : ii - j]; }
+#pragma unroll
+    for (int j = 1; j <= RMAX; j++) { TL_KEEP(a[j]); TL_KEEP(b[j]); }
+    bool cnd = inr && pk > b[1] && (PSY3 ? pk > a[1] : pk >= a[1]);
     const int run = PSY3 ? tl_run_psy3(ii) : tl_run_psy1(ii);
     const double max = pk - 7;
     uint32_t r = (uint32_t)i;
 #pragma unroll
     for (int j = 2; j <= RMAX; j++) {
-        const double a = w.px[ii + j], b = w.px[ii - j < 0 ? 0 : ii - j];
         const bool in = j <= run;
-        const bool fa = PSY3 ? (pk - a) < 7.0 : max < a;
-        const bool fb = PSY3 ? (pk - b) < 7.0 : max < b;
+        const bool fa = PSY3 ? (pk - a[j]) < 7.0 : max < a[j];
+        const bool fb = PSY3 ? (pk - b[j]) < 7.0 : max < b[j];
         cnd = cnd && !(in && fa);
         r |= (in && fb) ? 1u << (10 + j - 2) : 0u;
     }
