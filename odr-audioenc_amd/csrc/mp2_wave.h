@@ -569,6 +569,14 @@ TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
 // decided in parallel from the original spectrum; the left half depends on which earlier candidates
 // were confirmed and is resolved by a short wave-uniform walk over the records.
 
+// power density in dB of one line (psycho_1.c:241-248, psycho_3.c:152-160), straight-line so that several lines' logarithms
+// (long dependent chains) can be in flight together
+TL_FN double tl_power_db(double e)
+{
+    const bool tiny = e < 1E-20;
+    const double v = 10 * tl_log10_pn(TL_SELECT(tiny, 1.0, e)) + TL_POWERNORM;
+    return TL_SELECT(tiny, -200.0 + TL_POWERNORM, v);
+}
 TL_FN int tl_run_psy1(int c) { return (c < 3 || c > 500) ? 0 : c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 12; }   // psycho_1.c:289-298
 TL_FN int tl_run_psy3(int c) { return c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 12; }                            // psycho_3.c:212-215
 
@@ -636,11 +644,25 @@ TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const 
     // buffer keeps those reads off each other's LDS banks.  Only subbands below sblimit (<= 30) are ever used.
     double *espk = w.u.fft + 513;
     TL_LANES_BEGIN
-    for (int i = lane; i < 512; i += 64) {
-        double e = energy[i];
-        w.px[i] = e < 1E-20 ? -200.0 + TL_POWERNORM : 10 * tl_log10_pn(e) + TL_POWERNORM;
-        w.ptype[i] = 0;
-        if (i < 480) espk[17 * (i >> 4) + (i & 15)] = 1073741824 * e;
+    for (int i0 = lane; i0 < 512; i0 += 256) {                     // four lines per lane at a time
+        double e[4], v[4];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int q = 0; q < 4; q++) e[q] = energy[i0 + 64 * q];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int q = 0; q < 4; q++) v[q] = tl_power_db(e[q]);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int q = 0; q < 4; q++) {
+            const int i = i0 + 64 * q;
+            w.px[i] = v[q];
+            w.ptype[i] = 0;
+            if (i < 480) espk[17 * (i >> 4) + (i & 15)] = 1073741824 * e[q];
+        }
     }
     TL_LANES_END
     TL_LANES_BEGIN
@@ -1294,18 +1316,34 @@ TL_FN int tl_psy3_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlo
     TL_LANES_BEGIN
     if (lane < 32) w.nsum[lane] = C->scale_db[w.minidx[ch][lane]];    // one table round trip for all subbands (nsum is free here)
     TL_LANES_END
+    PA(double, pxa, 8);
+    TL_LANES_BEGIN
+    for (int h = 0; h < 2; h++) {                                   // four lines per lane at a time
+        double e[4], v[4];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int q = 0; q < 4; q++) e[q] = energy[lane + 64 * (4 * h + q)];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int q = 0; q < 4; q++) v[q] = tl_power_db(e[q]);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int q = 0; q < 4; q++) {
+            const int i = lane + 64 * (4 * h + q);
+            w.px[i] = i == 0 ? 0.0 : v[q];
+            L(pxa)[4 * h + q] = i == 0 ? TL_DBMIN : v[q];
+        }
+    }
+    TL_LANES_END
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
     for (int it = 0; it < 8; it++) {
         PV(double, pxv); PV(double, pxm);
-        TL_LANES_BEGIN
-        const int i = lane + 64 * it;
-        const double e = energy[i];
-        const double v = e < 1E-20 ? -200.0 + TL_POWERNORM : 10 * tl_log10_pn(e) + TL_POWERNORM;
-        w.px[i] = i == 0 ? 0.0 : v;
-        L(pxv) = i == 0 ? TL_DBMIN : v;
-        TL_LANES_END
+        TL_LANES_BEGIN L(pxv) = L(pxa)[it]; TL_LANES_END
         TL_ROW16_MAX_F64(pxm, pxv);
         TL_LANES_BEGIN
         if ((lane & 15) == 15) {
@@ -1317,7 +1355,7 @@ TL_FN int tl_psy3_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlo
         TL_LANES_END
     }
     TL_LANES_BEGIN
-    if (lane == 0) { const double e = energy[512]; w.px[512] = e < 1E-20 ? -200.0 + TL_POWERNORM : 10 * tl_log10_pn(e) + TL_POWERNORM; }
+    if (lane == 0) w.px[512] = tl_power_db(energy[512]);
     TL_LANES_END
     // ---- tone labelling (psycho_3.c:186-247) ----
     // (1) local maxima 2..499 whose right-hand neighbours are >= 7 dB down, compacted ascending
