@@ -313,6 +313,34 @@ TL_FN double tl_div_by(double s, double d, double r)
     e = __builtin_fma(-q, d, s);
     return __builtin_fma(e, r, q);
 }
+// First and last masker with blo < bark <= bhi among the tones [0, ntone) -> a0..a1 and among the noise components
+// [ntone, nm) -> b0..b1 (empty: first > last).  Lane-private: called inside a lanes block.
+TL_FN void tl_mask_spans(const TlMasker *mk, int nm, int ntone, double blo, double bhi, int &a0, int &a1, int &b0, int &b1)
+{
+    a0 = nm; a1 = -1; b0 = nm; b1 = -1;
+    for (int tb = 0; tb < nm; tb += 32) {                           // 32 maskers -> one hit mask, eight barks per LDS round trip
+        uint32_t m = 0;
+        for (int t8 = 0; t8 < 32 && tb + t8 < nm; t8 += 8) {
+            double mb[8];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 8; q++) mb[q] = mk[tb + t8 + q].bark;              // entries past nm (< TL_MASKER_MAX) are masked below
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 8; q++) m |= (mb[q] > blo && mb[q] <= bhi) ? 1u << (t8 + q) : 0u;
+        }
+        const int left = nm - tb, tleft = ntone - tb;
+        m &= left >= 32 ? ~0u : (1u << left) - 1u;
+        const uint32_t tmask = tleft >= 32 ? ~0u : tleft <= 0 ? 0u : (1u << tleft) - 1u;
+        const uint32_t mt = m & tmask, mn = m & ~tmask;
+        const int ft = tb + __builtin_ctz(mt | 0x80000000u), lt = tb + 31 - __builtin_clz(mt | 1u);
+        const int fn = tb + __builtin_ctz(mn | 0x80000000u), ln = tb + 31 - __builtin_clz(mn | 1u);
+        a0 = (mt && ft < a0) ? ft : a0; a1 = mt ? lt : a1;
+        b0 = (mn && fn < b0) ? fn : b0; b1 = mn ? ln : b1;
+    }
+}
 TL_FN unsigned tl_sf_index(const double *TL_RESTRICT sf, double cur_max)
 {   // encode_new.c:208-218
     unsigned i = 32;
@@ -947,29 +975,8 @@ TL_FN void tl_psy1_thresholds(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, 
             const double blo = (bk0 < bk1 ? bk0 : bk1) - 8.0, bhi = (bk0 < bk1 ? bk1 : bk0) + 3.0;
             const TlMasker *mk = TL_MK4(w);
             const int nm = ntone + nnoise;
-            int a0 = nm, a1 = -1, b0 = nm, b1 = -1;                 // spans inside the tone part and inside the noise part
-            for (int tb = 0; tb < nm; tb += 32) {                   // 32 maskers -> one hit mask, eight barks per LDS round trip
-                uint32_t m = 0;
-                for (int t8 = 0; t8 < 32 && tb + t8 < nm; t8 += 8) {
-                    double mb[8];
-#ifndef TL_EMULATE
-#pragma unroll
-#endif
-                    for (int q = 0; q < 8; q++) mb[q] = mk[tb + t8 + q].bark;      // entries past nm (< TL_MASKER_MAX) are masked below
-#ifndef TL_EMULATE
-#pragma unroll
-#endif
-                    for (int q = 0; q < 8; q++) m |= (mb[q] > blo && mb[q] <= bhi) ? 1u << (t8 + q) : 0u;      // superset of both lines' (-3 <= dz < 8)
-                }
-                const int left = nm - tb, tleft = ntone - tb;
-                m &= left >= 32 ? ~0u : (1u << left) - 1u;
-                const uint32_t tmask = tleft >= 32 ? ~0u : tleft <= 0 ? 0u : (1u << tleft) - 1u;
-                const uint32_t mt = m & tmask, mn = m & ~tmask;
-                const int ft = tb + __builtin_ctz(mt | 0x80000000u), lt = tb + 31 - __builtin_clz(mt | 1u);
-                const int fn = tb + __builtin_ctz(mn | 0x80000000u), ln = tb + 31 - __builtin_clz(mn | 1u);
-                a0 = (mt && ft < a0) ? ft : a0; a1 = mt ? lt : a1;
-                b0 = (mn && fn < b0) ? fn : b0; b1 = mn ? ln : b1;
-            }
+            int a0, a1, b0, b1;                                     // spans inside the tone part and inside the noise part
+            tl_mask_spans(mk, nm, ntone, blo, bhi, a0, a1, b0, b1);
             double x0 = TL_DBMIN, x1 = TL_DBMIN;
             for (int part = 0; part < 2; part++) {
                 const int t_first = part ? b0 : a0, t_last = part ? b1 : a1;
@@ -1584,20 +1591,23 @@ TL_FN void tl_psy3_back(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const 
     TL_LANES_BEGIN
     for (int t = lane; t < ntone + nnoise; t += 64) tl_masker_consts(TL_MK4(w), TL_MK_X(w), TL_MK_BARK(w), t, t < ntone);
     TL_LANES_END
-    // lines 0..127: every lane folds the maskers into two lines (two independent dB-sum chains at a time)
+    // lines 0..127: every lane folds the maskers into two ADJACENT lines (two independent dB-sum chains at a time) and
+    // walks only the maskers that can reach one of them (-3 <= dz < 8 bark; the exact test stays in the step)
     TL_LANES_BEGIN
     {
-        const int j0 = lane, j1 = 64 + lane;
+        const int j0 = 2 * lane, j1 = j0 + 1;
         const int line0 = C->p3_subset[j0], line1 = C->p3_subset[j1];
         const double b0 = bark[line0], b1 = bark[line1];
-        double lt0 = TL_DBMIN, ln0 = TL_DBMIN, lt1 = TL_DBMIN, ln1 = TL_DBMIN;
         const TlMasker *mk = TL_MK4(w);
-        for (int t = 0; t < ntone; t++) {
+        int ta0, ta1, tb0, tb1;
+        tl_mask_spans(mk, ntone + nnoise, ntone, (b0 < b1 ? b0 : b1) - 8.0, (b0 < b1 ? b1 : b0) + 3.0, ta0, ta1, tb0, tb1);
+        double lt0 = TL_DBMIN, ln0 = TL_DBMIN, lt1 = TL_DBMIN, ln1 = TL_DBMIN;
+        for (int t = ta0; t <= ta1; t++) {
             const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, n = mk[t].n;
             lt0 = tl_mask_step(db, lt0, b0 - mb, av, g, n);
             lt1 = tl_mask_step(db, lt1, b1 - mb, av, g, n);
         }
-        for (int t = ntone; t < ntone + nnoise; t++) {
+        for (int t = tb0; t <= tb1; t++) {
             const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, n = mk[t].n;
             ln0 = tl_mask_step(db, ln0, b0 - mb, av, g, n);
             ln1 = tl_mask_step(db, ln1, b1 - mb, av, g, n);
