@@ -10,6 +10,11 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if not hasattr(config, "workerinput"):
+        # test-only checkers (oracle, lane-loop emulation) are built once, before any pytest-xdist worker loads them
+        import subprocess
+        for d, target in ((ROOT / "oracle", ["libmp2oracle.so"]), (ROOT / "tests" / "emu", [])):
+            subprocess.run(["make", "-s", "-C", str(d)] + target, check=False)
 
 
 @pytest.fixture(scope="session")
