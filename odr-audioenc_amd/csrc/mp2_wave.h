@@ -1936,21 +1936,37 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             const int c = lane & 1, i = lane >> 1;
             if (c < nch) {
                 const int ya = i == 0 ? 16 : i + 16, yb = i == 0 ? 16 : (i <= 16 ? 16 - i : 80 - i);
+                // yprime = ya-sum (i == 0), ya-sum + yb-sum (i <= 16), ya-sum - yb-sum (i >= 17) as ONE addition: the yb-sum
+                // with its sign flipped (a - b == a + (-b)) or replaced by -0.0 (a + (-0.0) == a, for every a)
+                const uint64_t keep = i == 0 ? 0ull : ~0ull, flip = (i == 0 || i > 16) ? 0x8000000000000000ull : 0ull;
+                // the batch's new samples (two per block) are all requested before the first block is computed
+                int na[TL_FB_BATCH], nb[TL_FB_BATCH];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
                 for (int bb = 0; bb < TL_FB_BATCH; bb++) {
                     // X[k] = pcm[t0 + 31 - k], t0 = index of the block's first new sample
+                    na[bb] = w.u.fbk.pcm[c][TL_HIST + 32 * (b0 + bb) + 31 - ya];
+                    nb[bb] = w.u.fbk.pcm[c][TL_HIST + 32 * (b0 + bb) + 31 - yb];
+                }
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                for (int bb = 0; bb < TL_FB_BATCH; bb++) { TL_KEEP(na[bb]); TL_KEEP(nb[bb]); }
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                for (int bb = 0; bb < TL_FB_BATCH; bb++) {
                     const int b = b0 + bb, q = 8 * (b & 1), h = b >> 1;
-                    L(xa)[q + (h & 7)] = w.u.fbk.pcm[c][TL_HIST + 32 * b + 31 - ya];
-                    L(xb)[q + (h & 7)] = w.u.fbk.pcm[c][TL_HIST + 32 * b + 31 - yb];
+                    L(xa)[q + (h & 7)] = na[bb];
+                    L(xb)[q + (h & 7)] = nb[bb];
                     double ta = (double)L(xa)[q + (h & 7)] * L(ca)[0];
                     double tb = (double)L(xb)[q + (h & 7)] * L(cb)[0];
                     for (int j = 1; j < 8; j++) {
                         ta += (double)L(xa)[q + ((h - j) & 7)] * L(ca)[j];
                         tb += (double)L(xb)[q + ((h - j) & 7)] * L(cb)[j];
                     }
-                    yp[bb][c][i] = i == 0 ? ta : (i <= 16 ? ta + tb : ta - tb);
+                    yp[bb][c][i] = ta + tl_u2d((tl_d2u(tb) & keep) ^ flip);
                 }
             }
             TL_LANES_END
