@@ -219,7 +219,7 @@ struct TlWaveLds {
     union alignas(16) {
         struct { int16_t pcm[2][TL_HIST + 1152]; } fbk;
         double fft[1024];
-        uint32_t frame[TL_MAX_FRAME_WORDS];
+        uint32_t frame[TL_MAX_FRAME_WORDS + 2];          // + 2: tl_put_bits48 may OR zeros into the two words after a field
     } u;
     double px[520];                     // psy: power spectrum in dB
     double tone_x[TL_TONE_MAX];         // psy: summed level of each confirmed tone
@@ -357,6 +357,16 @@ TL_FN void tl_put_bits(uint32_t *frame, int pos, uint32_t val, int nbits)
         TL_ATOMIC_OR(&frame[w], val >> (nbits - room));
         TL_ATOMIC_OR(&frame[w + 1], val << (32 - (nbits - room)));
     }
+}
+// The same for a field of 1..48 bits (three codewords of a subband at once), without branches on the field's position:
+// the left-aligned value, followed by 32 zero bits, shifted right by the offset inside the first word, is three words.
+TL_FN void tl_put_bits48(uint32_t *frame, int pos, uint64_t val, int nbits)
+{
+    const int w = pos >> 5, o = pos & 31;
+    const uint64_t top = val << (64 - nbits);
+    TL_ATOMIC_OR(&frame[w], (uint32_t)(top >> (32 + o)));
+    TL_ATOMIC_OR(&frame[w + 1], (uint32_t)(top >> o));
+    if (o + nbits > 64) TL_ATOMIC_OR(&frame[w + 2], (uint32_t)(((top & 0xffffffffull) << 32) >> o));
 }
 TL_FN uint32_t tl_get_bit(const uint32_t *frame, int pos) { return (frame[pos >> 5] >> (31 - (pos & 31))) & 1u; }
 TL_FN uint32_t tl_bswap(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
@@ -2375,20 +2385,19 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
                     if (joint) s = .5 * (s + L(oth)[x]);
                     double d = tl_div_by(s, sfv, rsf);                   // == s / sfv (encode_new.c:507,511)
                     d = d * L(q_a) + L(q_b);
-                    unsigned sig = 1;
-                    if (!(d >= 0)) { sig = 0; d += 1.0; }
-                    unsigned qv = (unsigned)(d * L(q_s2nf));
-                    if (sig) qv |= (unsigned)L(q_s2n);
-                    v[x] = qv;
+                    const bool neg = !(d >= 0);                          // encode_new.c:528-534; d + 0.0 changes no quantised value
+                    d += TL_SELECT(neg, 1.0, 0.0);
+                    const unsigned qv = (unsigned)(d * L(q_s2nf));
+                    v[x] = qv | (neg ? 0u : (unsigned)L(q_s2n));
                 }
+                // three codewords of nb bits, or one codeword v0 + v1*steps + v2*steps^2 of nb bits (encode_new.c:574-592): one field
                 const int nb = L(q_nb);
                 const int pos = p_smp + r * n_smp + L(o_smp);
-                if (L(q_grp) == 3) {
-                    tl_put_bits(frame, pos, v[0], nb); tl_put_bits(frame, pos + nb, v[1], nb); tl_put_bits(frame, pos + 2 * nb, v[2], nb);
-                } else {
-                    unsigned y = (unsigned)L(q_steps);
-                    tl_put_bits(frame, pos, v[0] + v[1] * y + v[2] * y * y, nb);
-                }
+                const bool three = L(q_grp) == 3;
+                const unsigned y = (unsigned)L(q_steps);
+                const uint64_t sep = ((uint64_t)v[0] << (2 * nb)) | ((uint64_t)v[1] << nb) | (uint64_t)v[2];
+                const uint64_t grp = (uint64_t)(v[0] + y * (v[1] + y * v[2]));
+                tl_put_bits48(frame, pos, TL_SELECT(three, sep, grp), three ? 3 * nb : nb);
             }
             if (taps) for (int x = 0; x < 3; x++) taps->subband[c][gr][j0 + x][sb] = (c < nch) ? v[x] : 0;
             TL_LANES_END
