@@ -63,7 +63,7 @@ void tl_build_tables(TlTables *T)
     for (int i = 0; i < 64; i++) T->shared.scalefactor[i] = T->scalefactor[i];
     {   // powers of x modulo the CRC-16 polynomial 0x8005 (CRC16_POLYNOMIAL, common.h:45)
         unsigned v = 1;
-        for (int e = 0; e < 384; e++) { T->crc_xpow[e] = (uint16_t)v; v <<= 1; if (v & 0x10000u) v = (v ^ 0x18005u) & 0xffffu; }
+        for (int e = 0; e < 512; e++) { T->crc_xpow[e] = (uint16_t)v; v <<= 1; if (v & 0x10000u) v = (v ^ 0x18005u) & 0xffffu; }
         {   // Reed-Solomon RS(255,207) of the EDI PFT layer: GF(2^8) with x^8+x^4+x^3+x^2+1, generator polynomial with roots
             // alpha^1..alpha^48 (contrib/edioutput/PFT.cpp:100-107: gfPoly 0x11d, firstRoot 1; contrib/fec/init_rs.h).
             uint8_t *lg = T->rs_log, *ex = T->rs_exp;
@@ -94,7 +94,7 @@ void tl_build_tables(TlTables *T)
             for (int b = 0; b < 8; b++) { ve <<= 1; if (ve & 0x10000u) ve = (ve ^ 0x11021u) & 0xffffu; }
         }
         unsigned v8 = 1;
-        for (int e = 0; e < 256; e++) { T->crc8_xpow[e] = (uint8_t)v8; v8 <<= 1; if (v8 & 0x100u) v8 = (v8 ^ 0x11Du) & 0xffu; }
+        for (int e = 0; e < 320; e++) { T->crc8_xpow[e] = (uint8_t)v8; v8 <<= 1; if (v8 & 0x100u) v8 = (v8 ^ 0x11Du) & 0xffu; }
     }
     // matrixing coefficients: cos scaled by 1e9, rounded half away from zero, scaled back (subband.c:125-137)
     for (int i = 0; i < 16; i++)

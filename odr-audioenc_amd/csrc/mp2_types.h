@@ -42,8 +42,8 @@ struct TlTables {
     uint8_t step_index[9][16];
     uint8_t nbal_line[9];
     uint8_t pad_[3];
-    uint16_t crc_xpow[384];      // x^e mod (x^16+x^15+x^2+1), e = 0..383: lets lanes fold CRC-16 chunks in parallel (crc.c:43-56)
-    uint8_t crc8_xpow[256];      // x^e mod (x^8+x^4+x^3+x^2+1), the ScF-CRC polynomial (crc.c:99-113)
+    uint16_t crc_xpow[512];      // x^e mod (x^16+x^15+x^2+1), e = 0..511: lets lanes fold CRC-16 chunks in parallel (crc.c:43-56)
+    uint8_t crc8_xpow[320];      // x^e mod (x^8+x^4+x^3+x^2+1), the ScF-CRC polynomial (crc.c:99-113)
     uint8_t rs_log[256], rs_exp[512];   // GF(2^8), field polynomial 0x11d: log (255 for 0) and antilog (doubled, no modulo)
     uint8_t rs_mlog[207][48];    // log of M[i][j]: parity byte j of the RS(255,207) codeword of the unit chunk e_i (csrc/edi_pft.h)
     uint16_t edi_xpow8[2048];    // x^(8k) mod (x^16+x^12+x^5+1): AF-packet CRC chunks (csrc/edi_af.h; contrib/crc.c:247-255)

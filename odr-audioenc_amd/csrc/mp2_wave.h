@@ -2327,16 +2327,14 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     }
     const bool live = c < nch && sb < sblimit;
     const int ba = live ? w.balloc[c][sb] : 0;
-    if (L(f_ba)) tl_put_bits(frame, p_ba + L(o_ba), (uint32_t)ba, L(f_ba));
+    if (L(f_ba)) tl_put_bits48(frame, p_ba + L(o_ba), (uint64_t)ba, L(f_ba));
     if (L(f_sel)) {
-        tl_put_bits(frame, p_sel + L(o_sel), w.scfsi[c][sb], 2);
-        int pos = p_scf + L(o_scf);
-        switch (w.scfsi[c][sb]) {                                   // write_scalefactors (encode_new.c:428-443)
-        case 0: tl_put_bits(frame, pos, (uint32_t)L(scf)[0], 6); tl_put_bits(frame, pos + 6, (uint32_t)L(scf)[1], 6);
-                tl_put_bits(frame, pos + 12, (uint32_t)L(scf)[2], 6); break;
-        case 1: case 3: tl_put_bits(frame, pos, (uint32_t)L(scf)[0], 6); tl_put_bits(frame, pos + 6, (uint32_t)L(scf)[2], 6); break;
-        default: tl_put_bits(frame, pos, (uint32_t)L(scf)[0], 6); break;
-        }
+        const unsigned si = w.scfsi[c][sb];
+        tl_put_bits48(frame, p_sel + L(o_sel), si, 2);
+        // write_scalefactors (encode_new.c:428-443): scfsi 0 -> three, 1/3 -> first and last, 2 -> one; as one field
+        const unsigned s0 = (unsigned)L(scf)[0], s1 = (unsigned)L(scf)[1], s2 = (unsigned)L(scf)[2];
+        const unsigned f3 = (s0 << 12) | (s1 << 6) | s2, f2 = (s0 << 6) | s2;
+        tl_put_bits48(frame, p_scf + L(o_scf), si == 0 ? f3 : si == 2 ? s0 : f2, L(f_scf));
     }
     TL_LANES_END
 
@@ -2405,29 +2403,30 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     }
 
     TL_STAMP(sp, 5);
-    // CRC-16 over header bits 16..31, bit_alloc and scfsi fields (crc.c:12-41); one lane, bit-serial
-    // Protected message = frame bits [16,32) then [48,p_scf).  The CRC register update is linear over GF(2), so
-    // lane L folds message bits [32L,32L+32) on its own (lane 0 also carries the 0xffff preset) and the chunks
-    // are combined as sum_L R_L * x^(bits after chunk L) mod P, with x^e mod P from a table; one XOR-reduce.
+    // CRC-16 over header bits 16..31, bit_alloc and scfsi fields (crc.c:12-41).
+    // Protected message M = frame bits [16,32) then [48,p_scf), n bits.  The register after M with preset I is
+    // (I(x) x^n + M(x) x^16) mod P -- linear over GF(2) -- so every lane takes one byte of M (a byte of the frame: the message is
+    // byte aligned in it) and adds up bit_k * x^(16 + bits after the byte + k) mod P, starting from a table value and
+    // multiplying by x per step; the two bytes of the preset ride on lanes 62/63; one XOR-reduce.
     unsigned crc16;
     {
         const int n = 16 + (p_scf - 48);
         PV(uint32_t, part);
         TL_LANES_BEGIN
         uint32_t acc = 0;
-        if (32 * lane < n) {
-            const uint32_t chunk = lane == 0 ? ((frame[0] & 0xffffu) << 16) | (frame[1] & 0xffffu) : frame[lane + 1];
-            const int cnt = n - 32 * lane < 32 ? n - 32 * lane : 32;
-            const int after = n - 32 * lane - cnt;
-            unsigned xp = T->crc_xpow[after];                        // x^after mod P: the only table read, issued ahead of the bit loop
-            unsigned r = lane == 0 ? 0xffffu : 0u;
-            for (int bit = 0; bit < cnt; bit++) {
-                const unsigned d = (chunk >> (31 - bit)) & 1u;
-                const unsigned fb = ((r >> 15) ^ d) & 1u;
-                r = ((r << 1) & 0xffffu) ^ (fb ? 0x8005u : 0u);
-            }
-            for (int b16 = 0; b16 < 16; b16++) {                    // acc = r(x) * x^after mod P, shift-and-add in GF(2)
-                acc ^= ((r >> b16) & 1u) ? xp : 0u;
+        const bool preset = lane >= 62;
+        const int first = 8 * lane;                                   // message bits [first, first + cnt)
+        if (first < n || preset) {
+            const int byte = lane < 2 ? lane + 2 : lane + 4;          // frame byte holding them
+            const int cnt = preset ? 8 : (n - first < 8 ? n - first : 8);
+            const int e0 = preset ? n + 8 * (63 - lane) : 16 + (n - first - cnt);     // exponent of the byte's last bit
+            unsigned xp = T->crc_xpow[e0];
+            const unsigned v = preset ? 0xffu : ((frame[byte >> 2] >> (24 - 8 * (byte & 3))) & 0xffu) >> (8 - cnt);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int k = 0; k < 8; k++) {                             // bits past cnt are zero
+                acc ^= ((v >> k) & 1u) ? xp : 0u;
                 xp = ((xp << 1) & 0xffffu) ^ ((xp & 0x8000u) ? 0x8005u : 0u);
             }
         }
@@ -2451,15 +2450,10 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         }
     }
     if (lane == 0) tl_put_bits(frame, 32, crc16, 16);
-    // this record's own remainder R = rec(x) * x^8 mod P (crc.c:99-113 with crc = 0), bit-serial over <= 9 bits
-    unsigned r8 = 0;
-    const int len = (int)(rec >> 16);
-    for (int b = 8; b >= 0; b--)
-        if (b < len) { const unsigned fb = ((r8 >> 7) ^ (rec >> b)) & 1u; r8 = ((r8 << 1) & 0xffu) ^ (fb ? 0x1Du : 0u); }
-    L(rlen) = len; L(rcrc) = r8;
+    L(rlen) = (int)(rec >> 16); L(rcrc) = rec & 0x1ffu;               // the record's bits; folded below (crc.c:99-113)
     TL_LANES_END
     // The CRC register update is linear over GF(2): the CRC of a band group (records concatenated in (sb,ch) order, crc.c:58-97)
-    // is the XOR of R_l * x^(bits after record l) mod P.  Bits-after from a prefix sum of the lengths, x^e from a table,
+    // is the XOR of rec_l(x) * x^(8 + bits after record l) mod P.  Bits-after from a prefix sum of the lengths, x^e from a table,
     // one XOR scan, then the four group values are differences of that scan at the group boundaries.
     {
         PV(int, lex);
@@ -2476,11 +2470,15 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         const int sb = lane >> 1;
         const int g = sb < 4 ? 0 : sb < 8 ? 1 : sb < 16 ? 2 : 3;
         const int after = (g == 0 ? gend[0] : g == 1 ? gend[1] : g == 2 ? gend[2] : gend[3]) - L(lex) - L(rlen);
-        unsigned xp = T->crc8_xpow[after & 255];
+        const int e0 = after + 8;                                    // <= 252 + 8: inside crc8_xpow[]
+        unsigned xp = T->crc8_xpow[e0 < 0 ? 0 : e0 > 319 ? 319 : e0];
         unsigned acc = 0;
-        const unsigned r8 = L(rcrc);
-        for (int b = 0; b < 8; b++) {                                // acc = R * x^after mod P, shift-and-add in GF(2)
-            acc ^= ((r8 >> b) & 1u) ? xp : 0u;
+        const unsigned rb = L(rcrc);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int b = 0; b < 9; b++) {                                // acc = rec(x) * x^(8 + after) mod P, shift-and-add in GF(2)
+            acc ^= ((rb >> b) & 1u) ? xp : 0u;
             xp = ((xp << 1) & 0xffu) ^ ((xp & 0x80u) ? 0x1Du : 0u);
         }
         L(part) = (L(rlen) && sb < sblimit) ? acc : 0u;
