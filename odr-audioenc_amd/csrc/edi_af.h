@@ -65,8 +65,9 @@ TL_FN uint8_t tl_edi_byte(const TlEdiFrame &F, uint32_t pos)
     }
     uint32_t p = pos - 10;
     if (p < 16) {                                                    // TagStarPTR("DSTI"), TagItems.cpp:46-66
-        const uint8_t t[16] = {'*', 'p', 't', 'r', 0, 0, 0, 0x40, 'D', 'S', 'T', 'I', 0, 0, 0, 0};
-        return t[p];
+        // "*ptr" 00 00 00 40 | "DSTI" 00 00 00 00, little-endian packed (a constant in registers, not an array in memory)
+        const uint64_t lo = 0x400000007274702aull, hi = 0x0000000049545344ull;
+        return (uint8_t)((p < 8 ? lo >> (8 * p) : hi >> (8 * (p - 8))) & 0xffu);
     }
     p -= 16;
     const uint32_t dsti_len = 2u + (F.atstf ? 8u : 0u);
@@ -104,7 +105,7 @@ TL_FN uint8_t tl_edi_byte(const TlEdiFrame &F, uint32_t pos)
     p -= 12;
     {                                                                // TagODRVersion, TagItems.cpp:387-413
         const uint32_t bits = (F.vlen + 4) * 8;
-        if (p < 4) { const uint8_t t[4] = {'O', 'D', 'R', 'v'}; return t[p]; }
+        if (p < 4) return (uint8_t)((0x7652444fu >> (8 * p)) & 0xffu);          // "ODRv"
         if (p < 8) return (uint8_t)(bits >> (8 * (7 - p)));
         if (p < 8 + F.vlen) return F.version[p - 8];
         return (uint8_t)(F.uptime >> (8 * (3 - (p - 8 - F.vlen))));

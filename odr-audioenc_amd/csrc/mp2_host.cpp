@@ -61,6 +61,23 @@ void tl_build_tables(TlTables *T)
             T->shared.qinfo_line[l][b] = (uint16_t)(q | (TL_BITS[q] << 5) | ((TL_GROUP[q] == 3 ? 1 : 0) << 10));
         }
     for (int i = 0; i < 64; i++) T->shared.scalefactor[i] = T->scalefactor[i];
+    {   // sf_transmission_pattern: pattern[5][5] of encode_new.c:296-301 as (sources of the three scalefactors, scfsi)
+        static const unsigned short pat[25] = {0x123, 0x122, 0x122, 0x133, 0x123, 0x113, 0x111, 0x111, 0x444, 0x113,
+                                               0x111, 0x111, 0x111, 0x333, 0x113, 0x222, 0x222, 0x222, 0x333, 0x123,
+                                               0x123, 0x122, 0x122, 0x133, 0x123};
+        memset(T->shared.sfpat, 0, sizeof T->shared.sfpat);
+        for (int i = 0; i < 25; i++) {
+            const int d0 = (pat[i] >> 8) & 15, d1 = (pat[i] >> 4) & 15, d2 = pat[i] & 15;
+            int sel;                                                 // encode_new.c:318-351
+            switch (pat[i]) {
+            case 0x123: sel = 0; break;
+            case 0x122: case 0x133: sel = 3; break;
+            case 0x113: sel = 1; break;
+            default: sel = 2; break;
+            }
+            T->shared.sfpat[i] = (uint8_t)((d0 - 1) | ((d1 - 1) << 2) | ((d2 - 1) << 4) | (sel << 6));
+        }
+    }
     {   // powers of x modulo the CRC-16 polynomial 0x8005 (CRC16_POLYNOMIAL, common.h:45)
         unsigned v = 1;
         for (int e = 0; e < 512; e++) { T->crc_xpow[e] = (uint16_t)v; v <<= 1; if (v & 0x10000u) v = (v ^ 0x18005u) & 0xffffu; }

@@ -21,6 +21,8 @@ struct TlBlockShared {
     int16_t bits12_line[9][16];  // 12*group*bits of step_index[line][ba] (encode_new.c:1125-1133)
     uint16_t qinfo_line[9][16];  // quantiser class of (line, ba): step_index | bits << 5 | (group == 3) << 10 (encode_new.c:16-100)
     double dct_t[16][2][16];     // matrixing coefficients m[r][2k+par] stored [k][par][r]: one k = 32 consecutive doubles
+    uint8_t sfpat[32];           // scalefactor transmission pattern of the class pair 5*c0+c1 (encode_new.c:296-301, ISO Table C.4):
+                                 //   source of sf0 | sf1 << 2 | sf2 << 4 (0..2 = sf0..sf2, 3 = min(sf0, sf2)) | scfsi << 6
 };
 
 // Tables common to every config.  (ref: enwindow.h, subband.c:125-137, psycho_1.c:170-178,225-233,

@@ -341,6 +341,8 @@ TL_FN void tl_mask_spans(const TlMasker *mk, int nm, int ntone, double blo, doub
         b0 = (mn && fn < b0) ? fn : b0; b1 = mn ? ln : b1;
     }
 }
+// scalefactors transmitted for scfsi 0..3: 3, 2, 1, 2 (encode_new.c:1101, sfsPerScfsi) -- from a constant, not from memory
+TL_FN int tl_sfs_count(unsigned scfsi) { return (int)((0x2123u >> (4u * (scfsi & 3u))) & 15u); }
 TL_FN unsigned tl_sf_index(const double *TL_RESTRICT sf, double cur_max)
 {   // encode_new.c:208-218
     unsigned i = 32;
@@ -2097,22 +2099,15 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         int d0 = s0 - s1, d1 = s1 - s2;
         int c0 = d0 <= -3 ? 0 : d0 < 0 ? 1 : d0 == 0 ? 2 : d0 < 3 ? 3 : 4;
         int c1 = d1 <= -3 ? 0 : d1 < 0 ? 1 : d1 == 0 ? 2 : d1 < 3 ? 3 : 4;
-        // pattern table rows c0, columns c1, as 3 hex digits
-        const unsigned short pat[25] = {0x123, 0x122, 0x122, 0x133, 0x123, 0x113, 0x111, 0x111, 0x444, 0x113,
-                                        0x111, 0x111, 0x111, 0x333, 0x113, 0x222, 0x222, 0x222, 0x333, 0x123,
-                                        0x123, 0x122, 0x122, 0x133, 0x123};
-        unsigned p = pat[c0 * 5 + c1];
-        int sel;
-        switch (p) {
-        case 0x123: sel = 0; break;
-        case 0x122: sel = 3; s2 = s1; break;
-        case 0x133: sel = 3; s1 = s2; break;
-        case 0x113: sel = 1; s1 = s0; break;
-        case 0x111: sel = 2; s1 = s2 = s0; break;
-        case 0x222: sel = 2; s0 = s2 = s1; break;
-        case 0x333: sel = 2; s0 = s1 = s2; break;
-        default: sel = 2; if (s0 > s2) s0 = s2; s1 = s2 = s0; break;       // 0x444
-        }
+        // pattern of the class pair: where each transmitted scalefactor comes from, and scfsi (no branches: a lane per cell)
+        const unsigned p = B->sfpat[c0 * 5 + c1];
+        const int m02 = s0 > s2 ? s2 : s0;                              // pattern 444: the larger scalefactor (smaller index) of the outer two
+        const unsigned q0 = p & 3u, q1 = (p >> 2) & 3u, q2 = (p >> 4) & 3u;
+        const int n0 = q0 == 0 ? s0 : q0 == 1 ? s1 : q0 == 2 ? s2 : m02;
+        const int n1 = q1 == 0 ? s0 : q1 == 1 ? s1 : q1 == 2 ? s2 : m02;
+        const int n2 = q2 == 0 ? s0 : q2 == 1 ? s1 : q2 == 2 ? s2 : m02;
+        const int sel = (int)(p >> 6);
+        s0 = n0; s1 = n1; s2 = n2;
         L(scf)[0] = s0; L(scf)[1] = s1; L(scf)[2] = s2;
         w.scf[c][0][sb] = (uint8_t)s0; w.scf[c][1][sb] = (uint8_t)s1; w.scf[c][2][sb] = (uint8_t)s2;
         w.scfsi[c][sb] = (uint8_t)sel;
@@ -2129,11 +2124,10 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     TL_LANES_BEGIN
     const int c = lane & 1, sb = lane >> 1;
     const bool live = c < nch && sb < sblimit;
-    const int sfs[4] = {3, 2, 1, 2};
     L(a_ln) = live ? C->line[sb] : 0;
     L(a_nbal) = live ? C->nbal[sb] : 0;
-    L(a_sfs) = live ? 6 * sfs[w.scfsi[c][sb]] : 0;
-    L(a_sfs_o) = (live && nch == 2) ? 6 * sfs[w.scfsi[1 - c][sb]] : 0;
+    L(a_sfs) = live ? 6 * tl_sfs_count(w.scfsi[c][sb]) : 0;
+    L(a_sfs_o) = (live && nch == 2) ? 6 * tl_sfs_count(w.scfsi[1 - c][sb]) : 0;
     L(a_smr) = live ? w.smr[c][sb] : 0.0;
     L(a_smr_o) = (live && nch == 2) ? w.smr[1 - c][sb] : 0.0;
     TL_LANES_END
@@ -2168,8 +2162,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             if (tries == 0) {
                 if (rq > adb) { mode = 1; } else break;
             } else if (!(rq > adb && try_ext > 0)) { mode_ext = try_ext; break; }
-            const int jsb[4] = {4, 8, 12, 16};
-            --try_ext; jsbound = jsb[try_ext]; tries++;
+            --try_ext; jsbound = 4 * (try_ext + 1); tries++;          // 16, 12, 8, 4
         }
     }
     int adb_left;
@@ -2305,10 +2298,9 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     const bool live = c < nch && sb < sblimit;
     const int ba = live ? w.balloc[c][sb] : 0;
     const bool own = sb < sblimit && c < (sb < jsbound ? nch : 1);     // transmits bit_alloc + samples
-    const int sfs[4] = {3, 2, 1, 2};
     L(f_ba) = own ? L(a_nbal) : 0;
     L(f_sel) = (live && ba) ? 2 : 0;
-    L(f_scf) = (live && ba) ? 6 * sfs[w.scfsi[c][sb]] : 0;
+    L(f_scf) = (live && ba) ? 6 * tl_sfs_count(w.scfsi[c][sb]) : 0;
     L(f_smp) = (own && ba) ? B->bits12_line[L(a_ln)][ba] / 12 : 0;     // group * bits of the cell's quantiser class
     TL_LANES_END
     TL_WAVE_EXSCAN_I32(o_ba, f_ba); TL_WAVE_EXSCAN_I32(o_sel, f_sel);
