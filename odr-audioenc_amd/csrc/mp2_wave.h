@@ -263,6 +263,17 @@ TL_FN double tl_add_db(const double *TL_RESTRICT dbtable, double a, double b)
     const double base = TL_SELECT(fdiff > -1.0, a, b);              // (int)fdiff >= 0
     return base + dbtable[idx];
 }
+// Two independent dB sums at once: both table entries are requested before either is used.
+TL_FN void tl_add_db2(const double *TL_RESTRICT dbtable, double &a0, double b0, double &a1, double b1)
+{
+    const double f0 = 10.0 * (a0 - b0), f1 = 10.0 * (a1 - b1);
+    const double g0 = __builtin_fabs(f0), g1 = __builtin_fabs(f1);
+    int i0 = TL_SELECT(g0 > 990.0, 1000, (int)g0), i1 = TL_SELECT(g1 > 990.0, 1000, (int)g1);
+    const double s0 = TL_SELECT(f0 > -1.0, a0, b0), s1 = TL_SELECT(f1 > -1.0, a1, b1);
+    TL_KEEP(i0); TL_KEEP(i1);
+    const double t0 = dbtable[i0], t1 = dbtable[i1];
+    a0 = s0 + t0; a1 = s1 + t1;
+}
 TL_FN uint64_t tl_mnr_key(double mnr)
 {   // order-preserving map double -> u64 for the allocation arg-min; ~0 = never chosen (encode_new.c:1068: small = 999999.0)
     uint64_t u = tl_d2u(mnr + 0.0);
@@ -278,17 +289,21 @@ TL_FN uint64_t tl_mnr_key(double mnr)
 // C is the inside A times B (a product with 0.0 or 1.0 is exact): 64-bit selects cost two instructions, a product one.
 // A masker out of reach (dz outside [-3, 8)) enters the dB sum as a level below -65536 dB, which leaves the sum as it
 // is (|difference| > 99 dB: the reference returns the larger operand, tl_add_db adds its -0.0 entry).
-TL_FN double tl_mask_step(const double *TL_RESTRICT db, double x, double dz, double av, double g, double n)
+TL_FN double tl_mask_term(double dz, double av, double g, double n, bool live = true)
 {
     const double ad = __builtin_fabs(dz);
     const bool s = dz < 0.0, o = ad >= 1.0;
     const double G = TL_SELECT(s, g, 17.0), H = TL_SELECT(s, 17.0, n);
     const double A = TL_SELECT(o, H, G), Bc = TL_SELECT(o, 1.0, 0.0);
     const double term = av - (A * (ad - Bc) + G * Bc);
-    const bool in = dz >= -3.0 && dz < 8.0;
+    const bool in = live && dz >= -3.0 && dz < 8.0;
     const uint64_t tu = tl_d2u(term);
     const uint32_t hi = TL_SELECT(in, (uint32_t)(tu >> 32), 0xC0F00000u);
-    return tl_add_db(db, x, tl_u2d(((uint64_t)hi << 32) | (tu & 0xffffffffull)));
+    return tl_u2d(((uint64_t)hi << 32) | (tu & 0xffffffffull));
+}
+TL_FN double tl_mask_step(const double *TL_RESTRICT db, double x, double dz, double av, double g, double n)
+{
+    return tl_add_db(db, x, tl_mask_term(dz, av, g, n));
 }
 TL_FN void tl_masker_consts(TlMasker *TL_RESTRICT mk, const double *TL_RESTRICT mx, const double *TL_RESTRICT mbk, int t, bool tonal)
 {
@@ -989,14 +1004,20 @@ TL_FN void tl_psy1_thresholds(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, 
             const int nm = ntone + nnoise;
             int a0, a1, b0, b1;                                     // spans inside the tone part and inside the noise part
             tl_mask_spans(mk, nm, ntone, blo, bhi, a0, a1, b0, b1);
+            // one walk over the tone span, then the noise span, two maskers per trip: their four masking terms do not depend on
+            // the running sums and are computed while the masker reads and the previous table look-ups are under way
             double x0 = TL_DBMIN, x1 = TL_DBMIN;
-            for (int part = 0; part < 2; part++) {
-                const int t_first = part ? b0 : a0, t_last = part ? b1 : a1;
-                for (int t = t_first; t <= t_last; t++) {
-                    const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, n = mk[t].n;
-                    x0 = tl_mask_step(db, x0, bk0 - mb, av, g, n);
-                    x1 = tl_mask_step(db, x1, bk1 - mb, av, g, n);
-                }
+            const int nt = a1 >= a0 ? a1 - a0 + 1 : 0, cnt = nt + (b1 >= b0 ? b1 - b0 + 1 : 0);
+            int t = nt ? a0 : b0;
+            for (int i = 0; i < cnt; i += 2) {
+                const int tA = t, tB = tA == a1 ? b0 : tA + 1;
+                t = tB == a1 ? b0 : tB + 1;
+                const TlMasker A = mk[tA & (TL_MASKER_MAX - 1)], Bm = mk[tB & (TL_MASKER_MAX - 1)];
+                const bool two = i + 1 < cnt;                           // an odd walk ends with a masker that reaches nothing
+                const double mA0 = tl_mask_term(bk0 - A.bark, A.av, A.g, A.n), mA1 = tl_mask_term(bk1 - A.bark, A.av, A.g, A.n);
+                const double mB0 = tl_mask_term(bk0 - Bm.bark, Bm.av, Bm.g, Bm.n, two), mB1 = tl_mask_term(bk1 - Bm.bark, Bm.av, Bm.g, Bm.n, two);
+                tl_add_db2(db, x0, mA0, x1, mA1);
+                tl_add_db2(db, x0, mB0, x1, mB1);
             }
             TL_LTG(w)[k0] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k0] : C->p1_hear[k0] - 12.0, x0);
             if (h1) TL_LTG(w)[k1] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k1] : C->p1_hear[k1] - 12.0, x1);
