@@ -2153,7 +2153,36 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     L(a_smr_o) = (live && nch == 2) ? w.smr[1 - c][sb] : 0.0;
     TL_LANES_END
     if (C->mode0 == 1) {
-        // try plain stereo, then jsbound 16, 12, 8, 4 (encode_new.c:803-819)
+        // try plain stereo, then jsbound 16, 12, 8, 4 (encode_new.c:803-819).  What a cell needs for "no audible noise"
+        // (bits_for_nonoise_new, encode_new.c:634-705) does not depend on the trial: the SNR column of an allocation line
+        // is increasing, so the first allocation that masks the cell's own SMR is the number of allocations that do not,
+        // and above jsbound (where the search goes on against the other channel's SMR) it is the larger of the two counts.
+        // Both counts and both prices are computed once; a trial only selects and sums.
+        PV(int, nz_own); PV(int, nz_jnt);
+        TL_LANES_BEGIN
+        int bo = 0, bj = 0;
+        if (lane < 2 * sblimit) {
+            const int ln = L(a_ln), maxAlloc = (1 << L(a_nbal)) - 1;
+            double sv[15];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 15; q++) sv[q] = B->snr_line[ln][q];
+            int n1 = 0, n2 = 0;
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 15; q++) {
+                const bool inr = q < maxAlloc - 1;
+                n1 += (inr && !((sv[q] - L(a_smr)) >= 0.0)) ? 1 : 0;
+                n2 += (inr && !((sv[q] - L(a_smr_o)) >= 0.0)) ? 1 : 0;
+            }
+            n2 = n2 > n1 ? n2 : n1;
+            bo = n1 > 0 ? B->bits12_line[ln][n1] + 2 + L(a_sfs) : 0;
+            bj = n2 > 0 ? B->bits12_line[ln][n2] + 4 + L(a_sfs) + L(a_sfs_o) : 0;
+        }
+        L(nz_own) = bo; L(nz_jnt) = bj;
+        TL_LANES_END
         mode = 0; mode_ext = 0; jsbound = sblimit;
         int tries = 0, try_ext = 4;
         for (;;) {
@@ -2161,22 +2190,8 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             TL_LANES_BEGIN
             const int c = lane & 1, sb = lane >> 1;
             int bitsn = 0;
-            if (sb < sblimit && c < (sb < jsbound ? nch : 1)) {
-                const int ln = L(a_ln);
-                const int maxAlloc = (1 << L(a_nbal)) - 1;
-                int ba;
-                for (ba = 0; ba < maxAlloc - 1; ba++)
-                    if ((B->snr_line[ln][ba] - L(a_smr)) >= 0.0) break;
-                if (nch == 2 && sb >= jsbound)
-                    for (; ba < maxAlloc - 1; ba++)
-                        if ((B->snr_line[ln][ba] - L(a_smr_o)) >= 0.0) break;
-                if (ba > 0) {
-                    int sel = 2, sc = L(a_sfs);
-                    if (nch == 2 && sb >= jsbound) { sel += 2; sc += L(a_sfs_o); }
-                    bitsn = B->bits12_line[ln][ba] + sel + sc;
-                }
-                bitsn += L(a_nbal);                                 // bbal share of this (sb,ch)
-            }
+            if (sb < sblimit && c < (sb < jsbound ? nch : 1))
+                bitsn = ((nch == 2 && sb >= jsbound) ? L(nz_jnt) : L(nz_own)) + L(a_nbal);     // + the bbal share of this (sb,ch)
             L(need) = bitsn;
             TL_LANES_END
             int rq = 32 + 16 + TL_WAVE_SUM_I32(need);

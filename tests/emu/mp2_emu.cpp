@@ -131,6 +131,16 @@ int emu_sizeof_lds(void) { return (int)sizeof(TlWaveLds); }
 double emu_log10(double x) { return tl_log10(x); }
 double emu_log10_pn(double x) { return tl_log10_pn(x); }
 double emu_pow10(double x) { return tl_pow10(x); }
+// the allocation code counts instead of searching: needs every allocation line's SNR column to be non-decreasing
+int emu_snr_monotone(void)
+{
+    static TlTables T; tl_build_tables(&T);
+    for (int l = 0; l < 9; l++) {
+        const int maxa = (1 << T.nbal_line[l]) - 1;
+        for (int b = 0; b + 1 < maxa; b++) if (!(T.shared.snr_line[l][b] <= T.shared.snr_line[l][b + 1])) return 0;
+    }
+    return 1;
+}
 void emu_scalefactors(double *out) { static TlTables T; tl_build_tables(&T); for (int i = 0; i < 64; i++) out[i] = T.scalefactor[i]; }
 // tl_div_by against the division it replaces; returns the number of mismatching quotients among n (s[i], d[i]) pairs
 long emu_div_by_check(const double *s, const double *d, long n)

@@ -96,6 +96,11 @@ def test_emulated_log10_pow10_accuracy():
     assert worst <= 1
 
 
+def test_snr_columns_increase():
+    """bits_for_nonoise as a count (joint-stereo trials) and the allocation rounds rely on it (encode_new.c:16-27,96-100)."""
+    assert E.lib().emu_snr_monotone() == 1
+
+
 def test_quantiser_division():
     """tl_div_by (reciprocal + two fused corrections) == IEEE division for every scalefactor divisor: random dividends over
     the subband-sample range, dividends that put the quotient next to a representable number, and dividends that put it
