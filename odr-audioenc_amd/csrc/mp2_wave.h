@@ -358,12 +358,26 @@ TL_FN void tl_mask_spans(const TlMasker *mk, int nm, int ntone, double blo, doub
 }
 // scalefactors transmitted for scfsi 0..3: 3, 2, 1, 2 (encode_new.c:1101, sfsPerScfsi) -- from a constant, not from memory
 TL_FN int tl_sfs_count(unsigned scfsi) { return (int)((0x2123u >> (4u * (scfsi & 3u))) & 15u); }
-TL_FN unsigned tl_sf_index(const double *TL_RESTRICT sf, double cur_max)
-{   // encode_new.c:208-218
+TL_FN unsigned tl_sf_index_ref(const double *TL_RESTRICT sf, double cur_max)
+{   // encode_new.c:208-218 as written there (the emulation build checks tl_sf_index against it)
     unsigned i = 32;
     for (unsigned l = 16; l; l >>= 1) { if (cur_max <= sf[i]) i += l; else i -= l; }
     if (cur_max > sf[i]) i--;
     return i;
+}
+// The same result without the chain of seven dependent table reads.  The table is decreasing, so the search returns
+// (number of entries >= cur_max) - 1 (0 when there is none).  Entry i is 2^(1 - i/3) cut to 14 decimals (and [63] = 1e-20): with
+// cur_max in [2^e, 2^(e+1)) and i0 = 3(1 - e), every entry above i0 is < 2^e and every entry below i0 - 3 is >= 2^(e+1);
+// entry i0 - 3 itself stands for 2^(e+1) but may fall just short of it (the cut), so it is looked at together with the
+// three entries in between: four reads, issued together.
+TL_FN unsigned tl_sf_index(const double *TL_RESTRICT sf, double cur_max)
+{
+    const int e = (int)((tl_d2u(cur_max) >> 52) & 0x7ffu) - 1023;
+    int i0 = 3 * (1 - e);
+    i0 = i0 < 3 ? 3 : i0 > 63 ? 63 : i0;
+    const double s3 = sf[i0 - 3], s2 = sf[i0 - 2], s1 = sf[i0 - 1], s0 = sf[i0];
+    const int cnt = (i0 - 3) + (cur_max <= s3 ? 1 : 0) + (cur_max <= s2 ? 1 : 0) + (cur_max <= s1 ? 1 : 0) + (cur_max <= s0 ? 1 : 0);
+    return (unsigned)(cnt > 0 ? cnt - 1 : 0);
 }
 TL_FN void tl_put_bits(uint32_t *frame, int pos, uint32_t val, int nbits)
 {   // MSB-first bit field at bit offset `pos`; words are big-endian bit order (bitstream.c:130-150)

@@ -141,6 +141,14 @@ int emu_snr_monotone(void)
     }
     return 1;
 }
+// tl_sf_index (three reads) against the reference's binary search; returns the number of disagreements
+long emu_sf_index_check(const double *v, long n)
+{
+    static TlTables T; tl_build_tables(&T);
+    long bad = 0;
+    for (long i = 0; i < n; i++) if (tl_sf_index(T.shared.scalefactor, v[i]) != tl_sf_index_ref(T.shared.scalefactor, v[i])) bad++;
+    return bad;
+}
 void emu_scalefactors(double *out) { static TlTables T; tl_build_tables(&T); for (int i = 0; i < 64; i++) out[i] = T.scalefactor[i]; }
 // tl_div_by against the division it replaces; returns the number of mismatching quotients among n (s[i], d[i]) pairs
 long emu_div_by_check(const double *s, const double *d, long n)

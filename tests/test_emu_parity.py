@@ -96,6 +96,24 @@ def test_emulated_log10_pow10_accuracy():
     assert worst <= 1
 
 
+def test_scalefactor_index():
+    """tl_sf_index (exponent bracket + three table reads) == the reference's binary search (encode_new.c:208-218): every table
+    entry and its neighbours, powers of two and their neighbours, random magnitudes over the whole range, zero and denormals."""
+    import ctypes as C
+    L = E.lib()
+    L.emu_sf_index_check.restype = C.c_long
+    L.emu_sf_index_check.argtypes = [C.c_void_p, C.c_long]
+    tab = (C.c_double * 64)()
+    L.emu_scalefactors(tab)
+    sf = np.array(tab)
+    rng = np.random.default_rng(11)
+    p2 = 2.0 ** np.arange(-80, 1)
+    vals = np.concatenate([sf, np.nextafter(sf, 0), np.nextafter(sf, 4), p2, np.nextafter(p2, 0), np.nextafter(p2, 4),
+                           10.0 ** rng.uniform(-25, 0.3, 400000), rng.uniform(0, 2, 400000), [0.0, 5e-324, 1e-310, 1e-300, 1.999999]])
+    vals = np.ascontiguousarray(vals[vals < 2.0])
+    assert L.emu_sf_index_check(vals.ctypes.data, len(vals)) == 0
+
+
 def test_snr_columns_increase():
     """bits_for_nonoise as a count (joint-stereo trials) and the allocation rounds rely on it (encode_new.c:16-27,96-100)."""
     assert E.lib().emu_snr_monotone() == 1
