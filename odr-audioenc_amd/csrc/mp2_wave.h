@@ -356,6 +356,20 @@ TL_FN void tl_mask_spans(const TlMasker *mk, int nm, int ntone, double blo, doub
         b0 = (mn && fn < b0) ? fn : b0; b1 = mn ? ln : b1;
     }
 }
+// Running minimum over rows [j0, j0 + n) in the reference's order and with its comparison (`if (m > v) m = v`), four rows
+// per LDS round trip; a short last group repeats the last row, which changes nothing.  take_first: m starts as row j0.
+TL_FN double tl_min_rows(const double *ltg, int j0, int n, double m, bool take_first)
+{
+    const int last = j0 + n - 1;
+    for (int j = j0; j <= last; j += 4) {
+        const double a = ltg[j], b = ltg[j + 1 <= last ? j + 1 : last], c = ltg[j + 2 <= last ? j + 2 : last], d = ltg[j + 3 <= last ? j + 3 : last];
+        if (take_first && j == j0) m = a; else if (m > a) m = a;
+        if (m > b) m = b;
+        if (m > c) m = c;
+        if (m > d) m = d;
+    }
+    return m;
+}
 // scalefactors transmitted for scfsi 0..3: 3, 2, 1, 2 (encode_new.c:1101, sfsPerScfsi) -- from a constant, not from memory
 TL_FN int tl_sfs_count(unsigned scfsi) { return (int)((0x2123u >> (4u * (scfsi & 3u))) & 15u); }
 TL_FN unsigned tl_sf_index_ref(const double *TL_RESTRICT sf, double cur_max)
@@ -1047,8 +1061,7 @@ TL_FN void tl_psy1_thresholds(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, 
         int n = C->p1_mm_n[lane], j0 = C->p1_mm_j0[lane];
         if (n == 0) m = C->p1_hear[sub - 1];
         else {
-            m = TL_LTG(w)[j0];
-            for (int j = j0 + 1; j < j0 + n; j++) if (m > TL_LTG(w)[j]) m = TL_LTG(w)[j];
+            m = tl_min_rows(TL_LTG(w), j0, n, 0.0, true);
         }
         double max = C->scale_db[w.minidx[ch][lane]];
         if (w.spike[lane] > max) max = w.spike[lane];
@@ -1693,7 +1706,7 @@ TL_FN void tl_psy3_back(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const 
     if (lane < 32) {
         double m = 999999.9;
         const int j0 = C->p3_sb_j0[lane], n = C->p3_sb_n[lane];
-        for (int j = j0; j < j0 + n; j++) if (m > TL_LTG(w)[j]) m = TL_LTG(w)[j];
+        m = tl_min_rows(TL_LTG(w), j0, n, m, false);
         w.smr[ch][lane] = w.spike[lane] - m;
     }
     TL_LANES_END
@@ -1865,8 +1878,22 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
         TL_LANES_BEGIN
         {
             double e = 0, c = 0;
-            if (lane < P->npart)
-                for (int j = P->part_lo[lane]; j < P->part_hi[lane]; j++) { e += energy[j]; c += energy[j] * cw[j]; }
+            if (lane < P->npart) {
+                const int lo = P->part_lo[lane], hi = P->part_hi[lane];
+                int j = lo;
+                for (; j + 8 <= hi; j += 8) {                           // eight lines' operands per LDS round trip, summed in line order
+                    double ev[8], cv[8];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                    for (int q = 0; q < 8; q++) { ev[q] = energy[j + q]; cv[q] = cw[j + q]; }
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                    for (int q = 0; q < 8; q++) { e += ev[q]; c += ev[q] * cv[q]; }
+                }
+                for (; j < hi; j++) { e += energy[j]; c += energy[j] * cw[j]; }
+            }
             ge[lane] = e; gc[lane] = c;
         }
         TL_LANES_END
