@@ -239,12 +239,13 @@ TL_HD int tl_rem_pio2(double x, double *y0, double *y1)
     return n;
 }
 TL_HD double tl_ksin(double x, double y, int iy)
-{
+{   // both forms are evaluated and one is selected: a wave's lanes are on both sides of the reduction threshold anyway
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                  S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     const double z = x * x, v = z * x, r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-    if (iy == 0) return x + v * (S1 + z * r);
-    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+    const double plain = x + v * (S1 + z * r);
+    const double tail = x - ((z * (0.5 * y - v * r) - y) - v * S1);
+    return iy == 0 ? plain : tail;
 }
 TL_HD double tl_kcos(double x, double y)
 {
@@ -253,53 +254,54 @@ TL_HD double tl_kcos(double x, double y)
     const double z = x * x;
     const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
     const int32_t ix = (int32_t)(tl_d2u(x) >> 32) & 0x7fffffff;
-    if (ix < 0x3FD33333) return 1.0 - (0.5 * z - (z * r - x * y));
+    const double zr = z * r - x * y;
+    const double small = 1.0 - (0.5 * z - zr);                      // |x| < 0.3
     const double qx = ix > 0x3fe90000 ? 0.28125 : tl_u2d((uint64_t)(uint32_t)(ix - 0x00200000) << 32);
     const double hz = 0.5 * z - qx, a = 1.0 - qx;
-    return a - (hz - (z * r - x * y));
+    return ix < 0x3FD33333 ? small : a - (hz - zr);
 }
 TL_HD void tl_sincos(double x, double *sn, double *cs)
 {
     const int32_t ix = (int32_t)(tl_d2u(x) >> 32) & 0x7fffffff;
-    double y0 = x, y1 = 0.0;
-    int n = 0;
-    if (ix > 0x3fe921fb) n = tl_rem_pio2(x, &y0, &y1);
-    const double s = tl_ksin(y0, y1, ix > 0x3fe921fb), c = tl_kcos(y0, y1);
-    switch (n & 3) {
-    case 0: *sn = s; *cs = c; break;
-    case 1: *sn = c; *cs = -s; break;
-    case 2: *sn = -s; *cs = -c; break;
-    default: *sn = -c; *cs = s; break;
-    }
+    const bool reduce = ix > 0x3fe921fb;                             // |x| > pi/4
+    double r0, r1;
+    const int nr = tl_rem_pio2(x, &r0, &r1);                         // harmless below the threshold (its result is dropped)
+    const double y0 = reduce ? r0 : x, y1 = reduce ? r1 : 0.0;
+    const int n = reduce ? nr : 0;
+    const double s = tl_ksin(y0, y1, reduce ? 1 : 0), c = tl_kcos(y0, y1);
+    const bool swap = n & 1;
+    const double a = swap ? c : s, b = swap ? s : c;                 // quadrants: (s, c), (c, -s), (-s, -c), (-c, s)
+    *sn = (n & 2) ? -a : a;
+    *cs = (((n + 1) & 2) != 0) ? -b : b;
 }
 
 TL_HD double tl_atan(double x)
-{
+{   // fdlibm s_atan.c, written without branches: the five argument ranges differ in the quotient that is formed (num/den), in
+    // the constant (hi, lo) added back and in nothing else, so both are selected and ONE division runs whatever mix of
+    // ranges the lanes of a wave are in.  The small-argument range (no reduction) is num/den = |x|/1 with hi = lo = 0:
+    // hi - ((t*p - lo) - t) is then t - t*p, the range's own formula, and the sign is applied at the end as in the others.
     const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01, aT2 = 1.42857142725034663711e-01,
                  aT3 = -1.11111104054623557880e-01, aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
                  aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02, aT8 = 4.97687799461593236017e-02,
                  aT9 = -3.65315727442169155270e-02, aT10 = 1.62858201153657823623e-02;
     const int32_t hx = (int32_t)(tl_d2u(x) >> 32), ix = hx & 0x7fffffff;
-    int id;
-    double hi = 0, lo = 0;
-    if (ix >= 0x44100000) { const double r = 1.57079632679489655800e+00 + 6.12323399573676603587e-17; return hx > 0 ? r : -r; }
-    if (ix < 0x3fdc0000) { if (ix < 0x3e400000) return x; id = -1; }
-    else {
-        x = x < 0 ? -x : x;
-        if (ix < 0x3ff30000) {
-            if (ix < 0x3fe60000) { id = 0; x = (2.0 * x - 1.0) / (2.0 + x); hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
-            else { id = 1; x = (x - 1.0) / (x + 1.0); hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
-        } else {
-            if (ix < 0x40038000) { id = 2; x = (x - 1.5) / (1.0 + 1.5 * x); hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
-            else { id = 3; x = -1.0 / x; hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
-        }
-    }
-    const double z = x * x, w = z * z;
+    const double ax = tl_u2d(tl_d2u(x) & 0x7fffffffffffffffull);
+    const bool r_small = ix < 0x3fdc0000, r0 = ix < 0x3fe60000, r1 = ix < 0x3ff30000, r2 = ix < 0x40038000;
+    const double num = r_small ? ax : r0 ? 2.0 * ax - 1.0 : r1 ? ax - 1.0 : r2 ? ax - 1.5 : -1.0;
+    const double den = r_small ? 1.0 : r0 ? 2.0 + ax : r1 ? ax + 1.0 : r2 ? 1.0 + 1.5 * ax : ax;
+    const double hi = r_small ? 0.0 : r0 ? 4.63647609000806093515e-01 : r1 ? 7.85398163397448278999e-01
+                    : r2 ? 9.82793723247329054082e-01 : 1.57079632679489655800e+00;
+    const double lo = r_small ? 0.0 : r0 ? 2.26987774529616870924e-17 : r1 ? 3.06161699786838301793e-17
+                    : r2 ? 1.39033110312309984516e-17 : 6.12323399573676603587e-17;
+    const double t = num / den;
+    const double z = t * t, w = z * z;
     const double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
     const double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-    if (id < 0) return x - x * (s1 + s2);
-    const double zz = hi - ((x * (s1 + s2) - lo) - x);
-    return hx < 0 ? -zz : zz;
+    const double zz = hi - ((t * (s1 + s2) - lo) - t);
+    double res = hx < 0 ? -zz : zz;
+    res = ix < 0x3e400000 ? x : res;                                  // |x| < 2^-27
+    const double big = 1.57079632679489655800e+00 + 6.12323399573676603587e-17;
+    return ix >= 0x44100000 ? (hx > 0 ? big : -big) : res;           // |x| >= 2^66
 }
 TL_HD double tl_atan2(double y, double x)
 {
