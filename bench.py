@@ -168,6 +168,16 @@ def main():
                 traffic = pm["hbm_bytes_per_launch"]
         except Exception:  # noqa: BLE001
             pass
+        # what actually binds the kernel: VALU issue (SQ counters, tools/pmc_sq.sh; committed measurement of this workload)
+        valu = None
+        try:
+            sq = json.load(open(ROOT / "profiles" / "sq_counters_latest.json"))
+            if traffic is not None:
+                d = sq["derived"]
+                valu = {"valu_busy_per_simd": d["valu_busy_per_simd_at_2_waves"], "wave_cycles_waiting": d["waiting_share"],
+                        "valu_instructions_per_frame": d["per_frame"]["valu"], "source": "profiles/sq_counters_latest.json"}
+        except Exception:  # noqa: BLE001
+            pass
         achieved = algo_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         res = {
             "metric": "real-time stereo DAB MP2 streams sustained (frames/s) @128 kbps/48 kHz",
@@ -185,6 +195,7 @@ def main():
                          "secondary_fp64": {"achieved_tflops": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 1e12, 3), "peak_tflops": 78.6,
                                             "frac": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 78.6e12, 5),
                                             "basis": "0.35 MFLOP algorithmic fp64 per stereo frame (SURVEY 8d), vector fp64 peak"},
+                         "valu_issue": valu,
                          "note": "the path is fp64-VALU/LDS-latency bound, not HBM bound (SURVEY F9): compulsory traffic is "
                                  "4992 B per 0.35 MFLOP frame"},
             "lds_bytes_per_stream": M.lds_bytes_per_stream(),

@@ -81,5 +81,6 @@ if acc:
                      "valu_busy_per_simd_at_2_waves": round(2 * sq["SQ_ACTIVE_INST_VALU"] / wc, 3),
                      "lds_conflict_share_of_lds_active": round(sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"], 3)}
     json.dump(sq, open(P / f"{ROUND}_{V}_sq_counters.json", "w"), indent=1)
+    json.dump(sq, open(P / "sq_counters_latest.json", "w"), indent=1)
     print(json.dumps(sq["derived"]))
 print(json.dumps({k: bench[k] for k in ("value", "ms_per_step")}), bench["roofline"]["kernel_ms"], bench.get("cpu_baseline", {}))
