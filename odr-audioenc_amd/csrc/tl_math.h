@@ -304,24 +304,19 @@ TL_HD double tl_atan(double x)
     return ix >= 0x44100000 ? (hx > 0 ? big : -big) : res;           // |x| >= 2^66
 }
 TL_HD double tl_atan2(double y, double x)
-{
+{   // fdlibm e_atan2.c for finite arguments, without branches (the quotient and the arctangent are always formed; the
+    // special cases select over them), so that several calls can be in flight in one lane
     const double pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16, pi_o_2 = 1.5707963267948965580E+00;
     const uint64_t ux = tl_d2u(x), uy = tl_d2u(y);
     const int32_t hx = (int32_t)(ux >> 32), hy = (int32_t)(uy >> 32), ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
     const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
-    if ((uy << 1) == 0) {                                   // y = +-0
-        switch (m) { case 0: case 1: return y; case 2: return pi; default: return -pi; }
-    }
-    if ((ux << 1) == 0) return hy < 0 ? -pi_o_2 : pi_o_2;  // x = +-0
     const int k = (iy - ix) >> 20;
-    double z;
-    if (k > 60) z = pi_o_2 + 0.5 * pi_lo;
-    else if (hx < 0 && k < -60) z = 0.0;
-    else { double q = y / x; z = tl_atan(q < 0 ? -q : q); }
-    switch (m) {
-    case 0: return z;
-    case 1: return -z;
-    case 2: return pi - (z - pi_lo);
-    default: return (z - pi_lo) - pi;
-    }
+    const double q = y / x;
+    double z = tl_atan(q < 0 ? -q : q);
+    z = (hx < 0 && k < -60) ? 0.0 : z;
+    z = k > 60 ? pi_o_2 + 0.5 * pi_lo : z;
+    double res = m == 0 ? z : m == 1 ? -z : m == 2 ? pi - (z - pi_lo) : (z - pi_lo) - pi;
+    res = (ux << 1) == 0 ? (hy < 0 ? -pi_o_2 : pi_o_2) : res;       // x = +-0
+    res = (uy << 1) == 0 ? (m <= 1 ? y : m == 2 ? pi : -pi) : res;  // y = +-0 (first in the original)
+    return res;
 }
