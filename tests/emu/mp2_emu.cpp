@@ -149,6 +149,23 @@ long emu_sf_index_check(const double *v, long n)
     for (long i = 0; i < n; i++) if (tl_sf_index(T.shared.scalefactor, v[i]) != tl_sf_index_ref(T.shared.scalefactor, v[i])) bad++;
     return bad;
 }
+// tl_put_bits48 against bit-by-bit writing: n consecutive fields (lengths 1..48) from bit `start`; returns mismatching words
+long emu_put_bits48_check(const uint64_t *val, const int32_t *len, long n, int start)
+{
+    static uint32_t a[TL_MAX_FRAME_WORDS + 2], b[TL_MAX_FRAME_WORDS + 2];
+    memset(a, 0, sizeof a); memset(b, 0, sizeof b);
+    int pos = start;
+    for (long i = 0; i < n && pos + len[i] <= TL_MAX_FRAME_BYTES * 8; i++) {
+        const uint64_t v = val[i] & ((len[i] == 64) ? ~0ull : ((1ull << len[i]) - 1ull));
+        tl_put_bits48(a, pos, v, len[i]);
+        for (int k = 0; k < len[i]; k++)                                  // MSB first
+            if ((v >> (len[i] - 1 - k)) & 1ull) b[(pos + k) >> 5] |= 1u << (31 - ((pos + k) & 31));
+        pos += len[i];
+    }
+    long bad = 0;
+    for (int w = 0; w < TL_MAX_FRAME_WORDS + 2; w++) bad += a[w] != b[w];
+    return bad;
+}
 void emu_scalefactors(double *out) { static TlTables T; tl_build_tables(&T); for (int i = 0; i < 64; i++) out[i] = T.scalefactor[i]; }
 // tl_div_by against the division it replaces; returns the number of mismatching quotients among n (s[i], d[i]) pairs
 long emu_div_by_check(const double *s, const double *d, long n)

@@ -96,6 +96,23 @@ def test_emulated_log10_pow10_accuracy():
     assert worst <= 1
 
 
+def test_put_bits48():
+    """tl_put_bits48 (a field of up to 48 bits as three OR-ed words) == writing the field bit by bit, for every start offset
+    inside a word and random field lengths, including fields that end exactly on a word boundary."""
+    import ctypes as C
+    L = E.lib()
+    L.emu_put_bits48_check.restype = C.c_long
+    L.emu_put_bits48_check.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int]
+    rng = np.random.default_rng(5)
+    for start in range(0, 64):
+        n = 600
+        lens = rng.integers(1, 49, n).astype(np.int32)
+        if start % 3 == 0:
+            lens[::5] = 32 - (start % 32) if start % 32 else 32       # some fields ending on / spanning whole words
+        vals = rng.integers(0, 1 << 62, n, dtype=np.uint64)
+        assert L.emu_put_bits48_check(vals.ctypes.data, lens.ctypes.data, n, start) == 0
+
+
 def test_scalefactor_index():
     """tl_sf_index (exponent bracket + three table reads) == the reference's binary search (encode_new.c:208-218): every table
     entry and its neighbours, powers of two and their neighbours, random magnitudes over the whole range, zero and denormals."""
