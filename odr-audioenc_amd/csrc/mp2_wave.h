@@ -971,6 +971,17 @@ TL_FN void tl_psy1_chain2(TlWaveLds &w, const double *TL_RESTRICT db, int nbands
         const double *vt = w.u.fft;
         const int i0 = second ? (int)w.bandoff[band] : L(r0), i1 = second ? (int)w.bandoff[band + 1] : L(r1);
         int i = i0;
+        for (; i + 8 <= i1; i += 8) {                               // eight steps' operands per LDS round trip
+            double p[8], t[8];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 8; q++) { p[q] = vp[i + q]; t[q] = vt[i + q]; }
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 8; q++) { sum = tl_add_db(db, p[q], sum); weight += t[q]; }
+        }
         for (; i + 4 <= i1; i += 4) {
             const double p0 = vp[i], p1 = vp[i + 1], p2 = vp[i + 2], p3 = vp[i + 3];
             const double t0 = vt[i], t1 = vt[i + 1], t2 = vt[i + 2], t3 = vt[i + 3];   // channel 1's terms; lanes < 32 ignore their sum
@@ -1584,6 +1595,17 @@ TL_FN void tl_psy3_chain2(TlWaveLds &w, const double *TL_RESTRICT db, int nb, PA
         const double *vp = second ? w.px : w.u.fft;
         const int i0 = second ? (int)w.bandoff[band] : L(r0), i1 = second ? (int)w.bandoff[band + 1] : L(r1);
         int i = i0;
+        for (; i + 8 <= i1; i += 8) {                               // eight steps' operands per LDS round trip
+            double p[8];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 8; q++) p[q] = vp[i + q];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 8; q++) sum = tl_add_db(db, p[q], sum);
+        }
         for (; i + 4 <= i1; i += 4) {
             const double p0 = vp[i], p1 = vp[i + 1], p2 = vp[i + 2], p3 = vp[i + 3];
             sum = tl_add_db(db, p0, sum); sum = tl_add_db(db, p1, sum); sum = tl_add_db(db, p2, sum); sum = tl_add_db(db, p3, sum);
