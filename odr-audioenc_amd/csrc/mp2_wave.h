@@ -1100,11 +1100,19 @@ TL_FN void tl_psy1_back(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const 
     L(ontone) = lane < nbands && w.ptype[L(ncen)] == TL_T_TONE;
     TL_LANES_END
     const bool centre_on_tone = TL_BALLOT(ontone) != 0ull;            // only then can a tone's level be replaced (rare)
-    for (int b = 1; b < nbands; b++) {
-        const int cb = TL_READLANE_I32(ncen, b);
-        const double vb = tl_u2d(((uint64_t)(uint32_t)TL_READLANE_I32(nsh, b) << 32) | (uint32_t)TL_READLANE_I32(nsl, b));
-        TL_LANES_BEGIN if (lane < b && L(ncen) == cb) L(nlev) = vb; TL_LANES_END
-    }
+    // Two bands with the same centre are rare too.  Every band writes its index at its centre in a scratch map (the candidate
+    // records are dead by now) and reads it back: with all centres distinct every band finds itself; otherwise some band
+    // finds another one (whichever write lands last) and the overwrite order is resolved band by band.
+    PV(bool, shared_c);
+    uint8_t *cmark = (uint8_t *)w.cinfo;                              // centres are 1..510
+    TL_LANES_BEGIN if (lane < nbands) cmark[L(ncen)] = (uint8_t)lane; TL_LANES_END
+    TL_LANES_BEGIN L(shared_c) = lane < nbands && cmark[L(ncen)] != (uint8_t)lane; TL_LANES_END
+    if (TL_BALLOT(shared_c) != 0ull)
+        for (int b = 1; b < nbands; b++) {
+            const int cb = TL_READLANE_I32(ncen, b);
+            const double vb = tl_u2d(((uint64_t)(uint32_t)TL_READLANE_I32(nsh, b) << 32) | (uint32_t)TL_READLANE_I32(nsl, b));
+            TL_LANES_BEGIN if (lane < b && L(ncen) == cb) L(nlev) = vb; TL_LANES_END
+        }
 
     // ---- decimation (psycho_1.c:409-470) ----
     {
