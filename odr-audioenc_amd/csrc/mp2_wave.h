@@ -226,7 +226,7 @@ struct TlWaveLds {
     double smr[2][32];
     double spike[32];                   // psy-1 spike / psy-3 Lsb
     double nsum[32];                    // psy noise sums per critical band
-    uint32_t cinfo[TL_CAND_MAX];        // tone candidates (line | left-fail mask << 10); psy-1 slow path: links
+    uint32_t cinfo[TL_CAND_MAX];        // tone candidates (line | left-fail mask << 10 | run << 21); psy-1 slow path: links
     int16_t conf_c[TL_TONE_MAX];        // confirmed tones: line | variant << 12 | erased << 13
     int16_t conf_nxt[TL_TONE_MAX];      // psy-1: chain links between confirmed tones
     int16_t tlist[TL_TONE_MAX];         // psy-1: chain order
@@ -695,7 +695,7 @@ TL_FN void tl_cand_chunk(TlWaveLds &w, int c8, int &ncand)
         cnd = cnd && !(in && fa);
         r |= (in && fb) ? 1u << (10 + j - 2) : 0u;
     }
-    L(isc) = cnd; L(rec) = r;
+    L(isc) = cnd; L(rec) = r | ((uint32_t)run << 21);             // line | left-fail mask << 10 | run << 21
     TL_LANES_END
     const uint64_t m = TL_BALLOT(isc);
     TL_LANES_BEGIN
@@ -778,9 +778,10 @@ TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const 
             const uint32_t info = (uint32_t)TL_READLANE_I32(crec, k - kb);
             const int c = (int)(info & 511u);
             if (last >= 0 && c - last <= run_last) continue;          // unlinked by the help loop, psycho_1.c:309-312
-            const int run = tl_run_psy1(c);
+            const int run = (int)(info >> 21);
+            const uint32_t lfail = (info >> 10) & 0x7ffu;
             bool ok = true;
-            if (last < 0) { if (info >> 10) ok = false; }
+            if (last < 0) { if (lfail) ok = false; }
             else {
                 // neighbours c-j <= R were erased to DBMIN by `last` (they pass), except `last` itself,
                 // which carries its summed level; neighbours above R (or below last-run_last) are original
@@ -789,7 +790,7 @@ TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const 
                 const int lo_j = c - last + run_last + 1 > 2 ? c - last + run_last + 1 : 2;
                 uint32_t orig = hi_j >= 2 ? (1u << (hi_j - 1)) - 1u : 0u;
                 if (lo_j <= run) orig |= ((1u << (run - 1)) - 1u) & ~((1u << (lo_j - 2)) - 1u);
-                if ((info >> 10) & orig) ok = false;
+                if (lfail & orig) ok = false;
                 if (ok && c - last >= 2 && c - last <= run) {
                     const double xl = tl_add_db(db, w.px[last], tl_add_db(db, last_var ? TL_DBMIN : w.px[last - 1], w.px[last + 1]));
                     if (w.px[c] - 7 < xl) ok = false;
@@ -1463,10 +1464,10 @@ TL_FN int tl_psy3_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlo
             const uint32_t info = (uint32_t)TL_READLANE_I32(crec, q - kb);
             const int k = (int)(info & 511u);
             if (k <= R) continue;
-            const int sr = tl_run_psy3(k);
+            const int sr = (int)(info >> 21);
             const int hi_j = sr < k - R - 1 ? sr : k - R - 1;         // bit j-2 set for j in [2, sr] with k-j > R
             const uint32_t orig = hi_j >= 2 ? (1u << (hi_j - 1)) - 1u : 0u;
-            if ((info >> 10) & orig) continue;
+            if (((info >> 10) & 0x7ffu) & orig) continue;
             if (nconf < TL_TONE_MAX) w.conf_c[nconf++] = (int16_t)(k | ((k - 1 <= R) ? (1 << 12) : 0));
             R = k + sr;
         }
