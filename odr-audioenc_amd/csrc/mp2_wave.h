@@ -2020,7 +2020,8 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         TL_LANES_END
         // Window taps as a rolling register file: tap j of block b is tap j+1 of block b+2 (the window advances 32
         // samples per block, the taps are 64 apart), so each block reads two new samples per lane from LDS instead of
-        // sixteen (kept as integers: sixteen more doubles would not fit the register file).  Slot of (b, j): [b & 1][((b >> 1) - j) & 7].
+        // sixteen (kept as integers and converted at every use: a window of doubles, converted once, measured slower each
+        // time it was tried).  Slot of (b, j): [b & 1][((b >> 1) - j) & 7].
         PA(int, xa, 16); PA(int, xb, 16);
         TL_LANES_BEGIN
         const int c = lane & 1, i = lane >> 1;
