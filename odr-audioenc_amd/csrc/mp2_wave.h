@@ -672,7 +672,7 @@ TL_FN void tl_cand_chunk(TlWaveLds &w, int c8, int &ncand)
 {
     PV(bool, isc); PV(uint32_t, rec);
     TL_LANES_BEGIN
-    const int i = 64 * c8 + lane;
+    const int i = 64 * c8 + lane - 1;                               // chunks start one line early: the run lengths change at 63, 127, 255
     const bool inr = i >= 2 && i < 500;
     const int ii = inr ? i : 16;
     // every neighbour is read before the first test (TL_KEEP: otherwise the compiler reads each one only if the
@@ -759,9 +759,10 @@ TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const 
     // ---- tonal components (psycho_1.c:267-340) ----
     // (1) local maxima 2..499 whose right-hand neighbours pass the 7 dB test, compacted ascending
     int ncand = 0;
-    tl_cand_chunk<3, false>(w, 0, ncand);                           // lines < 64: run <= 3
-    for (int c8 = 1; c8 < 3; c8++) tl_cand_chunk<6, false>(w, c8, ncand);     // < 192: run <= 6
-    for (int c8 = 3; c8 < 8; c8++) tl_cand_chunk<12, false>(w, c8, ncand);
+    tl_cand_chunk<2, false>(w, 0, ncand);                           // lines -1..62: run 2
+    tl_cand_chunk<3, false>(w, 1, ncand);                           // 63..126: run 3
+    for (int c8 = 2; c8 < 4; c8++) tl_cand_chunk<6, false>(w, c8, ncand);     // 127..254: run 6
+    for (int c8 = 4; c8 < 8; c8++) tl_cand_chunk<12, false>(w, c8, ncand);    // 255..510: run 12
     TL_STAMP(sp, 2);
     // (2) wave-uniform walk: which candidates become tones.  State of the reference's list walk that
     //     matters: the last confirmed tone (`last`), its erasure reach R = last + run(last), and the
@@ -1447,9 +1448,10 @@ TL_FN int tl_psy3_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlo
     // ---- tone labelling (psycho_3.c:186-247) ----
     // (1) local maxima 2..499 whose right-hand neighbours are >= 7 dB down, compacted ascending
     int ncand = 0;
-    tl_cand_chunk<3, true>(w, 0, ncand);                            // lines < 64: run <= 3
-    for (int c8 = 1; c8 < 3; c8++) tl_cand_chunk<6, true>(w, c8, ncand);      // < 192: run <= 6
-    for (int c8 = 3; c8 < 8; c8++) tl_cand_chunk<12, true>(w, c8, ncand);
+    tl_cand_chunk<2, true>(w, 0, ncand);                           // lines -1..62: run 2
+    tl_cand_chunk<3, true>(w, 1, ncand);                           // 63..126: run 3
+    for (int c8 = 2; c8 < 4; c8++) tl_cand_chunk<6, true>(w, c8, ncand);     // 127..254: run 6
+    for (int c8 = 4; c8 < 8; c8++) tl_cand_chunk<12, true>(w, c8, ncand);    // 255..510: run 12
     TL_STAMP(sp, 2);
     // (2) wave-uniform walk.  A confirmed tone k erases lines k-sr..k+sr (itself included) to DBMIN
     //     (psycho_3.c:243-244); a later maximum inside that reach R has power DBMIN and always fails,
