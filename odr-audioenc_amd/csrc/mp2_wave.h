@@ -1717,9 +1717,11 @@ TL_FN void tl_psy3_back(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const 
         const int j = 128 + (lane & 7), line = C->p3_subset[j];
         const double bj = bark[line];
         const TlMasker *mk = TL_MK4(w);
-        const int t0 = lane < 8 ? 0 : ntone, t1 = lane < 8 ? ntone : ntone + nnoise;
+        int ta0, ta1, tb0, tb1;                                       // only the maskers that can reach the line (it is one of the top eight)
+        tl_mask_spans(mk, ntone + nnoise, ntone, bj - 8.0, bj + 3.0, ta0, ta1, tb0, tb1);
+        const int t0 = lane < 8 ? ta0 : tb0, t1 = lane < 8 ? ta1 : tb1;
         double acc = TL_DBMIN;
-        for (int t = t0; t < t1; t++) {
+        for (int t = t0; t <= t1; t++) {
             const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, n = mk[t].n;
             acc = tl_mask_step(db, acc, bj - mb, av, g, n);
         }
