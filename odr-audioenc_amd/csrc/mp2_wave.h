@@ -2402,7 +2402,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     // ---- K6: header, CRC, bit_alloc, scfsi, scalefactors, quantised samples -> LDS frame ----
     uint32_t *frame = w.u.frame;
     TL_LANES_BEGIN
-    for (int i = lane; i < TL_MAX_FRAME_WORDS; i += 64) frame[i] = 0;
+    for (int i = lane; i < ((lg_frame + 3) >> 2) + 2; i += 64) frame[i] = 0;      // this frame's words (+ 2: tl_put_bits48)
     TL_LANES_END
     PV(int, f_ba); PV(int, f_sel); PV(int, f_scf); PV(int, f_smp);
     PV(int, o_ba); PV(int, o_sel); PV(int, o_scf); PV(int, o_smp);
