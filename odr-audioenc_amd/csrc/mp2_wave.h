@@ -1346,7 +1346,7 @@ TL_FN void tl_psy1_stereo(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlB
         PV(double, wdummy);
         // the weight terms are gone; tl_psy1_chain's weight output is ignored (the parked sums are used)
         TL_LANES_BEGIN
-        for (int i = lane; i < 504; i += 64) w.u.fft[i] = 0.0;
+        for (int i = lane; i < 504; i += 64) { uint64_t z = 0; TL_KEEP(z); w.u.fft[i] = tl_u2d(z); }   // (a zero made here, not a register kept through the frame)
         TL_LANES_END
         tl_psy1_chain(w, B->dbtable, nbands, bsum, wdummy);
     } else {
