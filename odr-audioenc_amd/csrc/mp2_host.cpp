@@ -147,6 +147,16 @@ void tl_build_tables(TlTables *T)
             T->fht_tw[n][2] = c1 * c1 - s1 * s1; T->fht_tw[n][3] = 2 * (c1 * s1);
         }
     }
+    // butterfly g of pass k is the general butterfly i = 1 + g mod (kx-1) of its block (tl_fht_pass); row of (k, i) in
+    // fht_tw: first row of the pass + i - 1 (first rows: k=4 -> 1, k=6 -> 8, k=8 -> 39)
+    const int first_row[3] = {1, 8, 39};
+    for (int p = 0; p < 3; p++) {
+        const int kx = (1 << (4 + 2 * p)) >> 1, ngen = 128 - 128 / kx;
+        for (int g = 0; g < 128; g++) {
+            const int gg = g < ngen ? g : 0, i = 1 + gg % (kx - 1);
+            for (int q = 0; q < 4; q++) T->fht_tw_lane[p][g][q] = T->fht_tw[first_row[p] + i - 1][q];
+        }
+    }
 }
 
 int tl_psy2_slot(long samplerate)

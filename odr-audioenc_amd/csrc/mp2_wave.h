@@ -476,16 +476,13 @@ TL_FN void tl_fht_store(double *x, int lane, const double (&e)[16])
 }
 // Twiddles (c1,s1,c2,s2) of the (up to) two general butterflies a lane runs in pass K; fetched one pass ahead.
 template <int K>
-TL_FN void tl_fht_twiddles(double (&t)[8], int twbase, const double (*TL_RESTRICT tw)[4], int lane)
-{
-    constexpr int kx = (1 << K) >> 1, NGEN = 128 - 128 / kx;
+TL_FN void tl_fht_twiddles(double (&t)[8], const TlTables *TL_RESTRICT T, int lane)
+{   // rows in lane order (TlTables::fht_tw_lane): one address per lane, no index arithmetic
+    const double (*tw)[4] = T->fht_tw_lane[(K - 4) / 2];
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int g = lane + 64 * it, gg = g < NGEN ? g : 0;
-        const int blk = gg / (kx - 1), i = 1 + (gg - blk * (kx - 1));
+    for (int it = 0; it < 2; it++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) t[4 * it + q] = tw[twbase + i - 1][q];
-    }
+        for (int q = 0; q < 4; q++) t[4 * it + q] = tw[lane + 64 * it][q];
 }
 template <int K>
 TL_FN void tl_fht_pass(double *x, const double (&t)[8], int lane)
@@ -550,7 +547,7 @@ TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         const int16_t *cs = pv.cur + ch * 1152 - 192 + lane;
         const double *hann = T->hann;
         TL_LAUNDER(hann);
-        tl_fht_twiddles<4>(L(twc), 1, T->fht_tw, lane);
+        tl_fht_twiddles<4>(L(twc), T, lane);
         double e[16];
 #ifndef TL_EMULATE
 #pragma unroll
@@ -570,7 +567,7 @@ TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
                 e[r4] = ((double)v[q] / 32768) * h[q];
             }
         }
-        tl_fht_twiddles<6>(L(twb), 8, T->fht_tw, lane);
+        tl_fht_twiddles<6>(L(twb), T, lane);
         tl_fht_head(e, T->fht_tw);
         tl_fht_store(x, lane, e);
     }
@@ -578,7 +575,7 @@ TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     TL_STAMP(sq, 1);
     TL_STAMP(sq, 2);
     TL_STAMP(sq, 3);
-    TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), 39, T->fht_tw, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), T, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
     TL_STAMP(sq, 4);
     TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
     TL_STAMP(sq, 5);
@@ -1827,7 +1824,7 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
             // of their use; slot of i inside the lane's block of sixteen: rev4(it) (see tl_fht_head)
             const double *win = P->window;
             TL_LAUNDER(win);
-            tl_fht_twiddles<4>(L(twc), 1, T->fht_tw, lane);
+            tl_fht_twiddles<4>(L(twc), T, lane);
             double e[16];
 #ifndef TL_EMULATE
 #pragma unroll
@@ -1852,12 +1849,12 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
                     e[r4] = h[q] * (double)v[q];
                 }
             }
-            tl_fht_twiddles<6>(L(twb), 8, T->fht_tw, lane);
+            tl_fht_twiddles<6>(L(twb), T, lane);
             tl_fht_head(e, T->fht_tw);
             tl_fht_store(x, lane, e);
         }
         TL_LANES_END
-        TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), 39, T->fht_tw, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), T, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
         TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
         TL_LANES_BEGIN tl_fht_pass<8>(x, L(twa), lane); TL_LANES_END
         TL_STAMP(sq, 1);
