@@ -2,13 +2,23 @@
 """bench.py -- headline benchmark of the batched DAB MP2 encode path on MI355X.
 
 Metric (BASELINE.json): real-time stereo DAB MP2 streams sustained, as frames/s, @128 kbps / 48 kHz.
-Workload at N=1 = BASELINE.json configs[1]: 4096 streams x 48 kHz stereo x 128 kbps, psy model 1, full
-encode (filterbank + psy + allocation + quantise + pack + CRC/ScF-CRC), PCM resident in HBM.
 
-A "step" = one launch of the hot path: every stream encodes FRAMES_PER_STEP consecutive frames
-(per-stream state stays in LDS between them).  One process per GPU; streams shard with no data-path
-collective (weak scaling: each rank owns its own 4096 streams); RCCL is used only for the barrier
-and the max-over-ranks of the elapsed time.
+Workload
+  N = 1 : BASELINE.json configs[1] -- 4096 streams x 48 kHz stereo x 128 kbps, psy model 1, mode 's', full encode
+          (filterbank + psy + allocation + quantise + pack + CRC/ScF-CRC), PCM resident in HBM.  After the timed region
+          (never inside it) the same process also times mode 'j', configs[2] (16384 streams, psy 3) and the
+          PCIe-inclusive rate (pinned host buffers through tlb_encode_host) and reports them under "also".
+  N > 1 : BASELINE.json configs[3] -- 16384 streams PER GPU, psy model 3 (131072 streams on 8 GPUs), weak scaling.
+
+A "step" = one launch of the hot path: every stream encodes --frames-per-step consecutive frames (per-stream state stays
+on chip between them).  One process per GPU; streams shard with no data-path collective; RCCL carries only the
+barriers, the max-over-ranks of the elapsed time and one all_gather of (frames, seconds) per rank.
+
+Launching: `python bench.py --gpus N` starts the N rank processes ITSELF (fresh children, created before this
+process imports torch or touches a GPU); under `python -m torch.distributed.run ... bench.py --gpus N` (WORLD_SIZE set)
+it is one of the ranks.  --gpus must equal the world size.  `--dry-run` replaces the GPU by the TEST-ONLY lane-loop
+emulation (tests/emu) over gloo so that the multi-rank plumbing can be exercised on a CPU box; its numbers are not
+measurements and the line says so.
 
 Prints ONE JSON line on rank 0.
 """
@@ -16,25 +26,80 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
 from pathlib import Path
 
-import numpy as np
-
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
-STREAMS_PER_GPU = 4096
-FRAMES_PER_STEP = 8
-FS, MODE, KBPS, PSY = 48000, "s", 128, 1
+FS, KBPS = 48000, 128
 ALGO_BYTES_PER_FRAME = 2 * 1152 * 2 + 144000 * KBPS // FS      # PCM in + bitstream out = 4992
 HBM_PEAK_GBS = 8000.0                                           # MI355X_MICROARCH.md: 8 TB/s HBM3E
+# BASELINE.json configs[k] -> (streams per GPU, psy model)
+CONFIGS = {1: (4096, 1), 2: (16384, 3), 3: (16384, 3)}
 
 
-def cpu_baseline(seconds_target=12.0):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=None, help="streams per GPU (default: the BASELINE config of this N)")
+    ap.add_argument("--frames-per-step", type=int, default=16)
+    ap.add_argument("--psy", type=int, default=None)
+    ap.add_argument("--mode", default="s")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements after the headline")
+    ap.add_argument("--dry-run", action="store_true", help="CPU emulation over gloo: plumbing check only, not a measurement")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent has not imported torch and
+    never touches a GPU), relay rank 0's JSON line, fail if any rank fails."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: rank(s) failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def workload_label(streams, psy, mode, frames_per_step, world):
+    k = None
+    if (streams, psy) == CONFIGS[1] and world == 1:
+        k = 1
+    elif (streams, psy) == CONFIGS[2]:
+        k = 2 if world == 1 else 3
+    tag = f"BASELINE configs[{k}]" if k is not None else "not a BASELINE config"
+    total = f", {streams * world} streams in total" if world > 1 else ""
+    return (f"{streams} streams/GPU x 48 kHz stereo (mode '{mode}') x 128 kbps, psy {psy}, full encode ({tag}{total}), "
+            f"{frames_per_step} frames/stream/step"), k
+
+
+def cpu_baseline(psy, mode, seconds_target=12.0):
     """The REAL reference (oracle/_ref/libtoolame_ref.so, built from the reference's own sources) when
     it travelled with the repo, else the oracle port; one core, bounded sample of the same workload."""
     ref_so = ROOT / "oracle" / "_ref" / "libtoolame_ref.so"
@@ -68,7 +133,7 @@ else:
     for i in range(n): O.mp2o_encode_frame(h, ptrs[i & 63], None, 0, out, 4096)
     dt = time.perf_counter() - t
 print(n / dt)
-""" % (FS, PSY, MODE, KBPS, FS, MODE, KBPS, PSY)
+""" % (FS, psy, mode, KBPS, FS, mode, KBPS, psy)
     kind = "reference" if ref_so.exists() else "port"
     cmd = [sys.executable, "-c", child, str(ref_so) if ref_so.exists() else "", str(ora_so)]
     try:
@@ -93,122 +158,233 @@ print(n / dt)
     except Exception as ex:  # noqa: BLE001
         allc = {"value": None, "error": str(ex)}
     return {"value": round(fps, 1), "unit": "frames/s", "cores": 1, "kind": kind, "all_cores": allc,
-            "sample": f"{nframes} frames of one stream (seed 0, tones+noise), {FS} Hz mode '{MODE}' {KBPS} kbps psy {PSY}, "
+            "sample": f"{nframes} frames of one stream (seed 0, tones+noise), {FS} Hz mode '{mode}' {KBPS} kbps psy {psy}, "
                       f"{'libtoolame-dab compiled from the reference sources' if kind == 'reference' else 'oracle/mp2_oracle.c'}, gcc -O2, 1 thread"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU, help="streams per GPU")
-    ap.add_argument("--frames-per-step", type=int, default=FRAMES_PER_STEP)
-    ap.add_argument("--psy", type=int, default=PSY)
-    ap.add_argument("--mode", default=MODE)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class GpuRun:
+    """One workload resident on this rank's GPU: two alternating PCM buffers (frames [0,F) and [F,2F) of every stream), the
+    batch, the output buffer.  step(i) = one launch."""
 
+    def __init__(self, M, torch, np, gen_pcm, stream_ids, F, mode, psy, local_rank):
+        S = len(stream_ids)
+        host = np.empty((2 * F, S, 2, 1152), dtype=np.int16)
+        for k, sid in enumerate(stream_ids):          # stream i uses seed i (SURVEY 8d)
+            host[:, k] = gen_pcm(sid, 0, 0, 2 * F)
+        self.pcm = [torch.from_numpy(host[:F].copy()).cuda(), torch.from_numpy(host[F:].copy()).cuda()]
+        self.batch = M.Batch([M.StreamConfig(samplerate=FS, mode=mode, bitrate=KBPS, psy_model=psy)] * S, device=local_rank)
+        self.out = torch.zeros((F, S, self.batch.out_stride), dtype=torch.uint8, device="cuda")
+        self.stream = torch.cuda.current_stream()
+        self.F, self.S, self.torch, self.np = F, S, torch, np
+
+    def step(self, i):
+        self.batch.encode_device(self.pcm[i & 1].data_ptr(), self.F, self.out.data_ptr(), stream=self.stream.cuda_stream)
+
+    def timed(self, dist, shard, warmup, steps):
+        """-> (max-over-ranks seconds, own seconds, mean kernel ms from HIP events on the launch stream)"""
+        torch = self.torch
+        for i in range(warmup):
+            self.step(i)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+
+        def run():
+            for i in range(steps):
+                evs[i][0].record(self.stream)
+                self.step(warmup + i)
+                evs[i][1].record(self.stream)
+
+        elapsed, own = shard.timed_region_detail(dist, run, device_sync=torch.cuda.synchronize, device="cuda")
+        kernel_ms = float(self.np.mean([a.elapsed_time(b) for a, b in evs]))
+        return elapsed, own, kernel_ms
+
+    def check(self):
+        chk = self.out[1, :4].cpu().numpy()          # the frames are real frames (sync word), never timed
+        assert all(bytes(chk[s, :2]) == b"\xff\xfc" for s in range(min(4, self.S))), "output is not an MPEG audio frame"
+
+    def close(self):
+        self.batch.close()
+        del self.pcm, self.out
+
+
+def pcie_inclusive(M, np, gen_pcm, F, psy, mode, local_rank, streams, reps=3):
+    """tlb_encode_host on PINNED host buffers: PCM over PCIe in, frames over PCIe out, per call.  A labelled secondary
+    figure; never `value`."""
+    L = M.load_library()
+    b = M.Batch([M.StreamConfig(samplerate=FS, mode=mode, bitrate=KBPS, psy_model=psy)] * streams, device=local_rank)
+    n_in, n_out = F * streams * 2304 * 2, F * streams * b.out_stride
+    p_in, p_out = L.tlb_host_alloc(n_in), L.tlb_host_alloc(n_out)
+    if not p_in or not p_out:
+        return {"value": None, "error": "tlb_host_alloc failed"}
+    pcm = np.ctypeslib.as_array(C.cast(p_in, C.POINTER(C.c_int16)), shape=(F, streams, 2, 1152))
+    base = np.stack([gen_pcm(s, 0, 0, F) for s in range(64)], axis=1)
+    pcm[...] = np.tile(base, (1, streams // 64 + 1, 1, 1))[:, :streams]
+    L.tlb_encode_host(b.h, p_in, F, None, None, p_out, None)        # first call allocates the device staging buffers
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rc = L.tlb_encode_host(b.h, p_in, F, None, None, p_out, None)
+        assert rc == 0
+    dt = time.perf_counter() - t0
+    L.tlb_host_free(p_in)
+    L.tlb_host_free(p_out)
+    b.close()
+    return {"value": round(reps * F * streams / dt, 1), "unit": "frames/s", "what": "tlb_encode_host, pinned host buffers: "
+            f"{n_in / 1e6:.0f} MB PCM in + {n_out / 1e6:.0f} MB frames out over PCIe per call, synchronous", "streams": streams,
+            "frames_per_call": F, "gbytes_per_s_over_pcie": round(reps * (n_in + n_out) / dt / 1e9, 2)}
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return spawn_ranks(args, argv)               # before torch / any GPU call in this process
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}; they must agree")
+
+    import numpy as np
     import torch
 
     import odr_audioenc_amd as M
     import odr_audioenc_amd.shard as shard
     from pcmgen import gen_pcm
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    rank, local_rank, world, dist = shard.init_from_env("nccl")      # "nccl" is RCCL on ROCm
-
-    S, F = args.streams, args.frames_per_step
-    # stream i of rank r uses seed r*S + i; two alternating PCM buffers = frames [0,F) and [F,2F)
+    world = args.gpus
+    cfg_streams, cfg_psy = CONFIGS[1] if world == 1 else CONFIGS[3]
+    S = args.streams if args.streams is not None else cfg_streams
+    psy = args.psy if args.psy is not None else cfg_psy
+    F = args.frames_per_step
     t0 = time.time()
-    host = np.empty((2 * F, S, 2, 1152), dtype=np.int16)
-    for k, sid in enumerate(shard.weak_stream_ids(rank, S)):
-        host[:, k] = gen_pcm(sid, 0, 0, 2 * F)
-    pcm = [torch.from_numpy(host[:F].copy()).cuda(), torch.from_numpy(host[F:].copy()).cuda()]
-    del host
-    batch = M.Batch([M.StreamConfig(samplerate=FS, mode=args.mode, bitrate=KBPS, psy_model=args.psy)] * S, device=local_rank)
-    out = torch.zeros((F, S, batch.out_stride), dtype=torch.uint8, device="cuda")
-    stream = torch.cuda.current_stream()
 
-    def step(i):
-        batch.encode_device(pcm[i & 1].data_ptr(), F, out.data_ptr(), stream=stream.cuda_stream)
+    if args.dry_run:
+        return dry_run(args, shard, np, gen_pcm, world, S if args.streams is not None else 2, psy, min(F, 2))
 
-    for i in range(args.warmup):
-        step(i)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback; --dry-run only checks the plumbing)")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, local_rank, world_env, dist = shard.init_from_env("nccl")      # "nccl" is RCCL on ROCm
+    assert world_env == world
+    observed_world = dist.get_world_size() if dist is not None else 1
 
-    def timed():
-        for i in range(args.steps):
-            evs[i][0].record(stream)
-            step(args.warmup + i)
-            evs[i][1].record(stream)
+    run = GpuRun(M, torch, np, gen_pcm, shard.weak_stream_ids(rank, S), F, args.mode, psy, local_rank)
+    elapsed, own, kernel_ms = run.timed(dist, shard, args.warmup, args.steps)
+    last_ms = run.batch.last_kernel_ms()
+    run.check()
+    # per-rank (frames, own seconds): the only exchanged payload besides barriers
+    per_rank = shard.gather_floats(dist, [S * F * args.steps, own], device="cuda")
+    run.close()
 
-    # barrier + synchronize on both sides, MAX over ranks (shard.timed_region)
-    elapsed = shard.timed_region(dist, timed, device_sync=torch.cuda.synchronize, device="cuda")
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    last_ms = batch.last_kernel_ms()
-
-    # sanity: the frames are real frames (sync word + right length), never timed
-    chk = out[1, :4].cpu().numpy()
-    assert all(bytes(chk[s, :2]) == b"\xff\xfc" for s in range(4)), "output is not an MPEG audio frame"
-
+    res = None
     if rank == 0:
-        frames = world * S * F * args.steps
+        frames = sum(int(p[0]) for p in per_rank)
         value = frames / elapsed
         algo_bytes_per_launch = ALGO_BYTES_PER_FRAME * S * F
-        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh); only
-        # quoted when the committed measurement was taken on this very workload
-        traffic = None
+        kname = f"tl_encode_kernel<{2 if psy == 4 else psy}>"
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh): a committed
+        # measurement, quoted only when it was taken on this very workload; never measured inside this run
+        traffic, traffic_source, valu = None, None, None
         try:
             pm = json.load(open(ROOT / "profiles" / "pmc_traffic_latest.json"))
             wl = pm["workload"]
-            if (wl["streams"], wl["frames_per_step"], wl["psy"], wl["mode"]) == (S, F, args.psy, args.mode):
+            if (wl["streams"], wl["frames_per_step"], wl["psy"], wl["mode"]) == (S, F, psy, args.mode):
                 traffic = pm["hbm_bytes_per_launch"]
-        except Exception:  # noqa: BLE001
-            pass
-        # what actually binds the kernel: VALU issue (SQ counters, tools/pmc_sq.sh; committed measurement of this workload)
-        valu = None
-        try:
-            sq = json.load(open(ROOT / "profiles" / "sq_counters_latest.json"))
-            if traffic is not None:
+                traffic_source = "profiles/pmc_traffic_latest.json (committed rocprofv3 --pmc measurement of this workload, not this run)"
+                sq = json.load(open(ROOT / "profiles" / "sq_counters_latest.json"))
                 d = sq["derived"]
-                valu = {"valu_busy_per_simd": d["valu_busy_per_simd_at_2_waves"], "wave_cycles_waiting": d["waiting_share"],
-                        "valu_instructions_per_frame": d["per_frame"]["valu"], "source": "profiles/sq_counters_latest.json"}
+                valu = {"valu_busy_per_simd": d.get("valu_busy_per_simd"), "wave_cycles_waiting": d["waiting_share"],
+                        "valu_instructions_per_frame": d["per_frame"]["valu"], "waves_per_simd": d.get("waves_per_simd"),
+                        "source": "profiles/sq_counters_latest.json (committed, not this run)"}
         except Exception:  # noqa: BLE001
             pass
         achieved = algo_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        label, cfg_k = workload_label(S, psy, args.mode, F, world)
         res = {
             "metric": "real-time stereo DAB MP2 streams sustained (frames/s) @128 kbps/48 kHz",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{S} streams/GPU x 48 kHz stereo (mode '{args.mode}') x 128 kbps, psy {args.psy}, full encode "
-                                   f"(BASELINE configs[1]), {F} frames/stream/step", "streams_per_gpu": S, "frames_per_step": F,
+            "config": {"workload": label, "baseline_config": cfg_k, "streams_per_gpu": S, "frames_per_step": F,
+                       "frames_per_stream_timed": F * args.steps, "frames_per_stream_warmup": F * args.warmup,
                        "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
             "realtime_streams": round(value / (FS / 1152.0), 1),
+            "world_size_observed": observed_world, "collective_backend": "rccl (torch.distributed nccl)" if dist is not None else None,
+            "per_gpu_frames_per_s": [round(p[0] / p[1], 1) for p in per_rank],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": f"tl_encode_kernel<{2 if args.psy == 4 else args.psy}>", "kernel_ms": round(kernel_ms, 4), "last_kernel_ms_hip_events": round(last_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kname, "kernel_ms": round(kernel_ms, 4), "last_kernel_ms_hip_events": round(last_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch,
+                         "binding_resource": "fp64 VALU issue + LDS latency chains (not HBM: 4992 B per 0.35 MFLOP frame, SURVEY F9)",
                          "secondary_fp64": {"achieved_tflops": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 1e12, 3), "peak_tflops": 78.6,
                                             "frac": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 78.6e12, 5),
                                             "basis": "0.35 MFLOP algorithmic fp64 per stereo frame (SURVEY 8d), vector fp64 peak"},
-                         "valu_issue": valu,
-                         "note": "the path is fp64-VALU/LDS-latency bound, not HBM bound (SURVEY F9): compulsory traffic is "
-                                 "4992 B per 0.35 MFLOP frame"},
+                         "valu_issue": valu},
             "lds_bytes_per_stream": M.lds_bytes_per_stream(),
-            "setup_s": round(time.time() - t0, 1),
         }
+    # ---- secondary measurements, after (outside) the headline's timed region; single GPU only ----
+    if world == 1 and not args.no_also:
+        also = {}
+        F2 = min(F, 8)                                # shorter launches: 16384 streams x 8 frames = 604 MB of PCM per buffer
+        for name, (s2, p2, m2, f2) in {"mode_j": (S, psy, "j" if args.mode != "j" else "s", F),
+                                       "configs2_psy3_16384": (CONFIGS[2][0], CONFIGS[2][1], "s", F2)}.items():
+            try:
+                r2 = GpuRun(M, torch, np, gen_pcm, range(s2), f2, m2, p2, local_rank)
+                e2, _, k2 = r2.timed(None, shard, max(2, args.warmup // 2), max(5, args.steps // 2))
+                r2.check()
+                r2.close()
+                n2 = max(5, args.steps // 2)
+                also[name] = {"workload": workload_label(s2, p2, m2, f2, 1)[0], "value": round(s2 * f2 * n2 / e2, 1), "unit": "frames/s",
+                              "steps": n2, "kernel_ms": round(k2, 4),
+                              "roofline_frac_hbm": round(ALGO_BYTES_PER_FRAME * s2 * f2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
+            except Exception as ex:  # noqa: BLE001
+                also[name] = {"value": None, "error": str(ex)}
+        try:
+            also["pcie_inclusive"] = pcie_inclusive(M, np, gen_pcm, F2, psy, args.mode, local_rank, S)
+        except Exception as ex:  # noqa: BLE001
+            also["pcie_inclusive"] = {"value": None, "error": str(ex)}
+        res["also"] = also
+    if rank == 0:
+        res["setup_s"] = round(time.time() - t0, 1)
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline()
-        elif world > 1:
+            res["cpu_baseline"] = cpu_baseline(psy, args.mode)
+        else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return 0
+
+
+def dry_run(args, shard, np, gen_pcm, world, S, psy, F):
+    """The same rank plumbing (env, process group, barriers, max-over-ranks, gather, rank-0 line) with the TEST-ONLY
+    emulation of the kernel standing in for the GPU, over gloo.  Not a measurement."""
+    import emulib as E
+    rank, local_rank, world_env, dist = shard.init_from_env("gloo")
+    assert world_env == world
+    ids = list(shard.weak_stream_ids(rank, S))
+    pcm = np.stack([gen_pcm(i, 0, 0, 2 * F) for i in ids], axis=1)
+    b = E.EmuBatch([dict(mode=args.mode, psy=psy)] * S)
+    steps = min(args.steps, 2)
+
+    def run():
+        for i in range(steps):
+            b.encode(pcm[(i & 1) * F:(i & 1) * F + F])
+
+    elapsed, own = shard.timed_region_detail(dist, run)
+    per_rank = shard.gather_floats(dist, [S * F * steps, own])
+    if rank == 0:
+        frames = sum(int(p[0]) for p in per_rank)
+        label, cfg_k = workload_label(S, psy, args.mode, F, world)
+        print(json.dumps({
+            "metric": "DRY RUN (CPU emulation of the kernel over gloo; plumbing check, NOT a measurement)", "dry_run": True,
+            "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": 0,
+            "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic", "config": {"workload": label, "streams_per_gpu": S, "frames_per_step": F},
+            "world_size_observed": dist.get_world_size() if dist is not None else 1, "collective_backend": "gloo" if dist is not None else None,
+            "per_gpu_frames_per_s": [round(p[0] / p[1], 1) for p in per_rank], "roofline": None, "cpu_baseline": None}), flush=True)
+    b.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -47,12 +47,33 @@ def barrier(dist, device_sync=None):
 
 def timed_region(dist, fn, device_sync=None, device="cpu"):
     """barrier + sync, run fn(), barrier + sync; returns MAX over ranks of the elapsed seconds."""
+    return timed_region_detail(dist, fn, device_sync, device)[0]
+
+
+def timed_region_detail(dist, fn, device_sync=None, device="cpu"):
+    """As timed_region; returns (MAX over ranks of the barrier-to-barrier seconds, this rank's own seconds from the
+    opening barrier to the end of its own device work -- what the per-GPU rate is computed from)."""
     barrier(dist, device_sync)
     t0 = time.perf_counter()
     fn()
+    if device_sync:
+        device_sync()
+    own = time.perf_counter() - t0
     barrier(dist, device_sync)
     elapsed = time.perf_counter() - t0
-    return reduce_max(dist, elapsed, device)
+    return reduce_max(dist, elapsed, device), own
+
+
+def gather_floats(dist, values, device="cpu"):
+    """all_gather of a short list of floats per rank -> [world][len(values)] (a few bytes: the only traffic besides
+    the barriers; on the GPU box it travels over RCCL/xGMI)."""
+    if dist is None:
+        return [[float(v) for v in values]]
+    import torch
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(x) for x in o.cpu().tolist()] for o in out]
 
 
 def reduce_max(dist, value, device="cpu"):

@@ -74,3 +74,44 @@ def test_two_rank_gloo_sharding(tmp_path):
     tail = b.flush()
     for i in range(6):
         assert merged[i] == got[i] + tail[i]
+
+
+def _run_bench(args, timeout=300):
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")})
+    return r
+
+
+def test_bench_gpus_spawns_ranks_dry_run():
+    """`python bench.py --gpus 2` (no launcher) starts two rank processes itself; with --dry-run the emulation stands in for
+    the GPU.  The line says n_gpus 2, the process group saw two ranks, both ranks contributed frames."""
+    import json
+    r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["world_size_observed"] == 2 and line["dry_run"] is True
+    assert len(line["per_gpu_frames_per_s"]) == 2 and all(v > 0 for v in line["per_gpu_frames_per_s"])
+    assert "configs[3]" not in line["config"]["workload"]          # 2 emulated streams per rank are not the BASELINE config
+    # the same code path at N = 1
+    r1 = _run_bench(["--gpus", "1", "--dry-run", "--steps", "2"])
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    l1 = json.loads(r1.stdout.strip().splitlines()[-1])
+    assert l1["n_gpus"] == 1 and l1["world_size_observed"] == 1 and len(l1["per_gpu_frames_per_s"]) == 1
+
+
+def test_bench_rejects_world_size_mismatch():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_bench_workload_labels():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    assert "configs[1]" in bench.workload_label(4096, 1, "s", 16, 1)[0]
+    assert "configs[2]" in bench.workload_label(16384, 3, "s", 8, 1)[0]
+    lab, k = bench.workload_label(16384, 3, "s", 8, 8)
+    assert k == 3 and "configs[3]" in lab and "131072 streams in total" in lab
+    assert bench.workload_label(4096, 3, "s", 8, 1)[1] is None
+    a = bench.parse_args(["--gpus", "8"])
+    assert a.gpus == 8 and a.streams is None and a.psy is None
