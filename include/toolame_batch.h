@@ -65,7 +65,8 @@ typedef struct {
     int bitrate;                   /* kbps; 0 = the reference default (192 / 160) */
     int psy_model;                 /* 0, 1, 2, 3 (toolame.c:202-210); 4 = psycho_4.c, an extension of this API only: the
                                       reference implements it (toolame.c:384-391) but its setter refuses it */
-    int pad_len;                   /* toolame_set_pad(): upper bound of xpad_len, 0..TLB_MAX_XPAD */
+    int pad_len;                   /* toolame_set_pad(): upper bound of xpad_len, 0..TLB_MAX_XPAD; must leave room for header, CRC and
+                                      bit allocation in the frame (else TLB_ERR_PAD) */
 } tlb_stream_config;
 
 typedef struct tlb_batch tlb_batch;
@@ -86,7 +87,7 @@ long tlb_frames_encoded(const tlb_batch *b);           /* per stream */
  *   d_pcm      int16  [nframes][nstreams][2][1152]   planar like `short buffer[2][1152]`; mono reads [0] only
  *   d_xpad     uint8  [nframes][nstreams][TLB_MAX_XPAD] or NULL: the xpad_len bytes in transmission order
  *              (X-PAD bytes, then the two F-PAD bytes; toolame.c:515-551)
- *   d_xpad_len int32  [nframes][nstreams] or NULL; each 0 or 2..pad_len
+ *   d_xpad_len int32  [nframes][nstreams] or NULL; each 0 or 2..pad_len (any other value: the frame carries no PAD)
  *   d_out      uint8  [nframes][nstreams][tlb_out_stride()]
  * Frame n of a stream is final only once frame n+1 has been analysed (its ScF-CRC is stored in frame
  * n, toolame.c:527-542), so output slot f of this call holds the frame that was pending before input
@@ -99,6 +100,11 @@ int tlb_encode_device(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
  * [nframes][nstreams] TlTaps records (csrc/mp2_types.h) for stage-level parity tests. */
 int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t *xpad, const int32_t *xpad_len,
                     uint8_t *out, void *taps);
+/* Pinned (page-locked) host memory for the host-buffer entry points: copies from/to it run at PCIe link rate and
+ * tlb_encode_host() queues copy-in, launch and copy-out without an intermediate synchronisation.  Pageable memory works
+ * too, only slower.  The batch keeps its device staging buffers between calls (no allocation per call after the first). */
+void *tlb_host_alloc(size_t bytes);
+void tlb_host_free(void *p);
 /* Copy every stream's pending (last) frame to out[nstreams][tlb_out_stride()] (host memory).
  * Streams that have not encoded any frame yet get zero bytes.  Does not change state. */
 int tlb_flush_host(tlb_batch *b, uint8_t *out);

@@ -48,7 +48,19 @@ TL_FN void tl_edi_pft_packet(const TlPftArgs &A, const TlPftTables &R, int s, in
     uint8_t *par = W.par;
     const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
     const uint8_t *gaf = A.af + slot * (size_t)A.af_stride;
-    const uint32_t l = (uint32_t)A.af_len[slot];
+    uint32_t l = (uint32_t)A.af_len[slot];
+    // an AF packet of no bytes, or of more than its slot / the staging buffer can hold, produces no fragments (the packet
+    // sequence number still advances): nothing below divides by a zero chunk count or copies past W.af
+    const uint32_t lmax = (uint32_t)A.af_stride < (uint32_t)sizeof(W.af) ? (uint32_t)A.af_stride : (uint32_t)sizeof(W.af);
+    if ((int32_t)l <= 0 || l > lmax) {
+        TL_LANES_BEGIN
+        if (lane == 0) {
+            A.nfrag[slot] = 0;
+            if (f == A.nframes - 1) A.pseq_out[s] = (uint16_t)(A.pseq[s] + A.nframes);
+        }
+        TL_LANES_END
+        return;
+    }
     TL_LANES_BEGIN
     for (uint32_t i = 4 * (uint32_t)lane; i < l; i += 256) *(uint32_t *)&W.af[i] = *(const uint32_t *)(gaf + i);     // af_stride is a multiple of 4
     TL_LANES_END

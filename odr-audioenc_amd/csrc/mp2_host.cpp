@@ -334,6 +334,11 @@ int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, 
         if (average - (double)whole != 0) return TL_ERR_SAMPLERATE;
         C->frame_bytes = whole;
         if (whole > TL_MAX_FRAME_BYTES || (whole & 3)) return TL_ERR_BITRATE;
+        // the PAD of a frame must leave room for header (4), CRC-16 (2), the bit_alloc fields and the ScF-CRC: with less the
+        // bit budget of toolame.c:292-301 goes negative (the reference then writes a broken frame); such a pad length is refused
+        int bbal = 0;
+        for (int sb = 0; sb < C->sblimit; sb++) bbal += C->nbal[sb] * (sb < C->jsbound0 ? C->nch : 1);
+        if (pad_len && 8 * (pad_len + C->dab_ext) + 32 + 16 + bbal > 8 * whole) return TL_ERR_PAD;
     }
     for (int i = 0; i < 63; i++) {
         const double sf = (double)TL_SCALEFACTOR_E14[i] / 1e14;

@@ -2694,7 +2694,10 @@ TL_FN void tl_encode_stream(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, co
         int xl = 0;
         if (A.xpad_len) {
             xl = A.xpad_len[slot];
-            if (xl < 2 || xl > TL_MAX_XPAD) xl = 0;
+            // the contract is 0 or 2..pad_len (toolame.c:515-516, odr-audioenc.cpp:803,830-834); anything else -- more than
+            // the stream's toolame_set_pad() length, more than the record holds -- is treated as "no PAD this frame"
+            // (tl_build_config has made sure that pad_len itself fits into the frame)
+            if (xl < 2 || xl > TL_MAX_XPAD || xl > C->dab_length) xl = 0;
             TL_LANES_BEGIN
             for (int i = lane; i < xl; i += 64) w.xpad[i] = A.xpad[slot * TL_MAX_XPAD + i];
             TL_LANES_END

@@ -16,7 +16,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define TL_HD __host__ __device__ __forceinline__
 #else
 #define TL_HD static inline

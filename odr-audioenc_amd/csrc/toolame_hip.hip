@@ -196,7 +196,20 @@ struct tlb_batch {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;
     bool timed = false;
+    // device staging of the host-buffer entry point (tlb_encode_host): grow-only, created on first use, so a caller that
+    // feeds one frame per call (the legacy shim) pays for no allocation after its first frame
+    void *stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // pcm, out, xpad, xpad_len, taps
+    size_t stage_cap[5] = {0, 0, 0, 0, 0};
 };
+
+static hipError_t stage_reserve(tlb_batch *b, int k, size_t bytes)
+{
+    if (b->stage_cap[k] >= bytes) return hipSuccess;
+    if (b->stage[k]) { (void)hipFree(b->stage[k]); b->stage[k] = nullptr; b->stage_cap[k] = 0; }
+    hipError_t e = hipMalloc(&b->stage[k], bytes);
+    if (e == hipSuccess) b->stage_cap[k] = bytes;
+    return e;
+}
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     fprintf(stderr, "libtoolame-dab-hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
@@ -231,6 +244,7 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_edi_state_tmp) (void)hipFree(b->d_edi_state_tmp);
     if (b->d_pseq_tmp) (void)hipFree(b->d_pseq_tmp);
     for (int p = 0; p < 4; p++) if (b->d_list[p]) (void)hipFree(b->d_list[p]);
+    for (int k = 0; k < 5; k++) if (b->stage[k]) (void)hipFree(b->stage[k]);
     if (b->d_psy2_tables) (void)hipFree(b->d_psy2_tables);
     if (b->d_psy2_state) (void)hipFree(b->d_psy2_state);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -373,36 +387,43 @@ int tlb_encode_device(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
 int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t *xpad, const int32_t *xpad_len,
                     uint8_t *out, void *taps)
 {
-    DevFree guard_;
     if (!b || !pcm || !out || nframes <= 0) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
     const size_t slots = (size_t)nframes * (size_t)b->nstreams;
-    int16_t *d_pcm = nullptr; uint8_t *d_xpad = nullptr; int32_t *d_xl = nullptr; uint8_t *d_out = nullptr; TlTaps *d_taps = nullptr;
-    int rc = TLB_OK;
-    hipError_t e = hipMalloc(&d_pcm, slots * 2304 * sizeof(int16_t));
-    if (e == hipSuccess) e = hipMalloc(&d_out, slots * (size_t)b->out_stride);
-    if (e == hipSuccess) e = hipMemset(d_out, 0, slots * (size_t)b->out_stride);
-    if (e == hipSuccess) e = hipMemcpy(d_pcm, pcm, slots * 2304 * sizeof(int16_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess && xpad && xpad_len) {
-        e = hipMalloc(&d_xpad, slots * TL_MAX_XPAD);
-        if (e == hipSuccess) e = hipMalloc(&d_xl, slots * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMemcpy(d_xpad, xpad, slots * TL_MAX_XPAD, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_xl, xpad_len, slots * sizeof(int32_t), hipMemcpyHostToDevice);
+    const size_t n_pcm = slots * 2304 * sizeof(int16_t), n_out = slots * (size_t)b->out_stride;
+    const bool with_xpad = xpad && xpad_len;
+    HIPCHK(stage_reserve(b, 0, n_pcm));
+    HIPCHK(stage_reserve(b, 1, n_out));
+    if (with_xpad) { HIPCHK(stage_reserve(b, 2, slots * TL_MAX_XPAD)); HIPCHK(stage_reserve(b, 3, slots * sizeof(int32_t))); }
+    if (taps) HIPCHK(stage_reserve(b, 4, slots * sizeof(TlTaps)));
+    int16_t *d_pcm = (int16_t *)b->stage[0]; uint8_t *d_out = (uint8_t *)b->stage[1];
+    uint8_t *d_xpad = with_xpad ? (uint8_t *)b->stage[2] : nullptr; int32_t *d_xl = with_xpad ? (int32_t *)b->stage[3] : nullptr;
+    TlTaps *d_taps = taps ? (TlTaps *)b->stage[4] : nullptr;
+    // copies and the launch are queued on the null stream; with pinned host buffers (tlb_host_alloc) the copies run at
+    // link rate and nothing blocks until the final synchronisation
+    HIPCHK(hipMemcpyAsync(d_pcm, pcm, n_pcm, hipMemcpyHostToDevice, nullptr));
+    if (with_xpad) {
+        HIPCHK(hipMemcpyAsync(d_xpad, xpad, slots * TL_MAX_XPAD, hipMemcpyHostToDevice, nullptr));
+        HIPCHK(hipMemcpyAsync(d_xl, xpad_len, slots * sizeof(int32_t), hipMemcpyHostToDevice, nullptr));
     }
-    if (e == hipSuccess && taps) {
-        e = hipMalloc(&d_taps, slots * sizeof(TlTaps));
-        if (e == hipSuccess) e = hipMemset(d_taps, 0, slots * sizeof(TlTaps));
-    }
-    if (e == hipSuccess) {
-        rc = tlb_launch(b, d_pcm, nframes, d_xpad, d_xl, d_out, d_taps, nullptr);
-        if (rc == TLB_OK) e = hipDeviceSynchronize();
-        if (rc == TLB_OK && e == hipSuccess) e = hipMemcpy(out, d_out, slots * (size_t)b->out_stride, hipMemcpyDeviceToHost);
-        if (rc == TLB_OK && e == hipSuccess && taps) e = hipMemcpy(taps, d_taps, slots * sizeof(TlTaps), hipMemcpyDeviceToHost);
-    }
-    for (void *p : {(void *)d_pcm, (void *)d_xpad, (void *)d_xl, (void *)d_out, (void *)d_taps}) if (p) guard_.v.push_back(p);
-    if (e != hipSuccess) { fprintf(stderr, "libtoolame-dab-hip: %s\n", hipGetErrorString(e)); return TLB_ERR_HIP; }
-    return rc;
+    HIPCHK(hipMemsetAsync(d_out, 0, n_out, nullptr));              // bytes the kernel does not write (slot 0 of the first call, tails of short frames) read as 0
+    if (taps) HIPCHK(hipMemsetAsync(d_taps, 0, slots * sizeof(TlTaps), nullptr));
+    int rc = tlb_launch(b, d_pcm, nframes, d_xpad, d_xl, d_out, d_taps, nullptr);
+    if (rc != TLB_OK) return rc;
+    HIPCHK(hipMemcpyAsync(out, d_out, n_out, hipMemcpyDeviceToHost, nullptr));
+    if (taps) HIPCHK(hipMemcpyAsync(taps, d_taps, slots * sizeof(TlTaps), hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return TLB_OK;
 }
+
+// Pinned host memory for callers of the host-buffer entry points (hipHostMalloc): PCIe copies from it run at link rate.
+void *tlb_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void tlb_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 // Diagnostic: per-stage s_memtime stamps [nframes][nstreams][32] (see TL_STAMP in mp2_wave.h).
 int tlb_encode_host_stamps(tlb_batch *b, const int16_t *pcm, int nframes, long long *stamps)
@@ -551,12 +572,17 @@ int tlb_edi_af_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_le
     HIPCHK(hipSetDevice(b->device));
     hipStream_t st = (hipStream_t)hip_stream;
     if (!b->d_edi_version) {
-        HIPCHK(hipMalloc(&b->d_edi_version, TL_EDI_MAX_VERSION));
-        HIPCHK(hipMalloc(&b->d_frame_bytes, sizeof(int32_t) * (size_t)b->nstreams));
-        HIPCHK(hipMalloc(&b->d_edi_state_tmp, sizeof(TlEdiState) * (size_t)b->nstreams));
+        // all three buffers or none: a failure half way must not leave the batch looking initialised
+        DevFree guard_;
+        uint8_t *d_v = nullptr; int32_t *d_fb = nullptr; TlEdiState *d_st = nullptr;
+        DEVALLOC(d_v, TL_EDI_MAX_VERSION);
+        DEVALLOC(d_fb, sizeof(int32_t) * (size_t)b->nstreams);
+        DEVALLOC(d_st, sizeof(TlEdiState) * (size_t)b->nstreams);
         std::vector<int32_t> fb((size_t)b->nstreams);
         for (int s = 0; s < b->nstreams; s++) fb[(size_t)s] = b->h_configs[b->h_stream_cfg[s]].frame_bytes;
-        HIPCHK(hipMemcpy(b->d_frame_bytes, fb.data(), sizeof(int32_t) * fb.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_fb, fb.data(), sizeof(int32_t) * fb.size(), hipMemcpyHostToDevice));
+        guard_.v.clear();
+        b->d_edi_version = d_v; b->d_frame_bytes = d_fb; b->d_edi_state_tmp = d_st;
     }
     if (version_len) HIPCHK(hipMemcpyAsync(b->d_edi_version, version, (size_t)version_len, hipMemcpyHostToDevice, st));
     TlEdiArgs A;
@@ -716,7 +742,8 @@ float tlb_last_kernel_ms(tlb_batch *b)
 // ------------------------------------------------------------------------------------------
 // legacy nine-function ABI: stream 0 of a private one-stream batch (libtoolame-dab/toolame.h:13-48)
 // ------------------------------------------------------------------------------------------
-namespace {
+}  // extern "C" (the shim's private state and helper have internal linkage: the library exports the nine names of libtoolame-dab.sym and tlb_*, nothing else)
+
 struct Legacy {
     bool inited = false;
     long samplerate = 48000;       // the reference leaves the rate at its zero-initialised default until set
@@ -728,11 +755,13 @@ struct Legacy {
     int lg_frame = 0, minimum = 4, fill = 0;     // emulated 4096-byte bit buffer (bitstream.c)
     long frame_num = 0;
     std::deque<unsigned char> fifo;              // final bytes not yet handed to the caller
-} g_legacy;
+    std::vector<unsigned char> frame;            // one frame from the device
+};
+static Legacy g_legacy;
 
-const int kLegacyBuf = 4096;       // common.h BUFFER_SIZE
+static const int kLegacyBuf = 4096;       // common.h BUFFER_SIZE
 
-int legacy_emit(unsigned char *out, size_t out_size, size_t n)
+static int legacy_emit(unsigned char *out, size_t out_size, size_t n)
 {
     size_t j = 0;
     for (size_t i = 0; i < n; i++) {
@@ -743,7 +772,8 @@ int legacy_emit(unsigned char *out, size_t out_size, size_t n)
     }
     return (int)(j > out_size ? out_size : j);
 }
-}  // namespace
+
+extern "C" {
 
 int toolame_init(void)
 {
@@ -765,7 +795,19 @@ int toolame_set_psy_model(int new_model)
     g_legacy.psy = new_model;
     return 0;
 }
-int toolame_set_bitrate(int brate) { g_legacy.kbps = brate; return 0; }   // validated at the first frame (needs rate+mode)
+int toolame_set_bitrate(int brate)
+{   // toolame.c:212-237: the rate is checked HERE, against the MPEG version the sample rate (already set, odr-audioenc.cpp:687-722)
+    // selected; the reference's BitrateIndex() prints this message and exit(-1)s (common.c:95-116) -- the shim returns non-zero
+    // instead, which sends odr-audioenc down its own "libtoolame-dab init failed" path (odr-audioenc.cpp:724-727)
+    TlConfig c;
+    const int rc = tl_build_config(&c, g_legacy.samplerate, g_legacy.mode, brate, g_legacy.psy, 0);
+    if (rc == TLB_ERR_BITRATE) {
+        fprintf(stderr, "BitrateIndex: %d is not a legal bitrate for version %i\n", brate, g_legacy.samplerate >= 32000 ? 1 : 0);
+        return 1;
+    }
+    g_legacy.kbps = brate;
+    return 0;
+}
 int toolame_set_samplerate(long sample_rate)
 {
     switch (sample_rate) {
@@ -795,6 +837,7 @@ int toolame_encode_frame(short buffer[2][1152], unsigned char *xpad_data, size_t
         }
         g.lg_frame = tlb_frame_bytes(g.batch, 0);
         g.minimum = g.lg_frame + 4;                        // toolame.c:298-300
+        g.frame.assign((size_t)tlb_out_stride(g.batch), 0);
     }
     unsigned char xrec[TLB_MAX_XPAD];
     int32_t xl = 0;
@@ -803,10 +846,15 @@ int toolame_encode_frame(short buffer[2][1152], unsigned char *xpad_data, size_t
         xl = (int32_t)xpad_len;                            // bytes [dab_length-xpad_len, dab_length) in transmission order
         memcpy(xrec, xpad_data + g.pad_len - (int)xpad_len, xpad_len);
     }
-    std::vector<unsigned char> out((size_t)g.lg_frame);
-    if (tlb_encode_host(g.batch, &buffer[0][0], 1, xrec, &xl, out.data(), nullptr) != TLB_OK) return 0;
+    // the batch keeps its device staging buffers between calls: no allocation per frame after the first
+    if (int rc = tlb_encode_host(g.batch, &buffer[0][0], 1, xrec, &xl, g.frame.data(), nullptr)) {
+        // the reference has no error return from this call (it exit()s on its own fatal errors, mem.c:28); losing frames
+        // silently would be worse than stopping
+        fprintf(stderr, "libtoolame-dab-hip: encoding on the GPU failed (error %d)\n", rc);
+        exit(-1);
+    }
     g.frame_num++;
-    if (g.frame_num > 1) g.fifo.insert(g.fifo.end(), out.begin(), out.end());   // frame n-1 is final now
+    if (g.frame_num > 1) g.fifo.insert(g.fifo.end(), g.frame.begin(), g.frame.begin() + g.lg_frame);   // frame n-1 is final now
     // bitstream.c:46-71: when the 4096-byte buffer fills, everything but the newest `minimum` bytes is handed out
     int written = 0;
     if (g.fill + g.lg_frame >= kLegacyBuf) {
@@ -821,8 +869,10 @@ int toolame_finish(unsigned char *output_buffer, size_t output_buffer_size)
     Legacy &g = g_legacy;
     if (!g.batch) return 0;
     std::vector<unsigned char> last((size_t)tlb_out_stride(g.batch));
-    if (g.frame_num > 0 && tlb_flush_host(g.batch, last.data()) == TLB_OK)
+    if (g.frame_num > 0) {
+        if (int rc = tlb_flush_host(g.batch, last.data())) { fprintf(stderr, "libtoolame-dab-hip: flushing the GPU encoder failed (error %d)\n", rc); exit(-1); }
         g.fifo.insert(g.fifo.end(), last.begin(), last.begin() + g.lg_frame);   // the last frame keeps its own ScF-CRC
+    }
     int n = legacy_emit(output_buffer, output_buffer_size, g.fifo.size());
     tlb_destroy(g.batch);
     g.batch = nullptr;

@@ -75,6 +75,10 @@ def load_library():
     L.tlb_frames_encoded.restype = C.c_long
     L.tlb_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tlb_encode_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tlb_host_alloc.restype = C.c_void_p
+    L.tlb_host_alloc.argtypes = [C.c_size_t]
+    L.tlb_host_free.argtypes = [C.c_void_p]
+    L.tlb_host_free.restype = None
     L.tlb_flush_host.argtypes = [C.c_void_p, C.c_void_p]
     L.tlb_flush_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.tlb_last_kernel_ms.argtypes = [C.c_void_p]

@@ -127,3 +127,89 @@ extern "C" int pftref_stream(const uint8_t *af, const int32_t *af_len, int nfram
     *pseq = p.m_pseq;
     return 0;
 }
+
+// ---- receiving side -------------------------------------------------------------------------------------------------
+// ODR-AudioEnc only sends; the check that what it sends can be RECEIVED is a receiver written from ETSI TS 102 821 clause 7
+// (PF header fields, de-interleaving, erasure positions), with the error correction itself done by the reference's own
+// decoder contrib/fec/decode_rs_char.c (Phil Karn's, the code ODR-DabMux's EDI input uses) and the AF CRC by contrib/crc.c.
+// Fragments whose `present` flag is 0 are treated as lost: every byte they carried becomes an erasure.
+// Returns the AF packet length (> 0), or < 0: -1 header inconsistency, -2 PF header CRC, -3 decoder failure, -4 AF CRC/LEN,
+// -5 capacity.
+extern "C" {
+#include "fec/fec.h"
+}
+extern "C" int pftref_reassemble(const uint8_t *frags, const int32_t *frag_len, int nfrag, int frag_stride, const uint8_t *present,
+                                 uint8_t *af_out, int af_cap, int *corrected)
+{
+    int fcount = -1, plen = -1, rsk = 0, rsz = 0, pseq = -1;
+    bool fec = false, addr = false;
+    if (corrected) *corrected = 0;
+    for (int i = 0; i < nfrag; i++) {                         // every present fragment: header CRC, consistent fields
+        if (!present[i]) continue;
+        const uint8_t *p = frags + (size_t)i * frag_stride;
+        if (p[0] != 'P' || p[1] != 'F') return -1;
+        const int ps = (p[2] << 8) | p[3], fi = (p[4] << 16) | (p[5] << 8) | p[6], fc = (p[7] << 16) | (p[8] << 8) | p[9];
+        const int pl = (p[10] << 8) | p[11];
+        const bool f = pl & 0x8000, a = pl & 0x4000;
+        const int hdr = 12 + (f ? 2 : 0) + (a ? 4 : 0);
+        uint16_t crc = 0xffff;
+        crc = crc16(crc, p, hdr);
+        crc ^= 0xffff;
+        if (p[hdr] != (crc >> 8) || p[hdr + 1] != (crc & 0xff)) return -2;
+        if (fi != i || fc != nfrag || frag_len[i] != hdr + 2 + (pl & 0x3fff)) return -1;
+        if (fcount < 0) { fcount = fc; plen = pl & 0x3fff; fec = f; addr = a; pseq = ps; if (f) { rsk = p[12]; rsz = p[13]; } }
+        else if (ps != pseq || f != fec || a != addr || (f && (rsk != p[12] || rsz != p[13])) || (f && plen != (pl & 0x3fff))) return -1;
+    }
+    if (fcount < 0) return -1;
+    const int hdr = 12 + (fec ? 2 : 0) + (addr ? 4 : 0) + 2;
+    std::vector<uint8_t> af;
+    if (!fec) {                                               // plain slices: nothing may be missing
+        for (int i = 0; i < nfrag; i++) {
+            if (!present[i]) return -3;
+            const uint8_t *p = frags + (size_t)i * frag_stride;
+            af.insert(af.end(), p + hdr, p + frag_len[i]);
+        }
+    } else {
+        const size_t total = (size_t)fcount * plen;           // interleaved RS block (+ up to Fcount-1 padding bytes)
+        const int cw = rsk + (int)PARITYBYTES;
+        const size_t c = total / cw;
+        std::vector<uint8_t> block(total, 0), erased(total, 0);
+        for (int i = 0; i < nfrag; i++)
+            for (int j = 0; j < plen; j++) {
+                const size_t ix = (size_t)j * fcount + i;
+                if (present[i]) block[ix] = frags[(size_t)i * frag_stride + hdr + j]; else erased[ix] = 1;
+            }
+        void *rs = init_rs_char(8, 0x11d, 1, 1, (int)PARITYBYTES, 0);
+        if (!rs) return -3;
+        for (size_t ci = 0; ci < c; ci++) {
+            uint8_t word[255];
+            int eras[255], ne = 0;
+            memset(word, 0, sizeof word);
+            for (int o = 0; o < cw; o++) {
+                const size_t ix = ci * cw + o;
+                const int pos = o < rsk ? o : 207 + (o - rsk);
+                word[pos] = block[ix];
+                if (erased[ix]) eras[ne++] = pos;
+            }
+            if (ne > (int)PARITYBYTES) { free_rs_char(rs); return -3; }      // beyond the code's erasure capacity (and the decoder's arrays)
+            const int r = decode_rs_char(rs, word, eras, ne);
+            if (r < 0) { free_rs_char(rs); return -3; }
+            if (corrected) *corrected += r;
+            af.insert(af.end(), word, word + rsk);
+        }
+        free_rs_char(rs);
+        if ((int)af.size() < rsz) return -1;
+        af.resize(af.size() - rsz);
+    }
+    // AF packet: "AF", LEN, ..., CRC over everything before it (contrib/edioutput/AFPacket.cpp:46-94)
+    if (af.size() < 12 || af[0] != 'A' || af[1] != 'F') return -4;
+    const size_t len = ((size_t)af[2] << 24) | ((size_t)af[3] << 16) | ((size_t)af[4] << 8) | af[5];
+    if (len + 12 != af.size()) return -4;
+    uint16_t crc = 0xffff;
+    crc = crc16(crc, af.data(), af.size() - 2);
+    crc ^= 0xffff;
+    if (af[af.size() - 2] != (crc >> 8) || af[af.size() - 1] != (crc & 0xff)) return -4;
+    if ((int)af.size() > af_cap) return -5;
+    memcpy(af_out, af.data(), af.size());
+    return (int)af.size();
+}

@@ -191,6 +191,42 @@ def ref_pft(af, af_len, pseq, fec, chunk_len=207, transport=0, addr_source=0, de
     return frags, flen, nfrag, ps
 
 
+def ref_reassemble(frags, flen, n, present):
+    """one AF packet back from its fragments (fragments with present[i] == 0 are lost) through the receiver of
+    oracle/pft_ref_driver.cpp: the reference's decode_rs_char.c corrects the erasures.  -> (bytes or None, error code / corrected symbols)"""
+    L = pft_ref_lib()
+    L.pftref_reassemble.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    fr = np.ascontiguousarray(frags[:n]); fl = np.ascontiguousarray(flen[:n], dtype=np.int32)
+    pr = np.ascontiguousarray(present, dtype=np.uint8)
+    out = np.zeros(4096, dtype=np.uint8)
+    corr = C.c_int(0)
+    r = L.pftref_reassemble(fr.ctypes.data, fl.ctypes.data, int(n), int(frags.shape[-1]), pr.ctypes.data, out.ctypes.data, out.size, C.byref(corr))
+    return (out[:r].tobytes(), corr.value) if r > 0 else (None, r)
+
+
+def check_reassembly(af, af_len, frags, flen, nfrag, fec, stride_f=7):
+    """decoder-side property for one PFT case: with ANY `fec` fragments lost the AF packet comes back bit-exactly (three loss
+    patterns per packet: the first, the last, a strided pick); with most fragments lost (more than 48 erasures per codeword) the decoder must NOT hand back a packet"""
+    nf, ns = nfrag.shape
+    for f in range(0, nf, max(1, nf // stride_f)):
+        for s in range(ns):
+            n, l = int(nfrag[f, s]), int(af_len[f, s])
+            want = af[f, s, :l].tobytes()
+            patterns = [list(range(fec)), list(range(n - fec, n)), [(3 + 5 * q) % n for q in range(fec)]] if fec else [[]]
+            for lost in patterns:
+                if len(set(lost)) != fec:
+                    continue
+                present = np.ones(n, dtype=np.uint8)
+                present[lost] = 0
+                got, info = ref_reassemble(frags[f, s], flen[f, s], n, present)
+                assert got == want, (f, s, lost, info)
+            if fec and n > 2:                                # more than 48 erasures per codeword: the decoder must refuse
+                present = np.ones(n, dtype=np.uint8)
+                present[: (n + 1) // 2 + 1] = 0
+                got, info = ref_reassemble(frags[f, s], flen[f, s], n, present)
+                assert got is None, (f, s, "decoded with most fragments lost")
+
+
 def pft_digest(frags, flen, nfrag):
     h = hashlib.sha256()
     for f in range(frags.shape[0]):

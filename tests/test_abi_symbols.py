@@ -48,3 +48,58 @@ def test_product_does_not_reference_oracle():
         if p.suffix in (".h", ".hip", ".cpp", ".py", ".inc") or p.name == "Makefile":
             t = p.read_text(errors="ignore")
             assert "oracle/" not in t.replace("oracle/mp2_oracle.c:psy3_run", "") and "mp2_emu" not in t and "libmp2oracle" not in t, p
+
+
+def _exported():
+    import subprocess
+    import odr_audioenc_amd as M
+    if not M.LIB_PATH.exists():
+        M.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", str(M.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    return [ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-2] in "TtDdBbRr"]
+
+
+def test_export_list_is_the_reference_sym_file_plus_tlb():
+    """The dynamic symbol table carries the nine names of libtoolame-dab.sym and the tlb_* API; the shim's private state
+    (g_legacy, legacy_emit) and nothing else toolame-/legacy-named leaks out."""
+    names = _exported()
+    assert sorted(n for n in names if n.startswith("toolame_")) == sorted(REF_SYMS)
+    assert not [n for n in names if "legacy" in n.lower()], [n for n in names if "legacy" in n.lower()]
+    assert sorted(n for n in names if n.startswith("tlb_")) == [n for n in _declared() if n.startswith("tlb_")]
+
+
+REF_HEADER = Path("/root/reference/libtoolame-dab/toolame.h")
+
+
+@pytest.mark.skipif(not REF_HEADER.exists(), reason="the reference tree is only present in the build container")
+def test_one_translation_unit_with_the_reference_header(tmp_path):
+    """include/toolame_batch.h and the reference's own toolame.h in ONE C translation unit: a conflicting prototype fails to
+    compile.  The TU takes the address of all nine functions with the reference's types and links against the product .so."""
+    import subprocess
+    import odr_audioenc_amd as M
+    src = tmp_path / "both.c"
+    src.write_text('#include "%s"\n#include "%s"\n' % (REF_HEADER, ROOT / "include" / "toolame_batch.h") + r"""
+#include <stdio.h>
+int main(void)
+{
+    int (*a)(void) = toolame_init; int (*b)(unsigned char *, size_t) = toolame_finish; int (*c)(void) = toolame_enable_byteswap;
+    int (*d)(const char) = toolame_set_channel_mode; int (*e)(int) = toolame_set_psy_model; int (*f)(int) = toolame_set_bitrate;
+    int (*g)(long) = toolame_set_samplerate; int (*h)(int) = toolame_set_pad;
+    int (*i)(short [2][1152], unsigned char *, size_t, unsigned char *, size_t) = toolame_encode_frame;
+    /* setter semantics that need no GPU: same call order as src/odr-audioenc.cpp:687-722 */
+    if (a() || g(48000) || e(1) || d('j')) return 2;
+    if (f(100) == 0) return 3;                 /* 100 kbps is not a Layer II rate: refused at the setter (toolame.c:212-237) */
+    if (f(128) != 0 || h(58) != 0) return 4;
+    if (g(24000) || f(384) == 0) return 5;     /* 384 kbps is not an MPEG-2 LSF rate */
+    if (f(64) != 0) return 6;
+    if (e(4) == 0 || d('x') == 0 || g(12345) == 0 || h(-1) == 0) return 7;
+    printf("%p%p%p%p%p%p%p%p%p\n", (void *)a, (void *)b, (void *)c, (void *)d, (void *)e, (void *)f, (void *)g, (void *)h, (void *)i);
+    return 0;
+}
+""")
+    exe = tmp_path / "both"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-o", str(exe), str(src), str(M.LIB_PATH), "-Wl,-rpath," + str(M.LIB_PATH.parent),
+                        "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)

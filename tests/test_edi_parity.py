@@ -111,3 +111,33 @@ def test_pft_recovers_the_af_packet():
                 for byte in cw:
                     acc = (ex[(lg[acc] + root) % 255] if acc else 0) ^ byte
                 assert acc == 0, (f, s, ci, root)
+
+
+@pytest.mark.parametrize("name", [c[0] for c in E.PFT_CASES])
+def test_pft_fragments_decode_with_the_reference_rs_decoder(name):
+    """Receiver-side pin of the fragment layout (contrib/edioutput/PFT.cpp itself is not buildable here): the emulated device
+    fragments, with `fec` of them dropped, go through a TS 102 821 receiver whose Reed-Solomon decoder is the reference's own
+    contrib/fec/decode_rs_char.c, and the AF packet (LEN and CRC checked) comes back bit-exactly."""
+    if E.pft_ref_lib() is None:
+        pytest.skip("oracle/_ref/libpft_ref.so not built (no /root/reference here)")
+    af, af_len, pseq, kw = E.pft_case_inputs(name)
+    frags, flen, nfrag, _ = E.emu_pft(af, af_len, pseq, **kw)
+    E.check_reassembly(af, af_len, frags, flen, nfrag, kw["fec"])
+
+
+def test_pft_empty_and_oversize_packets_make_no_fragments():
+    """an AF length of 0, a negative one or one beyond the slot yields zero fragments (no division by a zero chunk count, no
+    copy past the staging buffer); the packets around it are unaffected and Pseq still advances per packet"""
+    af, af_len, pseq, kw = E.pft_case_inputs("fec2")
+    good = E.emu_pft(af, af_len, pseq, **kw)
+    bad_len = af_len.copy()
+    bad_len[3, 0], bad_len[5, 1], bad_len[9, 0] = 0, af.shape[2] + 4, -7
+    frags, flen, nfrag, ps = E.emu_pft(af, bad_len, pseq, **kw)
+    assert nfrag[3, 0] == 0 and nfrag[5, 1] == 0 and nfrag[9, 0] == 0 and (ps == good[3]).all()
+    mask = np.ones(nfrag.shape, dtype=bool)
+    mask[3, 0] = mask[5, 1] = mask[9, 0] = False
+    assert (nfrag[mask] == good[2][mask]).all() and (frags[mask] == good[0][mask]).all()
+    for fec in (0, 2):
+        k2 = dict(kw, fec=fec)
+        _, _, n2, _ = E.emu_pft(af[:4], np.zeros((4, af.shape[1]), dtype=np.int32), pseq, **k2)
+        assert (n2 == 0).all()

@@ -200,3 +200,36 @@ def test_emulated_illegal_configs():
     for kw in (dict(samplerate=44100), dict(kbps=100), dict(mode="x"), dict(psy=5), dict(psy=-1), dict(pad_len=-1), dict(pad_len=999)):
         with pytest.raises(ValueError):
             E.EmuBatch([kw])
+
+
+def test_xpad_length_contract():
+    """d_xpad_len is 0 or 2..pad_len (include/toolame_batch.h).  A value above the stream's toolame_set_pad() length, above the
+    record size, or 1, and any value on a stream created with pad_len 0, makes the frame carry no PAD: the bytes equal an
+    encode without PAD (nothing is written outside the frame).  A pad length that leaves no room for header, CRC and bit
+    allocation is refused when the stream is created."""
+    nf = 4
+    pcm = gen_pcm(77, 0, 0, nf)
+    rng = np.random.default_rng(9)
+    xp = rng.integers(0, 256, size=(nf, E.TL_MAX_XPAD), dtype=np.uint8)
+    for cfg, bad in ((dict(mode="j", psy=1, pad_len=20), (21, 58, 200, 201, 100000, 1, -3)),
+                     (dict(mode="s", psy=3, pad_len=0), (2, 16, 58, 200, 4096)),
+                     (dict(mode="m", psy=1, kbps=8, samplerate=24000, pad_len=0), (58, 48, 44, 2))):
+        ref, _ = _emu_stream(pcm, **cfg)
+        for v in bad:
+            xl = np.full(nf, v, dtype=np.int32)
+            got, _ = _emu_stream(pcm, xp, xl, **cfg)
+            assert got == ref, (cfg, v)
+    # lengths inside the contract still carry their bytes (and differ from the PAD-less stream)
+    cfg = dict(mode="j", psy=1, pad_len=20)
+    ref, _ = _emu_stream(pcm, **cfg)
+    got, _ = _emu_stream(pcm, xp, np.full(nf, 20, dtype=np.int32), **cfg)
+    assert got != ref and len(got) == len(ref)
+    e = O.OracleEncoder(mode="j", psy=1, pad_len=20)          # reference layout: padlen + 1 bytes, the last one = the valid length
+    want = b"".join(e.encode(pcm[i], bytes(xp[i, :20]) + b"\x14", 20) for i in range(nf)) + e.finish()
+    e.close()
+    assert got == want
+    for kw in (dict(samplerate=24000, mode="m", kbps=8, pad_len=58), dict(samplerate=24000, mode="m", kbps=8, pad_len=40),
+               dict(samplerate=48000, mode="m", kbps=32, pad_len=90), dict(samplerate=16000, mode="m", kbps=8, pad_len=66)):
+        with pytest.raises(ValueError):
+            E.EmuBatch([kw])
+    E.EmuBatch([dict(samplerate=24000, mode="m", kbps=8, pad_len=16)]).close()

@@ -11,6 +11,7 @@ import pytest
 import emulib as E
 import oraclelib as O
 from conftest import golden_cases
+from framecheck import crc16_frame_ok as _crc16_frame_ok
 from pcmgen import gen_pcm
 
 pytestmark = pytest.mark.gpu
@@ -161,33 +162,105 @@ def test_configuration_sweep_vs_oracle(M):
     b.close()
 
 
-def test_full_size_properties(M):
-    """BASELINE configs[1] size (4096 streams, psy 1): size-independent properties instead of a full
-    oracle run -- identical inputs give identical frames, every frame starts with the sync header,
-    replicas of stream k match the oracle for a sample of k, and the CRC-16 of every frame verifies."""
-    nstreams, nframes = 4096, 3
-    base = np.stack([gen_pcm(s, 0, 0, nframes) for s in range(64)], axis=1)
-    pcm = np.tile(base, (1, nstreams // 64, 1, 1))
-    b = M.Batch([M.StreamConfig(mode="s", psy_model=1)] * nstreams)
+def _full_size(M, nstreams, nframes, psy, nbase, oracle_samples):
+    base = np.stack([gen_pcm(s, 0, 0, nframes) for s in range(nbase)], axis=1)
+    pcm = np.tile(base, (1, nstreams // nbase, 1, 1))
+    b = M.Batch([M.StreamConfig(mode="s", psy_model=psy)] * nstreams)
     got, _ = b.encode(pcm)
     tail = b.flush()
     full = [g + t for g, t in zip(got, tail)]
     for s in range(nstreams):
-        assert full[s] == full[s % 64], s
+        assert full[s] == full[s % nbase], s                          # identical inputs, identical frames, wherever the wave ran
         assert full[s][:2] == b"\xff\xfc" and len(full[s]) == nframes * 384
-    for s in (0, 17, 63):
-        ref, _ = O.oracle_stream(pcm[:, s], mode="s", psy=1)
+    for s in range(nbase):                                            # every distinct frame of the batch: CRC-16 recomputed from its bytes
+        for f in range(nframes):
+            assert _crc16_frame_ok(full[s][384 * f: 384 * (f + 1)]), (s, f)
+    for s in oracle_samples:
+        ref, _ = O.oracle_stream(pcm[:, s], mode="s", psy=psy)
         assert full[s] == ref
     b.close()
 
 
-def test_legacy_abi_burst_cadence(M):
-    """The nine reference symbols: same call order as src/odr-audioenc.cpp:687-722, same bursty
-    return lengths as the real reference (golden `lens`), same bytes."""
-    g = np.load([p for p in golden_cases() if p.stem == "p1_48k_j_128_k0"][0])
+def test_full_size_properties(M):
+    """BASELINE configs[1] size (4096 streams, psy 1): size-independent properties instead of a full oracle run -- identical
+    inputs give identical frames wherever they sit in the batch, every frame starts with the sync header and has the right
+    length, the CRC-16 of every distinct frame is recomputed from its bytes, and a sample of streams equals the oracle."""
+    _full_size(M, 4096, 3, 1, 64, (0, 17, 63))
+
+
+def test_full_size_properties_configs2(M):
+    """BASELINE configs[2] size: 16384 streams x psy 3, the same properties."""
+    _full_size(M, 16384, 3, 3, 128, (0, 77, 127))
+
+
+def test_psy3_silence_and_impulse_device_equals_emulation(M):
+    """psy 3 on digital silence and on a lone impulse -- inputs the reference itself cannot encode (psycho_3.c:299 indexes
+    with (int)(0.0/0.0)) and the commonest real input of a fleet of radio streams -- mixed into one batch with healthy
+    streams and with psy 1 on the same signals: device bytes and every tap equal the host emulation of the same kernel
+    source bit for bit (a NaN-to-int conversion or a -0.0 that behaves differently on gfx950 would show here), and the
+    emulation equals the oracle's defined behaviour."""
+    kinds = [1, 3, 0, 1, 3, 6, 1, 3, 7, 1]
+    cfgs = [dict(psy=3, mode="s"), dict(psy=3, mode="s"), dict(psy=3, mode="s"), dict(psy=3, mode="j"), dict(psy=3, mode="j"),
+            dict(psy=3, mode="j"), dict(psy=3, mode="m", kbps=64), dict(psy=3, mode="m", kbps=64, samplerate=24000), dict(psy=1, mode="j"),
+            dict(psy=1, mode="s")]
+    nframes = 8
+    pcm = np.stack([gen_pcm(200 + s, kinds[s], 0, nframes) for s in range(len(cfgs))], axis=1)
+    pcm[4:, 0] = gen_pcm(300, 0, 4, nframes - 4)                      # silence, then programme: the state carries over
+    pcm[4:, 2] = 0                                                    # programme, then silence
+    e = E.EmuBatch(cfgs)
+    eg, et = e.encode(pcm, want_taps=True)
+    b = M.Batch([M.StreamConfig(samplerate=c.get("samplerate", 48000), mode=c["mode"], bitrate=c.get("kbps", 128), psy_model=c["psy"]) for c in cfgs])
+    dg, dt = b.encode(pcm, want_taps=True)
+    assert dg == eg and b.flush() == e.flush()
+    for name in ("sb_sample", "smr", "max_sc"):
+        assert np.array_equal(dt[name].view(np.uint64), et[name].view(np.uint64)), name
+    for name in ("subband", "scalar", "scalar_pre", "j_scale", "scfsi", "bit_alloc", "adb_left", "mode", "mode_ext", "crc16", "scfcrc"):
+        assert np.array_equal(dt[name], et[name]), name
+    assert np.isfinite(dt["smr"]).all()
+    for s, c in enumerate(cfgs):
+        ref, _ = O.oracle_stream(pcm[:, s], samplerate=c.get("samplerate", 48000), mode=c["mode"], kbps=c.get("kbps", 128), psy=c["psy"])
+        assert dg[s] + b.flush()[s] == ref, s
+    b.close()
+    e.close()
+
+
+def test_xpad_length_contract_on_device(M):
+    """d_xpad_len outside 0 / 2..pad_len: the frame carries no PAD and nothing is written outside the stream's working set --
+    the neighbours in the same workgroup keep producing the oracle's bytes (an over-long length used to reach
+    negative word offsets in LDS)."""
+    nf, ns = 4, 8
+    cfgs = [M.StreamConfig(mode="j", psy_model=1, pad_len=20), M.StreamConfig(mode="s", psy_model=3, pad_len=0),
+            M.StreamConfig(samplerate=24000, mode="m", bitrate=8, psy_model=1, pad_len=0), M.StreamConfig(mode="j", psy_model=1, pad_len=58)] * 2
+    pcm = np.stack([gen_pcm(400 + s, 0, 0, nf) for s in range(ns)], axis=1)
+    rng = np.random.default_rng(11)
+    xp = rng.integers(0, 256, size=(nf, ns, E.TL_MAX_XPAD), dtype=np.uint8)
+    xl = np.zeros((nf, ns), dtype=np.int32)
+    xl[:, 0], xl[:, 1], xl[:, 2], xl[:, 3] = 58, 58, 58, 58           # only stream 3 (and 7, below) may carry 58 bytes
+    xl[:, 4], xl[:, 5], xl[:, 6], xl[:, 7] = 100000, 2, 48, 58
+    b = M.Batch(cfgs)
+    got, _ = b.encode(pcm, xp, xl)
+    tail = b.flush()
+    for s, c in enumerate(cfgs):
+        legal = 2 <= xl[0, s] <= c.pad_len
+        e = O.OracleEncoder(samplerate=c.samplerate, mode=c.mode, kbps=c.bitrate, psy=c.psy_model, pad_len=c.pad_len)
+        want = b"".join(e.encode(pcm[i, s], (bytes(xp[i, s, :c.pad_len]) + bytes([c.pad_len])) if legal else None, c.pad_len if legal else 0)
+                        for i in range(nf)) + e.finish()
+        e.close()
+        assert got[s] + tail[s] == want, s
+    b.close()
+    with pytest.raises(M.ToolameError):
+        M.Batch([M.StreamConfig(samplerate=24000, mode="m", bitrate=8, pad_len=58)])
+
+
+@pytest.mark.parametrize("path", [p for p in golden_cases() if not p.stem.startswith("p4_")], ids=lambda p: p.stem)
+def test_legacy_abi_burst_cadence(M, path):
+    """The nine reference symbols on EVERY golden case the legacy setters can express (psy 0..3; all rates, modes, bitrates,
+    X-PAD): same call order as src/odr-audioenc.cpp:687-722, same bursty return lengths as the real reference (golden `lens`,
+    bitstream.c:46-71), same bytes."""
+    import ctypes as C
+    g = np.load(path)
     fs, mode, kbps, psy, kind, seed, pad_len, nframes = (int(v) for v in g["cfg"])
     L = M.legacy_api()
-    import ctypes as C
     assert L.toolame_init() == 0
     assert L.toolame_set_samplerate(fs) == 0
     assert L.toolame_set_psy_model(psy) == 0
@@ -200,7 +273,11 @@ def test_legacy_abi_burst_cadence(M):
     chunks, lens = [], []
     for i in range(nframes):
         buf = np.ascontiguousarray(pcm[i])
-        n = L.toolame_encode_frame(buf.ctypes.data, None, 0, out, 4096)
+        if "xpad" in g:
+            xd = np.ascontiguousarray(g["xpad"][i], dtype=np.uint8)  # the reference's layout: padlen + 1 bytes
+            n = L.toolame_encode_frame(buf.ctypes.data, xd.ctypes.data, int(g["xpad_len"][i]), out, 4096)
+        else:
+            n = L.toolame_encode_frame(buf.ctypes.data, None, 0, out, 4096)
         chunks.append(bytes(out[:n]))
         lens.append(n)
     n = L.toolame_finish(out, 4096)
@@ -208,6 +285,20 @@ def test_legacy_abi_burst_cadence(M):
     lens.append(n)
     assert lens == list(g["lens"])
     assert b"".join(chunks) == g["data"].tobytes()
+
+
+def test_legacy_setters_validate(M):
+    """toolame_set_bitrate refuses an illegal rate at the setter, for the MPEG version the sample rate selected
+    (toolame.c:212-237 -> BitrateIndex, common.c:95-116), and a too-small output buffer truncates with a message
+    (bitstream.c:54-58)."""
+    L = M.legacy_api()
+    assert L.toolame_init() == 0 and L.toolame_set_samplerate(48000) == 0 and L.toolame_set_channel_mode(b"s") == 0
+    assert L.toolame_set_bitrate(100) != 0 and L.toolame_set_bitrate(144) != 0      # 144 is an LSF rate only
+    assert L.toolame_set_bitrate(0) == 0 and L.toolame_set_bitrate(128) == 0
+    assert L.toolame_set_samplerate(24000) == 0
+    assert L.toolame_set_bitrate(384) != 0 and L.toolame_set_bitrate(144) == 0
+    assert L.toolame_set_samplerate(11025) != 0 and L.toolame_set_pad(-2) != 0
+    assert L.toolame_init() == 0
 
 
 def test_errors(M):
@@ -334,4 +425,8 @@ def test_edi_pft_fragments(M):
         f1, l1, n1 = b.edi_pft(af[:half], af_len[:half], ps2, **kw)
         f2, l2, n2 = b.edi_pft(af[half:], af_len[half:], ps2, **kw)
         assert (np.concatenate([f1, f2]) == frags).all() and (np.concatenate([n1, n2]) == nfrag).all() and (ps2 == ps).all(), name
+        # receiver side, on the DEVICE's fragments: `fec` of them lost, the reference's decode_rs_char.c corrects the erasures, the
+        # AF packet (LEN, CRC) comes back bit-exactly
+        if E.pft_ref_lib() is not None:
+            E.check_reassembly(af, af_len, frags, flen, nfrag, kw["fec"])
         b.close()
