@@ -102,6 +102,11 @@ struct TlPsy2State {
     double phi[2][2][513];
 };
 
+// What the psy kernel of models 1 and 3 hands to the encode kernel per frame: per (channel, subband) the level A that competes
+// with the scalefactor level and the minimum masking threshold m;  SMR = max(A, scale_db[min scalefactor index]) - m
+// (psycho_1.c:568-581: A = spike level; psycho_3.c:163-183,409-432: A = strongest line of the subband).
+struct TlPsyOut { double a[2][32]; double m[2][32]; };
+
 // Per-stream state that persists across launches.
 struct TlStreamState {
     int16_t hist[2][TL_HIST];               // last 480 PCM samples per channel
@@ -141,5 +146,6 @@ struct TlLaunch {
     long long *stamps;                // [nframes][nstreams][32] cycle stamps (diagnostic builds) or null
     const TlPsy2Tables *psy2_tables;  // [*] indexed by TlConfig::psy2_tab, or null when no stream uses psy 2
     TlPsy2State *psy2_state;          // [nstreams] or null
+    TlPsyOut *psy_out;                // [nframes][nstreams] psy kernel -> encode kernel (models 1 and 3), or null
     int32_t nstreams, nframes, out_stride, nlist;
 };

@@ -210,10 +210,22 @@ TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
 // ------------------------------------------------------------------------------------------
 // Per-wave LDS working set.
 #define TL_CAND_MAX 256              // local maxima with passing right side (<= 249)
-#define TL_FB_BATCH 12               // filterbank blocks per LDS round trip (36 = 3 x 12); the window outputs go through the (idle) psy arrays px[] .. cinfo[]
-#define TL_TONE_MAX 80               // confirmed tones per channel-frame (hard bound ~75: erasure spacing)
+#define TL_FB_BATCH 12               // fused kernels: filterbank blocks per LDS round trip (36 = 3 x 12); the window outputs go through the (idle) psy arrays px[] .. cinfo[]
+#define TL_FB_BATCH_MAIN 4           // encode kernel of the split path: 36 = 9 x 4 (a smaller scratch, fewer live registers)
+#define TL_PSY_EXT 5                 // tl_encode_frame<TL_PSY_EXT>: SMR from the psy kernel's TlPsyOut (models 1 and 3)
+#define TL_TONE_MAX 77               // confirmed tones per channel-frame (hard bound 75: a tone erases run lines either side, 20 + 16 + 19 + 19 fit below line 500); sized so that three 4-wave psy workgroups fit one CU's LDS
 #define TL_MASKER_MAX 128            // tones + noise components after decimation
+// psy 1/3: the FHT needs 1024 doubles, what follows it needs the 513 energies (lower half) and the power spectrum in dB
+// (520 entries) side by side -- so the power spectrum lives in the transform's upper half (dead once the energies exist),
+// 9 entries longer than the transform: 4 KB less LDS per wave than a separate array.
+#define TL_FFT_WORDS (513 + 520)
+#define TL_PX(w) ((w).u.fft + 513)
+// Energies are stored at i ^ ((i >> 4) & 15) (a permutation inside each group of 16 lines): line-parallel accesses stay
+// spread over the banks, and the spike sums -- a lane per subband walking its 16 lines (psycho_1.c:252-257) -- no longer
+// collide (16 lanes at stride 16 doubles would share one bank pair; the XOR gives each its own).
+#define TL_EX(i) ((i) ^ (((i) >> 4) & 15))
 struct TlWaveLds {
+    static constexpr bool kSplit = false;
     // Stage-exclusive 8 KB: [PCM history | frame] + filterbank scratch  ->  FHT buffer / energy (and, once the
     // energies are dead, the masker lists and thresholds)  ->  the frame being packed.
     union alignas(16) {
@@ -221,7 +233,7 @@ struct TlWaveLds {
         double fft[1024];
         uint32_t frame[TL_MAX_FRAME_WORDS + 2];          // + 2: tl_put_bits48 may OR zeros into the two words after a field
     } u;
-    double px[520];                     // psy: power spectrum in dB
+    double px[520];                     // psy 2/4: c[] / fthr[]; filterbank: window-output scratch (psy 1/3 run on TlPsyLds, power spectrum at TL_PX)
     double tone_x[TL_TONE_MAX];         // psy: summed level of each confirmed tone
     double smr[2][32];
     double spike[32];                   // psy-1 spike / psy-3 Lsb
@@ -239,6 +251,65 @@ struct TlWaveLds {
     uint8_t balloc[2][32];
     uint8_t minidx[2][32];
     uint8_t xpad[TL_MAX_XPAD];
+    static constexpr int kFbBatch = TL_FB_BATCH;
+    static constexpr bool kLdsPending = false;
+    typedef double (*YpRows)[2][34];    // [kFbBatch][2][32 (+2: the four addresses a matrixing read touches sit on different banks)]
+#ifdef TL_EMULATE
+    YpRows yp_rows() { return (YpRows)px; }
+    uint32_t *pending_words() { return nullptr; }
+#else
+    __device__ YpRows yp_rows() { return (YpRows)px; }
+    __device__ uint32_t *pending_words() { return nullptr; }
+#endif
+};
+// Per-wave LDS of the encode kernel of the split path (models 1 and 3 run in their own kernel): PCM staging / frame being
+// packed, the filterbank's window-output scratch, the pending frame (kept on chip for all frames of a launch) and the
+// small per-subband arrays.
+struct TlMainLds {
+    static constexpr bool kSplit = false;
+    static constexpr int kFbBatch = TL_FB_BATCH_MAIN;
+    static constexpr bool kLdsPending = true;
+    union alignas(16) {
+        struct { int16_t pcm[2][TL_HIST + 1152]; } fbk;
+        uint32_t frame[TL_MAX_FRAME_WORDS + 2];
+    } u;
+    double yp[TL_FB_BATCH_MAIN][2][34];
+    uint32_t pending[TL_MAX_FRAME_WORDS];
+    double smr[2][32];
+    int16_t ncentre[32];                // (ScF-CRC scratch)
+    uint8_t scf[2][3][32];
+    uint8_t jscale[3][32];
+    uint8_t scfsi[2][32];
+    uint8_t balloc[2][32];
+    uint8_t minidx[2][32];
+    uint8_t xpad[TL_MAX_XPAD];
+    typedef double (*YpRows)[2][34];
+#ifdef TL_EMULATE
+    YpRows yp_rows() { return yp; }
+    uint32_t *pending_words() { return pending; }
+#else
+    __device__ YpRows yp_rows() { return yp; }
+    __device__ uint32_t *pending_words() { return pending; }
+#endif
+};
+// What the psy kernel of models 1 and 3 hands to the encode kernel per frame: per (channel, subband) the level A that competes
+// with the scalefactor level and the minimum masking threshold m;  SMR = max(A, scale_db[min scalefactor index]) - m
+// (psycho_1.c:568-581: A = spike level; psycho_3.c:163-183,409-432: A = strongest line of the subband).
+// Per-wave LDS of the psy kernel (models 1 and 3): TlWaveLds without what only the rest of the encoder needs.
+struct TlPsyLds {
+    static constexpr bool kSplit = true;
+    struct { double fft[TL_FFT_WORDS]; } u;
+    TlPsyOut *po;                       // where this unit's result goes (HBM)
+    double tone_x[TL_TONE_MAX];
+    double spike[32];
+    double nsum[32];
+    uint32_t cinfo[TL_CAND_MAX];
+    int16_t conf_c[TL_TONE_MAX];
+    int16_t conf_nxt[TL_TONE_MAX];
+    int16_t tlist[TL_TONE_MAX];
+    int16_t ncentre[32];
+    int16_t bandoff[40];
+    uint8_t ptype[520];
 };
 // masker lists / thresholds live in the low half of the FHT buffer once the energies are no longer needed
 #define TL_MK_X(w) ((w).u.fft)                         /* [TL_MASKER_MAX] */
@@ -526,12 +597,13 @@ TL_FN void tl_fht_pass(double *x, const double (&t)[8], int lane)
 }
 
 // Hann window of samples [t-192, t+832) + FHT + energy (psycho_1.c:57-76,215-239, fft.c:1278-1293).
-// Leaves energy[0..512] in w.u.fft[0..512].
+// Leaves energy[i] in w.u.fft[TL_EX(i)], i = 0..512.
 // A stream's PCM as the kernel sees it in HBM: this frame (planar [2][1152]) and the 480 samples per
 // channel that precede it (the stream state on the first frame of a launch, the previous input frame after).
 struct TlPcmView { const int16_t *cur; const int16_t *hist; int hist_stride; };
 
-TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPcmView &pv, int ch, long long *sp)
+template <class W>
+TL_FN void tl_psy_spectrum(W &w, const TlTables *TL_RESTRICT T, const TlPcmView &pv, int ch, long long *sp)
 {
     double *x = w.u.fft;
     long long *sq = (sp && ch == 0) ? sp + 16 : nullptr;      // channel 0's pass-by-pass stamps: slots 24..30 of the frame's record
@@ -620,20 +692,20 @@ TL_FN void tl_psy_spectrum(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
                 b2 = c1 * g2 - s1 * f3; a = s1 * g2 + c1 * f3;
                 const double o_g2 = g0 - a, o_g0 = g0 + a, o_f3 = f1 - b2, o_f1 = f1 + b2;     // x[768-i], x[256-i], x[i+768], x[i+256]
                 // E[j] = (x[j]^2 + x[1024-j]^2) / 2 with a = x[j] first, as in the reference
-                x[i] = (o_f0 * o_f0 + o_g3 * o_g3) / 2.0;
-                x[256 - i] = (o_g0 * o_g0 + o_f3 * o_f3) / 2.0;
-                x[256 + i] = (o_f1 * o_f1 + o_g2 * o_g2) / 2.0;
-                x[512 - i] = (o_g1 * o_g1 + o_f2 * o_f2) / 2.0;
+                x[TL_EX(i)] = (o_f0 * o_f0 + o_g3 * o_g3) / 2.0;
+                x[TL_EX(256 - i)] = (o_g0 * o_g0 + o_f3 * o_f3) / 2.0;
+                x[TL_EX(256 + i)] = (o_f1 * o_f1 + o_g2 * o_g2) / 2.0;
+                x[TL_EX(512 - i)] = (o_g1 * o_g1 + o_f2 * o_f2) / 2.0;
             } else if (g == 127) {
                 double f1 = fi0 - fi1, f0 = fi0 + fi1, f3 = fi2 - fi3, f2 = fi2 + fi3;
                 const double o_f2 = f0 - f2, o_f0 = f0 + f2, o_f3 = f1 - f3, o_f1 = f1 + f3;     // x[512], x[0], x[768], x[256]
                 double g1 = gi0 - gi1, g0 = gi0 + gi1, g3 = SQRT2 * gi3, g2 = SQRT2 * gi2;
                 const double o_g2 = g0 - g2, o_g0 = g0 + g2, o_g3 = g1 - g3, o_g1 = g1 + g3;     // x[640], x[128], x[896], x[384]
-                x[0] = o_f0 * o_f0;
+                x[0] = o_f0 * o_f0;                                   // TL_EX leaves multiples of 256 where they are
                 x[512] = o_f2 * o_f2;
                 x[256] = (o_f1 * o_f1 + o_f3 * o_f3) / 2.0;
-                x[128] = (o_g0 * o_g0 + o_g3 * o_g3) / 2.0;
-                x[384] = (o_g1 * o_g1 + o_g2 * o_g2) / 2.0;
+                x[TL_EX(128)] = (o_g0 * o_g0 + o_g3 * o_g3) / 2.0;
+                x[TL_EX(384)] = (o_g1 * o_g1 + o_g2 * o_g2) / 2.0;
             }
         }
         TL_LANES_END
@@ -664,9 +736,10 @@ TL_FN int tl_run_psy3(int c) { return c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 1
 // 7 dB test; the left-hand failures are recorded as a bit mask for the walk that follows (psycho_1.c:267-300,
 // psycho_3.c:186-236).  RMAX is the largest run inside the chunk, so the neighbour reads are straight-line code
 // and overlap; PSY3 selects psycho_3's strict maximum and its (peak - neighbour) < 7 form of the test.
-template <int RMAX, bool PSY3>
-TL_FN void tl_cand_chunk(TlWaveLds &w, int c8, int &ncand)
+template <int RMAX, bool PSY3, class W>
+TL_FN void tl_cand_chunk(W &w, int c8, int &ncand)
 {
+    const double *px = TL_PX(w);
     PV(bool, isc); PV(uint32_t, rec);
     TL_LANES_BEGIN
     const int i = 64 * c8 + lane - 1;                               // chunks start one line early: the run lengths change at 63, 127, 255
@@ -675,9 +748,9 @@ TL_FN void tl_cand_chunk(TlWaveLds &w, int c8, int &ncand)
     // every neighbour is read before the first test (TL_KEEP: otherwise the compiler reads each one only if the
     // tests so far passed -- a chain of dependent LDS round trips)
     double a[RMAX + 1], b[RMAX + 1];
-    const double pk = w.px[ii];
+    const double pk = px[ii];
 #pragma unroll
-    for (int j = 1; j <= RMAX; j++) { a[j] = w.px[ii + j]; b[j] = w.px[ii - j < 0 ? 0 : ii - j]; }
+    for (int j = 1; j <= RMAX; j++) { a[j] = px[ii + j]; b[j] = px[ii - j < 0 ? 0 : ii - j]; }
 #pragma unroll
     for (int j = 1; j <= RMAX; j++) { TL_KEEP(a[j]); TL_KEEP(b[j]); }
     bool cnd = inr && pk > b[1] && (PSY3 ? pk > a[1] : pk >= a[1]);
@@ -710,26 +783,26 @@ TL_FN void tl_cand_chunk(TlWaveLds &w, int c8, int &ncand)
 // uses the LDS arrays.
 struct TlPsy1Ch { int nconf, nlist; bool dead_head; };
 
-TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+template <class W>
+TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
                              const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
 {
-    const double *energy = w.u.fft;
-    const double *db = B->dbtable;
+    const double *energy = w.u.fft;                                   // line i at TL_EX(i)
+    double *px = TL_PX(w);
     TL_STAMP(sp, 0);
     tl_psy_spectrum(w, T, pv, ch, sp);
     TL_STAMP(sp, 1);
 
     // power density spectrum (psycho_1.c:241-248); spike (psycho_1.c:252-257)
-    // The spike sums read 16 consecutive energies per lane; a copy with row stride 17 in the (free) upper half of the
-    // buffer keeps those reads off each other's LDS banks.  Only subbands below sblimit (<= 30) are ever used.
-    double *espk = w.u.fft + 513;
+    // The spike sums read 16 consecutive energies per lane; the energies' XOR layout keeps those reads off each other's
+    // LDS banks.  Only subbands below sblimit (<= 30) are ever used.
     TL_LANES_BEGIN
     for (int i0 = lane; i0 < 512; i0 += 256) {                     // four lines per lane at a time
         double e[4], v[4];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int q = 0; q < 4; q++) e[q] = energy[i0 + 64 * q];
+        for (int q = 0; q < 4; q++) e[q] = energy[TL_EX(i0 + 64 * q)];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
@@ -739,16 +812,23 @@ TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const 
 #endif
         for (int q = 0; q < 4; q++) {
             const int i = i0 + 64 * q;
-            w.px[i] = v[q];
+            px[i] = v[q];
             w.ptype[i] = 0;
-            if (i < 480) espk[17 * (i >> 4) + (i & 15)] = 1073741824 * e[q];
         }
     }
     TL_LANES_END
     TL_LANES_BEGIN
     if (lane < 30) {
+        double e[16];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int j = 0; j < 16; j++) e[j] = energy[16 * lane + (j ^ (lane & 15))];      // == energy[TL_EX(16 * lane + j)]
         double sum = 1E-20;
-        for (int j = 0; j < 16; j++) sum += espk[17 * lane + j];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int j = 0; j < 16; j++) sum += 1073741824 * e[j];
         w.spike[lane] = 10.0 * tl_log10_pn(sum);
     }
     TL_LANES_END
@@ -756,10 +836,10 @@ TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const 
     // ---- tonal components (psycho_1.c:267-340) ----
     // (1) local maxima 2..499 whose right-hand neighbours pass the 7 dB test, compacted ascending
     int ncand = 0;
-    tl_cand_chunk<2, false>(w, 0, ncand);                           // lines -1..62: run 2
-    tl_cand_chunk<3, false>(w, 1, ncand);                           // 63..126: run 3
-    for (int c8 = 2; c8 < 4; c8++) tl_cand_chunk<6, false>(w, c8, ncand);     // 127..254: run 6
-    for (int c8 = 4; c8 < 8; c8++) tl_cand_chunk<12, false>(w, c8, ncand);    // 255..510: run 12
+    tl_cand_chunk<2, false, W>(w, 0, ncand);                           // lines -1..62: run 2
+    tl_cand_chunk<3, false, W>(w, 1, ncand);                           // 63..126: run 3
+    for (int c8 = 2; c8 < 4; c8++) tl_cand_chunk<6, false, W>(w, c8, ncand);     // 127..254: run 6
+    for (int c8 = 4; c8 < 8; c8++) tl_cand_chunk<12, false, W>(w, c8, ncand);    // 255..510: run 12
     TL_STAMP(sp, 2);
     // (2) wave-uniform walk: which candidates become tones.  State of the reference's list walk that
     //     matters: the last confirmed tone (`last`), its erasure reach R = last + run(last), and the
@@ -790,8 +870,8 @@ TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const 
                 if (lo_j <= run) orig |= ((1u << (run - 1)) - 1u) & ~((1u << (lo_j - 2)) - 1u);
                 if (lfail & orig) ok = false;
                 if (ok && c - last >= 2 && c - last <= run) {
-                    const double xl = tl_add_db(db, w.px[last], tl_add_db(db, last_var ? TL_DBMIN : w.px[last - 1], w.px[last + 1]));
-                    if (w.px[c] - 7 < xl) ok = false;
+                    const double xl = tl_add_db(db, px[last], tl_add_db(db, last_var ? TL_DBMIN : px[last - 1], px[last + 1]));
+                    if (px[c] - 7 < xl) ok = false;
                 }
             }
             if (!ok) continue;                                        // rejected: only unlinked, psycho_1.c:330-338
@@ -819,17 +899,17 @@ TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const 
     TL_LANES_BEGIN
     for (int i = lane; i < nconf; i += 64) {
         const int cc = w.conf_c[i], c = cc & 511, var = (cc >> 12) & 1;
-        w.tone_x[i] = tl_add_db(db, w.px[c], tl_add_db(db, var ? TL_DBMIN : w.px[c - 1], w.px[c + 1]));
+        w.tone_x[i] = tl_add_db(db, px[c], tl_add_db(db, var ? TL_DBMIN : px[c - 1], px[c + 1]));
     }
     TL_LANES_END
     TL_LANES_BEGIN
-    for (int i = lane; i < nconf; i += 64) { const int c = w.conf_c[i] & 511; w.px[c] = w.tone_x[i]; w.ptype[c] = TL_T_TONE; }
+    for (int i = lane; i < nconf; i += 64) { const int c = w.conf_c[i] & 511; px[c] = w.tone_x[i]; w.ptype[c] = TL_T_TONE; }
     TL_LANES_END
     // (4) erasures (psycho_1.c:322-326); a tone erased by its successor ends up DBMIN / not TONE
     TL_LANES_BEGIN
     for (int i = lane; i < nconf; i += 64) {
         const int c = w.conf_c[i] & 511, run = tl_run_psy1(c);
-        for (int j = 1; j <= run; j++) { w.px[c - j] = TL_DBMIN; w.px[c + j] = TL_DBMIN; w.ptype[c - j] = 0; w.ptype[c + j] = 0; }
+        for (int j = 1; j <= run; j++) { px[c - j] = TL_DBMIN; px[c + j] = TL_DBMIN; w.ptype[c - j] = 0; w.ptype[c + j] = 0; }
     }
     TL_LANES_END
     // (5) the tone list in chain order (psycho_1.c list head `*tone`): walk the links, then decimate
@@ -855,11 +935,12 @@ TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const 
     // ---- noise components (psycho_1.c:356-376) ----
     // Line-parallel preparation: the lines a band will actually sum (not tonal, not erased) are compacted in
     // ascending order together with their weight terms, so the sequential part is a bare dB-sum chain.
-    // vt[] overwrites the energies in place (a compacted position is always below its line), vp[] uses the dead
-    // upper half of the FHT buffer.
+    // vt[] overwrites the energies and vp[] the power spectrum in place (a compacted position is never above its line, and a
+    // chunk of 64 lines is read completely before its entries are written).  power[] is gone after this: the dead-head
+    // replay rebuilds what it reads (tl_psy1_deadhead).
     const int nbands = C->p1_ncb - 1;
     {
-        double *vt = w.u.fft, *vp = w.u.fft + 520;
+        double *vt = w.u.fft, *vp = px;
         int nvalid = 0;
         PA(uint32_t, linfo, 8); PA(double, lrw, 8);                 // the table reads of all eight chunks in one batch
         TL_LANES_BEGIN
@@ -879,9 +960,9 @@ TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const 
             const int lo = (int)((info >> 8) & 0xfffu), hi = (int)(info >> 20);
             bool v = false; double t = 0, p = 0;
             if (info) {                                             // line inside the bands
-                p = w.px[j];
+                p = px[j];
                 v = w.ptype[j] != TL_T_TONE && p != TL_DBMIN;
-                t = tl_div_by(1073741824 * energy[j] * (double)(j - lo), (double)(hi - lo), L(lrw)[base >> 6]);   // == num / (hi - lo)
+                t = tl_div_by(1073741824 * energy[TL_EX(j)] * (double)(j - lo), (double)(hi - lo), L(lrw)[base >> 6]);   // == num / (hi - lo)
             }
             L(ok) = v; L(tv) = t; L(pvv) = p; L(bnd) = (info && j == lo) ? (int)(info & 0xffu) : -1;
             TL_LANES_END
@@ -908,7 +989,8 @@ TL_FN TlPsy1Ch tl_psy1_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const 
 
 // weight sums of the bands (psycho_1.c:364-366), ascending line order; lane b < nbands owns band b.  Only used where the
 // weights cannot ride along with the dB-sum chain (channel 0 of a stereo frame, whose terms leave LDS before its chain runs).
-TL_FN void tl_psy1_weights(TlWaveLds &w, int nbands, PARG(double, wt))
+template <class W>
+TL_FN void tl_psy1_weights(W &w, int nbands, PARG(double, wt))
 {
     TL_LANES_BEGIN
     double weight = 0.0;
@@ -933,13 +1015,14 @@ TL_FN void tl_psy1_weights(TlWaveLds &w, int nbands, PARG(double, wt))
     TL_LANES_END
 }
 
-// dB sums and weight sums of the bands of ONE channel (levels at fft+520, weight terms at fft): lane b < nbands
-TL_FN void tl_psy1_chain(TlWaveLds &w, const double *TL_RESTRICT db, int nbands, PARG(double, bsum), PARG(double, wt))
+// dB sums and weight sums of the bands of ONE channel (levels at TL_PX, weight terms at fft): lane b < nbands
+template <class W>
+TL_FN void tl_psy1_chain(W &w, const double *TL_RESTRICT db, int nbands, PARG(double, bsum), PARG(double, wt))
 {
     TL_LANES_BEGIN
     double sum = TL_DBMIN, weight = 0.0;
     if (lane < nbands) {
-        const double *vt = w.u.fft, *vp = w.u.fft + 520;
+        const double *vt = w.u.fft, *vp = TL_PX(w);
         const int i0 = w.bandoff[lane], i1 = w.bandoff[lane + 1];
         int i = i0;
         for (; i + 4 <= i1; i += 4) {                               // operands of four steps in flight per LDS round trip
@@ -956,47 +1039,43 @@ TL_FN void tl_psy1_chain(TlWaveLds &w, const double *TL_RESTRICT db, int nbands,
     TL_LANES_END
 }
 
-// dB sums of BOTH channels at once: lanes 0..31 walk channel 0's bands (levels parked in px[], ranges in r0/r1), lanes 32..63
-// channel 1's (levels at fft+520, weight terms at fft, ranges from bandoff[]).  Result: lane b holds channel 0's sum, lane
-// 32+b channel 1's sum and weight (wt2; lanes < 32 get 0).
-TL_FN void tl_psy1_chain2(TlWaveLds &w, const double *TL_RESTRICT db, int nbands, PARG(int, r0), PARG(int, r1), PARG(double, bsum), PARG(double, wt2))
+// dB sums of BOTH channels at once: lanes 0..31 walk channel 0's bands (levels parked at fft[], ranges in r0/r1), lanes 32..63
+// channel 1's (levels at TL_PX, ranges from bandoff[]).  Result: lane b holds channel 0's sum, lane 32+b channel 1's.
+template <class W>
+TL_FN void tl_psy1_chain2(W &w, const double *TL_RESTRICT db, int nbands, PARG(int, r0), PARG(int, r1), PARG(double, bsum))
 {
     TL_LANES_BEGIN
-    double sum = TL_DBMIN, weight = 0.0;
+    double sum = TL_DBMIN;
     const int band = lane & 31;
     if (band < nbands) {
         const bool second = lane >= 32;
-        const double *vp = second ? w.u.fft + 520 : w.px;
-        const double *vt = w.u.fft;
+        const double *vp = second ? TL_PX(w) : w.u.fft;
         const int i0 = second ? (int)w.bandoff[band] : L(r0), i1 = second ? (int)w.bandoff[band + 1] : L(r1);
         int i = i0;
         for (; i + 8 <= i1; i += 8) {                               // eight steps' operands per LDS round trip
-            double p[8], t[8];
+            double p[8];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-            for (int q = 0; q < 8; q++) { p[q] = vp[i + q]; t[q] = vt[i + q]; }
+            for (int q = 0; q < 8; q++) p[q] = vp[i + q];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-            for (int q = 0; q < 8; q++) { sum = tl_add_db(db, p[q], sum); weight += t[q]; }
+            for (int q = 0; q < 8; q++) sum = tl_add_db(db, p[q], sum);
         }
         for (; i + 4 <= i1; i += 4) {
             const double p0 = vp[i], p1 = vp[i + 1], p2 = vp[i + 2], p3 = vp[i + 3];
-            const double t0 = vt[i], t1 = vt[i + 1], t2 = vt[i + 2], t3 = vt[i + 3];   // channel 1's terms; lanes < 32 ignore their sum
-            sum = tl_add_db(db, p0, sum); weight += t0;
-            sum = tl_add_db(db, p1, sum); weight += t1;
-            sum = tl_add_db(db, p2, sum); weight += t2;
-            sum = tl_add_db(db, p3, sum); weight += t3;
+            sum = tl_add_db(db, p0, sum); sum = tl_add_db(db, p1, sum); sum = tl_add_db(db, p2, sum); sum = tl_add_db(db, p3, sum);
         }
-        for (; i < i1; i++) { sum = tl_add_db(db, vp[i], sum); weight += vt[i]; }
+        for (; i < i1; i++) sum = tl_add_db(db, vp[i], sum);
     }
-    L(bsum) = sum; L(wt2) = lane >= 32 ? weight : 0.0;
+    L(bsum) = sum;
     TL_LANES_END
 }
 
 // band centres (psycho_1.c:367-388) from the sums and weights of lanes b < nbands; needs ptype[] of the channel
-TL_FN void tl_psy1_centres(TlWaveLds &w, const TlConfig *TL_RESTRICT C, int nbands, PARG(double, bsum), PARG(double, wt))
+template <class W>
+TL_FN void tl_psy1_centres(W &w, const TlConfig *TL_RESTRICT C, int nbands, PARG(double, bsum), PARG(double, wt))
 {
     TL_LANES_BEGIN
     if (lane < nbands) {
@@ -1016,9 +1095,9 @@ TL_FN void tl_psy1_centres(TlWaveLds &w, const TlConfig *TL_RESTRICT C, int nban
 }
 
 // individual + global masking thresholds, minimum per subband, SMR (psycho_1.c:480-581) from the masker lists
-TL_FN void tl_psy1_thresholds(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const TlConfig *TL_RESTRICT C, int ch, int ntone, int nnoise, long long *sp)
+template <class W>
+TL_FN void tl_psy1_thresholds(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, int ntone, int nnoise, long long *sp)
 {
-    const double *db = B->dbtable;
     TL_STAMP(sp, 5);
 
     TL_DBG_DUMP("psy1", ch, ntone, nnoise, TL_MK_X(w), TL_MK_BARK(w));
@@ -1073,15 +1152,21 @@ TL_FN void tl_psy1_thresholds(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, 
         else {
             m = tl_min_rows(TL_LTG(w), j0, n, 0.0, true);
         }
-        double max = C->scale_db[w.minidx[ch][lane]];
-        if (w.spike[lane] > max) max = w.spike[lane];
-        w.smr[ch][lane] = max - m;
+        if constexpr (W::kSplit) {                                  // the encode kernel finishes the line (tl_smr_from_psy)
+            TlPsyOut *po = w.po;
+            po->a[ch][lane] = w.spike[lane]; po->m[ch][lane] = m;
+        } else {
+            double max = C->scale_db[w.minidx[ch][lane]];
+            if (w.spike[lane] > max) max = w.spike[lane];
+            w.smr[ch][lane] = max - m;
+        }
     }
     TL_LANES_END
 }
 
 // band levels, decimation (psycho_1.c:390-470) and everything after; the regular (not dead-head) case
-TL_FN void tl_psy1_back(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, long long *sp)
+template <class W>
+TL_FN void tl_psy1_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, long long *sp)
 {
     const int nbands = C->p1_ncb - 1, nlist = st.nlist;
     int ntone = 0, nnoise = 0;
@@ -1191,22 +1276,30 @@ TL_FN void tl_psy1_back(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const 
         TL_LANES_END
         nnoise = __builtin_popcountll(mn);
     }
-    tl_psy1_thresholds(w, B, C, ch, ntone, nnoise, sp);
+    tl_psy1_thresholds(w, db, C, ch, ntone, nnoise, sp);
 }
 
 // the dead-head replay (see tl_psy1_front): works on power[] (px) and the shared links like the reference
-TL_FN void tl_psy1_deadhead(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, long long *sp)
+template <class W>
+TL_FN void tl_psy1_deadhead(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, long long *sp)
 {
     const int nbands = C->p1_ncb - 1, nconf = st.nconf;
     const uint8_t *map = C->p1_map;
+    double *px = TL_PX(w);
     int ntone = 0, nnoise = 0;
     TL_STAMP(sp, 4);
     {
-        // every non-tonal line inside the bands is consumed (set to DBMIN) by its band, psycho_1.c:363 (the replay reads power[])
+        // power[] as the replay needs it.  The array itself was compacted in place (tl_psy1_front), but the replay only ever
+        // reads the lines of its chains: a confirmed tone's line holds the tone's summed level (psycho_1.c:317-321) unless
+        // its successor erased it (DBMIN, :322-326); every other line the replay can reach is non-tonal and inside the
+        // bands, i.e. consumed by its band (DBMIN, psycho_1.c:363).
         TL_LANES_BEGIN
-        for (int j = C->p1_cbound[0] + lane; j < C->p1_cbound[nbands]; j += 64) if (w.ptype[j] != TL_T_TONE) w.px[j] = TL_DBMIN;
+        for (int j = lane; j < 520; j += 64) px[j] = TL_DBMIN;
         TL_LANES_END
-        TL_DBG_DUMP("deadhead", ch, 0, 0, w.px, w.px);
+        TL_LANES_BEGIN
+        for (int i = lane; i < nconf; i += 64) { const int cc = w.conf_c[i]; if (!((cc >> 13) & 1)) px[cc & 511] = w.tone_x[i]; }
+        TL_LANES_END
+        TL_DBG_DUMP("deadhead", ch, 0, 0, px, px);
         int16_t *pnext = (int16_t *)w.cinfo;                // candidate records are dead by now
         TL_LANES_BEGIN
         for (int i = lane; i < 512; i += 64) pnext[i] = TL_STOP;
@@ -1224,22 +1317,22 @@ TL_FN void tl_psy1_deadhead(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, co
                 const int centre = w.ncentre[i];
                 if (last == TL_LAST) noise = centre;
                 else { pnext[centre] = TL_LAST; pnext[last] = (int16_t)centre; }
-                w.px[centre] = w.nsum[i]; w.ptype[centre] = TL_T_NOISE; last = centre;
+                px[centre] = w.nsum[i]; w.ptype[centre] = TL_T_NOISE; last = centre;
             }
         }
         {   // psycho_1.c:409-470 verbatim on the shared links
             int i = tone, old = TL_STOP, guard = 0;
             while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
-                if (w.px[i] < C->p1_hear[map[i]]) {
-                    w.ptype[i] = 0; w.px[i] = TL_DBMIN;
+                if (px[i] < C->p1_hear[map[i]]) {
+                    w.ptype[i] = 0; px[i] = TL_DBMIN;
                     if (old == TL_STOP) tone = pnext[i]; else pnext[old] = pnext[i];
                 } else old = i;
                 i = pnext[i];
             }
             i = noise; old = TL_STOP; guard = 0;
             while (i != TL_LAST && i != TL_STOP && guard++ < 600) {
-                if (w.px[i] < C->p1_hear[map[i]]) {
-                    w.ptype[i] = 0; w.px[i] = TL_DBMIN;
+                if (px[i] < C->p1_hear[map[i]]) {
+                    w.ptype[i] = 0; px[i] = TL_DBMIN;
                     if (old == TL_STOP) noise = pnext[i]; else pnext[old] = pnext[i];
                 } else old = i;
                 i = pnext[i];
@@ -1250,43 +1343,45 @@ TL_FN void tl_psy1_deadhead(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, co
                 if (nx == TL_LAST) break;
                 if (nx == TL_STOP) break;                     // (the reference would index power[-100]; never reached in practice)
                 if (C->p1_bark[map[nx]] - C->p1_bark[map[i]] < 0.5) {
-                    if (w.px[nx] > w.px[i]) {
+                    if (px[nx] > px[i]) {
                         if (old == TL_STOP) tone = nx; else pnext[old] = (int16_t)nx;
-                        w.ptype[i] = 0; w.px[i] = TL_DBMIN; i = nx;
+                        w.ptype[i] = 0; px[i] = TL_DBMIN; i = nx;
                     } else {
-                        w.ptype[nx] = 0; w.px[nx] = TL_DBMIN;
+                        w.ptype[nx] = 0; px[nx] = TL_DBMIN;
                         pnext[i] = pnext[nx]; old = i;
                     }
                 } else { old = i; i = nx; }
             }
             guard = 0;
             for (int t = tone; t != TL_LAST && t != TL_STOP && ntone < TL_MASKER_MAX - 32 && guard++ < 600; t = pnext[t]) {
-                TL_MK_X(w)[ntone] = w.px[t]; TL_MK_BARK(w)[ntone] = C->p1_bark[map[t]]; ntone++;
+                TL_MK_X(w)[ntone] = px[t]; TL_MK_BARK(w)[ntone] = C->p1_bark[map[t]]; ntone++;
             }
             guard = 0;
             for (int t = noise; t != TL_LAST && t != TL_STOP && ntone + nnoise < TL_MASKER_MAX && guard++ < 600; t = pnext[t]) {
-                TL_MK_X(w)[ntone + nnoise] = w.px[t]; TL_MK_BARK(w)[ntone + nnoise] = C->p1_bark[map[t]]; nnoise++;
+                TL_MK_X(w)[ntone + nnoise] = px[t]; TL_MK_BARK(w)[ntone + nnoise] = C->p1_bark[map[t]]; nnoise++;
             }
         }
         TL_SYNC();
     }
-    tl_psy1_thresholds(w, B, C, ch, ntone, nnoise, sp);
+    tl_psy1_thresholds(w, db, C, ch, ntone, nnoise, sp);
 }
 
 // one channel start to end (mono streams; stereo streams when a dead-head case forces the plain order)
-TL_FN void tl_psy1_finish(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, long long *sp)
+template <class W>
+TL_FN void tl_psy1_finish(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, long long *sp)
 {
     const int nbands = C->p1_ncb - 1;
     PV(double, wt); PV(double, bsum);
-    tl_psy1_chain(w, B->dbtable, nbands, bsum, wt);
+    tl_psy1_chain(w, db, nbands, bsum, wt);
     tl_psy1_centres(w, C, nbands, bsum, wt);
-    if (st.dead_head) tl_psy1_deadhead(w, B, C, ch, st, sp); else tl_psy1_back(w, B, C, ch, st, sp);
+    if (st.dead_head) tl_psy1_deadhead(w, db, C, ch, st, sp); else tl_psy1_back(w, db, C, ch, st, sp);
 }
-TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+template <class W>
+TL_FN void tl_psy1(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
                    const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
 {
-    const TlPsy1Ch st = tl_psy1_front(w, T, B, C, pv, ch, sp);
-    tl_psy1_finish(w, B, C, ch, st, sp);
+    const TlPsy1Ch st = tl_psy1_front(w, T, db, C, pv, ch, sp);
+    tl_psy1_finish(w, db, C, ch, st, sp);
 }
 
 // Both channels of a stereo frame.  Order: front(0) -> park channel 0's front results in registers -> front(1) -> the dB-sum
@@ -1294,16 +1389,17 @@ TL_FN void tl_psy1(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockSha
 // Parked: the compacted levels (<= 466 doubles: 8 per lane), the tone records (conf_c, tlist, tone_x), the spike levels, the
 // band ranges and the weight sums.  ptype[] is not parked: after the tone labelling a line is TONE exactly if it is the line
 // of a confirmed tone that was not erased by its successor, so it is rebuilt from conf_c.  A dead-head channel (see
-// tl_psy1_front) falls back to the plain per-channel order, which needs that channel's power[] array intact.
-TL_FN void tl_psy1_stereo(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+// tl_psy1_front) falls back to the plain per-channel order.
+template <class W>
+TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
                           const TlConfig *TL_RESTRICT C, const TlPcmView &pv, long long *sp)
 {
     const int nbands = C->p1_ncb - 1;
     long long *sp0 = sp ? sp + 8 : nullptr, *sp1 = sp ? sp + 16 : nullptr;
-    const TlPsy1Ch s0 = tl_psy1_front(w, T, B, C, pv, 0, sp0);
+    const TlPsy1Ch s0 = tl_psy1_front(w, T, db, C, pv, 0, sp0);
     if (s0.dead_head) {                                               // plain order for both channels
-        tl_psy1_finish(w, B, C, 0, s0, sp0);
-        tl_psy1(w, T, B, C, pv, 1, sp1);
+        tl_psy1_finish(w, db, C, 0, s0, sp0);
+        tl_psy1(w, T, db, C, pv, 1, sp1);
         return;
     }
     // ---- park channel 0 ----
@@ -1312,7 +1408,7 @@ TL_FN void tl_psy1_stereo(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlB
     tl_psy1_weights(w, nbands, wt0);
     TL_LANES_BEGIN
     L(r0) = lane < nbands ? (int)w.bandoff[lane] : 0; L(r1) = lane < nbands ? (int)w.bandoff[lane + 1] : 0;
-    const double *vp = w.u.fft + 520;
+    const double *vp = TL_PX(w);
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
@@ -1324,15 +1420,15 @@ TL_FN void tl_psy1_stereo(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlB
     L(pspk) = w.spike[lane & 31];
     TL_LANES_END
     // ---- channel 1's front; a dead-head channel 1 is finished in the plain order first ----
-    const TlPsy1Ch s1 = tl_psy1_front(w, T, B, C, pv, 1, sp1);
+    const TlPsy1Ch s1 = tl_psy1_front(w, T, db, C, pv, 1, sp1);
     PV(double, bsum); PV(double, wt1);
     if (s1.dead_head) {
-        tl_psy1_finish(w, B, C, 1, s1, sp1);
+        tl_psy1_finish(w, db, C, 1, s1, sp1);
         TL_LANES_BEGIN
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int k = 0; k < 8; k++) if (lane + 64 * k < 504) w.u.fft[520 + lane + 64 * k] = L(pvp)[k];
+        for (int k = 0; k < 8; k++) if (lane + 64 * k < 504) TL_PX(w)[lane + 64 * k] = L(pvp)[k];
         if (lane <= nbands) w.bandoff[lane] = (int16_t)(lane < nbands ? L(r0) : 0);
         TL_LANES_END
         // bandoff[nbands] = end of the last band
@@ -1345,27 +1441,27 @@ TL_FN void tl_psy1_stereo(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlB
         TL_LANES_BEGIN
         for (int i = lane; i < 504; i += 64) { uint64_t z = 0; TL_KEEP(z); w.u.fft[i] = tl_u2d(z); }   // (a zero made here, not a register kept through the frame)
         TL_LANES_END
-        tl_psy1_chain(w, B->dbtable, nbands, bsum, wdummy);
+        tl_psy1_chain(w, db, nbands, bsum, wdummy);
     } else {
-        // ---- both chains ----
+        // ---- both chains: channel 1's weight sums first (its terms sit where channel 0's levels go) ----
+        tl_psy1_weights(w, nbands, wt1);
         TL_LANES_BEGIN
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int k = 0; k < 8; k++) if (lane + 64 * k < 504) w.px[lane + 64 * k] = L(pvp)[k];     // channel 1's power[] is no longer needed
+        for (int k = 0; k < 8; k++) if (lane + 64 * k < 504) w.u.fft[lane + 64 * k] = L(pvp)[k];
         TL_LANES_END
-        PV(double, wt2);
         TL_STAMP(sp1, 4);
-        tl_psy1_chain2(w, B->dbtable, nbands, r0, r1, bsum, wt2);
-        // ---- back(1): its sums and weights move from lanes 32+b to lanes b ----
+        tl_psy1_chain2(w, db, nbands, r0, r1, bsum);
+        // ---- back(1): its sums move from lanes 32+b to lanes b ----
         PV(double, bsum1);
 #ifdef TL_EMULATE
-        for (int lane = 0; lane < 64; ++lane) { bsum1[lane] = bsum[(lane + 32) & 63]; wt1[lane] = wt2[(lane + 32) & 63]; }
+        for (int lane = 0; lane < 64; ++lane) bsum1[lane] = bsum[(lane + 32) & 63];
 #else
-        bsum1 = __shfl(bsum, (int)((threadIdx.x + 32u) & 63u), 64); wt1 = __shfl(wt2, (int)((threadIdx.x + 32u) & 63u), 64);
+        bsum1 = __shfl(bsum, (int)((threadIdx.x + 32u) & 63u), 64);
 #endif
         tl_psy1_centres(w, C, nbands, bsum1, wt1);
-        tl_psy1_back(w, B, C, 1, s1, sp1);
+        tl_psy1_back(w, db, C, 1, s1, sp1);
     }
     // ---- channel 0 returns to the LDS arrays ----
     TL_LANES_BEGIN
@@ -1379,16 +1475,17 @@ TL_FN void tl_psy1_stereo(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlB
     for (int i = lane; i < s0.nconf; i += 64) { const int cc = w.conf_c[i]; if (!((cc >> 13) & 1)) w.ptype[cc & 511] = TL_T_TONE; }
     TL_LANES_END
     tl_psy1_centres(w, C, nbands, bsum, wt0);
-    tl_psy1_back(w, B, C, 0, s0, sp0);
+    tl_psy1_back(w, db, C, 0, s0, sp0);
 }
 
 // ------------------------------------------------------------------------------------------
 // psy model 3 (psycho_3.c:71-432) for channel `ch`; result in w.smr[ch][0..32).
-TL_FN int tl_psy3_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+template <class W>
+TL_FN int tl_psy3_front(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
                    const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
 {
-    const double *energy = w.u.fft;
-    const double *db = B->dbtable;
+    const double *energy = w.u.fft;                                   // line i at TL_EX(i)
+    double *px = TL_PX(w);
     const double *bark = C->p3_bark, *ath = C->p3_ath;
     TL_STAMP(sp, 0);
     tl_psy_spectrum(w, T, pv, ch, sp);
@@ -1398,9 +1495,11 @@ TL_FN int tl_psy3_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlo
     // to 0.0 (oracle/mp2_oracle.c:psy3_run)
     // and Lsb (psycho_3.c:163-183; line 512 is skipped, see oracle) -> w.spike.  A subband's 16 lines sit in one row of
     // 16 lanes, so its maximum is a row reduction of the values just computed (no strided re-read of px).
-    TL_LANES_BEGIN
-    if (lane < 32) w.nsum[lane] = C->scale_db[w.minidx[ch][lane]];    // one table round trip for all subbands (nsum is free here)
-    TL_LANES_END
+    if constexpr (!W::kSplit) {
+        TL_LANES_BEGIN
+        if (lane < 32) w.nsum[lane] = C->scale_db[w.minidx[ch][lane]];    // one table round trip for all subbands (nsum is free here)
+        TL_LANES_END
+    }
     PA(double, pxa, 8);
     TL_LANES_BEGIN
     for (int h = 0; h < 2; h++) {                                   // four lines per lane at a time
@@ -1408,7 +1507,7 @@ TL_FN int tl_psy3_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlo
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int q = 0; q < 4; q++) e[q] = energy[lane + 64 * (4 * h + q)];
+        for (int q = 0; q < 4; q++) e[q] = energy[TL_EX(lane + 64 * (4 * h + q))];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
@@ -1418,7 +1517,7 @@ TL_FN int tl_psy3_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlo
 #endif
         for (int q = 0; q < 4; q++) {
             const int i = lane + 64 * (4 * h + q);
-            w.px[i] = i == 0 ? 0.0 : v[q];
+            px[i] = i == 0 ? 0.0 : v[q];
             L(pxa)[4 * h + q] = i == 0 ? TL_DBMIN : v[q];
         }
     }
@@ -1434,21 +1533,21 @@ TL_FN int tl_psy3_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlo
         if ((lane & 15) == 15) {
             const int sb = (lane + 64 * it) >> 4;
             const double xmax = TL_DBMIN < L(pxm) ? L(pxm) : TL_DBMIN;
-            const double val = w.nsum[sb];
-            w.spike[sb] = xmax > val ? xmax : val;
+            if constexpr (W::kSplit) w.spike[sb] = xmax;             // the encode kernel takes the maximum with the scalefactor level (tl_smr_from_psy)
+            else { const double val = w.nsum[sb]; w.spike[sb] = xmax > val ? xmax : val; }
         }
         TL_LANES_END
     }
     TL_LANES_BEGIN
-    if (lane == 0) w.px[512] = tl_power_db(energy[512]);
+    if (lane == 0) px[512] = tl_power_db(energy[512]);
     TL_LANES_END
     // ---- tone labelling (psycho_3.c:186-247) ----
     // (1) local maxima 2..499 whose right-hand neighbours are >= 7 dB down, compacted ascending
     int ncand = 0;
-    tl_cand_chunk<2, true>(w, 0, ncand);                           // lines -1..62: run 2
-    tl_cand_chunk<3, true>(w, 1, ncand);                           // 63..126: run 3
-    for (int c8 = 2; c8 < 4; c8++) tl_cand_chunk<6, true>(w, c8, ncand);     // 127..254: run 6
-    for (int c8 = 4; c8 < 8; c8++) tl_cand_chunk<12, true>(w, c8, ncand);    // 255..510: run 12
+    tl_cand_chunk<2, true, W>(w, 0, ncand);                           // lines -1..62: run 2
+    tl_cand_chunk<3, true, W>(w, 1, ncand);                           // 63..126: run 3
+    for (int c8 = 2; c8 < 4; c8++) tl_cand_chunk<6, true, W>(w, c8, ncand);     // 127..254: run 6
+    for (int c8 = 4; c8 < 8; c8++) tl_cand_chunk<12, true, W>(w, c8, ncand);    // 255..510: run 12
     TL_STAMP(sp, 2);
     // (2) wave-uniform walk.  A confirmed tone k erases lines k-sr..k+sr (itself included) to DBMIN
     //     (psycho_3.c:243-244); a later maximum inside that reach R has power DBMIN and always fails,
@@ -1478,15 +1577,15 @@ TL_FN int tl_psy3_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlo
     TL_LANES_BEGIN
     for (int i = lane; i < nconf; i += 64) {
         const int cc = w.conf_c[i], k = cc & 511;
-        const double temp = tl_add_db(db, (cc >> 12) & 1 ? TL_DBMIN : w.px[k - 1], w.px[k]);
-        w.tone_x[i] = tl_add_db(db, temp, w.px[k + 1]);
+        const double temp = tl_add_db(db, (cc >> 12) & 1 ? TL_DBMIN : px[k - 1], px[k]);
+        w.tone_x[i] = tl_add_db(db, temp, px[k + 1]);
     }
     TL_LANES_END
     // (4) erasures
     TL_LANES_BEGIN
     for (int i = lane; i < nconf; i += 64) {
         const int k = w.conf_c[i] & 511, sr = tl_run_psy3(k);
-        for (int j = -sr; j <= sr; j++) w.px[k + j] = TL_DBMIN;
+        for (int j = -sr; j <= sr; j++) px[k + j] = TL_DBMIN;
     }
     TL_LANES_END
     TL_STAMP(sp, 3);
@@ -1494,10 +1593,13 @@ TL_FN int tl_psy3_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlo
     const int nb = C->p3_cbands;
     // Line-parallel preparation as in psy 1: the lines that are summed (not erased) are compacted in ascending
     // order -- levels in place in px[], energies in place in the FHT buffer (a compacted position is always below
-    // its line), the centre-of-gravity terms (j-lo)*e in the buffer's upper half -- so the per-band part is three
-    // bare chains.  energy[512] shares its slot with the first centre term and is read up front.
+    // its line), and each entry's distance j - lo from its band's first line (the factor of its centre-of-gravity term
+    // (j-lo)*e, psycho_3.c:283-289) as 16 bits in the candidate records' place, which are dead by now -- so the per-band
+    // part is three bare chains.
     {
-        double *ve = w.u.fft, *vc = w.u.fft + 512, *vp = w.px;
+        double *ve = w.u.fft, *vp = px;
+        uint16_t *vj = (uint16_t *)w.cinfo;                          // [512]
+        static_assert(sizeof(w.cinfo) >= 512 * sizeof(uint16_t), "distance records");
         PV(double, e512);
         TL_LANES_BEGIN L(e512) = energy[512]; TL_LANES_END
         int nvalid = 0;
@@ -1512,25 +1614,24 @@ TL_FN int tl_psy3_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlo
 #pragma unroll
 #endif
         for (int base = 0; base < 576; base += 64) {                // lines 1..512
-            PV(bool, ok); PV(double, ev); PV(double, cv); PV(double, pvv); PV(int, bnd);
+            PV(bool, ok); PV(double, ev); PV(int, dj); PV(double, pvv); PV(int, bnd);
             TL_LANES_BEGIN
             const int j = base + lane;
             const uint32_t info = L(linfo)[base >> 6];
             const int lo = (int)((info >> 8) & 0xfffu);
-            bool v = false; double e = 0, c = 0, p = 0;
+            bool v = false; double e = 0, p = 0;
             if (info) {
-                p = w.px[j];
+                p = px[j];
                 v = p != TL_DBMIN;
-                e = j == 512 ? L(e512) : energy[j];
-                c = (j - lo) * e;
+                e = j == 512 ? L(e512) : energy[TL_EX(j)];
             }
-            L(ok) = v; L(ev) = e; L(cv) = c; L(pvv) = p; L(bnd) = (info && j == lo) ? (int)(info & 0xffu) : -1;
+            L(ok) = v; L(ev) = e; L(dj) = j - lo; L(pvv) = p; L(bnd) = (info && j == lo) ? (int)(info & 0xffu) : -1;
             TL_LANES_END
             const uint64_t m = TL_BALLOT(ok);
             TL_LANES_BEGIN
             const int pos = nvalid + __builtin_popcountll(m & ((1ull << lane) - 1ull));
             if (L(bnd) >= 0) w.bandoff[L(bnd)] = (int16_t)pos;     // first line of its band
-            if (L(ok)) { ve[pos] = L(ev); vc[pos] = L(cv); vp[pos] = L(pvv); }
+            if (L(ok)) { ve[pos] = L(ev); vj[pos] = (uint16_t)L(dj); vp[pos] = L(pvv); }
             TL_LANES_END
             nvalid += __builtin_popcountll(m);
         }
@@ -1542,12 +1643,14 @@ TL_FN int tl_psy3_front(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlo
 
 // energy sum and centre-of-gravity sum of the bands (psycho_3.c:283-289), ascending line order; lane b < nb.  Used on their own
 // for stereo frames, where only the levels take part in the shared dB-sum chain.
-TL_FN void tl_psy3_moments(TlWaveLds &w, int nb, PARG(double, es), PARG(double, cg))
+template <class W>
+TL_FN void tl_psy3_moments(W &w, int nb, PARG(double, es), PARG(double, cg))
 {
     TL_LANES_BEGIN
     double esum = 0, cw = 0;
     if (lane < nb) {
-        const double *ve = w.u.fft, *vc = w.u.fft + 512;
+        const double *ve = w.u.fft;
+        const uint16_t *vj = (const uint16_t *)w.cinfo;
         const int i0 = w.bandoff[lane], i1 = w.bandoff[lane + 1];
         int i = i0;
         for (; i + 8 <= i1; i += 8) {                               // operands of eight steps per LDS round trip, summed in order
@@ -1555,37 +1658,39 @@ TL_FN void tl_psy3_moments(TlWaveLds &w, int nb, PARG(double, es), PARG(double, 
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-            for (int q = 0; q < 8; q++) { e[q] = ve[i + q]; c[q] = vc[i + q]; }
+            for (int q = 0; q < 8; q++) { e[q] = ve[i + q]; c[q] = (int)vj[i + q] * e[q]; }     // (j - lo) * e, psycho_3.c:287
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
             for (int q = 0; q < 8; q++) { esum += e[q]; cw += c[q]; }
         }
-        for (; i < i1; i++) { esum += ve[i]; cw += vc[i]; }
+        for (; i < i1; i++) { esum += ve[i]; cw += (int)vj[i] * ve[i]; }
     }
     L(es) = esum; L(cg) = cw;
     TL_LANES_END
 }
 
 // dB sums, energy sums and centre-of-gravity sums of the bands of ONE channel: lane b < nb
-TL_FN void tl_psy3_chain(TlWaveLds &w, const double *TL_RESTRICT db, int nb, PARG(double, bsum), PARG(double, es), PARG(double, cg))
+template <class W>
+TL_FN void tl_psy3_chain(W &w, const double *TL_RESTRICT db, int nb, PARG(double, bsum), PARG(double, es), PARG(double, cg))
 {
     TL_LANES_BEGIN
     double sum = TL_DBMIN, esum = 0, cw = 0;
     if (lane < nb) {
-        const double *ve = w.u.fft, *vc = w.u.fft + 512, *vp = w.px;
+        const double *ve = w.u.fft, *vp = TL_PX(w);
+        const uint16_t *vj = (const uint16_t *)w.cinfo;
         const int i0 = w.bandoff[lane], i1 = w.bandoff[lane + 1];
         int i = i0;
         for (; i + 4 <= i1; i += 4) {                               // operands of four steps in flight per LDS round trip
             const double p0 = vp[i], p1 = vp[i + 1], p2 = vp[i + 2], p3 = vp[i + 3];
             const double e0 = ve[i], e1 = ve[i + 1], e2 = ve[i + 2], e3 = ve[i + 3];
-            const double c0 = vc[i], c1 = vc[i + 1], c2 = vc[i + 2], c3 = vc[i + 3];
+            const double c0 = (int)vj[i] * e0, c1 = (int)vj[i + 1] * e1, c2 = (int)vj[i + 2] * e2, c3 = (int)vj[i + 3] * e3;
             sum = tl_add_db(db, p0, sum); esum += e0; cw += c0;
             sum = tl_add_db(db, p1, sum); esum += e1; cw += c1;
             sum = tl_add_db(db, p2, sum); esum += e2; cw += c2;
             sum = tl_add_db(db, p3, sum); esum += e3; cw += c3;
         }
-        for (; i < i1; i++) { sum = tl_add_db(db, vp[i], sum); esum += ve[i]; cw += vc[i]; }
+        for (; i < i1; i++) { sum = tl_add_db(db, vp[i], sum); esum += ve[i]; cw += (int)vj[i] * ve[i]; }
     }
     L(bsum) = sum; L(es) = esum; L(cg) = cw;
     TL_LANES_END
@@ -1593,14 +1698,15 @@ TL_FN void tl_psy3_chain(TlWaveLds &w, const double *TL_RESTRICT db, int nb, PAR
 
 // dB sums of BOTH channels at once: lanes 0..31 walk channel 0's bands (levels parked at fft[], ranges in r0/r1), lanes 32..63
 // channel 1's (levels in px[], ranges from bandoff[]).  Lane b holds channel 0's sum, lane 32+b channel 1's.
-TL_FN void tl_psy3_chain2(TlWaveLds &w, const double *TL_RESTRICT db, int nb, PARG(int, r0), PARG(int, r1), PARG(double, bsum))
+template <class W>
+TL_FN void tl_psy3_chain2(W &w, const double *TL_RESTRICT db, int nb, PARG(int, r0), PARG(int, r1), PARG(double, bsum))
 {
     TL_LANES_BEGIN
     double sum = TL_DBMIN;
     const int band = lane & 31;
     if (band < nb) {
         const bool second = lane >= 32;
-        const double *vp = second ? w.px : w.u.fft;
+        const double *vp = second ? TL_PX(w) : w.u.fft;
         const int i0 = second ? (int)w.bandoff[band] : L(r0), i1 = second ? (int)w.bandoff[band + 1] : L(r1);
         int i = i0;
         for (; i + 8 <= i1; i += 8) {                               // eight steps' operands per LDS round trip
@@ -1625,10 +1731,10 @@ TL_FN void tl_psy3_chain2(TlWaveLds &w, const double *TL_RESTRICT db, int nb, PA
 }
 
 // band centres, decimation, thresholds, SMR (psycho_3.c:290-432) from the sums of lanes b < nb
-TL_FN void tl_psy3_back(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const TlConfig *TL_RESTRICT C, int ch, int nconf,
+template <class W>
+TL_FN void tl_psy3_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, int nconf,
                         PARG(double, bsum), PARG(double, es), PARG(double, cg), long long *sp)
 {
-    const double *db = B->dbtable;
     const double *bark = C->p3_bark, *ath = C->p3_ath;
     const int nb = C->p3_cbands;
     PV(bool, keepn); PV(double, nx); PV(double, nbk);
@@ -1739,29 +1845,32 @@ TL_FN void tl_psy3_back(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const 
         double m = 999999.9;
         const int j0 = C->p3_sb_j0[lane], n = C->p3_sb_n[lane];
         m = tl_min_rows(TL_LTG(w), j0, n, m, false);
-        w.smr[ch][lane] = w.spike[lane] - m;
+        if constexpr (W::kSplit) { TlPsyOut *po = w.po; po->a[ch][lane] = w.spike[lane]; po->m[ch][lane] = m; }
+        else w.smr[ch][lane] = w.spike[lane] - m;
     }
     TL_LANES_END
 }
 
 
-TL_FN void tl_psy3(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+template <class W>
+TL_FN void tl_psy3(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
                    const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
 {
-    const int nconf = tl_psy3_front(w, T, B, C, pv, ch, sp);
+    const int nconf = tl_psy3_front(w, T, db, C, pv, ch, sp);
     PV(double, bsum); PV(double, es); PV(double, cg);
-    tl_psy3_chain(w, B->dbtable, C->p3_cbands, bsum, es, cg);
-    tl_psy3_back(w, B, C, ch, nconf, bsum, es, cg, sp);
+    tl_psy3_chain(w, db, C->p3_cbands, bsum, es, cg);
+    tl_psy3_back(w, db, C, ch, nconf, bsum, es, cg, sp);
 }
 
 // Both channels of a stereo frame, organised like tl_psy1_stereo: front(0) -> channel 0's compacted levels, tone records, Lsb
 // and band moments wait in registers -> front(1) -> both dB-sum chains side by side -> back(1) -> back(0).
-TL_FN void tl_psy3_stereo(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+template <class W>
+TL_FN void tl_psy3_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
                           const TlConfig *TL_RESTRICT C, const TlPcmView &pv, long long *sp)
 {
     const int nb = C->p3_cbands;
     long long *sp0 = sp ? sp + 8 : nullptr, *sp1 = sp ? sp + 16 : nullptr;
-    const int nconf0 = tl_psy3_front(w, T, B, C, pv, 0, sp0);
+    const int nconf0 = tl_psy3_front(w, T, db, C, pv, 0, sp0);
     PV(double, es0); PV(double, cg0); PV(int, r0); PV(int, r1);
     PA(double, pvp, 8); PV(int, pcc); PV(double, ptx0); PV(double, ptx1); PV(double, pspk);
     tl_psy3_moments(w, nb, es0, cg0);
@@ -1770,35 +1879,35 @@ TL_FN void tl_psy3_stereo(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlB
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-    for (int k = 0; k < 8; k++) L(pvp)[k] = w.px[lane + 64 * k];
+    for (int k = 0; k < 8; k++) L(pvp)[k] = TL_PX(w)[lane + 64 * k];
     const int hi = 64 + lane < TL_TONE_MAX ? 64 + lane : 0;
     L(pcc) = (int)((uint32_t)(uint16_t)w.conf_c[lane] | ((uint32_t)(uint16_t)w.conf_c[hi] << 16));
     L(ptx0) = w.tone_x[lane]; L(ptx1) = w.tone_x[hi];
     L(pspk) = w.spike[lane & 31];
     TL_LANES_END
-    const int nconf1 = tl_psy3_front(w, T, B, C, pv, 1, sp1);
+    const int nconf1 = tl_psy3_front(w, T, db, C, pv, 1, sp1);
     PV(double, es1); PV(double, cg1); PV(double, bsum); PV(double, bsum1);
     tl_psy3_moments(w, nb, es1, cg1);
     TL_LANES_BEGIN
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-    for (int k = 0; k < 8; k++) w.u.fft[lane + 64 * k] = L(pvp)[k];   // channel 1's energies and centre terms are summed: the buffer is free
+    for (int k = 0; k < 8; k++) w.u.fft[lane + 64 * k] = L(pvp)[k];   // channel 1's energies are summed: the buffer's lower half is free
     TL_LANES_END
-    tl_psy3_chain2(w, B->dbtable, nb, r0, r1, bsum);
+    tl_psy3_chain2(w, db, nb, r0, r1, bsum);
 #ifdef TL_EMULATE
     for (int lane = 0; lane < 64; ++lane) bsum1[lane] = bsum[(lane + 32) & 63];
 #else
     bsum1 = __shfl(bsum, (int)((threadIdx.x + 32u) & 63u), 64);
 #endif
-    tl_psy3_back(w, B, C, 1, nconf1, bsum1, es1, cg1, sp1);
+    tl_psy3_back(w, db, C, 1, nconf1, bsum1, es1, cg1, sp1);
     TL_LANES_BEGIN
     const int hi = 64 + lane < TL_TONE_MAX ? 64 + lane : 0;
     w.conf_c[lane] = (int16_t)(L(pcc) & 0xffff); w.tone_x[lane] = L(ptx0);
     if (64 + lane < TL_TONE_MAX) { w.conf_c[hi] = (int16_t)((uint32_t)L(pcc) >> 16); w.tone_x[hi] = L(ptx1); }
     if (lane < 32) w.spike[lane] = L(pspk);
     TL_LANES_END
-    tl_psy3_back(w, B, C, 0, nconf0, bsum, es0, cg0, sp0);
+    tl_psy3_back(w, db, C, 0, nconf0, bsum, es0, cg0, sp0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1992,11 +2101,13 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
 // ------------------------------------------------------------------------------------------
 // One frame of one stream.  lane = 2*sb + ch owns subband sb of channel ch.  PSY (the psy model) is a compile-time
 // parameter: one kernel per model keeps each kernel's code and register footprint to what that model needs.
-template <int PSY>
-TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
-                           const TlConfig *TL_RESTRICT C, const TlPsy2Tables *TL_RESTRICT P2, TlPsy2State *TL_RESTRICT S2,
-                           const TlPcmView &pv, TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, TlTaps *taps, long long *sp)
+static_assert(offsetof(TlWaveLds, cinfo) + sizeof(((TlWaveLds *)0)->cinfo) - offsetof(TlWaveLds, px) >= sizeof(double) * TL_FB_BATCH * 68, "filterbank scratch");
+template <int PSY, class W>
+TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+                           const TlConfig *TL_RESTRICT C, const TlPsy2Tables *TL_RESTRICT P2, TlPsy2State *TL_RESTRICT S2, const TlPsyOut *TL_RESTRICT PO,
+                           const TlPcmView &pv, TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, bool last_frame, TlTaps *taps, long long *sp)
 {
+    constexpr int FB = W::kFbBatch;
     const int nch = C->nch, sblimit = C->sblimit;
     PA(double, smp, 36);            // sb_sample[ch][gr][bl][sb] of this lane's (sb,ch), b = gr*12+bl
     PA(int, scf, 3);
@@ -2033,12 +2144,11 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
                 L(xb)[8 * b + ((0 - j) & 7)] = c < nch ? w.u.fbk.pcm[c][TL_HIST + 32 * b + 31 - yb - 64 * j] : 0;
             }
         TL_LANES_END
-        double (*yp)[2][34] = (double (*)[2][34])w.px;              // [TL_FB_BATCH][2][32 (+2: the four addresses a matrixing read touches sit on different banks)]
-        static_assert(offsetof(TlWaveLds, cinfo) + sizeof(w.cinfo) - offsetof(TlWaveLds, px) >= sizeof(double) * TL_FB_BATCH * 68, "filterbank scratch");
+        typename W::YpRows yp = w.yp_rows();
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int b0 = 0; b0 < 36; b0 += TL_FB_BATCH) {
+        for (int b0 = 0; b0 < 36; b0 += FB) {
             TL_LANES_BEGIN
             const int c = lane & 1, i = lane >> 1;
             if (c < nch) {
@@ -2047,11 +2157,11 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
                 // with its sign flipped (a - b == a + (-b)) or replaced by -0.0 (a + (-0.0) == a, for every a)
                 const uint64_t keep = i == 0 ? 0ull : ~0ull, flip = (i == 0 || i > 16) ? 0x8000000000000000ull : 0ull;
                 // the batch's new samples (two per block) are all requested before the first block is computed
-                int na[TL_FB_BATCH], nb[TL_FB_BATCH];
+                int na[FB], nb[FB];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-                for (int bb = 0; bb < TL_FB_BATCH; bb++) {
+                for (int bb = 0; bb < FB; bb++) {
                     // X[k] = pcm[t0 + 31 - k], t0 = index of the block's first new sample
                     na[bb] = w.u.fbk.pcm[c][TL_HIST + 32 * (b0 + bb) + 31 - ya];
                     nb[bb] = w.u.fbk.pcm[c][TL_HIST + 32 * (b0 + bb) + 31 - yb];
@@ -2059,11 +2169,11 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-                for (int bb = 0; bb < TL_FB_BATCH; bb++) { TL_KEEP(na[bb]); TL_KEEP(nb[bb]); }
+                for (int bb = 0; bb < FB; bb++) { TL_KEEP(na[bb]); TL_KEEP(nb[bb]); }
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-                for (int bb = 0; bb < TL_FB_BATCH; bb++) {
+                for (int bb = 0; bb < FB; bb++) {
                     const int b = b0 + bb, q = 8 * (b & 1), h = b >> 1;
                     L(xa)[q + (h & 7)] = na[bb];
                     L(xb)[q + (h & 7)] = nb[bb];
@@ -2077,32 +2187,32 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
                 }
             }
             TL_LANES_END
-            PA(double, part, TL_FB_BATCH);
+            PA(double, part, FB);
             TL_LANES_BEGIN
             const int c = lane & 1, sb = lane >> 1, par = sb < 16 ? 0 : 1, r = sb < 16 ? sb : 31 - sb;
-            double acc[TL_FB_BATCH];
-            for (int bb = 0; bb < TL_FB_BATCH; bb++) acc[bb] = 0.0;
+            double acc[FB];
+            for (int bb = 0; bb < FB; bb++) acc[bb] = 0.0;
             if (c < nch)
                 for (int k = 0; k < 16; k++) {
                     const double m = B->dct_t[k][par][r];               // shared LDS copy, conflict-free per k
-                    for (int bb = 0; bb < TL_FB_BATCH; bb++) acc[bb] += m * yp[bb][c][2 * k + par];
+                    for (int bb = 0; bb < FB; bb++) acc[bb] += m * yp[bb][c][2 * k + par];
                 }
-            for (int bb = 0; bb < TL_FB_BATCH; bb++) L(part)[bb] = acc[bb];
+            for (int bb = 0; bb < FB; bb++) L(part)[bb] = acc[bb];
             TL_LANES_END
-            PA(double, oth, TL_FB_BATCH);
+            PA(double, oth, FB);
 #ifdef TL_EMULATE
             for (int lane = 0; lane < 64; ++lane)
-                for (int bb = 0; bb < TL_FB_BATCH; bb++) oth[lane][bb] = part[2 * (31 - (lane >> 1)) + (lane & 1)][bb];
+                for (int bb = 0; bb < FB; bb++) oth[lane][bb] = part[2 * (31 - (lane >> 1)) + (lane & 1)][bb];
 #else
             {
                 const int lane_ = (int)(threadIdx.x & 63u), partner = 2 * (31 - (lane_ >> 1)) + (lane_ & 1);
 #pragma unroll
-                for (int bb = 0; bb < TL_FB_BATCH; bb++) oth[bb] = __shfl(part[bb], partner, 64);
+                for (int bb = 0; bb < FB; bb++) oth[bb] = __shfl(part[bb], partner, 64);
             }
 #endif
             TL_LANES_BEGIN
             const int c = lane & 1, sb = lane >> 1;
-            for (int bb = 0; bb < TL_FB_BATCH; bb++)
+            for (int bb = 0; bb < FB; bb++)
                 L(smp)[b0 + bb] = c < nch ? (sb < 16 ? L(part)[bb] + L(oth)[bb] : L(oth)[bb] - L(part)[bb]) : 0.0;
             TL_LANES_END
         }
@@ -2177,12 +2287,21 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
         TL_LANES_END
     } else if constexpr (PSY == 2) {
         for (int ch = 0; ch < nch; ch++) tl_psy2(w, T, P2, S2, pv, ch, sp ? sp + 8 + 8 * ch : nullptr);
-    } else if constexpr (PSY == 1) {
-        if (nch == 2) tl_psy1_stereo(w, T, B, C, pv, sp);
-        else tl_psy1(w, T, B, C, pv, 0, sp ? sp + 8 : nullptr);
     } else {
-        if (nch == 2) tl_psy3_stereo(w, T, B, C, pv, sp);
-        else tl_psy3(w, T, B, C, pv, 0, sp ? sp + 8 : nullptr);
+        // models 1 and 3: the psy kernel left, per (channel, subband), the level A that competes with the scalefactor level and
+        // the minimum masking threshold m (TlPsyOut); the SMR line itself needs this frame's scalefactors and is finished here:
+        // psycho_1.c:575-580 (max = scale level; if (spike > max) max = spike; smr = max - ltmin) and psycho_3.c:180-182,428
+        // (Lsb = max(Xmax, scale level); smr = Lsb - ltmin) are the same three operations.
+        static_assert(PSY == TL_PSY_EXT, "models 1 and 3 run in the psy kernel");
+        TL_LANES_BEGIN
+        const int c = lane & 1, sb = lane >> 1;
+        if (c < nch) {
+            const double a = PO->a[c][sb], m = PO->m[c][sb];
+            const double val = C->scale_db[w.minidx[c][sb]];
+            const double top = a > val ? a : val;
+            w.smr[c][sb] = top - m;
+        }
+        TL_LANES_END
     }
 
     TL_STAMP(sp, 3);
@@ -2617,7 +2736,7 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     if (taps) {
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
-        taps->smr[c][sb] = (c < nch && (PSY != 1 || sb < sblimit)) ? w.smr[c][sb] : 0.0;   // psy 1 leaves sb >= sblimit unset
+        taps->smr[c][sb] = (c < nch && (C->psy != 1 || sb < sblimit)) ? w.smr[c][sb] : 0.0;   // psy 1 leaves sb >= sblimit unset
         taps->scfsi[c][sb] = w.scfsi[c][sb]; taps->bit_alloc[c][sb] = w.balloc[c][sb];
         for (int gr = 0; gr < 3; gr++) taps->scalar[c][gr][sb] = w.scf[c][gr][sb];
         if (lane == 0) { taps->adb_left = adb_left; taps->mode = mode; taps->mode_ext = mode_ext; taps->jsbound = jsbound; taps->crc16 = (int)crc16; }
@@ -2629,9 +2748,10 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
     // ---- emit: patch the previous frame's ScF-CRC slot with this frame's CRC and hand it out;
     //      this frame becomes the pending one (toolame.c:527-542, "one frame in memory") ----
     const int nwords = (lg_frame + 3) >> 2;
+    uint32_t *pend = W::kLdsPending ? w.pending_words() : st->pending;     // on chip for all frames of a launch, or in the stream state
     TL_LANES_BEGIN
     for (int i = lane; i < nwords; i += 64) {
-        uint32_t prev = st->pending[i];
+        uint32_t prev = pend[i];
         if (have_prev && out_prev) {
             // overlay bytes [tail, tail+dab_ext) of the previous frame with this frame's ScF-CRC bytes
             for (int k = 0; k < C->dab_ext; k++) {
@@ -2646,28 +2766,70 @@ TL_FN void tl_encode_frame(TlWaveLds &w, const TlTables *TL_RESTRICT T, const Tl
             if (rem >= 4) ((uint32_t *)out_prev)[i] = le;
             else for (int b = 0; b < rem; b++) out_prev[4 * i + b] = (uint8_t)(le >> (8 * b));
         }
-        st->pending[i] = frame[i];
+        pend[i] = frame[i];
+        if (W::kLdsPending && last_frame) st->pending[i] = frame[i];     // the launch's last frame goes back to the stream state
     }
     TL_LANES_END
     TL_STAMP(sp, 7);
 }
 
 // ------------------------------------------------------------------------------------------
-// A wave encodes `nframes` consecutive frames of stream `s`; state stays in LDS across frames.
+// A stream's PCM around frame f of a launch: the frame itself and the 480 samples per channel before it (the stream state
+// on the first frame of a launch, the previous input frame after).
+TL_FN TlPcmView tl_pcm_view(const TlLaunch &A, const TlStreamState *st, int s, int f)
+{
+    const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
+    TlPcmView pv;
+    pv.cur = A.pcm + slot * 2304;
+    if (f == 0) { pv.hist = &st->hist[0][0]; pv.hist_stride = TL_HIST; }
+    else { pv.hist = A.pcm + (slot - (size_t)A.nstreams) * 2304 + (1152 - TL_HIST); pv.hist_stride = 1152; }
+    return pv;
+}
+
+// One unit of the psy kernel (models 1 and 3): both channels of frame f of stream s -> A.psy_out[f][s].  The model reads
+// nothing but PCM (the window of a frame: the last 192 samples before it and its first 832), so units are independent of each
+// other -- of other streams AND of other frames of the same stream -- and the kernel runs them in any order on any wave.
 template <int PSY>
-TL_FN void tl_encode_stream(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, const TlLaunch &A, int s)
+TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch &A, int s, int f)
+{
+    const TlTables *T = A.tables;
+    const TlConfig *C = &A.configs[A.stream_cfg[s]];
+    const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
+    const TlPcmView pv = tl_pcm_view(A, &A.state[s], s, f);
+    TlPsyOut *po = &A.psy_out[slot];
+    TL_LANES_BEGIN
+    (&po->a[0][0])[lane] = 0.0; (&po->m[0][0])[lane] = 0.0;           // entries the model leaves alone (mono: channel 1; psy 1: sb >= sblimit)
+    if (lane == 0) w.po = po;
+    TL_LANES_END
+    long long *sp = A.stamps ? A.stamps + slot * 32 : nullptr;
+    if constexpr (PSY == 1) {
+        if (C->nch == 2) tl_psy1_stereo(w, T, db, C, pv, sp);
+        else tl_psy1(w, T, db, C, pv, 0, sp ? sp + 8 : nullptr);
+    } else {
+        if (C->nch == 2) tl_psy3_stereo(w, T, db, C, pv, sp);
+        else tl_psy3(w, T, db, C, pv, 0, sp ? sp + 8 : nullptr);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// A wave encodes `nframes` consecutive frames of stream `s`; state stays in LDS across frames.
+template <int PSY, class W>
+TL_FN void tl_encode_stream(W &w, const TlBlockShared *TL_RESTRICT B, const TlLaunch &A, int s)
 {
     const TlTables *T = A.tables;
     const TlConfig *C = &A.configs[A.stream_cfg[s]];
     TlStreamState *st = &A.state[s];
     const int nch = C->nch;
     int done = st->frames_done;
+    if (W::kLdsPending) {                                             // the pending frame stays on chip for the whole launch
+        uint32_t *pend = w.pending_words();
+        TL_LANES_BEGIN
+        for (int i = lane; i < ((C->frame_bytes + 3) >> 2); i += 64) pend[i] = st->pending[i];
+        TL_LANES_END
+    }
     for (int f = 0; f < A.nframes; f++) {
         const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
-        TlPcmView pv;
-        pv.cur = A.pcm + slot * 2304;
-        if (f == 0) { pv.hist = &st->hist[0][0]; pv.hist_stride = TL_HIST; }
-        else { pv.hist = A.pcm + (slot - (size_t)A.nstreams) * 2304 + (1152 - TL_HIST); pv.hist_stride = 1152; }
+        const TlPcmView pv = tl_pcm_view(A, st, s, f);
         TL_STAMP(A.stamps ? A.stamps + slot * 32 : nullptr, 31);        // frame begin, before the PCM staging
         TL_LANES_BEGIN
         {
@@ -2702,8 +2864,9 @@ TL_FN void tl_encode_stream(TlWaveLds &w, const TlBlockShared *TL_RESTRICT B, co
             for (int i = lane; i < xl; i += 64) w.xpad[i] = A.xpad[slot * TL_MAX_XPAD + i];
             TL_LANES_END
         }
-        tl_encode_frame<PSY>(w, T, B, C, A.psy2_tables ? &A.psy2_tables[C->psy2_tab] : nullptr, A.psy2_state ? &A.psy2_state[s] : nullptr, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, A.taps ? &A.taps[slot] : nullptr,
-                        A.stamps ? A.stamps + slot * 32 : nullptr);
+        tl_encode_frame<PSY>(w, T, B, C, A.psy2_tables ? &A.psy2_tables[C->psy2_tab] : nullptr, A.psy2_state ? &A.psy2_state[s] : nullptr,
+                             A.psy_out ? &A.psy_out[slot] : nullptr, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, f == A.nframes - 1,
+                             A.taps ? &A.taps[slot] : nullptr, A.stamps ? A.stamps + slot * 32 : nullptr);
         done++;
     }
     // the last 480 samples per channel of the last input frame become the stream's history

@@ -22,9 +22,24 @@ static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 
 #define TL_WAVES_PER_BLOCK 4
 
-// One wavefront per stream: block = TL_WAVES_PER_BLOCK independent waves, no
-// block-level barrier after the table copy; each wave keeps its stream's working set in its own LDS slice.
-// One kernel per psy model (template), launched over the streams that use it (A.stream_list).
+// ---- kernels of the encode path ------------------------------------------------------------------------------------------
+// One wavefront per stream.  Two shapes:
+//
+//  * psy models 0, 2 and 4: ONE kernel, tl_encode_kernel<PSY>: a workgroup = 4 independent waves, each takes one stream
+//    through the frames of the launch (model 2/4 carries prediction state from frame to frame).
+//
+//  * psy models 1 and 3 (the ones DAB uses): TWO kernels.
+//      tl_psy_kernel<PSY>   the psychoacoustic model alone.  It reads nothing but PCM, so every (stream, frame) is an
+//                           independent unit: persistent waves take units off a strided list, no per-stream state, no
+//                           frame order.  Without the filterbank's 72 sample registers and the encoder's arrays it fits
+//                           168 VGPRs and 11.3 KB of LDS per wave: 3 waves per SIMD instead of 2.  Output: 1 KB per frame
+//                           (TlPsyOut: level and minimum masking threshold per subband).
+//      tl_main_kernel       filterbank, scalefactors, SMR from TlPsyOut, bit allocation, quantiser, packing, CRCs; one wave
+//                           per stream, frames in order (the pending frame stays in LDS for the whole launch).  Also 3 waves
+//                           per SIMD.
+//    The price is HBM traffic the fused form did not have (PCM is read by both kernels, TlPsyOut is written and read):
+//    ~2.2 x the algorithmic bytes -- on a path that uses 1-2 % of the HBM bandwidth and is bound by VALU issue and LDS
+//    latency, where occupancy is what pays (DESIGN.md section 4 has the counters of both forms).
 template <int PSY>
 __global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK, 2) tl_encode_kernel(TlLaunch A)
 {
@@ -43,6 +58,59 @@ __global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK, 2) tl_encode_kernel(T
     if (k >= A.nlist) return;
     const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
     tl_encode_stream<PSY>(lds[wave], &shared, A, s);
+}
+
+// psy kernel: TL_PSY_WAVES waves per workgroup share one copy of the dB-sum table (8 KB); two workgroups per CU.
+// psy kernel: the twelve waves a CU holds at 168 VGPRs are ONE workgroup sharing one copy of the dB-sum table (8 KB).  LDS is
+// handed out in granules of 1280 bytes on gfx950 (160 KB / 128): three 4-wave workgroups with a table each do not fit.
+#ifndef TL_PSY_WAVES
+#define TL_PSY_WAVES 12
+#endif
+#ifndef TL_PSY_WPE
+#define TL_PSY_WPE 3
+#endif
+#ifndef TL_MAIN_WPE
+#define TL_MAIN_WPE 3
+#endif
+#define TL_LDS_GRANULE 1280u
+static_assert(((sizeof(double) * 1002 + TL_PSY_WAVES * sizeof(TlPsyLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE) * (12 / TL_PSY_WAVES) <= 128, "twelve psy waves per CU");
+template <int PSY>
+__global__ void __launch_bounds__(64 * TL_PSY_WAVES) __attribute__((amdgpu_waves_per_eu(TL_PSY_WPE, TL_PSY_WPE))) tl_psy_kernel(TlLaunch A)
+{
+    __shared__ double dbt[1002];
+    __shared__ TlPsyLds lds[TL_PSY_WAVES];
+    for (int i = (int)threadIdx.x; i < 1002; i += 64 * TL_PSY_WAVES) dbt[i] = A.tables->shared.dbtable[i];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nunits = A.nlist * A.nframes, stride = (int)gridDim.x * TL_PSY_WAVES;
+    for (int u = (int)blockIdx.x * TL_PSY_WAVES + wave; u < nunits; u += stride) {
+        const int f = u / A.nlist, k = u - f * A.nlist;             // neighbouring waves: neighbouring streams of one frame
+        const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
+        tl_psy_unit<PSY>(lds[wave], dbt, A, s, f);
+    }
+}
+
+// encode kernel of the split path: the tables it needs on dependent-load chains (TlBlockShared without the dB-sum table)
+struct TlMainShared { char bytes[sizeof(TlBlockShared) - offsetof(TlBlockShared, scalefactor)]; };
+static_assert(offsetof(TlBlockShared, dbtable) == 0 && offsetof(TlBlockShared, scalefactor) == sizeof(double) * 1002, "dbtable leads TlBlockShared");
+static_assert(((sizeof(TlMainShared) + TL_WAVES_PER_BLOCK * sizeof(TlMainLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE) * 3 <= 128, "three encode workgroups per CU");
+__global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TL_MAIN_WPE, TL_MAIN_WPE))) tl_main_kernel(TlLaunch A)
+{
+    __shared__ TlMainShared sh;
+    __shared__ TlMainLds lds[TL_WAVES_PER_BLOCK];
+    {
+        const double *src = (const double *)&A.tables->shared.scalefactor[0];
+        double *dst = (double *)&sh;
+        for (int i = (int)threadIdx.x; i < (int)(sizeof(TlMainShared) / 8); i += 64 * TL_WAVES_PER_BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    // the encode path never touches B->dbtable: a TlBlockShared pointer whose dbtable part lies before the copied block
+    const TlBlockShared *B = (const TlBlockShared *)((const char *)&sh - offsetof(TlBlockShared, scalefactor));
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int k = (int)blockIdx.x * TL_WAVES_PER_BLOCK + wave;
+    if (k >= A.nlist) return;
+    const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
+    tl_encode_stream<TL_PSY_EXT>(lds[wave], B, A, s);
 }
 
 // Ingest glue of the caller (src/odr-audioenc.cpp:1030-1051 gain + peak, :1139-1152
@@ -193,13 +261,15 @@ struct tlb_batch {
     int32_t *d_frame_bytes = nullptr;
     TlEdiState *d_edi_state_tmp = nullptr;
     uint16_t *d_pseq_tmp = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;   // ev_mid: between the psy kernel and the encode kernel (models 1/3)
+    bool have_mid = false;
     hipStream_t last_stream = nullptr;
     bool timed = false;
     // device staging of the host-buffer entry point (tlb_encode_host): grow-only, created on first use, so a caller that
     // feeds one frame per call (the legacy shim) pays for no allocation after its first frame
-    void *stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // pcm, out, xpad, xpad_len, taps
-    size_t stage_cap[5] = {0, 0, 0, 0, 0};
+    void *stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // pcm, out, xpad, xpad_len, taps; [5] = TlPsyOut records
+    size_t stage_cap[6] = {0, 0, 0, 0, 0, 0};
+    int num_cu = 256;
 };
 
 static hipError_t stage_reserve(tlb_batch *b, int k, size_t bytes)
@@ -244,11 +314,12 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_edi_state_tmp) (void)hipFree(b->d_edi_state_tmp);
     if (b->d_pseq_tmp) (void)hipFree(b->d_pseq_tmp);
     for (int p = 0; p < 4; p++) if (b->d_list[p]) (void)hipFree(b->d_list[p]);
-    for (int k = 0; k < 5; k++) if (b->stage[k]) (void)hipFree(b->stage[k]);
+    for (int k = 0; k < 6; k++) if (b->stage[k]) (void)hipFree(b->stage[k]);
     if (b->d_psy2_tables) (void)hipFree(b->d_psy2_tables);
     if (b->d_psy2_state) (void)hipFree(b->d_psy2_state);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
+    if (b->ev_mid) (void)hipEventDestroy(b->ev_mid);
     delete b;
 }
 
@@ -278,6 +349,7 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
         if (b->h_configs[found].frame_bytes > b->out_stride) b->out_stride = b->h_configs[found].frame_bytes;
     }
     HIPCHK(hipSetDevice(device));
+    { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) b->num_cu = n; }
     TlTables *ht = new TlTables;
     tl_build_tables(ht);
     hipError_t e = hipMalloc(&b->d_tables, sizeof(TlTables));
@@ -318,6 +390,7 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
     }
     HIPCHK(hipEventCreate(&b->ev0));
     HIPCHK(hipEventCreate(&b->ev1));
+    HIPCHK(hipEventCreate(&b->ev_mid));
     return TLB_OK;
 }
 
@@ -359,17 +432,30 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
     A.out = d_out; A.taps = d_taps; A.stamps = d_stamps;
     A.psy2_tables = b->d_psy2_tables; A.psy2_state = b->d_psy2_state;
     A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride;
+    if (b->n_list[1] || b->n_list[3]) {
+        // TlPsyOut records of this launch (psy kernel -> encode kernel), grow-only.  NOTE: one buffer per batch -- launches of
+        // one batch are ordered on one stream (they share the stream state anyway)
+        HIPCHK(stage_reserve(b, 5, (size_t)nframes * (size_t)b->nstreams * sizeof(TlPsyOut)));
+        A.psy_out = (TlPsyOut *)b->stage[5];
+    }
     HIPCHK(hipEventRecord(b->ev0, st));
+    b->have_mid = false;
     for (int p = 0; p < 4; p++) {
         if (!b->n_list[p]) continue;
         A.stream_list = b->d_list[p]; A.nlist = b->n_list[p];
         const int blocks = (b->n_list[p] + TL_WAVES_PER_BLOCK - 1) / TL_WAVES_PER_BLOCK;
-        switch (p) {
-        case 0: hipLaunchKernelGGL(tl_encode_kernel<0>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A); break;
-        case 1: hipLaunchKernelGGL(tl_encode_kernel<1>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A); break;
-        case 2: hipLaunchKernelGGL(tl_encode_kernel<2>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A); break;
-        default: hipLaunchKernelGGL(tl_encode_kernel<3>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A); break;
-        }
+        if (p == 1 || p == 3) {
+            // persistent psy waves: twelve per CU (three per SIMD), each walks the (stream, frame) units with the grid's stride
+            const long units = (long)b->n_list[p] * nframes;
+            long pb = (units + TL_PSY_WAVES - 1) / TL_PSY_WAVES;
+            if (pb > (12L / TL_PSY_WAVES) * b->num_cu) pb = (12L / TL_PSY_WAVES) * b->num_cu;
+            if (p == 1) hipLaunchKernelGGL(tl_psy_kernel<1>, dim3((unsigned)pb), dim3(64 * TL_PSY_WAVES), 0, st, A);
+            else hipLaunchKernelGGL(tl_psy_kernel<3>, dim3((unsigned)pb), dim3(64 * TL_PSY_WAVES), 0, st, A);
+            HIPCHK(hipGetLastError());
+            if (!b->n_list[0] && !b->n_list[2] && !(b->n_list[1] && b->n_list[3])) { HIPCHK(hipEventRecord(b->ev_mid, st)); b->have_mid = true; }
+            hipLaunchKernelGGL(tl_main_kernel, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);
+        } else if (p == 0) hipLaunchKernelGGL(tl_encode_kernel<0>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);
+        else hipLaunchKernelGGL(tl_encode_kernel<2>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(b->ev1, st));
@@ -737,6 +823,18 @@ float tlb_last_kernel_ms(tlb_batch *b)
     float ms = -1.0f;
     if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) return -1.0f;
     return ms;
+}
+
+// Durations of the two kernels of the most recent launch of a batch whose streams all use ONE of the models 1 and 3 (the psy
+// kernel, then the encode kernel), hipEvents on the launch stream.  Returns non-zero when the last launch was of another shape.
+int tlb_last_stage_ms(tlb_batch *b, float *psy_ms, float *encode_ms)
+{
+    if (!b || !b->timed || !b->have_mid || !psy_ms || !encode_ms) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipEventSynchronize(b->ev1));
+    HIPCHK(hipEventElapsedTime(psy_ms, b->ev0, b->ev_mid));
+    HIPCHK(hipEventElapsedTime(encode_ms, b->ev_mid, b->ev1));
+    return TLB_OK;
 }
 
 // ------------------------------------------------------------------------------------------

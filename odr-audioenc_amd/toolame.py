@@ -15,7 +15,7 @@ from pathlib import Path
 import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libtoolame_dab_hip.so"
+LIB_PATH = Path(os.environ.get("TLB_LIB_PATH") or PKG_DIR / "libtoolame_dab_hip.so")     # TLB_LIB_PATH: kernel experiments (tools/) only
 MAX_XPAD = 200
 SAMPLES = 1152
 
@@ -83,6 +83,7 @@ def load_library():
     L.tlb_flush_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.tlb_last_kernel_ms.argtypes = [C.c_void_p]
     L.tlb_last_kernel_ms.restype = C.c_float
+    L.tlb_last_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.tlb_version.restype = C.c_char_p
     L.tlb_set_gain_db.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.tlb_ingest_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -278,6 +279,13 @@ class Batch:
 
     def last_kernel_ms(self):
         return float(self.L.tlb_last_kernel_ms(self.h))
+
+    def last_stage_ms(self):
+        """(psy kernel ms, encode kernel ms) of the last launch, or None when the batch is not all model 1 or all model 3"""
+        a, b = C.c_float(0), C.c_float(0)
+        if self.L.tlb_last_stage_ms(self.h, C.byref(a), C.byref(b)):
+            return None
+        return float(a.value), float(b.value)
 
     def reset(self):
         rc = self.L.tlb_reset(self.h)

@@ -69,12 +69,23 @@ int emu_encode(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, co
     A.psy2_state = e->psy2_state.empty() ? nullptr : e->psy2_state.data();
     A.nstreams = (int)e->state.size(); A.nframes = nframes; A.out_stride = out_stride;
     static thread_local TlWaveLds w;
+    static thread_local TlMainLds wm;
+    static thread_local TlPsyLds wp;
+    // models 1 and 3 as on the device: the psy kernel's units first (every frame of every such stream, any order: here frames
+    // descending to show that nothing is carried from frame to frame), then the encode kernel reading their TlPsyOut records
+    std::vector<TlPsyOut> psy_out((size_t)nframes * (size_t)A.nstreams);
+    A.psy_out = psy_out.data();
+    for (int f = nframes - 1; f >= 0; f--)
+        for (int s = 0; s < A.nstreams; s++) {
+            const int m = e->configs[e->stream_cfg[s]].psy;
+            if (m == 1) tl_psy_unit<1>(wp, e->tables.shared.dbtable, A, s, f);
+            else if (m == 3) tl_psy_unit<3>(wp, e->tables.shared.dbtable, A, s, f);
+        }
     for (int s = 0; s < A.nstreams; s++)
         switch (e->configs[e->stream_cfg[s]].psy) {
         case 0: tl_encode_stream<0>(w, &e->tables.shared, A, s); break;
-        case 1: tl_encode_stream<1>(w, &e->tables.shared, A, s); break;
         case 2: case 4: tl_encode_stream<2>(w, &e->tables.shared, A, s); break;     // model 4: the psy-2 code on its own tables
-        default: tl_encode_stream<3>(w, &e->tables.shared, A, s); break;
+        default: tl_encode_stream<TL_PSY_EXT>(wm, &e->tables.shared, A, s); break;  // models 1 and 3
         }
     return 0;
 }
