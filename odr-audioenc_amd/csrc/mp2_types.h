@@ -147,5 +147,8 @@ struct TlLaunch {
     const TlPsy2Tables *psy2_tables;  // [*] indexed by TlConfig::psy2_tab, or null when no stream uses psy 2
     TlPsy2State *psy2_state;          // [nstreams] or null
     TlPsyOut *psy_out;                // [nframes][nstreams] psy kernel -> encode kernel (models 1 and 3), or null
+    uint8_t *scfcrc;                  // [nframes][nstreams][4] ScF-CRC bytes of each frame (split path: encode kernel -> finish kernel)
+    uint32_t *newpend;                // [nstreams][TL_MAX_FRAME_WORDS] last frame of the launch, before it becomes the pending one
+    int32_t *work;                    // [2] unit counters of the persistent kernels (psy, encode): waves take the next unit off them
     int32_t nstreams, nframes, out_stride, nlist;
 };

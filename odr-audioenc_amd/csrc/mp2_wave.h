@@ -252,29 +252,25 @@ struct TlWaveLds {
     uint8_t minidx[2][32];
     uint8_t xpad[TL_MAX_XPAD];
     static constexpr int kFbBatch = TL_FB_BATCH;
-    static constexpr bool kLdsPending = false;
+    static constexpr bool kFrameParallel = false;
     typedef double (*YpRows)[2][34];    // [kFbBatch][2][32 (+2: the four addresses a matrixing read touches sit on different banks)]
 #ifdef TL_EMULATE
     YpRows yp_rows() { return (YpRows)px; }
-    uint32_t *pending_words() { return nullptr; }
 #else
     __device__ YpRows yp_rows() { return (YpRows)px; }
-    __device__ uint32_t *pending_words() { return nullptr; }
 #endif
 };
 // Per-wave LDS of the encode kernel of the split path (models 1 and 3 run in their own kernel): PCM staging / frame being
-// packed, the filterbank's window-output scratch, the pending frame (kept on chip for all frames of a launch) and the
-// small per-subband arrays.
+// packed, the filterbank's window-output scratch and the small per-subband arrays.
 struct TlMainLds {
     static constexpr bool kSplit = false;
     static constexpr int kFbBatch = TL_FB_BATCH_MAIN;
-    static constexpr bool kLdsPending = true;
+    static constexpr bool kFrameParallel = true;
     union alignas(16) {
         struct { int16_t pcm[2][TL_HIST + 1152]; } fbk;
         uint32_t frame[TL_MAX_FRAME_WORDS + 2];
     } u;
     double yp[TL_FB_BATCH_MAIN][2][34];
-    uint32_t pending[TL_MAX_FRAME_WORDS];
     double smr[2][32];
     int16_t ncentre[32];                // (ScF-CRC scratch)
     uint8_t scf[2][3][32];
@@ -286,10 +282,8 @@ struct TlMainLds {
     typedef double (*YpRows)[2][34];
 #ifdef TL_EMULATE
     YpRows yp_rows() { return yp; }
-    uint32_t *pending_words() { return pending; }
 #else
     __device__ YpRows yp_rows() { return yp; }
-    __device__ uint32_t *pending_words() { return pending; }
 #endif
 };
 // What the psy kernel of models 1 and 3 hands to the encode kernel per frame: per (channel, subband) the level A that competes
@@ -2102,10 +2096,14 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
 // One frame of one stream.  lane = 2*sb + ch owns subband sb of channel ch.  PSY (the psy model) is a compile-time
 // parameter: one kernel per model keeps each kernel's code and register footprint to what that model needs.
 static_assert(offsetof(TlWaveLds, cinfo) + sizeof(((TlWaveLds *)0)->cinfo) - offsetof(TlWaveLds, px) >= sizeof(double) * TL_FB_BATCH * 68, "filterbank scratch");
+// Where a frame of the frame-parallel encode kernel goes (exactly one of bytes / words is set): the output slot it waits in
+// for its successor's ScF-CRC, or -- the last frame of a launch -- the batch's pending buffer (big-endian words like
+// TlStreamState::pending); and the slot for its own ScF-CRC bytes, which tl_finish_stream stores into the frame before it.
+struct TlFrameOut { uint8_t *bytes; uint32_t *words; uint8_t *scfcrc; };
 template <int PSY, class W>
 TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
                            const TlConfig *TL_RESTRICT C, const TlPsy2Tables *TL_RESTRICT P2, TlPsy2State *TL_RESTRICT S2, const TlPsyOut *TL_RESTRICT PO,
-                           const TlPcmView &pv, TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, bool last_frame, TlTaps *taps, long long *sp)
+                           const TlPcmView &pv, TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, const TlFrameOut &fo, TlTaps *taps, long long *sp)
 {
     constexpr int FB = W::kFbBatch;
     const int nch = C->nch, sblimit = C->sblimit;
@@ -2748,10 +2746,25 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     // ---- emit: patch the previous frame's ScF-CRC slot with this frame's CRC and hand it out;
     //      this frame becomes the pending one (toolame.c:527-542, "one frame in memory") ----
     const int nwords = (lg_frame + 3) >> 2;
-    uint32_t *pend = W::kLdsPending ? w.pending_words() : st->pending;     // on chip for all frames of a launch, or in the stream state
+    if constexpr (W::kFrameParallel) {
+        // frames of a stream are encoded by different waves in any order: this one only files its frame and its ScF-CRC;
+        // tl_finish_stream puts each frame's CRC into the frame before it once the launch's frames are all there
+        TL_LANES_BEGIN
+        for (int i = lane; i < nwords; i += 64) {
+            if (fo.words) fo.words[i] = frame[i];
+            else {
+                const uint32_t le = tl_bswap(frame[i]);
+                const int rem = lg_frame - 4 * i;
+                if (rem >= 4) ((uint32_t *)fo.bytes)[i] = le;
+                else for (int b = 0; b < rem; b++) fo.bytes[4 * i + b] = (uint8_t)(le >> (8 * b));
+            }
+        }
+        if (lane < 4) fo.scfcrc[lane] = lane < C->dab_ext ? (uint8_t)w.ncentre[lane] : 0;
+        TL_LANES_END
+    } else {
     TL_LANES_BEGIN
     for (int i = lane; i < nwords; i += 64) {
-        uint32_t prev = pend[i];
+        uint32_t prev = st->pending[i];
         if (have_prev && out_prev) {
             // overlay bytes [tail, tail+dab_ext) of the previous frame with this frame's ScF-CRC bytes
             for (int k = 0; k < C->dab_ext; k++) {
@@ -2766,10 +2779,10 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
             if (rem >= 4) ((uint32_t *)out_prev)[i] = le;
             else for (int b = 0; b < rem; b++) out_prev[4 * i + b] = (uint8_t)(le >> (8 * b));
         }
-        pend[i] = frame[i];
-        if (W::kLdsPending && last_frame) st->pending[i] = frame[i];     // the launch's last frame goes back to the stream state
+        st->pending[i] = frame[i];
     }
     TL_LANES_END
+    }
     TL_STAMP(sp, 7);
 }
 
@@ -2811,8 +2824,49 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
     }
 }
 
+// [history | frame] -> LDS in 8-byte pieces, 120 + 288 per channel.  All of a lane's loads are issued before the first LDS
+// write so the HBM latency is paid once per frame, not once per piece.
+template <class W>
+TL_FN void tl_stage_pcm(W &w, const TlPcmView &pv, int nch)
+{
+    TL_LANES_BEGIN
+    {
+        constexpr int HP = TL_HIST / 4, CP = 1152 / 4, PER = HP + CP;      // pieces per channel
+        constexpr int NIT = (2 * PER + 63) / 64;
+        uint64_t v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = lane + 64 * it, ch = i >= PER ? 1 : 0, k = i - ch * PER;
+            v[it] = 0;
+            if (i < PER * nch)
+                v[it] = k < HP ? *(const uint64_t *)(pv.hist + ch * pv.hist_stride + 4 * k)
+                               : *(const uint64_t *)(pv.cur + ch * 1152 + 4 * (k - HP));
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = lane + 64 * it, ch = i >= PER ? 1 : 0, k = i - ch * PER;
+            if (i < PER * nch) *(uint64_t *)&w.u.fbk.pcm[ch][4 * k] = v[it];
+        }
+    }
+    TL_LANES_END
+}
+// X-PAD bytes of a slot -> LDS; returns the length the frame carries.  The contract is 0 or 2..pad_len (toolame.c:515-516,
+// odr-audioenc.cpp:803,830-834); anything else -- more than the stream's toolame_set_pad() length, more than the record
+// holds -- is treated as "no PAD this frame" (tl_build_config has made sure that pad_len itself fits into the frame).
+template <class W>
+TL_FN int tl_stage_xpad(W &w, const TlLaunch &A, const TlConfig *C, size_t slot)
+{
+    if (!A.xpad_len) return 0;
+    int xl = A.xpad_len[slot];
+    if (xl < 2 || xl > TL_MAX_XPAD || xl > C->dab_length) xl = 0;
+    TL_LANES_BEGIN
+    for (int i = lane; i < xl; i += 64) w.xpad[i] = A.xpad[slot * TL_MAX_XPAD + i];
+    TL_LANES_END
+    return xl;
+}
+
 // ------------------------------------------------------------------------------------------
-// A wave encodes `nframes` consecutive frames of stream `s`; state stays in LDS across frames.
+// Fused kernels (psy models 0, 2, 4): a wave encodes `nframes` consecutive frames of stream `s`.
 template <int PSY, class W>
 TL_FN void tl_encode_stream(W &w, const TlBlockShared *TL_RESTRICT B, const TlLaunch &A, int s)
 {
@@ -2821,51 +2875,15 @@ TL_FN void tl_encode_stream(W &w, const TlBlockShared *TL_RESTRICT B, const TlLa
     TlStreamState *st = &A.state[s];
     const int nch = C->nch;
     int done = st->frames_done;
-    if (W::kLdsPending) {                                             // the pending frame stays on chip for the whole launch
-        uint32_t *pend = w.pending_words();
-        TL_LANES_BEGIN
-        for (int i = lane; i < ((C->frame_bytes + 3) >> 2); i += 64) pend[i] = st->pending[i];
-        TL_LANES_END
-    }
+    const TlFrameOut none = {nullptr, nullptr, nullptr};
     for (int f = 0; f < A.nframes; f++) {
         const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
         const TlPcmView pv = tl_pcm_view(A, st, s, f);
         TL_STAMP(A.stamps ? A.stamps + slot * 32 : nullptr, 31);        // frame begin, before the PCM staging
-        TL_LANES_BEGIN
-        {
-            // [history | frame] -> LDS in 8-byte pieces, 120 + 288 per channel.  All of a lane's loads are issued
-            // before the first LDS write so the HBM latency is paid once per frame, not once per piece.
-            constexpr int HP = TL_HIST / 4, CP = 1152 / 4, PER = HP + CP;      // pieces per channel
-            constexpr int NIT = (2 * PER + 63) / 64;
-            uint64_t v[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; it++) {
-                const int i = lane + 64 * it, ch = i >= PER ? 1 : 0, k = i - ch * PER;
-                v[it] = 0;
-                if (i < PER * nch)
-                    v[it] = k < HP ? *(const uint64_t *)(pv.hist + ch * pv.hist_stride + 4 * k)
-                                   : *(const uint64_t *)(pv.cur + ch * 1152 + 4 * (k - HP));
-            }
-#pragma unroll
-            for (int it = 0; it < NIT; it++) {
-                const int i = lane + 64 * it, ch = i >= PER ? 1 : 0, k = i - ch * PER;
-                if (i < PER * nch) *(uint64_t *)&w.u.fbk.pcm[ch][4 * k] = v[it];
-            }
-        }
-        TL_LANES_END
-        int xl = 0;
-        if (A.xpad_len) {
-            xl = A.xpad_len[slot];
-            // the contract is 0 or 2..pad_len (toolame.c:515-516, odr-audioenc.cpp:803,830-834); anything else -- more than
-            // the stream's toolame_set_pad() length, more than the record holds -- is treated as "no PAD this frame"
-            // (tl_build_config has made sure that pad_len itself fits into the frame)
-            if (xl < 2 || xl > TL_MAX_XPAD || xl > C->dab_length) xl = 0;
-            TL_LANES_BEGIN
-            for (int i = lane; i < xl; i += 64) w.xpad[i] = A.xpad[slot * TL_MAX_XPAD + i];
-            TL_LANES_END
-        }
+        tl_stage_pcm(w, pv, nch);
+        const int xl = tl_stage_xpad(w, A, C, slot);
         tl_encode_frame<PSY>(w, T, B, C, A.psy2_tables ? &A.psy2_tables[C->psy2_tab] : nullptr, A.psy2_state ? &A.psy2_state[s] : nullptr,
-                             A.psy_out ? &A.psy_out[slot] : nullptr, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, f == A.nframes - 1,
+                             nullptr, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, none,
                              A.taps ? &A.taps[slot] : nullptr, A.stamps ? A.stamps + slot * 32 : nullptr);
         done++;
     }
@@ -2878,6 +2896,71 @@ TL_FN void tl_encode_stream(W &w, const TlBlockShared *TL_RESTRICT B, const TlLa
             *(uint32_t *)&st->hist[ch][k] = ch < nch ? *(const uint32_t *)(last + ch * 1152 + (1152 - TL_HIST) + k) : 0u;
         }
         if (lane == 0) st->frames_done = done;
+        TL_LANES_END
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Split path (psy models 1 and 3), encode kernel: one unit = frame f of stream s.  Like the psy kernel's units these are
+// independent of each other: the filterbank's history is PCM (the previous input frame, or the stream state before frame 0),
+// the SMR comes from the psy kernel's record, and the one thing a frame owes its predecessor -- its ScF-CRC, which travels in
+// the frame before (toolame.c:527-542) -- is filed aside and put in place by tl_finish_stream.
+TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const TlLaunch &A, int s, int f)
+{
+    const TlConfig *C = &A.configs[A.stream_cfg[s]];
+    TlStreamState *st = &A.state[s];
+    const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
+    const TlPcmView pv = tl_pcm_view(A, st, s, f);
+    long long *sp = A.stamps ? A.stamps + slot * 32 : nullptr;
+    TL_STAMP(sp, 31);
+    tl_stage_pcm(w, pv, C->nch);
+    const int xl = tl_stage_xpad(w, A, C, slot);
+    TlFrameOut fo;
+    fo.bytes = f + 1 < A.nframes ? A.out + (slot + (size_t)A.nstreams) * (size_t)A.out_stride : nullptr;     // waits in the next slot
+    fo.words = f + 1 < A.nframes ? nullptr : A.newpend + (size_t)s * TL_MAX_FRAME_WORDS;
+    fo.scfcrc = A.scfcrc + slot * 4;
+    tl_encode_frame<TL_PSY_EXT>(w, A.tables, B, C, nullptr, nullptr, &A.psy_out[slot], pv, st, xl, nullptr, false, fo,
+                                A.taps ? &A.taps[slot] : nullptr, sp);
+}
+
+// After the units of a launch: for stream s, hand out the frame that was pending before the launch (slot 0), store every
+// frame's ScF-CRC into the frame before it, make the launch's last frame the pending one, roll the PCM history forward.
+TL_FN void tl_finish_stream(const TlLaunch &A, int s)
+{
+    const TlConfig *C = &A.configs[A.stream_cfg[s]];
+    TlStreamState *st = &A.state[s];
+    const int lg_frame = C->frame_bytes, nwords = (lg_frame + 3) >> 2, dab_ext = C->dab_ext, nch = C->nch;
+    const int tail = lg_frame - 2 - dab_ext;
+    const bool have_prev = st->frames_done > 0;
+    uint8_t *out0 = A.out + (size_t)s * (size_t)A.out_stride;
+    TL_LANES_BEGIN
+    if (have_prev)
+        for (int i = lane; i < nwords; i += 64) {
+            const uint32_t le = tl_bswap(st->pending[i]);
+            const int rem = lg_frame - 4 * i;
+            if (rem >= 4) ((uint32_t *)out0)[i] = le;
+            else for (int b = 0; b < rem; b++) out0[4 * i + b] = (uint8_t)(le >> (8 * b));
+        }
+    TL_LANES_END
+    TL_LANES_BEGIN
+    for (int f = lane; f < A.nframes; f += 64)
+        if (f > 0 || have_prev) {
+            const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
+            uint8_t *o = A.out + slot * (size_t)A.out_stride + tail;
+            for (int k = 0; k < dab_ext; k++) o[k] = A.scfcrc[slot * 4 + k];
+        }
+    TL_LANES_END
+    TL_LANES_BEGIN
+    for (int i = lane; i < nwords; i += 64) st->pending[i] = A.newpend[(size_t)s * TL_MAX_FRAME_WORDS + i];
+    TL_LANES_END
+    {
+        const int16_t *last = A.pcm + ((size_t)(A.nframes - 1) * (size_t)A.nstreams + (size_t)s) * 2304;
+        TL_LANES_BEGIN
+        for (int i = lane; i < (TL_HIST / 2) * 2; i += 64) {
+            const int ch = i / (TL_HIST / 2), k = (i % (TL_HIST / 2)) * 2;
+            *(uint32_t *)&st->hist[ch][k] = ch < nch ? *(const uint32_t *)(last + ch * 1152 + (1152 - TL_HIST) + k) : 0u;
+        }
+        if (lane == 0) st->frames_done += A.nframes;
         TL_LANES_END
     }
 }

@@ -61,6 +61,14 @@ __global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK, 2) tl_encode_kernel(T
 }
 
 // psy kernel: TL_PSY_WAVES waves per workgroup share one copy of the dB-sum table (8 KB); two workgroups per CU.
+// next unit of a persistent kernel's work list (device-scope atomic: the counter is shared by all XCDs)
+static __device__ __forceinline__ int tl_next_unit(int32_t *counter)
+{
+    int u = 0;
+    if ((threadIdx.x & 63u) == 0) u = atomicAdd(counter, 1);
+    return __builtin_amdgcn_readfirstlane(u);
+}
+
 // psy kernel: the twelve waves a CU holds at 168 VGPRs are ONE workgroup sharing one copy of the dB-sum table (8 KB).  LDS is
 // handed out in granules of 1280 bytes on gfx950 (160 KB / 128): three 4-wave workgroups with a table each do not fit.
 #ifndef TL_PSY_WAVES
@@ -82,9 +90,11 @@ __global__ void __launch_bounds__(64 * TL_PSY_WAVES) __attribute__((amdgpu_waves
     for (int i = (int)threadIdx.x; i < 1002; i += 64 * TL_PSY_WAVES) dbt[i] = A.tables->shared.dbtable[i];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nunits = A.nlist * A.nframes, stride = (int)gridDim.x * TL_PSY_WAVES;
-    for (int u = (int)blockIdx.x * TL_PSY_WAVES + wave; u < nunits; u += stride) {
-        const int f = u / A.nlist, k = u - f * A.nlist;             // neighbouring waves: neighbouring streams of one frame
+    const int nunits = A.nlist * A.nframes;
+    for (;;) {                                                      // units cost different amounts: every wave takes the next one when it is free
+        const int u = tl_next_unit(&A.work[0]);
+        if (u >= nunits) break;
+        const int f = u / A.nlist, k = u - f * A.nlist;             // units taken one after the other: neighbouring streams of one frame
         const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
         tl_psy_unit<PSY>(lds[wave], dbt, A, s, f);
     }
@@ -107,10 +117,22 @@ __global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK) __attribute__((amdgpu
     // the encode path never touches B->dbtable: a TlBlockShared pointer whose dbtable part lies before the copied block
     const TlBlockShared *B = (const TlBlockShared *)((const char *)&sh - offsetof(TlBlockShared, scalefactor));
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int k = (int)blockIdx.x * TL_WAVES_PER_BLOCK + wave;
+    const int nunits = A.nlist * A.nframes;
+    for (;;) {
+        const int u = tl_next_unit(&A.work[1]);
+        if (u >= nunits) break;
+        const int f = u / A.nlist, k = u - f * A.nlist;
+        const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
+        tl_main_unit(lds[wave], B, A, s, f);
+    }
+}
+
+// finish pass of the split path: one wave per stream (tl_finish_stream)
+__global__ void __launch_bounds__(256) tl_finish_kernel(TlLaunch A)
+{
+    const int k = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (k >= A.nlist) return;
-    const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
-    tl_encode_stream<TL_PSY_EXT>(lds[wave], B, A, s);
+    tl_finish_stream(A, __builtin_amdgcn_readfirstlane(A.stream_list[k]));
 }
 
 // Ingest glue of the caller (src/odr-audioenc.cpp:1030-1051 gain + peak, :1139-1152
@@ -267,8 +289,10 @@ struct tlb_batch {
     bool timed = false;
     // device staging of the host-buffer entry point (tlb_encode_host): grow-only, created on first use, so a caller that
     // feeds one frame per call (the legacy shim) pays for no allocation after its first frame
-    void *stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // pcm, out, xpad, xpad_len, taps; [5] = TlPsyOut records
-    size_t stage_cap[6] = {0, 0, 0, 0, 0, 0};
+    void *stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // pcm, out, xpad, xpad_len, taps; [5] = TlPsyOut records, [6] = ScF-CRC bytes
+    size_t stage_cap[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t *d_newpend = nullptr;               // split path: the launch's last frame of every stream
+    int32_t *d_work = nullptr;                   // unit counters of the persistent kernels
     int num_cu = 256;
 };
 
@@ -314,7 +338,9 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_edi_state_tmp) (void)hipFree(b->d_edi_state_tmp);
     if (b->d_pseq_tmp) (void)hipFree(b->d_pseq_tmp);
     for (int p = 0; p < 4; p++) if (b->d_list[p]) (void)hipFree(b->d_list[p]);
-    for (int k = 0; k < 6; k++) if (b->stage[k]) (void)hipFree(b->stage[k]);
+    for (int k = 0; k < 7; k++) if (b->stage[k]) (void)hipFree(b->stage[k]);
+    if (b->d_newpend) (void)hipFree(b->d_newpend);
+    if (b->d_work) (void)hipFree(b->d_work);
     if (b->d_psy2_tables) (void)hipFree(b->d_psy2_tables);
     if (b->d_psy2_state) (void)hipFree(b->d_psy2_state);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -388,6 +414,11 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
         HIPCHK(hipMalloc(&b->d_psy2_state, sizeof(TlPsy2State) * (size_t)nstreams));
         HIPCHK(hipMemset(b->d_psy2_state, 0, sizeof(TlPsy2State) * (size_t)nstreams));
     }
+    if (b->n_list[1] || b->n_list[3]) {
+        HIPCHK(hipMalloc(&b->d_newpend, sizeof(uint32_t) * TL_MAX_FRAME_WORDS * (size_t)nstreams));
+        HIPCHK(hipMemset(b->d_newpend, 0, sizeof(uint32_t) * TL_MAX_FRAME_WORDS * (size_t)nstreams));
+        HIPCHK(hipMalloc(&b->d_work, sizeof(int32_t) * 2));
+    }
     HIPCHK(hipEventCreate(&b->ev0));
     HIPCHK(hipEventCreate(&b->ev1));
     HIPCHK(hipEventCreate(&b->ev_mid));
@@ -436,7 +467,8 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         // TlPsyOut records of this launch (psy kernel -> encode kernel), grow-only.  NOTE: one buffer per batch -- launches of
         // one batch are ordered on one stream (they share the stream state anyway)
         HIPCHK(stage_reserve(b, 5, (size_t)nframes * (size_t)b->nstreams * sizeof(TlPsyOut)));
-        A.psy_out = (TlPsyOut *)b->stage[5];
+        HIPCHK(stage_reserve(b, 6, (size_t)nframes * (size_t)b->nstreams * 4));
+        A.psy_out = (TlPsyOut *)b->stage[5]; A.scfcrc = (uint8_t *)b->stage[6]; A.newpend = b->d_newpend; A.work = b->d_work;
     }
     HIPCHK(hipEventRecord(b->ev0, st));
     b->have_mid = false;
@@ -445,15 +477,20 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         A.stream_list = b->d_list[p]; A.nlist = b->n_list[p];
         const int blocks = (b->n_list[p] + TL_WAVES_PER_BLOCK - 1) / TL_WAVES_PER_BLOCK;
         if (p == 1 || p == 3) {
-            // persistent psy waves: twelve per CU (three per SIMD), each walks the (stream, frame) units with the grid's stride
+            // persistent waves, twelve per CU (three per SIMD) in both kernels; they take (stream, frame) units off a counter
             const long units = (long)b->n_list[p] * nframes;
+            HIPCHK(hipMemsetAsync(b->d_work, 0, sizeof(int32_t) * 2, st));
             long pb = (units + TL_PSY_WAVES - 1) / TL_PSY_WAVES;
             if (pb > (12L / TL_PSY_WAVES) * b->num_cu) pb = (12L / TL_PSY_WAVES) * b->num_cu;
             if (p == 1) hipLaunchKernelGGL(tl_psy_kernel<1>, dim3((unsigned)pb), dim3(64 * TL_PSY_WAVES), 0, st, A);
             else hipLaunchKernelGGL(tl_psy_kernel<3>, dim3((unsigned)pb), dim3(64 * TL_PSY_WAVES), 0, st, A);
             HIPCHK(hipGetLastError());
             if (!b->n_list[0] && !b->n_list[2] && !(b->n_list[1] && b->n_list[3])) { HIPCHK(hipEventRecord(b->ev_mid, st)); b->have_mid = true; }
-            hipLaunchKernelGGL(tl_main_kernel, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);
+            long mb = (units + TL_WAVES_PER_BLOCK - 1) / TL_WAVES_PER_BLOCK;
+            if (mb > (long)TL_MAIN_WPE * b->num_cu) mb = (long)TL_MAIN_WPE * b->num_cu;
+            hipLaunchKernelGGL(tl_main_kernel, dim3((unsigned)mb), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(tl_finish_kernel, dim3((unsigned)((b->n_list[p] + 3) / 4)), dim3(256), 0, st, A);
         } else if (p == 0) hipLaunchKernelGGL(tl_encode_kernel<0>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);
         else hipLaunchKernelGGL(tl_encode_kernel<2>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);
         HIPCHK(hipGetLastError());

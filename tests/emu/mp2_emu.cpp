@@ -71,10 +71,14 @@ int emu_encode(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, co
     static thread_local TlWaveLds w;
     static thread_local TlMainLds wm;
     static thread_local TlPsyLds wp;
-    // models 1 and 3 as on the device: the psy kernel's units first (every frame of every such stream, any order: here frames
-    // descending to show that nothing is carried from frame to frame), then the encode kernel reading their TlPsyOut records
+    // models 1 and 3 as on the device: the psy kernel's units (every frame of every such stream; any order: here frames
+    // descending, to show that nothing is carried from frame to frame), the encode kernel's units (any order: here frames
+    // descending within streams ascending), then the finish pass per stream
     std::vector<TlPsyOut> psy_out((size_t)nframes * (size_t)A.nstreams);
-    A.psy_out = psy_out.data();
+    std::vector<uint8_t> scfcrc((size_t)nframes * (size_t)A.nstreams * 4);
+    std::vector<uint32_t> newpend((size_t)A.nstreams * TL_MAX_FRAME_WORDS);
+    A.psy_out = psy_out.data(); A.scfcrc = scfcrc.data(); A.newpend = newpend.data();
+    auto split = [&](int s) { const int m = e->configs[e->stream_cfg[s]].psy; return m == 1 || m == 3; };
     for (int f = nframes - 1; f >= 0; f--)
         for (int s = 0; s < A.nstreams; s++) {
             const int m = e->configs[e->stream_cfg[s]].psy;
@@ -82,11 +86,11 @@ int emu_encode(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, co
             else if (m == 3) tl_psy_unit<3>(wp, e->tables.shared.dbtable, A, s, f);
         }
     for (int s = 0; s < A.nstreams; s++)
-        switch (e->configs[e->stream_cfg[s]].psy) {
-        case 0: tl_encode_stream<0>(w, &e->tables.shared, A, s); break;
-        case 2: case 4: tl_encode_stream<2>(w, &e->tables.shared, A, s); break;     // model 4: the psy-2 code on its own tables
-        default: tl_encode_stream<TL_PSY_EXT>(wm, &e->tables.shared, A, s); break;  // models 1 and 3
-        }
+        if (split(s)) for (int f = nframes - 1; f >= 0; f--) tl_main_unit(wm, &e->tables.shared, A, s, f);
+    for (int s = 0; s < A.nstreams; s++)
+        if (split(s)) tl_finish_stream(A, s);
+        else if (e->configs[e->stream_cfg[s]].psy == 0) tl_encode_stream<0>(w, &e->tables.shared, A, s);
+        else tl_encode_stream<2>(w, &e->tables.shared, A, s);             // models 2 and 4 (4: the psy-2 code on its own tables)
     return 0;
 }
 int emu_pending(void *h, int s, uint8_t *out)
