@@ -36,7 +36,7 @@ double freq2bark(double freq)                      // ath.c:73-78
 void tl_build_tables(TlTables *T)
 {
     memset(T, 0, sizeof *T);
-    for (int i = 0; i < 512; i++) T->enwindow[i] = (double)TL_ENWINDOW_E9[i] / 1e9;
+    for (int i = 0; i < 512; i++) { T->enwindow[i] = (double)TL_ENWINDOW_E9[i] / 1e9; T->enwindow_s[i] = T->enwindow[i] / 32768; }
     for (int i = 0; i < 63; i++) T->scalefactor[i] = (double)TL_SCALEFACTOR_E14[i] / 1e14;
     T->scalefactor[63] = 1e-20;
     for (int q = 0; q < 18; q++) {

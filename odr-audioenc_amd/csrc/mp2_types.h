@@ -29,6 +29,7 @@ struct TlBlockShared {
 // fft.c:38-73,1139-1149, encode_new.c:16-100,448-462)
 struct TlTables {
     double enwindow[512];
+    double enwindow_s[512];      // enwindow / 32768: the filterbank scales the coefficient instead of the sample (exact, see mp2_wave.h K1)
     double dct[16][32];
     double hann[1024];
     double dbtable[1000];

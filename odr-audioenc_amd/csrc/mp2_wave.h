@@ -211,7 +211,9 @@ TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
 // Per-wave LDS working set.
 #define TL_CAND_MAX 256              // local maxima with passing right side (<= 249)
 #define TL_FB_BATCH 12               // fused kernels: filterbank blocks per LDS round trip (36 = 3 x 12); the window outputs go through the (idle) psy arrays px[] .. cinfo[]
-#define TL_FB_BATCH_MAIN 4           // encode kernel of the split path: 36 = 9 x 4 (a smaller scratch, fewer live registers)
+#ifndef TL_FB_BATCH_MAIN
+#define TL_FB_BATCH_MAIN 6           // encode kernel of the split path: 36 = 6 x 6 (a smaller scratch, fewer live registers)
+#endif
 #define TL_PSY_EXT 5                 // tl_encode_frame<TL_PSY_EXT>: SMR from the psy kernel's TlPsyOut (models 1 and 3)
 #define TL_TONE_MAX 77               // confirmed tones per channel-frame (hard bound 75: a tone erases run lines either side, 20 + 16 + 19 + 19 fit below line 500); sized so that three 4-wave psy workgroups fit one CU's LDS
 #define TL_MASKER_MAX 128            // tones + noise components after decimation
@@ -2103,7 +2105,8 @@ struct TlFrameOut { uint8_t *bytes; uint32_t *words; uint8_t *scfcrc; };
 template <int PSY, class W>
 TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
                            const TlConfig *TL_RESTRICT C, const TlPsy2Tables *TL_RESTRICT P2, TlPsy2State *TL_RESTRICT S2, const TlPsyOut *TL_RESTRICT PO,
-                           const TlPcmView &pv, TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, const TlFrameOut &fo, TlTaps *taps, long long *sp)
+                           const TlPcmView &pv, TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, const TlFrameOut &fo,
+                           const double *TL_RESTRICT enw_s, TlTaps *taps, long long *sp)
 {
     constexpr int FB = W::kFbBatch;
     const int nch = C->nch, sblimit = C->sblimit;
@@ -2118,20 +2121,15 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     // Matrixing stage: lane (ch,sb) owns the even-k chain s0 (sb<16) or the odd-k chain s1 (sb>=16) of row
     // min(sb,31-sb); the two halves swap values (a move, not a re-association): s[i]=s0+s1, s[31-i]=s0-s1.
     {
-        PA(double, ca, 8); PA(double, cb, 8);
-        const double *enw = T->enwindow;
-        TL_LAUNDER(enw);                // re-read per frame: 32 VGPRs of coefficients must not stay live through the other stages
-        TL_LANES_BEGIN
-        const int i = lane >> 1;
-        const int ya = i == 0 ? 16 : i + 16, yb = i == 0 ? 16 : (i <= 16 ? 16 - i : 80 - i);
         // the reference scales the sample, (pcm/32768)*C (subband.c:233,249); scaling the coefficient instead is the
-        // same real product rounded once (2^-15 is exact, nothing underflows), so the bits are identical
-        for (int j = 0; j < 8; j++) { L(ca)[j] = enw[ya + 64 * j] / 32768; L(cb)[j] = enw[yb + 64 * j] / 32768; }
-        TL_LANES_END
+        // same real product rounded once (2^-15 is exact, nothing underflows), so the bits are identical: enw_s = C / 32768
+        // (host table; the encode kernel of the split path reads its workgroup's LDS copy).
         // Window taps as a rolling register file: tap j of block b is tap j+1 of block b+2 (the window advances 32
         // samples per block, the taps are 64 apart), so each block reads two new samples per lane from LDS instead of
         // sixteen (kept as integers and converted at every use: a window of doubles, converted once, measured slower each
         // time it was tried).  Slot of (b, j): [b & 1][((b >> 1) - j) & 7].
+        // The coefficients are NOT kept in registers across batches: a batch fetches the eight of its ya-sums, runs them for
+        // all its blocks, then the eight of its yb-sums -- 16 registers live instead of 32 next to the 72 of the samples.
         PA(int, xa, 16); PA(int, xb, 16);
         TL_LANES_BEGIN
         const int c = lane & 1, i = lane >> 1;
@@ -2154,8 +2152,9 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
                 // yprime = ya-sum (i == 0), ya-sum + yb-sum (i <= 16), ya-sum - yb-sum (i >= 17) as ONE addition: the yb-sum
                 // with its sign flipped (a - b == a + (-b)) or replaced by -0.0 (a + (-0.0) == a, for every a)
                 const uint64_t keep = i == 0 ? 0ull : ~0ull, flip = (i == 0 || i > 16) ? 0x8000000000000000ull : 0ull;
-                // the batch's new samples (two per block) are all requested before the first block is computed
+                // the batch's new samples (two per block) and its first coefficients are all requested before the first block is computed
                 int na[FB], nb[FB];
+                double cf[8], ta[FB];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
@@ -2167,6 +2166,10 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
+                for (int j = 0; j < 8; j++) cf[j] = enw_s[ya + 64 * j];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
                 for (int bb = 0; bb < FB; bb++) { TL_KEEP(na[bb]); TL_KEEP(nb[bb]); }
 #ifndef TL_EMULATE
 #pragma unroll
@@ -2174,14 +2177,23 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
                 for (int bb = 0; bb < FB; bb++) {
                     const int b = b0 + bb, q = 8 * (b & 1), h = b >> 1;
                     L(xa)[q + (h & 7)] = na[bb];
+                    double t = (double)L(xa)[q + (h & 7)] * cf[0];
+                    for (int j = 1; j < 8; j++) t += (double)L(xa)[q + ((h - j) & 7)] * cf[j];
+                    ta[bb] = t;
+                }
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                for (int j = 0; j < 8; j++) cf[j] = enw_s[yb + 64 * j];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                for (int bb = 0; bb < FB; bb++) {
+                    const int b = b0 + bb, q = 8 * (b & 1), h = b >> 1;
                     L(xb)[q + (h & 7)] = nb[bb];
-                    double ta = (double)L(xa)[q + (h & 7)] * L(ca)[0];
-                    double tb = (double)L(xb)[q + (h & 7)] * L(cb)[0];
-                    for (int j = 1; j < 8; j++) {
-                        ta += (double)L(xa)[q + ((h - j) & 7)] * L(ca)[j];
-                        tb += (double)L(xb)[q + ((h - j) & 7)] * L(cb)[j];
-                    }
-                    yp[bb][c][i] = ta + tl_u2d((tl_d2u(tb) & keep) ^ flip);
+                    double t = (double)L(xb)[q + (h & 7)] * cf[0];
+                    for (int j = 1; j < 8; j++) t += (double)L(xb)[q + ((h - j) & 7)] * cf[j];
+                    yp[bb][c][i] = ta[bb] + tl_u2d((tl_d2u(t) & keep) ^ flip);
                 }
             }
             TL_LANES_END
@@ -2883,7 +2895,7 @@ TL_FN void tl_encode_stream(W &w, const TlBlockShared *TL_RESTRICT B, const TlLa
         tl_stage_pcm(w, pv, nch);
         const int xl = tl_stage_xpad(w, A, C, slot);
         tl_encode_frame<PSY>(w, T, B, C, A.psy2_tables ? &A.psy2_tables[C->psy2_tab] : nullptr, A.psy2_state ? &A.psy2_state[s] : nullptr,
-                             nullptr, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, none,
+                             nullptr, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, none, T->enwindow_s,
                              A.taps ? &A.taps[slot] : nullptr, A.stamps ? A.stamps + slot * 32 : nullptr);
         done++;
     }
@@ -2905,7 +2917,7 @@ TL_FN void tl_encode_stream(W &w, const TlBlockShared *TL_RESTRICT B, const TlLa
 // independent of each other: the filterbank's history is PCM (the previous input frame, or the stream state before frame 0),
 // the SMR comes from the psy kernel's record, and the one thing a frame owes its predecessor -- its ScF-CRC, which travels in
 // the frame before (toolame.c:527-542) -- is filed aside and put in place by tl_finish_stream.
-TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const TlLaunch &A, int s, int f)
+TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s, const TlLaunch &A, int s, int f)
 {
     const TlConfig *C = &A.configs[A.stream_cfg[s]];
     TlStreamState *st = &A.state[s];
@@ -2919,7 +2931,7 @@ TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const 
     fo.bytes = f + 1 < A.nframes ? A.out + (slot + (size_t)A.nstreams) * (size_t)A.out_stride : nullptr;     // waits in the next slot
     fo.words = f + 1 < A.nframes ? nullptr : A.newpend + (size_t)s * TL_MAX_FRAME_WORDS;
     fo.scfcrc = A.scfcrc + slot * 4;
-    tl_encode_frame<TL_PSY_EXT>(w, A.tables, B, C, nullptr, nullptr, &A.psy_out[slot], pv, st, xl, nullptr, false, fo,
+    tl_encode_frame<TL_PSY_EXT>(w, A.tables, B, C, nullptr, nullptr, &A.psy_out[slot], pv, st, xl, nullptr, false, fo, enw_s,
                                 A.taps ? &A.taps[slot] : nullptr, sp);
 }
 

@@ -101,21 +101,23 @@ __global__ void __launch_bounds__(64 * TL_PSY_WAVES) __attribute__((amdgpu_waves
 }
 
 // encode kernel of the split path: the tables it needs on dependent-load chains (TlBlockShared without the dB-sum table)
-struct TlMainShared { char bytes[sizeof(TlBlockShared) - offsetof(TlBlockShared, scalefactor)]; };
+struct TlMainShared { double enw_s[512]; char bytes[sizeof(TlBlockShared) - offsetof(TlBlockShared, scalefactor)]; };
 static_assert(offsetof(TlBlockShared, dbtable) == 0 && offsetof(TlBlockShared, scalefactor) == sizeof(double) * 1002, "dbtable leads TlBlockShared");
-static_assert(((sizeof(TlMainShared) + TL_WAVES_PER_BLOCK * sizeof(TlMainLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE) * 3 <= 128, "three encode workgroups per CU");
-__global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(TL_MAIN_WPE, TL_MAIN_WPE))) tl_main_kernel(TlLaunch A)
+#define TL_MAIN_WAVES (4 * TL_MAIN_WPE)       // one workgroup per CU: one copy of the tables
+static_assert((sizeof(TlMainShared) + TL_MAIN_WAVES * sizeof(TlMainLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "the encode workgroup fits a CU");
+__global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_waves_per_eu(TL_MAIN_WPE, TL_MAIN_WPE))) tl_main_kernel(TlLaunch A)
 {
     __shared__ TlMainShared sh;
-    __shared__ TlMainLds lds[TL_WAVES_PER_BLOCK];
+    __shared__ TlMainLds lds[TL_MAIN_WAVES];
     {
         const double *src = (const double *)&A.tables->shared.scalefactor[0];
-        double *dst = (double *)&sh;
-        for (int i = (int)threadIdx.x; i < (int)(sizeof(TlMainShared) / 8); i += 64 * TL_WAVES_PER_BLOCK) dst[i] = src[i];
+        double *dst = (double *)&sh.bytes[0];
+        for (int i = (int)threadIdx.x; i < (int)(sizeof(sh.bytes) / 8); i += 64 * TL_MAIN_WAVES) dst[i] = src[i];
+        for (int i = (int)threadIdx.x; i < 512; i += 64 * TL_MAIN_WAVES) sh.enw_s[i] = A.tables->enwindow_s[i];
     }
     __syncthreads();
     // the encode path never touches B->dbtable: a TlBlockShared pointer whose dbtable part lies before the copied block
-    const TlBlockShared *B = (const TlBlockShared *)((const char *)&sh - offsetof(TlBlockShared, scalefactor));
+    const TlBlockShared *B = (const TlBlockShared *)((const char *)&sh.bytes[0] - offsetof(TlBlockShared, scalefactor));
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nunits = A.nlist * A.nframes;
     for (;;) {
@@ -123,7 +125,7 @@ __global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK) __attribute__((amdgpu
         if (u >= nunits) break;
         const int f = u / A.nlist, k = u - f * A.nlist;
         const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
-        tl_main_unit(lds[wave], B, A, s, f);
+        tl_main_unit(lds[wave], B, sh.enw_s, A, s, f);
     }
 }
 
@@ -486,9 +488,9 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
             else hipLaunchKernelGGL(tl_psy_kernel<3>, dim3((unsigned)pb), dim3(64 * TL_PSY_WAVES), 0, st, A);
             HIPCHK(hipGetLastError());
             if (!b->n_list[0] && !b->n_list[2] && !(b->n_list[1] && b->n_list[3])) { HIPCHK(hipEventRecord(b->ev_mid, st)); b->have_mid = true; }
-            long mb = (units + TL_WAVES_PER_BLOCK - 1) / TL_WAVES_PER_BLOCK;
-            if (mb > (long)TL_MAIN_WPE * b->num_cu) mb = (long)TL_MAIN_WPE * b->num_cu;
-            hipLaunchKernelGGL(tl_main_kernel, dim3((unsigned)mb), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);
+            long mb = (units + TL_MAIN_WAVES - 1) / TL_MAIN_WAVES;
+            if (mb > b->num_cu) mb = b->num_cu;
+            hipLaunchKernelGGL(tl_main_kernel, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(tl_finish_kernel, dim3((unsigned)((b->n_list[p] + 3) / 4)), dim3(256), 0, st, A);
         } else if (p == 0) hipLaunchKernelGGL(tl_encode_kernel<0>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);

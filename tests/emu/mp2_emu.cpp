@@ -86,7 +86,7 @@ int emu_encode(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, co
             else if (m == 3) tl_psy_unit<3>(wp, e->tables.shared.dbtable, A, s, f);
         }
     for (int s = 0; s < A.nstreams; s++)
-        if (split(s)) for (int f = nframes - 1; f >= 0; f--) tl_main_unit(wm, &e->tables.shared, A, s, f);
+        if (split(s)) for (int f = nframes - 1; f >= 0; f--) tl_main_unit(wm, &e->tables.shared, e->tables.enwindow_s, A, s, f);
     for (int s = 0; s < A.nstreams; s++)
         if (split(s)) tl_finish_stream(A, s);
         else if (e->configs[e->stream_cfg[s]].psy == 0) tl_encode_stream<0>(w, &e->tables.shared, A, s);
