@@ -2826,7 +2826,12 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
     (&po->a[0][0])[lane] = 0.0; (&po->m[0][0])[lane] = 0.0;           // entries the model leaves alone (mono: channel 1; psy 1: sb >= sblimit)
     if (lane == 0) w.po = po;
     TL_LANES_END
+#ifdef TL_NO_PSY_STAMPS
+    long long *sp = nullptr;
+#else
     long long *sp = A.stamps ? A.stamps + slot * 32 : nullptr;
+#endif
+    TL_STAMP(sp, 15);                                                 // unit begin (slots 8..14 / 16..22: the channels' stages, 24..30: FHT passes)
     if constexpr (PSY == 1) {
         if (C->nch == 2) tl_psy1_stereo(w, T, db, C, pv, sp);
         else tl_psy1(w, T, db, C, pv, 0, sp ? sp + 8 : nullptr);
@@ -2834,6 +2839,7 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
         if (C->nch == 2) tl_psy3_stereo(w, T, db, C, pv, sp);
         else tl_psy3(w, T, db, C, pv, 0, sp ? sp + 8 : nullptr);
     }
+    TL_STAMP(sp, 23);                                                 // unit end
 }
 
 // [history | frame] -> LDS in 8-byte pieces, 120 + 288 per channel.  All of a lane's loads are issued before the first LDS
@@ -2923,7 +2929,11 @@ TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const 
     TlStreamState *st = &A.state[s];
     const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
     const TlPcmView pv = tl_pcm_view(A, st, s, f);
+#ifdef TL_NO_MAIN_STAMPS
+    long long *sp = nullptr;
+#else
     long long *sp = A.stamps ? A.stamps + slot * 32 : nullptr;
+#endif
     TL_STAMP(sp, 31);
     tl_stage_pcm(w, pv, C->nch);
     const int xl = tl_stage_xpad(w, A, C, slot);

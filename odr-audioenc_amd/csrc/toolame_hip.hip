@@ -61,12 +61,15 @@ __global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK, 2) tl_encode_kernel(T
 }
 
 // psy kernel: TL_PSY_WAVES waves per workgroup share one copy of the dB-sum table (8 KB); two workgroups per CU.
-// next unit of a persistent kernel's work list (device-scope atomic: the counter is shared by all XCDs)
+// Next unit of a persistent kernel's work list (device-scope atomic: the counter is shared by all XCDs).  Every lane adds 1
+// -- hipcc folds that into ONE atomic of +64 per wave (its wave-level atomic optimiser) -- and the unit is the wave's base
+// / 64.  No `if (lane == 0)` in the source: with one, LLVM threaded the branch together with an equal test at the end of
+// the previous unit (the diagnostic stamps) into a loop that some lanes never left.
 static __device__ __forceinline__ int tl_next_unit(int32_t *counter)
 {
-    int u = 0;
-    if ((threadIdx.x & 63u) == 0) u = atomicAdd(counter, 1);
-    return __builtin_amdgcn_readfirstlane(u);
+    __builtin_amdgcn_wave_barrier();
+    const int u = atomicAdd(counter, 1);
+    return __builtin_amdgcn_readfirstlane(u) >> 6;
 }
 
 // psy kernel: the twelve waves a CU holds at 168 VGPRs are ONE workgroup sharing one copy of the dB-sum table (8 KB).  LDS is

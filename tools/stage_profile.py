@@ -23,9 +23,13 @@ L.tlb_encode_host_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p
 st = np.zeros((F, S, 32), dtype=np.int64)
 assert L.tlb_encode_host_stamps(b.h, np.ascontiguousarray(pcm).ctypes.data, F, st.ctypes.data) == 0
 st = st[1:]                                   # skip the first (cold) frame
-names = ["filterbank", "scalefactors", "psy", "sfpattern+bitalloc", "quantise+pack", "crc+scfcrc+pad", "emit"]
+names = ["filterbank", "scalefactors", "psy" if psy in (0, 2, 4) else "smr from the psy kernel's record", "sfpattern+bitalloc", "quantise+pack", "crc+scfcrc+pad", "emit"]
 tot = (st[..., 7] - st[..., 0]).mean()
-print(f"psy {psy} mode {mode} {S} streams: {tot:.0f} cycles/frame/wave")
+print(f"psy {psy} mode {mode} {S} streams: {tot:.0f} s_memtime ticks/frame/wave in the {'fused' if psy in (0, 2, 4) else 'encode'} kernel")
+if psy in (1, 3):
+    ptot = (st[..., 23] - st[..., 15]).mean()
+    print(f"psy kernel: {ptot:.0f} ticks/unit/wave; shares below are of encode + psy = {tot + ptot:.0f}")
+    tot = tot + ptot
 for i, n in enumerate(names):
     d = (st[..., i + 1] - st[..., i]).mean()
     print(f"  {n:22s} {d:10.0f}  {100 * d / tot:5.1f}%")
