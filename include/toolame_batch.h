@@ -127,12 +127,24 @@ int tlb_ingest_host(tlb_batch *b, const int16_t *interleaved, int nframes, int16
 int tlb_silence_device(tlb_batch *b, const int16_t *d_peaks, int nframes, uint32_t *d_silence_ms, void *hip_stream);
 int tlb_silence_host(tlb_batch *b, const int16_t *peaks, int nframes, uint32_t *silence_ms);
 
-/* Egress framing of the step after the path (ZeroMQ part): one ODR-DabMux ZMQ message per frame,
+/* Egress framing of the step after the path.
+ *
+ * UNITS.  ODR-AudioEnc does not send MP2 frames: it cuts the encoder's byte stream into pieces of 3 * bitrate bytes (24 ms)
+ * and calls send_frame() once per piece (src/odr-audioenc.cpp:1211-1219, "ODR-DabMux expects frames of length 3*bitrate").
+ * At 48 kHz a frame is one unit; an MPEG-2 LSF frame is two (24 kHz) or three (16 kHz).  Every egress buffer below is laid
+ * out by SLOT v = frame * tlb_egress_max_units_per_frame() + unit: [nframes * max_upf][nstreams][...]; a stream with fewer
+ * units per frame than the batch's maximum leaves its surplus slots absent (length / datasize 0).  For an all-48-kHz batch
+ * max_upf is 1 and a slot is a frame.  32 kHz (1.5 units per frame) is not a DAB rate (odr-audioenc.cpp:560-563); a batch
+ * that contains it has max_upf 0 and the egress calls return TLB_ERR_SAMPLERATE. */
+int tlb_egress_unit_bytes(const tlb_batch *b, int stream);          /* 3 * kbps */
+int tlb_egress_units_per_frame(const tlb_batch *b, int stream);     /* 1, 2, 3; 0 = not a whole number */
+int tlb_egress_max_units_per_frame(const tlb_batch *b);
+/* ZeroMQ part: one ODR-DabMux ZMQ message per unit,
  * `struct zmq_frame_header_t` (src/Outputs.h:76-89: u16 version = 1, u16 encoder = ZMQ_ENCODER_MPEG_L2 = 2, u32 datasize,
- * i16 audiolevel_left, i16 audiolevel_right, packed, little-endian) followed by the frame (Outputs.cpp:101-138).
+ * i16 audiolevel_left, i16 audiolevel_right, packed, little-endian) followed by the unit (Outputs.cpp:101-138).
  *   d_frames uint8 [nframes][nstreams][tlb_out_stride()]   (tlb_encode_device output)
- *   d_peaks  int16 [nframes][nstreams][2] or NULL (levels 0)  (tlb_ingest_device output)
- *   d_msgs   uint8 [nframes][nstreams][tlb_zmq_msg_stride()]; message length of a stream = 12 + tlb_frame_bytes()
+ *   d_peaks  int16 [nframes][nstreams][2] or NULL (levels 0)  (tlb_ingest_device output; a frame's levels go with all its units)
+ *   d_msgs   uint8 [nframes * max_upf][nstreams][tlb_zmq_msg_stride()]; message length of a stream = 12 + tlb_egress_unit_bytes()
  * Sockets and CURVE stay with the caller (out of scope). */
 int tlb_zmq_msg_stride(const tlb_batch *b);
 int tlb_zmq_frame_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_peaks, int nframes, uint8_t *d_msgs, void *hip_stream);
@@ -148,7 +160,8 @@ int tlb_zmq_frame_host(tlb_batch *b, const uint8_t *frames, const int16_t *peaks
  *   d_frames  uint8 [nframes][nstreams][tlb_out_stride()]       (tlb_encode_device output)
  *   d_levels  int16 [nframes][nstreams][2] or NULL (levels 0)   (tlb_ingest_device peaks)
  *   d_state   tlb_edi_state [nstreams]
- *   d_pkts    uint8 [nframes][nstreams][tlb_edi_af_stride()], d_pkt_len int32 [nframes][nstreams] = bytes used
+ *   d_pkts    uint8 [nframes * max_upf][nstreams][tlb_edi_af_stride()], d_pkt_len int32 [nframes * max_upf][nstreams] = bytes used
+ *             (slot order, see UNITS above: one AF packet per 24-ms unit, each advancing timestamp, DLFC and SEQ; 0 = absent slot)
  * `version` is host memory (<= 64 bytes).  The PFT layer for UDP destinations is tlb_edi_pft_* below; sockets stay with the caller. */
 typedef struct tlb_edi_state {
     int64_t edi_time, send_version_at_time;
@@ -170,7 +183,8 @@ int tlb_edi_af_host(tlb_batch *b, const uint8_t *frames, const int16_t *levels, 
  * fragments, PF header ("PF", Pseq, Findex, Fcount, FEC|Addr|Plen, [RSk, RSz], [Source, Dest], CRC-16) + payload.
  * fec = 0: fragmentation only (1400-byte slices), as the reference's default configuration (EDIConfig.h:69-70).
  *   d_af      uint8 [nframes][nstreams][af_stride], d_af_len int32 [nframes][nstreams]     (tlb_edi_af_device output)
- *   d_pseq    uint16 [nstreams]: PFT::m_pseq per stream, advanced by nframes
+ *   d_pseq    uint16 [nstreams]: PFT::m_pseq per stream, advanced by the number of packets present (d_af_len > 0); `nframes` here
+ *             counts packet slots (nframes * max_upf of the AF call)
  *   d_frags   uint8 [nframes][nstreams][max_frags][frag_stride], d_frag_len int32 [nframes][nstreams][max_frags],
  *   d_nfrag   int32 [nframes][nstreams];  max_frags / frag_stride at least what tlb_edi_pft_shape() reports for this af_stride
  *   (every AF packet length up to af_stride is covered; at most 10 chunks per packet, i.e. chunk_len >= af_stride / 10)

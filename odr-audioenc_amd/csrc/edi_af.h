@@ -8,8 +8,15 @@
 //
 // Written in the same lane-SPMD style as mp2_wave.h (include it first): compiled by hipcc for gfx950 and, with
 // -DTL_EMULATE, as a lane loop for the CPU tests.  One wavefront builds one packet; the sender state (timestamp,
-// sequence and frame counters, version cadence) advances per frame, which is a few integer operations, so the wave of
-// frame f simply replays f+1 advances from the state at the start of the call.
+// sequence and frame counters, version cadence) advances per packet, which is a few integer operations, so the wave of
+// packet e simply replays e+1 advances from the state at the start of the call.
+//
+// UNITS.  What ODR-AudioEnc sends is not the MP2 frame but pieces of 3 * bitrate bytes = 24 ms of the byte stream
+// (src/odr-audioenc.cpp:1211-1219: "ODR-DabMux expects frames of length 3*bitrate"), each through send_frame() with its own
+// +24 ms timestamp, DLFC and SEQ (src/Outputs.cpp:194-261).  At 48 kHz a frame IS one unit; an MPEG-2 LSF frame carries two
+// (24 kHz, 48 ms) or three (16 kHz, 72 ms).  Packet slot v = f * max_upf + u holds unit u of frame f; a stream with fewer
+// units per frame than the batch's maximum leaves its surplus slots absent (length 0), and only present units advance the
+// sender state.
 #pragma once
 #include <stdint.h>
 #include <string.h>
@@ -35,9 +42,10 @@ struct TlEdiArgs {
     const uint8_t *version;          // ODRv version string (not terminated)
     const uint16_t *xpow8;           // x^(8k) mod (x^16+x^12+x^5+1), k = 0..TL_EDI_XPOW-1
     const int32_t *frame_bytes;      // [nstreams]
-    uint8_t *pkts;                   // [nframes][nstreams][pkt_stride]
-    int32_t *pkt_len;                // [nframes][nstreams]
-    int32_t nstreams, nframes, out_stride, pkt_stride, version_len;
+    const int32_t *unit_bytes;       // [nstreams] 3 * kbps: what one send_frame() carries (divides frame_bytes)
+    uint8_t *pkts;                   // [nframes * max_upf][nstreams][pkt_stride]
+    int32_t *pkt_len;                // [nframes * max_upf][nstreams]; 0 = absent slot
+    int32_t nstreams, nframes, out_stride, pkt_stride, version_len, max_upf;
 };
 #define TL_EDI_XPOW 2048             // longest AF packet: 10 + 16 + 18 + 11 + 1728 + 12 + 12 + version < 2048 bytes
 #define TL_EDI_MAX_VERSION 64
@@ -112,16 +120,25 @@ TL_FN uint8_t tl_edi_byte(const TlEdiFrame &F, uint32_t pos)
     }
 }
 
-// AF packet of frame f (0-based within this call) of stream s.
-TL_FN void tl_edi_af_packet(const TlEdiArgs &A, int s, int f)
+// AF packet of slot v (0-based within this call: unit v % max_upf of frame v / max_upf) of stream s.
+TL_FN void tl_edi_af_packet(const TlEdiArgs &A, int s, int v)
 {
     TlEdiState st = A.state[s];
-    const uint32_t n = (uint32_t)A.frame_bytes[s];
+    const uint32_t n = (uint32_t)A.unit_bytes[s];
+    const int upf = A.frame_bytes[s] / (int)n, f = v / A.max_upf, u = v - f * A.max_upf;
+    const size_t pslot = (size_t)v * (size_t)A.nstreams + (size_t)s;
+    if (u >= upf) {                                                   // this stream has no unit here
+        TL_LANES_BEGIN
+        if (lane == 0) A.pkt_len[pslot] = 0;
+        TL_LANES_END
+        return;
+    }
+    const int e = f * upf + u;                                        // units of this stream before this one, in this call
     {
         const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
-        // ---- sender state, Outputs.cpp:214-257; frames 0..f-1 only advance it ----
+        // ---- sender state, Outputs.cpp:214-257; units 0..e-1 only advance it ----
         uint16_t dlfc = 0, seq = 0; uint8_t with_version = 0;
-        for (int k = 0; k <= f; k++) {
+        for (int k = 0; k <= e; k++) {
             st.timestamp += 24u << 14;                               // 24 ms at timestamp level 2
             if (st.timestamp > 0xf9FFffu) { st.timestamp -= 0xfa0000u; st.edi_time += 1; st.num_seconds_sent++; }
             dlfc = st.dlfc; st.dlfc = (uint16_t)((st.dlfc + 1) % 5000);
@@ -130,7 +147,7 @@ TL_FN void tl_edi_af_packet(const TlEdiArgs &A, int s, int f)
             seq = st.seq; st.seq = (uint16_t)(st.seq + 1);
         }
         TlEdiFrame F;
-        F.payload = A.frames + slot * (size_t)A.out_stride;
+        F.payload = A.frames + slot * (size_t)A.out_stride + (size_t)u * n;
         F.version = A.version; F.vlen = (uint32_t)A.version_len; F.n = n;
         F.atstf = st.tist ? 1 : 0;
         F.utco = (uint8_t)(st.tai_utc_offset - 32);                  // TagDSTI::set_edi_time, TagItems.cpp:265-274
@@ -144,7 +161,7 @@ TL_FN void tl_edi_af_packet(const TlEdiArgs &A, int s, int f)
         F.taglen = 16 + (10 + (F.atstf ? 8 : 0)) + (11 + n) + 12 + (F.with_version ? 12 + F.vlen : 0);
         F.pay_lo = 10 + 16 + (10 + (F.atstf ? 8 : 0)) + 11;
         const uint32_t body = 10 + F.taglen;                         // bytes covered by the CRC
-        uint8_t *pkt = A.pkts + slot * (size_t)A.pkt_stride;
+        uint8_t *pkt = A.pkts + pslot * (size_t)A.pkt_stride;
 
         // ---- bytes + CRC.  Lane l owns bytes [l*C, l*C+C), C a multiple of 4 (<= 32): it builds them once as up to eight
         //      words and folds them into its own CRC remainder (lane 0 carries the 0xffff preset).  The register update is
@@ -203,10 +220,10 @@ TL_FN void tl_edi_af_packet(const TlEdiArgs &A, int s, int f)
                 *(uint32_t *)(pkt + q) = word;                        // pkt_stride and C are multiples of 4
             }
         }
-        if (lane == 0) A.pkt_len[slot] = (int32_t)(body + 2);
+        if (lane == 0) A.pkt_len[pslot] = (int32_t)(body + 2);
         TL_LANES_END
     }
-    if (f == A.nframes - 1) {
+    if (f == A.nframes - 1 && u == upf - 1) {                         // the stream's last unit of the call
         TL_LANES_BEGIN
         if (lane == 0) A.state_out[s] = st;
         TL_LANES_END

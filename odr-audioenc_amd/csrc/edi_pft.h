@@ -49,15 +49,32 @@ TL_FN void tl_edi_pft_packet(const TlPftArgs &A, const TlPftTables &R, int s, in
     const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
     const uint8_t *gaf = A.af + slot * (size_t)A.af_stride;
     uint32_t l = (uint32_t)A.af_len[slot];
-    // an AF packet of no bytes, or of more than its slot / the staging buffer can hold, produces no fragments (the packet
-    // sequence number still advances): nothing below divides by a zero chunk count or copies past W.af
+    // Pseq counts the AF packets that exist.  A slot of length <= 0 is an ABSENT packet (tl_edi_af_packet leaves the surplus
+    // unit slots of a stream that way): no fragments, no sequence number.  A packet longer than its slot / the staging
+    // buffer is dropped (no fragments) but counted.  Nothing below divides by a zero chunk count or copies past W.af.
+    PV(int, cnt);
+    TL_LANES_BEGIN
+    int c_ = 0;
+    for (int v = lane; v < A.nframes; v += 64) c_ += (v < f && A.af_len[(size_t)v * (size_t)A.nstreams + (size_t)s] > 0) ? 1 : 0;
+    L(cnt) = c_;
+    TL_LANES_END
+    const int before = TL_WAVE_SUM_I32(cnt);                         // packets of this stream before this one, in this call
+    if (f == A.nframes - 1) {
+        PV(int, cnt2);
+        TL_LANES_BEGIN
+        int c_ = 0;
+        for (int v = lane; v < A.nframes; v += 64) c_ += A.af_len[(size_t)v * (size_t)A.nstreams + (size_t)s] > 0 ? 1 : 0;
+        L(cnt2) = c_;
+        TL_LANES_END
+        const int total = TL_WAVE_SUM_I32(cnt2);
+        TL_LANES_BEGIN
+        if (lane == 0) A.pseq_out[s] = (uint16_t)(A.pseq[s] + total);
+        TL_LANES_END
+    }
     const uint32_t lmax = (uint32_t)A.af_stride < (uint32_t)sizeof(W.af) ? (uint32_t)A.af_stride : (uint32_t)sizeof(W.af);
     if ((int32_t)l <= 0 || l > lmax) {
         TL_LANES_BEGIN
-        if (lane == 0) {
-            A.nfrag[slot] = 0;
-            if (f == A.nframes - 1) A.pseq_out[s] = (uint16_t)(A.pseq[s] + A.nframes);
-        }
+        if (lane == 0) A.nfrag[slot] = 0;
         TL_LANES_END
         return;
     }
@@ -103,7 +120,7 @@ TL_FN void tl_edi_pft_packet(const TlPftArgs &A, const TlPftTables &R, int s, in
     }
     uint8_t *out = A.frags + slot * (size_t)A.max_frags * (size_t)A.frag_stride;
     const uint32_t hdr = 12 + (rs ? 2 : 0) + (A.transport ? 4 : 0) + 2;
-    const uint32_t pseq = (uint32_t)(uint16_t)(A.pseq[s] + f);
+    const uint32_t pseq = (uint32_t)(uint16_t)(A.pseq[s] + before);
     // ---- payloads ----
     TL_LANES_BEGIN
     for (uint32_t idx = (uint32_t)lane; idx < nfr * fsz; idx += 64) {
@@ -151,9 +168,6 @@ TL_FN void tl_edi_pft_packet(const TlPftArgs &A, const TlPftTables &R, int s, in
         o[n] = (uint8_t)(r >> 8); o[n + 1] = (uint8_t)r;
         A.frag_len[slot * (size_t)A.max_frags + i] = (int32_t)(hdr + plen_bytes);
     }
-    if (lane == 0) {
-        A.nfrag[slot] = (int32_t)nfr;
-        if (f == A.nframes - 1) A.pseq_out[s] = (uint16_t)(A.pseq[s] + A.nframes);
-    }
+    if (lane == 0) A.nfrag[slot] = (int32_t)nfr;
     TL_LANES_END
 }

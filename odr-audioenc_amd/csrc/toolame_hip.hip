@@ -211,32 +211,37 @@ __global__ void tl_silence_kernel(const int16_t *__restrict__ peaks, uint32_t *_
 }
 
 // ZeroMQ wire format of the step after the path (src/Outputs.h:76-99, Outputs.cpp:101-138):
-// packed header {u16 version=1, u16 encoder=2 (MPEG L2), u32 datasize, i16 level_left, i16 level_right} + frame bytes.
-// msgs [nslots][msg_stride]; one block per slot.
+// packed header {u16 version=1, u16 encoder=2 (MPEG L2), u32 datasize, i16 level_left, i16 level_right} + the unit's bytes.
+// One message per UNIT of 3 * bitrate bytes (src/odr-audioenc.cpp:1211-1219): message slot v = f * max_upf + u carries bytes
+// [u * unit, (u + 1) * unit) of frame f; a stream with fewer units per frame leaves its surplus slots empty (datasize 0 in an
+// all-zero header).  msgs [nframes * max_upf][nstreams][msg_stride]; one block per slot.
 __global__ void tl_zmq_frame_kernel(const uint8_t *__restrict__ frames, const int16_t *__restrict__ peaks, uint8_t *__restrict__ msgs,
-                                    const TlConfig *configs, const int32_t *stream_cfg, int nstreams, int out_stride, int msg_stride)
+                                    const TlConfig *configs, const int32_t *stream_cfg, int nstreams, int out_stride, int msg_stride, int max_upf)
 {
-    const size_t slot = blockIdx.x;
-    const int s = (int)(slot % (size_t)nstreams);
-    const int n = configs[stream_cfg[s]].frame_bytes;
-    uint8_t *m = msgs + slot * (size_t)msg_stride;
+    const size_t pslot = blockIdx.x;
+    const int s = (int)(pslot % (size_t)nstreams), v = (int)(pslot / (size_t)nstreams), f = v / max_upf, u = v - f * max_upf;
+    const size_t slot = (size_t)f * (size_t)nstreams + (size_t)s;
+    const TlConfig &c = configs[stream_cfg[s]];
+    const int n = 3 * c.kbps, upf = c.frame_bytes / n;
+    uint8_t *m = msgs + pslot * (size_t)msg_stride;
+    if (u >= upf) { if (threadIdx.x < 3) ((uint32_t *)m)[threadIdx.x] = 0u; return; }
     if (threadIdx.x < 3) {
         const int pl = peaks ? peaks[slot * 2] : 0, pr = peaks ? peaks[slot * 2 + 1] : 0;
         const uint32_t w = threadIdx.x == 0 ? (1u | (2u << 16)) : threadIdx.x == 1 ? (uint32_t)n
                                             : ((uint32_t)(uint16_t)pl | ((uint32_t)(uint16_t)pr << 16));
         ((uint32_t *)m)[threadIdx.x] = w;
     }
-    const uint32_t *src = (const uint32_t *)(frames + slot * (size_t)out_stride);
+    const uint32_t *src = (const uint32_t *)(frames + slot * (size_t)out_stride + (size_t)u * n);      // unit sizes are multiples of 4
     for (int i = (int)threadIdx.x; i < (n >> 2); i += (int)blockDim.x) ((uint32_t *)m)[3 + i] = src[i];
 }
 
 // EDI AF packets of the step after the path (EDI part; csrc/edi_af.h): one wavefront per packet,
-// blockIdx.y = frame of the call, four streams per workgroup.
+// blockIdx.y = packet slot (frame * max_upf + unit) of the call, four streams per workgroup.
 __global__ void __launch_bounds__(256) tl_edi_af_kernel(TlEdiArgs A)
 {
     const int s = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (s >= A.nstreams) return;
-    tl_edi_af_packet(A, s, (int)blockIdx.y);
+    tl_edi_af_packet(A, s, (int)blockIdx.y);      // blockIdx.y = packet slot
 }
 
 // EDI PFT layer (csrc/edi_pft.h): one wavefront per AF packet, blockIdx.y = frame of the call.  The Reed-Solomon tables
@@ -285,7 +290,8 @@ struct tlb_batch {
     TlPsy2Tables *d_psy2_tables = nullptr;     // 4 slots (tl_psy2_slot), only when a stream uses psy 2
     TlPsy2State *d_psy2_state = nullptr;
     uint8_t *d_edi_version = nullptr;            // EDI: ODRv string and per-stream frame sizes (allocated on first use)
-    int32_t *d_frame_bytes = nullptr;
+    int32_t *d_frame_bytes = nullptr, *d_unit_bytes = nullptr;
+    int max_upf = 1;                             // egress units (3 * kbps bytes) per frame: 1 at 48 kHz, 2 at 24 kHz, 3 at 16 kHz; 0 = a stream's frames are no whole number of units
     TlEdiState *d_edi_state_tmp = nullptr;
     uint16_t *d_pseq_tmp = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;   // ev_mid: between the psy kernel and the encode kernel (models 1/3)
@@ -340,6 +346,7 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_gain) (void)hipFree(b->d_gain);
     if (b->d_edi_version) (void)hipFree(b->d_edi_version);
     if (b->d_frame_bytes) (void)hipFree(b->d_frame_bytes);
+    if (b->d_unit_bytes) (void)hipFree(b->d_unit_bytes);
     if (b->d_edi_state_tmp) (void)hipFree(b->d_edi_state_tmp);
     if (b->d_pseq_tmp) (void)hipFree(b->d_pseq_tmp);
     for (int p = 0; p < 4; p++) if (b->d_list[p]) (void)hipFree(b->d_list[p]);
@@ -378,6 +385,11 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
         }
         b->h_stream_cfg[s] = found;
         if (b->h_configs[found].frame_bytes > b->out_stride) b->out_stride = b->h_configs[found].frame_bytes;
+        {
+            const int unit = 3 * b->h_configs[found].kbps, fb = b->h_configs[found].frame_bytes;
+            if (fb % unit) b->max_upf = 0;                          // 32 kHz: 1.5 units per frame -- not a DAB rate (odr-audioenc.cpp:560-563)
+            else if (b->max_upf && fb / unit > b->max_upf) b->max_upf = fb / unit;
+        }
     }
     HIPCHK(hipSetDevice(device));
     { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) b->num_cu = n; }
@@ -642,13 +654,22 @@ int tlb_silence_host(tlb_batch *b, const int16_t *peaks, int nframes, uint32_t *
 }
 
 int tlb_zmq_msg_stride(const tlb_batch *b) { return b ? 12 + b->out_stride : 0; }
+int tlb_egress_unit_bytes(const tlb_batch *b, int s) { return (b && s >= 0 && s < b->nstreams) ? 3 * b->h_configs[b->h_stream_cfg[s]].kbps : 0; }
+int tlb_egress_units_per_frame(const tlb_batch *b, int s)
+{
+    if (!b || s < 0 || s >= b->nstreams) return 0;
+    const TlConfig &c = b->h_configs[b->h_stream_cfg[s]];
+    return c.frame_bytes % (3 * c.kbps) ? 0 : c.frame_bytes / (3 * c.kbps);
+}
+int tlb_egress_max_units_per_frame(const tlb_batch *b) { return b ? b->max_upf : 0; }
 
 int tlb_zmq_frame_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_peaks, int nframes, uint8_t *d_msgs, void *hip_stream)
 {
     if (!b || !d_frames || !d_msgs || nframes <= 0) return TLB_ERR_ARG;
+    if (!b->max_upf) return TLB_ERR_SAMPLERATE;
     HIPCHK(hipSetDevice(b->device));
-    hipLaunchKernelGGL(tl_zmq_frame_kernel, dim3((unsigned)((size_t)nframes * (size_t)b->nstreams)), dim3(128), 0, (hipStream_t)hip_stream,
-                       d_frames, d_peaks, d_msgs, b->d_configs, b->d_stream_cfg, b->nstreams, b->out_stride, 12 + b->out_stride);
+    hipLaunchKernelGGL(tl_zmq_frame_kernel, dim3((unsigned)((size_t)nframes * (size_t)b->max_upf * (size_t)b->nstreams)), dim3(128), 0, (hipStream_t)hip_stream,
+                       d_frames, d_peaks, d_msgs, b->d_configs, b->d_stream_cfg, b->nstreams, b->out_stride, 12 + b->out_stride, b->max_upf);
     HIPCHK(hipGetLastError());
     return TLB_OK;
 }
@@ -657,17 +678,18 @@ int tlb_zmq_frame_host(tlb_batch *b, const uint8_t *frames, const int16_t *peaks
 {
     DevFree guard_;
     if (!b || !frames || !msgs || nframes <= 0) return TLB_ERR_ARG;
+    if (!b->max_upf) return TLB_ERR_SAMPLERATE;
     HIPCHK(hipSetDevice(b->device));
-    const size_t slots = (size_t)nframes * (size_t)b->nstreams, ms = 12 + (size_t)b->out_stride;
+    const size_t slots = (size_t)nframes * (size_t)b->nstreams, ms = 12 + (size_t)b->out_stride, pslots = slots * (size_t)b->max_upf;
     uint8_t *d_f = nullptr, *d_m = nullptr; int16_t *d_p = nullptr;
     DEVALLOC(d_f, slots * (size_t)b->out_stride);
-    DEVALLOC(d_m, slots * ms);
-    HIPCHK(hipMemset(d_m, 0, slots * ms));
+    DEVALLOC(d_m, pslots * ms);
+    HIPCHK(hipMemset(d_m, 0, pslots * ms));
     HIPCHK(hipMemcpy(d_f, frames, slots * (size_t)b->out_stride, hipMemcpyHostToDevice));
     if (peaks) { DEVALLOC(d_p, slots * 4); HIPCHK(hipMemcpy(d_p, peaks, slots * 4, hipMemcpyHostToDevice)); }
     int rc = tlb_zmq_frame_device(b, d_f, d_p, nframes, d_m, nullptr);
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(msgs, d_m, slots * ms, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(msgs, d_m, pslots * ms, hipMemcpyDeviceToHost));
 
     return rc;
 }
@@ -696,29 +718,32 @@ int tlb_edi_af_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_le
                       const char *version, int version_len, uint8_t *d_pkts, int32_t *d_pkt_len, void *hip_stream)
 {
     if (!b || !d_frames || !d_state || !d_pkts || !d_pkt_len || nframes <= 0 || nframes > 65535 || version_len < 0 || version_len > TL_EDI_MAX_VERSION ||
-        (version_len && !version)) return TLB_ERR_ARG;
+        (version_len && !version) || (long)nframes * (b->max_upf ? b->max_upf : 1) > 65535) return TLB_ERR_ARG;
+    if (!b->max_upf) return TLB_ERR_SAMPLERATE;
     HIPCHK(hipSetDevice(b->device));
     hipStream_t st = (hipStream_t)hip_stream;
     if (!b->d_edi_version) {
         // all three buffers or none: a failure half way must not leave the batch looking initialised
         DevFree guard_;
-        uint8_t *d_v = nullptr; int32_t *d_fb = nullptr; TlEdiState *d_st = nullptr;
+        uint8_t *d_v = nullptr; int32_t *d_fb = nullptr, *d_ub = nullptr; TlEdiState *d_st = nullptr;
         DEVALLOC(d_v, TL_EDI_MAX_VERSION);
         DEVALLOC(d_fb, sizeof(int32_t) * (size_t)b->nstreams);
+        DEVALLOC(d_ub, sizeof(int32_t) * (size_t)b->nstreams);
         DEVALLOC(d_st, sizeof(TlEdiState) * (size_t)b->nstreams);
-        std::vector<int32_t> fb((size_t)b->nstreams);
-        for (int s = 0; s < b->nstreams; s++) fb[(size_t)s] = b->h_configs[b->h_stream_cfg[s]].frame_bytes;
+        std::vector<int32_t> fb((size_t)b->nstreams), ub((size_t)b->nstreams);
+        for (int s = 0; s < b->nstreams; s++) { fb[(size_t)s] = b->h_configs[b->h_stream_cfg[s]].frame_bytes; ub[(size_t)s] = 3 * b->h_configs[b->h_stream_cfg[s]].kbps; }
         HIPCHK(hipMemcpy(d_fb, fb.data(), sizeof(int32_t) * fb.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_ub, ub.data(), sizeof(int32_t) * ub.size(), hipMemcpyHostToDevice));
         guard_.v.clear();
-        b->d_edi_version = d_v; b->d_frame_bytes = d_fb; b->d_edi_state_tmp = d_st;
+        b->d_edi_version = d_v; b->d_frame_bytes = d_fb; b->d_unit_bytes = d_ub; b->d_edi_state_tmp = d_st;
     }
     if (version_len) HIPCHK(hipMemcpyAsync(b->d_edi_version, version, (size_t)version_len, hipMemcpyHostToDevice, st));
     TlEdiArgs A;
     A.frames = d_frames; A.levels = d_levels; A.state = (const TlEdiState *)d_state; A.state_out = b->d_edi_state_tmp; A.version = b->d_edi_version;
-    A.xpow8 = b->d_tables->edi_xpow8; A.frame_bytes = b->d_frame_bytes; A.pkts = d_pkts; A.pkt_len = d_pkt_len;
-    A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride;
+    A.xpow8 = b->d_tables->edi_xpow8; A.frame_bytes = b->d_frame_bytes; A.unit_bytes = b->d_unit_bytes; A.pkts = d_pkts; A.pkt_len = d_pkt_len;
+    A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride; A.max_upf = b->max_upf;
     A.pkt_stride = tlb_edi_af_stride(b, version_len); A.version_len = version_len;
-    hipLaunchKernelGGL(tl_edi_af_kernel, dim3((unsigned)((b->nstreams + 3) / 4), (unsigned)nframes), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(tl_edi_af_kernel, dim3((unsigned)((b->nstreams + 3) / 4), (unsigned)(nframes * b->max_upf)), dim3(256), 0, st, A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(d_state, b->d_edi_state_tmp, sizeof(TlEdiState) * (size_t)b->nstreams, hipMemcpyDeviceToDevice, st));
     return TLB_OK;
@@ -731,21 +756,22 @@ int tlb_edi_af_host(tlb_batch *b, const uint8_t *frames, const int16_t *levels, 
     if (!b || !frames || !state || !pkts || !pkt_len || nframes <= 0) return TLB_ERR_ARG;
     const int stride = tlb_edi_af_stride(b, version_len);
     if (!stride) return TLB_ERR_ARG;
+    if (!b->max_upf) return TLB_ERR_SAMPLERATE;
     HIPCHK(hipSetDevice(b->device));
-    const size_t slots = (size_t)nframes * (size_t)b->nstreams;
+    const size_t slots = (size_t)nframes * (size_t)b->nstreams, pslots = slots * (size_t)b->max_upf;
     uint8_t *d_f = nullptr, *d_p = nullptr; int16_t *d_l = nullptr; tlb_edi_state *d_s = nullptr; int32_t *d_n = nullptr;
     DEVALLOC(d_f, slots * (size_t)b->out_stride);
-    DEVALLOC(d_p, slots * (size_t)stride);
+    DEVALLOC(d_p, pslots * (size_t)stride);
     DEVALLOC(d_s, sizeof(tlb_edi_state) * (size_t)b->nstreams);
-    DEVALLOC(d_n, sizeof(int32_t) * slots);
-    HIPCHK(hipMemset(d_p, 0, slots * (size_t)stride));
+    DEVALLOC(d_n, sizeof(int32_t) * pslots);
+    HIPCHK(hipMemset(d_p, 0, pslots * (size_t)stride));
     HIPCHK(hipMemcpy(d_f, frames, slots * (size_t)b->out_stride, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_s, state, sizeof(tlb_edi_state) * (size_t)b->nstreams, hipMemcpyHostToDevice));
     if (levels) { DEVALLOC(d_l, slots * 4); HIPCHK(hipMemcpy(d_l, levels, slots * 4, hipMemcpyHostToDevice)); }
     int rc = tlb_edi_af_device(b, d_f, d_l, nframes, d_s, version, version_len, d_p, d_n, nullptr);
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpy(pkts, d_p, slots * (size_t)stride, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(pkt_len, d_n, sizeof(int32_t) * slots, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(pkts, d_p, pslots * (size_t)stride, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(pkt_len, d_n, sizeof(int32_t) * pslots, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(state, d_s, sizeof(tlb_edi_state) * (size_t)b->nstreams, hipMemcpyDeviceToHost);
 
     if (e != hipSuccess) return TLB_ERR_HIP;

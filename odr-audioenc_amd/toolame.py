@@ -88,6 +88,11 @@ def load_library():
     L.tlb_set_gain_db.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.tlb_ingest_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tlb_ingest_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    for f in ("tlb_egress_unit_bytes", "tlb_egress_units_per_frame"):
+        getattr(L, f).argtypes = [C.c_void_p, C.c_int]
+    L.tlb_egress_max_units_per_frame.argtypes = [C.c_void_p]
+    L.tlb_zmq_msg_stride.argtypes = [C.c_void_p]
+    L.tlb_zmq_frame_host.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
     L.tlb_edi_state_init.argtypes = [C.c_void_p, C.c_longlong, C.c_uint, C.c_int, C.c_int]
     L.tlb_edi_state_init.restype = None
     L.tlb_edi_af_stride.argtypes = [C.c_void_p, C.c_int]
@@ -162,6 +167,9 @@ class Batch:
         self.configs = configs
         self.frame_bytes = [self.L.tlb_frame_bytes(self.h, s) for s in range(self.nstreams)]
         self.out_stride = self.L.tlb_out_stride(self.h)
+        self.unit_bytes = [self.L.tlb_egress_unit_bytes(self.h, s) for s in range(self.nstreams)]
+        self.units_per_frame = [self.L.tlb_egress_units_per_frame(self.h, s) for s in range(self.nstreams)]
+        self.max_upf = self.L.tlb_egress_max_units_per_frame(self.h)
         self._first = True
 
     # -- host-buffer path (tests, legacy-style callers) ------------------------------------
@@ -239,7 +247,8 @@ class Batch:
 
     def edi_af(self, frames, levels, state, version=b""):
         """frames uint8 [nframes, nstreams, out_stride] (encode() layout), levels int16 [nframes, nstreams, 2] or None,
-        state = edi_state_init(...) (advanced in place) -> (packets uint8 [nframes, nstreams, stride], lengths int32)"""
+        state = edi_state_init(...) (advanced in place) -> (packets uint8 [nframes * max_upf, nstreams, stride], lengths int32):
+        one packet per 24-ms unit in slot order frame * max_upf + unit (include/toolame_batch.h, UNITS)"""
         f = np.ascontiguousarray(frames, dtype=np.uint8)
         nf = f.shape[0]
         if f.shape != (nf, self.nstreams, self.out_stride) or state.dtype != EDI_STATE_DTYPE or state.shape != (self.nstreams,):
@@ -248,13 +257,30 @@ class Batch:
         ps = self.L.tlb_edi_af_stride(self.h, len(version))
         if ps <= 0:
             raise ToolameError(18, "version string too long")
-        pkts = np.zeros((nf, self.nstreams, ps), dtype=np.uint8)
-        plen = np.zeros((nf, self.nstreams), dtype=np.int32)
+        if self.max_upf <= 0:
+            raise ToolameError(1, "a stream's frames are no whole number of 24-ms units (32 kHz)")
+        pkts = np.zeros((nf * self.max_upf, self.nstreams, ps), dtype=np.uint8)
+        plen = np.zeros((nf * self.max_upf, self.nstreams), dtype=np.int32)
         rc = self.L.tlb_edi_af_host(self.h, f.ctypes.data, lv.ctypes.data if lv is not None else None, nf, state.ctypes.data,
                                     bytes(version), len(version), pkts.ctypes.data, plen.ctypes.data)
         if rc:
             raise ToolameError(rc, "tlb_edi_af_host")
         return pkts, plen
+
+    def zmq_frames(self, frames, peaks=None):
+        """frames uint8 [nframes, nstreams, out_stride] -> ZeroMQ messages uint8 [nframes * max_upf, nstreams, 12 + out_stride],
+        one per 24-ms unit in slot order (struct zmq_frame_header_t + unit; datasize 0 = absent slot)"""
+        f = np.ascontiguousarray(frames, dtype=np.uint8)
+        nf = f.shape[0]
+        if f.shape != (nf, self.nstreams, self.out_stride) or self.max_upf <= 0:
+            raise ToolameError(18 if self.max_upf > 0 else 1, f"frames {f.shape}")
+        pk = np.ascontiguousarray(peaks, dtype=np.int16) if peaks is not None else None
+        ms = self.L.tlb_zmq_msg_stride(self.h)
+        msgs = np.zeros((nf * self.max_upf, self.nstreams, ms), dtype=np.uint8)
+        rc = self.L.tlb_zmq_frame_host(self.h, f.ctypes.data, pk.ctypes.data if pk is not None else None, nf, msgs.ctypes.data)
+        if rc:
+            raise ToolameError(rc, "tlb_zmq_frame_host")
+        return msgs
 
     def edi_pft(self, af, af_len, pseq, fec=0, chunk_len=207, transport=False, addr_source=0, dest_port=0):
         """AF packets (edi_af() output) -> PFT fragments.  pseq uint16 [nstreams] is advanced in place.

@@ -47,21 +47,30 @@ def pkt_stride(out_stride, vlen):
     return (10 + 16 + 18 + 11 + out_stride + 12 + 12 + vlen + 2 + 3) & ~3
 
 
-def emu_af(frames, levels, frame_bytes, state, version=VERSION):
+def _units(frame_bytes, unit_bytes):
+    fb = np.ascontiguousarray(frame_bytes, dtype=np.int32)
+    ub = fb.copy() if unit_bytes is None else np.ascontiguousarray(unit_bytes, dtype=np.int32)
+    assert (fb % ub == 0).all()
+    return fb, ub, int((fb // ub).max())
+
+
+def emu_af(frames, levels, frame_bytes, state, version=VERSION, unit_bytes=None):
+    """unit_bytes [nstreams] = 3 * kbps, what one send carries (default: the whole frame, as at 48 kHz).  Packets come back in
+    slot order v = frame * max_upf + unit: [nframes * max_upf, nstreams, stride]; absent slots have length 0."""
     import emulib as E
     L = E.lib()
     assert L.emu_sizeof_edi_state() == EDI_STATE.itemsize
     nf, ns, stride = frames.shape
+    fb, ub, mu = _units(frame_bytes, unit_bytes)
     ps = pkt_stride(stride, len(version))
-    pkts = np.zeros((nf, ns, ps), dtype=np.uint8)
-    plen = np.zeros((nf, ns), dtype=np.int32)
-    fb = np.ascontiguousarray(frame_bytes, dtype=np.int32)
+    pkts = np.zeros((nf * mu, ns, ps), dtype=np.uint8)
+    plen = np.zeros((nf * mu, ns), dtype=np.int32)
     st = state.copy()
     lv = np.ascontiguousarray(levels, dtype=np.int16) if levels is not None else None
     L.emu_edi_af.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int,
-                             C.c_void_p, C.c_int, C.c_void_p]
+                             C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     assert L.emu_edi_af(frames.ctypes.data, lv.ctypes.data if lv is not None else None, nf, ns, stride, fb.ctypes.data,
-                        st.ctypes.data, version, len(version), pkts.ctypes.data, ps, plen.ctypes.data) == 0
+                        st.ctypes.data, version, len(version), pkts.ctypes.data, ps, plen.ctypes.data, ub.ctypes.data, mu) == 0
     return pkts, plen, st
 
 
@@ -77,23 +86,28 @@ def ref_lib():
     return L
 
 
-def ref_af(frames, levels, frame_bytes, state, version=VERSION):
-    """the reference's own TagItems/TagPacket/AFPacket classes, one stream at a time"""
+def ref_af(frames, levels, frame_bytes, state, version=VERSION, unit_bytes=None):
+    """the reference's own TagItems/TagPacket/AFPacket classes, one stream at a time.  A stream's frames are cut into the
+    3*bitrate-byte pieces odr-audioenc.cpp:1211-1219 sends (one write_frame() each, with the levels of the frame they came
+    from) and laid out in the same slot order as emu_af."""
     L = ref_lib()
     nf, ns, stride = frames.shape
+    fb, ub, mu = _units(frame_bytes, unit_bytes)
     ps = pkt_stride(stride, len(version))
-    pkts = np.zeros((nf, ns, ps), dtype=np.uint8)
-    plen = np.zeros((nf, ns), dtype=np.int32)
+    pkts = np.zeros((nf * mu, ns, ps), dtype=np.uint8)
+    plen = np.zeros((nf * mu, ns), dtype=np.int32)
     st = state.copy()
     for s in range(ns):
-        f = np.ascontiguousarray(frames[:, s, :])
-        lv = np.ascontiguousarray(levels[:, s, :], dtype=np.int16) if levels is not None else None
+        upf, U = int(fb[s] // ub[s]), int(ub[s])
+        f = np.ascontiguousarray(frames[:, s, : upf * U].reshape(nf * upf, U))
+        lv = np.ascontiguousarray(np.repeat(levels[:, s, :], upf, axis=0), dtype=np.int16) if levels is not None else None
         one = st[s:s + 1].copy()
-        pk = np.zeros((nf, ps), dtype=np.uint8)
-        pl = np.zeros(nf, dtype=np.int32)
-        assert L.ediref_stream(f.ctypes.data, nf, int(frame_bytes[s]), stride, lv.ctypes.data if lv is not None else None,
+        pk = np.zeros((nf * upf, ps), dtype=np.uint8)
+        pl = np.zeros(nf * upf, dtype=np.int32)
+        assert L.ediref_stream(f.ctypes.data, nf * upf, U, U, lv.ctypes.data if lv is not None else None,
                                one.ctypes.data, version, len(version), pk.ctypes.data, ps, pl.ctypes.data) == 0
-        pkts[:, s, :], plen[:, s], st[s] = pk, pl, one[0]
+        v = (np.arange(nf)[:, None] * mu + np.arange(upf)[None, :]).reshape(-1)        # slot of (frame, unit)
+        pkts[v, s, :], plen[v, s], st[s] = pk, pl, one[0]
     return pkts, plen, st
 
 
@@ -111,7 +125,15 @@ CASES = [
     ("tist_wrap", 120, [384, 288], (1700000000, 250, 1, 37), (65530, 4990), True),
     ("plain", 60, [384], (1600000123, 0, 0, 37), (0, 0), False),
     ("long_version_cadence", 900, [576, 96, 384], (1751234567, 1015, 1, 37), (12, 2500), True),
+    # MPEG-2 LSF streams next to a 48 kHz one: two (24 kHz) and three (16 kHz) 24-ms units per frame, one send each
+    ("lsf_mixed", 450, [384, 384, 192, 432], (1766000000, 500, 1, 37), (65000, 4900), True),
 ]
+# (sample rate, kbps, mode) of the streams of the cases that are not all 48 kHz; unit = 3 * kbps bytes
+CASE_STREAMS = {"lsf_mixed": [(48000, 128, "s"), (24000, 64, "s"), (24000, 32, "m"), (16000, 48, "s")]}
+
+
+def case_unit_bytes(name):
+    return np.array([3 * k for _, k, _ in CASE_STREAMS[name]], dtype=np.int32) if name in CASE_STREAMS else None
 
 
 def case_inputs(name):
@@ -204,13 +226,15 @@ def ref_reassemble(frags, flen, n, present):
     return (out[:r].tobytes(), corr.value) if r > 0 else (None, r)
 
 
-def check_reassembly(af, af_len, frags, flen, nfrag, fec, stride_f=7):
+def check_reassembly(af, af_len, frags, flen, nfrag, fec, stride_f=7, present_only=False):
     """decoder-side property for one PFT case: with ANY `fec` fragments lost the AF packet comes back bit-exactly (three loss
     patterns per packet: the first, the last, a strided pick); with most fragments lost (more than 48 erasures per codeword) the decoder must NOT hand back a packet"""
     nf, ns = nfrag.shape
     for f in range(0, nf, max(1, nf // stride_f)):
         for s in range(ns):
             n, l = int(nfrag[f, s]), int(af_len[f, s])
+            if present_only and l <= 0:
+                continue
             want = af[f, s, :l].tobytes()
             patterns = [list(range(fec)), list(range(n - fec, n)), [(3 + 5 * q) % n for q in range(fec)]] if fec else [[]]
             for lost in patterns:

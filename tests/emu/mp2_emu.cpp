@@ -103,9 +103,10 @@ int emu_pending(void *h, int s, uint8_t *out)
 }
 // EDI AF packets (csrc/edi_af.h) of nframes frames of nstreams streams, emulated wave per stream.
 // frames [nframes][nstreams][out_stride], levels [nframes][nstreams][2] or null, state [nstreams] (advanced),
-// pkts [nframes][nstreams][pkt_stride], pkt_len [nframes][nstreams]
+// unit_bytes [nstreams] (3 * kbps; divides frame_bytes), pkts [nframes * max_upf][nstreams][pkt_stride], pkt_len [nframes * max_upf][nstreams]
 int emu_edi_af(const uint8_t *frames, const int16_t *levels, int nframes, int nstreams, int out_stride, const int32_t *frame_bytes,
-               TlEdiState *state, const uint8_t *version, int version_len, uint8_t *pkts, int pkt_stride, int32_t *pkt_len)
+               TlEdiState *state, const uint8_t *version, int version_len, uint8_t *pkts, int pkt_stride, int32_t *pkt_len,
+               const int32_t *unit_bytes, int max_upf)
 {
     static TlTables T;
     static bool built = false;
@@ -114,9 +115,9 @@ int emu_edi_af(const uint8_t *frames, const int16_t *levels, int nframes, int ns
     std::vector<TlEdiState> next((size_t)nstreams);
     A.frames = frames; A.levels = levels; A.state = state; A.state_out = next.data(); A.version = version; A.xpow8 = T.edi_xpow8; A.frame_bytes = frame_bytes;
     A.pkts = pkts; A.pkt_len = pkt_len; A.nstreams = nstreams; A.nframes = nframes; A.out_stride = out_stride;
-    A.pkt_stride = pkt_stride; A.version_len = version_len;
-    for (int f = 0; f < nframes; f++)
-        for (int s = 0; s < nstreams; s++) tl_edi_af_packet(A, s, f);
+    A.pkt_stride = pkt_stride; A.version_len = version_len; A.unit_bytes = unit_bytes; A.max_upf = max_upf;
+    for (int v = 0; v < nframes * max_upf; v++)
+        for (int s = 0; s < nstreams; s++) tl_edi_af_packet(A, s, v);
     memcpy(state, next.data(), sizeof(TlEdiState) * (size_t)nstreams);
     return 0;
 }

@@ -14,7 +14,7 @@ import edilib as E
 out = {}
 for name, *_ in E.CASES:
     frames, levels, fb, st = E.case_inputs(name)
-    pkts, plen, st2 = E.ref_af(frames, levels, fb, st)
+    pkts, plen, st2 = E.ref_af(frames, levels, fb, st, unit_bytes=E.case_unit_bytes(name))
     out[name + "_head"] = pkts[:16]
     out[name + "_len"] = plen
     out[name + "_sha"] = np.frombuffer(bytes.fromhex(E.digest(pkts, plen)), dtype=np.uint8)

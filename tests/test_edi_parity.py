@@ -21,7 +21,7 @@ def _check(name, pkts, plen, st):
 @pytest.mark.parametrize("name", [c[0] for c in E.CASES])
 def test_emulated_device_code_vs_golden(name):
     frames, levels, fb, st = E.case_inputs(name)
-    _check(name, *E.emu_af(frames, levels, fb, st))
+    _check(name, *E.emu_af(frames, levels, fb, st, unit_bytes=E.case_unit_bytes(name)))
 
 
 @pytest.mark.parametrize("name", [c[0] for c in E.CASES])
@@ -29,7 +29,7 @@ def test_reference_classes_vs_golden(name):
     if E.ref_lib() is None:
         pytest.skip("oracle/_ref/libedi_ref.so not built (no /root/reference here)")
     frames, levels, fb, st = E.case_inputs(name)
-    _check(name, *E.ref_af(frames, levels, fb, st))
+    _check(name, *E.ref_af(frames, levels, fb, st, unit_bytes=E.case_unit_bytes(name)))
 
 
 def test_packet_structure():
@@ -125,19 +125,50 @@ def test_pft_fragments_decode_with_the_reference_rs_decoder(name):
     E.check_reassembly(af, af_len, frags, flen, nfrag, kw["fec"])
 
 
-def test_pft_empty_and_oversize_packets_make_no_fragments():
-    """an AF length of 0, a negative one or one beyond the slot yields zero fragments (no division by a zero chunk count, no
-    copy past the staging buffer); the packets around it are unaffected and Pseq still advances per packet"""
+def test_pft_absent_and_oversize_packets():
+    """an AF length of 0 (or below) is an ABSENT packet -- the surplus unit slots of a stream with fewer units per frame than
+    its batch -- and takes no Pseq; a length beyond the slot is dropped but counted; neither makes fragments (no division by
+    a zero chunk count, no copy past the staging buffer) and the packets around them only shift their sequence numbers"""
     af, af_len, pseq, kw = E.pft_case_inputs("fec2")
     good = E.emu_pft(af, af_len, pseq, **kw)
     bad_len = af_len.copy()
     bad_len[3, 0], bad_len[5, 1], bad_len[9, 0] = 0, af.shape[2] + 4, -7
     frags, flen, nfrag, ps = E.emu_pft(af, bad_len, pseq, **kw)
-    assert nfrag[3, 0] == 0 and nfrag[5, 1] == 0 and nfrag[9, 0] == 0 and (ps == good[3]).all()
-    mask = np.ones(nfrag.shape, dtype=bool)
-    mask[3, 0] = mask[5, 1] = mask[9, 0] = False
-    assert (nfrag[mask] == good[2][mask]).all() and (frags[mask] == good[0][mask]).all()
+    assert nfrag[3, 0] == 0 and nfrag[5, 1] == 0 and nfrag[9, 0] == 0
+    assert ps[0] == np.uint16(good[3][0] - 2) and ps[1] == good[3][1]          # stream 0 lost two sequence numbers, stream 1 none
+    n = af.shape[0]
+    for s, absent in ((0, [3, 9]), (1, [])):
+        for f in range(n):
+            if nfrag[f, s] == 0:
+                continue
+            shift = sum(1 for a in absent if a < f)
+            assert nfrag[f, s] == good[2][f, s]
+            want = good[0][f, s].copy()
+            got = frags[f, s]
+            for i in range(nfrag[f, s]):                               # same fragments, Pseq lower by the absent packets before
+                ps_w = int.from_bytes(want[i, 2:4].tobytes(), "big")
+                assert int.from_bytes(got[i, 2:4].tobytes(), "big") == (ps_w - shift) % 65536
+            hdr = 16
+            assert (got[:, hdr:] == want[:, hdr:]).all()
     for fec in (0, 2):
         k2 = dict(kw, fec=fec)
-        _, _, n2, _ = E.emu_pft(af[:4], np.zeros((4, af.shape[1]), dtype=np.int32), pseq, **k2)
-        assert (n2 == 0).all()
+        _, _, n2, p2 = E.emu_pft(af[:4], np.zeros((4, af.shape[1]), dtype=np.int32), pseq, **k2)
+        assert (n2 == 0).all() and (p2 == pseq).all()
+
+
+def test_lsf_units_feed_the_pft_layer():
+    """the mixed 48 k / 24 k / 16 k case end to end on the emulated device code: AF packets in slot order (absent slots of
+    the streams with fewer units) -> PFT fragments; every present packet reassembles through the reference's RS decoder and
+    each stream's Pseq advanced by its own number of units"""
+    if E.pft_ref_lib() is None:
+        pytest.skip("oracle/_ref/libpft_ref.so not built (no /root/reference here)")
+    frames, levels, fb, st = E.case_inputs("lsf_mixed")
+    frames, levels = frames[:12], levels[:12]
+    ub = E.case_unit_bytes("lsf_mixed")
+    pkts, plen, _ = E.emu_af(frames, levels, fb, st, unit_bytes=ub)
+    assert pkts.shape[0] == 12 * 3 and (plen[:, 0].reshape(12, 3)[:, 1:] == 0).all() and (plen[:, 3] > 0).all()
+    pseq = np.array([65530, 7, 100, 0], dtype=np.uint16)
+    frags, flen, nfrag, ps = E.emu_pft(pkts, plen, pseq, fec=2)
+    assert list((ps - pseq).astype(np.uint16)) == [12, 24, 24, 36]
+    assert ((nfrag > 0) == (plen > 0)).all()
+    E.check_reassembly(pkts, plen, frags, flen, nfrag, 2, present_only=True)

@@ -360,8 +360,6 @@ def test_zmq_frame_header(M):
     cfgs = [M.StreamConfig(mode="j"), M.StreamConfig(mode="s", bitrate=192), M.StreamConfig(mode="m", bitrate=64)]
     b = M.Batch(cfgs)
     L = M.load_library()
-    L.tlb_zmq_msg_stride.argtypes = [C.c_void_p]
-    L.tlb_zmq_frame_host.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p]
     nf = 2
     rng = np.random.default_rng(5)
     frames = rng.integers(0, 256, size=(nf, 3, b.out_stride), dtype=np.uint8)
@@ -386,7 +384,11 @@ def test_edi_af_packets(M):
     kb = {96: 32, 288: 96, 384: 128, 576: 192}                  # frame bytes -> kbps at 48 kHz
     for name, *_ in E.CASES:
         frames, levels, fb, st = E.case_inputs(name)
-        b = M.Batch([M.StreamConfig(mode="s" if n > 96 else "m", bitrate=kb[int(n)]) for n in fb])
+        if name in E.CASE_STREAMS:                              # mixed 48 k / 24 k / 16 k: two or three 24-ms units per LSF frame
+            b = M.Batch([M.StreamConfig(samplerate=r, mode=m, bitrate=k) for r, k, m in E.CASE_STREAMS[name]])
+            assert b.max_upf == 3 and b.units_per_frame == [1, 2, 2, 3] and list(b.unit_bytes) == list(E.case_unit_bytes(name))
+        else:
+            b = M.Batch([M.StreamConfig(mode="s" if n > 96 else "m", bitrate=kb[int(n)]) for n in fb])
         assert list(b.frame_bytes) == [int(n) for n in fb] and b.out_stride == frames.shape[2]
         state = st.astype(M.EDI_STATE_DTYPE)
         pkts, plen = b.edi_af(frames, levels, state, E.VERSION)
@@ -394,6 +396,19 @@ def test_edi_af_packets(M):
         assert (pkts[:16] == g[name + "_head"]).all(), name
         assert E.digest(pkts, plen) == bytes(g[name + "_sha"]).hex(), name
         assert state.tobytes() == g[name + "_state"].tobytes(), name
+        if name in E.CASE_STREAMS:                              # the ZeroMQ messages of the same batch: one per unit
+            import struct
+            msgs = b.zmq_frames(frames[:8], levels[:8])
+            for f in range(8):
+                for s2 in range(b.nstreams):
+                    U, upf = b.unit_bytes[s2], b.units_per_frame[s2]
+                    for u in range(b.max_upf):
+                        m = msgs[f * b.max_upf + u, s2]
+                        if u >= upf:
+                            assert not m[:12].any(), (f, s2, u)
+                            continue
+                        want = struct.pack("<HHIhh", 1, 2, U, int(levels[f, s2, 0]), int(levels[f, s2, 1])) + frames[f, s2, u * U:(u + 1) * U].tobytes()
+                        assert m[:12 + U].tobytes() == want, (f, s2, u)
         # two calls of half the frames == one call (the state carries everything)
         half = frames.shape[0] // 2
         state2 = st.astype(M.EDI_STATE_DTYPE)
