@@ -195,6 +195,7 @@ class GpuRun:
 
         elapsed, own = shard.timed_region_detail(dist, run, device_sync=torch.cuda.synchronize, device="cuda")
         kernel_ms = float(self.np.mean([a.elapsed_time(b) for a, b in evs]))
+        self.stage_ms = self.batch.last_stage_ms()      # (psy kernel, encode + finish kernels) of the last launch, models 1/3
         return elapsed, own, kernel_ms
 
     def check(self):
@@ -271,6 +272,7 @@ def main():
     run.check()
     # per-rank (frames, own seconds): the only exchanged payload besides barriers
     per_rank = shard.gather_floats(dist, [S * F * args.steps, own], device="cuda")
+    run_stage_ms = run.stage_ms
     run.close()
 
     res = None
@@ -278,7 +280,13 @@ def main():
         frames = sum(int(p[0]) for p in per_rank)
         value = frames / elapsed
         algo_bytes_per_launch = ALGO_BYTES_PER_FRAME * S * F
-        kname = f"tl_encode_kernel<{2 if psy == 4 else psy}>"
+        split = psy in (1, 3)
+        kname = (f"tl_psy_kernel<{psy}> + tl_main_kernel + tl_finish_kernel (the three kernels of one launch of the path)" if split
+                 else f"tl_encode_kernel<{2 if psy == 4 else psy}>")
+        kernels = None
+        if split and run_stage_ms:
+            kernels = {f"tl_psy_kernel<{psy}>": round(run_stage_ms[0], 4), "tl_main_kernel + tl_finish_kernel": round(run_stage_ms[1], 4),
+                       "source": "hipEvents on the launch stream inside the library (tlb_last_stage_ms), last timed launch"}
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh): a committed
         # measurement, quoted only when it was taken on this very workload; never measured inside this run
         traffic, traffic_source, valu = None, None, None
@@ -287,12 +295,13 @@ def main():
             wl = pm["workload"]
             if (wl["streams"], wl["frames_per_step"], wl["psy"], wl["mode"]) == (S, F, psy, args.mode):
                 traffic = pm["hbm_bytes_per_launch"]
-                traffic_source = "profiles/pmc_traffic_latest.json (committed rocprofv3 --pmc measurement of this workload, not this run)"
+                traffic_source = ("profiles/pmc_traffic_latest.json (committed rocprofv3 --pmc measurement of this workload, summed over the launch's "
+                                  "kernels: " + ", ".join(f"{k} {v['hbm_bytes_per_launch']}" for k, v in pm["kernels"].items()) + "; not measured in this run)")
                 sq = json.load(open(ROOT / "profiles" / "sq_counters_latest.json"))
-                d = sq["derived"]
-                valu = {"valu_busy_per_simd": d.get("valu_busy_per_simd"), "wave_cycles_waiting": d["waiting_share"],
-                        "valu_instructions_per_frame": d["per_frame"]["valu"], "waves_per_simd": d.get("waves_per_simd"),
-                        "source": "profiles/sq_counters_latest.json (committed, not this run)"}
+                valu = {k: {"valu_busy_per_simd": c["derived"]["valu_busy_per_simd"], "waves_per_simd": c["derived"]["waves_per_simd"],
+                            "wave_cycles_waiting": c["derived"]["waiting_share"], "valu_instructions_per_frame": c["derived"]["per_frame"]["valu"]}
+                        for k, c in sq["kernels"].items()}
+                valu["source"] = "profiles/sq_counters_latest.json (committed rocprofv3 --pmc SQ counters of this workload, not this run)"
         except Exception:  # noqa: BLE001
             pass
         achieved = algo_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
@@ -310,9 +319,10 @@ def main():
             "per_gpu_frames_per_s": [round(p[0] / p[1], 1) for p in per_rank],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": kname, "kernel_ms": round(kernel_ms, 4), "last_kernel_ms_hip_events": round(last_ms, 4),
+                         "kernel": kname, "kernel_ms": round(kernel_ms, 4), "last_kernel_ms_hip_events": round(last_ms, 4), "kernels_ms": kernels,
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch,
-                         "binding_resource": "fp64 VALU issue + LDS latency chains (not HBM: 4992 B per 0.35 MFLOP frame, SURVEY F9)",
+                         "binding_resource": "fp64 VALU issue + LDS latency chains (not HBM: 4992 B per 0.35 MFLOP frame, SURVEY F9); models 1/3 "
+                                             "trade HBM traffic for occupancy (PCM read by two kernels, 1 KB/frame psy record)",
                          "secondary_fp64": {"achieved_tflops": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 1e12, 3), "peak_tflops": 78.6,
                                             "frac": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 78.6e12, 5),
                                             "basis": "0.35 MFLOP algorithmic fp64 per stereo frame (SURVEY 8d), vector fp64 peak"},
