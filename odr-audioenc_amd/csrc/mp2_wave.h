@@ -297,7 +297,6 @@ struct TlPsyLds {
     struct { double fft[TL_FFT_WORDS]; } u;
     TlPsyOut *po;                       // where this unit's result goes (HBM)
     double tone_x[TL_TONE_MAX];
-    double spike[32];
     double nsum[32];
     uint32_t cinfo[TL_CAND_MAX];
     int16_t conf_c[TL_TONE_MAX];
@@ -604,7 +603,7 @@ TL_FN void tl_psy_spectrum(W &w, const TlTables *TL_RESTRICT T, const TlPcmView 
     double *x = w.u.fft;
     long long *sq = (sp && ch == 0) ? sp + 16 : nullptr;      // channel 0's pass-by-pass stamps: slots 24..30 of the frame's record
     TL_STAMP(sq, 0);
-    // twiddles travel one pass ahead of their use (twc: k=4, twb: k=6, twa: k=8)
+    // twiddles travel one pass ahead of their use (twc: k=4 with the window, twb: k=6 during pass 4, twa: k=8 during pass 6): two sets live at most
     PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
     TL_LANES_BEGIN
     {
@@ -635,7 +634,6 @@ TL_FN void tl_psy_spectrum(W &w, const TlTables *TL_RESTRICT T, const TlPcmView 
                 e[r4] = ((double)v[q] / 32768) * h[q];
             }
         }
-        tl_fht_twiddles<6>(L(twb), T, lane);
         tl_fht_head(e, T->fht_tw);
         tl_fht_store(x, lane, e);
     }
@@ -643,9 +641,9 @@ TL_FN void tl_psy_spectrum(W &w, const TlTables *TL_RESTRICT T, const TlPcmView 
     TL_STAMP(sq, 1);
     TL_STAMP(sq, 2);
     TL_STAMP(sq, 3);
-    TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), T, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_twiddles<6>(L(twb), T, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
     TL_STAMP(sq, 4);
-    TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), T, lane); tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
     TL_STAMP(sq, 5);
     // Last pass (k=8) and energies (fft.c:1278-1293) in one go: the eight outputs of a k=8 butterfly are x[i+256q] and
     // x[256-i+256q], and line j pairs with 1024-j -- so butterfly i holds both members of the pairs of lines i, 256-i, 256+i
@@ -825,8 +823,11 @@ TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *
 #pragma unroll
 #endif
         for (int j = 0; j < 16; j++) sum += 1073741824 * e[j];
-        w.spike[lane] = 10.0 * tl_log10_pn(sum);
+        const double spk = 10.0 * tl_log10_pn(sum);
+        if constexpr (W::kSplit) { TlPsyOut *po = w.po; po->a[ch][lane] = spk; }       // final as it is: straight to the record (nothing to park)
+        else w.spike[lane] = spk;
     }
+    if constexpr (W::kSplit) { if (lane >= 30 && lane < 32) { TlPsyOut *po = w.po; po->a[ch][lane] = 0.0; } }
     TL_LANES_END
 
     // ---- tonal components (psycho_1.c:267-340) ----
@@ -1148,15 +1149,15 @@ TL_FN void tl_psy1_thresholds(W &w, const double *TL_RESTRICT db, const TlConfig
         else {
             m = tl_min_rows(TL_LTG(w), j0, n, 0.0, true);
         }
-        if constexpr (W::kSplit) {                                  // the encode kernel finishes the line (tl_smr_from_psy)
+        if constexpr (W::kSplit) {                                  // the encode kernel finishes the line (tl_encode_frame, TL_PSY_EXT)
             TlPsyOut *po = w.po;
-            po->a[ch][lane] = w.spike[lane]; po->m[ch][lane] = m;
+            po->m[ch][lane] = m;
         } else {
             double max = C->scale_db[w.minidx[ch][lane]];
             if (w.spike[lane] > max) max = w.spike[lane];
             w.smr[ch][lane] = max - m;
         }
-    }
+    } else if constexpr (W::kSplit) { if (lane < 32) { TlPsyOut *po = w.po; po->m[ch][lane] = 0.0; } }      // subbands the model leaves alone
     TL_LANES_END
 }
 
@@ -1413,7 +1414,7 @@ TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     L(pcc) = (int)((uint32_t)(uint16_t)w.conf_c[lane] | ((uint32_t)(uint16_t)w.conf_c[hi] << 16));
     L(ptl) = (int)((uint32_t)(uint16_t)w.tlist[lane] | ((uint32_t)(uint16_t)w.tlist[hi] << 16));
     L(ptx0) = w.tone_x[lane]; L(ptx1) = w.tone_x[hi];
-    L(pspk) = w.spike[lane & 31];
+    if constexpr (!W::kSplit) L(pspk) = w.spike[lane & 31];
     TL_LANES_END
     // ---- channel 1's front; a dead-head channel 1 is finished in the plain order first ----
     const TlPsy1Ch s1 = tl_psy1_front(w, T, db, C, pv, 1, sp1);
@@ -1465,7 +1466,7 @@ TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     const int hi = 64 + lane < TL_TONE_MAX ? 64 + lane : 0;
     w.conf_c[lane] = (int16_t)(L(pcc) & 0xffff); w.tlist[lane] = (int16_t)(L(ptl) & 0xffff); w.tone_x[lane] = L(ptx0);
     if (64 + lane < TL_TONE_MAX) { w.conf_c[hi] = (int16_t)((uint32_t)L(pcc) >> 16); w.tlist[hi] = (int16_t)((uint32_t)L(ptl) >> 16); w.tone_x[hi] = L(ptx1); }
-    if (lane < 32) w.spike[lane] = L(pspk);
+    if constexpr (!W::kSplit) { if (lane < 32) w.spike[lane] = L(pspk); }
     TL_LANES_END
     TL_LANES_BEGIN
     for (int i = lane; i < s0.nconf; i += 64) { const int cc = w.conf_c[i]; if (!((cc >> 13) & 1)) w.ptype[cc & 511] = TL_T_TONE; }
@@ -1529,7 +1530,7 @@ TL_FN int tl_psy3_front(W &w, const TlTables *TL_RESTRICT T, const double *TL_RE
         if ((lane & 15) == 15) {
             const int sb = (lane + 64 * it) >> 4;
             const double xmax = TL_DBMIN < L(pxm) ? L(pxm) : TL_DBMIN;
-            if constexpr (W::kSplit) w.spike[sb] = xmax;             // the encode kernel takes the maximum with the scalefactor level (tl_smr_from_psy)
+            if constexpr (W::kSplit) { TlPsyOut *po = w.po; po->a[ch][sb] = xmax; }      // the encode kernel takes the maximum with the scalefactor level
             else { const double val = w.nsum[sb]; w.spike[sb] = xmax > val ? xmax : val; }
         }
         TL_LANES_END
@@ -1841,7 +1842,7 @@ TL_FN void tl_psy3_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_R
         double m = 999999.9;
         const int j0 = C->p3_sb_j0[lane], n = C->p3_sb_n[lane];
         m = tl_min_rows(TL_LTG(w), j0, n, m, false);
-        if constexpr (W::kSplit) { TlPsyOut *po = w.po; po->a[ch][lane] = w.spike[lane]; po->m[ch][lane] = m; }
+        if constexpr (W::kSplit) { TlPsyOut *po = w.po; po->m[ch][lane] = m; }
         else w.smr[ch][lane] = w.spike[lane] - m;
     }
     TL_LANES_END
@@ -1879,7 +1880,7 @@ TL_FN void tl_psy3_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     const int hi = 64 + lane < TL_TONE_MAX ? 64 + lane : 0;
     L(pcc) = (int)((uint32_t)(uint16_t)w.conf_c[lane] | ((uint32_t)(uint16_t)w.conf_c[hi] << 16));
     L(ptx0) = w.tone_x[lane]; L(ptx1) = w.tone_x[hi];
-    L(pspk) = w.spike[lane & 31];
+    if constexpr (!W::kSplit) L(pspk) = w.spike[lane & 31];
     TL_LANES_END
     const int nconf1 = tl_psy3_front(w, T, db, C, pv, 1, sp1);
     PV(double, es1); PV(double, cg1); PV(double, bsum); PV(double, bsum1);
@@ -1901,7 +1902,7 @@ TL_FN void tl_psy3_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     const int hi = 64 + lane < TL_TONE_MAX ? 64 + lane : 0;
     w.conf_c[lane] = (int16_t)(L(pcc) & 0xffff); w.tone_x[lane] = L(ptx0);
     if (64 + lane < TL_TONE_MAX) { w.conf_c[hi] = (int16_t)((uint32_t)L(pcc) >> 16); w.tone_x[hi] = L(ptx1); }
-    if (lane < 32) w.spike[lane] = L(pspk);
+    if constexpr (!W::kSplit) { if (lane < 32) w.spike[lane] = L(pspk); }
     TL_LANES_END
     tl_psy3_back(w, db, C, 0, nconf0, bsum, es0, cg0, sp0);
 }
@@ -2823,7 +2824,7 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
     const TlPcmView pv = tl_pcm_view(A, &A.state[s], s, f);
     TlPsyOut *po = &A.psy_out[slot];
     TL_LANES_BEGIN
-    (&po->a[0][0])[lane] = 0.0; (&po->m[0][0])[lane] = 0.0;           // entries the model leaves alone (mono: channel 1; psy 1: sb >= sblimit)
+    if (C->nch == 1 && lane < 32) { po->a[1][lane] = 0.0; po->m[1][lane] = 0.0; }     // the model writes every entry of the channels it runs
     if (lane == 0) w.po = po;
     TL_LANES_END
 #ifdef TL_NO_PSY_STAMPS
