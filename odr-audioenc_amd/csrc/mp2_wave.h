@@ -200,6 +200,11 @@ TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
 #else
 #define TL_DBG_DUMP(tag, ch, nt, nn, x, b) ((void)0)
 #endif
+// Diagnostic builds only (tools/instr_budget.sh): TL_EXP_LEVEL = n removes the last n stages of psy model 1 (results are then
+// wrong on purpose); the VALU-instruction counters of successive levels attribute the instructions to the stages.
+#ifndef TL_EXP_LEVEL
+#define TL_EXP_LEVEL 0
+#endif
 #define TL_DBMIN (-200.0)
 #define TL_POWERNORM 90.3090
 #define TL_T_NOISE 10
@@ -717,10 +722,11 @@ TL_FN void tl_psy_spectrum(W &w, const TlTables *TL_RESTRICT T, const TlPcmView 
 
 // power density in dB of one line (psycho_1.c:241-248, psycho_3.c:152-160), straight-line so that several lines' logarithms
 // (long dependent chains) can be in flight together
-TL_FN double tl_power_db(double e)
+// db = the psy kernel's shared block (TlPsyShared): the logarithm's table sits behind the dB-sum table
+TL_FN double tl_power_db(double e, const double *TL_RESTRICT db)
 {
     const bool tiny = e < 1E-20;
-    const double v = 10 * tl_log10_pn(TL_SELECT(tiny, 1.0, e)) + TL_POWERNORM;
+    const double v = 10 * tl_log10_tab(TL_SELECT(tiny, 1.0, e), TL_LOG10_TAB(db), TL_LOG10_POLY(db)) + TL_POWERNORM;
     return TL_SELECT(tiny, -200.0 + TL_POWERNORM, v);
 }
 TL_FN int tl_run_psy1(int c) { return (c < 3 || c > 500) ? 0 : c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 12; }   // psycho_1.c:289-298
@@ -784,14 +790,14 @@ TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *
     const double *energy = w.u.fft;                                   // line i at TL_EX(i)
     double *px = TL_PX(w);
     TL_STAMP(sp, 0);
-    tl_psy_spectrum(w, T, pv, ch, sp);
+    if (TL_EXP_LEVEL < 8) tl_psy_spectrum(w, T, pv, ch, sp);
     TL_STAMP(sp, 1);
 
     // power density spectrum (psycho_1.c:241-248); spike (psycho_1.c:252-257)
     // The spike sums read 16 consecutive energies per lane; the energies' XOR layout keeps those reads off each other's
     // LDS banks.  Only subbands below sblimit (<= 30) are ever used.
     TL_LANES_BEGIN
-    for (int i0 = lane; i0 < 512; i0 += 256) {                     // four lines per lane at a time
+    for (int i0 = lane; i0 < (TL_EXP_LEVEL >= 7 ? 0 : 512); i0 += 256) {                     // four lines per lane at a time
         double e[4], v[4];
 #ifndef TL_EMULATE
 #pragma unroll
@@ -800,7 +806,7 @@ TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int q = 0; q < 4; q++) v[q] = tl_power_db(e[q]);
+        for (int q = 0; q < 4; q++) v[q] = tl_power_db(e[q], db);
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
@@ -812,7 +818,7 @@ TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *
     }
     TL_LANES_END
     TL_LANES_BEGIN
-    if (lane < 30) {
+    if (lane < (TL_EXP_LEVEL >= 7 ? 0 : 30)) {
         double e[16];
 #ifndef TL_EMULATE
 #pragma unroll
@@ -823,7 +829,7 @@ TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *
 #pragma unroll
 #endif
         for (int j = 0; j < 16; j++) sum += 1073741824 * e[j];
-        const double spk = 10.0 * tl_log10_pn(sum);
+        const double spk = 10.0 * tl_log10_tab(sum, TL_LOG10_TAB(db), TL_LOG10_POLY(db));
         if constexpr (W::kSplit) { TlPsyOut *po = w.po; po->a[ch][lane] = spk; }       // final as it is: straight to the record (nothing to park)
         else w.spike[lane] = spk;
     }
@@ -833,10 +839,12 @@ TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *
     // ---- tonal components (psycho_1.c:267-340) ----
     // (1) local maxima 2..499 whose right-hand neighbours pass the 7 dB test, compacted ascending
     int ncand = 0;
+    if (TL_EXP_LEVEL < 6) {
     tl_cand_chunk<2, false, W>(w, 0, ncand);                           // lines -1..62: run 2
     tl_cand_chunk<3, false, W>(w, 1, ncand);                           // 63..126: run 3
     for (int c8 = 2; c8 < 4; c8++) tl_cand_chunk<6, false, W>(w, c8, ncand);     // 127..254: run 6
     for (int c8 = 4; c8 < 8; c8++) tl_cand_chunk<12, false, W>(w, c8, ncand);    // 255..510: run 12
+    }
     TL_STAMP(sp, 2);
     // (2) wave-uniform walk: which candidates become tones.  State of the reference's list walk that
     //     matters: the last confirmed tone (`last`), its erasure reach R = last + run(last), and the
@@ -846,7 +854,7 @@ TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *
     {
         int last = -1, run_last = 0, R = -1, last_var = 0;
         any_erased = false;
-        for (int kb = 0; kb < ncand; kb += 64) {                        // 64 records per LDS round trip, then lane reads
+        for (int kb = 0; kb < (TL_EXP_LEVEL >= 5 ? 0 : ncand); kb += 64) {                        // 64 records per LDS round trip, then lane reads
         PV(int, crec);
         TL_LANES_BEGIN L(crec) = (int)w.cinfo[kb + lane < TL_CAND_MAX ? kb + lane : 0]; TL_LANES_END
         for (int k = kb; k < ncand && k < kb + 64; k++) {
@@ -949,7 +957,7 @@ TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int base = 0; base < 512; base += 64) {
+        for (int base = 0; base < (TL_EXP_LEVEL >= 4 ? 0 : 512); base += 64) {
             PV(bool, ok); PV(double, tv); PV(double, pvv); PV(int, bnd);
             TL_LANES_BEGIN
             const int j = base + lane;
@@ -1107,7 +1115,7 @@ TL_FN void tl_psy1_thresholds(W &w, const double *TL_RESTRICT db, const TlConfig
     // reaches lines with -3 <= dz < 8 bark, so a lane first finds the first and last masker (tones, then noise, in list
     // order) that reaches either of its lines and walks only that span; the per-line range test stays in the walk, so
     // nothing depends on the lists being sorted.
-    for (int base = 1; base < sub; base += 128) {       // 126..132 lines: one full pass + a 4-line tail at most
+    for (int base = 1; base < (TL_EXP_LEVEL >= 1 ? 0 : sub); base += 128) {       // 126..132 lines: one full pass + a 4-line tail at most
         TL_LANES_BEGIN
         const int k0 = base + 2 * lane, k1 = k0 + 1;
         const bool h0 = k0 < sub, h1 = k1 < sub;
@@ -1168,6 +1176,7 @@ TL_FN void tl_psy1_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_R
     const int nbands = C->p1_ncb - 1, nlist = st.nlist;
     int ntone = 0, nnoise = 0;
     TL_STAMP(sp, 4);
+    if (TL_EXP_LEVEL >= 2) { tl_psy1_thresholds(w, db, C, ch, 0, 0, sp); return; }
     // The reference now writes every band's sum to power[centre] in band order -- a later band overwrites an earlier one
     // that chose the same line, and (through the centre+1 rule above) a centre may even land on a tone's line
     // (psycho_1.c:390-398) -- and the decimation reads the levels back from power[].  The same values without the array:
@@ -1402,7 +1411,7 @@ TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     // ---- park channel 0 ----
     PV(double, wt0); PV(int, r0); PV(int, r1);
     PA(double, pvp, 8); PV(int, pcc); PV(int, ptl); PV(double, ptx0); PV(double, ptx1); PV(double, pspk);
-    tl_psy1_weights(w, nbands, wt0);
+    if (TL_EXP_LEVEL < 3) tl_psy1_weights(w, nbands, wt0);
     TL_LANES_BEGIN
     L(r0) = lane < nbands ? (int)w.bandoff[lane] : 0; L(r1) = lane < nbands ? (int)w.bandoff[lane + 1] : 0;
     const double *vp = TL_PX(w);
@@ -1441,7 +1450,7 @@ TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
         tl_psy1_chain(w, db, nbands, bsum, wdummy);
     } else {
         // ---- both chains: channel 1's weight sums first (its terms sit where channel 0's levels go) ----
-        tl_psy1_weights(w, nbands, wt1);
+        if (TL_EXP_LEVEL < 3) tl_psy1_weights(w, nbands, wt1);
         TL_LANES_BEGIN
 #ifndef TL_EMULATE
 #pragma unroll
@@ -1449,7 +1458,7 @@ TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
         for (int k = 0; k < 8; k++) if (lane + 64 * k < 504) w.u.fft[lane + 64 * k] = L(pvp)[k];
         TL_LANES_END
         TL_STAMP(sp1, 4);
-        tl_psy1_chain2(w, db, nbands, r0, r1, bsum);
+        if (TL_EXP_LEVEL < 3) tl_psy1_chain2(w, db, nbands, r0, r1, bsum);
         // ---- back(1): its sums move from lanes 32+b to lanes b ----
         PV(double, bsum1);
 #ifdef TL_EMULATE
@@ -1457,7 +1466,7 @@ TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
 #else
         bsum1 = __shfl(bsum, (int)((threadIdx.x + 32u) & 63u), 64);
 #endif
-        tl_psy1_centres(w, C, nbands, bsum1, wt1);
+        if (TL_EXP_LEVEL < 3) tl_psy1_centres(w, C, nbands, bsum1, wt1);
         tl_psy1_back(w, db, C, 1, s1, sp1);
     }
     // ---- channel 0 returns to the LDS arrays ----
@@ -1471,7 +1480,7 @@ TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     TL_LANES_BEGIN
     for (int i = lane; i < s0.nconf; i += 64) { const int cc = w.conf_c[i]; if (!((cc >> 13) & 1)) w.ptype[cc & 511] = TL_T_TONE; }
     TL_LANES_END
-    tl_psy1_centres(w, C, nbands, bsum, wt0);
+    if (TL_EXP_LEVEL < 3) tl_psy1_centres(w, C, nbands, bsum, wt0);
     tl_psy1_back(w, db, C, 0, s0, sp0);
 }
 
@@ -1508,7 +1517,7 @@ TL_FN int tl_psy3_front(W &w, const TlTables *TL_RESTRICT T, const double *TL_RE
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int q = 0; q < 4; q++) v[q] = tl_power_db(e[q]);
+        for (int q = 0; q < 4; q++) v[q] = tl_power_db(e[q], db);
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
@@ -1536,7 +1545,7 @@ TL_FN int tl_psy3_front(W &w, const TlTables *TL_RESTRICT T, const double *TL_RE
         TL_LANES_END
     }
     TL_LANES_BEGIN
-    if (lane == 0) px[512] = tl_power_db(energy[512]);
+    if (lane == 0) px[512] = tl_power_db(energy[512], db);
     TL_LANES_END
     // ---- tone labelling (psycho_3.c:186-247) ----
     // (1) local maxima 2..499 whose right-hand neighbours are >= 7 dB down, compacted ascending
