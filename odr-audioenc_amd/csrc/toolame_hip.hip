@@ -95,10 +95,11 @@ __global__ void __launch_bounds__(64 * TL_PSY_WAVES) __attribute__((amdgpu_waves
     __syncthreads();
     const double *dbt = psh.dbtable;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nunits = A.nlist * A.nframes;
-    for (;;) {                                                      // units cost different amounts: every wave takes the next one when it is free
-        const int u = tl_next_unit(&A.work[0]);
-        if (u >= nunits) break;
+    const int nunits = A.nlist * A.nframes, nwaves = (int)gridDim.x * TL_PSY_WAVES;
+    // units cost different amounts: every wave takes the next one when it is free.  The FIRST unit of a wave is its own index
+    // (no counter access: three thousand waves asking one address at once queue for tens of microseconds), the rest come off
+    // the counter, which therefore starts at the number of waves.
+    for (int u = (int)blockIdx.x * TL_PSY_WAVES + wave; u < nunits; u = nwaves + tl_next_unit(&A.work[0])) {
         const int f = u / A.nlist, k = u - f * A.nlist;             // units taken one after the other: neighbouring streams of one frame
         const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
         tl_psy_unit<PSY>(lds[wave], dbt, A, s, f);
@@ -124,10 +125,8 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
     // the encode path never touches B->dbtable: a TlBlockShared pointer whose dbtable part lies before the copied block
     const TlBlockShared *B = (const TlBlockShared *)((const char *)&sh.bytes[0] - offsetof(TlBlockShared, scalefactor));
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nunits = A.nlist * A.nframes;
-    for (;;) {
-        const int u = tl_next_unit(&A.work[1]);
-        if (u >= nunits) break;
+    const int nunits = A.nlist * A.nframes, nwaves = (int)gridDim.x * TL_MAIN_WAVES;
+    for (int u = (int)blockIdx.x * TL_MAIN_WAVES + wave; u < nunits; u = nwaves + tl_next_unit(&A.work[1])) {      // as in the psy kernel
         const int f = u / A.nlist, k = u - f * A.nlist;
         const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
         tl_main_unit(lds[wave], B, sh.enw_s, A, s, f);
