@@ -10,8 +10,8 @@ Workload
           PCIe-inclusive rate (pinned host buffers through tlb_encode_host) and reports them under "also".
   N > 1 : BASELINE.json configs[3] -- 16384 streams PER GPU, psy model 3 (131072 streams on 8 GPUs), weak scaling.
 
-A "step" = one launch of the hot path: every stream encodes --frames-per-step consecutive frames (per-stream state stays
-on chip between them).  One process per GPU; streams shard with no data-path collective; RCCL carries only the
+A "step" = one launch of the hot path: every stream encodes --frames-per-step consecutive frames (default: 131072 (stream,
+frame) units per launch, i.e. 32 frames at 4096 streams, 8 at 16384; the kernels' ramp-up and tail are paid once per launch).  One process per GPU; streams shard with no data-path collective; RCCL carries only the
 barriers, the max-over-ranks of the elapsed time and one all_gather of (frames, seconds) per rank.
 
 Launching: `python bench.py --gpus N` starts the N rank processes ITSELF (fresh children, created before this
@@ -49,7 +49,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=None, help="streams per GPU (default: the BASELINE config of this N)")
-    ap.add_argument("--frames-per-step", type=int, default=16)
+    ap.add_argument("--frames-per-step", type=int, default=None, help="frames per stream per launch (default: 131072 (stream, frame) units per launch: 32 at 4096 streams, 8 at 16384)")
     ap.add_argument("--psy", type=int, default=None)
     ap.add_argument("--mode", default="s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -253,7 +253,7 @@ def main():
     cfg_streams, cfg_psy = CONFIGS[1] if world == 1 else CONFIGS[3]
     S = args.streams if args.streams is not None else cfg_streams
     psy = args.psy if args.psy is not None else cfg_psy
-    F = args.frames_per_step
+    F = args.frames_per_step if args.frames_per_step is not None else max(1, 131072 // S)
     t0 = time.time()
 
     if args.dry_run:
@@ -332,7 +332,7 @@ def main():
     # ---- secondary measurements, after (outside) the headline's timed region; single GPU only ----
     if world == 1 and not args.no_also:
         also = {}
-        F2 = min(F, 8)                                # shorter launches: 16384 streams x 8 frames = 604 MB of PCM per buffer
+        F2 = max(1, 131072 // CONFIGS[2][0])        # 16384 streams x 8 frames = 604 MB of PCM per buffer
         for name, (s2, p2, m2, f2) in {"mode_j": (S, psy, "j" if args.mode != "j" else "s", F),
                                        "configs2_psy3_16384": (CONFIGS[2][0], CONFIGS[2][1], "s", F2)}.items():
             try:
@@ -347,7 +347,7 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 also[name] = {"value": None, "error": str(ex)}
         try:
-            also["pcie_inclusive"] = pcie_inclusive(M, np, gen_pcm, F2, psy, args.mode, local_rank, S)
+            also["pcie_inclusive"] = pcie_inclusive(M, np, gen_pcm, 8, psy, args.mode, local_rank, S)
         except Exception as ex:  # noqa: BLE001
             also["pcie_inclusive"] = {"value": None, "error": str(ex)}
         res["also"] = also
