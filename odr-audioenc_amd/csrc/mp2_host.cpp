@@ -5,7 +5,6 @@
 #include <string.h>
 
 #include "mp2_tables.inc"
-#include "tl_log_table.inc"
 
 namespace {
 const double kRefPi = 3.14159265358979;            // common.h:26 -- truncated in the reference
@@ -37,10 +36,6 @@ double freq2bark(double freq)                      // ath.c:73-78
 void tl_build_tables(TlTables *T)
 {
     memset(T, 0, sizeof *T);
-    {   // psy kernel's LDS block: the dB-sum table again, and the logarithm's table (bit patterns, tl_log_table.inc)
-        for (int i = 0; i < 128; i++) for (int q = 0; q < 2; q++) { uint64_t u = TL_LOG10_TAB_BITS[i][q]; memcpy(&T->psy_shared.log10_tab[i][q], &u, 8); }
-        for (int i = 0; i < 8; i++) { uint64_t u = TL_LOG10_POLY_BITS[i]; memcpy(&T->psy_shared.log10_poly[i], &u, 8); }
-    }
     for (int i = 0; i < 512; i++) { T->enwindow[i] = (double)TL_ENWINDOW_E9[i] / 1e9; T->enwindow_s[i] = T->enwindow[i] / 32768; }
     for (int i = 0; i < 63; i++) T->scalefactor[i] = (double)TL_SCALEFACTOR_E14[i] / 1e14;
     T->scalefactor[63] = 1e-20;
@@ -138,7 +133,6 @@ void tl_build_tables(TlTables *T)
         T->shared.dbtable[i] = T->dbtable[i];
     }
     T->shared.dbtable[1000] = -0.0; T->shared.dbtable[1001] = -0.0;
-    for (int i = 0; i < 1002; i++) T->psy_shared.dbtable[i] = T->shared.dbtable[i];
     // Buneman recurrence of fft.c:1139-1149 unrolled into a table (passes k = 2,4,6,8)
     int n = 0;
     for (int k = 2; k <= 8; k += 2) {

@@ -25,16 +25,6 @@ struct TlBlockShared {
                                  //   source of sf0 | sf1 << 2 | sf2 << 4 (0..2 = sf0..sf2, 3 = min(sf0, sf2)) | scfsi << 6
 };
 
-// What the psy kernel (models 1 and 3) keeps in LDS per workgroup: the dB-sum table and, right behind it, the table and the
-// polynomial of tl_log10_tab (tl_math.h).  The kernels get ONE pointer (to dbtable); the logarithm's data sit at fixed offsets.
-struct TlPsyShared {
-    double dbtable[1002];        // as TlBlockShared::dbtable
-    double log10_tab[128][2];    // {invc, logc}, tools/gen_log_table.py
-    double log10_poly[8];
-};
-#define TL_LOG10_TAB(db) ((const double (*)[2])((db) + 1002))
-#define TL_LOG10_POLY(db) ((db) + 1002 + 256)
-
 // Tables common to every config.  (ref: enwindow.h, subband.c:125-137, psycho_1.c:170-178,225-233,
 // fft.c:38-73,1139-1149, encode_new.c:16-100,448-462)
 struct TlTables {
@@ -62,7 +52,6 @@ struct TlTables {
     uint8_t rs_mlog[207][48];    // log of M[i][j]: parity byte j of the RS(255,207) codeword of the unit chunk e_i (csrc/edi_pft.h)
     uint16_t edi_xpow8[2048];    // x^(8k) mod (x^16+x^12+x^5+1): AF-packet CRC chunks (csrc/edi_af.h; contrib/crc.c:247-255)
     TlBlockShared shared;
-    TlPsyShared psy_shared;
 };
 
 // Per-config constants.  (ref: toolame.c:120-262, common.c:76-144, encode_new.c:104-125)

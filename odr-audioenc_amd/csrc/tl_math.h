@@ -121,31 +121,6 @@ TL_HD double tl_log10_pn(double x)
     return one ? 0.0 : res;
 }
 
-// log10(x) for positive NORMAL finite x, table driven (tools/gen_log_table.py): no division, no hi/lo recombination -- a
-// third of tl_log10_pn's instructions.  x = 2^k z, z in [0.6875, 1.375); entry i = top 7 bits of z's offset holds
-// invc ~ 1/c_i and logc = -log10(invc); r = fma(z, invc, -1) is exact, log10(x) = (k log10(2) + logc) + log10(1 + r).
-// Within 2 ulp of glibc's log10 over the encoder's range (tests/test_emu_parity.py); `tab` = TlTables::log10_tab (the psy
-// kernel reads its workgroup's LDS copy).  Explicit fma only: the same bits on the device and in the host emulation.
-TL_HD double tl_log10_tab(double x, const double (*tab)[2], const double *poly)
-{
-    const double log10_2hi = 3.01029995663611771306e-01, log10_2lo = 3.69423907715893078616e-13;   // hi: 13 trailing zero bits, k*hi exact
-    const uint64_t ix = tl_d2u(x);
-    const uint64_t tmp = ix - 0x3fe6000000000000ull;
-    const int i = (int)((tmp >> 45) & 127u);
-    const int k = (int)((int64_t)tmp >> 52);
-    const double z = tl_u2d(ix - (tmp & 0xfff0000000000000ull));
-    const double invc = tab[i][0], logc = tab[i][1];
-    const double r = __builtin_fma(z, invc, -1.0);
-    const double kd = (double)k;
-    const double t = __builtin_fma(kd, log10_2hi, logc);
-    double p = poly[7];
-    p = __builtin_fma(p, r, poly[6]); p = __builtin_fma(p, r, poly[5]); p = __builtin_fma(p, r, poly[4]);
-    p = __builtin_fma(p, r, poly[3]); p = __builtin_fma(p, r, poly[2]); p = __builtin_fma(p, r, poly[1]);
-    p = __builtin_fma(p, r, poly[0]);
-    const double lo = __builtin_fma(kd, log10_2lo, p * r);
-    return t + lo;
-}
-
 // 10^x for |x| < 300.
 TL_HD double tl_pow10(double x)
 {

@@ -84,16 +84,14 @@ static __device__ __forceinline__ int tl_next_unit(int32_t *counter)
 #define TL_MAIN_WPE 3
 #endif
 #define TL_LDS_GRANULE 1280u
-static_assert(((sizeof(TlPsyShared) + TL_PSY_WAVES * sizeof(TlPsyLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE) * (12 / TL_PSY_WAVES) <= 128, "twelve psy waves per CU");
+static_assert(((sizeof(double) * 1002 + TL_PSY_WAVES * sizeof(TlPsyLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE) * (12 / TL_PSY_WAVES) <= 128, "twelve psy waves per CU");
 template <int PSY>
 __global__ void __launch_bounds__(64 * TL_PSY_WAVES) __attribute__((amdgpu_waves_per_eu(TL_PSY_WPE, TL_PSY_WPE))) tl_psy_kernel(TlLaunch A)
 {
-    __shared__ TlPsyShared psh;                      // dB-sum table + the logarithm's table, one copy per workgroup
+    __shared__ double dbt[1002];                     // the dB-sum table, one copy per workgroup
     __shared__ TlPsyLds lds[TL_PSY_WAVES];
-    static_assert(sizeof(TlPsyShared) % 8 == 0, "copied as doubles");
-    for (int i = (int)threadIdx.x; i < (int)(sizeof(TlPsyShared) / 8); i += 64 * TL_PSY_WAVES) ((double *)&psh)[i] = ((const double *)&A.tables->psy_shared)[i];
+    for (int i = (int)threadIdx.x; i < 1002; i += 64 * TL_PSY_WAVES) dbt[i] = A.tables->shared.dbtable[i];
     __syncthreads();
-    const double *dbt = psh.dbtable;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nunits = A.nlist * A.nframes, nwaves = (int)gridDim.x * TL_PSY_WAVES;
     // units cost different amounts: every wave takes the next one when it is free.  The FIRST unit of a wave is its own index

@@ -82,8 +82,8 @@ int emu_encode(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, co
     for (int f = nframes - 1; f >= 0; f--)
         for (int s = 0; s < A.nstreams; s++) {
             const int m = e->configs[e->stream_cfg[s]].psy;
-            if (m == 1) tl_psy_unit<1>(wp, e->tables.psy_shared.dbtable, A, s, f);
-            else if (m == 3) tl_psy_unit<3>(wp, e->tables.psy_shared.dbtable, A, s, f);
+            if (m == 1) tl_psy_unit<1>(wp, e->tables.shared.dbtable, A, s, f);
+            else if (m == 3) tl_psy_unit<3>(wp, e->tables.shared.dbtable, A, s, f);
         }
     for (int s = 0; s < A.nstreams; s++)
         if (split(s)) for (int f = nframes - 1; f >= 0; f--) tl_main_unit(wm, &e->tables.shared, e->tables.enwindow_s, A, s, f);
@@ -146,7 +146,6 @@ int emu_sizeof_taps(void) { return (int)sizeof(TlTaps); }
 int emu_sizeof_lds(void) { return (int)sizeof(TlWaveLds); }
 double emu_log10(double x) { return tl_log10(x); }
 double emu_log10_pn(double x) { return tl_log10_pn(x); }
-double emu_log10_tab(double x) { static TlTables T; static bool built = false; if (!built) { tl_build_tables(&T); built = true; } return tl_log10_tab(x, T.psy_shared.log10_tab, T.psy_shared.log10_poly); }
 double emu_pow10(double x) { return tl_pow10(x); }
 // the allocation code counts instead of searching: needs every allocation line's SNR column to be non-decreasing
 int emu_snr_monotone(void)

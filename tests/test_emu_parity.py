@@ -77,7 +77,7 @@ def test_emulated_kernel_vs_oracle_fuzz(psy, mode, fs, kbps):
 
 
 def test_emulated_log10_pow10_accuracy():
-    """csrc/tl_math.h against glibc: <= 2 ulp (log10), <= 3 ulp (table-driven log10), <= 1 ulp (pow10) over the encoder's ranges."""
+    """csrc/tl_math.h against glibc: <= 2 ulp (log10), <= 1 ulp (pow10) over the encoder's ranges."""
     import math
     L = E.lib()
     rng = np.random.default_rng(0)
@@ -89,16 +89,6 @@ def test_emulated_log10_pow10_accuracy():
     # the straight-line variant used on clamped spectra is the same function on positive normals, bit for bit
     for x in np.concatenate([10 ** rng.uniform(-20, 12, 20000), 1 + rng.uniform(-0.1, 0.1, 5000), [1.0, 1e-20, 0.5, 2.0]]):
         assert np.float64(L.emu_log10_pn(float(x))).view(np.int64) == np.float64(L.emu_log10(float(x))).view(np.int64)
-    # the table-driven logarithm of the psy kernel (power spectrum, spike levels): within 3 ulp of glibc, exact at 1
-    import ctypes as C
-    L.emu_log10_tab.restype = C.c_double
-    L.emu_log10_tab.argtypes = [C.c_double]
-    worst = 0
-    for x in np.concatenate([10 ** rng.uniform(-20, 12, 40000), 1 + rng.uniform(-0.1, 0.1, 10000), 1 + rng.uniform(-0.01, 0.01, 10000),
-                             [1e-20, 0.5, 2.0, 0.99609375, 1.0078125, 0.6875, 1.375]]):
-        a, b = L.emu_log10_tab(float(x)), math.log10(float(x))
-        worst = max(worst, abs(int(np.float64(a).view(np.int64)) - int(np.float64(b).view(np.int64))))
-    assert worst <= 3 and L.emu_log10_tab(1.0) == 0.0
     worst = 0
     for x in rng.uniform(-20, 25, 20000):
         a, b = L.emu_pow10(float(x)), math.pow(10.0, float(x))
