@@ -232,7 +232,6 @@ TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
 // collide (16 lanes at stride 16 doubles would share one bank pair; the XOR gives each its own).
 #define TL_EX(i) ((i) ^ (((i) >> 4) & 15))
 struct TlWaveLds {
-    static constexpr bool kSplit = false;
     // Stage-exclusive 8 KB: [PCM history | frame] + filterbank scratch  ->  FHT buffer / energy (and, once the
     // energies are dead, the masker lists and thresholds)  ->  the frame being packed.
     union alignas(16) {
@@ -270,7 +269,6 @@ struct TlWaveLds {
 // Per-wave LDS of the encode kernel of the split path (models 1 and 3 run in their own kernel): PCM staging / frame being
 // packed, the filterbank's window-output scratch and the small per-subband arrays.
 struct TlMainLds {
-    static constexpr bool kSplit = false;
     static constexpr int kFbBatch = TL_FB_BATCH_MAIN;
     static constexpr bool kFrameParallel = true;
     union alignas(16) {
@@ -298,7 +296,6 @@ struct TlMainLds {
 // (psycho_1.c:568-581: A = spike level; psycho_3.c:163-183,409-432: A = strongest line of the subband).
 // Per-wave LDS of the psy kernel (models 1 and 3): TlWaveLds without what only the rest of the encoder needs.
 struct TlPsyLds {
-    static constexpr bool kSplit = true;
     struct { double fft[TL_FFT_WORDS]; } u;
     TlPsyOut *po;                       // where this unit's result goes (HBM)
     double tone_x[TL_TONE_MAX];
@@ -833,10 +830,9 @@ TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *
 #endif
         for (int j = 0; j < 16; j++) sum += 1073741824 * e[j];
         const double spk = 10.0 * tl_log10_pn(sum);
-        if constexpr (W::kSplit) { TlPsyOut *po = w.po; po->a[ch][lane] = spk; }       // final as it is: straight to the record (nothing to park)
-        else w.spike[lane] = spk;
-    }
-    if constexpr (W::kSplit) { if (lane >= 30 && lane < 32) { TlPsyOut *po = w.po; po->a[ch][lane] = 0.0; } }
+        TlPsyOut *po = w.po;
+        po->a[ch][lane] = spk;                                      // final as it is: straight to the record (nothing to park)
+    } else if (lane < 32) { TlPsyOut *po = w.po; po->a[ch][lane] = 0.0; }
     TL_LANES_END
 
     // ---- tonal components (psycho_1.c:267-340) ----
@@ -1160,15 +1156,9 @@ TL_FN void tl_psy1_thresholds(W &w, const double *TL_RESTRICT db, const TlConfig
         else {
             m = tl_min_rows(TL_LTG(w), j0, n, 0.0, true);
         }
-        if constexpr (W::kSplit) {                                  // the encode kernel finishes the line (tl_encode_frame, TL_PSY_EXT)
-            TlPsyOut *po = w.po;
-            po->m[ch][lane] = m;
-        } else {
-            double max = C->scale_db[w.minidx[ch][lane]];
-            if (w.spike[lane] > max) max = w.spike[lane];
-            w.smr[ch][lane] = max - m;
-        }
-    } else if constexpr (W::kSplit) { if (lane < 32) { TlPsyOut *po = w.po; po->m[ch][lane] = 0.0; } }      // subbands the model leaves alone
+        TlPsyOut *po = w.po;                                        // the encode kernel finishes the line (tl_encode_frame, TL_PSY_EXT):
+        po->m[ch][lane] = m;                                        // SMR = max(spike, scale level) - m, psycho_1.c:575-580
+    } else if (lane < 32) { TlPsyOut *po = w.po; po->m[ch][lane] = 0.0; }      // subbands the model leaves alone
     TL_LANES_END
 }
 
@@ -1413,7 +1403,7 @@ TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     }
     // ---- park channel 0 ----
     PV(double, wt0); PV(int, r0); PV(int, r1);
-    PA(double, pvp, 8); PV(int, pcc); PV(int, ptl); PV(double, ptx0); PV(double, ptx1); PV(double, pspk);
+    PA(double, pvp, 8); PV(int, pcc); PV(int, ptl); PV(double, ptx0); PV(double, ptx1);
     if (TL_EXP_LEVEL < 3) tl_psy1_weights(w, nbands, wt0);
     TL_LANES_BEGIN
     L(r0) = lane < nbands ? (int)w.bandoff[lane] : 0; L(r1) = lane < nbands ? (int)w.bandoff[lane + 1] : 0;
@@ -1426,7 +1416,6 @@ TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     L(pcc) = (int)((uint32_t)(uint16_t)w.conf_c[lane] | ((uint32_t)(uint16_t)w.conf_c[hi] << 16));
     L(ptl) = (int)((uint32_t)(uint16_t)w.tlist[lane] | ((uint32_t)(uint16_t)w.tlist[hi] << 16));
     L(ptx0) = w.tone_x[lane]; L(ptx1) = w.tone_x[hi];
-    if constexpr (!W::kSplit) L(pspk) = w.spike[lane & 31];
     TL_LANES_END
     // ---- channel 1's front; a dead-head channel 1 is finished in the plain order first ----
     const TlPsy1Ch s1 = tl_psy1_front(w, T, db, C, pv, 1, sp1);
@@ -1478,7 +1467,6 @@ TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     const int hi = 64 + lane < TL_TONE_MAX ? 64 + lane : 0;
     w.conf_c[lane] = (int16_t)(L(pcc) & 0xffff); w.tlist[lane] = (int16_t)(L(ptl) & 0xffff); w.tone_x[lane] = L(ptx0);
     if (64 + lane < TL_TONE_MAX) { w.conf_c[hi] = (int16_t)((uint32_t)L(pcc) >> 16); w.tlist[hi] = (int16_t)((uint32_t)L(ptl) >> 16); w.tone_x[hi] = L(ptx1); }
-    if constexpr (!W::kSplit) { if (lane < 32) w.spike[lane] = L(pspk); }
     TL_LANES_END
     TL_LANES_BEGIN
     for (int i = lane; i < s0.nconf; i += 64) { const int cc = w.conf_c[i]; if (!((cc >> 13) & 1)) w.ptype[cc & 511] = TL_T_TONE; }
@@ -1502,13 +1490,8 @@ TL_FN int tl_psy3_front(W &w, const TlTables *TL_RESTRICT T, const double *TL_RE
 
     // power[1..512] (psycho_3.c:152-160); power[0] is an uninitialised slot in the reference, pinned
     // to 0.0 (oracle/mp2_oracle.c:psy3_run)
-    // and Lsb (psycho_3.c:163-183; line 512 is skipped, see oracle) -> w.spike.  A subband's 16 lines sit in one row of
+    // and the strongest line Xmax of each subband (psycho_3.c:163-183; line 512 is skipped, see oracle) -> the output record.  A subband's 16 lines sit in one row of
     // 16 lanes, so its maximum is a row reduction of the values just computed (no strided re-read of px).
-    if constexpr (!W::kSplit) {
-        TL_LANES_BEGIN
-        if (lane < 32) w.nsum[lane] = C->scale_db[w.minidx[ch][lane]];    // one table round trip for all subbands (nsum is free here)
-        TL_LANES_END
-    }
     PA(double, pxa, 8);
     TL_LANES_BEGIN
     for (int h = 0; h < 2; h++) {                                   // four lines per lane at a time
@@ -1542,8 +1525,8 @@ TL_FN int tl_psy3_front(W &w, const TlTables *TL_RESTRICT T, const double *TL_RE
         if ((lane & 15) == 15) {
             const int sb = (lane + 64 * it) >> 4;
             const double xmax = TL_DBMIN < L(pxm) ? L(pxm) : TL_DBMIN;
-            if constexpr (W::kSplit) { TlPsyOut *po = w.po; po->a[ch][sb] = xmax; }      // the encode kernel takes the maximum with the scalefactor level
-            else { const double val = w.nsum[sb]; w.spike[sb] = xmax > val ? xmax : val; }
+            TlPsyOut *po = w.po;
+            po->a[ch][sb] = xmax;                                   // the encode kernel takes the maximum with the scalefactor level (psycho_3.c:180-182)
         }
         TL_LANES_END
     }
@@ -1854,8 +1837,8 @@ TL_FN void tl_psy3_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_R
         double m = 999999.9;
         const int j0 = C->p3_sb_j0[lane], n = C->p3_sb_n[lane];
         m = tl_min_rows(TL_LTG(w), j0, n, m, false);
-        if constexpr (W::kSplit) { TlPsyOut *po = w.po; po->m[ch][lane] = m; }
-        else w.smr[ch][lane] = w.spike[lane] - m;
+        TlPsyOut *po = w.po;
+        po->m[ch][lane] = m;
     }
     TL_LANES_END
 }
@@ -1881,7 +1864,7 @@ TL_FN void tl_psy3_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     long long *sp0 = sp ? sp + 8 : nullptr, *sp1 = sp ? sp + 16 : nullptr;
     const int nconf0 = tl_psy3_front(w, T, db, C, pv, 0, sp0);
     PV(double, es0); PV(double, cg0); PV(int, r0); PV(int, r1);
-    PA(double, pvp, 8); PV(int, pcc); PV(double, ptx0); PV(double, ptx1); PV(double, pspk);
+    PA(double, pvp, 8); PV(int, pcc); PV(double, ptx0); PV(double, ptx1);
     tl_psy3_moments(w, nb, es0, cg0);
     TL_LANES_BEGIN
     L(r0) = lane < nb ? (int)w.bandoff[lane] : 0; L(r1) = lane < nb ? (int)w.bandoff[lane + 1] : 0;
@@ -1892,7 +1875,6 @@ TL_FN void tl_psy3_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     const int hi = 64 + lane < TL_TONE_MAX ? 64 + lane : 0;
     L(pcc) = (int)((uint32_t)(uint16_t)w.conf_c[lane] | ((uint32_t)(uint16_t)w.conf_c[hi] << 16));
     L(ptx0) = w.tone_x[lane]; L(ptx1) = w.tone_x[hi];
-    if constexpr (!W::kSplit) L(pspk) = w.spike[lane & 31];
     TL_LANES_END
     const int nconf1 = tl_psy3_front(w, T, db, C, pv, 1, sp1);
     PV(double, es1); PV(double, cg1); PV(double, bsum); PV(double, bsum1);
@@ -1914,7 +1896,6 @@ TL_FN void tl_psy3_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     const int hi = 64 + lane < TL_TONE_MAX ? 64 + lane : 0;
     w.conf_c[lane] = (int16_t)(L(pcc) & 0xffff); w.tone_x[lane] = L(ptx0);
     if (64 + lane < TL_TONE_MAX) { w.conf_c[hi] = (int16_t)((uint32_t)L(pcc) >> 16); w.tone_x[hi] = L(ptx1); }
-    if constexpr (!W::kSplit) { if (lane < 32) w.spike[lane] = L(pspk); }
     TL_LANES_END
     tl_psy3_back(w, db, C, 0, nconf0, bsum, es0, cg0, sp0);
 }
