@@ -495,6 +495,7 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         if (p == 1 || p == 3) {
             // persistent waves, twelve per CU (three per SIMD) in both kernels; they take (stream, frame) units off a counter
             const long units = (long)b->n_list[p] * nframes;
+            if (units > (1L << 24)) return TLB_ERR_ARG;             // the unit counters count 64 per unit in 32 bits (tl_next_unit)
             HIPCHK(hipMemsetAsync(b->d_work, 0, sizeof(int32_t) * 2, st));
             long pb = (units + TL_PSY_WAVES - 1) / TL_PSY_WAVES;
             if (pb > (12L / TL_PSY_WAVES) * b->num_cu) pb = (12L / TL_PSY_WAVES) * b->num_cu;

@@ -181,6 +181,24 @@ def _full_size(M, nstreams, nframes, psy, nbase, oracle_samples):
     b.close()
 
 
+def test_baseline_configs4_mixed_batch(M):
+    """BASELINE configs[4]: 32 kHz mono 64 kbps and 48 kHz stereo 192 kbps streams INTERLEAVED in one batch, psy model 4 (and
+    the same with model 2, which the reference's own setter can select), against the oracle byte for byte; fed in two calls."""
+    nstreams, nframes = 64, 10
+    for psy in (4, 2):
+        cfgs = [M.StreamConfig(samplerate=32000, mode="m", bitrate=64, psy_model=psy) if s % 2 == 0
+                else M.StreamConfig(samplerate=48000, mode="s", bitrate=192, psy_model=psy) for s in range(nstreams)]
+        pcm = np.stack([gen_pcm(7000 + s, (0, 7)[(s // 2) % 2], 0, nframes) for s in range(nstreams)], axis=1)
+        b = M.Batch(cfgs)
+        g1, _ = b.encode(pcm[:4])
+        g2, _ = b.encode(pcm[4:])
+        tail = b.flush()
+        for s, c in enumerate(cfgs):
+            ref, _ = O.oracle_stream(pcm[:, s], samplerate=c.samplerate, mode=c.mode, kbps=c.bitrate, psy=psy)
+            assert g1[s] + g2[s] + tail[s] == ref, (psy, s)
+        b.close()
+
+
 def test_full_size_properties(M):
     """BASELINE configs[1] size (4096 streams, psy 1): size-independent properties instead of a full oracle run -- identical
     inputs give identical frames wherever they sit in the batch, every frame starts with the sync header and has the right
