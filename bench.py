@@ -55,6 +55,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements after the headline")
     ap.add_argument("--dry-run", action="store_true", help="CPU emulation over gloo: plumbing check only, not a measurement")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="collective backend of the ranks; gloo (with ranks sharing GPUs: device = LOCAL_RANK mod device count) is for smoke-testing "
+                         "the multi-rank path on a box with fewer GPUs than ranks -- its value is not a scaling measurement")
     return ap.parse_args(argv)
 
 
@@ -176,6 +179,7 @@ class GpuRun:
         self.out = torch.zeros((F, S, self.batch.out_stride), dtype=torch.uint8, device="cuda")
         self.stream = torch.cuda.current_stream()
         self.F, self.S, self.torch, self.np = F, S, torch, np
+        self.cdev = "cuda"
 
     def step(self, i):
         self.batch.encode_device(self.pcm[i & 1].data_ptr(), self.F, self.out.data_ptr(), stream=self.stream.cuda_stream)
@@ -193,7 +197,7 @@ class GpuRun:
                 self.step(warmup + i)
                 evs[i][1].record(self.stream)
 
-        elapsed, own = shard.timed_region_detail(dist, run, device_sync=torch.cuda.synchronize, device="cuda")
+        elapsed, own = shard.timed_region_detail(dist, run, device_sync=torch.cuda.synchronize, device=self.cdev)
         kernel_ms = float(self.np.mean([a.elapsed_time(b) for a, b in evs]))
         self.stage_ms = self.batch.last_stage_ms()      # (psy kernel, encode + finish kernels) of the last launch, models 1/3
         return elapsed, own, kernel_ms
@@ -261,17 +265,24 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback; --dry-run only checks the plumbing)")
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    rank, local_rank, world_env, dist = shard.init_from_env("nccl")      # "nccl" is RCCL on ROCm
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and int(os.environ.get("LOCAL_RANK", "0")) >= ndev:
+        raise SystemExit(f"bench.py: rank needs GPU {os.environ.get('LOCAL_RANK')} but the box has {ndev} (RCCL wants one GPU per rank)")
+    dev_index = int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev)
+    torch.cuda.set_device(dev_index)
+    rank, local_rank, world_env, dist = shard.init_from_env(args.backend, device_index=dev_index)      # "nccl" is RCCL on ROCm
+    local_rank = dev_index
+    cdev = "cuda" if args.backend == "nccl" else "cpu"          # where the collectives' few scalars live
     assert world_env == world
     observed_world = dist.get_world_size() if dist is not None else 1
 
     run = GpuRun(M, torch, np, gen_pcm, shard.weak_stream_ids(rank, S), F, args.mode, psy, local_rank)
+    run.cdev = cdev
     elapsed, own, kernel_ms = run.timed(dist, shard, args.warmup, args.steps)
     last_ms = run.batch.last_kernel_ms()
     run.check()
     # per-rank (frames, own seconds): the only exchanged payload besides barriers
-    per_rank = shard.gather_floats(dist, [S * F * args.steps, own], device="cuda")
+    per_rank = shard.gather_floats(dist, [S * F * args.steps, own], device=cdev)
     run_stage_ms = run.stage_ms
     run.close()
 
@@ -315,7 +326,7 @@ def main():
                        "frames_per_stream_timed": F * args.steps, "frames_per_stream_warmup": F * args.warmup,
                        "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
             "realtime_streams": round(value / (FS / 1152.0), 1),
-            "world_size_observed": observed_world, "collective_backend": "rccl (torch.distributed nccl)" if dist is not None else None,
+            "world_size_observed": observed_world, "collective_backend": ("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo (smoke test: ranks may share GPUs)") if dist is not None else None,
             "per_gpu_frames_per_s": [round(p[0] / p[1], 1) for p in per_rank],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,

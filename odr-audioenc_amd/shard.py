@@ -6,7 +6,7 @@ import os
 import time
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, device_index=None):
     """-> (rank, local_rank, world, dist or None).  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -21,7 +21,7 @@ def init_from_env(backend=None):
     if not dist.is_initialized():
         kw = {}
         if backend == "nccl":
-            kw["device_id"] = torch.device("cuda", local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank if device_index is None else device_index)
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world, dist
 
