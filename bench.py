@@ -233,7 +233,8 @@ def pcie_inclusive(M, np, gen_pcm, F, psy, mode, local_rank, streams, reps=3):
     L.tlb_host_free(p_out)
     b.close()
     return {"value": round(reps * F * streams / dt, 1), "unit": "frames/s", "what": "tlb_encode_host, pinned host buffers: "
-            f"{n_in / 1e6:.0f} MB PCM in + {n_out / 1e6:.0f} MB frames out over PCIe per call, synchronous", "streams": streams,
+            f"{n_in / 1e6:.0f} MB PCM in + {n_out / 1e6:.0f} MB frames out over PCIe per call (copy-in, kernels and copy-out of four chunks of frames "
+            "overlapped on three streams inside the library; the call returns when everything is back on the host)", "streams": streams,
             "frames_per_call": F, "gbytes_per_s_over_pcie": round(reps * (n_in + n_out) / dt / 1e9, 2)}
 
 

@@ -21,6 +21,7 @@
 static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 
 #define TL_WAVES_PER_BLOCK 4
+#define TLB_HOST_CHUNKS 4            // tlb_encode_host pipelines a big call in this many chunks of frames
 
 // ---- kernels of the encode path ------------------------------------------------------------------------------------------
 // One wavefront per stream.  Two shapes:
@@ -301,6 +302,8 @@ struct tlb_batch {
     // feeds one frame per call (the legacy shim) pays for no allocation after its first frame
     void *stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // pcm, out, xpad, xpad_len, taps; [5] = TlPsyOut records, [6] = ScF-CRC bytes
     size_t stage_cap[7] = {0, 0, 0, 0, 0, 0, 0};
+    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;   // host-buffer entry point: copy-in / kernels / copy-out
+    hipEvent_t ev_in[TLB_HOST_CHUNKS] = {}, ev_run[TLB_HOST_CHUNKS] = {};
     uint32_t *d_newpend = nullptr;               // split path: the launch's last frame of every stream
     int32_t *d_work = nullptr;                   // unit counters of the persistent kernels
     int num_cu = 256;
@@ -350,6 +353,10 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_pseq_tmp) (void)hipFree(b->d_pseq_tmp);
     for (int p = 0; p < 4; p++) if (b->d_list[p]) (void)hipFree(b->d_list[p]);
     for (int k = 0; k < 7; k++) if (b->stage[k]) (void)hipFree(b->stage[k]);
+    for (int i = 0; i < TLB_HOST_CHUNKS; i++) { if (b->ev_in[i]) (void)hipEventDestroy(b->ev_in[i]); if (b->ev_run[i]) (void)hipEventDestroy(b->ev_run[i]); }
+    if (b->s_in) (void)hipStreamDestroy(b->s_in);
+    if (b->s_run) (void)hipStreamDestroy(b->s_run);
+    if (b->s_out) (void)hipStreamDestroy(b->s_out);
     if (b->d_newpend) (void)hipFree(b->d_newpend);
     if (b->d_work) (void)hipFree(b->d_work);
     if (b->d_psy2_tables) (void)hipFree(b->d_psy2_tables);
@@ -539,20 +546,45 @@ int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t
     int16_t *d_pcm = (int16_t *)b->stage[0]; uint8_t *d_out = (uint8_t *)b->stage[1];
     uint8_t *d_xpad = with_xpad ? (uint8_t *)b->stage[2] : nullptr; int32_t *d_xl = with_xpad ? (int32_t *)b->stage[3] : nullptr;
     TlTaps *d_taps = taps ? (TlTaps *)b->stage[4] : nullptr;
-    // copies and the launch are queued on the null stream; with pinned host buffers (tlb_host_alloc) the copies run at
-    // link rate and nothing blocks until the final synchronisation
-    HIPCHK(hipMemcpyAsync(d_pcm, pcm, n_pcm, hipMemcpyHostToDevice, nullptr));
-    if (with_xpad) {
-        HIPCHK(hipMemcpyAsync(d_xpad, xpad, slots * TL_MAX_XPAD, hipMemcpyHostToDevice, nullptr));
-        HIPCHK(hipMemcpyAsync(d_xl, xpad_len, slots * sizeof(int32_t), hipMemcpyHostToDevice, nullptr));
+    // Big calls go through in up to four chunks of whole frames on three streams: while the kernels of chunk c run, chunk c+1
+    // comes in over PCIe and chunk c-1 goes out (the link is full duplex; with pinned host buffers, tlb_host_alloc, the
+    // copies run at link rate).  The kernels themselves stay in frame order on one stream -- the streams' state passes from
+    // chunk to chunk.  Small calls (the legacy shim: one frame) and tap runs are one chunk.
+    const int nchunks = (taps || n_pcm < (8u << 20) || nframes < 2) ? 1 : (nframes < TLB_HOST_CHUNKS ? nframes : TLB_HOST_CHUNKS);
+    if (!b->s_in) {
+        HIPCHK(hipStreamCreateWithFlags(&b->s_in, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&b->s_run, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&b->s_out, hipStreamNonBlocking));
+        for (int i = 0; i < TLB_HOST_CHUNKS; i++) { HIPCHK(hipEventCreateWithFlags(&b->ev_in[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b->ev_run[i], hipEventDisableTiming)); }
     }
-    HIPCHK(hipMemsetAsync(d_out, 0, n_out, nullptr));              // bytes the kernel does not write (slot 0 of the first call, tails of short frames) read as 0
-    if (taps) HIPCHK(hipMemsetAsync(d_taps, 0, slots * sizeof(TlTaps), nullptr));
-    int rc = tlb_launch(b, d_pcm, nframes, d_xpad, d_xl, d_out, d_taps, nullptr);
-    if (rc != TLB_OK) return rc;
-    HIPCHK(hipMemcpyAsync(out, d_out, n_out, hipMemcpyDeviceToHost, nullptr));
-    if (taps) HIPCHK(hipMemcpyAsync(taps, d_taps, slots * sizeof(TlTaps), hipMemcpyDeviceToHost, nullptr));
-    HIPCHK(hipStreamSynchronize(nullptr));
+    // TlPsyOut / ScF-CRC scratch sized for the largest chunk up front (tlb_launch would otherwise re-allocate between chunks)
+    const int per = (nframes + nchunks - 1) / nchunks;
+    if (b->n_list[1] || b->n_list[3]) {
+        HIPCHK(stage_reserve(b, 5, (size_t)per * (size_t)b->nstreams * sizeof(TlPsyOut)));
+        HIPCHK(stage_reserve(b, 6, (size_t)per * (size_t)b->nstreams * 4));
+    }
+    HIPCHK(hipMemsetAsync(d_out, 0, n_out, b->s_in));              // bytes the kernels do not write (slot 0 of the first call, tails of short frames) read as 0
+    if (taps) HIPCHK(hipMemsetAsync(d_taps, 0, slots * sizeof(TlTaps), b->s_in));
+    for (int c = 0, f0 = 0; c < nchunks; c++, f0 += per) {
+        const int nf = f0 + per <= nframes ? per : nframes - f0;
+        const size_t o = (size_t)f0 * (size_t)b->nstreams, n = (size_t)nf * (size_t)b->nstreams;
+        HIPCHK(hipMemcpyAsync(d_pcm + o * 2304, pcm + o * 2304, n * 2304 * sizeof(int16_t), hipMemcpyHostToDevice, b->s_in));
+        if (with_xpad) {
+            HIPCHK(hipMemcpyAsync(d_xpad + o * TL_MAX_XPAD, xpad + o * TL_MAX_XPAD, n * TL_MAX_XPAD, hipMemcpyHostToDevice, b->s_in));
+            HIPCHK(hipMemcpyAsync(d_xl + o, xpad_len + o, n * sizeof(int32_t), hipMemcpyHostToDevice, b->s_in));
+        }
+        HIPCHK(hipEventRecord(b->ev_in[c], b->s_in));
+        HIPCHK(hipStreamWaitEvent(b->s_run, b->ev_in[c], 0));
+        int rc = tlb_launch(b, d_pcm + o * 2304, nf, with_xpad ? d_xpad + o * TL_MAX_XPAD : nullptr, with_xpad ? d_xl + o : nullptr,
+                            d_out + o * (size_t)b->out_stride, d_taps ? d_taps + o : nullptr, b->s_run);
+        if (rc != TLB_OK) { (void)hipDeviceSynchronize(); return rc; }
+        HIPCHK(hipEventRecord(b->ev_run[c], b->s_run));
+        HIPCHK(hipStreamWaitEvent(b->s_out, b->ev_run[c], 0));
+        HIPCHK(hipMemcpyAsync(out + o * (size_t)b->out_stride, d_out + o * (size_t)b->out_stride, n * (size_t)b->out_stride, hipMemcpyDeviceToHost, b->s_out));
+        if (taps) HIPCHK(hipMemcpyAsync((TlTaps *)taps + o, d_taps + o, n * sizeof(TlTaps), hipMemcpyDeviceToHost, b->s_out));
+    }
+    HIPCHK(hipStreamSynchronize(b->s_out));
+    HIPCHK(hipStreamSynchronize(b->s_run));
     return TLB_OK;
 }
 
