@@ -48,7 +48,7 @@ int toolame_encode_frame(short buffer[2][1152], unsigned char *xpad_data, size_t
 
 enum {
     TLB_OK = 0,
-    TLB_ERR_SAMPLERATE = 1,        /* SmpFrqIndex, common.c:118-144 (+ 44.1/22.05 kHz: padding slots unsupported) */
+    TLB_ERR_SAMPLERATE = 1,        /* SmpFrqIndex, common.c:118-144; the egress calls: a rate whose frames are no whole number of 24-ms units */
     TLB_ERR_MODE = 2,              /* toolame.c:195-197 */
     TLB_ERR_PSY = 3,               /* toolame.c:204-207 */
     TLB_ERR_BITRATE = 4,           /* common.c:95-116 (the reference exit(-1)s; we return an error) */
@@ -60,7 +60,7 @@ enum {
 
 /* The six knobs odr-audioenc sets (src/odr-audioenc.cpp:687-722), per stream. */
 typedef struct {
-    long samplerate;               /* 48000, 32000, 24000, 16000 */
+    long samplerate;               /* 48000, 32000, 24000, 16000, 44100, 22050 */
     char mode;                     /* 's' stereo, 'j' joint stereo, 'd' dual channel, 'm' mono */
     int bitrate;                   /* kbps; 0 = the reference default (192 / 160) */
     int psy_model;                 /* 0, 1, 2, 3 (toolame.c:202-210); 4 = psycho_4.c, an extension of this API only: the
@@ -79,8 +79,10 @@ void tlb_destroy(tlb_batch *b);
 int tlb_reset(tlb_batch *b);                       /* back to the state right after tlb_create() */
 
 int tlb_nstreams(const tlb_batch *b);
-int tlb_frame_bytes(const tlb_batch *b, int stream);   /* 144000*kbps/fs: 384 @128k/48k, 576 @192k/48k ... */
-int tlb_out_stride(const tlb_batch *b);                /* max frame_bytes over the batch, multiple of 4 */
+int tlb_frame_bytes(const tlb_batch *b, int stream);   /* 144000*kbps/fs: 384 @128k/48k, 576 @192k/48k ...; at 44.1 / 22.05 kHz the frames
+                                                          WITHOUT a padding slot (417 @128k/44.1k) -- some frames are one byte longer,
+                                                          see the _len entry points */
+int tlb_out_stride(const tlb_batch *b);                /* longest frame over the batch, rounded up to a multiple of 4 */
 long tlb_frames_encoded(const tlb_batch *b);           /* per stream */
 
 /* Encode `nframes` frames of every stream, buffers resident in HBM.
@@ -97,6 +99,15 @@ long tlb_frames_encoded(const tlb_batch *b);           /* per stream */
  * on one stream (they share the streams' state and the batch's scratch buffers); at most 2^24 (stream, frame) pairs per call. */
 int tlb_encode_device(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d_xpad,
                       const int32_t *d_xpad_len, uint8_t *d_out, void *hip_stream);
+/* 44.1 and 22.05 kHz (libtoolame-dab encodes them; DAB itself does not use them, src/odr-audioenc.cpp:560-563): a frame is
+ * tlb_frame_bytes() or one byte more (padding slot, availbits.c:49-62, header bit 9).  The _len variants also report the length
+ * of the frame in every output slot (0: none): d_out_len int32 [nframes][nstreams] / out_len [nstreams] for the flush. */
+int tlb_encode_device_len(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d_xpad, const int32_t *d_xpad_len,
+                          uint8_t *d_out, int32_t *d_out_len, void *hip_stream);
+int tlb_encode_host_len(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t *xpad, const int32_t *xpad_len,
+                        uint8_t *out, int32_t *out_len, void *taps);
+int tlb_flush_host_len(tlb_batch *b, uint8_t *out, int32_t *out_len);
+int tlb_flush_device_len(tlb_batch *b, uint8_t *d_out, int32_t *d_out_len, void *hip_stream);
 /* Same with host buffers (synchronous; copies over PCIe).  `taps`, if not NULL, receives
  * [nframes][nstreams] TlTaps records (csrc/mp2_types.h) for stage-level parity tests. */
 int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t *xpad, const int32_t *xpad_len,

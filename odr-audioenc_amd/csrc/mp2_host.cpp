@@ -160,8 +160,8 @@ void tl_build_tables(TlTables *T)
 }
 
 int tl_psy2_slot(long samplerate)
-{   // one table set per distinct rate the device path supports
-    switch (samplerate) { case 48000: return 0; case 32000: return 1; case 24000: return 2; default: return 3; }
+{   // one table set per distinct rate the device path supports (TL_PSY2_SLOTS)
+    switch (samplerate) { case 48000: return 0; case 32000: return 1; case 24000: return 2; case 16000: return 3; case 44100: return 4; default: return 5; }
 }
 
 void tl_build_psy2_tables(TlPsy2Tables *P, long samplerate)
@@ -283,15 +283,17 @@ int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, 
     case 32000: C->version = 1; C->fs_idx = 2; break;
     case 24000: C->version = 0; C->fs_idx = 1; break;
     case 16000: C->version = 0; C->fs_idx = 2; break;
-    // 44100 / 22050 need padding slots (availbits.c:49-62); DAB does not use them
-    // (src/odr-audioenc.cpp:560-563 accepts 24000/48000 only) -- rejected by the device path.
+    // 44100 / 22050: frames of two lengths (padding slots, availbits.c:49-62).  DAB does not use them
+    // (src/odr-audioenc.cpp:560-563 accepts 24000/48000 only); the library does, like libtoolame-dab.
+    case 44100: C->version = 1; C->fs_idx = 0; break;
+    case 22050: C->version = 0; C->fs_idx = 0; break;
     default: return TL_ERR_SAMPLERATE;
     }
     // toolame.c:204-207 accepts 0..3; model 4 (psycho_4.c, unreachable through the reference's setter) is an extension of
     // the batched API only -- the legacy toolame_set_psy_model() shim keeps rejecting it
     if (psy < 0 || psy > 4) return TL_ERR_PSY;
     C->psy = psy;
-    C->psy2_tab = tl_psy2_slot(samplerate) + (psy == 4 ? 4 : 0);   // slots 0..3: psy 2, 4..7: psy 4
+    C->psy2_tab = tl_psy2_slot(samplerate) + (psy == 4 ? TL_PSY2_SLOTS : 0);   // slots 0..5: psy 2, 6..11: psy 4
     switch (mode) {                                               // toolame.c:174-200
     case 's': C->mode0 = 0; C->mode_ext0 = 0; break;
     case 'd': C->mode0 = 2; C->mode_ext0 = 0; break;
@@ -328,12 +330,12 @@ int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, 
         C->line[sb] = TL_LINE[C->tab * 32 + sb];
         C->nbal[sb] = sb < C->sblimit ? TL_NBAL[C->line[sb]] : 0;
     }
-    {   // slots per frame (availbits.c:36-67); the supported rates never need a padding slot
+    {   // slots per frame (availbits.c:36-67): `whole`, and the fraction that makes some frames one slot longer
         const double average = (1152.0 / kSfreq[C->version][C->fs_idx]) * ((double)kbps / 8.0);
         const int whole = (int)average;
-        if (average - (double)whole != 0) return TL_ERR_SAMPLERATE;
         C->frame_bytes = whole;
-        if (whole > TL_MAX_FRAME_BYTES || (whole & 3)) return TL_ERR_BITRATE;
+        C->pad_frac = average - (double)whole;
+        if (whole + (C->pad_frac != 0 ? 1 : 0) > TL_MAX_FRAME_BYTES) return TL_ERR_BITRATE;
         // the PAD of a frame must leave room for header (4), CRC-16 (2), the bit_alloc fields and the ScF-CRC: with less the
         // bit budget of toolame.c:292-301 goes negative (the reference then writes a broken frame); such a pad length is refused
         int bbal = 0;

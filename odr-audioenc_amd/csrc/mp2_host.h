@@ -20,6 +20,7 @@ enum {
 
 void tl_build_tables(TlTables *T);
 // psy-2 tables for a sample rate (48000/32000/24000/16000); returns the table slot 0..2 used as TlConfig::psy2_tab
+#define TL_PSY2_SLOTS 6      // sample rates with their own psy-2 / psy-4 tables: 48, 32, 24, 16, 44.1, 22.05 kHz
 int tl_psy2_slot(long samplerate);
 void tl_build_psy2_tables(TlPsy2Tables *P, long samplerate);
 void tl_build_psy4_tables(TlPsy2Tables *P, long samplerate);   // psy model 4 mapped onto the psy-2 record

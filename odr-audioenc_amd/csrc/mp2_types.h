@@ -57,7 +57,8 @@ struct TlTables {
 // Per-config constants.  (ref: toolame.c:120-262, common.c:76-144, encode_new.c:104-125)
 struct TlConfig {
     int32_t version, fs_idx, br_idx, kbps, nch, mode0, mode_ext0, tab, sblimit, jsbound0;
-    int32_t dab_ext, dab_length, psy, frame_bytes, br_per_ch;
+    int32_t dab_ext, dab_length, psy, frame_bytes, br_per_ch;   // frame_bytes: slots of a frame WITHOUT the padding slot (availbits.c:49 `whole`)
+    double pad_frac;             // availbits.c:50 `frac`: 0 at 48/32/24/16 kHz; at 44.1/22.05 kHz some frames carry one padding slot more
     int32_t p1_ncb, p1_sub, p3_cbands, psy2_tab;
     uint8_t line[32];            // alloc-table line per subband (255 above sblimit)
     uint8_t nbal[32];            // bits of the bit_alloc field per subband
@@ -113,7 +114,8 @@ struct TlStreamState {
     int16_t hist[2][TL_HIST];               // last 480 PCM samples per channel
     uint32_t pending[TL_MAX_FRAME_WORDS];   // previous frame, waiting for its ScF-CRC (toolame.c:527-542)
     int32_t frames_done;
-    int32_t pad_;
+    int32_t pending_len;                    // its length in bytes (frame_bytes, or one more: padding slot)
+    double slot_lag;                        // availbits.c:27-33 `slots.lag`, the padding recurrence's state after frames_done frames
 };
 
 // Optional per-frame stage taps for parity tests (written only when a tap buffer is given).
@@ -143,6 +145,7 @@ struct TlLaunch {
     const uint8_t *xpad;              // [nframes][nstreams][TL_MAX_XPAD] or null
     const int32_t *xpad_len;          // [nframes][nstreams] or null
     uint8_t *out;                     // [nframes][nstreams][out_stride]: slot f holds frame (f-1); slot 0 = pending
+    int32_t *out_len;                 // [nframes][nstreams] bytes of the frame in each slot (0: none), or null
     TlTaps *taps;                     // [nframes][nstreams] or null
     long long *stamps;                // [nframes][nstreams][32] cycle stamps (diagnostic builds) or null
     const TlPsy2Tables *psy2_tables;  // [*] indexed by TlConfig::psy2_tab, or null when no stream uses psy 2
@@ -150,6 +153,8 @@ struct TlLaunch {
     TlPsyOut *psy_out;                // [nframes][nstreams] psy kernel -> encode kernel (models 1 and 3), or null
     uint8_t *scfcrc;                  // [nframes][nstreams][4] ScF-CRC bytes of each frame (split path: encode kernel -> finish kernel)
     uint32_t *newpend;                // [nstreams][TL_MAX_FRAME_WORDS] last frame of the launch, before it becomes the pending one
+    uint8_t *padbits;                 // [nframes][nstreams] padding slot of each frame (tl_slots_stream), or null: no stream of the launch pads
+    double *newlag;                   // [nstreams] the slot recurrence's state after the launch (with padbits)
     int32_t *work;                    // [2] unit counters of the persistent kernels (psy, encode): waves take the next unit off them
     int32_t nstreams, nframes, out_stride, nlist;
 };

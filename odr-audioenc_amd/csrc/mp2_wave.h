@@ -2100,7 +2100,7 @@ template <int PSY, class W>
 TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
                            const TlConfig *TL_RESTRICT C, const TlPsy2Tables *TL_RESTRICT P2, TlPsy2State *TL_RESTRICT S2, const TlPsyOut *TL_RESTRICT PO,
                            const TlPcmView &pv, TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, const TlFrameOut &fo,
-                           const double *TL_RESTRICT enw_s, TlTaps *taps, long long *sp)
+                           const double *TL_RESTRICT enw_s, int padding, TlTaps *taps, long long *sp)
 {
     constexpr int FB = W::kFbBatch;
     const int nch = C->nch, sblimit = C->sblimit;
@@ -2334,7 +2334,7 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     TL_LANES_END
 
     // ---- K5: bit allocation (encode_new.c:733-886, :634-705, :1061-1187) ----
-    const int lg_frame = C->frame_bytes;
+    const int lg_frame = C->frame_bytes + padding;                  // availbits.c:64: (whole + extra) slots
     int adb = lg_frame * 8 - (C->dab_ext * 8 + (xpad_len ? xpad_len : 2) * 8);     // toolame.c:292-301
     int mode = C->mode0, mode_ext = C->mode_ext0, jsbound = C->jsbound0;
     // per-lane constants of the allocation loops
@@ -2546,7 +2546,7 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     const int c = lane & 1, sb = lane >> 1;
     if (lane == 0) {     // write_header (encode_new.c:356-373)
         uint32_t h = (0xfffu << 20) | ((uint32_t)C->version << 19) | (2u << 17) | (0u << 16)
-                   | ((uint32_t)C->br_idx << 12) | ((uint32_t)C->fs_idx << 10) | (0u << 9) | (0u << 8)
+                   | ((uint32_t)C->br_idx << 12) | ((uint32_t)C->fs_idx << 10) | ((uint32_t)padding << 9) | (0u << 8)
                    | ((uint32_t)mode << 6) | ((uint32_t)mode_ext << 4);
         TL_ATOMIC_OR(&frame[0], h);
     }
@@ -2768,31 +2768,54 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         if (lane < 4) fo.scfcrc[lane] = lane < C->dab_ext ? (uint8_t)w.ncentre[lane] : 0;
         TL_LANES_END
     } else {
+    // the previous frame has its own length (a padding slot more or less at 44.1 / 22.05 kHz); its ScF-CRC bytes sit
+    // 2 + dab_ext bytes before ITS end (toolame.c:530-532 writes them lg_frame bytes behind the current position)
+    const int prev_len = st->pending_len, ptail = prev_len - 2 - C->dab_ext, pwords = (prev_len + 3) >> 2;
     TL_LANES_BEGIN
-    for (int i = lane; i < nwords; i += 64) {
-        uint32_t prev = st->pending[i];
-        if (have_prev && out_prev) {
-            // overlay bytes [tail, tail+dab_ext) of the previous frame with this frame's ScF-CRC bytes
+    for (int i = lane; i < (nwords > pwords ? nwords : pwords); i += 64) {
+        if (have_prev && out_prev && i < pwords) {
+            uint32_t prev = st->pending[i];
             for (int k = 0; k < C->dab_ext; k++) {
-                int bp = tail + k;
+                int bp = ptail + k;
                 if ((bp >> 2) == i) {
                     int sh = 24 - 8 * (bp & 3);
                     prev = (prev & ~(0xffu << sh)) | ((uint32_t)(w.ncentre[k] & 0xff) << sh);
                 }
             }
             uint32_t le = tl_bswap(prev);
-            int rem = lg_frame - 4 * i;
+            int rem = prev_len - 4 * i;
             if (rem >= 4) ((uint32_t *)out_prev)[i] = le;
             else for (int b = 0; b < rem; b++) out_prev[4 * i + b] = (uint8_t)(le >> (8 * b));
         }
-        st->pending[i] = frame[i];
+        if (i < nwords) st->pending[i] = frame[i];
     }
+    TL_LANES_END
+    TL_LANES_BEGIN
+    if (lane == 0) st->pending_len = lg_frame;
     TL_LANES_END
     }
     TL_STAMP(sp, 7);
 }
 
 // ------------------------------------------------------------------------------------------
+// One step of the padding recurrence (availbits.c:49-62): does the next frame carry a padding slot?  fp64 as in the reference.
+TL_FN int tl_slot_step(double &lag, double frac)
+{
+    if (frac == 0) return 0;
+    if (lag > (frac - 1.0)) { lag -= frac; return 0; }
+    lag += (1 - frac);
+    return 1;
+}
+// Split path, 44.1 / 22.05 kHz only: the recurrence is sequential, the frames are not -- so one lane per stream runs it over
+// the launch's frames first and leaves every frame's padding bit for the units (and the state after the launch for the finish pass).
+TL_FN void tl_slots_stream(const TlLaunch &A, int s)
+{
+    const double frac = A.configs[A.stream_cfg[s]].pad_frac;
+    double lag = A.state[s].slot_lag;
+    for (int f = 0; f < A.nframes; f++) A.padbits[(size_t)f * (size_t)A.nstreams + (size_t)s] = (uint8_t)tl_slot_step(lag, frac);
+    A.newlag[s] = lag;
+}
+
 // A stream's PCM around frame f of a launch: the frame itself and the 480 samples per channel before it (the stream state
 // on the first frame of a launch, the previous input frame after).
 TL_FN TlPcmView tl_pcm_view(const TlLaunch &A, const TlStreamState *st, int s, int f)
@@ -2887,6 +2910,7 @@ TL_FN void tl_encode_stream(W &w, const TlBlockShared *TL_RESTRICT B, const TlLa
     TlStreamState *st = &A.state[s];
     const int nch = C->nch;
     int done = st->frames_done;
+    double lag = st->slot_lag;
     const TlFrameOut none = {nullptr, nullptr, nullptr};
     for (int f = 0; f < A.nframes; f++) {
         const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
@@ -2894,8 +2918,10 @@ TL_FN void tl_encode_stream(W &w, const TlBlockShared *TL_RESTRICT B, const TlLa
         TL_STAMP(A.stamps ? A.stamps + slot * 32 : nullptr, 31);        // frame begin, before the PCM staging
         tl_stage_pcm(w, pv, nch);
         const int xl = tl_stage_xpad(w, A, C, slot);
+        const int padding = tl_slot_step(lag, C->pad_frac);
+        if (A.out_len) { const int pl = done > 0 ? st->pending_len : 0; TL_LANES_BEGIN if (lane == 0) A.out_len[slot] = pl; TL_LANES_END }
         tl_encode_frame<PSY>(w, T, B, C, A.psy2_tables ? &A.psy2_tables[C->psy2_tab] : nullptr, A.psy2_state ? &A.psy2_state[s] : nullptr,
-                             nullptr, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, none, T->enwindow_s,
+                             nullptr, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, none, T->enwindow_s, padding,
                              A.taps ? &A.taps[slot] : nullptr, A.stamps ? A.stamps + slot * 32 : nullptr);
         done++;
     }
@@ -2907,7 +2933,7 @@ TL_FN void tl_encode_stream(W &w, const TlBlockShared *TL_RESTRICT B, const TlLa
             const int ch = i / (TL_HIST / 2), k = (i % (TL_HIST / 2)) * 2;
             *(uint32_t *)&st->hist[ch][k] = ch < nch ? *(const uint32_t *)(last + ch * 1152 + (1152 - TL_HIST) + k) : 0u;
         }
-        if (lane == 0) st->frames_done = done;
+        if (lane == 0) { st->frames_done = done; st->slot_lag = lag; }
         TL_LANES_END
     }
 }
@@ -2935,7 +2961,8 @@ TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const 
     fo.bytes = f + 1 < A.nframes ? A.out + (slot + (size_t)A.nstreams) * (size_t)A.out_stride : nullptr;     // waits in the next slot
     fo.words = f + 1 < A.nframes ? nullptr : A.newpend + (size_t)s * TL_MAX_FRAME_WORDS;
     fo.scfcrc = A.scfcrc + slot * 4;
-    tl_encode_frame<TL_PSY_EXT>(w, A.tables, B, C, nullptr, nullptr, &A.psy_out[slot], pv, st, xl, nullptr, false, fo, enw_s,
+    const int padding = A.padbits ? (int)A.padbits[slot] : 0;
+    tl_encode_frame<TL_PSY_EXT>(w, A.tables, B, C, nullptr, nullptr, &A.psy_out[slot], pv, st, xl, nullptr, false, fo, enw_s, padding,
                                 A.taps ? &A.taps[slot] : nullptr, sp);
 }
 
@@ -2945,29 +2972,36 @@ TL_FN void tl_finish_stream(const TlLaunch &A, int s)
 {
     const TlConfig *C = &A.configs[A.stream_cfg[s]];
     TlStreamState *st = &A.state[s];
-    const int lg_frame = C->frame_bytes, nwords = (lg_frame + 3) >> 2, dab_ext = C->dab_ext, nch = C->nch;
-    const int tail = lg_frame - 2 - dab_ext;
+    const int whole = C->frame_bytes, dab_ext = C->dab_ext, nch = C->nch;
     const bool have_prev = st->frames_done > 0;
+    const int prev_len = st->pending_len;
     uint8_t *out0 = A.out + (size_t)s * (size_t)A.out_stride;
+    // slot 0: the frame that was pending before the launch, with the ScF-CRC of the launch's first frame
     TL_LANES_BEGIN
     if (have_prev)
-        for (int i = lane; i < nwords; i += 64) {
+        for (int i = lane; i < ((prev_len + 3) >> 2); i += 64) {
             const uint32_t le = tl_bswap(st->pending[i]);
-            const int rem = lg_frame - 4 * i;
+            const int rem = prev_len - 4 * i;
             if (rem >= 4) ((uint32_t *)out0)[i] = le;
             else for (int b = 0; b < rem; b++) out0[4 * i + b] = (uint8_t)(le >> (8 * b));
         }
     TL_LANES_END
+    // slot f holds frame f-1 (slot 0: the old pending frame); frame f's ScF-CRC goes 2 + dab_ext bytes before the END of the
+    // frame in slot f -- whose length (a padding slot more or less at 44.1 / 22.05 kHz) comes from the slot recurrence
     TL_LANES_BEGIN
-    for (int f = lane; f < A.nframes; f += 64)
+    for (int f = lane; f < A.nframes; f += 64) {
+        const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
+        const int len = f > 0 ? whole + (A.padbits ? (int)A.padbits[slot - (size_t)A.nstreams] : 0) : prev_len;
         if (f > 0 || have_prev) {
-            const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
-            uint8_t *o = A.out + slot * (size_t)A.out_stride + tail;
+            uint8_t *o = A.out + slot * (size_t)A.out_stride + (len - 2 - dab_ext);
             for (int k = 0; k < dab_ext; k++) o[k] = A.scfcrc[slot * 4 + k];
         }
+        if (A.out_len) A.out_len[slot] = (f > 0 || have_prev) ? len : 0;
+    }
     TL_LANES_END
+    const int last_len = whole + (A.padbits ? (int)A.padbits[(size_t)(A.nframes - 1) * (size_t)A.nstreams + (size_t)s] : 0);
     TL_LANES_BEGIN
-    for (int i = lane; i < nwords; i += 64) st->pending[i] = A.newpend[(size_t)s * TL_MAX_FRAME_WORDS + i];
+    for (int i = lane; i < ((last_len + 3) >> 2); i += 64) st->pending[i] = A.newpend[(size_t)s * TL_MAX_FRAME_WORDS + i];
     TL_LANES_END
     {
         const int16_t *last = A.pcm + ((size_t)(A.nframes - 1) * (size_t)A.nstreams + (size_t)s) * 2304;
@@ -2976,7 +3010,7 @@ TL_FN void tl_finish_stream(const TlLaunch &A, int s)
             const int ch = i / (TL_HIST / 2), k = (i % (TL_HIST / 2)) * 2;
             *(uint32_t *)&st->hist[ch][k] = ch < nch ? *(const uint32_t *)(last + ch * 1152 + (1152 - TL_HIST) + k) : 0u;
         }
-        if (lane == 0) st->frames_done += A.nframes;
+        if (lane == 0) { st->frames_done += A.nframes; st->pending_len = last_len; if (A.padbits) st->slot_lag = A.newlag[s]; }
         TL_LANES_END
     }
 }

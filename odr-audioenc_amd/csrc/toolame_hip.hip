@@ -132,6 +132,14 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
     }
 }
 
+// slot recurrence of the split path (44.1 / 22.05 kHz streams only): one lane per stream (tl_slots_stream)
+__global__ void __launch_bounds__(256) tl_slots_kernel(TlLaunch A)
+{
+    const int k = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (k >= A.nlist) return;
+    tl_slots_stream(A, A.stream_list[k]);
+}
+
 // finish pass of the split path: one wave per stream (tl_finish_stream)
 __global__ void __launch_bounds__(256) tl_finish_kernel(TlLaunch A)
 {
@@ -263,14 +271,15 @@ __global__ void __launch_bounds__(256) tl_edi_pft_kernel(TlPftArgs A, const TlTa
 
 // pending frame (big-endian words in the stream state) -> bytes
 __global__ void tl_flush_kernel(const TlStreamState *state, const TlConfig *configs, const int32_t *stream_cfg,
-                                uint8_t *out, int nstreams, int out_stride)
+                                uint8_t *out, int32_t *out_len, int nstreams, int out_stride)
 {
     const int s = (int)blockIdx.x;
     if (s >= nstreams) return;
-    const int n = configs[stream_cfg[s]].frame_bytes;
     const bool any = state[s].frames_done > 0;
+    const int n = any ? state[s].pending_len : 0;                   // frame_bytes, or one more (padding slot)
     for (int i = (int)threadIdx.x; i < out_stride; i += (int)blockDim.x)
-        out[(size_t)s * out_stride + i] = (any && i < n) ? (uint8_t)(state[s].pending[i >> 2] >> (24 - 8 * (i & 3))) : 0;
+        out[(size_t)s * out_stride + i] = i < n ? (uint8_t)(state[s].pending[i >> 2] >> (24 - 8 * (i & 3))) : 0;
+    if (out_len && threadIdx.x == 0) out_len[s] = n;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -300,11 +309,13 @@ struct tlb_batch {
     bool timed = false;
     // device staging of the host-buffer entry point (tlb_encode_host): grow-only, created on first use, so a caller that
     // feeds one frame per call (the legacy shim) pays for no allocation after its first frame
-    void *stage[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // pcm, out, xpad, xpad_len, taps; [5] = TlPsyOut records, [6] = ScF-CRC bytes
-    size_t stage_cap[7] = {0, 0, 0, 0, 0, 0, 0};
+    void *stage[9] = {};                         // pcm, out, xpad, xpad_len, taps; [5] = TlPsyOut records, [6] = ScF-CRC bytes, [7] = padding bits, [8] = frame lengths (host entry)
+    size_t stage_cap[9] = {};
     hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;   // host-buffer entry point: copy-in / kernels / copy-out
     hipEvent_t ev_in[TLB_HOST_CHUNKS] = {}, ev_run[TLB_HOST_CHUNKS] = {};
     uint32_t *d_newpend = nullptr;               // split path: the launch's last frame of every stream
+    double *d_newlag = nullptr;                  // split path, 44.1 / 22.05 kHz: slot recurrence state after the launch
+    bool pads[4] = {false, false, false, false}; // some stream of the psy model's list has frames of two lengths
     int32_t *d_work = nullptr;                   // unit counters of the persistent kernels
     int num_cu = 256;
 };
@@ -352,13 +363,14 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_edi_state_tmp) (void)hipFree(b->d_edi_state_tmp);
     if (b->d_pseq_tmp) (void)hipFree(b->d_pseq_tmp);
     for (int p = 0; p < 4; p++) if (b->d_list[p]) (void)hipFree(b->d_list[p]);
-    for (int k = 0; k < 7; k++) if (b->stage[k]) (void)hipFree(b->stage[k]);
+    for (int k = 0; k < 9; k++) if (b->stage[k]) (void)hipFree(b->stage[k]);
     for (int i = 0; i < TLB_HOST_CHUNKS; i++) { if (b->ev_in[i]) (void)hipEventDestroy(b->ev_in[i]); if (b->ev_run[i]) (void)hipEventDestroy(b->ev_run[i]); }
     if (b->s_in) (void)hipStreamDestroy(b->s_in);
     if (b->s_run) (void)hipStreamDestroy(b->s_run);
     if (b->s_out) (void)hipStreamDestroy(b->s_out);
     if (b->d_newpend) (void)hipFree(b->d_newpend);
     if (b->d_work) (void)hipFree(b->d_work);
+    if (b->d_newlag) (void)hipFree(b->d_newlag);
     if (b->d_psy2_tables) (void)hipFree(b->d_psy2_tables);
     if (b->d_psy2_state) (void)hipFree(b->d_psy2_state);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -390,7 +402,10 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
             found = (int)uniq.size() - 1;
         }
         b->h_stream_cfg[s] = found;
-        if (b->h_configs[found].frame_bytes > b->out_stride) b->out_stride = b->h_configs[found].frame_bytes;
+        {
+            const int longest = (b->h_configs[found].frame_bytes + (b->h_configs[found].pad_frac != 0 ? 1 : 0) + 3) & ~3;
+            if (longest > b->out_stride) b->out_stride = longest;
+        }
         {
             const int unit = 3 * b->h_configs[found].kbps, fb = b->h_configs[found].frame_bytes;
             if (fb % unit) b->max_upf = 0;                          // 32 kHz: 1.5 units per frame -- not a DAB rate (odr-audioenc.cpp:560-563)
@@ -417,7 +432,7 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
     for (int p = 0; p < 4; p++) {
         std::vector<int32_t> ids;
         // kernel p serves psy model p; model 4 runs the psy-2 kernel on its own tables (mp2_host.cpp: tl_build_psy4_tables)
-        for (int s2 = 0; s2 < nstreams; s2++) { const int m = b->h_configs[b->h_stream_cfg[s2]].psy; if ((m == 4 ? 2 : m) == p) ids.push_back(s2); }
+        for (int s2 = 0; s2 < nstreams; s2++) { const int m = b->h_configs[b->h_stream_cfg[s2]].psy; if ((m == 4 ? 2 : m) == p) { ids.push_back(s2); b->pads[p] |= b->h_configs[b->h_stream_cfg[s2]].pad_frac != 0; } }
         b->n_list[p] = (int)ids.size();
         if (ids.empty()) continue;
         HIPCHK(hipMalloc(&b->d_list[p], sizeof(int32_t) * ids.size()));
@@ -426,14 +441,14 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
     bool any2 = false;
     for (auto &c : b->h_configs) any2 |= c.psy == 2 || c.psy == 4;
     if (any2) {
-        const long rates[4] = {48000, 32000, 24000, 16000};
-        std::vector<TlPsy2Tables> ht2(8);                            // slots 0..3: psy 2 per rate, 4..7: psy 4 per rate
-        for (int i = 0; i < 4; i++) {
+        const long rates[TL_PSY2_SLOTS] = {48000, 32000, 24000, 16000, 44100, 22050};
+        std::vector<TlPsy2Tables> ht2(2 * TL_PSY2_SLOTS);            // psy 2 per rate, then psy 4 per rate
+        for (int i = 0; i < TL_PSY2_SLOTS; i++) {
             tl_build_psy2_tables(&ht2[tl_psy2_slot(rates[i])], rates[i]);
-            tl_build_psy4_tables(&ht2[4 + tl_psy2_slot(rates[i])], rates[i]);
+            tl_build_psy4_tables(&ht2[TL_PSY2_SLOTS + tl_psy2_slot(rates[i])], rates[i]);
         }
-        HIPCHK(hipMalloc(&b->d_psy2_tables, sizeof(TlPsy2Tables) * 8));
-        HIPCHK(hipMemcpy(b->d_psy2_tables, ht2.data(), sizeof(TlPsy2Tables) * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc(&b->d_psy2_tables, sizeof(TlPsy2Tables) * ht2.size()));
+        HIPCHK(hipMemcpy(b->d_psy2_tables, ht2.data(), sizeof(TlPsy2Tables) * ht2.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMalloc(&b->d_psy2_state, sizeof(TlPsy2State) * (size_t)nstreams));
         HIPCHK(hipMemset(b->d_psy2_state, 0, sizeof(TlPsy2State) * (size_t)nstreams));
     }
@@ -441,6 +456,7 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
         HIPCHK(hipMalloc(&b->d_newpend, sizeof(uint32_t) * TL_MAX_FRAME_WORDS * (size_t)nstreams));
         HIPCHK(hipMemset(b->d_newpend, 0, sizeof(uint32_t) * TL_MAX_FRAME_WORDS * (size_t)nstreams));
         HIPCHK(hipMalloc(&b->d_work, sizeof(int32_t) * 2));
+        if (b->pads[1] || b->pads[3]) HIPCHK(hipMalloc(&b->d_newlag, sizeof(double) * (size_t)nstreams));
     }
     HIPCHK(hipEventCreate(&b->ev0));
     HIPCHK(hipEventCreate(&b->ev1));
@@ -475,7 +491,7 @@ int tlb_out_stride(const tlb_batch *b) { return b ? b->out_stride : 0; }
 long tlb_frames_encoded(const tlb_batch *b) { return b ? b->frames : 0; }
 
 static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d_xpad, const int32_t *d_xpad_len,
-                      uint8_t *d_out, TlTaps *d_taps, hipStream_t st, long long *d_stamps = nullptr)
+                      uint8_t *d_out, TlTaps *d_taps, hipStream_t st, long long *d_stamps = nullptr, int32_t *d_out_len = nullptr)
 {
     if (!b || !d_pcm || !d_out || nframes <= 0) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
@@ -483,7 +499,7 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
     memset(&A, 0, sizeof A);
     A.tables = b->d_tables; A.configs = b->d_configs; A.stream_cfg = b->d_stream_cfg; A.state = b->d_state;
     A.pcm = d_pcm; A.xpad = d_xpad_len ? d_xpad : nullptr; A.xpad_len = d_xpad ? d_xpad_len : nullptr;
-    A.out = d_out; A.taps = d_taps; A.stamps = d_stamps;
+    A.out = d_out; A.out_len = d_out_len; A.taps = d_taps; A.stamps = d_stamps;
     A.psy2_tables = b->d_psy2_tables; A.psy2_state = b->d_psy2_state;
     A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride;
     if (b->n_list[1] || b->n_list[3]) {
@@ -492,6 +508,7 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         HIPCHK(stage_reserve(b, 5, (size_t)nframes * (size_t)b->nstreams * sizeof(TlPsyOut)));
         HIPCHK(stage_reserve(b, 6, (size_t)nframes * (size_t)b->nstreams * 4));
         A.psy_out = (TlPsyOut *)b->stage[5]; A.scfcrc = (uint8_t *)b->stage[6]; A.newpend = b->d_newpend; A.work = b->d_work;
+        if (b->pads[1] || b->pads[3]) HIPCHK(stage_reserve(b, 7, (size_t)nframes * (size_t)b->nstreams));
     }
     HIPCHK(hipEventRecord(b->ev0, st));
     b->have_mid = false;
@@ -503,6 +520,8 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
             // persistent waves, twelve per CU (three per SIMD) in both kernels; they take (stream, frame) units off a counter
             const long units = (long)b->n_list[p] * nframes;
             if (units > (1L << 24)) return TLB_ERR_ARG;             // the unit counters count 64 per unit in 32 bits (tl_next_unit)
+            A.padbits = b->pads[p] ? (uint8_t *)b->stage[7] : nullptr; A.newlag = b->d_newlag;
+            if (b->pads[p]) { hipLaunchKernelGGL(tl_slots_kernel, dim3((unsigned)((b->n_list[p] + 255) / 256)), dim3(256), 0, st, A); HIPCHK(hipGetLastError()); }
             HIPCHK(hipMemsetAsync(b->d_work, 0, sizeof(int32_t) * 2, st));
             long pb = (units + TL_PSY_WAVES - 1) / TL_PSY_WAVES;
             if (pb > (12L / TL_PSY_WAVES) * b->num_cu) pb = (12L / TL_PSY_WAVES) * b->num_cu;
@@ -530,9 +549,20 @@ int tlb_encode_device(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
 {
     return tlb_launch(b, d_pcm, nframes, d_xpad, d_xpad_len, d_out, nullptr, (hipStream_t)hip_stream);
 }
+int tlb_encode_device_len(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d_xpad, const int32_t *d_xpad_len,
+                          uint8_t *d_out, int32_t *d_out_len, void *hip_stream)
+{
+    return tlb_launch(b, d_pcm, nframes, d_xpad, d_xpad_len, d_out, nullptr, (hipStream_t)hip_stream, nullptr, d_out_len);
+}
 
 int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t *xpad, const int32_t *xpad_len,
                     uint8_t *out, void *taps)
+{
+    return tlb_encode_host_len(b, pcm, nframes, xpad, xpad_len, out, nullptr, taps);
+}
+
+int tlb_encode_host_len(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t *xpad, const int32_t *xpad_len,
+                        uint8_t *out, int32_t *out_len, void *taps)
 {
     if (!b || !pcm || !out || nframes <= 0) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
@@ -543,6 +573,8 @@ int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t
     HIPCHK(stage_reserve(b, 1, n_out));
     if (with_xpad) { HIPCHK(stage_reserve(b, 2, slots * TL_MAX_XPAD)); HIPCHK(stage_reserve(b, 3, slots * sizeof(int32_t))); }
     if (taps) HIPCHK(stage_reserve(b, 4, slots * sizeof(TlTaps)));
+    if (out_len) HIPCHK(stage_reserve(b, 8, slots * sizeof(int32_t)));
+    int32_t *d_len = out_len ? (int32_t *)b->stage[8] : nullptr;
     int16_t *d_pcm = (int16_t *)b->stage[0]; uint8_t *d_out = (uint8_t *)b->stage[1];
     uint8_t *d_xpad = with_xpad ? (uint8_t *)b->stage[2] : nullptr; int32_t *d_xl = with_xpad ? (int32_t *)b->stage[3] : nullptr;
     TlTaps *d_taps = taps ? (TlTaps *)b->stage[4] : nullptr;
@@ -576,12 +608,13 @@ int tlb_encode_host(tlb_batch *b, const int16_t *pcm, int nframes, const uint8_t
         HIPCHK(hipEventRecord(b->ev_in[c], b->s_in));
         HIPCHK(hipStreamWaitEvent(b->s_run, b->ev_in[c], 0));
         int rc = tlb_launch(b, d_pcm + o * 2304, nf, with_xpad ? d_xpad + o * TL_MAX_XPAD : nullptr, with_xpad ? d_xl + o : nullptr,
-                            d_out + o * (size_t)b->out_stride, d_taps ? d_taps + o : nullptr, b->s_run);
+                            d_out + o * (size_t)b->out_stride, d_taps ? d_taps + o : nullptr, b->s_run, nullptr, d_len ? d_len + o : nullptr);
         if (rc != TLB_OK) { (void)hipDeviceSynchronize(); return rc; }
         HIPCHK(hipEventRecord(b->ev_run[c], b->s_run));
         HIPCHK(hipStreamWaitEvent(b->s_out, b->ev_run[c], 0));
         HIPCHK(hipMemcpyAsync(out + o * (size_t)b->out_stride, d_out + o * (size_t)b->out_stride, n * (size_t)b->out_stride, hipMemcpyDeviceToHost, b->s_out));
         if (taps) HIPCHK(hipMemcpyAsync((TlTaps *)taps + o, d_taps + o, n * sizeof(TlTaps), hipMemcpyDeviceToHost, b->s_out));
+        if (out_len) HIPCHK(hipMemcpyAsync(out_len + o, d_len + o, n * sizeof(int32_t), hipMemcpyDeviceToHost, b->s_out));
     }
     HIPCHK(hipStreamSynchronize(b->s_out));
     HIPCHK(hipStreamSynchronize(b->s_run));
@@ -889,31 +922,34 @@ int tlb_edi_pft_host(tlb_batch *b, const uint8_t *af, const int32_t *af_len, int
     return rc;
 }
 
-int tlb_flush_device(tlb_batch *b, uint8_t *d_out, void *hip_stream)
+int tlb_flush_device_len(tlb_batch *b, uint8_t *d_out, int32_t *d_out_len, void *hip_stream)
 {
     if (!b || !d_out) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
     hipLaunchKernelGGL(tl_flush_kernel, dim3(b->nstreams), dim3(128), 0, (hipStream_t)hip_stream, b->d_state, b->d_configs,
-                       b->d_stream_cfg, d_out, b->nstreams, b->out_stride);
+                       b->d_stream_cfg, d_out, d_out_len, b->nstreams, b->out_stride);
     HIPCHK(hipGetLastError());
     return TLB_OK;
 }
+int tlb_flush_device(tlb_batch *b, uint8_t *d_out, void *hip_stream) { return tlb_flush_device_len(b, d_out, nullptr, hip_stream); }
 
-int tlb_flush_host(tlb_batch *b, uint8_t *out)
+int tlb_flush_host_len(tlb_batch *b, uint8_t *out, int32_t *out_len)
 {
     DevFree guard_;
     if (!b || !out) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
-    uint8_t *d = nullptr;
+    uint8_t *d = nullptr; int32_t *dl = nullptr;
     const size_t n = (size_t)b->nstreams * (size_t)b->out_stride;
     DEVALLOC(d, n);
-    int rc = tlb_flush_device(b, d, nullptr);
+    DEVALLOC(dl, sizeof(int32_t) * (size_t)b->nstreams);
+    int rc = tlb_flush_device_len(b, d, dl, nullptr);
     hipError_t e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(out, d, n, hipMemcpyDeviceToHost);
-
+    if (e == hipSuccess && out_len) e = hipMemcpy(out_len, dl, sizeof(int32_t) * (size_t)b->nstreams, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return TLB_ERR_HIP;
     return rc;
 }
+int tlb_flush_host(tlb_batch *b, uint8_t *out) { return tlb_flush_host_len(b, out, nullptr); }
 
 float tlb_last_kernel_ms(tlb_batch *b)
 {
@@ -950,7 +986,8 @@ struct Legacy {
     int psy = 1;                   // DFLT_PSY, encoder.h:11
     int pad_len = 0;
     tlb_batch *batch = nullptr;
-    int lg_frame = 0, minimum = 4, fill = 0;     // emulated 4096-byte bit buffer (bitstream.c)
+    int lg_frame = 0, minimum = 4, fill = 0;     // emulated 4096-byte bit buffer (bitstream.c); lg_frame: a frame without padding slot
+    double frac = 0, lag = 0;                    // the slot recurrence on the host (availbits.c:49-62): length of the frame being encoded
     long frame_num = 0;
     std::deque<unsigned char> fifo;              // final bytes not yet handed to the caller
     std::vector<unsigned char> frame;            // one frame from the device
@@ -1034,9 +1071,13 @@ int toolame_encode_frame(short buffer[2][1152], unsigned char *xpad_data, size_t
             exit(-1);
         }
         g.lg_frame = tlb_frame_bytes(g.batch, 0);
-        g.minimum = g.lg_frame + 4;                        // toolame.c:298-300
+        g.frac = g.batch->h_configs[0].pad_frac; g.lag = 0;
         g.frame.assign((size_t)tlb_out_stride(g.batch), 0);
     }
+    // length of THIS frame (the reference's bit buffer fills with it now; its bytes come out of the GPU one call later)
+    int cur_len = g.lg_frame;
+    if (g.frac != 0) { if (g.lag > (g.frac - 1.0)) g.lag -= g.frac; else { cur_len++; g.lag += (1 - g.frac); } }
+    if (g.frame_num == 0) g.minimum = cur_len + 4;           // toolame.c:298-300: frame 1's length
     unsigned char xrec[TLB_MAX_XPAD];
     int32_t xl = 0;
     memset(xrec, 0, sizeof xrec);
@@ -1045,20 +1086,21 @@ int toolame_encode_frame(short buffer[2][1152], unsigned char *xpad_data, size_t
         memcpy(xrec, xpad_data + g.pad_len - (int)xpad_len, xpad_len);
     }
     // the batch keeps its device staging buffers between calls: no allocation per frame after the first
-    if (int rc = tlb_encode_host(g.batch, &buffer[0][0], 1, xrec, &xl, g.frame.data(), nullptr)) {
+    int32_t prev_len = 0;
+    if (int rc = tlb_encode_host_len(g.batch, &buffer[0][0], 1, xrec, &xl, g.frame.data(), &prev_len, nullptr)) {
         // the reference has no error return from this call (it exit()s on its own fatal errors, mem.c:28); losing frames
         // silently would be worse than stopping
         fprintf(stderr, "libtoolame-dab-hip: encoding on the GPU failed (error %d)\n", rc);
         exit(-1);
     }
     g.frame_num++;
-    if (g.frame_num > 1) g.fifo.insert(g.fifo.end(), g.frame.begin(), g.frame.begin() + g.lg_frame);   // frame n-1 is final now
+    if (g.frame_num > 1) g.fifo.insert(g.fifo.end(), g.frame.begin(), g.frame.begin() + prev_len);   // frame n-1 is final now
     // bitstream.c:46-71: when the 4096-byte buffer fills, everything but the newest `minimum` bytes is handed out
     int written = 0;
-    if (g.fill + g.lg_frame >= kLegacyBuf) {
+    if (g.fill + cur_len >= kLegacyBuf) {
         written = legacy_emit(output_buffer, output_buffer_size, (size_t)(kLegacyBuf - g.minimum));
-        g.fill = g.minimum + (g.fill + g.lg_frame - kLegacyBuf);
-    } else g.fill += g.lg_frame;
+        g.fill = g.minimum + (g.fill + cur_len - kLegacyBuf);
+    } else g.fill += cur_len;
     return written;
 }
 
@@ -1068,8 +1110,9 @@ int toolame_finish(unsigned char *output_buffer, size_t output_buffer_size)
     if (!g.batch) return 0;
     std::vector<unsigned char> last((size_t)tlb_out_stride(g.batch));
     if (g.frame_num > 0) {
-        if (int rc = tlb_flush_host(g.batch, last.data())) { fprintf(stderr, "libtoolame-dab-hip: flushing the GPU encoder failed (error %d)\n", rc); exit(-1); }
-        g.fifo.insert(g.fifo.end(), last.begin(), last.begin() + g.lg_frame);   // the last frame keeps its own ScF-CRC
+        int32_t last_len = 0;
+        if (int rc = tlb_flush_host_len(g.batch, last.data(), &last_len)) { fprintf(stderr, "libtoolame-dab-hip: flushing the GPU encoder failed (error %d)\n", rc); exit(-1); }
+        g.fifo.insert(g.fifo.end(), last.begin(), last.begin() + last_len);   // the last frame keeps its own ScF-CRC
     }
     int n = legacy_emit(output_buffer, output_buffer_size, g.fifo.size());
     tlb_destroy(g.batch);

@@ -19,7 +19,7 @@ LIB_PATH = Path(os.environ.get("TLB_LIB_PATH") or PKG_DIR / "libtoolame_dab_hip.
 MAX_XPAD = 200
 SAMPLES = 1152
 
-_ERR = {1: "illegal sample rate (48000/32000/24000/16000 Hz supported)", 2: "bad channel mode", 3: "invalid PSY model",
+_ERR = {1: "illegal sample rate (48000/44100/32000/24000/22050/16000 Hz; the egress calls: no 32/44.1/22.05 kHz)", 2: "bad channel mode", 3: "invalid PSY model",
         4: "illegal bitrate for this MPEG version", 5: "invalid XPAD length", 16: "no usable HIP device",
         17: "HIP runtime error", 18: "bad argument"}
 
@@ -80,6 +80,9 @@ def load_library():
     L.tlb_host_free.argtypes = [C.c_void_p]
     L.tlb_host_free.restype = None
     L.tlb_flush_host.argtypes = [C.c_void_p, C.c_void_p]
+    L.tlb_flush_host_len.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tlb_encode_host_len.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tlb_encode_device_len.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tlb_flush_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.tlb_last_kernel_ms.argtypes = [C.c_void_p]
     L.tlb_last_kernel_ms.restype = C.c_float
@@ -189,25 +192,25 @@ class Batch:
             xl = np.ascontiguousarray(xpad_len, dtype=np.int32)
             if xp.shape != (nf, self.nstreams, MAX_XPAD) or xl.shape != (nf, self.nstreams):
                 raise ToolameError(18, "xpad shape")
-        rc = self.L.tlb_encode_host(self.h, pcm.ctypes.data, nf, xp.ctypes.data if xp is not None else None,
-                                    xl.ctypes.data if xl is not None else None, out.ctypes.data,
-                                    taps.ctypes.data if taps is not None else None)
+        lens = np.zeros((nf, self.nstreams), dtype=np.int32)
+        rc = self.L.tlb_encode_host_len(self.h, pcm.ctypes.data, nf, xp.ctypes.data if xp is not None else None,
+                                        xl.ctypes.data if xl is not None else None, out.ctypes.data, lens.ctypes.data,
+                                        taps.ctypes.data if taps is not None else None)
         if rc:
-            raise ToolameError(rc, "tlb_encode_host")
-        first = 1 if self._first else 0
+            raise ToolameError(rc, "tlb_encode_host_len")
         self._first = False
-        res = [b"".join(out[f, s, : self.frame_bytes[s]].tobytes() for f in range(first, nf)) for s in range(self.nstreams)]
+        # a slot's length: 0 for slot 0 of the very first call (no frame yet); frame_bytes, or one more at 44.1 / 22.05 kHz
+        res = [b"".join(out[f, s, : lens[f, s]].tobytes() for f in range(nf)) for s in range(self.nstreams)]
         return res, taps
 
     def flush(self):
         """toolame_finish(): the last (pending) frame of every stream, carrying its own ScF-CRC."""
         out = np.zeros((self.nstreams, self.out_stride), dtype=np.uint8)
-        rc = self.L.tlb_flush_host(self.h, out.ctypes.data)
+        lens = np.zeros(self.nstreams, dtype=np.int32)
+        rc = self.L.tlb_flush_host_len(self.h, out.ctypes.data, lens.ctypes.data)
         if rc:
-            raise ToolameError(rc, "tlb_flush_host")
-        if self._first:
-            return [b""] * self.nstreams
-        return [out[s, : self.frame_bytes[s]].tobytes() for s in range(self.nstreams)]
+            raise ToolameError(rc, "tlb_flush_host_len")
+        return [out[s, : lens[s]].tobytes() for s in range(self.nstreams)]
 
     # -- device-resident path (bench, production) -------------------------------------------
     def encode_device(self, d_pcm_ptr, nframes, d_out_ptr, d_xpad_ptr=None, d_xpad_len_ptr=None, stream=None):

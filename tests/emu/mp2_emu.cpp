@@ -42,11 +42,11 @@ void *emu_create(int nstreams, const long *fs, const char *mode, const int *kbps
     bool any2 = false;
     for (auto &c : e->configs) any2 |= c.psy == 2 || c.psy == 4;
     if (any2) {
-        const long rates[4] = {48000, 32000, 24000, 16000};
-        e->psy2_tables.resize(8);
-        for (int i = 0; i < 4; i++) {
+        const long rates[TL_PSY2_SLOTS] = {48000, 32000, 24000, 16000, 44100, 22050};
+        e->psy2_tables.resize(2 * TL_PSY2_SLOTS);
+        for (int i = 0; i < TL_PSY2_SLOTS; i++) {
             tl_build_psy2_tables(&e->psy2_tables[tl_psy2_slot(rates[i])], rates[i]);
-            tl_build_psy4_tables(&e->psy2_tables[4 + tl_psy2_slot(rates[i])], rates[i]);
+            tl_build_psy4_tables(&e->psy2_tables[TL_PSY2_SLOTS + tl_psy2_slot(rates[i])], rates[i]);
         }
         e->psy2_state.resize(nstreams);
         memset(e->psy2_state.data(), 0, sizeof(TlPsy2State) * nstreams);
@@ -56,15 +56,23 @@ void *emu_create(int nstreams, const long *fs, const char *mode, const int *kbps
 }
 void emu_destroy(void *h) { delete (Emu *)h; }
 int emu_frame_bytes(void *h, int s) { return ((Emu *)h)->configs[s].frame_bytes; }
+int emu_max_frame_bytes(void *h, int s) { const TlConfig &c = ((Emu *)h)->configs[s]; return c.frame_bytes + (c.pad_frac != 0 ? 1 : 0); }
 
+int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, const int32_t *xpad_len, uint8_t *out,
+                   int out_stride, TlTaps *taps, int32_t *out_len);
 int emu_encode(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, const int32_t *xpad_len, uint8_t *out,
                int out_stride, TlTaps *taps)
+{
+    return emu_encode_len(h, pcm, nframes, xpad, xpad_len, out, out_stride, taps, nullptr);
+}
+int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, const int32_t *xpad_len, uint8_t *out,
+                   int out_stride, TlTaps *taps, int32_t *out_len)
 {
     Emu *e = (Emu *)h;
     TlLaunch A;
     memset(&A, 0, sizeof A);
     A.tables = &e->tables; A.configs = e->configs.data(); A.stream_cfg = e->stream_cfg.data();
-    A.state = e->state.data(); A.pcm = pcm; A.xpad = xpad; A.xpad_len = xpad_len; A.out = out; A.taps = taps;
+    A.state = e->state.data(); A.pcm = pcm; A.xpad = xpad; A.xpad_len = xpad_len; A.out = out; A.out_len = out_len; A.taps = taps;
     A.psy2_tables = e->psy2_tables.empty() ? nullptr : e->psy2_tables.data();
     A.psy2_state = e->psy2_state.empty() ? nullptr : e->psy2_state.data();
     A.nstreams = (int)e->state.size(); A.nframes = nframes; A.out_stride = out_stride;
@@ -78,6 +86,12 @@ int emu_encode(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, co
     std::vector<uint8_t> scfcrc((size_t)nframes * (size_t)A.nstreams * 4);
     std::vector<uint32_t> newpend((size_t)A.nstreams * TL_MAX_FRAME_WORDS);
     A.psy_out = psy_out.data(); A.scfcrc = scfcrc.data(); A.newpend = newpend.data();
+    // 44.1 / 22.05 kHz: the slot recurrence first (sequential per stream), then the units read its padding bits
+    std::vector<uint8_t> padbits((size_t)nframes * (size_t)A.nstreams);
+    std::vector<double> newlag((size_t)A.nstreams);
+    bool pads = false;
+    for (int s = 0; s < A.nstreams; s++) pads |= e->configs[e->stream_cfg[s]].pad_frac != 0;
+    if (pads) { A.padbits = padbits.data(); A.newlag = newlag.data(); }
     auto split = [&](int s) { const int m = e->configs[e->stream_cfg[s]].psy; return m == 1 || m == 3; };
     for (int f = nframes - 1; f >= 0; f--)
         for (int s = 0; s < A.nstreams; s++) {
@@ -85,6 +99,7 @@ int emu_encode(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, co
             if (m == 1) tl_psy_unit<1>(wp, e->tables.shared.dbtable, A, s, f);
             else if (m == 3) tl_psy_unit<3>(wp, e->tables.shared.dbtable, A, s, f);
         }
+    if (pads) for (int s = 0; s < A.nstreams; s++) if (split(s)) tl_slots_stream(A, s);
     for (int s = 0; s < A.nstreams; s++)
         if (split(s)) for (int f = nframes - 1; f >= 0; f--) tl_main_unit(wm, &e->tables.shared, e->tables.enwindow_s, A, s, f);
     for (int s = 0; s < A.nstreams; s++)
@@ -97,7 +112,7 @@ int emu_pending(void *h, int s, uint8_t *out)
 {
     Emu *e = (Emu *)h;
     if (e->state[s].frames_done == 0) return 0;
-    int n = e->configs[s].frame_bytes;
+    int n = e->state[s].pending_len;
     for (int i = 0; i < n; i++) out[i] = (uint8_t)(e->state[s].pending[i >> 2] >> (24 - 8 * (i & 3)));
     return n;
 }

@@ -31,6 +31,8 @@ def lib():
         L.emu_destroy.argtypes = [C.c_void_p]
         L.emu_frame_bytes.argtypes = [C.c_void_p, C.c_int]
         L.emu_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.emu_encode_len.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_max_frame_bytes.argtypes = [C.c_void_p, C.c_int]
         L.emu_pending.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_log10.restype = C.c_double
         L.emu_log10.argtypes = [C.c_double]
@@ -70,7 +72,7 @@ class EmuBatch:
             raise ValueError(f"illegal configuration (code {err.value})")
         self.n = n
         self.frame_bytes = [self.L.emu_frame_bytes(self.h, s) for s in range(n)]
-        self.stride = max(self.frame_bytes)
+        self.stride = (max(self.L.emu_max_frame_bytes(self.h, s) for s in range(n)) + 3) & ~3
         self.frames_in = 0
 
     def encode(self, pcm, xpad=None, xpad_len=None, want_taps=False):
@@ -86,13 +88,13 @@ class EmuBatch:
             xp = np.ascontiguousarray(xpad, dtype=np.uint8)
             xl = np.ascontiguousarray(xpad_len, dtype=np.int32)
             assert xp.shape == (nf, self.n, TL_MAX_XPAD) and xl.shape == (nf, self.n)
-        self.L.emu_encode(self.h, pcm.ctypes.data, nf, xp.ctypes.data if xp is not None else None,
-                          xl.ctypes.data if xl is not None else None, out.ctypes.data, self.stride,
-                          taps.ctypes.data if taps is not None else None)
+        lens = np.zeros((nf, self.n), dtype=np.int32)
+        self.L.emu_encode_len(self.h, pcm.ctypes.data, nf, xp.ctypes.data if xp is not None else None,
+                              xl.ctypes.data if xl is not None else None, out.ctypes.data, self.stride,
+                              taps.ctypes.data if taps is not None else None, lens.ctypes.data)
         res = []
-        for s in range(self.n):
-            first = 1 if self.frames_in == 0 else 0      # slot 0 of the very first call holds no frame
-            res.append(b"".join(out[f, s, : self.frame_bytes[s]].tobytes() for f in range(first, nf)))
+        for s in range(self.n):                          # a slot's length: 0 for slot 0 of the very first call (no frame yet); at 44.1 /
+            res.append(b"".join(out[f, s, : lens[f, s]].tobytes() for f in range(nf)))      # 22.05 kHz frame_bytes or one more
         self.frames_in += nf
         return res, taps
 

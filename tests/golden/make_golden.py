@@ -45,6 +45,11 @@ def cases():
                     continue  # the reference segfaults on digital silence with psy 3 (psycho_3.c:299)
                 out.append(dict(name=f"p{psy}_48k_{mode}_128_k{kind}", samplerate=48000, mode=mode, kbps=128,
                                 psy=psy, kind=kind, seed=7 + kind, pad_len=0))
+    # 44.1 / 22.05 kHz: frames of two lengths (padding slots, availbits.c:49-62) -- the library encodes them, DAB does not use them
+    for psy, fs, mode, kbps in ((1, 44100, "s", 128), (1, 44100, "j", 192), (3, 44100, "s", 128), (0, 44100, "m", 64), (2, 44100, "s", 128),
+                                (1, 22050, "m", 32), (1, 22050, "s", 64), (3, 22050, "j", 96), (2, 22050, "m", 32)):
+        out.append(dict(name=f"p{psy}_{fs // 1000}k_{mode}_{kbps}_k0", samplerate=fs, mode=mode, kbps=kbps, psy=psy, kind=0,
+                        seed=300 + psy + kbps, pad_len=0))
     out.append(dict(name="p1_48k_j_128_xpad", samplerate=48000, mode="j", kbps=128, psy=1, kind=0, seed=42, pad_len=58))
     out.append(dict(name="p3_48k_s_192_xpad", samplerate=48000, mode="s", kbps=192, psy=3, kind=0, seed=43, pad_len=58))
     return out

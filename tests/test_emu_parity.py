@@ -197,7 +197,7 @@ def test_quantiser_division():
 
 
 def test_emulated_illegal_configs():
-    for kw in (dict(samplerate=44100), dict(kbps=100), dict(mode="x"), dict(psy=5), dict(psy=-1), dict(pad_len=-1), dict(pad_len=999)):
+    for kw in (dict(samplerate=11025), dict(kbps=100), dict(mode="x"), dict(psy=5), dict(psy=-1), dict(pad_len=-1), dict(pad_len=999)):
         with pytest.raises(ValueError):
             E.EmuBatch([kw])
 
@@ -233,3 +233,21 @@ def test_xpad_length_contract():
         with pytest.raises(ValueError):
             E.EmuBatch([kw])
     E.EmuBatch([dict(samplerate=24000, mode="m", kbps=8, pad_len=16)]).close()
+
+
+@pytest.mark.parametrize("fs,mode,kbps", [(44100, "s", 128), (44100, "j", 192), (44100, "m", 64), (44100, "d", 384), (44100, "s", 96),
+                                          (22050, "s", 64), (22050, "m", 32), (22050, "j", 160), (22050, "m", 8)])
+def test_padding_slot_rates_vs_oracle(fs, mode, kbps):
+    """44.1 and 22.05 kHz: frames of two lengths (padding slots, availbits.c:49-62; header bit 9).  Every psy model, frames fed
+    in ragged chunks (the slot recurrence's state passes from call to call), bytes against the oracle."""
+    nf = 14
+    for psy in (0, 1, 2, 3):
+        pcm = gen_pcm(900 + psy + kbps, (0, 7, 5, 4)[psy], 0, nf)
+        ref, _ = O.oracle_stream(pcm, samplerate=fs, mode=mode, kbps=kbps, psy=psy)
+        got, _ = _emu_stream(pcm, chunks=(1, 2, 4, nf - 7), samplerate=fs, mode=mode, kbps=kbps, psy=psy)
+        assert got == ref, (fs, mode, kbps, psy)
+        if psy == 1:
+            b = E.EmuBatch([dict(samplerate=fs, mode=mode, kbps=kbps, psy=psy)])
+            whole = b.frame_bytes[0]
+            assert len(ref) > nf * whole or (1152 * kbps * 125) % fs == 0      # some frames carry the extra slot
+            b.close()

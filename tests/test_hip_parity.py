@@ -137,7 +137,9 @@ def test_configuration_sweep_vs_oracle(M):
     rates = {48000: [(m, k) for m in "sjdm" for k in ((64, 96, 128, 160, 192, 256, 384) if m != "m" else (32, 48, 64, 96, 128, 192))],
              32000: [("s", 128), ("j", 192), ("m", 64), ("m", 96), ("d", 256)],
              24000: [("s", 64), ("j", 96), ("m", 32), ("m", 64), ("s", 128)],
-             16000: [("m", 24), ("s", 48), ("j", 64)]}
+             16000: [("m", 24), ("s", 48), ("j", 64)],
+             44100: [("s", 128), ("j", 192), ("m", 64), ("d", 256), ("s", 384)],      # frames of two lengths (padding slots)
+             22050: [("m", 32), ("s", 64), ("j", 160), ("m", 8)]}
     nframes, cfgs, pcms, refs = 5, [], [], []
     n = 0
     for fs, lst in rates.items():
@@ -320,7 +322,7 @@ def test_legacy_setters_validate(M):
 
 
 def test_errors(M):
-    for kw in (dict(samplerate=44100), dict(samplerate=12345), dict(bitrate=100), dict(mode="x"), dict(psy_model=7),
+    for kw in (dict(samplerate=11025), dict(samplerate=12345), dict(bitrate=100), dict(mode="x"), dict(psy_model=7),
                dict(pad_len=-1)):
         with pytest.raises(M.ToolameError):
             M.Batch([M.StreamConfig(**kw)])
