@@ -18,7 +18,9 @@ from pcmgen import gen_pcm
 RATES = {48000: [(m, k) for m in "sjdm" for k in ((64, 96, 128, 160, 192, 256, 384) if m != "m" else (32, 48, 64, 96, 128, 192))],
          32000: [("s", 128), ("j", 192), ("m", 64), ("m", 96), ("d", 256)],
          24000: [("s", 64), ("j", 96), ("m", 32), ("m", 64), ("s", 128)],
-         16000: [("m", 24), ("s", 48), ("j", 64)]}
+         16000: [("m", 24), ("s", 48), ("j", 64)],
+         44100: [("s", 128), ("j", 192), ("m", 64), ("d", 256), ("s", 384), ("j", 96)],
+         22050: [("m", 32), ("s", 64), ("j", 160), ("m", 8), ("s", 128)]}
 
 
 def ref_of(job):
