@@ -41,11 +41,11 @@ void tl_build_tables(TlTables *T)
     T->scalefactor[63] = 1e-20;
     for (int q = 0; q < 18; q++) {
         T->snr[q] = (double)TL_SNR_E2[q] / 100.0;
-        T->qa[q] = (double)TL_QUANT_A_E9[q] / 1e9;
-        T->qb[q] = (double)TL_QUANT_B_E9[q] / 1e9;
-        T->steps[q] = TL_STEPS[q];
-        T->steps2n[q] = TL_STEPS2N[q];
-        T->steps2n_f[q] = (double)TL_STEPS2N[q];
+        T->pack.qa[q] = (double)TL_QUANT_A_E9[q] / 1e9;
+        T->pack.qb[q] = (double)TL_QUANT_B_E9[q] / 1e9;
+        T->pack.steps[q] = TL_STEPS[q];
+        T->pack.steps2n[q] = TL_STEPS2N[q];
+        T->pack.steps2n_f[q] = (double)TL_STEPS2N[q];
         T->bits[q] = TL_BITS[q];
         T->group[q] = TL_GROUP[q];
     }
@@ -80,7 +80,7 @@ void tl_build_tables(TlTables *T)
     }
     {   // powers of x modulo the CRC-16 polynomial 0x8005 (CRC16_POLYNOMIAL, common.h:45)
         unsigned v = 1;
-        for (int e = 0; e < 512; e++) { T->crc_xpow[e] = (uint16_t)v; v <<= 1; if (v & 0x10000u) v = (v ^ 0x18005u) & 0xffffu; }
+        for (int e = 0; e < 512; e++) { T->pack.crc_xpow[e] = (uint16_t)v; v <<= 1; if (v & 0x10000u) v = (v ^ 0x18005u) & 0xffffu; }
         {   // Reed-Solomon RS(255,207) of the EDI PFT layer: GF(2^8) with x^8+x^4+x^3+x^2+1, generator polynomial with roots
             // alpha^1..alpha^48 (contrib/edioutput/PFT.cpp:100-107: gfPoly 0x11d, firstRoot 1; contrib/fec/init_rs.h).
             uint8_t *lg = T->rs_log, *ex = T->rs_exp;
@@ -111,7 +111,7 @@ void tl_build_tables(TlTables *T)
             for (int b = 0; b < 8; b++) { ve <<= 1; if (ve & 0x10000u) ve = (ve ^ 0x11021u) & 0xffffu; }
         }
         unsigned v8 = 1;
-        for (int e = 0; e < 320; e++) { T->crc8_xpow[e] = (uint8_t)v8; v8 <<= 1; if (v8 & 0x100u) v8 = (v8 ^ 0x11Du) & 0xffu; }
+        for (int e = 0; e < 320; e++) { T->pack.crc8_xpow[e] = (uint8_t)v8; v8 <<= 1; if (v8 & 0x100u) v8 = (v8 ^ 0x11Du) & 0xffu; }
     }
     // matrixing coefficients: cos scaled by 1e9, rounded half away from zero, scaled back (subband.c:125-137)
     for (int i = 0; i < 16; i++)

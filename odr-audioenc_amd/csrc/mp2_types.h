@@ -25,6 +25,17 @@ struct TlBlockShared {
                                  //   source of sf0 | sf1 << 2 | sf2 << 4 (0..2 = sf0..sf2, 3 = min(sf0, sf2)) | scfsi << 6
 };
 
+// Small tables of the packing stage that sit on dependent-load chains (quantiser class constants, CRC powers): the encode
+// kernel of the split path keeps a copy in LDS, the fused kernels read them where they are (TlTables::pack).
+struct TlPackTables {
+    double qa[18], qb[18];
+    double steps2n_f[18];        // (double)steps2n[q]
+    int32_t steps[18];
+    int32_t steps2n[18];
+    uint16_t crc_xpow[512];      // x^e mod (x^16+x^15+x^2+1), e = 0..511: lets lanes fold CRC-16 chunks in parallel (crc.c:43-56)
+    uint8_t crc8_xpow[320];      // x^e mod (x^8+x^4+x^3+x^2+1), the ScF-CRC polynomial (crc.c:99-113)
+};
+
 // Tables common to every config.  (ref: enwindow.h, subband.c:125-137, psycho_1.c:170-178,225-233,
 // fft.c:38-73,1139-1149, encode_new.c:16-100,448-462)
 struct TlTables {
@@ -37,17 +48,12 @@ struct TlTables {
     double fht_tw_lane[3][128][4];   // the same rows in the order the lanes of passes k=4,6,8 use them: [pass][butterfly g][.]
     double scalefactor[64];
     double snr[18];
-    double qa[18], qb[18];
-    double steps2n_f[18];        // (double)steps2n[q]
-    int32_t steps[18];
-    int32_t steps2n[18];
+    TlPackTables pack;
     uint8_t bits[18];
     uint8_t group[18];           // 3 = three codewords, 1 = one grouped codeword
     uint8_t step_index[9][16];
     uint8_t nbal_line[9];
     uint8_t pad_[3];
-    uint16_t crc_xpow[512];      // x^e mod (x^16+x^15+x^2+1), e = 0..511: lets lanes fold CRC-16 chunks in parallel (crc.c:43-56)
-    uint8_t crc8_xpow[320];      // x^e mod (x^8+x^4+x^3+x^2+1), the ScF-CRC polynomial (crc.c:99-113)
     uint8_t rs_log[256], rs_exp[512];   // GF(2^8), field polynomial 0x11d: log (255 for 0) and antilog (doubled, no modulo)
     uint8_t rs_mlog[207][48];    // log of M[i][j]: parity byte j of the RS(255,207) codeword of the unit chunk e_i (csrc/edi_pft.h)
     uint16_t edi_xpow8[2048];    // x^(8k) mod (x^16+x^12+x^5+1): AF-packet CRC chunks (csrc/edi_af.h; contrib/crc.c:247-255)

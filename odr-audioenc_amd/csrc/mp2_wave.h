@@ -2100,7 +2100,7 @@ template <int PSY, class W>
 TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
                            const TlConfig *TL_RESTRICT C, const TlPsy2Tables *TL_RESTRICT P2, TlPsy2State *TL_RESTRICT S2, const TlPsyOut *TL_RESTRICT PO,
                            const TlPcmView &pv, TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, const TlFrameOut &fo,
-                           const double *TL_RESTRICT enw_s, int padding, TlTaps *taps, long long *sp)
+                           const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, int padding, TlTaps *taps, long long *sp)
 {
     constexpr int FB = W::kFbBatch;
     const int nch = C->nch, sblimit = C->sblimit;
@@ -2576,8 +2576,8 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         const unsigned qi = ba ? B->qinfo_line[L(a_ln)][ba] : 0u;   // class, bits and grouping from the shared LDS copy
         const int q = (int)(qi & 31u);
         const bool joint = any_joint && sb >= jsbound;
-        L(q_ba) = ba; L(q_nb) = (int)((qi >> 5) & 31u); L(q_grp) = ((qi >> 10) & 1u) ? 3 : 1; L(q_s2n) = T->steps2n[q]; L(q_steps) = T->steps[q];
-        L(q_a) = T->qa[q]; L(q_b) = T->qb[q]; L(q_s2nf) = T->steps2n_f[q];
+        L(q_ba) = ba; L(q_nb) = (int)((qi >> 5) & 31u); L(q_grp) = ((qi >> 10) & 1u) ? 3 : 1; L(q_s2n) = K->steps2n[q]; L(q_steps) = K->steps[q];
+        L(q_a) = K->qa[q]; L(q_b) = K->qb[q]; L(q_s2nf) = K->steps2n_f[q];
         for (int gr = 0; gr < 3; gr++) {
             L(q_sf)[gr] = B->scalefactor[joint ? w.jscale[gr][sb] : L(scf)[gr]];
             L(q_rsf)[gr] = 1.0 / L(q_sf)[gr];                          // one division per granule instead of twelve
@@ -2645,7 +2645,7 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
             const int byte = lane < 2 ? lane + 2 : lane + 4;          // frame byte holding them
             const int cnt = preset ? 8 : (n - first < 8 ? n - first : 8);
             const int e0 = preset ? n + 8 * (63 - lane) : 16 + (n - first - cnt);     // exponent of the byte's last bit
-            unsigned xp = T->crc_xpow[e0];
+            unsigned xp = K->crc_xpow[e0];
             const unsigned v = preset ? 0xffu : ((frame[byte >> 2] >> (24 - 8 * (byte & 3))) & 0xffu) >> (8 - cnt);
 #ifndef TL_EMULATE
 #pragma unroll
@@ -2696,7 +2696,7 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         const int g = sb < 4 ? 0 : sb < 8 ? 1 : sb < 16 ? 2 : 3;
         const int after = (g == 0 ? gend[0] : g == 1 ? gend[1] : g == 2 ? gend[2] : gend[3]) - L(lex) - L(rlen);
         const int e0 = after + 8;                                    // <= 252 + 8: inside crc8_xpow[]
-        unsigned xp = T->crc8_xpow[e0 < 0 ? 0 : e0 > 319 ? 319 : e0];
+        unsigned xp = K->crc8_xpow[e0 < 0 ? 0 : e0 > 319 ? 319 : e0];
         unsigned acc = 0;
         const unsigned rb = L(rcrc);
 #ifndef TL_EMULATE
@@ -2921,7 +2921,7 @@ TL_FN void tl_encode_stream(W &w, const TlBlockShared *TL_RESTRICT B, const TlLa
         const int padding = tl_slot_step(lag, C->pad_frac);
         if (A.out_len) { const int pl = done > 0 ? st->pending_len : 0; TL_LANES_BEGIN if (lane == 0) A.out_len[slot] = pl; TL_LANES_END }
         tl_encode_frame<PSY>(w, T, B, C, A.psy2_tables ? &A.psy2_tables[C->psy2_tab] : nullptr, A.psy2_state ? &A.psy2_state[s] : nullptr,
-                             nullptr, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, none, T->enwindow_s, padding,
+                             nullptr, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, none, T->enwindow_s, &T->pack, padding,
                              A.taps ? &A.taps[slot] : nullptr, A.stamps ? A.stamps + slot * 32 : nullptr);
         done++;
     }
@@ -2943,7 +2943,7 @@ TL_FN void tl_encode_stream(W &w, const TlBlockShared *TL_RESTRICT B, const TlLa
 // independent of each other: the filterbank's history is PCM (the previous input frame, or the stream state before frame 0),
 // the SMR comes from the psy kernel's record, and the one thing a frame owes its predecessor -- its ScF-CRC, which travels in
 // the frame before (toolame.c:527-542) -- is filed aside and put in place by tl_finish_stream.
-TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s, const TlLaunch &A, int s, int f)
+TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, const TlLaunch &A, int s, int f)
 {
     const TlConfig *C = &A.configs[A.stream_cfg[s]];
     TlStreamState *st = &A.state[s];
@@ -2962,7 +2962,7 @@ TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const 
     fo.words = f + 1 < A.nframes ? nullptr : A.newpend + (size_t)s * TL_MAX_FRAME_WORDS;
     fo.scfcrc = A.scfcrc + slot * 4;
     const int padding = A.padbits ? (int)A.padbits[slot] : 0;
-    tl_encode_frame<TL_PSY_EXT>(w, A.tables, B, C, nullptr, nullptr, &A.psy_out[slot], pv, st, xl, nullptr, false, fo, enw_s, padding,
+    tl_encode_frame<TL_PSY_EXT>(w, A.tables, B, C, nullptr, nullptr, &A.psy_out[slot], pv, st, xl, nullptr, false, fo, enw_s, K, padding,
                                 A.taps ? &A.taps[slot] : nullptr, sp);
 }
 

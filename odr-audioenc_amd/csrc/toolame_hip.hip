@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(64 * TL_PSY_WAVES) __attribute__((amdgpu_waves
 }
 
 // encode kernel of the split path: the tables it needs on dependent-load chains (TlBlockShared without the dB-sum table)
-struct TlMainShared { double enw_s[512]; char bytes[sizeof(TlBlockShared) - offsetof(TlBlockShared, scalefactor)]; };
+struct TlMainShared { double enw_s[512]; char bytes[sizeof(TlBlockShared) - offsetof(TlBlockShared, scalefactor)]; TlPackTables pack; };
 static_assert(offsetof(TlBlockShared, dbtable) == 0 && offsetof(TlBlockShared, scalefactor) == sizeof(double) * 1002, "dbtable leads TlBlockShared");
 #define TL_MAIN_WAVES (4 * TL_MAIN_WPE)       // one workgroup per CU: one copy of the tables
 static_assert((sizeof(TlMainShared) + TL_MAIN_WAVES * sizeof(TlMainLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "the encode workgroup fits a CU");
@@ -119,6 +119,8 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
         double *dst = (double *)&sh.bytes[0];
         for (int i = (int)threadIdx.x; i < (int)(sizeof(sh.bytes) / 8); i += 64 * TL_MAIN_WAVES) dst[i] = src[i];
         for (int i = (int)threadIdx.x; i < 512; i += 64 * TL_MAIN_WAVES) sh.enw_s[i] = A.tables->enwindow_s[i];
+        static_assert(sizeof(TlPackTables) % 8 == 0, "copied as doubles");
+        for (int i = (int)threadIdx.x; i < (int)(sizeof(TlPackTables) / 8); i += 64 * TL_MAIN_WAVES) ((double *)&sh.pack)[i] = ((const double *)&A.tables->pack)[i];
     }
     __syncthreads();
     // the encode path never touches B->dbtable: a TlBlockShared pointer whose dbtable part lies before the copied block
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
     for (int u = (int)blockIdx.x * TL_MAIN_WAVES + wave; u < nunits; u = nwaves + tl_next_unit(&A.work[1])) {      // as in the psy kernel
         const int f = u / A.nlist, k = u - f * A.nlist;
         const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
-        tl_main_unit(lds[wave], B, sh.enw_s, A, s, f);
+        tl_main_unit(lds[wave], B, sh.enw_s, &sh.pack, A, s, f);
     }
 }
 

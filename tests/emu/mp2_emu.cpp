@@ -101,7 +101,7 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
         }
     if (pads) for (int s = 0; s < A.nstreams; s++) if (split(s)) tl_slots_stream(A, s);
     for (int s = 0; s < A.nstreams; s++)
-        if (split(s)) for (int f = nframes - 1; f >= 0; f--) tl_main_unit(wm, &e->tables.shared, e->tables.enwindow_s, A, s, f);
+        if (split(s)) for (int f = nframes - 1; f >= 0; f--) tl_main_unit(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, f);
     for (int s = 0; s < A.nstreams; s++)
         if (split(s)) tl_finish_stream(A, s);
         else if (e->configs[e->stream_cfg[s]].psy == 0) tl_encode_stream<0>(w, &e->tables.shared, A, s);
