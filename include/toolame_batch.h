@@ -62,7 +62,7 @@ enum {
 typedef struct {
     long samplerate;               /* 48000, 32000, 24000, 16000, 44100, 22050 */
     char mode;                     /* 's' stereo, 'j' joint stereo, 'd' dual channel, 'm' mono */
-    int bitrate;                   /* kbps; 0 = the reference default (192 / 160) */
+    int bitrate;                   /* kbps; 0 = the reference default, bitrate[version][10] (toolame.c:217-218): 192 (MPEG-1) / 96 (LSF) */
     int psy_model;                 /* 0, 1, 2, 3 (toolame.c:202-210); 4 = psycho_4.c, an extension of this API only: the
                                       reference implements it (toolame.c:384-391) but its setter refuses it */
     int pad_len;                   /* toolame_set_pad(): upper bound of xpad_len, 0..TLB_MAX_XPAD; must leave room for header, CRC and
