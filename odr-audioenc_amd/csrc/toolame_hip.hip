@@ -33,7 +33,7 @@ static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 //      tl_psy_kernel<PSY>   the psychoacoustic model alone.  It reads nothing but PCM, so every (stream, frame) is an
 //                           independent unit: persistent waves take units off a strided list, no per-stream state, no
 //                           frame order.  Without the filterbank's 72 sample registers and the encoder's arrays it fits
-//                           168 VGPRs and 11.3 KB of LDS per wave: 3 waves per SIMD instead of 2.  Output: 1 KB per frame
+//                           168 VGPRs and 11.0 KB of LDS per wave: 3 waves per SIMD instead of 2.  Output: 1 KB per frame
 //                           (TlPsyOut: level and minimum masking threshold per subband).
 //      tl_main_kernel       filterbank, scalefactors, SMR from TlPsyOut, bit allocation, quantiser, packing, CRCs; one wave
 //                           per stream, frames in order (the pending frame stays in LDS for the whole launch).  Also 3 waves
