@@ -358,6 +358,17 @@ def main():
                               "roofline_frac_hbm": round(ALGO_BYTES_PER_FRAME * s2 * f2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
             except Exception as ex:  # noqa: BLE001
                 also[name] = {"value": None, "error": str(ex)}
+        try:     # BASELINE configs[0] on the GPU: ONE stream -- its frames are independent units for the kernels, so one stream fills the chip
+            n1 = 16384
+            r1 = GpuRun(M, torch, np, gen_pcm, [0], n1 // 2, args.mode, psy, local_rank)
+            e1, _, k1 = r1.timed(None, shard, 2, 6)
+            r1.check()
+            r1.close()
+            also["one_stream"] = {"workload": f"1 stream x {n1 // 2} frames per launch (48 kHz stereo 128 kbps, psy {psy}, mode '{args.mode}'; BASELINE configs[0] "
+                                              "is this stream on the CPU reference)", "value": round((n1 // 2) * 6 / e1, 1), "unit": "frames/s",
+                                  "x_realtime": round((n1 // 2) * 6 / e1 / (FS / 1152.0), 1), "kernel_ms": round(k1, 4)}
+        except Exception as ex:  # noqa: BLE001
+            also["one_stream"] = {"value": None, "error": str(ex)}
         try:
             also["pcie_inclusive"] = pcie_inclusive(M, np, gen_pcm, 8, psy, args.mode, local_rank, S)
         except Exception as ex:  # noqa: BLE001

@@ -201,6 +201,20 @@ def test_baseline_configs4_mixed_batch(M):
         b.close()
 
 
+def test_one_stream_many_frames(M):
+    """Frames of one stream are independent units for the kernels of models 1 and 3: ONE stream with 600 frames in one call
+    (then 7 more in a second call, then the flush) equals the oracle, which encodes them one after the other."""
+    nframes = 607
+    for psy, mode, fs, kbps in ((1, "j", 48000, 128), (3, "s", 44100, 192)):
+        pcm = gen_pcm(9000 + psy, 0, 0, nframes)[:, None]
+        b = M.Batch([M.StreamConfig(samplerate=fs, mode=mode, bitrate=kbps, psy_model=psy)])
+        g1, _ = b.encode(pcm[:600])
+        g2, _ = b.encode(pcm[600:])
+        ref, _ = O.oracle_stream(pcm[:, 0], samplerate=fs, mode=mode, kbps=kbps, psy=psy)
+        assert g1[0] + g2[0] + b.flush()[0] == ref, (psy, mode, fs)
+        b.close()
+
+
 def test_full_size_properties(M):
     """BASELINE configs[1] size (4096 streams, psy 1): size-independent properties instead of a full oracle run -- identical
     inputs give identical frames wherever they sit in the batch, every frame starts with the sync header and has the right
