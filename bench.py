@@ -169,11 +169,14 @@ class GpuRun:
     """One workload resident on this rank's GPU: two alternating PCM buffers (frames [0,F) and [F,2F) of every stream), the
     batch, the output buffer.  step(i) = one launch."""
 
-    def __init__(self, M, torch, np, gen_pcm, stream_ids, F, mode, psy, local_rank):
+    def __init__(self, M, torch, np, gen_pcm, stream_ids, F, mode, psy, local_rank, distinct=None):
         S = len(stream_ids)
         host = np.empty((2 * F, S, 2, 1152), dtype=np.int16)
-        for k, sid in enumerate(stream_ids):          # stream i uses seed i (SURVEY 8d)
+        nd = S if distinct is None else min(S, distinct)
+        for k, sid in enumerate(stream_ids[:nd]):     # stream i uses seed i (SURVEY 8d)
             host[:, k] = gen_pcm(sid, 0, 0, 2 * F)
+        for k in range(nd, S, nd):                    # secondary workloads only: the signals repeat every `distinct` streams
+            host[:, k:k + nd] = host[:, :min(nd, S - k)]
         self.pcm = [torch.from_numpy(host[:F].copy()).cuda(), torch.from_numpy(host[F:].copy()).cuda()]
         self.batch = M.Batch([M.StreamConfig(samplerate=FS, mode=mode, bitrate=KBPS, psy_model=psy)] * S, device=local_rank)
         self.out = torch.zeros((F, S, self.batch.out_stride), dtype=torch.uint8, device="cuda")
@@ -203,7 +206,7 @@ class GpuRun:
         return elapsed, own, kernel_ms
 
     def check(self):
-        chk = self.out[1, :4].cpu().numpy()          # the frames are real frames (sync word), never timed
+        chk = self.out[min(1, self.F - 1), :4].cpu().numpy()          # the frames are real frames (sync word), never timed
         assert all(bytes(chk[s, :2]) == b"\xff\xfc" for s in range(min(4, self.S))), "output is not an MPEG audio frame"
 
     def close(self):
@@ -369,6 +372,18 @@ def main():
                                   "x_realtime": round((n1 // 2) * 6 / e1 / (FS / 1152.0), 1), "kernel_ms": round(k1, 4)}
         except Exception as ex:  # noqa: BLE001
             also["one_stream"] = {"value": None, "error": str(ex)}
+        try:     # the whole population of BASELINE configs[3] (131072 streams, psy 3) on ONE GPU, one 24-ms frame each per launch
+            nt = 131072
+            rt = GpuRun(M, torch, np, gen_pcm, list(range(nt)), 1, args.mode, 3, local_rank, distinct=4096)
+            et, _, kt = rt.timed(None, shard, 2, 6)
+            rt.check()
+            rt.close()
+            also["tick_131072"] = {"workload": f"{nt} streams x 1 frame per launch on one GPU (48 kHz stereo 128 kbps, psy 3, mode '{args.mode}'): "
+                                               "one real-time tick of everything BASELINE configs[3] spreads over 8 GPUs; 4096 distinct signals, repeated",
+                                   "value": round(nt * 6 / et, 1), "unit": "frames/s", "kernel_ms": round(kt, 4),
+                                   "share_of_the_24_ms_tick": round(kt / 24.0, 4)}
+        except Exception as ex:  # noqa: BLE001
+            also["tick_131072"] = {"value": None, "error": str(ex)}
         try:
             also["pcie_inclusive"] = pcie_inclusive(M, np, gen_pcm, 8, psy, args.mode, local_rank, S)
         except Exception as ex:  # noqa: BLE001
