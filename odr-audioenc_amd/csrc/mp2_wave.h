@@ -2943,6 +2943,7 @@ TL_FN void tl_encode_stream(W &w, const TlBlockShared *TL_RESTRICT B, const TlLa
 // independent of each other: the filterbank's history is PCM (the previous input frame, or the stream state before frame 0),
 // the SMR comes from the psy kernel's record, and the one thing a frame owes its predecessor -- its ScF-CRC, which travels in
 // the frame before (toolame.c:527-542) -- is filed aside and put in place by tl_finish_stream.
+template <int PSY>     // TL_PSY_EXT: SMR from the psy kernel's record (models 1 and 3); 0: model 0, which needs nothing but this frame's scalefactors
 TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, const TlLaunch &A, int s, int f)
 {
     const TlConfig *C = &A.configs[A.stream_cfg[s]];
@@ -2962,7 +2963,7 @@ TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const 
     fo.words = f + 1 < A.nframes ? nullptr : A.newpend + (size_t)s * TL_MAX_FRAME_WORDS;
     fo.scfcrc = A.scfcrc + slot * 4;
     const int padding = A.padbits ? (int)A.padbits[slot] : 0;
-    tl_encode_frame<TL_PSY_EXT>(w, A.tables, B, C, nullptr, nullptr, &A.psy_out[slot], pv, st, xl, nullptr, false, fo, enw_s, K, padding,
+    tl_encode_frame<PSY>(w, A.tables, B, C, nullptr, nullptr, PSY == TL_PSY_EXT ? &A.psy_out[slot] : nullptr, pv, st, xl, nullptr, false, fo, enw_s, K, padding,
                                 A.taps ? &A.taps[slot] : nullptr, sp);
 }
 

@@ -24,23 +24,25 @@ static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 #define TLB_HOST_CHUNKS 4            // tlb_encode_host pipelines a big call in this many chunks of frames
 
 // ---- kernels of the encode path ------------------------------------------------------------------------------------------
-// One wavefront per stream.  Two shapes:
+// One wavefront per unit of work.  Two shapes:
 //
-//  * psy models 0, 2 and 4: ONE kernel, tl_encode_kernel<PSY>: a workgroup = 4 independent waves, each takes one stream
-//    through the frames of the launch (model 2/4 carries prediction state from frame to frame).
-//
-//  * psy models 1 and 3 (the ones DAB uses): TWO kernels.
-//      tl_psy_kernel<PSY>   the psychoacoustic model alone.  It reads nothing but PCM, so every (stream, frame) is an
-//                           independent unit: persistent waves take units off a strided list, no per-stream state, no
-//                           frame order.  Without the filterbank's 72 sample registers and the encoder's arrays it fits
-//                           168 VGPRs and 11.0 KB of LDS per wave: 3 waves per SIMD instead of 2.  Output: 1 KB per frame
-//                           (TlPsyOut: level and minimum masking threshold per subband).
-//      tl_main_kernel       filterbank, scalefactors, SMR from TlPsyOut, bit allocation, quantiser, packing, CRCs; one wave
-//                           per stream, frames in order (the pending frame stays in LDS for the whole launch).  Also 3 waves
-//                           per SIMD.
+//  * psy models 0, 1 and 3 (the ones DAB services use): the frames of a launch are independent units, (stream, frame).
+//      tl_psy_kernel<PSY>   models 1 and 3: the psychoacoustic model alone.  It reads nothing but PCM.  Without the
+//                           filterbank's 72 sample registers and the encoder's arrays it fits 168 VGPRs and 11.0 KB of LDS
+//                           per wave: 3 waves per SIMD instead of 2.  Output: 1 KB per frame (TlPsyOut: level and minimum
+//                           masking threshold per subband).
+//      tl_main_kernel<PSY>  filterbank, scalefactors, SMR (from TlPsyOut; model 0: from the scalefactors, no psy kernel),
+//                           bit allocation, quantiser, packing, CRCs.  The filterbank's history is PCM, so these units
+//                           are independent too; the one thing a frame owes its predecessor (its ScF-CRC travels in the
+//                           frame before) is filed aside.  Also 3 waves per SIMD.
+//      tl_finish_kernel     a wave per stream: the pending frame of the last launch to slot 0, ScF-CRCs into place, state.
+//    Both big kernels are persistent: 12 waves per CU take units off a device-wide counter.
 //    The price is HBM traffic the fused form did not have (PCM is read by both kernels, TlPsyOut is written and read):
-//    ~2.2 x the algorithmic bytes -- on a path that uses 1-2 % of the HBM bandwidth and is bound by VALU issue and LDS
+//    2.7 x the algorithmic bytes -- on a path that uses 1-2 % of the HBM bandwidth and is bound by VALU issue and LDS
 //    latency, where occupancy is what pays (DESIGN.md section 4 has the counters of both forms).
+//
+//  * psy models 2 and 4: ONE fused kernel, tl_encode_kernel<2>: a workgroup = 4 independent waves, each takes one stream
+//    through the frames of the launch in order (the model carries prediction state from pass to pass).
 template <int PSY>
 __global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK, 2) tl_encode_kernel(TlLaunch A)
 {
@@ -110,6 +112,7 @@ struct TlMainShared { double enw_s[512]; char bytes[sizeof(TlBlockShared) - offs
 static_assert(offsetof(TlBlockShared, dbtable) == 0 && offsetof(TlBlockShared, scalefactor) == sizeof(double) * 1002, "dbtable leads TlBlockShared");
 #define TL_MAIN_WAVES (4 * TL_MAIN_WPE)       // one workgroup per CU: one copy of the tables
 static_assert((sizeof(TlMainShared) + TL_MAIN_WAVES * sizeof(TlMainLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "the encode workgroup fits a CU");
+template <int PSY>     // TL_PSY_EXT: models 1 and 3 (after tl_psy_kernel); 0: model 0, no psy kernel
 __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_waves_per_eu(TL_MAIN_WPE, TL_MAIN_WPE))) tl_main_kernel(TlLaunch A)
 {
     __shared__ TlMainShared sh;
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
     for (int u = (int)blockIdx.x * TL_MAIN_WAVES + wave; u < nunits; u = nwaves + tl_next_unit(&A.work[1])) {      // as in the psy kernel
         const int f = u / A.nlist, k = u - f * A.nlist;
         const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
-        tl_main_unit(lds[wave], B, sh.enw_s, &sh.pack, A, s, f);
+        tl_main_unit<PSY>(lds[wave], B, sh.enw_s, &sh.pack, A, s, f);
     }
 }
 
@@ -454,11 +457,11 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
         HIPCHK(hipMalloc(&b->d_psy2_state, sizeof(TlPsy2State) * (size_t)nstreams));
         HIPCHK(hipMemset(b->d_psy2_state, 0, sizeof(TlPsy2State) * (size_t)nstreams));
     }
-    if (b->n_list[1] || b->n_list[3]) {
+    if (b->n_list[0] || b->n_list[1] || b->n_list[3]) {
         HIPCHK(hipMalloc(&b->d_newpend, sizeof(uint32_t) * TL_MAX_FRAME_WORDS * (size_t)nstreams));
         HIPCHK(hipMemset(b->d_newpend, 0, sizeof(uint32_t) * TL_MAX_FRAME_WORDS * (size_t)nstreams));
         HIPCHK(hipMalloc(&b->d_work, sizeof(int32_t) * 2));
-        if (b->pads[1] || b->pads[3]) HIPCHK(hipMalloc(&b->d_newlag, sizeof(double) * (size_t)nstreams));
+        if (b->pads[0] || b->pads[1] || b->pads[3]) HIPCHK(hipMalloc(&b->d_newlag, sizeof(double) * (size_t)nstreams));
     }
     HIPCHK(hipEventCreate(&b->ev0));
     HIPCHK(hipEventCreate(&b->ev1));
@@ -504,13 +507,13 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
     A.out = d_out; A.out_len = d_out_len; A.taps = d_taps; A.stamps = d_stamps;
     A.psy2_tables = b->d_psy2_tables; A.psy2_state = b->d_psy2_state;
     A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride;
-    if (b->n_list[1] || b->n_list[3]) {
+    if (b->n_list[0] || b->n_list[1] || b->n_list[3]) {
         // TlPsyOut records of this launch (psy kernel -> encode kernel), grow-only.  NOTE: one buffer per batch -- launches of
         // one batch are ordered on one stream (they share the stream state anyway)
         HIPCHK(stage_reserve(b, 5, (size_t)nframes * (size_t)b->nstreams * sizeof(TlPsyOut)));
         HIPCHK(stage_reserve(b, 6, (size_t)nframes * (size_t)b->nstreams * 4));
         A.psy_out = (TlPsyOut *)b->stage[5]; A.scfcrc = (uint8_t *)b->stage[6]; A.newpend = b->d_newpend; A.work = b->d_work;
-        if (b->pads[1] || b->pads[3]) HIPCHK(stage_reserve(b, 7, (size_t)nframes * (size_t)b->nstreams));
+        if (b->pads[0] || b->pads[1] || b->pads[3]) HIPCHK(stage_reserve(b, 7, (size_t)nframes * (size_t)b->nstreams));
     }
     HIPCHK(hipEventRecord(b->ev0, st));
     b->have_mid = false;
@@ -518,7 +521,7 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         if (!b->n_list[p]) continue;
         A.stream_list = b->d_list[p]; A.nlist = b->n_list[p];
         const int blocks = (b->n_list[p] + TL_WAVES_PER_BLOCK - 1) / TL_WAVES_PER_BLOCK;
-        if (p == 1 || p == 3) {
+        if (p != 2) {
             // persistent waves, twelve per CU (three per SIMD) in both kernels; they take (stream, frame) units off a counter
             const long units = (long)b->n_list[p] * nframes;
             if (units > (1L << 24)) return TLB_ERR_ARG;             // the unit counters count 64 per unit in 32 bits (tl_next_unit)
@@ -528,16 +531,16 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
             long pb = (units + TL_PSY_WAVES - 1) / TL_PSY_WAVES;
             if (pb > (12L / TL_PSY_WAVES) * b->num_cu) pb = (12L / TL_PSY_WAVES) * b->num_cu;
             if (p == 1) hipLaunchKernelGGL(tl_psy_kernel<1>, dim3((unsigned)pb), dim3(64 * TL_PSY_WAVES), 0, st, A);
-            else hipLaunchKernelGGL(tl_psy_kernel<3>, dim3((unsigned)pb), dim3(64 * TL_PSY_WAVES), 0, st, A);
+            else if (p == 3) hipLaunchKernelGGL(tl_psy_kernel<3>, dim3((unsigned)pb), dim3(64 * TL_PSY_WAVES), 0, st, A);
             HIPCHK(hipGetLastError());
-            if (!b->n_list[0] && !b->n_list[2] && !(b->n_list[1] && b->n_list[3])) { HIPCHK(hipEventRecord(b->ev_mid, st)); b->have_mid = true; }
+            if (p && !b->n_list[0] && !b->n_list[2] && !(b->n_list[1] && b->n_list[3])) { HIPCHK(hipEventRecord(b->ev_mid, st)); b->have_mid = true; }
             long mb = (units + TL_MAIN_WAVES - 1) / TL_MAIN_WAVES;
             if (mb > b->num_cu) mb = b->num_cu;
-            hipLaunchKernelGGL(tl_main_kernel, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);
+            if (p == 0) hipLaunchKernelGGL(tl_main_kernel<0>, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);       // model 0: no psy kernel
+            else hipLaunchKernelGGL(tl_main_kernel<TL_PSY_EXT>, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(tl_finish_kernel, dim3((unsigned)((b->n_list[p] + 3) / 4)), dim3(256), 0, st, A);
-        } else if (p == 0) hipLaunchKernelGGL(tl_encode_kernel<0>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);
-        else hipLaunchKernelGGL(tl_encode_kernel<2>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);
+        } else hipLaunchKernelGGL(tl_encode_kernel<2>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(b->ev1, st));
@@ -593,7 +596,7 @@ int tlb_encode_host_len(tlb_batch *b, const int16_t *pcm, int nframes, const uin
     }
     // TlPsyOut / ScF-CRC scratch sized for the largest chunk up front (tlb_launch would otherwise re-allocate between chunks)
     const int per = (nframes + nchunks - 1) / nchunks;
-    if (b->n_list[1] || b->n_list[3]) {
+    if (b->n_list[0] || b->n_list[1] || b->n_list[3]) {
         HIPCHK(stage_reserve(b, 5, (size_t)per * (size_t)b->nstreams * sizeof(TlPsyOut)));
         HIPCHK(stage_reserve(b, 6, (size_t)per * (size_t)b->nstreams * 4));
     }

@@ -79,7 +79,7 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
     static thread_local TlWaveLds w;
     static thread_local TlMainLds wm;
     static thread_local TlPsyLds wp;
-    // models 1 and 3 as on the device: the psy kernel's units (every frame of every such stream; any order: here frames
+    // models 0, 1 and 3 as on the device: the psy kernel's units (models 1 and 3: every frame of every such stream; any order: here frames
     // descending, to show that nothing is carried from frame to frame), the encode kernel's units (any order: here frames
     // descending within streams ascending), then the finish pass per stream
     std::vector<TlPsyOut> psy_out((size_t)nframes * (size_t)A.nstreams);
@@ -92,7 +92,7 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
     bool pads = false;
     for (int s = 0; s < A.nstreams; s++) pads |= e->configs[e->stream_cfg[s]].pad_frac != 0;
     if (pads) { A.padbits = padbits.data(); A.newlag = newlag.data(); }
-    auto split = [&](int s) { const int m = e->configs[e->stream_cfg[s]].psy; return m == 1 || m == 3; };
+    auto split = [&](int s) { const int m = e->configs[e->stream_cfg[s]].psy; return m == 0 || m == 1 || m == 3; };
     for (int f = nframes - 1; f >= 0; f--)
         for (int s = 0; s < A.nstreams; s++) {
             const int m = e->configs[e->stream_cfg[s]].psy;
@@ -101,10 +101,12 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
         }
     if (pads) for (int s = 0; s < A.nstreams; s++) if (split(s)) tl_slots_stream(A, s);
     for (int s = 0; s < A.nstreams; s++)
-        if (split(s)) for (int f = nframes - 1; f >= 0; f--) tl_main_unit(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, f);
+        if (split(s)) for (int f = nframes - 1; f >= 0; f--) {
+            if (e->configs[e->stream_cfg[s]].psy == 0) tl_main_unit<0>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, f);
+            else tl_main_unit<TL_PSY_EXT>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, f);
+        }
     for (int s = 0; s < A.nstreams; s++)
         if (split(s)) tl_finish_stream(A, s);
-        else if (e->configs[e->stream_cfg[s]].psy == 0) tl_encode_stream<0>(w, &e->tables.shared, A, s);
         else tl_encode_stream<2>(w, &e->tables.shared, A, s);             // models 2 and 4 (4: the psy-2 code on its own tables)
     return 0;
 }
