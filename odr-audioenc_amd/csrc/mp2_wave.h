@@ -291,9 +291,11 @@ struct TlMainLds {
     __device__ YpRows yp_rows() { return yp; }
 #endif
 };
-// What the psy kernel of models 1 and 3 hands to the encode kernel per frame: per (channel, subband) the level A that competes
-// with the scalefactor level and the minimum masking threshold m;  SMR = max(A, scale_db[min scalefactor index]) - m
-// (psycho_1.c:568-581: A = spike level; psycho_3.c:163-183,409-432: A = strongest line of the subband).
+// Per-wave LDS of the psy kernel of models 2 and 4: the transform / energies (partition sums in its dead upper half) and c[] / fthr[].
+struct TlPsy2Lds {
+    struct { double fft[1024]; } u;
+    double px[520];
+};
 // Per-wave LDS of the psy kernel (models 1 and 3): TlWaveLds without what only the rest of the encoder needs.
 struct TlPsyLds {
     struct { double fft[TL_FFT_WORDS]; } u;
@@ -1906,8 +1908,9 @@ TL_FN void tl_psy3_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
 // PCM history on pass 0, samples 96..575 of the frame on pass 1 (the reference's savebuf shift by 576).
 // Line-parallel: FFT, unpredictability (sincos/atan2/sqrt per line), thresholds; partition-parallel:
 // grouping, spreading, SNR.  Every sum is one lane's sequential chain in the reference's order.
-TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_RESTRICT P,
-                   TlPsy2State *TL_RESTRICT S, const TlPcmView &pv, int ch, long long *sp)
+template <class W>
+TL_FN void tl_psy2(W &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_RESTRICT P,
+                   TlPsy2State *TL_RESTRICT S, const TlPcmView &pv, int ch, long long *sp, double *smr_out)
 {
     double *x = w.u.fft;
     double *cw = w.px;                       // c[] (unpredictability), then fthr[]
@@ -2081,7 +2084,7 @@ TL_FN void tl_psy2(TlWaveLds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
             double snr = lane < 13 ? sum_energy / (minthres * 17.0) : sum_energy / minthres;
             snr = 4.342944819 * tl_log(snr);
             if (pass == 0) L(snr0) = snr;
-            else w.smr[ch][lane] = L(snr0) > snr ? L(snr0) : snr;
+            else smr_out[lane] = L(snr0) > snr ? L(snr0) : snr;
         }
         TL_LANES_END
         TL_STAMP(sq, 6);
@@ -2290,7 +2293,14 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         }
         TL_LANES_END
     } else if constexpr (PSY == 2) {
-        for (int ch = 0; ch < nch; ch++) tl_psy2(w, T, P2, S2, pv, ch, sp ? sp + 8 + 8 * ch : nullptr);
+        if constexpr (W::kFrameParallel) {                       // models 2 and 4, split path: the psy-2 kernel left the SMR itself
+            TL_LANES_BEGIN
+            const int c = lane & 1, sb = lane >> 1;
+            if (c < nch) w.smr[c][sb] = PO->a[c][sb];
+            TL_LANES_END
+        } else {
+            for (int ch = 0; ch < nch; ch++) tl_psy2(w, T, P2, S2, pv, ch, sp ? sp + 8 + 8 * ch : nullptr, w.smr[ch]);
+        }
     } else {
         // models 1 and 3: the psy kernel left, per (channel, subband), the level A that competes with the scalefactor level and
         // the minimum masking threshold m (TlPsyOut); the SMR line itself needs this frame's scalefactors and is finished here:
@@ -2859,6 +2869,21 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
     TL_STAMP(sp, 23);                                                 // unit end
 }
 
+// Models 2 and 4 on the split path.  The model carries r/phi of the two previous passes per channel (psycho_2.c:300-306), so
+// the frames of a channel are a chain -- but the two channels of a stream share nothing: one unit = all frames of the launch
+// of ONE channel of one stream, in order.  It leaves the SMR itself in TlPsyOut::a (the model's last line needs no scalefactors).
+TL_FN void tl_psy2_chain(TlPsy2Lds &w, const TlLaunch &A, int s, int ch)
+{
+    const TlConfig *C = &A.configs[A.stream_cfg[s]];
+    if (ch >= C->nch) return;
+    for (int f = 0; f < A.nframes; f++) {
+        const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
+        const TlPcmView pv = tl_pcm_view(A, &A.state[s], s, f);
+        tl_psy2(w, A.tables, &A.psy2_tables[C->psy2_tab], &A.psy2_state[s], pv, ch,
+                A.stamps ? A.stamps + slot * 32 + 8 + 8 * ch : nullptr, &A.psy_out[slot].a[ch][0]);
+    }
+}
+
 // [history | frame] -> LDS in 8-byte pieces, 120 + 288 per channel.  All of a lane's loads are issued before the first LDS
 // write so the HBM latency is paid once per frame, not once per piece.
 template <class W>
@@ -2943,7 +2968,7 @@ TL_FN void tl_encode_stream(W &w, const TlBlockShared *TL_RESTRICT B, const TlLa
 // independent of each other: the filterbank's history is PCM (the previous input frame, or the stream state before frame 0),
 // the SMR comes from the psy kernel's record, and the one thing a frame owes its predecessor -- its ScF-CRC, which travels in
 // the frame before (toolame.c:527-542) -- is filed aside and put in place by tl_finish_stream.
-template <int PSY>     // TL_PSY_EXT: SMR from the psy kernel's record (models 1 and 3); 0: model 0, which needs nothing but this frame's scalefactors
+template <int PSY>     // TL_PSY_EXT: SMR from the psy kernel's record (models 1 and 3); 2: the psy-2 kernel's SMR (models 2 and 4); 0: model 0, which needs nothing but this frame's scalefactors
 TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, const TlLaunch &A, int s, int f)
 {
     const TlConfig *C = &A.configs[A.stream_cfg[s]];
@@ -2963,7 +2988,7 @@ TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const 
     fo.words = f + 1 < A.nframes ? nullptr : A.newpend + (size_t)s * TL_MAX_FRAME_WORDS;
     fo.scfcrc = A.scfcrc + slot * 4;
     const int padding = A.padbits ? (int)A.padbits[slot] : 0;
-    tl_encode_frame<PSY>(w, A.tables, B, C, nullptr, nullptr, PSY == TL_PSY_EXT ? &A.psy_out[slot] : nullptr, pv, st, xl, nullptr, false, fo, enw_s, K, padding,
+    tl_encode_frame<PSY>(w, A.tables, B, C, nullptr, nullptr, PSY != 0 ? &A.psy_out[slot] : nullptr, pv, st, xl, nullptr, false, fo, enw_s, K, padding,
                                 A.taps ? &A.taps[slot] : nullptr, sp);
 }
 

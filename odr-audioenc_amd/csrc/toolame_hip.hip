@@ -107,6 +107,22 @@ __global__ void __launch_bounds__(64 * TL_PSY_WAVES) __attribute__((amdgpu_waves
     }
 }
 
+// psy kernel of models 2 and 4: a unit = one channel of one stream through the frames of the launch (tl_psy2_chain); units
+// [0, nlist) are the first channels, [nlist, 2 nlist) the second ones (mono streams: nothing to do).  No table in LDS (the
+// model's tables are read through the caches), 12.1 KB per wave: twelve waves per CU like the other psy kernels.
+#define TL_PSY2_WAVES 12
+static_assert((TL_PSY2_WAVES * sizeof(TlPsy2Lds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "twelve psy-2 waves per CU");
+__global__ void __launch_bounds__(64 * TL_PSY2_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) tl_psy2_kernel(TlLaunch A)
+{
+    __shared__ TlPsy2Lds lds[TL_PSY2_WAVES];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nunits = 2 * A.nlist, nwaves = (int)gridDim.x * TL_PSY2_WAVES;
+    for (int u = (int)blockIdx.x * TL_PSY2_WAVES + wave; u < nunits; u = nwaves + tl_next_unit(&A.work[0])) {
+        const int ch = u >= A.nlist ? 1 : 0, k = u - ch * A.nlist;
+        tl_psy2_chain(lds[wave], A, __builtin_amdgcn_readfirstlane(A.stream_list[k]), ch);
+    }
+}
+
 // encode kernel of the split path: the tables it needs on dependent-load chains (TlBlockShared without the dB-sum table)
 struct TlMainShared { double enw_s[512]; char bytes[sizeof(TlBlockShared) - offsetof(TlBlockShared, scalefactor)]; TlPackTables pack; };
 static_assert(offsetof(TlBlockShared, dbtable) == 0 && offsetof(TlBlockShared, scalefactor) == sizeof(double) * 1002, "dbtable leads TlBlockShared");
@@ -457,11 +473,11 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
         HIPCHK(hipMalloc(&b->d_psy2_state, sizeof(TlPsy2State) * (size_t)nstreams));
         HIPCHK(hipMemset(b->d_psy2_state, 0, sizeof(TlPsy2State) * (size_t)nstreams));
     }
-    if (b->n_list[0] || b->n_list[1] || b->n_list[3]) {
+    {
         HIPCHK(hipMalloc(&b->d_newpend, sizeof(uint32_t) * TL_MAX_FRAME_WORDS * (size_t)nstreams));
         HIPCHK(hipMemset(b->d_newpend, 0, sizeof(uint32_t) * TL_MAX_FRAME_WORDS * (size_t)nstreams));
         HIPCHK(hipMalloc(&b->d_work, sizeof(int32_t) * 2));
-        if (b->pads[0] || b->pads[1] || b->pads[3]) HIPCHK(hipMalloc(&b->d_newlag, sizeof(double) * (size_t)nstreams));
+        if (b->pads[0] || b->pads[1] || b->pads[2] || b->pads[3]) HIPCHK(hipMalloc(&b->d_newlag, sizeof(double) * (size_t)nstreams));
     }
     HIPCHK(hipEventCreate(&b->ev0));
     HIPCHK(hipEventCreate(&b->ev1));
@@ -507,40 +523,41 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
     A.out = d_out; A.out_len = d_out_len; A.taps = d_taps; A.stamps = d_stamps;
     A.psy2_tables = b->d_psy2_tables; A.psy2_state = b->d_psy2_state;
     A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride;
-    if (b->n_list[0] || b->n_list[1] || b->n_list[3]) {
+    {
         // TlPsyOut records of this launch (psy kernel -> encode kernel), grow-only.  NOTE: one buffer per batch -- launches of
         // one batch are ordered on one stream (they share the stream state anyway)
         HIPCHK(stage_reserve(b, 5, (size_t)nframes * (size_t)b->nstreams * sizeof(TlPsyOut)));
         HIPCHK(stage_reserve(b, 6, (size_t)nframes * (size_t)b->nstreams * 4));
         A.psy_out = (TlPsyOut *)b->stage[5]; A.scfcrc = (uint8_t *)b->stage[6]; A.newpend = b->d_newpend; A.work = b->d_work;
-        if (b->pads[0] || b->pads[1] || b->pads[3]) HIPCHK(stage_reserve(b, 7, (size_t)nframes * (size_t)b->nstreams));
+        if (b->pads[0] || b->pads[1] || b->pads[2] || b->pads[3]) HIPCHK(stage_reserve(b, 7, (size_t)nframes * (size_t)b->nstreams));
     }
     HIPCHK(hipEventRecord(b->ev0, st));
     b->have_mid = false;
     for (int p = 0; p < 4; p++) {
         if (!b->n_list[p]) continue;
         A.stream_list = b->d_list[p]; A.nlist = b->n_list[p];
-        const int blocks = (b->n_list[p] + TL_WAVES_PER_BLOCK - 1) / TL_WAVES_PER_BLOCK;
-        if (p != 2) {
-            // persistent waves, twelve per CU (three per SIMD) in both kernels; they take (stream, frame) units off a counter
-            const long units = (long)b->n_list[p] * nframes;
-            if (units > (1L << 24)) return TLB_ERR_ARG;             // the unit counters count 64 per unit in 32 bits (tl_next_unit)
-            A.padbits = b->pads[p] ? (uint8_t *)b->stage[7] : nullptr; A.newlag = b->d_newlag;
-            if (b->pads[p]) { hipLaunchKernelGGL(tl_slots_kernel, dim3((unsigned)((b->n_list[p] + 255) / 256)), dim3(256), 0, st, A); HIPCHK(hipGetLastError()); }
-            HIPCHK(hipMemsetAsync(b->d_work, 0, sizeof(int32_t) * 2, st));
-            long pb = (units + TL_PSY_WAVES - 1) / TL_PSY_WAVES;
-            if (pb > (12L / TL_PSY_WAVES) * b->num_cu) pb = (12L / TL_PSY_WAVES) * b->num_cu;
-            if (p == 1) hipLaunchKernelGGL(tl_psy_kernel<1>, dim3((unsigned)pb), dim3(64 * TL_PSY_WAVES), 0, st, A);
-            else if (p == 3) hipLaunchKernelGGL(tl_psy_kernel<3>, dim3((unsigned)pb), dim3(64 * TL_PSY_WAVES), 0, st, A);
-            HIPCHK(hipGetLastError());
-            if (p && !b->n_list[0] && !b->n_list[2] && !(b->n_list[1] && b->n_list[3])) { HIPCHK(hipEventRecord(b->ev_mid, st)); b->have_mid = true; }
-            long mb = (units + TL_MAIN_WAVES - 1) / TL_MAIN_WAVES;
-            if (mb > b->num_cu) mb = b->num_cu;
-            if (p == 0) hipLaunchKernelGGL(tl_main_kernel<0>, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);       // model 0: no psy kernel
-            else hipLaunchKernelGGL(tl_main_kernel<TL_PSY_EXT>, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);
-            HIPCHK(hipGetLastError());
-            hipLaunchKernelGGL(tl_finish_kernel, dim3((unsigned)((b->n_list[p] + 3) / 4)), dim3(256), 0, st, A);
-        } else hipLaunchKernelGGL(tl_encode_kernel<2>, dim3(blocks), dim3(64 * TL_WAVES_PER_BLOCK), 0, st, A);
+        // persistent waves, twelve per CU (three per SIMD) in every kernel; they take their units off a counter
+        const long units = (long)b->n_list[p] * nframes;
+        if (units > (1L << 24)) return TLB_ERR_ARG;                 // the unit counters count 64 per unit in 32 bits (tl_next_unit)
+        A.padbits = b->pads[p] ? (uint8_t *)b->stage[7] : nullptr; A.newlag = b->d_newlag;
+        if (b->pads[p]) { hipLaunchKernelGGL(tl_slots_kernel, dim3((unsigned)((b->n_list[p] + 255) / 256)), dim3(256), 0, st, A); HIPCHK(hipGetLastError()); }
+        HIPCHK(hipMemsetAsync(b->d_work, 0, sizeof(int32_t) * 2, st));
+        long pb = (units + TL_PSY_WAVES - 1) / TL_PSY_WAVES;
+        if (pb > (12L / TL_PSY_WAVES) * b->num_cu) pb = (12L / TL_PSY_WAVES) * b->num_cu;
+        long qb = (2L * b->n_list[p] + TL_PSY2_WAVES - 1) / TL_PSY2_WAVES;
+        if (qb > b->num_cu) qb = b->num_cu;
+        if (p == 1) hipLaunchKernelGGL(tl_psy_kernel<1>, dim3((unsigned)pb), dim3(64 * TL_PSY_WAVES), 0, st, A);
+        else if (p == 3) hipLaunchKernelGGL(tl_psy_kernel<3>, dim3((unsigned)pb), dim3(64 * TL_PSY_WAVES), 0, st, A);
+        else if (p == 2) hipLaunchKernelGGL(tl_psy2_kernel, dim3((unsigned)qb), dim3(64 * TL_PSY2_WAVES), 0, st, A);
+        HIPCHK(hipGetLastError());
+        if (p && b->n_list[p] == b->nstreams) { HIPCHK(hipEventRecord(b->ev_mid, st)); b->have_mid = true; }      // one model in the batch: psy | encode split of the time
+        long mb = (units + TL_MAIN_WAVES - 1) / TL_MAIN_WAVES;
+        if (mb > b->num_cu) mb = b->num_cu;
+        if (p == 0) hipLaunchKernelGGL(tl_main_kernel<0>, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);       // model 0: no psy kernel
+        else if (p == 2) hipLaunchKernelGGL(tl_main_kernel<2>, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);
+        else hipLaunchKernelGGL(tl_main_kernel<TL_PSY_EXT>, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(tl_finish_kernel, dim3((unsigned)((b->n_list[p] + 3) / 4)), dim3(256), 0, st, A);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(b->ev1, st));
@@ -596,7 +613,7 @@ int tlb_encode_host_len(tlb_batch *b, const int16_t *pcm, int nframes, const uin
     }
     // TlPsyOut / ScF-CRC scratch sized for the largest chunk up front (tlb_launch would otherwise re-allocate between chunks)
     const int per = (nframes + nchunks - 1) / nchunks;
-    if (b->n_list[0] || b->n_list[1] || b->n_list[3]) {
+    {
         HIPCHK(stage_reserve(b, 5, (size_t)per * (size_t)b->nstreams * sizeof(TlPsyOut)));
         HIPCHK(stage_reserve(b, 6, (size_t)per * (size_t)b->nstreams * 4));
     }
