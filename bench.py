@@ -295,12 +295,12 @@ def main():
         frames = sum(int(p[0]) for p in per_rank)
         value = frames / elapsed
         algo_bytes_per_launch = ALGO_BYTES_PER_FRAME * S * F
-        split = psy in (1, 3)
-        kname = (f"tl_psy_kernel<{psy}> + tl_main_kernel + tl_finish_kernel (the three kernels of one launch of the path)" if split
-                 else f"tl_encode_kernel<{2 if psy == 4 else psy}>")
+        pk = {0: None, 1: "tl_psy_kernel<1>", 2: "tl_psy2_kernel", 3: "tl_psy_kernel<3>", 4: "tl_psy2_kernel"}[psy]
+        kname = (f"{pk} + tl_main_kernel + tl_finish_kernel (the three kernels of one launch of the path)" if pk
+                 else "tl_main_kernel<0> + tl_finish_kernel (model 0 has no psy kernel)")
         kernels = None
-        if split and run_stage_ms:
-            kernels = {f"tl_psy_kernel<{psy}>": round(run_stage_ms[0], 4), "tl_main_kernel + tl_finish_kernel": round(run_stage_ms[1], 4),
+        if pk and run_stage_ms:
+            kernels = {pk: round(run_stage_ms[0], 4), "tl_main_kernel + tl_finish_kernel": round(run_stage_ms[1], 4),
                        "source": "hipEvents on the launch stream inside the library (tlb_last_stage_ms), last timed launch"}
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh): a committed
         # measurement, quoted only when it was taken on this very workload; never measured inside this run
@@ -336,8 +336,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kname, "kernel_ms": round(kernel_ms, 4), "last_kernel_ms_hip_events": round(last_ms, 4), "kernels_ms": kernels,
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch,
-                         "binding_resource": "fp64 VALU issue + LDS latency chains (not HBM: 4992 B per 0.35 MFLOP frame, SURVEY F9); models 1/3 "
-                                             "trade HBM traffic for occupancy (PCM read by two kernels, 1 KB/frame psy record)",
+                         "binding_resource": "fp64 VALU issue + LDS latency chains (not HBM: 4992 B per 0.35 MFLOP frame, SURVEY F9); the split "
+                                             "into a psy and an encode kernel trades HBM traffic for occupancy (PCM read by two kernels, 1 KB/frame psy record)",
                          "secondary_fp64": {"achieved_tflops": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 1e12, 3), "peak_tflops": 78.6,
                                             "frac": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 78.6e12, 5),
                                             "basis": "0.35 MFLOP algorithmic fp64 per stereo frame (SURVEY 8d), vector fp64 peak"},

@@ -215,7 +215,6 @@ TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
 // ------------------------------------------------------------------------------------------
 // Per-wave LDS working set.
 #define TL_CAND_MAX 256              // local maxima with passing right side (<= 249)
-#define TL_FB_BATCH 12               // fused kernels: filterbank blocks per LDS round trip (36 = 3 x 12); the window outputs go through the (idle) psy arrays px[] .. cinfo[]
 #ifndef TL_FB_BATCH_MAIN
 #define TL_FB_BATCH_MAIN 6           // encode kernel of the split path: 36 = 6 x 6 (a smaller scratch, fewer live registers)
 #endif
@@ -231,46 +230,10 @@ TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
 // spread over the banks, and the spike sums -- a lane per subband walking its 16 lines (psycho_1.c:252-257) -- no longer
 // collide (16 lanes at stride 16 doubles would share one bank pair; the XOR gives each its own).
 #define TL_EX(i) ((i) ^ (((i) >> 4) & 15))
-struct TlWaveLds {
-    // Stage-exclusive 8 KB: [PCM history | frame] + filterbank scratch  ->  FHT buffer / energy (and, once the
-    // energies are dead, the masker lists and thresholds)  ->  the frame being packed.
-    union alignas(16) {
-        struct { int16_t pcm[2][TL_HIST + 1152]; } fbk;
-        double fft[1024];
-        uint32_t frame[TL_MAX_FRAME_WORDS + 2];          // + 2: tl_put_bits48 may OR zeros into the two words after a field
-    } u;
-    double px[520];                     // psy 2/4: c[] / fthr[]; filterbank: window-output scratch (psy 1/3 run on TlPsyLds, power spectrum at TL_PX)
-    double tone_x[TL_TONE_MAX];         // psy: summed level of each confirmed tone
-    double smr[2][32];
-    double spike[32];                   // psy-1 spike / psy-3 Lsb
-    double nsum[32];                    // psy noise sums per critical band
-    uint32_t cinfo[TL_CAND_MAX];        // tone candidates (line | left-fail mask << 10 | run << 21); psy-1 slow path: links
-    int16_t conf_c[TL_TONE_MAX];        // confirmed tones: line | variant << 12 | erased << 13
-    int16_t conf_nxt[TL_TONE_MAX];      // psy-1: chain links between confirmed tones
-    int16_t tlist[TL_TONE_MAX];         // psy-1: chain order
-    int16_t ncentre[32];
-    int16_t bandoff[40];                // psy-1/3: first compacted entry of each critical band
-    uint8_t ptype[520];
-    uint8_t scf[2][3][32];
-    uint8_t jscale[3][32];
-    uint8_t scfsi[2][32];
-    uint8_t balloc[2][32];
-    uint8_t minidx[2][32];
-    uint8_t xpad[TL_MAX_XPAD];
-    static constexpr int kFbBatch = TL_FB_BATCH;
-    static constexpr bool kFrameParallel = false;
-    typedef double (*YpRows)[2][34];    // [kFbBatch][2][32 (+2: the four addresses a matrixing read touches sit on different banks)]
-#ifdef TL_EMULATE
-    YpRows yp_rows() { return (YpRows)px; }
-#else
-    __device__ YpRows yp_rows() { return (YpRows)px; }
-#endif
-};
-// Per-wave LDS of the encode kernel of the split path (models 1 and 3 run in their own kernel): PCM staging / frame being
+// Per-wave LDS of the encode kernel (the psy models run in their own kernels): PCM staging / frame being
 // packed, the filterbank's window-output scratch and the small per-subband arrays.
 struct TlMainLds {
     static constexpr int kFbBatch = TL_FB_BATCH_MAIN;
-    static constexpr bool kFrameParallel = true;
     union alignas(16) {
         struct { int16_t pcm[2][TL_HIST + 1152]; } fbk;
         uint32_t frame[TL_MAX_FRAME_WORDS + 2];
@@ -296,7 +259,7 @@ struct TlPsy2Lds {
     struct { double fft[1024]; } u;
     double px[520];
 };
-// Per-wave LDS of the psy kernel (models 1 and 3): TlWaveLds without what only the rest of the encoder needs.
+// Per-wave LDS of the psy kernel (models 1 and 3).
 struct TlPsyLds {
     struct { double fft[TL_FFT_WORDS]; } u;
     TlPsyOut *po;                       // where this unit's result goes (HBM)
@@ -2094,15 +2057,14 @@ TL_FN void tl_psy2(W &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_R
 // ------------------------------------------------------------------------------------------
 // One frame of one stream.  lane = 2*sb + ch owns subband sb of channel ch.  PSY (the psy model) is a compile-time
 // parameter: one kernel per model keeps each kernel's code and register footprint to what that model needs.
-static_assert(offsetof(TlWaveLds, cinfo) + sizeof(((TlWaveLds *)0)->cinfo) - offsetof(TlWaveLds, px) >= sizeof(double) * TL_FB_BATCH * 68, "filterbank scratch");
 // Where a frame of the frame-parallel encode kernel goes (exactly one of bytes / words is set): the output slot it waits in
 // for its successor's ScF-CRC, or -- the last frame of a launch -- the batch's pending buffer (big-endian words like
 // TlStreamState::pending); and the slot for its own ScF-CRC bytes, which tl_finish_stream stores into the frame before it.
 struct TlFrameOut { uint8_t *bytes; uint32_t *words; uint8_t *scfcrc; };
 template <int PSY, class W>
 TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
-                           const TlConfig *TL_RESTRICT C, const TlPsy2Tables *TL_RESTRICT P2, TlPsy2State *TL_RESTRICT S2, const TlPsyOut *TL_RESTRICT PO,
-                           const TlPcmView &pv, TlStreamState *st, int xpad_len, uint8_t *out_prev, bool have_prev, const TlFrameOut &fo,
+                           const TlConfig *TL_RESTRICT C, const TlPsyOut *TL_RESTRICT PO,
+                           const TlPcmView &pv, int xpad_len, const TlFrameOut &fo,
                            const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, int padding, TlTaps *taps, long long *sp)
 {
     constexpr int FB = W::kFbBatch;
@@ -2293,14 +2255,10 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         }
         TL_LANES_END
     } else if constexpr (PSY == 2) {
-        if constexpr (W::kFrameParallel) {                       // models 2 and 4, split path: the psy-2 kernel left the SMR itself
-            TL_LANES_BEGIN
-            const int c = lane & 1, sb = lane >> 1;
-            if (c < nch) w.smr[c][sb] = PO->a[c][sb];
-            TL_LANES_END
-        } else {
-            for (int ch = 0; ch < nch; ch++) tl_psy2(w, T, P2, S2, pv, ch, sp ? sp + 8 + 8 * ch : nullptr, w.smr[ch]);
-        }
+        TL_LANES_BEGIN                                           // models 2 and 4: the psy-2 kernel left the SMR itself
+        const int c = lane & 1, sb = lane >> 1;
+        if (c < nch) w.smr[c][sb] = PO->a[c][sb];
+        TL_LANES_END
     } else {
         // models 1 and 3: the psy kernel left, per (channel, subband), the level A that competes with the scalefactor level and
         // the minimum masking threshold m (TlPsyOut); the SMR line itself needs this frame's scalefactors and is finished here:
@@ -2759,51 +2717,22 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
     }
 
     TL_STAMP(sp, 6);
-    // ---- emit: patch the previous frame's ScF-CRC slot with this frame's CRC and hand it out;
-    //      this frame becomes the pending one (toolame.c:527-542, "one frame in memory") ----
+    // ---- emit (toolame.c:527-542 keeps "one frame in memory" to patch its ScF-CRC slot with the next frame's CRC) ----
     const int nwords = (lg_frame + 3) >> 2;
-    if constexpr (W::kFrameParallel) {
-        // frames of a stream are encoded by different waves in any order: this one only files its frame and its ScF-CRC;
-        // tl_finish_stream puts each frame's CRC into the frame before it once the launch's frames are all there
-        TL_LANES_BEGIN
-        for (int i = lane; i < nwords; i += 64) {
-            if (fo.words) fo.words[i] = frame[i];
-            else {
-                const uint32_t le = tl_bswap(frame[i]);
-                const int rem = lg_frame - 4 * i;
-                if (rem >= 4) ((uint32_t *)fo.bytes)[i] = le;
-                else for (int b = 0; b < rem; b++) fo.bytes[4 * i + b] = (uint8_t)(le >> (8 * b));
-            }
-        }
-        if (lane < 4) fo.scfcrc[lane] = lane < C->dab_ext ? (uint8_t)w.ncentre[lane] : 0;
-        TL_LANES_END
-    } else {
-    // the previous frame has its own length (a padding slot more or less at 44.1 / 22.05 kHz); its ScF-CRC bytes sit
-    // 2 + dab_ext bytes before ITS end (toolame.c:530-532 writes them lg_frame bytes behind the current position)
-    const int prev_len = st->pending_len, ptail = prev_len - 2 - C->dab_ext, pwords = (prev_len + 3) >> 2;
+    // frames of a stream are encoded by different waves in any order: this one only files its frame and its ScF-CRC;
+    // tl_finish_stream puts each frame's CRC into the frame before it once the launch's frames are all there
     TL_LANES_BEGIN
-    for (int i = lane; i < (nwords > pwords ? nwords : pwords); i += 64) {
-        if (have_prev && out_prev && i < pwords) {
-            uint32_t prev = st->pending[i];
-            for (int k = 0; k < C->dab_ext; k++) {
-                int bp = ptail + k;
-                if ((bp >> 2) == i) {
-                    int sh = 24 - 8 * (bp & 3);
-                    prev = (prev & ~(0xffu << sh)) | ((uint32_t)(w.ncentre[k] & 0xff) << sh);
-                }
-            }
-            uint32_t le = tl_bswap(prev);
-            int rem = prev_len - 4 * i;
-            if (rem >= 4) ((uint32_t *)out_prev)[i] = le;
-            else for (int b = 0; b < rem; b++) out_prev[4 * i + b] = (uint8_t)(le >> (8 * b));
+    for (int i = lane; i < nwords; i += 64) {
+        if (fo.words) fo.words[i] = frame[i];
+        else {
+            const uint32_t le = tl_bswap(frame[i]);
+            const int rem = lg_frame - 4 * i;
+            if (rem >= 4) ((uint32_t *)fo.bytes)[i] = le;
+            else for (int b = 0; b < rem; b++) fo.bytes[4 * i + b] = (uint8_t)(le >> (8 * b));
         }
-        if (i < nwords) st->pending[i] = frame[i];
     }
+    if (lane < 4) fo.scfcrc[lane] = lane < C->dab_ext ? (uint8_t)w.ncentre[lane] : 0;
     TL_LANES_END
-    TL_LANES_BEGIN
-    if (lane == 0) st->pending_len = lg_frame;
-    TL_LANES_END
-    }
     TL_STAMP(sp, 7);
 }
 
@@ -2926,45 +2855,7 @@ TL_FN int tl_stage_xpad(W &w, const TlLaunch &A, const TlConfig *C, size_t slot)
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused kernels (psy models 0, 2, 4): a wave encodes `nframes` consecutive frames of stream `s`.
-template <int PSY, class W>
-TL_FN void tl_encode_stream(W &w, const TlBlockShared *TL_RESTRICT B, const TlLaunch &A, int s)
-{
-    const TlTables *T = A.tables;
-    const TlConfig *C = &A.configs[A.stream_cfg[s]];
-    TlStreamState *st = &A.state[s];
-    const int nch = C->nch;
-    int done = st->frames_done;
-    double lag = st->slot_lag;
-    const TlFrameOut none = {nullptr, nullptr, nullptr};
-    for (int f = 0; f < A.nframes; f++) {
-        const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
-        const TlPcmView pv = tl_pcm_view(A, st, s, f);
-        TL_STAMP(A.stamps ? A.stamps + slot * 32 : nullptr, 31);        // frame begin, before the PCM staging
-        tl_stage_pcm(w, pv, nch);
-        const int xl = tl_stage_xpad(w, A, C, slot);
-        const int padding = tl_slot_step(lag, C->pad_frac);
-        if (A.out_len) { const int pl = done > 0 ? st->pending_len : 0; TL_LANES_BEGIN if (lane == 0) A.out_len[slot] = pl; TL_LANES_END }
-        tl_encode_frame<PSY>(w, T, B, C, A.psy2_tables ? &A.psy2_tables[C->psy2_tab] : nullptr, A.psy2_state ? &A.psy2_state[s] : nullptr,
-                             nullptr, pv, st, xl, A.out + slot * (size_t)A.out_stride, done > 0, none, T->enwindow_s, &T->pack, padding,
-                             A.taps ? &A.taps[slot] : nullptr, A.stamps ? A.stamps + slot * 32 : nullptr);
-        done++;
-    }
-    // the last 480 samples per channel of the last input frame become the stream's history
-    {
-        const int16_t *last = A.pcm + ((size_t)(A.nframes - 1) * (size_t)A.nstreams + (size_t)s) * 2304;
-        TL_LANES_BEGIN
-        for (int i = lane; i < (TL_HIST / 2) * 2; i += 64) {
-            const int ch = i / (TL_HIST / 2), k = (i % (TL_HIST / 2)) * 2;
-            *(uint32_t *)&st->hist[ch][k] = ch < nch ? *(const uint32_t *)(last + ch * 1152 + (1152 - TL_HIST) + k) : 0u;
-        }
-        if (lane == 0) { st->frames_done = done; st->slot_lag = lag; }
-        TL_LANES_END
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Split path (psy models 1 and 3), encode kernel: one unit = frame f of stream s.  Like the psy kernel's units these are
+// Encode kernel: one unit = frame f of stream s.  Like the psy kernel's units these are
 // independent of each other: the filterbank's history is PCM (the previous input frame, or the stream state before frame 0),
 // the SMR comes from the psy kernel's record, and the one thing a frame owes its predecessor -- its ScF-CRC, which travels in
 // the frame before (toolame.c:527-542) -- is filed aside and put in place by tl_finish_stream.
@@ -2988,7 +2879,7 @@ TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const 
     fo.words = f + 1 < A.nframes ? nullptr : A.newpend + (size_t)s * TL_MAX_FRAME_WORDS;
     fo.scfcrc = A.scfcrc + slot * 4;
     const int padding = A.padbits ? (int)A.padbits[slot] : 0;
-    tl_encode_frame<PSY>(w, A.tables, B, C, nullptr, nullptr, PSY != 0 ? &A.psy_out[slot] : nullptr, pv, st, xl, nullptr, false, fo, enw_s, K, padding,
+    tl_encode_frame<PSY>(w, A.tables, B, C, PSY != 0 ? &A.psy_out[slot] : nullptr, pv, xl, fo, enw_s, K, padding,
                                 A.taps ? &A.taps[slot] : nullptr, sp);
 }
 

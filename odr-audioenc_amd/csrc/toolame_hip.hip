@@ -20,11 +20,10 @@
 
 static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 
-#define TL_WAVES_PER_BLOCK 4
 #define TLB_HOST_CHUNKS 4            // tlb_encode_host pipelines a big call in this many chunks of frames
 
 // ---- kernels of the encode path ------------------------------------------------------------------------------------------
-// One wavefront per unit of work.  Two shapes:
+// One wavefront per unit of work:
 //
 //  * psy models 0, 1 and 3 (the ones DAB services use): the frames of a launch are independent units, (stream, frame).
 //      tl_psy_kernel<PSY>   models 1 and 3: the psychoacoustic model alone.  It reads nothing but PCM.  Without the
@@ -41,29 +40,9 @@ static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 //    2.7 x the algorithmic bytes -- on a path that uses 1-2 % of the HBM bandwidth and is bound by VALU issue and LDS
 //    latency, where occupancy is what pays (DESIGN.md section 4 has the counters of both forms).
 //
-//  * psy models 2 and 4: ONE fused kernel, tl_encode_kernel<2>: a workgroup = 4 independent waves, each takes one stream
-//    through the frames of the launch in order (the model carries prediction state from pass to pass).
-template <int PSY>
-__global__ void __launch_bounds__(64 * TL_WAVES_PER_BLOCK, 2) tl_encode_kernel(TlLaunch A)
-{
-    __shared__ TlBlockShared shared;                 // tables on dependent-load chains, one copy per workgroup
-    __shared__ TlWaveLds lds[TL_WAVES_PER_BLOCK];
-    static_assert(sizeof(TlBlockShared) % 8 == 0, "copied as doubles");
-    {
-        const double *src = (const double *)&A.tables->shared;
-        double *dst = (double *)&shared;
-        for (int i = (int)threadIdx.x; i < (int)(sizeof(TlBlockShared) / 8); i += 64 * TL_WAVES_PER_BLOCK) dst[i] = src[i];
-    }
-    __syncthreads();                                 // the only workgroup barrier: the waves are independent from here on
-    // wave-uniform by construction; say so, or every pointer derived from the stream id lives in VGPRs
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int k = (int)blockIdx.x * TL_WAVES_PER_BLOCK + wave;
-    if (k >= A.nlist) return;
-    const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
-    tl_encode_stream<PSY>(lds[wave], &shared, A, s);
-}
-
-// psy kernel: TL_PSY_WAVES waves per workgroup share one copy of the dB-sum table (8 KB); two workgroups per CU.
+//  * psy models 2 and 4 carry prediction state from pass to pass (psycho_2.c:300-306), per channel: tl_psy2_kernel takes
+//    one CHANNEL of one stream through the frames of the launch (12 waves per CU as well) and leaves the SMR in TlPsyOut;
+//    tl_main_kernel<2> and tl_finish_kernel as above.
 // Next unit of a persistent kernel's work list (device-scope atomic: the counter is shared by all XCDs).  Every lane adds 1
 // -- hipcc folds that into ONE atomic of +64 per wave (its wave-level atomic optimiser) -- and the unit is the wave's base
 // / 64.  No `if (lane == 0)` in the source: with one, LLVM threaded the branch together with an equal test at the end of
@@ -366,7 +345,13 @@ int tlb_device_count(void)
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
-int tlb_lds_bytes_per_stream(void) { return (int)sizeof(TlWaveLds); }
+int tlb_lds_bytes_per_stream(void)
+{   // per WAVE (= per unit in flight): the largest of the kernels' per-wave blocks
+    size_t m = sizeof(TlMainLds);
+    if (sizeof(TlPsyLds) > m) m = sizeof(TlPsyLds);
+    if (sizeof(TlPsy2Lds) > m) m = sizeof(TlPsy2Lds);
+    return (int)m;
+}
 const char *tlb_version(void) { return "odr-audioenc_amd 0.1 (gfx950, wave-per-stream, fp64)"; }
 
 void tlb_destroy(tlb_batch *b)
@@ -523,8 +508,7 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
     A.out = d_out; A.out_len = d_out_len; A.taps = d_taps; A.stamps = d_stamps;
     A.psy2_tables = b->d_psy2_tables; A.psy2_state = b->d_psy2_state;
     A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride;
-    {
-        // TlPsyOut records of this launch (psy kernel -> encode kernel), grow-only.  NOTE: one buffer per batch -- launches of
+    {   // TlPsyOut records of this launch (psy kernel -> encode kernel), grow-only.  NOTE: one buffer per batch -- launches of
         // one batch are ordered on one stream (they share the stream state anyway)
         HIPCHK(stage_reserve(b, 5, (size_t)nframes * (size_t)b->nstreams * sizeof(TlPsyOut)));
         HIPCHK(stage_reserve(b, 6, (size_t)nframes * (size_t)b->nstreams * 4));

@@ -161,7 +161,7 @@ int emu_edi_pft(const uint8_t *af, const int32_t *af_len, int nframes, int nstre
     return 0;
 }
 int emu_sizeof_taps(void) { return (int)sizeof(TlTaps); }
-int emu_sizeof_lds(void) { return (int)sizeof(TlWaveLds); }
+int emu_sizeof_lds(void) { return (int)sizeof(TlMainLds); }
 double emu_log10(double x) { return tl_log10(x); }
 double emu_log10_pn(double x) { return tl_log10_pn(x); }
 double emu_pow10(double x) { return tl_pow10(x); }

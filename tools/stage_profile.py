@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-stage share of a frame's cycles inside tl_encode_kernel (s_memtime stamps).
+"""Diagnostic: per-stage share of a frame's cycles inside the encode and psy kernels (s_memtime stamps).
 Run on the GPU box: python tools/stage_profile.py [psy] [mode] [nstreams]"""
 import ctypes as C
 import sys
@@ -23,9 +23,9 @@ L.tlb_encode_host_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p
 st = np.zeros((F, S, 32), dtype=np.int64)
 assert L.tlb_encode_host_stamps(b.h, np.ascontiguousarray(pcm).ctypes.data, F, st.ctypes.data) == 0
 st = st[1:]                                   # skip the first (cold) frame
-names = ["filterbank", "scalefactors", "psy" if psy in (0, 2, 4) else "smr from the psy kernel's record", "sfpattern+bitalloc", "quantise+pack", "crc+scfcrc+pad", "emit"]
+names = ["filterbank", "scalefactors", "psy 0" if psy == 0 else "smr from the psy kernel's record", "sfpattern+bitalloc", "quantise+pack", "crc+scfcrc+pad", "emit"]
 tot = (st[..., 7] - st[..., 0]).mean()
-print(f"psy {psy} mode {mode} {S} streams: {tot:.0f} s_memtime ticks/frame/wave in the {'fused' if psy in (0, 2, 4) else 'encode'} kernel")
+print(f"psy {psy} mode {mode} {S} streams: {tot:.0f} s_memtime ticks/frame/wave in the encode kernel")
 if psy in (1, 3):
     ptot = (st[..., 23] - st[..., 15]).mean()
     print(f"psy kernel: {ptot:.0f} ticks/unit/wave; shares below are of encode + psy = {tot + ptot:.0f}")
@@ -34,7 +34,7 @@ for i, n in enumerate(names):
     d = (st[..., i + 1] - st[..., i]).mean()
     print(f"  {n:22s} {d:10.0f}  {100 * d / tot:5.1f}%")
 pn = ["spectrum(FHT)", "power+candidates", "tonal walk", "noise bands", "decimation", "threshold", "minmask+smr"]
-if psy == 2:      # stamps of the first of the two 576-sample passes
+if psy in (2, 4):      # stamps of the first of the two 576-sample passes of a frame, in tl_psy2_kernel (shares: of the ENCODE kernel's ticks)
     pn = ["window+FHT", "energy/phase/unpred.", "partitions", "spreading+SNR", "line thresholds", "subbands", "-"]
 for ch in range(2):
     base = 8 + 8 * ch
@@ -54,6 +54,3 @@ if st[..., 25].max() > 0:
 if st[..., 31].max() > 0:
     d = (st[..., 0] - st[..., 31]).mean()
     print(f"  PCM staging before stamp 0: {d:8.0f}  {100 * d / tot:5.1f}% (not in the total above)")
-    if st.shape[0] > 1:
-        g = (st[1:, :, 31] - st[:-1, :, 7]).mean()
-        print(f"  gap between frames (emit end -> next frame begin): {g:8.0f}")
