@@ -1876,8 +1876,8 @@ TL_FN void tl_psy2(W &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_R
                    TlPsy2State *TL_RESTRICT S, const TlPcmView &pv, int ch, long long *sp, double *smr_out)
 {
     double *x = w.u.fft;
-    double *cw = w.px;                       // c[] (unpredictability), then fthr[]
-    double *ge = w.u.fft + 520, *gc = ge + 64, *ecb = gc + 64, *nb = ecb + 64;   // dead upper half of the FHT buffer
+    double *cw = w.px, *ge = w.u.fft + 520;  // c[] (unpredictability), then fthr[]; partition sums in the
+    double *gc = ge + 64, *ecb = gc + 64, *nb = ecb + 64;   // dead upper half of the FHT buffer
     PV(double, snr0);
     for (int pass = 0; pass < 2; pass++) {
         long long *sq = pass == 0 ? sp : nullptr;                  // stage stamps of the first pass

@@ -89,9 +89,11 @@ __global__ void __launch_bounds__(64 * TL_PSY_WAVES) __attribute__((amdgpu_waves
 // psy kernel of models 2 and 4: a unit = one channel of one stream through the frames of the launch (tl_psy2_chain); units
 // [0, nlist) are the first channels, [nlist, 2 nlist) the second ones (mono streams: nothing to do).  No table in LDS (the
 // model's tables are read through the caches), 12.1 KB per wave: twelve waves per CU like the other psy kernels.
+#ifndef TL_PSY2_WAVES
 #define TL_PSY2_WAVES 12
+#endif
 static_assert((TL_PSY2_WAVES * sizeof(TlPsy2Lds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "twelve psy-2 waves per CU");
-__global__ void __launch_bounds__(64 * TL_PSY2_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) tl_psy2_kernel(TlLaunch A)
+__global__ void __launch_bounds__(64 * TL_PSY2_WAVES) __attribute__((amdgpu_waves_per_eu(TL_PSY2_WAVES / 4, TL_PSY2_WAVES / 4))) tl_psy2_kernel(TlLaunch A)
 {
     __shared__ TlPsy2Lds lds[TL_PSY2_WAVES];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -11,7 +11,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 G, P = ROOT / "gpurun_out", ROOT / "profiles"
 V = sys.argv[1]
-KERNELS = ("tl_psy_kernel", "tl_main_kernel", "tl_finish_kernel", "tl_encode_kernel")
+KERNELS = ("tl_psy_kernel", "tl_psy2_kernel", "tl_main_kernel", "tl_finish_kernel")
 
 
 def cp(src, dst=None):
@@ -66,8 +66,8 @@ k2, t2 = traffic("psy2")
 if k2:
     d2 = {"version": V, "workload": dict(wl, psy=2), "kernels": k2, "hbm_bytes_per_launch": t2, "algorithmic_bytes_per_launch": 4992 * frames,
           "ratio_to_algorithmic": round(t2 / (4992 * frames), 3),
-          "note": "tl_encode_kernel<2> (models 2 and 4, fused): the r/phi prediction state of psycho_2.c:300-306 (32.8 KB per stream) is read and "
-                  "written per 576-sample pass", "source": f"tools/profile_round2.sh {V}; raw CSVs: profiles/{V}_pmc_psy2_*"}
+          "note": "tl_psy2_kernel (models 2 and 4): the r/phi prediction state of psycho_2.c:300-306 (32.8 KB per stream) is read and "
+                  "written per 576-sample pass; then tl_main_kernel<2> + tl_finish_kernel as for the other models", "source": f"tools/profile_round2.sh {V}; raw CSVs: profiles/{V}_pmc_psy2_*"}
     json.dump(d2, open(P / f"{V}_pmc_traffic_psy2.json", "w"), indent=1)
     print("psy2 traffic", t2, "ratio", d2["ratio_to_algorithmic"])
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One profiling round on the GPU box (round 2 layout: psy kernel + encode kernel + finish kernel for models 1/3).
+# One profiling round on the GPU box (psy kernel + encode kernel + finish kernel).
 #   bash tools/profile_round2.sh TAG      -> everything under gpurun_out/, then (here) tools/install_profiles2.py TAG
 # rocprofv3 runs the program itself after `--` (python3 bench.py ...); counters are collected in their own passes with
 # --kernel-trace only (never with the sys/hip/hsa trace domains).
@@ -32,11 +32,12 @@ $T bash tools/pmc_split.sh ${V}_psy3 --psy 3 --streams 16384 --frames-per-step 8
 $T bash tools/pmc_split.sh ${V}_psy2 --psy 2 > gpurun_out/sq_${V}_psy2.txt 2>&1
 cat gpurun_out/sq_${V}_hl.txt
 # 5. where a frame's time goes (s_memtime stamps)
-for p in 1 2 3; do $T python3 tools/stage_profile.py $p s 3072 > gpurun_out/stage_${V}_psy$p.txt 2>&1; done
+for p in 0 1 2 3; do $T python3 tools/stage_profile.py $p s 3072 > gpurun_out/stage_${V}_psy$p.txt 2>&1; done
 # 6. other workloads, one line each
 $T python3 bench.py --no-cpu-baseline --no-also --psy 2 2>/dev/null | tail -1 > gpurun_out/bench_${V}_psy2.json
 $T python3 bench.py --no-cpu-baseline --no-also --psy 4 2>/dev/null | tail -1 > gpurun_out/bench_${V}_psy4.json
 $T python3 bench.py --no-cpu-baseline --no-also --psy 0 --streams 16384 --frames-per-step 8 2>/dev/null | tail -1 > gpurun_out/bench_${V}_psy0_16384.json
+$T python3 bench.py --no-cpu-baseline --no-also --psy 0 2>/dev/null | tail -1 > gpurun_out/bench_${V}_psy0.json
 $T python3 bench.py --no-cpu-baseline --no-also --psy 3 --streams 16384 --frames-per-step 8 2>/dev/null | tail -1 > gpurun_out/bench_${V}_cfg2_psy3_16384.json
 $T python3 bench.py --no-cpu-baseline --no-also --frames-per-step 8 2>/dev/null | tail -1 > gpurun_out/bench_${V}_cfg1_F8.json
 $T python3 tools/edi_bench.py > gpurun_out/edi_bench_${V}.txt 2>&1
