@@ -295,9 +295,10 @@ def main():
         frames = sum(int(p[0]) for p in per_rank)
         value = frames / elapsed
         algo_bytes_per_launch = ALGO_BYTES_PER_FRAME * S * F
-        pk = {0: None, 1: "tl_psy_kernel<1>", 2: "tl_psy2_kernel", 3: "tl_psy_kernel<3>", 4: "tl_psy2_kernel"}[psy]
-        kname = (f"{pk} + tl_main_kernel + tl_finish_kernel (the three kernels of one launch of the path)" if pk
-                 else "tl_main_kernel<0> + tl_finish_kernel (model 0 has no psy kernel)")
+        pk = "tl_psy2_kernel" if psy in (2, 4) else None
+        kname = (f"{pk} + tl_main_kernel<2> + tl_finish_kernel (the three kernels of one launch of the path)" if pk
+                 else "tl_main_kernel<0> + tl_finish_kernel (model 0 has no psy kernel)" if psy == 0
+                 else f"tl_frame_kernel<{psy}> (psy model, then encoder, per (stream, frame) unit) + tl_finish_kernel")
         kernels = None
         if pk and run_stage_ms:
             kernels = {pk: round(run_stage_ms[0], 4), "tl_main_kernel + tl_finish_kernel": round(run_stage_ms[1], 4),
@@ -336,8 +337,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kname, "kernel_ms": round(kernel_ms, 4), "last_kernel_ms_hip_events": round(last_ms, 4), "kernels_ms": kernels,
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch,
-                         "binding_resource": "fp64 VALU issue + LDS latency chains (not HBM: 4992 B per 0.35 MFLOP frame, SURVEY F9); the split "
-                                             "into a psy and an encode kernel trades HBM traffic for occupancy (PCM read by two kernels, 1 KB/frame psy record)",
+                         "binding_resource": "fp64 VALU issue + LDS latency chains (not HBM: 4992 B per 0.35 MFLOP frame, SURVEY F9)",
                          "secondary_fp64": {"achieved_tflops": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 1e12, 3), "peak_tflops": 78.6,
                                             "frac": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 78.6e12, 5),
                                             "basis": "0.35 MFLOP algorithmic fp64 per stereo frame (SURVEY 8d), vector fp64 peak"},

@@ -215,8 +215,9 @@ int tlb_encode_host_stamps(tlb_batch *b, const int16_t *pcm, int nframes, long l
 /* Duration in milliseconds of the most recent tlb_encode_device()/tlb_encode_host() kernel, measured
  * with hipEvents on the launch stream (synchronises on that stream).  < 0 on error. */
 float tlb_last_kernel_ms(tlb_batch *b);
-/* Models 1 to 4 run as two kernels (the psychoacoustic model, then the rest of the encoder).  Their durations for the most
- * recent launch of a batch whose streams all use the same one of these models; non-zero return for any other batch. */
+/* Models 2 and 4 run as two kernels (the psychoacoustic model, then the rest of the encoder).  Their durations for the most
+ * recent launch of a batch whose streams all use these models; non-zero return for any other batch (models 1 and 3 run
+ * model and encoder in one kernel, model 0 has no model kernel). */
 int tlb_last_stage_ms(tlb_batch *b, float *psy_ms, float *encode_ms);
 /* LDS bytes per wavefront: the largest per-wave block among the kernels (each holds 12 waves per CU). */
 int tlb_lds_bytes_per_stream(void);

@@ -2883,6 +2883,19 @@ TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const 
                                 A.taps ? &A.taps[slot] : nullptr, sp);
 }
 
+// Models 1 and 3: one unit = frame f of stream s, psy model first, then the encoder, by the same wave.  The two phases
+// share the wave's LDS block (a union: the model's arrays are dead when the encoder starts) and nothing else but the
+// model's record.
+union TlFrameLds { TlPsyLds p; TlMainLds m; };
+template <int PSY>
+TL_FN void tl_frame_unit(TlFrameLds &w, const double *TL_RESTRICT db, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s,
+                         const TlPackTables *TL_RESTRICT K, const TlLaunch &Apsy, const TlLaunch &Amain, int s, int f)
+{
+    tl_psy_unit<PSY>(w.p, db, Apsy, s, f);
+    TL_SYNC();
+    tl_main_unit<TL_PSY_EXT>(w.m, B, enw_s, K, Amain, s, f);
+}
+
 // After the units of a launch: for stream s, hand out the frame that was pending before the launch (slot 0), store every
 // frame's ScF-CRC into the frame before it, make the launch's last frame the pending one, roll the PCM history forward.
 TL_FN void tl_finish_stream(const TlLaunch &A, int s)

@@ -54,38 +54,12 @@ static __device__ __forceinline__ int tl_next_unit(int32_t *counter)
     return __builtin_amdgcn_readfirstlane(u) >> 6;
 }
 
-// psy kernel: the twelve waves a CU holds at 168 VGPRs are ONE workgroup sharing one copy of the dB-sum table (8 KB).  LDS is
-// handed out in granules of 1280 bytes on gfx950 (160 KB / 128): three 4-wave workgroups with a table each do not fit.
-#ifndef TL_PSY_WAVES
-#define TL_PSY_WAVES 12
-#endif
-#ifndef TL_PSY_WPE
-#define TL_PSY_WPE 3
-#endif
+// LDS is handed out in granules of 1280 bytes on gfx950 (160 KB / 128): the twelve waves a CU holds at 3 per SIMD are ONE
+// workgroup sharing one copy of the tables (three 4-wave workgroups with a copy each do not fit).
 #ifndef TL_MAIN_WPE
 #define TL_MAIN_WPE 3
 #endif
 #define TL_LDS_GRANULE 1280u
-static_assert(((sizeof(double) * 1002 + TL_PSY_WAVES * sizeof(TlPsyLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE) * (12 / TL_PSY_WAVES) <= 128, "twelve psy waves per CU");
-template <int PSY>
-__global__ void __launch_bounds__(64 * TL_PSY_WAVES) __attribute__((amdgpu_waves_per_eu(TL_PSY_WPE, TL_PSY_WPE))) tl_psy_kernel(TlLaunch A)
-{
-    __shared__ double dbt[1002];                     // the dB-sum table, one copy per workgroup
-    __shared__ TlPsyLds lds[TL_PSY_WAVES];
-    for (int i = (int)threadIdx.x; i < 1002; i += 64 * TL_PSY_WAVES) dbt[i] = A.tables->shared.dbtable[i];
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nunits = A.nlist * A.nframes, nwaves = (int)gridDim.x * TL_PSY_WAVES;
-    // units cost different amounts: every wave takes the next one when it is free.  The FIRST unit of a wave is its own index
-    // (no counter access: three thousand waves asking one address at once queue for tens of microseconds), the rest come off
-    // the counter, which therefore starts at the number of waves.
-    for (int u = (int)blockIdx.x * TL_PSY_WAVES + wave; u < nunits; u = nwaves + tl_next_unit(&A.work[0])) {
-        const int f = u / A.nlist, k = u - f * A.nlist;             // units taken one after the other: neighbouring streams of one frame
-        const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
-        tl_psy_unit<PSY>(lds[wave], dbt, A, s, f);
-    }
-}
-
 // psy kernel of models 2 and 4: a unit = one channel of one stream through the frames of the launch (tl_psy2_chain); units
 // [0, nlist) are the first channels, [nlist, 2 nlist) the second ones (mono streams: nothing to do).  No table in LDS (the
 // model's tables are read through the caches), 12.1 KB per wave: twelve waves per CU like the other psy kernels.
@@ -131,6 +105,46 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
         const int f = u / A.nlist, k = u - f * A.nlist;
         const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
         tl_main_unit<PSY>(lds[wave], B, sh.enw_s, &sh.pack, A, s, f);
+    }
+}
+
+// Models 1 and 3: psy model and encoder of a (stream, frame) unit by the same wave, one after the other (tl_frame_unit).
+// Registers: the model needs 118, the encoder 154 -- the kernel needs the larger, not the sum, because the model runs BEFORE
+// the filterbank fills its 72 sample registers (round 1's fused kernel ran it in the middle: 256).  LDS: the union of the
+// two phases' blocks; both table sets (dB sums 7.8 KB, encoder 12.1 KB) once per workgroup.  The PCM the model read is still
+// in L2 when the encoder stages it.
+static_assert((sizeof(double) * 1002 + sizeof(TlMainShared) + TL_MAIN_WAVES * sizeof(TlFrameLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "the workgroup fits a CU");
+template <int PSY>
+__global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_waves_per_eu(TL_MAIN_WPE, TL_MAIN_WPE))) tl_frame_kernel(TlLaunch A)
+{
+    __shared__ double dbt[1002];
+    __shared__ TlMainShared sh;
+    __shared__ TlFrameLds lds[TL_MAIN_WAVES];
+    {
+        for (int i = (int)threadIdx.x; i < 1002; i += 64 * TL_MAIN_WAVES) dbt[i] = A.tables->shared.dbtable[i];
+        const double *src = (const double *)&A.tables->shared.scalefactor[0];
+        double *dst = (double *)&sh.bytes[0];
+        for (int i = (int)threadIdx.x; i < (int)(sizeof(sh.bytes) / 8); i += 64 * TL_MAIN_WAVES) dst[i] = src[i];
+        for (int i = (int)threadIdx.x; i < 512; i += 64 * TL_MAIN_WAVES) sh.enw_s[i] = A.tables->enwindow_s[i];
+        for (int i = (int)threadIdx.x; i < (int)(sizeof(TlPackTables) / 8); i += 64 * TL_MAIN_WAVES) ((double *)&sh.pack)[i] = ((const double *)&A.tables->pack)[i];
+    }
+    __syncthreads();
+    const TlBlockShared *B = (const TlBlockShared *)((const char *)&sh.bytes[0] - offsetof(TlBlockShared, scalefactor));
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nunits = A.nlist * A.nframes, nwaves = (int)gridDim.x * TL_MAIN_WAVES;
+    for (int u = (int)blockIdx.x * TL_MAIN_WAVES + wave; u < nunits; u = nwaves + tl_next_unit(&A.work[0])) {
+        const int f = u / A.nlist, k = u - f * A.nlist;
+        const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // each phase reads the launch record afresh from the kernel-argument segment (scalar loads), so that nothing but s
+        // and f lives in registers across the two
+        typedef const __attribute__((address_space(4))) TlLaunch *KArg;
+        KArg a1 = (KArg)__builtin_amdgcn_kernarg_segment_ptr(), a2 = a1;
+        asm volatile("" : "+s"(a1));
+        asm volatile("" : "+s"(a2));
+        const TlLaunch A1 = *a1, A2 = *a2;
+        tl_frame_unit<PSY>(lds[wave], dbt, B, sh.enw_s, &sh.pack, A1, A2, s, f);
+#endif
     }
 }
 
@@ -305,7 +319,7 @@ struct tlb_batch {
     int max_upf = 1;                             // egress units (3 * kbps bytes) per frame: 1 at 48 kHz, 2 at 24 kHz, 3 at 16 kHz; 0 = a stream's frames are no whole number of units
     TlEdiState *d_edi_state_tmp = nullptr;
     uint16_t *d_pseq_tmp = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;   // ev_mid: between the psy kernel and the encode kernel (models 1/3)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;   // ev_mid: between the psy-2 kernel and the encode kernel (models 2/4)
     bool have_mid = false;
     hipStream_t last_stream = nullptr;
     bool timed = false;
@@ -528,13 +542,19 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         A.padbits = b->pads[p] ? (uint8_t *)b->stage[7] : nullptr; A.newlag = b->d_newlag;
         if (b->pads[p]) { hipLaunchKernelGGL(tl_slots_kernel, dim3((unsigned)((b->n_list[p] + 255) / 256)), dim3(256), 0, st, A); HIPCHK(hipGetLastError()); }
         HIPCHK(hipMemsetAsync(b->d_work, 0, sizeof(int32_t) * 2, st));
-        long pb = (units + TL_PSY_WAVES - 1) / TL_PSY_WAVES;
-        if (pb > (12L / TL_PSY_WAVES) * b->num_cu) pb = (12L / TL_PSY_WAVES) * b->num_cu;
         long qb = (2L * b->n_list[p] + TL_PSY2_WAVES - 1) / TL_PSY2_WAVES;
         if (qb > b->num_cu) qb = b->num_cu;
-        if (p == 1) hipLaunchKernelGGL(tl_psy_kernel<1>, dim3((unsigned)pb), dim3(64 * TL_PSY_WAVES), 0, st, A);
-        else if (p == 3) hipLaunchKernelGGL(tl_psy_kernel<3>, dim3((unsigned)pb), dim3(64 * TL_PSY_WAVES), 0, st, A);
-        else if (p == 2) hipLaunchKernelGGL(tl_psy2_kernel, dim3((unsigned)qb), dim3(64 * TL_PSY2_WAVES), 0, st, A);
+        if (p == 1 || p == 3) {                                      // psy model and encoder in one kernel
+            long mb1 = (units + TL_MAIN_WAVES - 1) / TL_MAIN_WAVES;
+            if (mb1 > b->num_cu) mb1 = b->num_cu;
+            if (p == 1) hipLaunchKernelGGL(tl_frame_kernel<1>, dim3((unsigned)mb1), dim3(64 * TL_MAIN_WAVES), 0, st, A);
+            else hipLaunchKernelGGL(tl_frame_kernel<3>, dim3((unsigned)mb1), dim3(64 * TL_MAIN_WAVES), 0, st, A);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(tl_finish_kernel, dim3((unsigned)((b->n_list[p] + 3) / 4)), dim3(256), 0, st, A);
+            HIPCHK(hipGetLastError());
+            continue;
+        }
+        if (p == 2) hipLaunchKernelGGL(tl_psy2_kernel, dim3((unsigned)qb), dim3(64 * TL_PSY2_WAVES), 0, st, A);
         HIPCHK(hipGetLastError());
         if (p && b->n_list[p] == b->nstreams) { HIPCHK(hipEventRecord(b->ev_mid, st)); b->have_mid = true; }      // one model in the batch: psy | encode split of the time
         long mb = (units + TL_MAIN_WAVES - 1) / TL_MAIN_WAVES;

@@ -77,11 +77,11 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
     A.psy2_state = e->psy2_state.empty() ? nullptr : e->psy2_state.data();
     A.nstreams = (int)e->state.size(); A.nframes = nframes; A.out_stride = out_stride;
     static thread_local TlMainLds wm;
-    static thread_local TlPsyLds wp;
+    static thread_local TlFrameLds wf;
     static thread_local TlPsy2Lds wq;
-    // As on the device: the psy kernels' units (models 1 and 3: every frame of every such stream, any order -- here frames
-    // descending, to show that nothing is carried from frame to frame; models 2 and 4: a chain per channel, second channels
-    // first), the encode kernel's units (any order: frames descending within streams ascending), the finish pass per stream
+    // As on the device: the psy-2 kernel's units (models 2 and 4: a chain per channel, second channels first), the (stream, frame)
+    // units (any order -- here frames descending within streams ascending, to show that nothing is carried from frame to
+    // frame; models 1 and 3: psy model, then encoder, in one LDS block), the finish pass per stream
     std::vector<TlPsyOut> psy_out((size_t)nframes * (size_t)A.nstreams);
     std::vector<uint8_t> scfcrc((size_t)nframes * (size_t)A.nstreams * 4);
     std::vector<uint32_t> newpend((size_t)A.nstreams * TL_MAX_FRAME_WORDS);
@@ -93,11 +93,6 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
     for (int s = 0; s < A.nstreams; s++) pads |= e->configs[e->stream_cfg[s]].pad_frac != 0;
     if (pads) { A.padbits = padbits.data(); A.newlag = newlag.data(); }
     auto model = [&](int s) { return e->configs[e->stream_cfg[s]].psy; };
-    for (int f = nframes - 1; f >= 0; f--)
-        for (int s = 0; s < A.nstreams; s++) {
-            if (model(s) == 1) tl_psy_unit<1>(wp, e->tables.shared.dbtable, A, s, f);
-            else if (model(s) == 3) tl_psy_unit<3>(wp, e->tables.shared.dbtable, A, s, f);
-        }
     for (int ch = 1; ch >= 0; ch--)
         for (int s = 0; s < A.nstreams; s++)
             if (model(s) == 2 || model(s) == 4) tl_psy2_chain(wq, A, s, ch);
@@ -106,7 +101,8 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
         for (int f = nframes - 1; f >= 0; f--) {
             if (model(s) == 0) tl_main_unit<0>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, f);
             else if (model(s) == 2 || model(s) == 4) tl_main_unit<2>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, f);
-            else tl_main_unit<TL_PSY_EXT>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, f);
+            else if (model(s) == 1) tl_frame_unit<1>(wf, e->tables.shared.dbtable, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, A, s, f);
+            else tl_frame_unit<3>(wf, e->tables.shared.dbtable, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, A, s, f);
         }
     for (int s = 0; s < A.nstreams; s++) tl_finish_stream(A, s);
     return 0;
