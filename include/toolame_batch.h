@@ -96,7 +96,7 @@ long tlb_frames_encoded(const tlb_batch *b);           /* per stream */
  * frame f: slot 0 = the last frame of the previous call (undefined on the very first call), slot f =
  * input frame f-1.  tlb_flush_*() hands out the final pending frame.
  * The launch is asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).  Launches of ONE batch must be ordered
- * on one stream (they share the streams' state and the batch's scratch buffers); at most 2^24 (stream, frame) pairs per call. */
+ * on one stream (they share the streams' state and the batch's scratch buffers); at most 2^30 (stream, frame) pairs per call. */
 int tlb_encode_device(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d_xpad,
                       const int32_t *d_xpad_len, uint8_t *d_out, void *hip_stream);
 /* 44.1 and 22.05 kHz (libtoolame-dab encodes them; DAB itself does not use them, src/odr-audioenc.cpp:560-563): a frame is

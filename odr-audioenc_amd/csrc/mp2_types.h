@@ -110,10 +110,8 @@ struct TlPsy2State {
     double phi[2][2][513];
 };
 
-// What the psy kernel of models 1 and 3 hands to the encode kernel per frame: per (channel, subband) the level A that competes
-// with the scalefactor level and the minimum masking threshold m;  SMR = max(A, scale_db[min scalefactor index]) - m
-// (psycho_1.c:568-581: A = spike level; psycho_3.c:163-183,409-432: A = strongest line of the subband).
-struct TlPsyOut { double a[2][32]; double m[2][32]; };
+// What the psy kernel of models 2 and 4 hands to the encode kernel per frame: the SMR per (channel, subband).
+struct TlPsyOut { double a[2][32]; };
 
 // Per-stream state that persists across launches.
 struct TlStreamState {
@@ -156,11 +154,11 @@ struct TlLaunch {
     long long *stamps;                // [nframes][nstreams][32] cycle stamps (diagnostic builds) or null
     const TlPsy2Tables *psy2_tables;  // [*] indexed by TlConfig::psy2_tab, or null when no stream uses psy 2
     TlPsy2State *psy2_state;          // [nstreams] or null
-    TlPsyOut *psy_out;                // [nframes][nstreams] psy kernel -> encode kernel (models 1 and 3), or null
+    TlPsyOut *psy_out;                // [nframes][nstreams] psy-2 kernel -> encode kernel (models 2 and 4), or null
     uint8_t *scfcrc;                  // [nframes][nstreams][4] ScF-CRC bytes of each frame (split path: encode kernel -> finish kernel)
     uint32_t *newpend;                // [nstreams][TL_MAX_FRAME_WORDS] last frame of the launch, before it becomes the pending one
     uint8_t *padbits;                 // [nframes][nstreams] padding slot of each frame (tl_slots_stream), or null: no stream of the launch pads
     double *newlag;                   // [nstreams] the slot recurrence's state after the launch (with padbits)
-    int32_t *work;                    // [2] unit counters of the persistent kernels (psy, encode): waves take the next unit off them
+    int32_t *work;                    // unit counters of the persistent kernels: [0] psy-2 kernel, [32 (1 + q)] list q of the eight per-XCD lists of (stream, frame) units
     int32_t nstreams, nframes, out_stride, nlist;
 };

@@ -218,7 +218,7 @@ TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
 #ifndef TL_FB_BATCH_MAIN
 #define TL_FB_BATCH_MAIN 6           // encode kernel of the split path: 36 = 6 x 6 (a smaller scratch, fewer live registers)
 #endif
-#define TL_PSY_EXT 5                 // tl_encode_frame<TL_PSY_EXT>: SMR from the psy kernel's TlPsyOut (models 1 and 3)
+#define TL_PSY_EXT 5                 // tl_encode_frame<TL_PSY_EXT>: SMR from the record the model left in the wave's LDS (models 1 and 3)
 #define TL_TONE_MAX 77               // confirmed tones per channel-frame (hard bound 75: a tone erases run lines either side, 20 + 16 + 19 + 19 fit below line 500); sized so that three 4-wave psy workgroups fit one CU's LDS
 #define TL_MASKER_MAX 128            // tones + noise components after decimation
 // psy 1/3: the FHT needs 1024 doubles, what follows it needs the 513 energies (lower half) and the power spectrum in dB
@@ -239,7 +239,8 @@ struct TlMainLds {
         uint32_t frame[TL_MAX_FRAME_WORDS + 2];
     } u;
     double yp[TL_FB_BATCH_MAIN][2][34];
-    double smr[2][32];
+    double smr[2][32];                  // models 1 and 3: until the SMR line, the level of the model's record
+    double psy_m[2][32];                // models 1 and 3: minimum masking threshold of the model's record
     int16_t ncentre[32];                // (ScF-CRC scratch)
     uint8_t scf[2][3][32];
     uint8_t jscale[3][32];
@@ -262,7 +263,6 @@ struct TlPsy2Lds {
 // Per-wave LDS of the psy kernel (models 1 and 3).
 struct TlPsyLds {
     struct { double fft[TL_FFT_WORDS]; } u;
-    TlPsyOut *po;                       // where this unit's result goes (HBM)
     double tone_x[TL_TONE_MAX];
     double nsum[32];
     uint32_t cinfo[TL_CAND_MAX];
@@ -750,7 +750,7 @@ struct TlPsy1Ch { int nconf, nlist; bool dead_head; };
 
 template <class W>
 TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
-                             const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
+                             const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, PARGA(double, rec, 4), long long *sp)
 {
     const double *energy = w.u.fft;                                   // line i at TL_EX(i)
     double *px = TL_PX(w);
@@ -795,9 +795,8 @@ TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *
 #endif
         for (int j = 0; j < 16; j++) sum += 1073741824 * e[j];
         const double spk = 10.0 * tl_log10_pn(sum);
-        TlPsyOut *po = w.po;
-        po->a[ch][lane] = spk;                                      // final as it is: straight to the record (nothing to park)
-    } else if (lane < 32) { TlPsyOut *po = w.po; po->a[ch][lane] = 0.0; }
+        L(rec)[ch] = spk;                                           // final as it is: straight to the record (nothing to park)
+    } else if (lane < 32) L(rec)[ch] = 0.0;
     TL_LANES_END
 
     // ---- tonal components (psycho_1.c:267-340) ----
@@ -1065,7 +1064,7 @@ TL_FN void tl_psy1_centres(W &w, const TlConfig *TL_RESTRICT C, int nbands, PARG
 
 // individual + global masking thresholds, minimum per subband, SMR (psycho_1.c:480-581) from the masker lists
 template <class W>
-TL_FN void tl_psy1_thresholds(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, int ntone, int nnoise, long long *sp)
+TL_FN void tl_psy1_thresholds(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, int ntone, int nnoise, PARGA(double, rec, 4), long long *sp)
 {
     TL_STAMP(sp, 5);
 
@@ -1121,20 +1120,19 @@ TL_FN void tl_psy1_thresholds(W &w, const double *TL_RESTRICT db, const TlConfig
         else {
             m = tl_min_rows(TL_LTG(w), j0, n, 0.0, true);
         }
-        TlPsyOut *po = w.po;                                        // the encode kernel finishes the line (tl_encode_frame, TL_PSY_EXT):
-        po->m[ch][lane] = m;                                        // SMR = max(spike, scale level) - m, psycho_1.c:575-580
-    } else if (lane < 32) { TlPsyOut *po = w.po; po->m[ch][lane] = 0.0; }      // subbands the model leaves alone
+        L(rec)[2 + ch] = m;                                         // the encoder finishes the line (tl_encode_frame, TL_PSY_EXT): SMR = max(spike, scale level) - m, psycho_1.c:575-580
+    } else if (lane < 32) L(rec)[2 + ch] = 0.0;                     // subbands the model leaves alone
     TL_LANES_END
 }
 
 // band levels, decimation (psycho_1.c:390-470) and everything after; the regular (not dead-head) case
 template <class W>
-TL_FN void tl_psy1_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, long long *sp)
+TL_FN void tl_psy1_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, PARGA(double, rec, 4), long long *sp)
 {
     const int nbands = C->p1_ncb - 1, nlist = st.nlist;
     int ntone = 0, nnoise = 0;
     TL_STAMP(sp, 4);
-    if (TL_EXP_LEVEL >= 2) { tl_psy1_thresholds(w, db, C, ch, 0, 0, sp); return; }
+    if (TL_EXP_LEVEL >= 2) { tl_psy1_thresholds(w, db, C, ch, 0, 0, rec, sp); return; }
     // The reference now writes every band's sum to power[centre] in band order -- a later band overwrites an earlier one
     // that chose the same line, and (through the centre+1 rule above) a centre may even land on a tone's line
     // (psycho_1.c:390-398) -- and the decimation reads the levels back from power[].  The same values without the array:
@@ -1240,12 +1238,12 @@ TL_FN void tl_psy1_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_R
         TL_LANES_END
         nnoise = __builtin_popcountll(mn);
     }
-    tl_psy1_thresholds(w, db, C, ch, ntone, nnoise, sp);
+    tl_psy1_thresholds(w, db, C, ch, ntone, nnoise, rec, sp);
 }
 
 // the dead-head replay (see tl_psy1_front): works on power[] (px) and the shared links like the reference
 template <class W>
-TL_FN void tl_psy1_deadhead(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, long long *sp)
+TL_FN void tl_psy1_deadhead(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, PARGA(double, rec, 4), long long *sp)
 {
     const int nbands = C->p1_ncb - 1, nconf = st.nconf;
     const uint8_t *map = C->p1_map;
@@ -1327,25 +1325,25 @@ TL_FN void tl_psy1_deadhead(W &w, const double *TL_RESTRICT db, const TlConfig *
         }
         TL_SYNC();
     }
-    tl_psy1_thresholds(w, db, C, ch, ntone, nnoise, sp);
+    tl_psy1_thresholds(w, db, C, ch, ntone, nnoise, rec, sp);
 }
 
 // one channel start to end (mono streams; stereo streams when a dead-head case forces the plain order)
 template <class W>
-TL_FN void tl_psy1_finish(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, long long *sp)
+TL_FN void tl_psy1_finish(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, PARGA(double, rec, 4), long long *sp)
 {
     const int nbands = C->p1_ncb - 1;
     PV(double, wt); PV(double, bsum);
     tl_psy1_chain(w, db, nbands, bsum, wt);
     tl_psy1_centres(w, C, nbands, bsum, wt);
-    if (st.dead_head) tl_psy1_deadhead(w, db, C, ch, st, sp); else tl_psy1_back(w, db, C, ch, st, sp);
+    if (st.dead_head) tl_psy1_deadhead(w, db, C, ch, st, rec, sp); else tl_psy1_back(w, db, C, ch, st, rec, sp);
 }
 template <class W>
 TL_FN void tl_psy1(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
-                   const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
+                   const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, PARGA(double, rec, 4), long long *sp)
 {
-    const TlPsy1Ch st = tl_psy1_front(w, T, db, C, pv, ch, sp);
-    tl_psy1_finish(w, db, C, ch, st, sp);
+    const TlPsy1Ch st = tl_psy1_front(w, T, db, C, pv, ch, rec, sp);
+    tl_psy1_finish(w, db, C, ch, st, rec, sp);
 }
 
 // Both channels of a stereo frame.  Order: front(0) -> park channel 0's front results in registers -> front(1) -> the dB-sum
@@ -1356,14 +1354,14 @@ TL_FN void tl_psy1(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRIC
 // tl_psy1_front) falls back to the plain per-channel order.
 template <class W>
 TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
-                          const TlConfig *TL_RESTRICT C, const TlPcmView &pv, long long *sp)
+                          const TlConfig *TL_RESTRICT C, const TlPcmView &pv, PARGA(double, rec, 4), long long *sp)
 {
     const int nbands = C->p1_ncb - 1;
     long long *sp0 = sp ? sp + 8 : nullptr, *sp1 = sp ? sp + 16 : nullptr;
-    const TlPsy1Ch s0 = tl_psy1_front(w, T, db, C, pv, 0, sp0);
+    const TlPsy1Ch s0 = tl_psy1_front(w, T, db, C, pv, 0, rec, sp0);
     if (s0.dead_head) {                                               // plain order for both channels
-        tl_psy1_finish(w, db, C, 0, s0, sp0);
-        tl_psy1(w, T, db, C, pv, 1, sp1);
+        tl_psy1_finish(w, db, C, 0, s0, rec, sp0);
+        tl_psy1(w, T, db, C, pv, 1, rec, sp1);
         return;
     }
     // ---- park channel 0 ----
@@ -1383,10 +1381,10 @@ TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     L(ptx0) = w.tone_x[lane]; L(ptx1) = w.tone_x[hi];
     TL_LANES_END
     // ---- channel 1's front; a dead-head channel 1 is finished in the plain order first ----
-    const TlPsy1Ch s1 = tl_psy1_front(w, T, db, C, pv, 1, sp1);
+    const TlPsy1Ch s1 = tl_psy1_front(w, T, db, C, pv, 1, rec, sp1);
     PV(double, bsum); PV(double, wt1);
     if (s1.dead_head) {
-        tl_psy1_finish(w, db, C, 1, s1, sp1);
+        tl_psy1_finish(w, db, C, 1, s1, rec, sp1);
         TL_LANES_BEGIN
 #ifndef TL_EMULATE
 #pragma unroll
@@ -1424,7 +1422,7 @@ TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
         bsum1 = __shfl(bsum, (int)((threadIdx.x + 32u) & 63u), 64);
 #endif
         if (TL_EXP_LEVEL < 3) tl_psy1_centres(w, C, nbands, bsum1, wt1);
-        tl_psy1_back(w, db, C, 1, s1, sp1);
+        tl_psy1_back(w, db, C, 1, s1, rec, sp1);
     }
     // ---- channel 0 returns to the LDS arrays ----
     TL_LANES_BEGIN
@@ -1437,14 +1435,14 @@ TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     for (int i = lane; i < s0.nconf; i += 64) { const int cc = w.conf_c[i]; if (!((cc >> 13) & 1)) w.ptype[cc & 511] = TL_T_TONE; }
     TL_LANES_END
     if (TL_EXP_LEVEL < 3) tl_psy1_centres(w, C, nbands, bsum, wt0);
-    tl_psy1_back(w, db, C, 0, s0, sp0);
+    tl_psy1_back(w, db, C, 0, s0, rec, sp0);
 }
 
 // ------------------------------------------------------------------------------------------
 // psy model 3 (psycho_3.c:71-432) for channel `ch`; result in w.smr[ch][0..32).
 template <class W>
 TL_FN int tl_psy3_front(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
-                   const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
+                   const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, PARGA(double, rec, 4), long long *sp)
 {
     const double *energy = w.u.fft;                                   // line i at TL_EX(i)
     double *px = TL_PX(w);
@@ -1486,12 +1484,14 @@ TL_FN int tl_psy3_front(W &w, const TlTables *TL_RESTRICT T, const double *TL_RE
         PV(double, pxv); PV(double, pxm);
         TL_LANES_BEGIN L(pxv) = L(pxa)[it]; TL_LANES_END
         TL_ROW16_MAX_F64(pxm, pxv);
+        // subband 4 it + r: the maximum sits in lane 16 r + 15; the record keeps it in lane 4 it + r (the encoder takes the
+        // maximum with the scalefactor level, psycho_3.c:180-182)
+        PV(double, xm);
+        TL_LANES_BEGIN L(xm) = TL_DBMIN < L(pxm) ? L(pxm) : TL_DBMIN; TL_LANES_END
         TL_LANES_BEGIN
-        if ((lane & 15) == 15) {
-            const int sb = (lane + 64 * it) >> 4;
-            const double xmax = TL_DBMIN < L(pxm) ? L(pxm) : TL_DBMIN;
-            TlPsyOut *po = w.po;
-            po->a[ch][sb] = xmax;                                   // the encode kernel takes the maximum with the scalefactor level (psycho_3.c:180-182)
+        {
+            const double v = TL_OTHER(xm, , 16 * (lane & 3) + 15);
+            if (lane < 32 && (lane >> 2) == it) L(rec)[ch] = v;
         }
         TL_LANES_END
     }
@@ -1690,7 +1690,7 @@ TL_FN void tl_psy3_chain2(W &w, const double *TL_RESTRICT db, int nb, PARG(int, 
 // band centres, decimation, thresholds, SMR (psycho_3.c:290-432) from the sums of lanes b < nb
 template <class W>
 TL_FN void tl_psy3_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, int nconf,
-                        PARG(double, bsum), PARG(double, es), PARG(double, cg), long long *sp)
+                        PARG(double, bsum), PARG(double, es), PARG(double, cg), PARGA(double, rec, 4), long long *sp)
 {
     const double *bark = C->p3_bark, *ath = C->p3_ath;
     const int nb = C->p3_cbands;
@@ -1802,8 +1802,7 @@ TL_FN void tl_psy3_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_R
         double m = 999999.9;
         const int j0 = C->p3_sb_j0[lane], n = C->p3_sb_n[lane];
         m = tl_min_rows(TL_LTG(w), j0, n, m, false);
-        TlPsyOut *po = w.po;
-        po->m[ch][lane] = m;
+        L(rec)[2 + ch] = m;
     }
     TL_LANES_END
 }
@@ -1811,23 +1810,23 @@ TL_FN void tl_psy3_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_R
 
 template <class W>
 TL_FN void tl_psy3(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
-                   const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, long long *sp)
+                   const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, PARGA(double, rec, 4), long long *sp)
 {
-    const int nconf = tl_psy3_front(w, T, db, C, pv, ch, sp);
+    const int nconf = tl_psy3_front(w, T, db, C, pv, ch, rec, sp);
     PV(double, bsum); PV(double, es); PV(double, cg);
     tl_psy3_chain(w, db, C->p3_cbands, bsum, es, cg);
-    tl_psy3_back(w, db, C, ch, nconf, bsum, es, cg, sp);
+    tl_psy3_back(w, db, C, ch, nconf, bsum, es, cg, rec, sp);
 }
 
 // Both channels of a stereo frame, organised like tl_psy1_stereo: front(0) -> channel 0's compacted levels, tone records, Lsb
 // and band moments wait in registers -> front(1) -> both dB-sum chains side by side -> back(1) -> back(0).
 template <class W>
 TL_FN void tl_psy3_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
-                          const TlConfig *TL_RESTRICT C, const TlPcmView &pv, long long *sp)
+                          const TlConfig *TL_RESTRICT C, const TlPcmView &pv, PARGA(double, rec, 4), long long *sp)
 {
     const int nb = C->p3_cbands;
     long long *sp0 = sp ? sp + 8 : nullptr, *sp1 = sp ? sp + 16 : nullptr;
-    const int nconf0 = tl_psy3_front(w, T, db, C, pv, 0, sp0);
+    const int nconf0 = tl_psy3_front(w, T, db, C, pv, 0, rec, sp0);
     PV(double, es0); PV(double, cg0); PV(int, r0); PV(int, r1);
     PA(double, pvp, 8); PV(int, pcc); PV(double, ptx0); PV(double, ptx1);
     tl_psy3_moments(w, nb, es0, cg0);
@@ -1841,7 +1840,7 @@ TL_FN void tl_psy3_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
     L(pcc) = (int)((uint32_t)(uint16_t)w.conf_c[lane] | ((uint32_t)(uint16_t)w.conf_c[hi] << 16));
     L(ptx0) = w.tone_x[lane]; L(ptx1) = w.tone_x[hi];
     TL_LANES_END
-    const int nconf1 = tl_psy3_front(w, T, db, C, pv, 1, sp1);
+    const int nconf1 = tl_psy3_front(w, T, db, C, pv, 1, rec, sp1);
     PV(double, es1); PV(double, cg1); PV(double, bsum); PV(double, bsum1);
     tl_psy3_moments(w, nb, es1, cg1);
     TL_LANES_BEGIN
@@ -1856,13 +1855,13 @@ TL_FN void tl_psy3_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
 #else
     bsum1 = __shfl(bsum, (int)((threadIdx.x + 32u) & 63u), 64);
 #endif
-    tl_psy3_back(w, db, C, 1, nconf1, bsum1, es1, cg1, sp1);
+    tl_psy3_back(w, db, C, 1, nconf1, bsum1, es1, cg1, rec, sp1);
     TL_LANES_BEGIN
     const int hi = 64 + lane < TL_TONE_MAX ? 64 + lane : 0;
     w.conf_c[lane] = (int16_t)(L(pcc) & 0xffff); w.tone_x[lane] = L(ptx0);
     if (64 + lane < TL_TONE_MAX) { w.conf_c[hi] = (int16_t)((uint32_t)L(pcc) >> 16); w.tone_x[hi] = L(ptx1); }
     TL_LANES_END
-    tl_psy3_back(w, db, C, 0, nconf0, bsum, es0, cg0, sp0);
+    tl_psy3_back(w, db, C, 0, nconf0, bsum, es0, cg0, rec, sp0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2260,15 +2259,16 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
         if (c < nch) w.smr[c][sb] = PO->a[c][sb];
         TL_LANES_END
     } else {
-        // models 1 and 3: the psy kernel left, per (channel, subband), the level A that competes with the scalefactor level and
-        // the minimum masking threshold m (TlPsyOut); the SMR line itself needs this frame's scalefactors and is finished here:
+        // models 1 and 3: the model (tl_frame_unit ran it before this frame body) left, per (channel, subband), the level A that
+        // competes with the scalefactor level (in smr[]) and the minimum masking threshold m (in psy_m[]); the SMR line itself
+        // needs this frame's scalefactors and is finished here:
         // psycho_1.c:575-580 (max = scale level; if (spike > max) max = spike; smr = max - ltmin) and psycho_3.c:180-182,428
         // (Lsb = max(Xmax, scale level); smr = Lsb - ltmin) are the same three operations.
-        static_assert(PSY == TL_PSY_EXT, "models 1 and 3 run in the psy kernel");
+        static_assert(PSY == TL_PSY_EXT, "models 1 and 3");
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
         if (c < nch) {
-            const double a = PO->a[c][sb], m = PO->m[c][sb];
+            const double a = w.smr[c][sb], m = w.psy_m[c][sb];
             const double val = C->scale_db[w.minidx[c][sb]];
             const double top = a > val ? a : val;
             w.smr[c][sb] = top - m;
@@ -2771,16 +2771,17 @@ TL_FN TlPcmView tl_pcm_view(const TlLaunch &A, const TlStreamState *st, int s, i
 // nothing but PCM (the window of a frame: the last 192 samples before it and its first 832), so units are independent of each
 // other -- of other streams AND of other frames of the same stream -- and the kernel runs them in any order on any wave.
 template <int PSY>
-TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch &A, int s, int f)
+TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch &A, int s, int f, PARGA(double, rec, 4))
 {
+    // rec: the model's result per subband, in the registers of lane = subband: [ch] the level that competes with the scalefactor
+    // level, [2 + ch] the minimum masking threshold (SMR = max(level, scale_db[min scalefactor index]) - threshold is the encoder's
+    // line: psycho_1.c:568-581 with level = spike level; psycho_3.c:163-183,409-432 with level = strongest line of the subband)
     const TlTables *T = A.tables;
     const TlConfig *C = &A.configs[A.stream_cfg[s]];
     const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
     const TlPcmView pv = tl_pcm_view(A, &A.state[s], s, f);
-    TlPsyOut *po = &A.psy_out[slot];
     TL_LANES_BEGIN
-    if (C->nch == 1 && lane < 32) { po->a[1][lane] = 0.0; po->m[1][lane] = 0.0; }     // the model writes every entry of the channels it runs
-    if (lane == 0) w.po = po;
+    L(rec)[0] = 0.0; L(rec)[1] = 0.0; L(rec)[2] = 0.0; L(rec)[3] = 0.0;     // the model writes every subband of the channels it runs
     TL_LANES_END
 #ifdef TL_NO_PSY_STAMPS
     long long *sp = nullptr;
@@ -2789,11 +2790,11 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
 #endif
     TL_STAMP(sp, 15);                                                 // unit begin (slots 8..14 / 16..22: the channels' stages, 24..30: FHT passes)
     if constexpr (PSY == 1) {
-        if (C->nch == 2) tl_psy1_stereo(w, T, db, C, pv, sp);
-        else tl_psy1(w, T, db, C, pv, 0, sp ? sp + 8 : nullptr);
+        if (C->nch == 2) tl_psy1_stereo(w, T, db, C, pv, rec, sp);
+        else tl_psy1(w, T, db, C, pv, 0, rec, sp ? sp + 8 : nullptr);
     } else {
-        if (C->nch == 2) tl_psy3_stereo(w, T, db, C, pv, sp);
-        else tl_psy3(w, T, db, C, pv, 0, sp ? sp + 8 : nullptr);
+        if (C->nch == 2) tl_psy3_stereo(w, T, db, C, pv, rec, sp);
+        else tl_psy3(w, T, db, C, pv, 0, rec, sp ? sp + 8 : nullptr);
     }
     TL_STAMP(sp, 23);                                                 // unit end
 }
@@ -2879,20 +2880,28 @@ TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const 
     fo.words = f + 1 < A.nframes ? nullptr : A.newpend + (size_t)s * TL_MAX_FRAME_WORDS;
     fo.scfcrc = A.scfcrc + slot * 4;
     const int padding = A.padbits ? (int)A.padbits[slot] : 0;
-    tl_encode_frame<PSY>(w, A.tables, B, C, PSY != 0 ? &A.psy_out[slot] : nullptr, pv, xl, fo, enw_s, K, padding,
+    tl_encode_frame<PSY>(w, A.tables, B, C, PSY == 2 ? &A.psy_out[slot] : nullptr, pv, xl, fo, enw_s, K, padding,
                                 A.taps ? &A.taps[slot] : nullptr, sp);
 }
 
 // Models 1 and 3: one unit = frame f of stream s, psy model first, then the encoder, by the same wave.  The two phases
 // share the wave's LDS block (a union: the model's arrays are dead when the encoder starts) and nothing else but the
-// model's record.
+// model's record, 4 values per subband, which waits in registers until the model is done.
 union TlFrameLds { TlPsyLds p; TlMainLds m; };
 template <int PSY>
 TL_FN void tl_frame_unit(TlFrameLds &w, const double *TL_RESTRICT db, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s,
                          const TlPackTables *TL_RESTRICT K, const TlLaunch &Apsy, const TlLaunch &Amain, int s, int f)
 {
-    tl_psy_unit<PSY>(w.p, db, Apsy, s, f);
+    PA(double, rec, 4);
+    tl_psy_unit<PSY>(w.p, db, Apsy, s, f, rec);
     TL_SYNC();
+    // the model's arrays are dead: its record goes where the encoder expects it (its own SMR array and the one beside it)
+    TL_LANES_BEGIN
+    if (lane < 32) {
+        w.m.smr[0][lane] = L(rec)[0]; w.m.smr[1][lane] = L(rec)[1];
+        w.m.psy_m[0][lane] = L(rec)[2]; w.m.psy_m[1][lane] = L(rec)[3];
+    }
+    TL_LANES_END
     tl_main_unit<TL_PSY_EXT>(w.m, B, enw_s, K, Amain, s, f);
 }
 

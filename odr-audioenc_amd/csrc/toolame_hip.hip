@@ -23,37 +23,74 @@ static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 #define TLB_HOST_CHUNKS 4            // tlb_encode_host pipelines a big call in this many chunks of frames
 
 // ---- kernels of the encode path ------------------------------------------------------------------------------------------
-// One wavefront per unit of work:
+// One wavefront per unit of work; every kernel is persistent: 12 waves per CU (3 per SIMD) take units off a device-wide counter.
 //
-//  * psy models 0, 1 and 3 (the ones DAB services use): the frames of a launch are independent units, (stream, frame).
-//      tl_psy_kernel<PSY>   models 1 and 3: the psychoacoustic model alone.  It reads nothing but PCM.  Without the
-//                           filterbank's 72 sample registers and the encoder's arrays it fits 168 VGPRs and 11.0 KB of LDS
-//                           per wave: 3 waves per SIMD instead of 2.  Output: 1 KB per frame (TlPsyOut: level and minimum
-//                           masking threshold per subband).
-//      tl_main_kernel<PSY>  filterbank, scalefactors, SMR (from TlPsyOut; model 0: from the scalefactors, no psy kernel),
-//                           bit allocation, quantiser, packing, CRCs.  The filterbank's history is PCM, so these units
-//                           are independent too; the one thing a frame owes its predecessor (its ScF-CRC travels in the
-//                           frame before) is filed aside.  Also 3 waves per SIMD.
-//      tl_finish_kernel     a wave per stream: the pending frame of the last launch to slot 0, ScF-CRCs into place, state.
-//    Both big kernels are persistent: 12 waves per CU take units off a device-wide counter.
-//    The price is HBM traffic the fused form did not have (PCM is read by both kernels, TlPsyOut is written and read):
-//    2.7 x the algorithmic bytes -- on a path that uses 1-2 % of the HBM bandwidth and is bound by VALU issue and LDS
-//    latency, where occupancy is what pays (DESIGN.md section 4 has the counters of both forms).
-//
+//  * psy models 1 and 3 (the ones DAB services use): unit = (stream, frame).  tl_frame_kernel<PSY>: the wave runs the
+//    psychoacoustic model (it reads nothing but PCM), then the encoder (filterbank, scalefactors, SMR, bit allocation,
+//    quantiser, packing, CRCs) of the same frame.  The filterbank's history is PCM, so frames are independent; the one
+//    thing a frame owes its predecessor (its ScF-CRC travels in the frame before) is filed aside.
+//  * psy model 0: tl_main_kernel<0>, the encoder alone (the model is three lines on the scalefactors).
 //  * psy models 2 and 4 carry prediction state from pass to pass (psycho_2.c:300-306), per channel: tl_psy2_kernel takes
-//    one CHANNEL of one stream through the frames of the launch (12 waves per CU as well) and leaves the SMR in TlPsyOut;
-//    tl_main_kernel<2> and tl_finish_kernel as above.
-// Next unit of a persistent kernel's work list (device-scope atomic: the counter is shared by all XCDs).  Every lane adds 1
-// -- hipcc folds that into ONE atomic of +64 per wave (its wave-level atomic optimiser) -- and the unit is the wave's base
-// / 64.  No `if (lane == 0)` in the source: with one, LLVM threaded the branch together with an equal test at the end of
-// the previous unit (the diagnostic stamps) into a loop that some lanes never left.
+//    one CHANNEL of one stream through the frames of the launch and leaves the SMR in TlPsyOut (HBM); then tl_main_kernel<2>.
+//  * tl_finish_kernel, a wave per stream: the pending frame of the last launch to slot 0, ScF-CRCs into place, state.
+//
+// History of the shape (DESIGN.md section 4 has the counters): round 1 ran the model in the MIDDLE of the encoder (256 VGPRs,
+// 2 waves per SIMD); round 2 first split model and encoder into two kernels (3 waves per SIMD each, but the PCM read twice and
+// a 1 KB record per frame through HBM), then put them back into one kernel one AFTER the other: the registers needed are the
+// maximum of the two phases, not the sum, the LDS blocks a union, the record four values per lane.
+// Next unit of a persistent kernel's work list: ONE returning device-scope atomic add per wave, issued by lane 0 alone.
+// The lane mask is narrowed inside the asm statement, not with an `if (lane == 0)`: LLVM threaded such a branch together
+// with the equal test of the diagnostic stamps at the end of the previous unit into a loop that some lanes never left; and
+// its wave-level atomic optimiser, which folds `atomicAdd(p, 1)` of 64 lanes into one add, only does so while it can prove the
+// address uniform -- when it cannot, the 64 adds of two waves interleave and units are handed out twice or never.
+// `counter` must be wave-uniform.
 static __device__ __forceinline__ int tl_next_unit(int32_t *counter)
 {
+    int u;
+    uint64_t saved;
     __builtin_amdgcn_wave_barrier();
-    const int u = atomicAdd(counter, 1);
-    return __builtin_amdgcn_readfirstlane(u) >> 6;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "global_atomic_add %0, %2, %3, %4 sc0\n\t"
+                 "s_waitcnt vmcnt(0)\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=&v"(u), "=&s"(saved) : "v"(0), "v"(1), "s"(counter) : "memory");
+    return __builtin_amdgcn_readfirstlane(u);
 }
-
+// (stream, frame) units come off EIGHT lists, one per XCD (each XCD has its own L2).  List q holds the streams k = q, q + 8, ...
+// of the launch's stream list, stream by stream, frames ascending: the waves of an XCD work on consecutive frames of a few
+// streams at a time, so the 480 samples of history a frame needs -- the tail of the frame before it, which a neighbouring
+// wave is reading as its own PCM -- come out of that XCD's L2 and not over the fabric a second time.  A wave whose own
+// list is empty goes on with the next XCD's (hop): the lists are for locality only, the balance stays that of one queue.
+// Returns false when all eight lists are empty.  Which waves share an XCD: workgroups are dealt round-robin over the XCDs
+// (observed, MI355X_MICROARCH.md "Workgroup dispatch"), so blockIdx % 8 is the group; a wrong guess costs locality, nothing
+// else.  A wave's FIRST unit is its rank within its group (no atomic: three thousand waves asking at once would queue);
+// the list heads therefore count from the number of waves of the group.
+#define TL_HEAD_STRIDE 32             // int32 per list head: one 128-byte line each
+static __device__ __forceinline__ bool tl_take_unit(int32_t *heads, int nlist, int nframes, int grp, int &hop, int &k, int &f, int first)
+{
+    while (hop < 8) {
+        const int q = (grp + hop) & 7;
+        const int nq = (nlist - q + 7) >> 3;                         // streams on list q
+        const int ng = (((int)gridDim.x - q + 7) >> 3) * (int)(blockDim.x >> 6);      // waves whose own list q is: they took units 0 .. ng-1 by rank
+        int v;
+        if (first >= 0) { v = first; first = -1; }
+        else {
+            // Another group's list is looked at before it is drawn from: at the end of a launch every wave walks the other
+            // seven lists, and three thousand returning atomics on a word that has nothing left to give queue for 35 us per
+            // list; a load does not queue.  A stale value costs one atomic, nothing else.
+            if (hop > 0 && ng + __hip_atomic_load(&heads[q * TL_HEAD_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nq * nframes) { hop++; continue; }
+            v = ng + tl_next_unit(&heads[q * TL_HEAD_STRIDE]);
+        }
+        if (v < nq * nframes) {
+            const int kk = v / nframes;
+            k = q + 8 * kk; f = v - kk * nframes;
+            return true;
+        }
+        hop++;
+    }
+    return false;
+}
 // LDS is handed out in granules of 1280 bytes on gfx950 (160 KB / 128): the twelve waves a CU holds at 3 per SIMD are ONE
 // workgroup sharing one copy of the tables (three 4-wave workgroups with a copy each do not fit).
 #ifndef TL_MAIN_WPE
@@ -83,7 +120,7 @@ struct TlMainShared { double enw_s[512]; char bytes[sizeof(TlBlockShared) - offs
 static_assert(offsetof(TlBlockShared, dbtable) == 0 && offsetof(TlBlockShared, scalefactor) == sizeof(double) * 1002, "dbtable leads TlBlockShared");
 #define TL_MAIN_WAVES (4 * TL_MAIN_WPE)       // one workgroup per CU: one copy of the tables
 static_assert((sizeof(TlMainShared) + TL_MAIN_WAVES * sizeof(TlMainLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "the encode workgroup fits a CU");
-template <int PSY>     // TL_PSY_EXT: models 1 and 3 (after tl_psy_kernel); 0: model 0, no psy kernel
+template <int PSY>     // 0: model 0 (no psy kernel); 2: models 2 and 4 (after tl_psy2_kernel)
 __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_waves_per_eu(TL_MAIN_WPE, TL_MAIN_WPE))) tl_main_kernel(TlLaunch A)
 {
     __shared__ TlMainShared sh;
@@ -100,9 +137,8 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
     // the encode path never touches B->dbtable: a TlBlockShared pointer whose dbtable part lies before the copied block
     const TlBlockShared *B = (const TlBlockShared *)((const char *)&sh.bytes[0] - offsetof(TlBlockShared, scalefactor));
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nunits = A.nlist * A.nframes, nwaves = (int)gridDim.x * TL_MAIN_WAVES;
-    for (int u = (int)blockIdx.x * TL_MAIN_WAVES + wave; u < nunits; u = nwaves + tl_next_unit(&A.work[1])) {      // as in the psy kernel
-        const int f = u / A.nlist, k = u - f * A.nlist;
+    const int grp = (int)blockIdx.x & 7;
+    for (int hop = 0, k, f, first = ((int)blockIdx.x >> 3) * TL_MAIN_WAVES + wave; tl_take_unit(A.work + TL_HEAD_STRIDE, A.nlist, A.nframes, grp, hop, k, f, first); first = -1) {
         const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
         tl_main_unit<PSY>(lds[wave], B, sh.enw_s, &sh.pack, A, s, f);
     }
@@ -131,9 +167,8 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
     __syncthreads();
     const TlBlockShared *B = (const TlBlockShared *)((const char *)&sh.bytes[0] - offsetof(TlBlockShared, scalefactor));
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nunits = A.nlist * A.nframes, nwaves = (int)gridDim.x * TL_MAIN_WAVES;
-    for (int u = (int)blockIdx.x * TL_MAIN_WAVES + wave; u < nunits; u = nwaves + tl_next_unit(&A.work[0])) {
-        const int f = u / A.nlist, k = u - f * A.nlist;
+    const int grp = (int)blockIdx.x & 7;
+    for (int hop = 0, k, f, first = ((int)blockIdx.x >> 3) * TL_MAIN_WAVES + wave; tl_take_unit(A.work + TL_HEAD_STRIDE, A.nlist, A.nframes, grp, hop, k, f, first); first = -1) {
         const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
 #if defined(__HIP_DEVICE_COMPILE__)
         // each phase reads the launch record afresh from the kernel-argument segment (scalar loads), so that nothing but s
@@ -325,7 +360,7 @@ struct tlb_batch {
     bool timed = false;
     // device staging of the host-buffer entry point (tlb_encode_host): grow-only, created on first use, so a caller that
     // feeds one frame per call (the legacy shim) pays for no allocation after its first frame
-    void *stage[9] = {};                         // pcm, out, xpad, xpad_len, taps; [5] = TlPsyOut records, [6] = ScF-CRC bytes, [7] = padding bits, [8] = frame lengths (host entry)
+    void *stage[9] = {};                         // pcm, out, xpad, xpad_len, taps; [5] = TlPsyOut records (models 2/4), [6] = ScF-CRC bytes, [7] = padding bits, [8] = frame lengths (host entry)
     size_t stage_cap[9] = {};
     hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;   // host-buffer entry point: copy-in / kernels / copy-out
     hipEvent_t ev_in[TLB_HOST_CHUNKS] = {}, ev_run[TLB_HOST_CHUNKS] = {};
@@ -477,7 +512,7 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
     {
         HIPCHK(hipMalloc(&b->d_newpend, sizeof(uint32_t) * TL_MAX_FRAME_WORDS * (size_t)nstreams));
         HIPCHK(hipMemset(b->d_newpend, 0, sizeof(uint32_t) * TL_MAX_FRAME_WORDS * (size_t)nstreams));
-        HIPCHK(hipMalloc(&b->d_work, sizeof(int32_t) * 2));
+        HIPCHK(hipMalloc(&b->d_work, sizeof(int32_t) * TL_HEAD_STRIDE * 9));
         if (b->pads[0] || b->pads[1] || b->pads[2] || b->pads[3]) HIPCHK(hipMalloc(&b->d_newlag, sizeof(double) * (size_t)nstreams));
     }
     HIPCHK(hipEventCreate(&b->ev0));
@@ -524,9 +559,9 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
     A.out = d_out; A.out_len = d_out_len; A.taps = d_taps; A.stamps = d_stamps;
     A.psy2_tables = b->d_psy2_tables; A.psy2_state = b->d_psy2_state;
     A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride;
-    {   // TlPsyOut records of this launch (psy kernel -> encode kernel), grow-only.  NOTE: one buffer per batch -- launches of
+    {   // TlPsyOut records of this launch (psy-2 kernel -> encode kernel, models 2 and 4 only) and ScF-CRC bytes, grow-only.  NOTE: one buffer per batch -- launches of
         // one batch are ordered on one stream (they share the stream state anyway)
-        HIPCHK(stage_reserve(b, 5, (size_t)nframes * (size_t)b->nstreams * sizeof(TlPsyOut)));
+        if (b->n_list[2]) HIPCHK(stage_reserve(b, 5, (size_t)nframes * (size_t)b->nstreams * sizeof(TlPsyOut)));
         HIPCHK(stage_reserve(b, 6, (size_t)nframes * (size_t)b->nstreams * 4));
         A.psy_out = (TlPsyOut *)b->stage[5]; A.scfcrc = (uint8_t *)b->stage[6]; A.newpend = b->d_newpend; A.work = b->d_work;
         if (b->pads[0] || b->pads[1] || b->pads[2] || b->pads[3]) HIPCHK(stage_reserve(b, 7, (size_t)nframes * (size_t)b->nstreams));
@@ -538,10 +573,10 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         A.stream_list = b->d_list[p]; A.nlist = b->n_list[p];
         // persistent waves, twelve per CU (three per SIMD) in every kernel; they take their units off a counter
         const long units = (long)b->n_list[p] * nframes;
-        if (units > (1L << 24)) return TLB_ERR_ARG;                 // the unit counters count 64 per unit in 32 bits (tl_next_unit)
+        if (units > (1L << 30)) return TLB_ERR_ARG;                 // unit indices are 32-bit
         A.padbits = b->pads[p] ? (uint8_t *)b->stage[7] : nullptr; A.newlag = b->d_newlag;
         if (b->pads[p]) { hipLaunchKernelGGL(tl_slots_kernel, dim3((unsigned)((b->n_list[p] + 255) / 256)), dim3(256), 0, st, A); HIPCHK(hipGetLastError()); }
-        HIPCHK(hipMemsetAsync(b->d_work, 0, sizeof(int32_t) * 2, st));
+        HIPCHK(hipMemsetAsync(b->d_work, 0, sizeof(int32_t) * TL_HEAD_STRIDE * 9, st));
         long qb = (2L * b->n_list[p] + TL_PSY2_WAVES - 1) / TL_PSY2_WAVES;
         if (qb > b->num_cu) qb = b->num_cu;
         if (p == 1 || p == 3) {                                      // psy model and encoder in one kernel
@@ -560,8 +595,7 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         long mb = (units + TL_MAIN_WAVES - 1) / TL_MAIN_WAVES;
         if (mb > b->num_cu) mb = b->num_cu;
         if (p == 0) hipLaunchKernelGGL(tl_main_kernel<0>, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);       // model 0: no psy kernel
-        else if (p == 2) hipLaunchKernelGGL(tl_main_kernel<2>, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);
-        else hipLaunchKernelGGL(tl_main_kernel<TL_PSY_EXT>, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);
+        else hipLaunchKernelGGL(tl_main_kernel<2>, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(tl_finish_kernel, dim3((unsigned)((b->n_list[p] + 3) / 4)), dim3(256), 0, st, A);
         HIPCHK(hipGetLastError());
@@ -620,7 +654,7 @@ int tlb_encode_host_len(tlb_batch *b, const int16_t *pcm, int nframes, const uin
     // TlPsyOut / ScF-CRC scratch sized for the largest chunk up front (tlb_launch would otherwise re-allocate between chunks)
     const int per = (nframes + nchunks - 1) / nchunks;
     {
-        HIPCHK(stage_reserve(b, 5, (size_t)per * (size_t)b->nstreams * sizeof(TlPsyOut)));
+        if (b->n_list[2]) HIPCHK(stage_reserve(b, 5, (size_t)per * (size_t)b->nstreams * sizeof(TlPsyOut)));
         HIPCHK(stage_reserve(b, 6, (size_t)per * (size_t)b->nstreams * 4));
     }
     HIPCHK(hipMemsetAsync(d_out, 0, n_out, b->s_in));              // bytes the kernels do not write (slot 0 of the first call, tails of short frames) read as 0
