@@ -11,7 +11,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 G, P = ROOT / "gpurun_out", ROOT / "profiles"
 V = sys.argv[1]
-KERNELS = ("tl_psy_kernel", "tl_psy2_kernel", "tl_main_kernel", "tl_finish_kernel")
+KERNELS = ("tl_frame_kernel", "tl_psy2_kernel", "tl_main_kernel", "tl_finish_kernel")
 
 
 def cp(src, dst=None):
@@ -55,9 +55,9 @@ if k1:
     d = {"version": f"{V} ({bench['value'] / 1e6:.2f} M frames/s)", "workload": wl, "kernels": k1, "hbm_bytes_per_launch": t1,
          "algorithmic_bytes_per_launch": 4992 * frames, "ratio_to_algorithmic": round(t1 / (4992 * frames), 3),
          "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
-         "note": "models 1/3 run as psy kernel + encode kernel + finish kernel: both big kernels read the PCM (4608 B/frame each) and the "
-                 "1 KB/frame TlPsyOut record is written by one and read by the other -- traffic bought for occupancy on a path that "
-                 "uses ~2 % of the HBM bandwidth (DESIGN.md section 4)",
+         "note": "models 1/3: tl_frame_kernel (psy model, then encoder, per (stream, frame) unit; the model's record stays on chip) + "
+                 "tl_finish_kernel; units come off per-XCD lists in stream order, so the PCM is fetched once and a frame's 480 samples of "
+                 "history come out of the XCD's L2 (DESIGN.md section 4)",
          "source": f"tools/profile_round2.sh {V} (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, kernel trace only); raw CSVs: profiles/{V}_pmc_hl_*"}
     json.dump(d, open(P / f"{V}_pmc_traffic.json", "w"), indent=1)
     json.dump(d, open(P / "pmc_traffic_latest.json", "w"), indent=1)

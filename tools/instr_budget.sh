@@ -1,5 +1,5 @@
 #!/bin/bash
-# Where do the psy kernel's VALU instructions go?  Diagnostic builds (TL_EXP_LEVEL = n removes the last n stages of psy model 1)
+# Where do the VALU instructions of the psy phase of tl_frame_kernel go?  Diagnostic builds (TL_EXP_LEVEL = n removes the last n stages of psy model 1)
 # under one SQ counter pass each.  Build the variants HERE first (tools/instr_budget.sh build), run on the GPU box (… run).
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
@@ -27,10 +27,10 @@ for n in range(9):
     acc = collections.defaultdict(list); dur = []
     for f in glob.glob(f"gpurun_out/ib_{n}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if "tl_psy_kernel" in row["Kernel_Name"]: acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            if "tl_frame_kernel" in row["Kernel_Name"]: acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for f in glob.glob(f"gpurun_out/ib_{n}/**/*kernel_trace.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if "tl_psy_kernel" in row["Kernel_Name"]: dur.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
+            if "tl_frame_kernel" in row["Kernel_Name"]: dur.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
     if not acc: print(n, "no data"); continue
     v = {k: sum(x) / len(x) / 65536 for k, x in acc.items()}
     ms = sum(dur) / len(dur)

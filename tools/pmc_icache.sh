@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"gpurun_out/ic_{tag}/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        for name in ("tl_psy_kernel", "tl_psy2_kernel", "tl_main_kernel", "tl_encode_kernel"):
+        for name in ("tl_frame_kernel", "tl_psy2_kernel", "tl_main_kernel"):
             if name in k:
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for name, c in acc.items():

@@ -21,13 +21,13 @@ dur = collections.defaultdict(list)
 for f in glob.glob(f"gpurun_out/sqs_{tag}_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        for name in ("tl_psy_kernel", "tl_psy2_kernel", "tl_main_kernel", "tl_encode_kernel"):
+        for name in ("tl_frame_kernel", "tl_psy2_kernel", "tl_main_kernel"):
             if name in k:
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for f in glob.glob(f"gpurun_out/sqs_{tag}_*/**/*kernel_trace.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
-        for name in ("tl_psy_kernel", "tl_psy2_kernel", "tl_main_kernel", "tl_encode_kernel"):
+        for name in ("tl_frame_kernel", "tl_psy2_kernel", "tl_main_kernel"):
             if name in k:
                 dur[name].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
 out = {"bench_args": sys.argv[2:], "note": "per launch; SQ cycle counters are in units of 4 clocks"}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One profiling round on the GPU box (psy kernel + encode kernel + finish kernel).
+# One profiling round on the GPU box.
 #   bash tools/profile_round2.sh TAG      -> everything under gpurun_out/, then (here) tools/install_profiles2.py TAG
 # rocprofv3 runs the program itself after `--` (python3 bench.py ...); counters are collected in their own passes with
 # --kernel-trace only (never with the sys/hip/hsa trace domains).

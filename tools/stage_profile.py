@@ -23,12 +23,12 @@ L.tlb_encode_host_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p
 st = np.zeros((F, S, 32), dtype=np.int64)
 assert L.tlb_encode_host_stamps(b.h, np.ascontiguousarray(pcm).ctypes.data, F, st.ctypes.data) == 0
 st = st[1:]                                   # skip the first (cold) frame
-names = ["filterbank", "scalefactors", "psy 0" if psy == 0 else "smr from the psy kernel's record", "sfpattern+bitalloc", "quantise+pack", "crc+scfcrc+pad", "emit"]
+names = ["filterbank", "scalefactors", "psy 0" if psy == 0 else "smr from the model's record", "sfpattern+bitalloc", "quantise+pack", "crc+scfcrc+pad", "emit"]
 tot = (st[..., 7] - st[..., 0]).mean()
 print(f"psy {psy} mode {mode} {S} streams: {tot:.0f} s_memtime ticks/frame/wave in the encode kernel")
 if psy in (1, 3):
     ptot = (st[..., 23] - st[..., 15]).mean()
-    print(f"psy kernel: {ptot:.0f} ticks/unit/wave; shares below are of encode + psy = {tot + ptot:.0f}")
+    print(f"psy phase: {ptot:.0f} ticks/unit/wave; shares below are of encode + psy = {tot + ptot:.0f}")
     tot = tot + ptot
 for i, n in enumerate(names):
     d = (st[..., i + 1] - st[..., i]).mean()
