@@ -310,7 +310,7 @@ class Batch:
         return float(self.L.tlb_last_kernel_ms(self.h))
 
     def last_stage_ms(self):
-        """(psy kernel ms, encode kernel ms) of the last launch, or None when the batch mixes models or uses model 0 (no psy kernel)"""
+        """(psy-2 kernel ms, encode kernel ms) of the last launch of an all-model-2/4 batch, else None (models 1/3: one kernel; model 0: no psy kernel)"""
         a, b = C.c_float(0), C.c_float(0)
         if self.L.tlb_last_stage_ms(self.h, C.byref(a), C.byref(b)):
             return None

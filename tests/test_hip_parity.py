@@ -131,6 +131,39 @@ def test_many_streams_vs_oracle(M, psy, mode, nstreams, nframes):
     b.close()
 
 
+@pytest.mark.parametrize("nstreams", [1, 7, 9, 37, 3100])
+def test_unit_lists_odd_shapes(M, nstreams):
+    """The (stream, frame) units of a launch come off eight per-XCD lists (stream k on list k % 8; a wave's first unit is its rank,
+    the rest off the list heads, then the other lists): every unit must be encoded exactly once whatever the shape -- fewer streams
+    than lists, fewer units than waves, more units than waves; launches of 1, 2 and 5 frames.  Models 1 (one kernel) and 0 / 2
+    (encode kernel alone / after the psy-2 kernel); every stream against the oracle up to 37 streams, 40 sampled ones of 3100 --
+    plus, for every stream, the sync word of every frame (a unit that was never encoded leaves zeros) and equality with the
+    stream 64 before it (the signals repeat every 64 streams)."""
+    nframes = 8
+    for psy, mode in ((1, "j"), (0, "s"), (2, "s")) if nstreams <= 37 else ((1, "s"),):
+        base = [gen_pcm(3000 + s, s % 8, 0, nframes) for s in range(min(nstreams, 64))]
+        pcm = np.stack([base[s % 64] for s in range(nstreams)], axis=1)
+        b = M.Batch([M.StreamConfig(mode=mode, psy_model=psy)] * nstreams)
+        chunks, pos = [b""] * nstreams, 0
+        for n in (1, 2, 5):
+            got, _ = b.encode(pcm[pos:pos + n])
+            chunks = [a + c for a, c in zip(chunks, got)]
+            pos += n
+        tail = b.flush()
+        b.close()
+        refs = {}
+        for s in (range(nstreams) if nstreams <= 37 else list(range(0, nstreams, 80)) + [nstreams - 1]):
+            if s % 64 not in refs:
+                refs[s % 64] = O.oracle_stream(pcm[:, s], mode=mode, psy=psy)[0]
+            assert chunks[s] + tail[s] == refs[s % 64], (psy, nstreams, s)
+        for s in range(nstreams):
+            data = chunks[s] + tail[s]
+            assert len(data) == 384 * nframes, (psy, nstreams, s)
+            assert all(data[384 * f:384 * f + 2] == b"\xff\xfc" for f in range(nframes)), (psy, nstreams, s)
+            if s >= 64:
+                assert data == chunks[s - 64] + tail[s - 64], (psy, nstreams, s)
+
+
 def test_configuration_sweep_vs_oracle(M):
     """Every legal (sample rate, mode, bitrate) x psy model as ONE mixed batch, a different signal per stream, against the
     oracle byte for byte (SURVEY 8d cfg5 generalised: mixed configurations share a launch)."""
