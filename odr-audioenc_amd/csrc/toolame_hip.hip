@@ -644,7 +644,9 @@ int tlb_encode_host_len(tlb_batch *b, const int16_t *pcm, int nframes, const uin
     // comes in over PCIe and chunk c-1 goes out (the link is full duplex; with pinned host buffers, tlb_host_alloc, the
     // copies run at link rate).  The kernels themselves stay in frame order on one stream -- the streams' state passes from
     // chunk to chunk.  Small calls (the legacy shim: one frame) and tap runs are one chunk.
-    const int nchunks = (taps || n_pcm < (8u << 20) || nframes < 2) ? 1 : (nframes < TLB_HOST_CHUNKS ? nframes : TLB_HOST_CHUNKS);
+    const int want = (taps || n_pcm < (8u << 20) || nframes < 2) ? 1 : (nframes < TLB_HOST_CHUNKS ? nframes : TLB_HOST_CHUNKS);
+    const int per = (nframes + want - 1) / want;                   // frames per chunk
+    const int nchunks = (nframes + per - 1) / per;                 // (5 frames: 2 + 2 + 1, three chunks, not four)
     if (!b->s_in) {
         HIPCHK(hipStreamCreateWithFlags(&b->s_in, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&b->s_run, hipStreamNonBlocking));
@@ -652,7 +654,6 @@ int tlb_encode_host_len(tlb_batch *b, const int16_t *pcm, int nframes, const uin
         for (int i = 0; i < TLB_HOST_CHUNKS; i++) { HIPCHK(hipEventCreateWithFlags(&b->ev_in[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b->ev_run[i], hipEventDisableTiming)); }
     }
     // TlPsyOut / ScF-CRC scratch sized for the largest chunk up front (tlb_launch would otherwise re-allocate between chunks)
-    const int per = (nframes + nchunks - 1) / nchunks;
     {
         if (b->n_list[2]) HIPCHK(stage_reserve(b, 5, (size_t)per * (size_t)b->nstreams * sizeof(TlPsyOut)));
         HIPCHK(stage_reserve(b, 6, (size_t)per * (size_t)b->nstreams * 4));

@@ -164,6 +164,30 @@ def test_unit_lists_odd_shapes(M, nstreams):
                 assert data == chunks[s - 64] + tail[s - 64], (psy, nstreams, s)
 
 
+@pytest.mark.parametrize("nframes", [5, 6, 9, 13])
+def test_host_path_chunking(M, nframes):
+    """tlb_encode_host cuts a big call (>= 8 MB of PCM) into up to four chunks of whole frames whose copies and kernels overlap;
+    frame counts that do not divide evenly (5 = 2 + 2 + 1: three chunks) must come out like the same frames fed one per call
+    (never chunked).  1900 streams x 4.6 KB = 8.7 MB per frame."""
+    nstreams = 1900
+    base = [gen_pcm(5000 + s, s % 8, 0, nframes) for s in range(64)]
+    pcm = np.stack([base[s % 64] for s in range(nstreams)], axis=1)
+    b1 = M.Batch([M.StreamConfig(mode="j", psy_model=1)] * nstreams)
+    whole, _ = b1.encode(pcm)
+    t1 = b1.flush()
+    b1.close()
+    b2 = M.Batch([M.StreamConfig(mode="j", psy_model=1)] * nstreams)
+    parts = [b""] * nstreams
+    for f in range(nframes):
+        got, _ = b2.encode(pcm[f:f + 1])
+        parts = [a + c for a, c in zip(parts, got)]
+    t2 = b2.flush()
+    b2.close()
+    assert whole == parts and t1 == t2
+    ref = O.oracle_stream(pcm[:, 5], mode="j", psy=1)[0]
+    assert whole[5] + t1[5] == ref
+
+
 def test_configuration_sweep_vs_oracle(M):
     """Every legal (sample rate, mode, bitrate) x psy model as ONE mixed batch, a different signal per stream, against the
     oracle byte for byte (SURVEY 8d cfg5 generalised: mixed configurations share a launch)."""
