@@ -57,40 +57,43 @@ static __device__ __forceinline__ int tl_next_unit(int32_t *counter)
                  : "=&v"(u), "=&s"(saved) : "v"(0), "v"(1), "s"(counter) : "memory");
     return __builtin_amdgcn_readfirstlane(u);
 }
-// (stream, frame) units come off EIGHT lists, one per XCD (each XCD has its own L2).  List q holds the streams k = q, q + 8, ...
-// of the launch's stream list, stream by stream, frames ascending: the waves of an XCD work on consecutive frames of a few
-// streams at a time, so the 480 samples of history a frame needs -- the tail of the frame before it, which a neighbouring
-// wave is reading as its own PCM -- come out of that XCD's L2 and not over the fabric a second time.  A wave whose own
-// list is empty goes on with the next XCD's (hop): the lists are for locality only, the balance stays that of one queue.
+// (stream, frame) units come off EIGHT lists, one per XCD (each XCD has its own L2).  The units of a launch, numbered stream by
+// stream with frames ascending (u = k * nframes + f), are dealt to the lists in blocks of 32 consecutive units: the waves of
+// an XCD work on consecutive frames of a few streams at a time, so the 480 samples of history a frame needs -- the tail of
+// the frame before it, which a neighbouring wave is reading as its own PCM -- come out of that XCD's L2 and not over the
+// fabric a second time (one stream with many frames spreads over all eight lists just the same).  A wave whose own list
+// is empty goes on with the next XCD's (hop): the lists are for locality only, the balance stays that of one queue.
 // Returns false when all eight lists are empty.  Which waves share an XCD: workgroups are dealt round-robin over the XCDs
 // (observed, MI355X_MICROARCH.md "Workgroup dispatch"), so blockIdx % 8 is the group; a wrong guess costs locality, nothing
 // else.  A wave's FIRST unit is its rank within its group (no atomic: three thousand waves asking at once would queue);
 // the list heads therefore count from the number of waves of the group.
 #define TL_HEAD_STRIDE 32             // int32 per list head: one 128-byte line each
+#define TL_LIST_BLOCK_LOG2 5          // 32 consecutive units per block
 static __device__ __forceinline__ bool tl_take_unit(int32_t *heads, int nlist, int nframes, int grp, int &hop, int &k, int &f, int first)
 {
+    const int nunits = nlist * nframes, nblocks = (nunits + (1 << TL_LIST_BLOCK_LOG2) - 1) >> TL_LIST_BLOCK_LOG2;
     while (hop < 8) {
         const int q = (grp + hop) & 7;
-        const int nq = (nlist - q + 7) >> 3;                         // streams on list q
-        const int ng = (((int)gridDim.x - q + 7) >> 3) * (int)(blockDim.x >> 6);      // waves whose own list q is: they took units 0 .. ng-1 by rank
+        const int lim = ((nblocks - q + 7) >> 3) << TL_LIST_BLOCK_LOG2;              // positions on list q (the launch's last block may be short)
+        const int ng = (((int)gridDim.x - q + 7) >> 3) * (int)(blockDim.x >> 6);      // waves whose own list q is: they took positions 0 .. ng-1 by rank
         int v;
         if (first >= 0) { v = first; first = -1; }
         else {
             // Another group's list is looked at before it is drawn from: at the end of a launch every wave walks the other
             // seven lists, and three thousand returning atomics on a word that has nothing left to give queue for 35 us per
             // list; a load does not queue.  A stale value costs one atomic, nothing else.
-            if (hop > 0 && ng + __hip_atomic_load(&heads[q * TL_HEAD_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nq * nframes) { hop++; continue; }
+            if (hop > 0 && ng + __hip_atomic_load(&heads[q * TL_HEAD_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= lim) { hop++; continue; }
             v = ng + tl_next_unit(&heads[q * TL_HEAD_STRIDE]);
         }
-        if (v < nq * nframes) {
-            const int kk = v / nframes;
-            k = q + 8 * kk; f = v - kk * nframes;
-            return true;
-        }
-        hop++;
+        if (v >= lim) { hop++; continue; }
+        const int u = ((((v >> TL_LIST_BLOCK_LOG2) << 3) + q) << TL_LIST_BLOCK_LOG2) + (v & ((1 << TL_LIST_BLOCK_LOG2) - 1));
+        if (u >= nunits) continue;                                   // past the end of the launch's last block: take again
+        k = u / nframes; f = u - k * nframes;
+        return true;
     }
     return false;
 }
+
 // LDS is handed out in granules of 1280 bytes on gfx950 (160 KB / 128): the twelve waves a CU holds at 3 per SIMD are ONE
 // workgroup sharing one copy of the tables (three 4-wave workgroups with a copy each do not fit).
 #ifndef TL_MAIN_WPE
