@@ -1,5 +1,6 @@
 """ctypes binding for the TEST-ONLY host emulation of the HIP kernels (tests/emu/libmp2emu.so)."""
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -24,8 +25,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        subprocess.run(["make", "-s", "-C", str(EMU_DIR)], check=True)
-        L = C.CDLL(str(EMU_DIR / "libmp2emu.so"))
+        alt = os.environ.get("TL_EMU_LIB")          # e.g. a sanitizer build (tools/emu_sanitize.sh)
+        if not alt:
+            subprocess.run(["make", "-s", "-C", str(EMU_DIR)], check=True)
+        L = C.CDLL(alt or str(EMU_DIR / "libmp2emu.so"))
         L.emu_create.restype = C.c_void_p
         L.emu_create.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.emu_destroy.argtypes = [C.c_void_p]
