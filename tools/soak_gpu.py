@@ -31,7 +31,14 @@ def ref_of(job):
         return None
 
 
+MODELS = [0, 1, 1, 1, 2, 3, 3, 4]      # TL_SOAK_MODELS=0,1,3 restricts the soak to the models with no known last-ulp ties
+
+
 def main():
+    global MODELS
+    import os
+    if os.environ.get("TL_SOAK_MODELS"):
+        MODELS = [int(x) for x in os.environ["TL_SOAK_MODELS"].split(",")]
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     F = int(sys.argv[2]) if len(sys.argv) > 2 else 12
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
@@ -40,7 +47,7 @@ def main():
     jobs = []
     while len(jobs) < S:
         fs, mode, kbps = combos[rng.integers(len(combos))] if rng.random() < 0.5 else (48000, "sj"[rng.integers(2)], (128, 192)[rng.integers(2)])
-        psy = int(rng.choice([0, 1, 1, 1, 2, 3, 3, 4]))
+        psy = int(rng.choice(MODELS))
         s = int(rng.integers(1 << 30))
         if rng.random() < 0.4:
             pcm = crafted(s)[:F] if F <= 6 else np.concatenate([crafted(s + i) for i in range((F + 5) // 6)])[:F]
