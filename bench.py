@@ -46,8 +46,8 @@ CONFIGS = {1: (4096, 1), 2: (16384, 3), 3: (16384, 3)}
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=None, help="streams per GPU (default: the BASELINE config of this N)")
     ap.add_argument("--frames-per-step", type=int, default=None, help="frames per stream per launch (default: 131072 (stream, frame) units per launch: 32 at 4096 streams, 8 at 16384)")
     ap.add_argument("--psy", type=int, default=None)
