@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Per-call time of the drop-in ABI (toolame_encode_frame, one stream, one frame per call) on the GPU box: what an unchanged
+odr-audioenc pays every 24 ms.   usage: tools/legacy_latency.py [frames]"""
+import ctypes as C
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import odr_audioenc_amd as M
+from pcmgen import gen_pcm
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+L = M.legacy_api()
+L.toolame_set_samplerate.argtypes = [C.c_long]
+L.toolame_set_channel_mode.argtypes = [C.c_char]
+L.toolame_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+L.toolame_init(); L.toolame_set_samplerate(48000); L.toolame_set_psy_model(1); L.toolame_set_channel_mode(b"j")
+L.toolame_set_bitrate(128); L.toolame_set_pad(0)
+pcm = gen_pcm(0, 0, 0, 64)
+out = (C.c_ubyte * 4096)()
+ts = []
+for i in range(n):
+    t = time.perf_counter()
+    L.toolame_encode_frame(pcm[i & 63].ctypes.data, None, 0, out, 4096)
+    ts.append(time.perf_counter() - t)
+ts = np.array(ts[20:]) * 1e3
+print(f"toolame_encode_frame, 48 kHz joint stereo 128 kbps psy 1: median {np.median(ts):.3f} ms, p99 {np.percentile(ts, 99):.3f} ms, max {ts.max():.3f} ms "
+      f"per call over {len(ts)} calls (a frame is 24 ms of audio)")
