@@ -303,7 +303,7 @@ def main():
         if pk and run_stage_ms:
             kernels = {pk: round(run_stage_ms[0], 4), "tl_main_kernel + tl_finish_kernel": round(run_stage_ms[1], 4),
                        "source": "hipEvents on the launch stream inside the library (tlb_last_stage_ms), last timed launch"}
-        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh): a committed
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, tools/profile_round2.sh): a committed
         # measurement, quoted only when it was taken on this very workload; never measured inside this run
         traffic, traffic_source, valu = None, None, None
         try:
