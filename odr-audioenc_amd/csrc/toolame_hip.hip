@@ -406,7 +406,7 @@ int tlb_lds_bytes_per_stream(void)
     if (sizeof(TlPsy2Lds) > m) m = sizeof(TlPsy2Lds);
     return (int)m;
 }
-const char *tlb_version(void) { return "odr-audioenc_amd 0.1 (gfx950, wave-per-stream, fp64)"; }
+const char *tlb_version(void) { return "odr-audioenc_amd 0.2 (gfx950, a wavefront per (stream, frame), fp64)"; }
 
 void tlb_destroy(tlb_batch *b)
 {
