@@ -363,8 +363,8 @@ struct tlb_batch {
     bool timed = false;
     // device staging of the host-buffer entry point (tlb_encode_host): grow-only, created on first use, so a caller that
     // feeds one frame per call (the legacy shim) pays for no allocation after its first frame
-    void *stage[9] = {};                         // pcm, out, xpad, xpad_len, taps; [5] = TlPsyOut records (models 2/4), [6] = ScF-CRC bytes, [7] = padding bits, [8] = frame lengths (host entry)
-    size_t stage_cap[9] = {};
+    void *stage[12] = {};                        // pcm, out, xpad, xpad_len, taps; [5] = TlPsyOut records (models 2/4), [6] = ScF-CRC bytes, [7] = padding bits, [8] = frame lengths (host entry); [9..11] = tlb_ingest_host: interleaved in, planar out, peaks
+    size_t stage_cap[12] = {};
     hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;   // host-buffer entry point: copy-in / kernels / copy-out
     hipEvent_t ev_in[TLB_HOST_CHUNKS] = {}, ev_run[TLB_HOST_CHUNKS] = {};
     uint32_t *d_newpend = nullptr;               // split path: the launch's last frame of every stream
@@ -423,7 +423,7 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_edi_state_tmp) (void)hipFree(b->d_edi_state_tmp);
     if (b->d_pseq_tmp) (void)hipFree(b->d_pseq_tmp);
     for (int p = 0; p < 4; p++) if (b->d_list[p]) (void)hipFree(b->d_list[p]);
-    for (int k = 0; k < 9; k++) if (b->stage[k]) (void)hipFree(b->stage[k]);
+    for (int k = 0; k < 12; k++) if (b->stage[k]) (void)hipFree(b->stage[k]);
     for (int i = 0; i < TLB_HOST_CHUNKS; i++) { if (b->ev_in[i]) (void)hipEventDestroy(b->ev_in[i]); if (b->ev_run[i]) (void)hipEventDestroy(b->ev_run[i]); }
     if (b->s_in) (void)hipStreamDestroy(b->s_in);
     if (b->s_run) (void)hipStreamDestroy(b->s_run);
@@ -737,21 +737,19 @@ int tlb_ingest_device(tlb_batch *b, const int16_t *d_interleaved, int nframes, i
 }
 
 int tlb_ingest_host(tlb_batch *b, const int16_t *interleaved, int nframes, int16_t *pcm, int16_t *peaks)
-{
-    DevFree guard_;
+{   // device staging kept between calls, like tlb_encode_host (an application calls this once per chunk of frames)
     if (!b || !interleaved || !pcm || !peaks || nframes <= 0) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
     const size_t slots = (size_t)nframes * (size_t)b->nstreams;
-    int16_t *d_in = nullptr, *d_out = nullptr, *d_pk = nullptr;
-    DEVALLOC(d_in, slots * 2304 * 2);
-    DEVALLOC(d_out, slots * 2304 * 2);
-    DEVALLOC(d_pk, slots * 2 * 2);
+    HIPCHK(stage_reserve(b, 9, slots * 2304 * 2));
+    HIPCHK(stage_reserve(b, 10, slots * 2304 * 2));
+    HIPCHK(stage_reserve(b, 11, slots * 2 * 2));
+    int16_t *d_in = (int16_t *)b->stage[9], *d_out = (int16_t *)b->stage[10], *d_pk = (int16_t *)b->stage[11];
     HIPCHK(hipMemcpy(d_in, interleaved, slots * 2304 * 2, hipMemcpyHostToDevice));
     int rc = tlb_ingest_device(b, d_in, nframes, d_out, d_pk, nullptr);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(pcm, d_out, slots * 2304 * 2, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(peaks, d_pk, slots * 2 * 2, hipMemcpyDeviceToHost));
-
     return rc;
 }
 
