@@ -43,7 +43,7 @@ static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 // with the equal test of the diagnostic stamps at the end of the previous unit into a loop that some lanes never left; and
 // its wave-level atomic optimiser, which folds `atomicAdd(p, 1)` of 64 lanes into one add, only does so while it can prove the
 // address uniform -- when it cannot, the 64 adds of two waves interleave and units are handed out twice or never.
-// `counter` must be wave-uniform.
+// `counter` must be wave-uniform and the call site wave-uniform control flow (lane 0 active: its registers carry the operands).
 static __device__ __forceinline__ int tl_next_unit(int32_t *counter)
 {
     int u;
