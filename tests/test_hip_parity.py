@@ -307,6 +307,19 @@ def test_one_stream_many_frames(M):
         b.close()
 
 
+def test_baseline_configs0_2000_frames(M):
+    """BASELINE configs[0] / SURVEY 8(d) cfg1 on the device: ONE stream, 2000 frames, seed 0, psycho_1, 's' and 'j', in one call
+    (2000 independent units) -- every byte against the oracle (itself gated against the live reference on the same input,
+    tests/test_oracle_golden.py)."""
+    pcm = gen_pcm(0, 0, 0, 2000)[:, None]
+    for mode in ("s", "j"):
+        b = M.Batch([M.StreamConfig(mode=mode, psy_model=1)])
+        got, _ = b.encode(pcm)
+        tail = b.flush()
+        b.close()
+        assert got[0] + tail[0] == O.oracle_stream(pcm[:, 0], mode=mode, psy=1)[0], mode
+
+
 def test_full_size_properties(M):
     """BASELINE configs[1] size (4096 streams, psy 1): size-independent properties instead of a full oracle run -- identical
     inputs give identical frames wherever they sit in the batch, every frame starts with the sync header and has the right

@@ -110,3 +110,18 @@ def test_silence_psy3_is_defined():
     """The reference segfaults here (psycho_3.c:299, (int)(0/0) index); the oracle defines it."""
     data, _ = O.oracle_stream(gen_pcm(0, 1, 0, 4), psy=3)
     assert len(data) == 4 * 384
+
+
+def test_baseline_configs0_2000_frames_oracle_equals_live_reference():
+    """BASELINE configs[0] / SURVEY 8(d) cfg1: ONE stream, 2000 frames, seed 0, 48 kHz stereo 128 kbps, psycho_1 -- the bit-exact
+    gate on the CPU: the restatement against the reference compiled from its own sources (oracle/_ref), bytes and burst lengths.
+    Skipped where the reference build is not present (it cannot travel as source)."""
+    if not O.REF_SO.exists():
+        pytest.skip("oracle/_ref/libtoolame_ref.so not built here")
+    from pcmgen import gen_pcm
+    pcm = gen_pcm(0, 0, 0, 2000)
+    for mode in ("s", "j"):
+        ref = O.reference_stream(pcm, mode=mode, psy=1)
+        data, lens = O.oracle_stream(pcm, mode=mode, psy=1)
+        assert data == ref["data"] and lens == ref["lens"], mode
+        assert len(data) == 2000 * 384
