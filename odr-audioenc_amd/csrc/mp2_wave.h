@@ -564,8 +564,7 @@ TL_FN void tl_fht_pass(double *x, const double (&t)[8], int lane)
 // channel that precede it (the stream state on the first frame of a launch, the previous input frame after).
 struct TlPcmView { const int16_t *cur; const int16_t *hist; int hist_stride; };
 
-template <class W>
-TL_FN void tl_psy_spectrum(W &w, const TlTables *TL_RESTRICT T, const TlPcmView &pv, int ch, long long *sp)
+TL_FN void tl_psy_spectrum(TlPsyLds &w, const TlTables *TL_RESTRICT T, const TlPcmView &pv, int ch, long long *sp)
 {
     double *x = w.u.fft;
     long long *sq = (sp && ch == 0) ? sp + 16 : nullptr;      // channel 0's pass-by-pass stamps: slots 24..30 of the frame's record
@@ -701,8 +700,8 @@ TL_FN int tl_run_psy3(int c) { return c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 1
 // 7 dB test; the left-hand failures are recorded as a bit mask for the walk that follows (psycho_1.c:267-300,
 // psycho_3.c:186-236).  RMAX is the largest run inside the chunk, so the neighbour reads are straight-line code
 // and overlap; PSY3 selects psycho_3's strict maximum and its (peak - neighbour) < 7 form of the test.
-template <int RMAX, bool PSY3, class W>
-TL_FN void tl_cand_chunk(W &w, int c8, int &ncand)
+template <int RMAX, bool PSY3>
+TL_FN void tl_cand_chunk(TlPsyLds &w, int c8, int &ncand)
 {
     const double *px = TL_PX(w);
     PV(bool, isc); PV(uint32_t, rec);
@@ -748,8 +747,7 @@ TL_FN void tl_cand_chunk(W &w, int c8, int &ncand)
 // uses the LDS arrays.
 struct TlPsy1Ch { int nconf, nlist; bool dead_head; };
 
-template <class W>
-TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
+TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
                              const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, PARGA(double, rec, 4), long long *sp)
 {
     const double *energy = w.u.fft;                                   // line i at TL_EX(i)
@@ -803,10 +801,10 @@ TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *
     // (1) local maxima 2..499 whose right-hand neighbours pass the 7 dB test, compacted ascending
     int ncand = 0;
     if (TL_EXP_LEVEL < 6) {
-    tl_cand_chunk<2, false, W>(w, 0, ncand);                           // lines -1..62: run 2
-    tl_cand_chunk<3, false, W>(w, 1, ncand);                           // 63..126: run 3
-    for (int c8 = 2; c8 < 4; c8++) tl_cand_chunk<6, false, W>(w, c8, ncand);     // 127..254: run 6
-    for (int c8 = 4; c8 < 8; c8++) tl_cand_chunk<12, false, W>(w, c8, ncand);    // 255..510: run 12
+    tl_cand_chunk<2, false>(w, 0, ncand);                           // lines -1..62: run 2
+    tl_cand_chunk<3, false>(w, 1, ncand);                           // 63..126: run 3
+    for (int c8 = 2; c8 < 4; c8++) tl_cand_chunk<6, false>(w, c8, ncand);     // 127..254: run 6
+    for (int c8 = 4; c8 < 8; c8++) tl_cand_chunk<12, false>(w, c8, ncand);    // 255..510: run 12
     }
     TL_STAMP(sp, 2);
     // (2) wave-uniform walk: which candidates become tones.  State of the reference's list walk that
@@ -957,8 +955,7 @@ TL_FN TlPsy1Ch tl_psy1_front(W &w, const TlTables *TL_RESTRICT T, const double *
 
 // weight sums of the bands (psycho_1.c:364-366), ascending line order; lane b < nbands owns band b.  Only used where the
 // weights cannot ride along with the dB-sum chain (channel 0 of a stereo frame, whose terms leave LDS before its chain runs).
-template <class W>
-TL_FN void tl_psy1_weights(W &w, int nbands, PARG(double, wt))
+TL_FN void tl_psy1_weights(TlPsyLds &w, int nbands, PARG(double, wt))
 {
     TL_LANES_BEGIN
     double weight = 0.0;
@@ -984,8 +981,7 @@ TL_FN void tl_psy1_weights(W &w, int nbands, PARG(double, wt))
 }
 
 // dB sums and weight sums of the bands of ONE channel (levels at TL_PX, weight terms at fft): lane b < nbands
-template <class W>
-TL_FN void tl_psy1_chain(W &w, const double *TL_RESTRICT db, int nbands, PARG(double, bsum), PARG(double, wt))
+TL_FN void tl_psy1_chain(TlPsyLds &w, const double *TL_RESTRICT db, int nbands, PARG(double, bsum), PARG(double, wt))
 {
     TL_LANES_BEGIN
     double sum = TL_DBMIN, weight = 0.0;
@@ -1009,8 +1005,7 @@ TL_FN void tl_psy1_chain(W &w, const double *TL_RESTRICT db, int nbands, PARG(do
 
 // dB sums of BOTH channels at once: lanes 0..31 walk channel 0's bands (levels parked at fft[], ranges in r0/r1), lanes 32..63
 // channel 1's (levels at TL_PX, ranges from bandoff[]).  Result: lane b holds channel 0's sum, lane 32+b channel 1's.
-template <class W>
-TL_FN void tl_psy1_chain2(W &w, const double *TL_RESTRICT db, int nbands, PARG(int, r0), PARG(int, r1), PARG(double, bsum))
+TL_FN void tl_psy1_chain2(TlPsyLds &w, const double *TL_RESTRICT db, int nbands, PARG(int, r0), PARG(int, r1), PARG(double, bsum))
 {
     TL_LANES_BEGIN
     double sum = TL_DBMIN;
@@ -1042,8 +1037,7 @@ TL_FN void tl_psy1_chain2(W &w, const double *TL_RESTRICT db, int nbands, PARG(i
 }
 
 // band centres (psycho_1.c:367-388) from the sums and weights of lanes b < nbands; needs ptype[] of the channel
-template <class W>
-TL_FN void tl_psy1_centres(W &w, const TlConfig *TL_RESTRICT C, int nbands, PARG(double, bsum), PARG(double, wt))
+TL_FN void tl_psy1_centres(TlPsyLds &w, const TlConfig *TL_RESTRICT C, int nbands, PARG(double, bsum), PARG(double, wt))
 {
     TL_LANES_BEGIN
     if (lane < nbands) {
@@ -1063,8 +1057,7 @@ TL_FN void tl_psy1_centres(W &w, const TlConfig *TL_RESTRICT C, int nbands, PARG
 }
 
 // individual + global masking thresholds, minimum per subband, SMR (psycho_1.c:480-581) from the masker lists
-template <class W>
-TL_FN void tl_psy1_thresholds(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, int ntone, int nnoise, PARGA(double, rec, 4), long long *sp)
+TL_FN void tl_psy1_thresholds(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, int ntone, int nnoise, PARGA(double, rec, 4), long long *sp)
 {
     TL_STAMP(sp, 5);
 
@@ -1126,8 +1119,7 @@ TL_FN void tl_psy1_thresholds(W &w, const double *TL_RESTRICT db, const TlConfig
 }
 
 // band levels, decimation (psycho_1.c:390-470) and everything after; the regular (not dead-head) case
-template <class W>
-TL_FN void tl_psy1_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, PARGA(double, rec, 4), long long *sp)
+TL_FN void tl_psy1_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, PARGA(double, rec, 4), long long *sp)
 {
     const int nbands = C->p1_ncb - 1, nlist = st.nlist;
     int ntone = 0, nnoise = 0;
@@ -1242,8 +1234,7 @@ TL_FN void tl_psy1_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_R
 }
 
 // the dead-head replay (see tl_psy1_front): works on power[] (px) and the shared links like the reference
-template <class W>
-TL_FN void tl_psy1_deadhead(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, PARGA(double, rec, 4), long long *sp)
+TL_FN void tl_psy1_deadhead(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, PARGA(double, rec, 4), long long *sp)
 {
     const int nbands = C->p1_ncb - 1, nconf = st.nconf;
     const uint8_t *map = C->p1_map;
@@ -1329,8 +1320,7 @@ TL_FN void tl_psy1_deadhead(W &w, const double *TL_RESTRICT db, const TlConfig *
 }
 
 // one channel start to end (mono streams; stereo streams when a dead-head case forces the plain order)
-template <class W>
-TL_FN void tl_psy1_finish(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, PARGA(double, rec, 4), long long *sp)
+TL_FN void tl_psy1_finish(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, PARGA(double, rec, 4), long long *sp)
 {
     const int nbands = C->p1_ncb - 1;
     PV(double, wt); PV(double, bsum);
@@ -1338,8 +1328,7 @@ TL_FN void tl_psy1_finish(W &w, const double *TL_RESTRICT db, const TlConfig *TL
     tl_psy1_centres(w, C, nbands, bsum, wt);
     if (st.dead_head) tl_psy1_deadhead(w, db, C, ch, st, rec, sp); else tl_psy1_back(w, db, C, ch, st, rec, sp);
 }
-template <class W>
-TL_FN void tl_psy1(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
+TL_FN void tl_psy1(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
                    const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, PARGA(double, rec, 4), long long *sp)
 {
     const TlPsy1Ch st = tl_psy1_front(w, T, db, C, pv, ch, rec, sp);
@@ -1352,8 +1341,7 @@ TL_FN void tl_psy1(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRIC
 // band ranges and the weight sums.  ptype[] is not parked: after the tone labelling a line is TONE exactly if it is the line
 // of a confirmed tone that was not erased by its successor, so it is rebuilt from conf_c.  A dead-head channel (see
 // tl_psy1_front) falls back to the plain per-channel order.
-template <class W>
-TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
+TL_FN void tl_psy1_stereo(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
                           const TlConfig *TL_RESTRICT C, const TlPcmView &pv, PARGA(double, rec, 4), long long *sp)
 {
     const int nbands = C->p1_ncb - 1;
@@ -1440,8 +1428,7 @@ TL_FN void tl_psy1_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
 
 // ------------------------------------------------------------------------------------------
 // psy model 3 (psycho_3.c:71-432) for channel `ch`; result in w.smr[ch][0..32).
-template <class W>
-TL_FN int tl_psy3_front(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
+TL_FN int tl_psy3_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
                    const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, PARGA(double, rec, 4), long long *sp)
 {
     const double *energy = w.u.fft;                                   // line i at TL_EX(i)
@@ -1501,10 +1488,10 @@ TL_FN int tl_psy3_front(W &w, const TlTables *TL_RESTRICT T, const double *TL_RE
     // ---- tone labelling (psycho_3.c:186-247) ----
     // (1) local maxima 2..499 whose right-hand neighbours are >= 7 dB down, compacted ascending
     int ncand = 0;
-    tl_cand_chunk<2, true, W>(w, 0, ncand);                           // lines -1..62: run 2
-    tl_cand_chunk<3, true, W>(w, 1, ncand);                           // 63..126: run 3
-    for (int c8 = 2; c8 < 4; c8++) tl_cand_chunk<6, true, W>(w, c8, ncand);     // 127..254: run 6
-    for (int c8 = 4; c8 < 8; c8++) tl_cand_chunk<12, true, W>(w, c8, ncand);    // 255..510: run 12
+    tl_cand_chunk<2, true>(w, 0, ncand);                           // lines -1..62: run 2
+    tl_cand_chunk<3, true>(w, 1, ncand);                           // 63..126: run 3
+    for (int c8 = 2; c8 < 4; c8++) tl_cand_chunk<6, true>(w, c8, ncand);     // 127..254: run 6
+    for (int c8 = 4; c8 < 8; c8++) tl_cand_chunk<12, true>(w, c8, ncand);    // 255..510: run 12
     TL_STAMP(sp, 2);
     // (2) wave-uniform walk.  A confirmed tone k erases lines k-sr..k+sr (itself included) to DBMIN
     //     (psycho_3.c:243-244); a later maximum inside that reach R has power DBMIN and always fails,
@@ -1600,8 +1587,7 @@ TL_FN int tl_psy3_front(W &w, const TlTables *TL_RESTRICT T, const double *TL_RE
 
 // energy sum and centre-of-gravity sum of the bands (psycho_3.c:283-289), ascending line order; lane b < nb.  Used on their own
 // for stereo frames, where only the levels take part in the shared dB-sum chain.
-template <class W>
-TL_FN void tl_psy3_moments(W &w, int nb, PARG(double, es), PARG(double, cg))
+TL_FN void tl_psy3_moments(TlPsyLds &w, int nb, PARG(double, es), PARG(double, cg))
 {
     TL_LANES_BEGIN
     double esum = 0, cw = 0;
@@ -1628,8 +1614,7 @@ TL_FN void tl_psy3_moments(W &w, int nb, PARG(double, es), PARG(double, cg))
 }
 
 // dB sums, energy sums and centre-of-gravity sums of the bands of ONE channel: lane b < nb
-template <class W>
-TL_FN void tl_psy3_chain(W &w, const double *TL_RESTRICT db, int nb, PARG(double, bsum), PARG(double, es), PARG(double, cg))
+TL_FN void tl_psy3_chain(TlPsyLds &w, const double *TL_RESTRICT db, int nb, PARG(double, bsum), PARG(double, es), PARG(double, cg))
 {
     TL_LANES_BEGIN
     double sum = TL_DBMIN, esum = 0, cw = 0;
@@ -1655,8 +1640,7 @@ TL_FN void tl_psy3_chain(W &w, const double *TL_RESTRICT db, int nb, PARG(double
 
 // dB sums of BOTH channels at once: lanes 0..31 walk channel 0's bands (levels parked at fft[], ranges in r0/r1), lanes 32..63
 // channel 1's (levels in px[], ranges from bandoff[]).  Lane b holds channel 0's sum, lane 32+b channel 1's.
-template <class W>
-TL_FN void tl_psy3_chain2(W &w, const double *TL_RESTRICT db, int nb, PARG(int, r0), PARG(int, r1), PARG(double, bsum))
+TL_FN void tl_psy3_chain2(TlPsyLds &w, const double *TL_RESTRICT db, int nb, PARG(int, r0), PARG(int, r1), PARG(double, bsum))
 {
     TL_LANES_BEGIN
     double sum = TL_DBMIN;
@@ -1688,8 +1672,7 @@ TL_FN void tl_psy3_chain2(W &w, const double *TL_RESTRICT db, int nb, PARG(int, 
 }
 
 // band centres, decimation, thresholds, SMR (psycho_3.c:290-432) from the sums of lanes b < nb
-template <class W>
-TL_FN void tl_psy3_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, int nconf,
+TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, int nconf,
                         PARG(double, bsum), PARG(double, es), PARG(double, cg), PARGA(double, rec, 4), long long *sp)
 {
     const double *bark = C->p3_bark, *ath = C->p3_ath;
@@ -1808,8 +1791,7 @@ TL_FN void tl_psy3_back(W &w, const double *TL_RESTRICT db, const TlConfig *TL_R
 }
 
 
-template <class W>
-TL_FN void tl_psy3(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
+TL_FN void tl_psy3(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
                    const TlConfig *TL_RESTRICT C, const TlPcmView &pv, int ch, PARGA(double, rec, 4), long long *sp)
 {
     const int nconf = tl_psy3_front(w, T, db, C, pv, ch, rec, sp);
@@ -1820,8 +1802,7 @@ TL_FN void tl_psy3(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRIC
 
 // Both channels of a stereo frame, organised like tl_psy1_stereo: front(0) -> channel 0's compacted levels, tone records, Lsb
 // and band moments wait in registers -> front(1) -> both dB-sum chains side by side -> back(1) -> back(0).
-template <class W>
-TL_FN void tl_psy3_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
+TL_FN void tl_psy3_stereo(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
                           const TlConfig *TL_RESTRICT C, const TlPcmView &pv, PARGA(double, rec, 4), long long *sp)
 {
     const int nb = C->p3_cbands;
@@ -1870,8 +1851,7 @@ TL_FN void tl_psy3_stereo(W &w, const TlTables *TL_RESTRICT T, const double *TL_
 // PCM history on pass 0, samples 96..575 of the frame on pass 1 (the reference's savebuf shift by 576).
 // Line-parallel: FFT, unpredictability (sincos/atan2/sqrt per line), thresholds; partition-parallel:
 // grouping, spreading, SNR.  Every sum is one lane's sequential chain in the reference's order.
-template <class W>
-TL_FN void tl_psy2(W &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_RESTRICT P,
+TL_FN void tl_psy2(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_RESTRICT P,
                    TlPsy2State *TL_RESTRICT S, const TlPcmView &pv, int ch, long long *sp, double *smr_out)
 {
     double *x = w.u.fft;
@@ -2060,13 +2040,13 @@ TL_FN void tl_psy2(W &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_R
 // for its successor's ScF-CRC, or -- the last frame of a launch -- the batch's pending buffer (big-endian words like
 // TlStreamState::pending); and the slot for its own ScF-CRC bytes, which tl_finish_stream stores into the frame before it.
 struct TlFrameOut { uint8_t *bytes; uint32_t *words; uint8_t *scfcrc; };
-template <int PSY, class W>
-TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+template <int PSY>
+TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
                            const TlConfig *TL_RESTRICT C, const TlPsyOut *TL_RESTRICT PO,
                            const TlPcmView &pv, int xpad_len, const TlFrameOut &fo,
                            const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, int padding, TlTaps *taps, long long *sp)
 {
-    constexpr int FB = W::kFbBatch;
+    constexpr int FB = TlMainLds::kFbBatch;
     const int nch = C->nch, sblimit = C->sblimit;
     PA(double, smp, 36);            // sb_sample[ch][gr][bl][sb] of this lane's (sb,ch), b = gr*12+bl
     PA(int, scf, 3);
@@ -2098,7 +2078,7 @@ TL_FN void tl_encode_frame(W &w, const TlTables *TL_RESTRICT T, const TlBlockSha
                 L(xb)[8 * b + ((0 - j) & 7)] = c < nch ? w.u.fbk.pcm[c][TL_HIST + 32 * b + 31 - yb - 64 * j] : 0;
             }
         TL_LANES_END
-        typename W::YpRows yp = w.yp_rows();
+        TlMainLds::YpRows yp = w.yp_rows();
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
@@ -2816,8 +2796,7 @@ TL_FN void tl_psy2_chain(TlPsy2Lds &w, const TlLaunch &A, int s, int ch)
 
 // [history | frame] -> LDS in 8-byte pieces, 120 + 288 per channel.  All of a lane's loads are issued before the first LDS
 // write so the HBM latency is paid once per frame, not once per piece.
-template <class W>
-TL_FN void tl_stage_pcm(W &w, const TlPcmView &pv, int nch)
+TL_FN void tl_stage_pcm(TlMainLds &w, const TlPcmView &pv, int nch)
 {
     TL_LANES_BEGIN
     {
@@ -2843,8 +2822,7 @@ TL_FN void tl_stage_pcm(W &w, const TlPcmView &pv, int nch)
 // X-PAD bytes of a slot -> LDS; returns the length the frame carries.  The contract is 0 or 2..pad_len (toolame.c:515-516,
 // odr-audioenc.cpp:803,830-834); anything else -- more than the stream's toolame_set_pad() length, more than the record
 // holds -- is treated as "no PAD this frame" (tl_build_config has made sure that pad_len itself fits into the frame).
-template <class W>
-TL_FN int tl_stage_xpad(W &w, const TlLaunch &A, const TlConfig *C, size_t slot)
+TL_FN int tl_stage_xpad(TlMainLds &w, const TlLaunch &A, const TlConfig *C, size_t slot)
 {
     if (!A.xpad_len) return 0;
     int xl = A.xpad_len[slot];
