@@ -1,8 +1,10 @@
-// mp2_wave.h -- the DAB MP2 (MPEG-1/2 Layer II) frame encoder as ONE WAVEFRONT PER STREAM.
+// mp2_wave.h -- the DAB MP2 (MPEG-1/2 Layer II) frame encoder as ONE WAVEFRONT PER (STREAM, FRAME).
 //
 // This is the MI355X-native restatement of toolame_encode_frame()
-// (/root/reference/libtoolame-dab/toolame.c:267-554): 64 lanes cooperate on one stream's frame,
+// (/root/reference/libtoolame-dab/toolame.c:267-554): 64 lanes cooperate on one frame of one stream,
 // all per-frame working state lives in LDS / registers, HBM sees PCM in and frame bytes out.
+// Units of work (tl_frame_unit, tl_main_unit, tl_psy2_chain, tl_finish_stream at the end of the file) are what
+// the kernels in toolame_hip.hip hand to their waves.
 //
 // The file is written in a lane-SPMD style that compiles two ways from the same source:
 //   * hipcc --offload-arch=gfx950 : TL_LANES_BEGIN/END open a per-lane scope, cross-lane
