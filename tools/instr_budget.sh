@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 if [ "${1:-run}" = build ]; then
   mkdir -p build
   for n in 1 2 3 4 5 6 7 8; do
-    (cd odr-audioenc_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-strict-aliasing -fPIC -Wno-unused-function \
+    (cd odr-audioenc_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -mllvm -disable-machine-licm -fno-strict-aliasing -fPIC -Wno-unused-function \
        -Wno-unused-variable -Wno-pass-failed -shared -o $R/build/lib_exp$n.so toolame_hip.hip -x hip mp2_host.cpp -DTL_EXP_LEVEL=$n) &
     if [ $((n % 4)) = 0 ]; then wait; fi
   done
@@ -32,7 +32,7 @@ for n in range(9):
         for row in csv.DictReader(open(f)):
             if "tl_frame_kernel" in row["Kernel_Name"]: dur.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
     if not acc: print(n, "no data"); continue
-    v = {k: sum(x) / len(x) / 65536 for k, x in acc.items()}
+    v = {k: sum(x) / len(x) / 131072 for k, x in acc.items()}
     ms = sum(dur) / len(dur)
     d = "" if prev is None else f"   stage: VALU {prev[0] - v['SQ_INSTS_VALU']:7.0f}  SALU {prev[1] - v['SQ_INSTS_SALU']:6.0f}  LDS {prev[2] - v['SQ_INSTS_LDS']:6.0f}  ms {prev[3] - ms:6.3f}"
     print(f"level {n} {names[n]:28s} per frame: VALU {v['SQ_INSTS_VALU']:7.0f} SALU {v['SQ_INSTS_SALU']:6.0f} LDS {v['SQ_INSTS_LDS']:6.0f}  kernel {ms:6.3f} ms{d}")
