@@ -1,0 +1,480 @@
+// tl_libm.h -- the reference's transcendental arithmetic, operation for operation.
+//
+// The reference calls the HOST's libm per frame: log10 / pow (psycho_1.c:245,254,373, psycho_3.c:158), sqrt,
+// cos+sin (gcc fuses the pairs of psycho_2.c:127-132 into one sincos call), log, exp (psycho_2.c:114-137,185,190,
+// 235,245, psycho_4.c:184-222,267,277,307,317) and atan2 (fft.c:1269-1274).  The oracle is the reference built here,
+// so "the reference's result" is what Ubuntu glibc 2.35 (libm.so.6, x86-64, an FMA-capable CPU: this container's
+// Xeon and the GPU box's EPYC alike) returns.  One ulp of difference decides tone tests and allocation ties on
+// degenerate signals (round-2 soak), so a GPU path that wants the reference's bytes has to produce glibc's bits.
+// This header restates the routines glibc 2.35 runs for those calls:
+//
+//   log    sysdeps/ieee754/dbl-64/e_log.c  (Szabolcs Nagy's table-driven log, N = 128), the build the ifunc resolver
+//          picks on FMA machines (__log_fma, libm.so.6 0x76660)
+//   log10  sysdeps/ieee754/dbl-64/e_log10.c (one baseline build, 0x29510): y*log10_2lo + ivln10*log(m) + y*log10_2hi
+//   exp    e_exp.c (__exp_fma 0x76470)           pow   e_pow.c (__pow_fma 0x768b0): log_inline + exp_inline
+//   sincos s_sincos.c + s_sin.c (IBM Accurate Mathematical Library as trimmed in 2.28+; ONE baseline build 0x2fa80,
+//          no FMA anywhere in it)                atan2 e_atan2.c + uatan.tbl (__atan2_fma 0x78060)
+//
+// The *_fma builds are compiled with -mfma -mavx2 and GCC's default -ffp-contract=fast, so WHICH products are fused
+// into which sums is the compiler's choice, not the source's: every fma() below is one vfmadd/vfmsub/vfnmadd of the
+// disassembly (`objdump -d libm.so.6`, addresses above), every separate * and + one vmulsd / vaddsd; the
+// expression trees were read off the instruction stream, not guessed.  This translation unit is compiled
+// -ffp-contract=off, so nothing else gets fused.  Tables: tl_libm_tables.inc (tools/extract_libm_tables.py reads
+// them out of the same libm.so.6, bit patterns, nothing retyped).
+//
+// Proof: tools/libm_agree.c runs every function here against the host's libm on >= 1e8 arguments each
+// (profiles/libm_agree_r03.txt: 0 differing results), tests/test_libm_agree.py on a smaller sample in the CPU suite.
+// Domain notes are at each function; outside them the functions still return what glibc returns unless stated.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define TLM_HD __host__ __device__ __forceinline__
+#else
+#define TLM_HD static inline
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TLM_TABLE_QUAL static __device__ const
+#else
+#define TLM_TABLE_QUAL static const
+#endif
+#include "tl_libm_tables.inc"
+
+TLM_HD uint64_t tlm_d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+TLM_HD double tlm_u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+#define TLM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#define TLM_D(bits) tlm_u2d(bits##ull)
+
+// ------------------------------------------------------------------------------------------------------------
+// log (e_log.c).  TAB = {invc, logc}[128] as bit patterns (global table or an LDS copy of it).
+// The two evaluation paths as straight-line pieces so that device code can run both and select.
+
+// |x - 1| small: x in [1 - 2^-4, 1 + 0x1.09p-4)  (e_log.c "close to 1.0" branch; __log_fma 0x76760-0x76832)
+TLM_HD double tlm_log_near1(double x)
+{
+    const double B0 = TLM_D(0xbfe0000000000000), B1 = tlm_u2d(tlm_log_poly1[1]), B2 = tlm_u2d(tlm_log_poly1[2]),
+                 B3 = tlm_u2d(tlm_log_poly1[3]), B4 = tlm_u2d(tlm_log_poly1[4]), B5 = tlm_u2d(tlm_log_poly1[5]),
+                 B6 = tlm_u2d(tlm_log_poly1[6]), B7 = tlm_u2d(tlm_log_poly1[7]), B8 = tlm_u2d(tlm_log_poly1[8]),
+                 B9 = tlm_u2d(tlm_log_poly1[9]), B10 = tlm_u2d(tlm_log_poly1[10]);
+    const double r = x - 1.0;
+    const double r2 = r * r;
+    const double r3 = r * r2;
+    const double q1 = TLM_FMA(r2, B3, TLM_FMA(B2, r, B1));
+    const double q2 = TLM_FMA(r2, B6, TLM_FMA(B5, r, B4));
+    const double q3 = TLM_FMA(r3, B10, TLM_FMA(r2, B9, TLM_FMA(B8, r, B7)));
+    const double y0 = TLM_FMA(TLM_FMA(q3, r3, q2), r3, q1);
+    const double t = TLM_FMA(r, 0x1p27, r);                 // r + w, w = r * 2^27
+    const double rhi = TLM_FMA(-0x1p27, r, t);              // (r + w) - w
+    const double rr = rhi * rhi;
+    const double rlo = r - rhi;
+    const double hi = TLM_FMA(rr, B0, r);                   // r + rhi*rhi*B0
+    double lo = TLM_FMA(rr, B0, r - hi);
+    lo = TLM_FMA(B0 * rlo, rhi + r, lo);
+    return hi + TLM_FMA(y0, r3, lo);
+}
+
+// the table path for positive NORMAL ix = bits of x (__log_fma 0x766a1-0x7675d)
+template <typename TAB>
+TLM_HD double tlm_log_main(uint64_t ix, TAB tab)
+{
+    const double ln2hi = tlm_u2d(tlm_log_ln2[0]), ln2lo = tlm_u2d(tlm_log_ln2[1]);
+    const double A0 = tlm_u2d(tlm_log_poly[0]), A1 = tlm_u2d(tlm_log_poly[1]), A2 = tlm_u2d(tlm_log_poly[2]),
+                 A3 = tlm_u2d(tlm_log_poly[3]), A4 = tlm_u2d(tlm_log_poly[4]);
+    const uint64_t tmp = ix - 0x3fe6000000000000ull;
+    const int i = (int)(tmp >> 45) & 127;
+    const int k = (int)((int64_t)tmp >> 52);
+    const uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
+    const double invc = tlm_u2d(tab[2 * i]), logc = tlm_u2d(tab[2 * i + 1]);
+    const double z = tlm_u2d(iz);
+    const double kd = (double)k;
+    const double r = TLM_FMA(z, invc, -1.0);
+    const double w = TLM_FMA(kd, ln2hi, logc);
+    const double hi = w + r;
+    const double lo = TLM_FMA(kd, ln2lo, (w - hi) + r);
+    const double r2 = r * r;
+    const double p = TLM_FMA(TLM_FMA(r, A4, A3), r2, TLM_FMA(r, A2, A1));
+    return TLM_FMA(r * r2, p, TLM_FMA(r2, A0, lo)) + hi;
+}
+
+TLM_HD bool tlm_log_is_near1(uint64_t ix)
+{
+    return ix - 0x3fee000000000000ull < 0x3ff1090000000000ull - 0x3fee000000000000ull;
+}
+
+// log(x), any x (the special cases return what __log_fma returns; errno is not modelled)
+template <typename TAB>
+TLM_HD double tlm_log_t(double x, TAB tab)
+{
+    uint64_t ix = tlm_d2u(x);
+    const uint32_t top = (uint32_t)(ix >> 48);
+    if (tlm_log_is_near1(ix)) return ix == 0x3ff0000000000000ull ? 0.0 : tlm_log_near1(x);
+    if (top - 0x0010 >= 0x7ff0 - 0x0010) {
+        if (ix * 2 == 0) return -1.0 / 0.0 * 1.0;
+        if (ix == 0x7ff0000000000000ull) return x;
+        if ((top & 0x8000) || (top & 0x7ff0) == 0x7ff0) return (x - x) / (x - x);
+        ix = tlm_d2u(x * 0x1p52) - (52ull << 52);
+    }
+    return tlm_log_main(ix, tab);
+}
+TLM_HD double tlm_log(double x) { return tlm_log_t(x, tlm_log_tab); }
+
+// log for positive normal x without branches (both paths, one select): what a wave runs anyway when its lanes disagree
+template <typename TAB>
+TLM_HD double tlm_log_pn(double x, TAB tab)
+{
+    const uint64_t ix = tlm_d2u(x);
+    const double a = tlm_log_near1(x), b = tlm_log_main(ix, tab);
+    const double r = tlm_log_is_near1(ix) ? a : b;
+    return ix == 0x3ff0000000000000ull ? 0.0 : r;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// log10 (e_log10.c, __ieee754_log10 0x29510: baseline build, separate multiplies and adds)
+template <typename TAB>
+TLM_HD double tlm_log10_t(double x, TAB tab)
+{
+    const double ivln10 = TLM_D(0x3fdbcb7b1526e50e), log10_2hi = TLM_D(0x3fd34413509f6000),
+                 log10_2lo = TLM_D(0x3d59fef311f12b36);
+    int64_t hx = (int64_t)tlm_d2u(x);
+    int32_t k = 0;
+    if (hx < 0x0010000000000000ll) {
+        if ((hx & 0x7fffffffffffffffll) == 0) return -0x1p54 / (x < 0 ? -x : x);
+        if (hx < 0) return (x - x) / (x - x);
+        k -= 54;
+        x *= 0x1p54;
+        hx = (int64_t)tlm_d2u(x);
+    }
+    if (hx >= 0x7ff0000000000000ll) return x + x;
+    k += (int32_t)(hx >> 52) - 1023;
+    const int32_t i = (int32_t)((uint32_t)k >> 31);
+    hx = (hx & 0x000fffffffffffffll) | ((int64_t)(0x3ff - i) << 52);
+    const double y = (double)(k + i);
+    const double z = y * log10_2lo + ivln10 * tlm_log_t(tlm_u2d((uint64_t)hx), tab);
+    return z + y * log10_2hi;
+}
+TLM_HD double tlm_log10(double x) { return tlm_log10_t(x, tlm_log_tab); }
+
+// log10 for positive NORMAL x, straight-line.  The mantissa handed to log is in [0.5, 2): always normal.
+template <typename TAB>
+TLM_HD double tlm_log10_pn(double x, TAB tab)
+{
+    const double ivln10 = TLM_D(0x3fdbcb7b1526e50e), log10_2hi = TLM_D(0x3fd34413509f6000),
+                 log10_2lo = TLM_D(0x3d59fef311f12b36);
+    const uint64_t hx = tlm_d2u(x);
+    const int32_t k = (int32_t)(hx >> 52) - 1023;
+    const int32_t i = (int32_t)((uint32_t)k >> 31);
+    const uint64_t m = (hx & 0x000fffffffffffffull) | ((uint64_t)(0x3ff - i) << 52);
+    const double y = (double)(k + i);
+    const double z = y * log10_2lo + ivln10 * tlm_log_pn(tlm_u2d(m), tab);
+    return z + y * log10_2hi;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// exp (e_exp.c).  exp_inline of e_pow.c is the same code with an extra low word and a sign bias, so one body
+// serves both: tlm_exp_core(x, xtail, with_tail).  __exp_fma 0x76470, exp part of __pow_fma 0x76a05-0x76ad3.
+TLM_HD double tlm_exp_special(double tmp, uint64_t sbits, uint64_t ki)
+{   // e_exp.c specialcase(): |x| >= 512, the scale 2^(k/N) may be outside the normal range
+    if ((ki & 0x80000000u) == 0) {
+        sbits -= 1009ull << 52;
+        const double scale = tlm_u2d(sbits);
+        return 0x1p1009 * TLM_FMA(scale, tmp, scale);
+    }
+    sbits += 1022ull << 52;
+    const double scale = tlm_u2d(sbits);
+    const double st = tmp * scale;
+    double y = scale + st;
+    if ((y < 0 ? -y : y) < 1.0) {
+        const double one = y < 0 ? -1.0 : 1.0;               // exp: always +1; pow's exp_inline: sign of y
+        double lo = (scale - y) + st;
+        const double hi = one + y;
+        lo = ((one - hi) + y) + lo;
+        y = (hi + lo) - one;
+        if (y == 0.0) y = tlm_u2d(sbits & 0x8000000000000000ull);
+    }
+    return 0x1p-1022 * y;
+}
+
+template <bool WITH_TAIL>
+TLM_HD double tlm_exp_core(double x, double xtail)
+{
+    const double invln2N = tlm_u2d(tlm_exp_head[0]), shift = tlm_u2d(tlm_exp_head[1]),
+                 negln2hiN = tlm_u2d(tlm_exp_head[2]), negln2loN = tlm_u2d(tlm_exp_head[3]),
+                 C2 = tlm_u2d(tlm_exp_head[4]), C3 = tlm_u2d(tlm_exp_head[5]), C4 = tlm_u2d(tlm_exp_head[6]),
+                 C5 = tlm_u2d(tlm_exp_head[7]);
+    uint32_t abstop = (uint32_t)(tlm_d2u(x) >> 52) & 0x7ff;
+    if (abstop - 0x3c9 >= 0x3f) {
+        if ((int32_t)(abstop - 0x3c9) < 0) return 1.0 + x;                  // |x| < 2^-54
+        if (abstop >= 0x409) {                                              // |x| >= 1024
+            if (!WITH_TAIL) {
+                if (tlm_d2u(x) == 0xfff0000000000000ull) return 0.0;
+                if (abstop >= 0x7ff) return 1.0 + x;
+            }
+            return (tlm_d2u(x) >> 63) ? 0x1p-767 * 0x1p-767 : 0x1p769 * 0x1p769;
+        }
+        abstop = 0;                                                         // 512 <= |x| < 1024
+    }
+    const double kd0 = TLM_FMA(x, invln2N, shift);
+    const uint64_t ki = tlm_d2u(kd0);
+    const double kd = kd0 - shift;
+    double r = TLM_FMA(kd, negln2loN, TLM_FMA(kd, negln2hiN, x));
+    if (WITH_TAIL) r = xtail + r;
+    const int idx = 2 * (int)(ki & 127);
+    const double tail = tlm_u2d(tlm_exp_tab[idx]);
+    const uint64_t sbits = tlm_exp_tab[idx + 1] + (ki << 45);
+    const double r2 = r * r;
+    const double tmp = TLM_FMA(TLM_FMA(r, C5, C4), r2 * r2, TLM_FMA(TLM_FMA(C3, r, C2), r2, r + tail));
+    if (abstop == 0) return tlm_exp_special(tmp, sbits, ki);
+    const double scale = tlm_u2d(sbits);
+    return TLM_FMA(scale, tmp, scale);
+}
+TLM_HD double tlm_exp(double x) { return tlm_exp_core<false>(x, 0.0); }
+
+// ------------------------------------------------------------------------------------------------------------
+// pow (e_pow.c): log_inline (__pow_fma 0x768fb-0x769f8) for positive normal x.
+TLM_HD double tlm_pow_log(uint64_t ix, double *tail)
+{
+    const double ln2hi = tlm_u2d(tlm_powlog_head[0]), ln2lo = tlm_u2d(tlm_powlog_head[1]);
+    const double A0 = tlm_u2d(tlm_powlog_head[2]), A1 = tlm_u2d(tlm_powlog_head[3]), A2 = tlm_u2d(tlm_powlog_head[4]),
+                 A3 = tlm_u2d(tlm_powlog_head[5]), A4 = tlm_u2d(tlm_powlog_head[6]), A5 = tlm_u2d(tlm_powlog_head[7]),
+                 A6 = tlm_u2d(tlm_powlog_head[8]);
+    const uint64_t tmp = ix - 0x3fe6955500000000ull;
+    const int i = (int)(tmp >> 45) & 127;
+    const int k = (int)((int64_t)tmp >> 52);
+    const uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
+    const double z = tlm_u2d(iz), kd = (double)k;
+    const double invc = tlm_u2d(tlm_powlog_tab[4 * i]), logc = tlm_u2d(tlm_powlog_tab[4 * i + 2]),
+                 logctail = tlm_u2d(tlm_powlog_tab[4 * i + 3]);
+    const double r = TLM_FMA(z, invc, -1.0);
+    const double t1 = TLM_FMA(kd, ln2hi, logc);
+    const double t2 = t1 + r;
+    const double lo1 = TLM_FMA(kd, ln2lo, logctail);
+    const double lo2 = (t1 - t2) + r;
+    const double ar = A0 * r;
+    const double ar2 = r * ar;
+    const double ar3 = r * ar2;
+    const double hi = t2 + ar2;
+    const double lo3 = TLM_FMA(ar, r, -ar2);
+    const double lo4 = (t2 - hi) + ar2;
+    const double p = TLM_FMA(ar2, TLM_FMA(TLM_FMA(r, A6, A5), ar2, TLM_FMA(r, A4, A3)), TLM_FMA(r, A2, A1));
+    const double lo = TLM_FMA(ar3, p, ((lo1 + lo2) + lo3) + lo4);
+    const double y = hi + lo;
+    *tail = (hi - y) + lo;
+    return y;
+}
+
+// pow(x, y) for finite x > 0 and finite y (the reference only ever raises 10.0 and 8/3)
+TLM_HD double tlm_pow_pos(double x, double y)
+{
+    uint64_t ix = tlm_d2u(x);
+    const uint64_t iy = tlm_d2u(y);
+    const uint32_t topx = (uint32_t)(ix >> 52), topy = (uint32_t)(iy >> 52) & 0x7ff;
+    if (topy - 0x3be >= 0x43e - 0x3be) {
+        if (2 * iy == 0) return 1.0;
+        if (ix == 0x3ff0000000000000ull) return 1.0;
+        if (topy < 0x3be) return ix > 0x3ff0000000000000ull ? 1.0 + y : 1.0 - y;       // |y| < 2^-65
+        return (ix > 0x3ff0000000000000ull) == (topy < 0x800 && !(iy >> 63)) ? 0x1p769 * 0x1p769 : 0x1p-767 * 0x1p-767;
+    }
+    if (topx == 0) ix = (tlm_d2u(x * 0x1p52) & 0x7fffffffffffffffull) - (52ull << 52);
+    double lo;
+    const double hi = tlm_pow_log(ix, &lo);
+    const double ehi = y * hi;
+    const double elo = TLM_FMA(y, lo, TLM_FMA(hi, y, -ehi));
+    return tlm_exp_core<true>(ehi, elo);
+}
+
+// pow(10.0, y): log_inline(10.0) does not depend on y -- its two words are constants
+// (tests/test_libm_agree.py recomputes them with tlm_pow_log and compares).
+#define TLM_LOG10_HI 0x40026bb1bbb55516ull
+#define TLM_LOG10_LO 0xbcaf48ad48200000ull
+TLM_HD double tlm_pow10(double y)
+{
+    const uint32_t topy = (uint32_t)(tlm_d2u(y) >> 52) & 0x7ff;
+    if (topy < 0x3be) return 1.0;                             // |y| < 2^-65 (and +-0): 1.0 + y rounds to 1.0
+    const double hi = tlm_u2d(TLM_LOG10_HI), lo = tlm_u2d(TLM_LOG10_LO);
+    const double ehi = y * hi;
+    const double elo = TLM_FMA(y, lo, TLM_FMA(hi, y, -ehi));
+    return tlm_exp_core<true>(ehi, elo);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// sincos (s_sincos.c / s_sin.c; sincos 0x2fa80: the one baseline build -- no fused operation anywhere).
+// |x| < 105414350 (reduce_sincos range); the encoder's phases stay below 11.
+#define TLM_SN3 TLM_D(0xbfc5555555555515)
+#define TLM_SN5 TLM_D(0x3f811110e829872f)
+#define TLM_CS2 0.5
+#define TLM_CS4 TLM_D(0xbfa5555555555535)
+#define TLM_CS6 TLM_D(0x3f56c16bedd9e239)
+#define TLM_BIG TLM_D(0x42c8000000000000)
+
+template <typename TAB>
+TLM_HD double tlm_do_cos(double x, double dx, TAB tab)
+{   // s_sin.c do_cos
+    if (x < 0) dx = -dx;
+    const double ax = x < 0 ? -x : x;
+    const double u = TLM_BIG + ax;
+    x = (ax - (u - TLM_BIG)) + dx;
+    const double xx = x * x;
+    const double s = x + (x * xx) * (TLM_SN3 + xx * TLM_SN5);
+    const double c = xx * (TLM_CS2 + xx * (TLM_CS4 + xx * TLM_CS6));
+    const int k = (int)(uint32_t)tlm_d2u(u) * 4;
+    const double sn = tlm_u2d(tab[k]), ssn = tlm_u2d(tab[k + 1]), cs = tlm_u2d(tab[k + 2]), ccs = tlm_u2d(tab[k + 3]);
+    const double cor = ((ccs - s * ssn) - cs * c) - sn * s;
+    return cs + cor;
+}
+
+TLM_HD double tlm_taylor_sin(double xx, double x, double dx)
+{   // s_sin.c TAYLOR_SIN / POLYNOMIAL
+    const double s1 = TLM_D(0xbfc5555555555555), s2 = TLM_D(0x3f81111111110ece), s3 = TLM_D(0xbf2a01a019db08b8),
+                 s4 = TLM_D(0x3ec71de27b9a7ed9), s5 = TLM_D(0xbe5addffc2fcdf59);
+    const double p = ((((s5 * xx + s4) * xx + s3) * xx + s2) * xx) + s1;
+    const double t = (p * x - 0.5 * dx) * xx + dx;
+    return x + t;
+}
+
+template <typename TAB>
+TLM_HD double tlm_do_sin(double x, double dx, TAB tab)
+{   // s_sin.c do_sin
+    const double xold = x;
+    const double ax = x < 0 ? -x : x;
+    if (ax < 0.126) return tlm_taylor_sin(x * x, x, dx);
+    if (x <= 0) dx = -dx;
+    const double u = TLM_BIG + ax;
+    x = ax - (u - TLM_BIG);
+    const double xx = x * x;
+    const double s = x + (dx + (x * xx) * (TLM_SN3 + xx * TLM_SN5));
+    const double c = x * dx + xx * (TLM_CS2 + xx * (TLM_CS4 + xx * TLM_CS6));
+    const int k = (int)(uint32_t)tlm_d2u(u) * 4;
+    const double sn = tlm_u2d(tab[k]), ssn = tlm_u2d(tab[k + 1]), cs = tlm_u2d(tab[k + 2]), ccs = tlm_u2d(tab[k + 3]);
+    const double cor = ((ssn + s * ccs) - sn * c) + cs * s;
+    const double r = sn + cor;
+    return tlm_u2d((tlm_d2u(r) & 0x7fffffffffffffffull) | (tlm_d2u(xold) & 0x8000000000000000ull));
+}
+
+template <typename TAB>
+TLM_HD void tlm_sincos_t(double x, double *sinx, double *cosx, TAB tab)
+{
+    const double hp0 = TLM_D(0x3ff921fb54442d18), hp1 = TLM_D(0x3c91a62633145c07);
+    const uint64_t sx = tlm_d2u(x) & 0x8000000000000000ull;
+    const int32_t k = (int32_t)(tlm_d2u(x) >> 32) & 0x7fffffff;
+    if (k < 0x400368fd) {
+        if (k < 0x3e400000) { *sinx = x; *cosx = 1.0; return; }                    // |x| < 2^-27
+        if (k < 0x3feb6000) {                                                      // |x| < 0.855469
+            *sinx = tlm_do_sin(x, 0.0, tab);
+            *cosx = tlm_do_cos(x, 0.0, tab);
+            return;
+        }
+        const double ax = x < 0 ? -x : x;                                          // |x| < 2.426265
+        const double y = hp0 - ax;
+        const double a = y + hp1;
+        const double da = (y - a) + hp1;
+        const double s = tlm_do_cos(a, da, tab);
+        *sinx = tlm_u2d((tlm_d2u(s) & 0x7fffffffffffffffull) | sx);
+        *cosx = tlm_do_sin(a, da, tab);
+        return;
+    }
+    // reduce_sincos (|x| < 105414350)
+    const double hpinv = TLM_D(0x3fe45f306dc9c883), toint = TLM_D(0x4338000000000000), mp1 = TLM_D(0x3ff921fb58000000),
+                 mp2 = TLM_D(0xbe4dde973c000000), pp3 = TLM_D(0xbc8cb3b398000000), pp4 = TLM_D(0xbacd747f23e32ed7);
+    const double t = x * hpinv + toint;
+    const double xn = t - toint;
+    const int n = (int)(uint32_t)tlm_d2u(t) & 3;
+    const double y = (x - xn * mp1) - xn * mp2;
+    double t1 = xn * pp3;
+    const double t2 = y - t1;
+    double db = (y - t2) - t1;
+    t1 = xn * pp4;
+    const double b = t2 - t1;
+    db += (t2 - b) - t1;
+    // s_sincos.c: for n = 1, 2 the reduced argument is negated; odd n swaps the outputs; n & 2 negates the cosine
+    double a = b, da = db;
+    if (n == 1 || n == 2) { a = -a; da = -da; }
+    const double s = tlm_do_sin(a, da, tab), c0 = tlm_do_cos(a, da, tab);
+    const double c = (n & 2) ? -c0 : c0;
+    *sinx = (n & 1) ? c : s;
+    *cosx = (n & 1) ? s : c;
+}
+TLM_HD void tlm_sincos(double x, double *s, double *c) { tlm_sincos_t(x, s, c, tlm_sincostab); }
+
+// ------------------------------------------------------------------------------------------------------------
+// atan2 (e_atan2.c, __atan2_fma 0x78060) for finite arguments.
+template <typename TAB>
+TLM_HD double tlm_atan2_t(double y, double x, TAB cij)
+{
+    const double hpi = TLM_D(0x3ff921fb54442d18), hpi1 = TLM_D(0x3c91a62633145c07), opi = TLM_D(0x400921fb54442d18),
+                 opi1 = TLM_D(0x3ca1a62633145c07);
+    const double d3 = TLM_D(0xbfd5555555555555), d5 = TLM_D(0x3fc99999999997fd), d7 = TLM_D(0xbfc24924923f7603),
+                 d9 = TLM_D(0x3fbc71c6e5129a3b), d11 = TLM_D(0xbfb7458022b13c25), d13 = TLM_D(0x3fb375f08b31cbce);
+    const uint64_t bx = tlm_d2u(x), by = tlm_d2u(y), sy = by & 0x8000000000000000ull;
+    const int32_t ux = (int32_t)(bx >> 32), uy = (int32_t)(by >> 32);
+    if ((by << 1) == 0) return (bx >> 63) ? tlm_u2d(tlm_d2u(opi) | sy) : y;    // y = +-0 (x = +-0 included)
+    if ((bx << 1) == 0) return tlm_u2d(tlm_d2u(hpi) | sy);     // x = +-0
+    double ax = tlm_u2d(bx & 0x7fffffffffffffffull), ay = tlm_u2d(by & 0x7fffffffffffffffull);
+    const int32_t de = (uy & 0x7ff00000) - (ux & 0x7ff00000);
+    if (de >= 59768832) return tlm_u2d(tlm_d2u(hpi) | sy);
+    if (de <= -59768832) {
+        if (x > 0) return tlm_u2d(tlm_d2u(ay / ax) | sy);       // (the underflow flag is not modelled)
+        return tlm_u2d(tlm_d2u(opi) | sy);
+    }
+    if (ax < 0x1p-500 || ay < 0x1p-500) { ax *= 0x1p500; ay *= 0x1p500; }
+    if (ax > 0x1p500 || ay > 0x1p500) { ax *= 0x1p-500; ay *= 0x1p-500; }
+    double u, du, z;
+    const bool ylx = ay < ax;
+    {
+        const double num = ylx ? ay : ax, den = ylx ? ax : ay;
+        u = num / den;
+        const double v = den * u;
+        const double vv = TLM_FMA(den, u, -v);                  // EMULV
+        du = ((num - v) - vv) / den;
+    }
+    const bool small = u < 0.0625;
+    double zz = 0, v = 0;
+    if (small) {
+        v = u * u;
+        zz = TLM_FMA(TLM_FMA(TLM_FMA(TLM_FMA(TLM_FMA(d13, v, d11), v, d9), v, d7), v, d5), v, d3);
+    } else {
+        const int i = (int)(TLM_FMA(u, 256.0, 0x1p52) - 0x1p52) - 16;
+        // row i of cij: {x_i, atan(x_i), c2..c6}
+        const double c0 = tlm_u2d(cij[7 * i]);
+        if (x > 0 && ylx) {                                     // (i): EADD(u - c0, du) keeps the low word
+            const double t3 = u - c0;
+            const double w = t3 + du;
+            const double at3 = t3 < 0 ? -t3 : t3, adu = du < 0 ? -du : du;
+            const double dv = at3 > adu ? (t3 - w) + du : (du - w) + t3;
+            const double t1 = tlm_u2d(cij[7 * i + 1]), t2 = tlm_u2d(cij[7 * i + 2]);
+            const double p = TLM_FMA(TLM_FMA(TLM_FMA(tlm_u2d(cij[7 * i + 6]), w, tlm_u2d(cij[7 * i + 5])), w,
+                                             tlm_u2d(cij[7 * i + 4])), w, tlm_u2d(cij[7 * i + 3]));
+            zz = TLM_FMA(w, t2, TLM_FMA(dv, t2, (w * w) * p));
+            z = t1 + zz;
+            return tlm_u2d((tlm_d2u(z) & 0x7fffffffffffffffull) | sy);
+        }
+        v = (u - c0) + du;
+        const double p = TLM_FMA(TLM_FMA(TLM_FMA(TLM_FMA(tlm_u2d(cij[7 * i + 6]), v, tlm_u2d(cij[7 * i + 5])), v,
+                                                 tlm_u2d(cij[7 * i + 4])), v, tlm_u2d(cij[7 * i + 3])), v,
+                                 tlm_u2d(cij[7 * i + 2]));
+        const double a1 = tlm_u2d(cij[7 * i + 1]);
+        if (x > 0) { zz = TLM_FMA(-v, p, hpi1); z = (hpi - a1) + zz; }          // (ii)
+        else if (!ylx && ax < ay) { zz = TLM_FMA(v, p, hpi1); z = (hpi + a1) + zz; }   // (iii)
+        else { zz = TLM_FMA(-v, p, opi1); z = (opi - a1) + zz; }                // (iv)
+        return tlm_u2d((tlm_d2u(z) & 0x7fffffffffffffffull) | sy);
+    }
+    const double uv = u * v;
+    if (x > 0) {
+        if (ylx) z = u + TLM_FMA(uv, zz, du);                                   // (i)
+        else {                                                                  // (ii): ESUB(hpi, u)
+            const double t2 = hpi - u;
+            const double cor = (hpi - t2) - u;
+            z = ((((cor + hpi1) - du) - uv * zz)) + t2;
+        }
+    } else if (!ylx && ax < ay) {                                               // (iii): EADD(hpi, u)
+        const double t2 = hpi + u;
+        const double cor = (hpi - t2) + u;
+        z = (((cor + hpi1) + du) + uv * zz) + t2;
+    } else {                                                                    // (iv): ESUB(opi, u)
+        const double t2 = opi - u;
+        const double cor = (opi - t2) - u;
+        z = (((cor + opi1) - du) - uv * zz) + t2;
+    }
+    return tlm_u2d((tlm_d2u(z) & 0x7fffffffffffffffull) | sy);
+}
+TLM_HD double tlm_atan2(double y, double x) { return tlm_atan2_t(y, x, tlm_atan_cij); }
