@@ -18,7 +18,7 @@
 // the reference's order; lanes are only ever assigned whole outputs, never partial sums.
 #pragma once
 #include "mp2_types.h"
-#include "tl_math.h"
+#include "tl_libm.h"
 #include <math.h>
 #include <stddef.h>
 
@@ -685,14 +685,13 @@ TL_FN void tl_psy_spectrum(TlPsyLds &w, const TlTables *TL_RESTRICT T, const TlP
 
 // power density in dB of one line (psycho_1.c:241-248, psycho_3.c:152-160), straight-line so that several lines' logarithms
 // (long dependent chains) can be in flight together
-// The logarithm is the fdlibm form (tl_math.h), which agrees with glibc's log10 bit for bit on 99.1 % of arguments.  That
-// matters: on degenerate spectra (a lone impulse: hundreds of lines of nearly equal level) the tone tests and the allocation
-// compare values that differ in the last bits, and a table-driven logarithm that was 3 x cheaper but matched glibc on only
-// 95.8 % of arguments changed frames of 10 % of such streams at 384 kbps (GPU soak, round 2) -- it was taken out again.
+// The logarithm is glibc 2.35's own (tl_libm.h: table-driven log, no division, then e_log10.c's recombination) -- bit-equal to
+// the reference's libm by construction.  That matters: on degenerate spectra (a lone impulse: hundreds of lines of nearly
+// equal level) the tone tests and the allocation compare values that differ in the last bits (GPU soak, round 2).
 TL_FN double tl_power_db(double e)
 {
     const bool tiny = e < 1E-20;
-    const double v = 10 * tl_log10_pn(TL_SELECT(tiny, 1.0, e)) + TL_POWERNORM;
+    const double v = 10 * tlm_log10_pn(TL_SELECT(tiny, 1.0, e), tlm_log_tab) + TL_POWERNORM;
     return TL_SELECT(tiny, -200.0 + TL_POWERNORM, v);
 }
 TL_FN int tl_run_psy1(int c) { return (c < 3 || c > 500) ? 0 : c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 12; }   // psycho_1.c:289-298
@@ -794,7 +793,7 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
 #pragma unroll
 #endif
         for (int j = 0; j < 16; j++) sum += 1073741824 * e[j];
-        const double spk = 10.0 * tl_log10_pn(sum);
+        const double spk = 10.0 * tlm_log10_pn(sum, tlm_log_tab);
         L(rec)[ch] = spk;                                           // final as it is: straight to the record (nothing to park)
     } else if (lane < 32) L(rec)[ch] = 0.0;
     TL_LANES_END
@@ -1048,7 +1047,7 @@ TL_FN void tl_psy1_centres(TlPsyLds &w, const TlConfig *TL_RESTRICT C, int nband
         int centre;
         if (sum <= TL_DBMIN) centre = (hi + lo) / 2;
         else {
-            double index = weight * tl_pow10(-0.1 * sum);
+            double index = weight * tlm_pow10_sl(-0.1 * sum);
             centre = lo + (int)(index * (double)(hi - lo));
         }
         centre = centre < 1 ? 1 : centre > 510 ? 510 : centre;     // out-of-range only on non-finite input (UB in the reference)
@@ -1927,20 +1926,20 @@ TL_FN void tl_psy2(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
                 const double r_o2 = S->r[ch][old][jn], r_n2 = S->r[ch][nw][jn], p_o2 = S->phi[ch][old][jn], p_n2 = S->phi[ch][nw][jn];
                 double e, phi;
                 if (j == 0) { e = L(xa) * L(xa); phi = 0.0; }
-                else if (j == 512) { e = L(xa) * L(xa); phi = tl_atan2(0.0, L(xa)); }
+                else if (j == 512) { e = L(xa) * L(xa); phi = tlm_atan2_sl(0.0, L(xa), tlm_atan_cij); }
                 else {
                     const double a = L(xa), b = L(xb);
                     e = (a * a + b * b) / 2.0;
                     if (e < 0.0005) { e = 0.0005; phi = 0; }
-                    else phi = tl_atan2(-a, b) + 3.14159265358979 / 4;
+                    else phi = tlm_atan2_sl(-a, b, tlm_atan_cij) + 3.14159265358979 / 4;
                 }
                 const double r_prime = 2.0 * L(r_o) - L(r_n);
                 const double phi_prime = 2.0 * L(p_o) - L(p_n);
                 const double rn = sqrt(e);
                 S->r[ch][nw][j] = rn; S->phi[ch][nw][j] = phi;
                 double sp, cp, spp, cpp;
-                tl_sincos(phi, &sp, &cp);
-                tl_sincos(phi_prime, &spp, &cpp);
+                tlm_sincos_sl(phi, &sp, &cp, tlm_sincostab);
+                tlm_sincos_sl(phi_prime, &spp, &cpp, tlm_sincostab);
                 const double t1 = rn * cp - r_prime * cpp;
                 const double t2 = rn * sp - r_prime * spp;
                 const double t3 = rn + fabs(r_prime);
@@ -1998,10 +1997,10 @@ TL_FN void tl_psy2(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
             }
             double cb = e != 0 ? c / e : 0;
             if (cb < .05) cb = 0.05; else if (cb > .5) cb = 0.5;
-            const double tb = -0.434294482 * tl_log(cb) - 0.301029996;
+            const double tb = -0.434294482 * tlm_log_pn(cb, tlm_log_tab) - 0.301029996;
             double bc = P->tmn[lane] * tb + 5.5 * (1.0 - tb);
             bc = bc > P->bmaxk[lane] ? bc : P->bmaxk[lane];
-            bc = tl_exp(-bc * 0.2302585093);
+            bc = tlm_exp_sl<false>(-bc * 0.2302585093, 0.0);
             ecb[lane] = e;
             nb[lane] = P->den[lane] != 0 ? e * bc / P->den[lane] : 0;
         }
@@ -2026,7 +2025,7 @@ TL_FN void tl_psy2(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
                 sum_energy += energy[j + k];
             }
             double snr = lane < 13 ? sum_energy / (minthres * 17.0) : sum_energy / minthres;
-            snr = 4.342944819 * tl_log(snr);
+            snr = 4.342944819 * tlm_log_pn(snr, tlm_log_tab);
             if (pass == 0) L(snr0) = snr;
             else smr_out[lane] = L(snr0) > snr ? L(snr0) : snr;
         }

@@ -43,6 +43,9 @@
 
 TLM_HD uint64_t tlm_d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
 TLM_HD double tlm_u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+#define TL_HD TLM_HD
+TLM_HD uint64_t tl_d2u(double d) { return tlm_d2u(d); }       // the names the kernels use
+TLM_HD double tl_u2d(uint64_t u) { return tlm_u2d(u); }
 #define TLM_FMA(a, b, c) __builtin_fma((a), (b), (c))
 #define TLM_D(bits) tlm_u2d(bits##ull)
 
@@ -478,3 +481,171 @@ TLM_HD double tlm_atan2_t(double y, double x, TAB cij)
     return tlm_u2d((tlm_d2u(z) & 0x7fffffffffffffffull) | sy);
 }
 TLM_HD double tlm_atan2(double y, double x) { return tlm_atan2_t(y, x, tlm_atan_cij); }
+
+// ------------------------------------------------------------------------------------------------------------
+// Straight-line forms for the device: the lanes of a wave are spread over every branch of the routines above, so
+// the wave executes all of them anyway; here the branches' COMMON work is done once and the results are selected.
+// Same operations on the selected path, hence the same bits (tools/libm_agree.cpp checks these forms as well).
+
+// sincos for |x| < 105414350.  All four argument ranges end in do_sin(a, da) and do_cos(a, da) of some reduced
+// argument; the ranges differ in (a, da), in which output takes which value and in the signs.
+template <typename TAB>
+TLM_HD void tlm_sincos_sl(double x, double *sinx, double *cosx, TAB tab)
+{
+    const double hp0 = TLM_D(0x3ff921fb54442d18), hp1 = TLM_D(0x3c91a62633145c07);
+    const double hpinv = TLM_D(0x3fe45f306dc9c883), toint = TLM_D(0x4338000000000000), mp1 = TLM_D(0x3ff921fb58000000),
+                 mp2 = TLM_D(0xbe4dde973c000000), pp3 = TLM_D(0xbc8cb3b398000000), pp4 = TLM_D(0xbacd747f23e32ed7);
+    const uint64_t bx = tlm_d2u(x), sx = bx & 0x8000000000000000ull;
+    const int32_t k = (int32_t)(bx >> 32) & 0x7fffffff;
+    const double ax = tlm_u2d(bx ^ sx);
+    const bool p1 = k < 0x3feb6000, p2 = !p1 && k < 0x400368fd;
+    // range 3: reduce_sincos
+    const double t = x * hpinv + toint;
+    const double xn = t - toint;
+    const int n = (int)(uint32_t)tlm_d2u(t) & 3;
+    const double y = (x - xn * mp1) - xn * mp2;
+    const double t1 = xn * pp3;
+    const double t2 = y - t1;
+    const double t1b = xn * pp4;
+    const double b = t2 - t1b;
+    const double db = ((y - t2) - t1) + ((t2 - b) - t1b);
+    const uint64_t flip = (n == 1 || n == 2) ? 0x8000000000000000ull : 0;
+    // range 2: pi/2 - |x|
+    const double yy = hp0 - ax;
+    const double a2 = yy + hp1;
+    const double da2 = (yy - a2) + hp1;
+    const double a = p1 ? x : p2 ? a2 : tlm_u2d(tlm_d2u(b) ^ flip);
+    const double da = p1 ? 0.0 : p2 ? da2 : tlm_u2d(tlm_d2u(db) ^ flip);
+    // do_sin / do_cos on (a, da): shared table row and first reduction
+    const uint64_t sa = tlm_d2u(a) & 0x8000000000000000ull;
+    const double aa = tlm_u2d(tlm_d2u(a) ^ sa);
+    const double u = TLM_BIG + aa;
+    const double xr = aa - (u - TLM_BIG);
+    const int row = (int)(uint32_t)tlm_d2u(u) * 4;
+    const double sn = tlm_u2d(tab[row]), ssn = tlm_u2d(tab[row + 1]), cs = tlm_u2d(tab[row + 2]), ccs = tlm_u2d(tab[row + 3]);
+    // do_cos: dx = a < 0 ? -da : da
+    double cosv;
+    {
+        const double dx = tlm_u2d(tlm_d2u(da) ^ (a < 0 ? 0x8000000000000000ull : 0));
+        const double xc = xr + dx;
+        const double xx = xc * xc;
+        const double s = xc + (xc * xx) * (TLM_SN3 + xx * TLM_SN5);
+        const double c = xx * (TLM_CS2 + xx * (TLM_CS4 + xx * TLM_CS6));
+        cosv = cs + (((ccs - s * ssn) - cs * c) - sn * s);
+    }
+    // do_sin: Taylor below 0.126, table above; dx = a <= 0 ? -da : da
+    double sinv;
+    {
+        const double ty = tlm_taylor_sin(a * a, a, da);
+        const double dx = tlm_u2d(tlm_d2u(da) ^ (a <= 0 ? 0x8000000000000000ull : 0));
+        const double xx = xr * xr;
+        const double s = xr + (dx + (xr * xx) * (TLM_SN3 + xx * TLM_SN5));
+        const double c = xr * dx + xx * (TLM_CS2 + xx * (TLM_CS4 + xx * TLM_CS6));
+        const double r = sn + (((ssn + s * ccs) - sn * c) + cs * s);
+        const double tb = tlm_u2d((tlm_d2u(r) & 0x7fffffffffffffffull) | sa);
+        sinv = aa < 0.126 ? ty : tb;
+    }
+    // who gets what
+    const double c3 = (n & 2) ? -cosv : cosv;                                        // range 3
+    double so = p1 ? sinv : p2 ? tlm_u2d((tlm_d2u(cosv) & 0x7fffffffffffffffull) | sx) : (n & 1) ? c3 : sinv;
+    double co = p1 ? cosv : p2 ? sinv : (n & 1) ? sinv : c3;
+    const bool tiny = k < 0x3e400000;
+    *sinx = tiny ? x : so;
+    *cosx = tiny ? 1.0 : co;
+}
+
+// atan2 for finite arguments: one quotient / remainder pair, both evaluation forms (polynomial below 1/16, table row
+// above), the four quadrant combinations selected at the end.
+template <typename TAB>
+TLM_HD double tlm_atan2_sl(double y, double x, TAB cij)
+{
+    const double hpi = TLM_D(0x3ff921fb54442d18), hpi1 = TLM_D(0x3c91a62633145c07), opi = TLM_D(0x400921fb54442d18),
+                 opi1 = TLM_D(0x3ca1a62633145c07);
+    const double d3 = TLM_D(0xbfd5555555555555), d5 = TLM_D(0x3fc99999999997fd), d7 = TLM_D(0xbfc24924923f7603),
+                 d9 = TLM_D(0x3fbc71c6e5129a3b), d11 = TLM_D(0xbfb7458022b13c25), d13 = TLM_D(0x3fb375f08b31cbce);
+    const uint64_t bx = tlm_d2u(x), by = tlm_d2u(y), sy = by & 0x8000000000000000ull;
+    const int32_t ux = (int32_t)(bx >> 32), uy = (int32_t)(by >> 32);
+    const bool xpos = !(bx >> 63);
+    double ax = tlm_u2d(bx & 0x7fffffffffffffffull), ay = tlm_u2d(by & 0x7fffffffffffffffull);
+    const double ax0 = ax, ay0 = ay;
+    const int32_t de = (uy & 0x7ff00000) - (ux & 0x7ff00000);
+    const bool dn = ax < 0x1p-500 || ay < 0x1p-500;
+    ax = dn ? ax * 0x1p500 : ax; ay = dn ? ay * 0x1p500 : ay;
+    const bool up = ax > 0x1p500 || ay > 0x1p500;
+    ax = up ? ax * 0x1p-500 : ax; ay = up ? ay * 0x1p-500 : ay;
+    const bool ylx = ay < ax;
+    const double num = ylx ? ay : ax, den = ylx ? ax : ay;
+    const double u = num / den;
+    const double pv = den * u;
+    const double du = ((num - pv) - TLM_FMA(den, u, -pv)) / den;
+    // form A: u < 1/16
+    const double v = u * u;
+    const double pa = TLM_FMA(TLM_FMA(TLM_FMA(TLM_FMA(TLM_FMA(d13, v, d11), v, d9), v, d7), v, d5), v, d3);
+    const double uv = u * v;
+    // form B: table row
+    int i = (int)(TLM_FMA(u, 256.0, 0x1p52) - 0x1p52) - 16;
+    i = i < 0 ? 0 : i > 240 ? 240 : i;                                    // (only form A's lanes can leave the table)
+    const double c0 = tlm_u2d(cij[7 * i]), c1 = tlm_u2d(cij[7 * i + 1]), c2 = tlm_u2d(cij[7 * i + 2]), c3 = tlm_u2d(cij[7 * i + 3]),
+                 c4 = tlm_u2d(cij[7 * i + 4]), c5 = tlm_u2d(cij[7 * i + 5]), c6 = tlm_u2d(cij[7 * i + 6]);
+    const double t3 = u - c0;
+    const double w = t3 + du;
+    const double p3 = TLM_FMA(TLM_FMA(TLM_FMA(c6, w, c5), w, c4), w, c3);
+    const double p2 = TLM_FMA(p3, w, c2);
+    const bool q1 = xpos && ylx, q2 = xpos && !ylx, q3 = !xpos && !ylx && ax < ay;      // else (iv)
+    double zA, zB;
+    {   // (i)
+        const double at3 = t3 < 0 ? -t3 : t3, adu = du < 0 ? -du : du;
+        const double dv = at3 > adu ? (t3 - w) + du : (du - w) + t3;
+        const double zB1 = c1 + TLM_FMA(w, c2, TLM_FMA(dv, c2, (w * w) * p3));
+        const double zA1 = u + TLM_FMA(uv, pa, du);
+        // (ii), (iii), (iv): pi/2 -, pi/2 +, pi - ; the three share their shape: base (-/+) u, base1 (-/+) stuff
+        const double base = q3 || q2 ? hpi : opi, base1 = q3 || q2 ? hpi1 : opi1;
+        const uint64_t sg = q3 ? 0 : 0x8000000000000000ull;              // (iii) adds, (ii) and (iv) subtract
+        const double su = tlm_u2d(tlm_d2u(u) ^ sg), sdu = tlm_u2d(tlm_d2u(du) ^ sg);
+        const double t2 = base + su;
+        const double cor = (base - t2) + su;
+        const double zz = uv * pa;
+        const double zA2 = (((cor + base1) + sdu) + tlm_u2d(tlm_d2u(zz) ^ sg)) + t2;
+        const double zB2 = (base + tlm_u2d(tlm_d2u(c1) ^ sg)) + TLM_FMA(tlm_u2d(tlm_d2u(w) ^ sg), p2, base1);
+        zA = q1 ? zA1 : zA2;
+        zB = q1 ? zB1 : zB2;
+    }
+    double z = u < 0.0625 ? zA : zB;
+    // extreme ratios and zeros
+    z = de <= -59768832 ? (xpos ? ay0 / ax0 : opi) : z;
+    z = de >= 59768832 ? hpi : z;
+    z = (bx << 1) == 0 ? hpi : z;
+    z = (by << 1) == 0 ? (xpos ? 0.0 : opi) : z;
+    return tlm_u2d((tlm_d2u(z) & 0x7fffffffffffffffull) | sy);
+}
+
+// exp / pow(10, y) for results inside the normal range (|x| < 512 resp. |y * ln 10| < 512), no branches.
+template <bool WITH_TAIL>
+TLM_HD double tlm_exp_sl(double x, double xtail)
+{
+    const double invln2N = tlm_u2d(tlm_exp_head[0]), shift = tlm_u2d(tlm_exp_head[1]),
+                 negln2hiN = tlm_u2d(tlm_exp_head[2]), negln2loN = tlm_u2d(tlm_exp_head[3]),
+                 C2 = tlm_u2d(tlm_exp_head[4]), C3 = tlm_u2d(tlm_exp_head[5]), C4 = tlm_u2d(tlm_exp_head[6]),
+                 C5 = tlm_u2d(tlm_exp_head[7]);
+    const uint32_t abstop = (uint32_t)(tlm_d2u(x) >> 52) & 0x7ff;
+    const double kd0 = TLM_FMA(x, invln2N, shift);
+    const uint64_t ki = tlm_d2u(kd0);
+    const double kd = kd0 - shift;
+    double r = TLM_FMA(kd, negln2loN, TLM_FMA(kd, negln2hiN, x));
+    if (WITH_TAIL) r = xtail + r;
+    const int idx = 2 * (int)(ki & 127);
+    const double tail = tlm_u2d(tlm_exp_tab[idx]);
+    const double scale = tlm_u2d(tlm_exp_tab[idx + 1] + (ki << 45));
+    const double r2 = r * r;
+    const double tmp = TLM_FMA(TLM_FMA(r, C5, C4), r2 * r2, TLM_FMA(TLM_FMA(C3, r, C2), r2, r + tail));
+    const double res = TLM_FMA(scale, tmp, scale);
+    return abstop < 0x3c9 ? 1.0 + x : res;                          // |x| < 2^-54
+}
+TLM_HD double tlm_pow10_sl(double y)
+{
+    const double hi = tlm_u2d(TLM_LOG10_HI), lo = tlm_u2d(TLM_LOG10_LO);
+    const double ehi = y * hi;
+    const double elo = TLM_FMA(y, lo, TLM_FMA(hi, y, -ehi));
+    const double res = tlm_exp_sl<true>(ehi, elo);
+    return ((uint32_t)(tlm_d2u(y) >> 52) & 0x7ff) < 0x3be ? 1.0 : res;      // |y| < 2^-65, +-0
+}

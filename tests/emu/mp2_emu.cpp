@@ -158,9 +158,9 @@ int emu_edi_pft(const uint8_t *af, const int32_t *af_len, int nframes, int nstre
 }
 int emu_sizeof_taps(void) { return (int)sizeof(TlTaps); }
 int emu_sizeof_lds(void) { return (int)sizeof(TlMainLds); }
-double emu_log10(double x) { return tl_log10(x); }
-double emu_log10_pn(double x) { return tl_log10_pn(x); }
-double emu_pow10(double x) { return tl_pow10(x); }
+double emu_log10(double x) { return tlm_log10(x); }
+double emu_log10_pn(double x) { return tlm_log10_pn(x, tlm_log_tab); }
+double emu_pow10(double x) { return tlm_pow10_sl(x); }
 // the allocation code counts instead of searching: needs every allocation line's SNR column to be non-decreasing
 int emu_snr_monotone(void)
 {

@@ -1,0 +1,39 @@
+"""csrc/tl_libm.h (the device's log / log10 / exp / pow / sincos / atan2) against THIS machine's libm, bit for bit.
+
+The oracle is the reference linked against the host's glibc, so these functions are part of what "the reference's result"
+means (third-party arithmetic).  tools/libm_agree.cpp draws arguments over the encoder's ranges, every
+binade and the branch points of each routine; the long run (>= 1e8 arguments per function) is kept in profiles/, the suite
+runs 2 M per function.  A libm other than glibc 2.35's dbl-64 routines on an FMA machine fails here -- which is the point:
+it would also change the oracle's bytes on degenerate signals."""
+import subprocess
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_tl_libm_equals_host_libm(tmp_path):
+    exe = tmp_path / "libm_agree"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-pthread", "-I", str(ROOT / "odr-audioenc_amd" / "csrc"),
+                    str(ROOT / "tools" / "libm_agree.cpp"), "-o", str(exe), "-lm"], check=True)
+    r = subprocess.run([str(exe), "2", "4", "7"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.count("0 differ") >= 14, r.stdout
+
+
+def test_tables_are_this_libms_tables():
+    """tl_libm_tables.inc is what tools/extract_libm_tables.py reads out of the libm.so.6 the oracle links against."""
+    import hashlib
+    import re
+    import struct
+    inc = (ROOT / "odr-audioenc_amd" / "csrc" / "tl_libm_tables.inc").read_text()
+    libm = Path("/lib/x86_64-linux-gnu/libm.so.6").read_bytes()
+    if hashlib.sha256(libm).hexdigest() not in inc:
+        import pytest
+        pytest.skip("another libm build: the agreement test above is the authority")
+    found = re.findall(r"libm\.so\.6 \.rodata (0x[0-9a-f]+)\nTLM_TABLE_QUAL uint64_t (\w+)\[(\d+)\]", inc)
+    assert len(found) == 10
+    for addr, name, n in ((int(a, 16), nm, int(k)) for a, nm, k in found):
+        body = inc[inc.index(name + "["):]
+        body = body[body.index("{") + 1: body.index("}")]
+        words = [int(w, 16) for w in re.findall(r"0x[0-9a-f]{16}", body)]
+        assert len(words) == n and tuple(words) == struct.unpack_from(f"<{n}Q", libm, addr), name

@@ -50,7 +50,9 @@ struct Tally {
 };
 
 static Tally T_log{"log"}, T_log10{"log10"}, T_log10pn{"log10 (straight-line form, positive normal)"}, T_exp{"exp"},
-    T_pow10{"pow(10, y)"}, T_pow{"pow(x > 0, y)"}, T_sin{"sincos: sin"}, T_cos{"sincos: cos"}, T_atan2{"atan2"};
+    T_pow10{"pow(10, y)"}, T_pow{"pow(x > 0, y)"}, T_sin{"sincos: sin"}, T_cos{"sincos: cos"}, T_atan2{"atan2"},
+    T_sinsl{"sincos, straight-line form: sin"}, T_cossl{"sincos, straight-line form: cos"}, T_atan2sl{"atan2, straight-line form"}, T_expsl{"exp, straight-line form (|x| < 512)"},
+    T_pow10sl{"pow(10, y), straight-line form (|y| < 222)"};
 
 static void chk1(Tally &t, double x, double got, double want)
 {
@@ -88,6 +90,7 @@ static void worker(int id, uint64_t per_fn, uint64_t seed)
         default: x = r.uniform(-745.2, -707.0); break;                               // subnormal results
         }
         chk1(T_exp, x, tlm_exp(x), exp(x));
+        if (fabs(x) < 512) chk1(T_expsl, x, tlm_exp_sl<false>(x, 0.0), exp(x));
         // ---- pow(10, y), pow(x, y)
         switch (i % 5) {
         case 0: x = r.uniform(-330, 310); break;
@@ -97,6 +100,7 @@ static void worker(int id, uint64_t per_fn, uint64_t seed)
         default: x = -0.1 * (double)(int64_t)(r.next() % 4001 - 2000) * 0.1; break;
         }
         chk1(T_pow10, x, tlm_pow10(x), pow(10.0, x));
+        if (fabs(x) < 222) chk1(T_pow10sl, x, tlm_pow10_sl(x), pow(10.0, x));
         {
             const double bx = (i & 1) ? r.binade(-300, 300) : r.uniform(0.01, 100.0);
             const double lim = 700.0 / fabs(log(bx) + 1e-300);
@@ -120,6 +124,9 @@ static void worker(int id, uint64_t per_fn, uint64_t seed)
             sincos(x, &s0, &c0);
             chk1(T_sin, x, s, s0);
             chk1(T_cos, x, c, c0);
+            tlm_sincos_sl(x, &s, &c, tlm_sincostab);
+            chk1(T_sinsl, x, s, s0);
+            chk1(T_cossl, x, c, c0);
         }
         // ---- atan2
         {
@@ -138,6 +145,9 @@ static void worker(int id, uint64_t per_fn, uint64_t seed)
             T_atan2.n++;
             const double got = tlm_atan2(y, xx), want = atan2(y, xx);
             if (!same(got, want)) T_atan2.miss("y=%a x=%a got %a want %a", y, xx, got, want);
+            T_atan2sl.n++;
+            const double got2 = tlm_atan2_sl(y, xx, tlm_atan_cij);
+            if (!same(got2, want)) T_atan2sl.miss("y=%a x=%a got %a want %a", y, xx, got2, want);
         }
     }
 }
@@ -163,7 +173,7 @@ int main(int argc, char **argv)
     for (unsigned t = 0; t < nthreads; t++) th.emplace_back(worker, (int)t, per, seed);
     for (auto &t : th) t.join();
     uint64_t bad = 0;
-    for (Tally *t : {&T_log, &T_log10, &T_log10pn, &T_exp, &T_pow10, &T_pow, &T_sin, &T_cos, &T_atan2}) {
+    for (Tally *t : {&T_log, &T_log10, &T_log10pn, &T_exp, &T_pow10, &T_pow, &T_sin, &T_cos, &T_atan2, &T_sinsl, &T_cossl, &T_atan2sl, &T_expsl, &T_pow10sl}) {
         printf("%-48s %12llu arguments  %llu differ (%.4f %% bit-equal)\n", t->name, (unsigned long long)t->n.load(),
                (unsigned long long)t->bad.load(), 100.0 * (double)(t->n - t->bad) / (double)t->n);
         for (auto &e : t->examples) printf("    %s\n", e.c_str());
