@@ -165,6 +165,41 @@ print(n / dt)
                       f"{'libtoolame-dab compiled from the reference sources' if kind == 'reference' else 'oracle/mp2_oracle.c'}, gcc -O2, 1 thread"}
 
 
+def committed_counters(S, F, psy, mode):
+    """HBM bytes per launch (PMC: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes) and the SQ issue counters of THIS
+    workload, from the files the last profiling round committed (profiles/LATEST names the tag; tools/profile_round3.sh): quoted
+    only when (streams, frames per step, psy model, mode) match; never measured inside a bench run."""
+    traffic, source, valu = None, None, None
+    try:
+        tag = (ROOT / "profiles" / "LATEST").read_text().split()[0]
+    except Exception:  # noqa: BLE001
+        return None, None, None
+    for f in sorted((ROOT / "profiles").glob(f"{tag}_pmc_traffic*.json")):
+        try:
+            pm = json.load(open(f))
+            wl = pm["workload"]
+            if (wl["streams"], wl["frames_per_step"], wl["psy"], wl["mode"]) == (S, F, psy, mode):
+                traffic = pm["hbm_bytes_per_launch"]
+                source = (f"profiles/{f.name} (committed rocprofv3 --pmc measurement of this workload, summed over the launch's kernels: "
+                          + ", ".join(f"{k} {v['hbm_bytes_per_launch']}" for k, v in pm["kernels"].items()) + "; not measured in this run)")
+                break
+        except Exception:  # noqa: BLE001
+            continue
+    for f in sorted((ROOT / "profiles").glob(f"{tag}_sq_counters*.json")):
+        try:
+            sq = json.load(open(f))
+            wl = sq["workload"]
+            if (wl["streams"], wl["frames_per_step"], wl["psy"], wl["mode"]) == (S, F, psy, mode):
+                valu = {k: {"valu_busy_per_simd": c["derived"]["valu_busy_per_simd"], "waves_per_simd": c["derived"]["waves_per_simd"],
+                            "wave_cycles_waiting": c["derived"]["waiting_share"], "valu_instructions_per_frame": c["derived"]["per_frame"]["valu"]}
+                        for k, c in sq["kernels"].items()}
+                valu["source"] = f"profiles/{f.name} (committed rocprofv3 --pmc SQ counters of this workload, not this run)"
+                break
+        except Exception:  # noqa: BLE001
+            continue
+    return traffic, source, valu
+
+
 class GpuRun:
     """One workload resident on this rank's GPU: two alternating PCM buffers (frames [0,F) and [F,2F) of every stream), the
     batch, the output buffer.  step(i) = one launch."""
@@ -178,6 +213,10 @@ class GpuRun:
         for k in range(nd, S, nd):                    # secondary workloads only: the signals repeat every `distinct` streams
             host[:, k:k + nd] = host[:, :min(nd, S - k)]
         self.pcm = [torch.from_numpy(host[:F].copy()).cuda(), torch.from_numpy(host[F:].copy()).cuda()]
+        self.check_streams = sorted({0, S - 1})
+        self.check_pcm = {k: host[:, k].copy() for k in self.check_streams}      # the 2F frames stream k loops over
+        self.launches = 0
+        self.cfg = (mode, psy)
         self.batch = M.Batch([M.StreamConfig(samplerate=FS, mode=mode, bitrate=KBPS, psy_model=psy)] * S, device=local_rank)
         self.out = torch.zeros((F, S, self.batch.out_stride), dtype=torch.uint8, device="cuda")
         self.stream = torch.cuda.current_stream()
@@ -185,7 +224,9 @@ class GpuRun:
         self.cdev = "cuda"
 
     def step(self, i):
+        assert (i & 1) == (self.launches & 1)          # the two PCM buffers alternate without a gap: each stream sees one looped signal
         self.batch.encode_device(self.pcm[i & 1].data_ptr(), self.F, self.out.data_ptr(), stream=self.stream.cuda_stream)
+        self.launches += 1
 
     def timed(self, dist, shard, warmup, steps):
         """-> (max-over-ranks seconds, own seconds, mean kernel ms from HIP events on the launch stream)"""
@@ -202,12 +243,35 @@ class GpuRun:
 
         elapsed, own = shard.timed_region_detail(dist, run, device_sync=torch.cuda.synchronize, device=self.cdev)
         kernel_ms = float(self.np.mean([a.elapsed_time(b) for a, b in evs]))
-        self.stage_ms = self.batch.last_stage_ms()      # (psy kernel, encode + finish kernels) of the last launch, models 1/3
+        self.stage_ms = self.batch.last_stage_ms()      # (psy-2 kernel, encode + finish kernels) of the last launch: batches of models 2/4 only
         return elapsed, own, kernel_ms
 
-    def check(self):
-        chk = self.out[min(1, self.F - 1), :4].cpu().numpy()          # the frames are real frames (sync word), never timed
+    def check(self, max_oracle_frames=12000):
+        """After the timed region: what the LAST timed launch wrote is what the reference writes.  The oracle (TEST-ONLY CPU
+        restatement, pinned against the compiled reference) encodes the same looped PCM of the first and the last stream from the
+        first warm-up launch on and its bytes for the last launch's frames are compared with the output buffer (slot f of a launch
+        holds the frame that became final during input frame f: global frame index (launches - 1) * F + f - 1)."""
+        import oraclelib as O
+        chk = self.out[min(1, self.F - 1), :4].cpu().numpy()
         assert all(bytes(chk[s, :2]) == b"\xff\xfc" for s in range(min(4, self.S))), "output is not an MPEG audio frame"
+        total = self.launches * self.F
+        if total > max_oracle_frames:
+            return {"checked": False, "why": f"{total} frames per stream since the first launch: beyond the oracle budget of this check"}
+        mode, psy = self.cfg
+        fb = self.batch.frame_bytes[0]
+        out = self.out.cpu().numpy()
+        for k in self.check_streams:
+            loop = self.check_pcm[k]
+            pcm = self.np.concatenate([loop] * (self.launches // 2 + 1))[:total]
+            ref = O.oracle_stream(pcm, samplerate=FS, mode=mode, kbps=KBPS, psy=psy)[0]
+            first = (self.launches - 1) * self.F - 1                    # global index of the frame in slot 0
+            for f in range(self.F):
+                g = first + f
+                if g < 0:
+                    continue
+                assert bytes(out[f, k, :fb]) == ref[g * fb:(g + 1) * fb], f"bench output differs from the oracle: stream {k}, slot {f}"
+        return {"checked": True, "streams": self.check_streams, "frames_compared_per_stream": self.F, "frames_encoded_by_the_oracle_per_stream": total,
+                "what": "the last timed launch's output buffer, byte for byte against oracle/mp2_oracle.c on the same looped PCM"}
 
     def close(self):
         self.batch.close()
@@ -239,6 +303,81 @@ def pcie_inclusive(M, np, gen_pcm, F, psy, mode, local_rank, streams, reps=3):
             f"{n_in / 1e6:.0f} MB PCM in + {n_out / 1e6:.0f} MB frames out over PCIe per call (copy-in, kernels and copy-out of four chunks of frames "
             "overlapped on three streams inside the library; the call returns when everything is back on the host)", "streams": streams,
             "frames_per_call": F, "gbytes_per_s_over_pcie": round(reps * (n_in + n_out) / dt / 1e9, 2)}
+
+
+def configs4_share(M, torch, np, gen_pcm, psy, local_rank, S=16384, F=8, steps=20):
+    """One GPU's share of BASELINE configs[4]: even streams 32 kHz mono 64 kbps, odd streams 48 kHz stereo 192 kbps, interleaved in
+    ONE batch (mixed configurations share a launch), psy 4 (the model configs[4] names) or psy 2 (what the reference's setter allows)."""
+    cfgs = [M.StreamConfig(samplerate=32000, mode="m", bitrate=64, psy_model=psy) if s % 2 == 0 else
+            M.StreamConfig(samplerate=48000, mode="s", bitrate=192, psy_model=psy) for s in range(S)]
+    base = np.stack([gen_pcm(s, 0, 0, 2 * F) for s in range(256)], axis=1)
+    host = np.tile(base, (1, S // 256, 1, 1))
+    pcm = [torch.from_numpy(host[:F].copy()).cuda(), torch.from_numpy(host[F:].copy()).cuda()]
+    b = M.Batch(cfgs, device=local_rank)
+    out = torch.zeros((F, S, b.out_stride), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream()
+    for i in range(2):
+        b.encode_device(pcm[i & 1].data_ptr(), F, out.data_ptr(), stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        b.encode_device(pcm[i & 1].data_ptr(), F, out.data_ptr(), stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # parity of what was timed: two streams of each kind against the oracle on the same looped PCM
+    import oraclelib as O
+    got = out.cpu().numpy()
+    launches, total = 2 + steps, (2 + steps) * F
+    for k in (0, 1, S - 2, S - 1):
+        c = cfgs[k]
+        loop = host[:, k]
+        ref = O.oracle_stream(np.concatenate([loop] * (launches // 2 + 1))[:total], samplerate=c.samplerate, mode=c.mode, kbps=c.bitrate, psy=psy)[0]
+        fb = b.frame_bytes[k]
+        for f in range(F):
+            g = (launches - 1) * F - 1 + f
+            assert bytes(got[f, k, :fb]) == ref[g * fb:(g + 1) * fb], f"configs[4] share: stream {k} slot {f} differs from the oracle"
+    b.close()
+    audio_s = (S // 2) * F * steps * (1152 / 32000 + 1152 / 48000)      # a 32 kHz frame is 36 ms of audio, a 48 kHz frame 24 ms
+    algo = (S // 2) * F * ((1152 * 2 + 144000 * 64 // 32000) + (2 * 1152 * 2 + 144000 * 192 // 48000))
+    return {"workload": f"{S} streams, even 32 kHz mono 64 kbps / odd 48 kHz stereo 192 kbps in one batch, psy {psy}, {F} frames/stream/launch "
+                        "(BASELINE configs[4], one GPU's share)", "value": round(S * F * steps / dt, 1), "unit": "frames/s",
+            "ms_per_launch": round(dt / steps * 1e3, 3), "streams_at_realtime": round(audio_s / dt),
+            "roofline_frac_hbm": round(algo / (dt / steps) / 1e9 / HBM_PEAK_GBS, 6), "output_check": "4 streams x the last launch's frames equal the oracle"}
+
+
+def tick_pipeline(M, np, gen_pcm, nstreams, psy, mode, local_rank, ticks=1000, egress="af", ngroups=0):
+    """The composed real-time loop body (tlb_tick_run: pinned host PCM -> PCIe -> ingest -> encode -> EDI AF packets -> PCIe -> pinned
+    host), one call per 24-ms tick for `nstreams` streams; wall-clock latency per tick, PCIe-inclusive.  The input buffer is
+    filled once (in a deployment the capture side writes it); every tick moves and encodes all of it."""
+    t = M.Tick([M.StreamConfig(samplerate=FS, mode=mode, bitrate=KBPS, psy_model=psy)] * nstreams, egress=egress, ngroups=ngroups,
+               version=b"odr-audioenc_amd bench", device=local_rank)
+    nd = min(nstreams, 1024)
+    base = np.stack([gen_pcm(s, 0, 0, 1)[0].T.reshape(-1) for s in range(nd)])          # interleaved L R L R
+    for k in range(0, nstreams, nd):
+        t.pcm[k:k + nd] = base[:min(nd, nstreams - k)]
+    for _ in range(5):
+        t.run()
+    lat, dev = np.empty(ticks), np.empty(ticks)
+    t0 = time.perf_counter()
+    for i in range(ticks):
+        a = time.perf_counter()
+        t.run()
+        lat[i] = time.perf_counter() - a
+        dev[i] = t.last_ms()
+    wall = time.perf_counter() - t0
+    pk = t.packets(0)
+    assert len(pk) == 1 and pk[0][:2] == b"AF", "no AF packet came out of the tick"
+    n_in, n_out = nstreams * 2304 * 2, nstreams * (len(pk[0]) + 4 + 4)
+    t.close()
+    lat *= 1e3
+    p50, p99 = float(np.percentile(lat, 50)), float(np.percentile(lat, 99))
+    return {"workload": f"{nstreams} streams x 1 frame per tick (48 kHz stereo {KBPS} kbps, psy {psy}, mode '{mode}'), tlb_tick_run: interleaved PCM in pinned host "
+                        f"memory -> PCIe -> gain/peak/de-interleave -> encode -> EDI AF packet per stream -> PCIe -> pinned host memory; {ticks} ticks back to back",
+            "ticks": ticks, "p50_ms": round(p50, 3), "p99_ms": round(p99, 3), "max_ms": round(float(lat.max()), 3), "mean_ms": round(float(lat.mean()), 3),
+            "device_ms_mean": round(float(dev.mean()), 3), "budget_ms": 24.0, "p99_share_of_budget": round(p99 / 24.0, 4),
+            "frames_per_s": round(nstreams * ticks / wall, 1), "mbytes_in_per_tick": round(n_in / 1e6, 1), "mbytes_out_per_tick": round(n_out / 1e6, 1),
+            "pcie_gbytes_per_s_in": round(n_in / (float(lat.mean()) * 1e-3) / 1e9, 2),
+            "limit": "the host-to-device link: " + f"{n_in / 1e6:.0f} MB of PCM per tick" if p50 > 0.5 * 24 else "none near the budget"}
 
 
 def main():
@@ -284,11 +423,15 @@ def main():
     run.cdev = cdev
     elapsed, own, kernel_ms = run.timed(dist, shard, args.warmup, args.steps)
     last_ms = run.batch.last_kernel_ms()
-    run.check()
+    checked = run.check()
     # per-rank (frames, own seconds): the only exchanged payload besides barriers
     per_rank = shard.gather_floats(dist, [S * F * args.steps, own], device=cdev)
     run_stage_ms = run.stage_ms
     run.close()
+    if dist is not None:          # nothing below is collective: the ranks part here, rank 0 goes on to its host-side legs alone
+        dist.destroy_process_group()
+        dist = None
+    had_group = world > 1
 
     res = None
     if rank == 0:
@@ -303,23 +446,7 @@ def main():
         if pk and run_stage_ms:
             kernels = {pk: round(run_stage_ms[0], 4), "tl_main_kernel + tl_finish_kernel": round(run_stage_ms[1], 4),
                        "source": "hipEvents on the launch stream inside the library (tlb_last_stage_ms), last timed launch"}
-        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, tools/profile_round2.sh): a committed
-        # measurement, quoted only when it was taken on this very workload; never measured inside this run
-        traffic, traffic_source, valu = None, None, None
-        try:
-            pm = json.load(open(ROOT / "profiles" / "pmc_traffic_latest.json"))
-            wl = pm["workload"]
-            if (wl["streams"], wl["frames_per_step"], wl["psy"], wl["mode"]) == (S, F, psy, args.mode):
-                traffic = pm["hbm_bytes_per_launch"]
-                traffic_source = ("profiles/pmc_traffic_latest.json (committed rocprofv3 --pmc measurement of this workload, summed over the launch's "
-                                  "kernels: " + ", ".join(f"{k} {v['hbm_bytes_per_launch']}" for k, v in pm["kernels"].items()) + "; not measured in this run)")
-                sq = json.load(open(ROOT / "profiles" / "sq_counters_latest.json"))
-                valu = {k: {"valu_busy_per_simd": c["derived"]["valu_busy_per_simd"], "waves_per_simd": c["derived"]["waves_per_simd"],
-                            "wave_cycles_waiting": c["derived"]["waiting_share"], "valu_instructions_per_frame": c["derived"]["per_frame"]["valu"]}
-                        for k, c in sq["kernels"].items()}
-                valu["source"] = "profiles/sq_counters_latest.json (committed rocprofv3 --pmc SQ counters of this workload, not this run)"
-        except Exception:  # noqa: BLE001
-            pass
+        traffic, traffic_source, valu = committed_counters(S, F, psy, args.mode)
         achieved = algo_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         label, cfg_k = workload_label(S, psy, args.mode, F, world)
         res = {
@@ -331,18 +458,20 @@ def main():
                        "frames_per_stream_timed": F * args.steps, "frames_per_stream_warmup": F * args.warmup,
                        "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
             "realtime_streams": round(value / (FS / 1152.0), 1),
-            "world_size_observed": observed_world, "collective_backend": ("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo (smoke test: ranks may share GPUs)") if dist is not None else None,
+            "world_size_observed": observed_world, "collective_backend": ("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo (smoke test: ranks may share GPUs)") if had_group else None,
             "per_gpu_frames_per_s": [round(p[0] / p[1], 1) for p in per_rank],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kname, "kernel_ms": round(kernel_ms, 4), "last_kernel_ms_hip_events": round(last_ms, 4), "kernels_ms": kernels,
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch,
-                         "binding_resource": "fp64 VALU issue + LDS latency chains (not HBM: 4992 B per 0.35 MFLOP frame, SURVEY F9)",
+                         "binding_resource": "fp64 VALU issue + LDS latency chains -- NOT HBM (4992 B per 0.35 MFLOP frame, SURVEY F9): `frac` is the HBM "
+                                             "fraction BASELINE.json asks for, the number that says how close the kernel is to ITS limit is valu_issue.*.valu_busy_per_simd",
                          "secondary_fp64": {"achieved_tflops": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 1e12, 3), "peak_tflops": 78.6,
                                             "frac": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 78.6e12, 5),
                                             "basis": "0.35 MFLOP algorithmic fp64 per stereo frame (SURVEY 8d), vector fp64 peak"},
                          "valu_issue": valu},
             "lds_bytes_per_stream": M.lds_bytes_per_stream(),
+            "output_check": checked,
         }
     # ---- secondary measurements, after (outside) the headline's timed region; single GPU only ----
     if world == 1 and not args.no_also:
@@ -356,16 +485,18 @@ def main():
             try:
                 r2 = GpuRun(M, torch, np, gen_pcm, range(s2), f2, m2, p2, local_rank)
                 e2, _, k2 = r2.timed(None, shard, max(2, args.warmup // 2), max(5, args.steps // 2))
-                r2.check()
+                chk2 = r2.check()
                 r2.close()
                 n2 = max(5, args.steps // 2)
                 wl2 = workload_label(s2, p2, m2, f2, 1)[0]
                 if name == "encoder_only_psy0":
                     wl2 = (f"{s2} streams/GPU x 48 kHz stereo (mode '{m2}') x 128 kbps, psy 0 = the encoder without a psychoacoustic model: filterbank, "
                            f"scalefactors, bit allocation, quantiser, packing (what BASELINE configs[1] calls 'filterbank+quantise kernels only'), {f2} frames/stream/step")
+                tr2, trs2, _ = committed_counters(s2, f2, p2, m2)
                 also[name] = {"workload": wl2, "value": round(s2 * f2 * n2 / e2, 1), "unit": "frames/s",
                               "steps": n2, "kernel_ms": round(k2, 4),
-                              "roofline_frac_hbm": round(ALGO_BYTES_PER_FRAME * s2 * f2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}
+                              "roofline_frac_hbm": round(ALGO_BYTES_PER_FRAME * s2 * f2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                              "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * s2 * f2, "traffic": tr2, "traffic_source": trs2, "output_check": chk2}
             except Exception as ex:  # noqa: BLE001
                 also[name] = {"value": None, "error": str(ex)}
         try:     # BASELINE configs[0] on the GPU: ONE stream -- its frames are independent units for the kernels, so one stream fills the chip
@@ -395,16 +526,25 @@ def main():
             also["pcie_inclusive"] = pcie_inclusive(M, np, gen_pcm, 8, psy, args.mode, local_rank, S)
         except Exception as ex:  # noqa: BLE001
             also["pcie_inclusive"] = {"value": None, "error": str(ex)}
+        for p4 in (4, 2):        # BASELINE configs[4] names psy 4 (an extension of the batched API); psy 2 is its sibling the reference's setter accepts
+            try:
+                also[f"configs4_share_psy{p4}"] = configs4_share(M, torch, np, gen_pcm, p4, local_rank)
+            except Exception as ex:  # noqa: BLE001
+                also[f"configs4_share_psy{p4}"] = {"value": None, "error": str(ex)}
+        also["tick_pipeline"] = {}
+        for nt2 in (16384, 131072):   # one GPU's share of BASELINE configs[3], and all of configs[3] on one GPU
+            try:
+                also["tick_pipeline"][str(nt2)] = tick_pipeline(M, np, gen_pcm, nt2, 3, args.mode, local_rank)
+            except Exception as ex:  # noqa: BLE001
+                also["tick_pipeline"][str(nt2)] = {"value": None, "error": str(ex)}
         res["also"] = also
     if rank == 0:
         res["setup_s"] = round(time.time() - t0, 1)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:         # rank 0's host cores, after every rank's timed region (N > 1: the configs[3] model, psy 3)
             res["cpu_baseline"] = cpu_baseline(psy, args.mode)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
     return 0
 
 

@@ -209,6 +209,54 @@ int tlb_edi_pft_host(tlb_batch *b, const uint8_t *af, const int32_t *af_len, int
                      int fec, int chunk_len, int transport, int addr_source, int dest_port,
                      uint8_t *frags, int32_t *frag_len, int32_t *nfrag, int max_frags, int frag_stride);
 
+/* The real-time loop body as ONE call per tick (src/odr-audioenc.cpp:1030-1051 gain / peak, :1139-1152
+ * de-interleave, :1158 toolame_encode_frame, :1208-1225 re-framing into units, src/Outputs.cpp:194-261 EDI::write_frame,
+ * contrib/edioutput/PFT.cpp for UDP): one frame of EVERY stream goes host -> PCIe -> ingest -> encode -> EDI AF packets
+ * (-> PFT fragments) -> PCIe -> host.  The tick object owns pinned host buffers and all device memory; streams are split into
+ * `ngroups` contiguous groups whose copy-in, kernels and copy-out overlap on three HIP streams.
+ *   1. fill tlb_tick_pcm(): int16 [nstreams][2304] interleaved s16le (and tlb_tick_xpad() [nstreams][TLB_MAX_XPAD] /
+ *      tlb_tick_xpad_len() [nstreams] when created with_xpad)
+ *   2. tlb_tick_run(): returns when everything is back in host memory
+ *   3. read tlb_tick_peaks() int16 [nstreams][2] and, per stream, tlb_tick_frame() / tlb_tick_packet(unit) /
+ *      tlb_tick_fragment(unit, k) (length 0 / count 0: nothing for this stream this tick)
+ * What comes out of run number n is the frame that became final during it -- input frame n-1 (one frame of latency, see
+ * tlb_encode_device; nothing on the very first run) -- in tlb_tick_units() units of 3*bitrate bytes (one per 48 kHz frame, two
+ * per 24 kHz frame, three per 16 kHz frame: a run is one FRAME of every stream, so an LSF batch runs every 48 / 72 ms).
+ * The audio levels sent with it are this run's peaks, as in the reference, whose send_frame() carries the peaks current at send
+ * time (odr-audioenc.cpp:1213-1219).  tlb_tick_finish() pushes the last (pending) frame of every stream through the same
+ * egress stage (toolame_finish at stream end); after it the object only answers the read accessors.
+ * egress: TLB_TICK_FRAMES (raw MP2 frames, any sample rate), TLB_TICK_EDI_AF (AF packets, tlb_edi_af_device),
+ * TLB_TICK_EDI_PFT (PFT fragments of those packets, tlb_edi_pft_device).  The EDI sender state of every stream starts as
+ * tlb_edi_state_init(now_s, delay_ms, tist, tai_utc_offset) and lives on the device. */
+#define TLB_TICK_FRAMES 0
+#define TLB_TICK_EDI_AF 1
+#define TLB_TICK_EDI_PFT 2
+typedef struct tlb_tick tlb_tick;
+typedef struct {
+    int egress;                    /* TLB_TICK_* */
+    int ngroups;                   /* 0 = pick (1 below 2048 streams, 2 below 8192, else 4) */
+    int with_xpad;                 /* X-PAD side input per tick */
+    const char *version; int version_len;     /* ODRv string (EDI) */
+    long long now_s; unsigned delay_ms; int tist; int tai_utc_offset;      /* tlb_edi_state_init() arguments */
+    int fec, chunk_len, transport, addr_source, dest_port;                 /* PFT layer (chunk_len 0 = 207) */
+} tlb_tick_config;
+tlb_tick *tlb_tick_create(int device, int nstreams, const tlb_stream_config *cfgs, const tlb_tick_config *tc, int *err);
+void tlb_tick_destroy(tlb_tick *t);
+int tlb_tick_set_gain_db(tlb_tick *t, int stream, double gain_db);
+int16_t *tlb_tick_pcm(tlb_tick *t);
+uint8_t *tlb_tick_xpad(tlb_tick *t);
+int32_t *tlb_tick_xpad_len(tlb_tick *t);
+int tlb_tick_run(tlb_tick *t);
+int tlb_tick_finish(tlb_tick *t);
+long tlb_tick_count(const tlb_tick *t);
+const int16_t *tlb_tick_peaks(const tlb_tick *t);
+int tlb_tick_units(const tlb_tick *t, int stream);
+const uint8_t *tlb_tick_frame(const tlb_tick *t, int stream, int *len);
+const uint8_t *tlb_tick_packet(const tlb_tick *t, int stream, int unit, int *len);
+int tlb_tick_fragments(const tlb_tick *t, int stream, int unit);
+const uint8_t *tlb_tick_fragment(const tlb_tick *t, int stream, int unit, int k, int *len);
+float tlb_tick_last_ms(tlb_tick *t);           /* first copy-in queued -> last copy-out done of the last run, device clock */
+
 /* Diagnostic only: per-stage cycle stamps [nframes][nstreams][32] (csrc/mp2_wave.h TL_STAMP), host buffers. */
 int tlb_encode_host_stamps(tlb_batch *b, const int16_t *pcm, int nframes, long long *stamps);
 

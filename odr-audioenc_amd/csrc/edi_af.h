@@ -3,8 +3,8 @@
 // ten seconds, ODRv (contrib/edioutput/TagItems.cpp:38-66,202-263,304-356,381-441) -- wrapped by
 // contrib/edioutput/AFPacket.cpp:46-94 (SYNC "AF", LEN, SEQ, AR = CRC flag | version 1.0, PT 'T', payload,
 // CRC-16/CCITT with init 0xffff and final inversion, contrib/crc.c:247-255).
-// This is what an EDI/TCP destination receives (PFT fragmentation + Reed-Solomon, used for UDP, is a further
-// layer and not built here).
+// This is what an EDI/TCP destination receives; the PFT layer for UDP destinations (Reed-Solomon + fragmentation,
+// contrib/edioutput/PFT.cpp) is csrc/edi_pft.h, which takes these packets as its input.
 //
 // Written in the same lane-SPMD style as mp2_wave.h (include it first): compiled by hipcc for gfx950 and, with
 // -DTL_EMULATE, as a lane loop for the CPU tests.  One wavefront builds one packet; the sender state (timestamp,

@@ -350,7 +350,7 @@ struct tlb_batch {
     std::vector<double> h_gain;
     int32_t *d_list[4] = {nullptr, nullptr, nullptr, nullptr};   // stream ids per psy model
     int n_list[4] = {0, 0, 0, 0};
-    TlPsy2Tables *d_psy2_tables = nullptr;     // 4 slots (tl_psy2_slot), only when a stream uses psy 2
+    TlPsy2Tables *d_psy2_tables = nullptr;     // 2 * TL_PSY2_SLOTS tables (psy 2 per sample rate, then psy 4 per sample rate; tl_psy2_slot), only when a stream uses psy 2 / 4
     TlPsy2State *d_psy2_state = nullptr;
     uint8_t *d_edi_version = nullptr;            // EDI: ODRv string and per-stream frame sizes (allocated on first use)
     int32_t *d_frame_bytes = nullptr, *d_unit_bytes = nullptr;
@@ -554,6 +554,7 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
                       uint8_t *d_out, TlTaps *d_taps, hipStream_t st, long long *d_stamps = nullptr, int32_t *d_out_len = nullptr)
 {
     if (!b || !d_pcm || !d_out || nframes <= 0) return TLB_ERR_ARG;
+    for (int p = 0; p < 4; p++) if ((long)b->n_list[p] * nframes > (1L << 30)) return TLB_ERR_ARG;   // unit indices are 32-bit; checked for every model before anything is queued
     HIPCHK(hipSetDevice(b->device));
     TlLaunch A;
     memset(&A, 0, sizeof A);
@@ -576,7 +577,6 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         A.stream_list = b->d_list[p]; A.nlist = b->n_list[p];
         // persistent waves, twelve per CU (three per SIMD) in every kernel; they take their units off a counter
         const long units = (long)b->n_list[p] * nframes;
-        if (units > (1L << 30)) return TLB_ERR_ARG;                 // unit indices are 32-bit
         A.padbits = b->pads[p] ? (uint8_t *)b->stage[7] : nullptr; A.newlag = b->d_newlag;
         if (b->pads[p]) { hipLaunchKernelGGL(tl_slots_kernel, dim3((unsigned)((b->n_list[p] + 255) / 256)), dim3(256), 0, st, A); HIPCHK(hipGetLastError()); }
         HIPCHK(hipMemsetAsync(b->d_work, 0, sizeof(int32_t) * TL_HEAD_STRIDE * 9, st));
@@ -594,7 +594,7 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         }
         if (p == 2) hipLaunchKernelGGL(tl_psy2_kernel, dim3((unsigned)qb), dim3(64 * TL_PSY2_WAVES), 0, st, A);
         HIPCHK(hipGetLastError());
-        if (p && b->n_list[p] == b->nstreams) { HIPCHK(hipEventRecord(b->ev_mid, st)); b->have_mid = true; }      // one model in the batch: psy | encode split of the time
+        if (p == 2 && b->n_list[p] == b->nstreams) { HIPCHK(hipEventRecord(b->ev_mid, st)); b->have_mid = true; }      // models 2/4 only in the batch: psy | encode split of the time
         long mb = (units + TL_MAIN_WAVES - 1) / TL_MAIN_WAVES;
         if (mb > b->num_cu) mb = b->num_cu;
         if (p == 0) hipLaunchKernelGGL(tl_main_kernel<0>, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);       // model 0: no psy kernel
@@ -663,27 +663,34 @@ int tlb_encode_host_len(tlb_batch *b, const int16_t *pcm, int nframes, const uin
     }
     HIPCHK(hipMemsetAsync(d_out, 0, n_out, b->s_in));              // bytes the kernels do not write (slot 0 of the first call, tails of short frames) read as 0
     if (taps) HIPCHK(hipMemsetAsync(d_taps, 0, slots * sizeof(TlTaps), b->s_in));
+    // From here on copies and kernels are in flight on three streams and touch the caller's buffers: every error path drains
+    // them before it returns (a caller that frees or reuses pcm / out on error must not race with a DMA transfer).
+#define HIPCHK_DRAIN(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "libtoolame-dab-hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    (void)hipStreamSynchronize(b->s_in); (void)hipStreamSynchronize(b->s_run); (void)hipStreamSynchronize(b->s_out); \
+    return TLB_ERR_HIP; } } while (0)
     for (int c = 0, f0 = 0; c < nchunks; c++, f0 += per) {
         const int nf = f0 + per <= nframes ? per : nframes - f0;
         const size_t o = (size_t)f0 * (size_t)b->nstreams, n = (size_t)nf * (size_t)b->nstreams;
-        HIPCHK(hipMemcpyAsync(d_pcm + o * 2304, pcm + o * 2304, n * 2304 * sizeof(int16_t), hipMemcpyHostToDevice, b->s_in));
+        HIPCHK_DRAIN(hipMemcpyAsync(d_pcm + o * 2304, pcm + o * 2304, n * 2304 * sizeof(int16_t), hipMemcpyHostToDevice, b->s_in));
         if (with_xpad) {
-            HIPCHK(hipMemcpyAsync(d_xpad + o * TL_MAX_XPAD, xpad + o * TL_MAX_XPAD, n * TL_MAX_XPAD, hipMemcpyHostToDevice, b->s_in));
-            HIPCHK(hipMemcpyAsync(d_xl + o, xpad_len + o, n * sizeof(int32_t), hipMemcpyHostToDevice, b->s_in));
+            HIPCHK_DRAIN(hipMemcpyAsync(d_xpad + o * TL_MAX_XPAD, xpad + o * TL_MAX_XPAD, n * TL_MAX_XPAD, hipMemcpyHostToDevice, b->s_in));
+            HIPCHK_DRAIN(hipMemcpyAsync(d_xl + o, xpad_len + o, n * sizeof(int32_t), hipMemcpyHostToDevice, b->s_in));
         }
-        HIPCHK(hipEventRecord(b->ev_in[c], b->s_in));
-        HIPCHK(hipStreamWaitEvent(b->s_run, b->ev_in[c], 0));
+        HIPCHK_DRAIN(hipEventRecord(b->ev_in[c], b->s_in));
+        HIPCHK_DRAIN(hipStreamWaitEvent(b->s_run, b->ev_in[c], 0));
         int rc = tlb_launch(b, d_pcm + o * 2304, nf, with_xpad ? d_xpad + o * TL_MAX_XPAD : nullptr, with_xpad ? d_xl + o : nullptr,
                             d_out + o * (size_t)b->out_stride, d_taps ? d_taps + o : nullptr, b->s_run, nullptr, d_len ? d_len + o : nullptr);
-        if (rc != TLB_OK) { (void)hipDeviceSynchronize(); return rc; }
-        HIPCHK(hipEventRecord(b->ev_run[c], b->s_run));
-        HIPCHK(hipStreamWaitEvent(b->s_out, b->ev_run[c], 0));
-        HIPCHK(hipMemcpyAsync(out + o * (size_t)b->out_stride, d_out + o * (size_t)b->out_stride, n * (size_t)b->out_stride, hipMemcpyDeviceToHost, b->s_out));
-        if (taps) HIPCHK(hipMemcpyAsync((TlTaps *)taps + o, d_taps + o, n * sizeof(TlTaps), hipMemcpyDeviceToHost, b->s_out));
-        if (out_len) HIPCHK(hipMemcpyAsync(out_len + o, d_len + o, n * sizeof(int32_t), hipMemcpyDeviceToHost, b->s_out));
+        if (rc != TLB_OK) { (void)hipStreamSynchronize(b->s_in); (void)hipStreamSynchronize(b->s_run); (void)hipStreamSynchronize(b->s_out); return rc; }
+        HIPCHK_DRAIN(hipEventRecord(b->ev_run[c], b->s_run));
+        HIPCHK_DRAIN(hipStreamWaitEvent(b->s_out, b->ev_run[c], 0));
+        HIPCHK_DRAIN(hipMemcpyAsync(out + o * (size_t)b->out_stride, d_out + o * (size_t)b->out_stride, n * (size_t)b->out_stride, hipMemcpyDeviceToHost, b->s_out));
+        if (taps) HIPCHK_DRAIN(hipMemcpyAsync((TlTaps *)taps + o, d_taps + o, n * sizeof(TlTaps), hipMemcpyDeviceToHost, b->s_out));
+        if (out_len) HIPCHK_DRAIN(hipMemcpyAsync(out_len + o, d_len + o, n * sizeof(int32_t), hipMemcpyDeviceToHost, b->s_out));
     }
-    HIPCHK(hipStreamSynchronize(b->s_out));
+    HIPCHK_DRAIN(hipStreamSynchronize(b->s_out));
     HIPCHK(hipStreamSynchronize(b->s_run));
+#undef HIPCHK_DRAIN
     return TLB_OK;
 }
 
@@ -1025,8 +1032,9 @@ float tlb_last_kernel_ms(tlb_batch *b)
     return ms;
 }
 
-// Durations of the two kernels of the most recent launch of a batch whose streams all use ONE of the models 1 and 3 (the psy
-// kernel, then the encode kernel), hipEvents on the launch stream.  Returns non-zero when the last launch was of another shape.
+// Durations of the two kernels of the most recent launch of a batch whose streams ALL use psy model 2 or 4 (tl_psy2_kernel,
+// then tl_main_kernel<2> + tl_finish_kernel), hipEvents on the launch stream.  Models 1 / 3 run one kernel per launch and
+// model 0 has no psy kernel: for those, and for mixed batches, the call returns non-zero.
 int tlb_last_stage_ms(tlb_batch *b, float *psy_ms, float *encode_ms)
 {
     if (!b || !b->timed || !b->have_mid || !psy_ms || !encode_ms) return TLB_ERR_ARG;
@@ -1037,11 +1045,294 @@ int tlb_last_stage_ms(tlb_batch *b, float *psy_ms, float *encode_ms)
     return TLB_OK;
 }
 
-// ------------------------------------------------------------------------------------------
-// legacy nine-function ABI: stream 0 of a private one-stream batch (libtoolame-dab/toolame.h:13-48)
-// ------------------------------------------------------------------------------------------
 }  // extern "C" (the shim's private state and helper have internal linkage: the library exports the nine names of libtoolame-dab.sym and tlb_*, nothing else)
 
+// ------------------------------------------------------------------------------------------
+// The caller's real-time loop body as ONE call per tick (include/toolame_batch.h, tlb_tick_*): what AudioEnc::run() does for
+// one stream every 24 ms -- gain / peak / de-interleave (src/odr-audioenc.cpp:1030-1051,1139-1152), toolame_encode_frame
+// (:1158), re-framing into 3*bitrate-byte units (:1208-1225), EDI::write_frame (src/Outputs.cpp:194-261, optionally the PFT
+// layer) -- for every stream of a GPU at once: interleaved PCM in pinned host memory -> PCIe -> tl_ingest_kernel ->
+// the encode kernels (one frame per stream) -> tl_edi_af_kernel (-> tl_edi_pft_kernel) -> PCIe -> pinned host memory.
+// The streams are split into groups (contiguous ranges, a private tlb_batch each): while group g's kernels run, group g+1's
+// PCM comes in and group g-1's packets go out, on three HIP streams (the link is full duplex).
+// ------------------------------------------------------------------------------------------
+struct TickGroup {
+    tlb_batch *b = nullptr;
+    int first = 0, n = 0, out_stride = 0, max_upf = 1, af_stride = 0, max_frags = 0, frag_stride = 0;
+    int16_t *d_inter = nullptr, *d_pcm = nullptr, *d_peaks = nullptr;
+    uint8_t *d_xpad = nullptr; int32_t *d_xl = nullptr;
+    uint8_t *d_frames = nullptr; int32_t *d_flen = nullptr;
+    tlb_edi_state *d_state = nullptr; uint8_t *d_pkts = nullptr; int32_t *d_plen = nullptr;
+    uint16_t *d_pseq = nullptr; uint8_t *d_frags = nullptr; int32_t *d_fraglen = nullptr, *d_nfrag = nullptr;
+    // this group's slices of the pinned host outputs
+    uint8_t *h_frames = nullptr; int32_t *h_flen = nullptr; uint8_t *h_pkts = nullptr; int32_t *h_plen = nullptr;
+    uint8_t *h_frags = nullptr; int32_t *h_fraglen = nullptr, *h_nfrag = nullptr;
+    hipEvent_t ev_in = nullptr, ev_run = nullptr;
+};
+struct tlb_tick {
+    int device = 0, nstreams = 0, egress = 0, version_len = 0, with_xpad = 0;
+    char version[TL_EDI_MAX_VERSION] = {};
+    int fec = 0, chunk_len = 207, transport = 0, addr_source = 0, dest_port = 0;
+    std::vector<TickGroup> groups;
+    std::vector<int> group_of;                   // stream -> group
+    int16_t *h_inter = nullptr, *h_peaks = nullptr; uint8_t *h_xpad = nullptr; int32_t *h_xl = nullptr;
+    std::vector<void *> pinned, dev;
+    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    long ticks = 0;
+    bool finished = false;
+};
+
+extern "C" {
+
+void tlb_tick_destroy(tlb_tick *t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    (void)hipDeviceSynchronize();
+    for (auto &g : t->groups) {
+        if (g.b) tlb_destroy(g.b);
+        if (g.ev_in) (void)hipEventDestroy(g.ev_in);
+        if (g.ev_run) (void)hipEventDestroy(g.ev_run);
+    }
+    for (void *p : t->dev) (void)hipFree(p);
+    for (void *p : t->pinned) (void)hipHostFree(p);
+    if (t->s_in) (void)hipStreamDestroy(t->s_in);
+    if (t->s_run) (void)hipStreamDestroy(t->s_run);
+    if (t->s_out) (void)hipStreamDestroy(t->s_out);
+    if (t->ev0) (void)hipEventDestroy(t->ev0);
+    if (t->ev1) (void)hipEventDestroy(t->ev1);
+    delete t;
+}
+
+static int tick_create_impl(tlb_tick *t, int device, int nstreams, const tlb_stream_config *cfgs, const tlb_tick_config *tc)
+{
+    t->device = device; t->nstreams = nstreams; t->egress = tc->egress; t->with_xpad = tc->with_xpad ? 1 : 0;
+    if (tc->egress < TLB_TICK_FRAMES || tc->egress > TLB_TICK_EDI_PFT || tc->version_len < 0 || tc->version_len > TL_EDI_MAX_VERSION ||
+        (tc->version_len && !tc->version)) return TLB_ERR_ARG;
+    t->version_len = tc->version_len;
+    if (tc->version_len) memcpy(t->version, tc->version, (size_t)tc->version_len);
+    t->fec = tc->fec; t->chunk_len = tc->chunk_len ? tc->chunk_len : 207; t->transport = tc->transport; t->addr_source = tc->addr_source; t->dest_port = tc->dest_port;
+    int ng = tc->ngroups > 0 ? tc->ngroups : (nstreams >= 8192 ? 4 : nstreams >= 2048 ? 2 : 1);
+    if (ng > nstreams) ng = nstreams;
+    t->groups.resize((size_t)ng);
+    t->group_of.resize((size_t)nstreams);
+    size_t n_frames = 0, n_pkts = 0, n_slots = 0, n_frags = 0, n_fragslots = 0;
+    for (int g = 0; g < ng; g++) {
+        TickGroup &G = t->groups[(size_t)g];
+        G.first = (int)((long)nstreams * g / ng); G.n = (int)((long)nstreams * (g + 1) / ng) - G.first;
+        for (int s = G.first; s < G.first + G.n; s++) t->group_of[(size_t)s] = g;
+        int err = 0;
+        G.b = tlb_create(device, G.n, cfgs + G.first, &err);
+        if (!G.b) return err ? err : TLB_ERR_HIP;
+        G.out_stride = G.b->out_stride; G.max_upf = G.b->max_upf;
+        if (tc->egress != TLB_TICK_FRAMES) {
+            if (!G.max_upf) return TLB_ERR_SAMPLERATE;
+            G.af_stride = tlb_edi_af_stride(G.b, tc->version_len);
+            if (tc->egress == TLB_TICK_EDI_PFT)
+                if (int rc = pft_shape(G.af_stride, t->fec, t->chunk_len, t->transport, &G.max_frags, &G.frag_stride)) return rc;
+        } else if (!G.max_upf) G.max_upf = 1;
+        n_frames += (size_t)G.n * (size_t)G.out_stride;
+        n_slots += (size_t)G.n * (size_t)G.max_upf;
+        n_pkts += (size_t)G.n * (size_t)G.max_upf * (size_t)G.af_stride;
+        n_fragslots += (size_t)G.n * (size_t)G.max_upf * (size_t)G.max_frags;
+        n_frags += (size_t)G.n * (size_t)G.max_upf * (size_t)G.max_frags * (size_t)G.frag_stride;
+    }
+    HIPCHK(hipSetDevice(device));
+    auto pin = [&](size_t bytes) -> void * { void *p = nullptr; if (hipHostMalloc(&p, bytes ? bytes : 4, hipHostMallocDefault) != hipSuccess) return nullptr; memset(p, 0, bytes ? bytes : 4); t->pinned.push_back(p); return p; };
+    auto dev = [&](size_t bytes) -> void * { void *p = nullptr; if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr; (void)hipMemset(p, 0, bytes ? bytes : 4); t->dev.push_back(p); return p; };
+    t->h_inter = (int16_t *)pin((size_t)nstreams * 2304 * sizeof(int16_t));
+    t->h_peaks = (int16_t *)pin((size_t)nstreams * 2 * sizeof(int16_t));
+    t->h_xpad = (uint8_t *)pin(t->with_xpad ? (size_t)nstreams * TL_MAX_XPAD : 0);
+    t->h_xl = (int32_t *)pin(t->with_xpad ? (size_t)nstreams * sizeof(int32_t) : 0);
+    uint8_t *h_frames = (uint8_t *)pin(n_frames); int32_t *h_flen = (int32_t *)pin((size_t)nstreams * sizeof(int32_t));
+    uint8_t *h_pkts = (uint8_t *)pin(n_pkts); int32_t *h_plen = (int32_t *)pin(n_slots * sizeof(int32_t));
+    uint8_t *h_frags = (uint8_t *)pin(n_frags); int32_t *h_fraglen = (int32_t *)pin(n_fragslots * sizeof(int32_t)), *h_nfrag = (int32_t *)pin(n_slots * sizeof(int32_t));
+    if (!t->h_inter || !t->h_peaks || !t->h_xpad || !t->h_xl || !h_frames || !h_flen || !h_pkts || !h_plen || !h_frags || !h_fraglen || !h_nfrag) return TLB_ERR_HIP;
+    std::vector<tlb_edi_state> st0;
+    size_t o_frames = 0, o_slots = 0, o_pkts = 0, o_frags = 0, o_fragslots = 0;
+    for (auto &G : t->groups) {
+        const size_t n = (size_t)G.n, slots = n * (size_t)G.max_upf;
+        G.d_inter = (int16_t *)dev(n * 2304 * 2); G.d_pcm = (int16_t *)dev(n * 2304 * 2); G.d_peaks = (int16_t *)dev(n * 4);
+        G.d_xpad = (uint8_t *)dev(t->with_xpad ? n * TL_MAX_XPAD : 0); G.d_xl = (int32_t *)dev(t->with_xpad ? n * 4 : 0);
+        G.d_frames = (uint8_t *)dev(n * (size_t)G.out_stride); G.d_flen = (int32_t *)dev(n * 4);
+        G.d_state = (tlb_edi_state *)dev(n * sizeof(tlb_edi_state));
+        G.d_pkts = (uint8_t *)dev(slots * (size_t)G.af_stride); G.d_plen = (int32_t *)dev(slots * 4);
+        G.d_pseq = (uint16_t *)dev(n * 2);
+        G.d_frags = (uint8_t *)dev(slots * (size_t)G.max_frags * (size_t)G.frag_stride); G.d_fraglen = (int32_t *)dev(slots * (size_t)G.max_frags * 4); G.d_nfrag = (int32_t *)dev(slots * 4);
+        if (!G.d_inter || !G.d_pcm || !G.d_peaks || !G.d_xpad || !G.d_xl || !G.d_frames || !G.d_flen || !G.d_state || !G.d_pkts || !G.d_plen || !G.d_pseq ||
+            !G.d_frags || !G.d_fraglen || !G.d_nfrag) return TLB_ERR_HIP;
+        G.h_frames = h_frames + o_frames; G.h_flen = h_flen + G.first; G.h_pkts = h_pkts + o_pkts; G.h_plen = h_plen + o_slots;
+        G.h_frags = h_frags + o_frags; G.h_fraglen = h_fraglen + o_fragslots; G.h_nfrag = h_nfrag + o_slots;
+        o_frames += n * (size_t)G.out_stride; o_slots += slots; o_pkts += slots * (size_t)G.af_stride;
+        o_fragslots += slots * (size_t)G.max_frags; o_frags += slots * (size_t)G.max_frags * (size_t)G.frag_stride;
+        st0.resize(n);
+        for (size_t i = 0; i < n; i++) tlb_edi_state_init(&st0[i], tc->now_s, tc->delay_ms, tc->tist, tc->tai_utc_offset);
+        HIPCHK(hipMemcpy(G.d_state, st0.data(), n * sizeof(tlb_edi_state), hipMemcpyHostToDevice));
+        HIPCHK(hipEventCreateWithFlags(&G.ev_in, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&G.ev_run, hipEventDisableTiming));
+    }
+    HIPCHK(hipStreamCreateWithFlags(&t->s_in, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&t->s_run, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&t->s_out, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&t->ev0));
+    HIPCHK(hipEventCreate(&t->ev1));
+    return TLB_OK;
+}
+
+tlb_tick *tlb_tick_create(int device, int nstreams, const tlb_stream_config *cfgs, const tlb_tick_config *tc, int *err)
+{
+    if (nstreams <= 0 || !cfgs || !tc) { if (err) *err = TLB_ERR_ARG; return nullptr; }
+    tlb_tick *t = new tlb_tick;
+    const int rc = tick_create_impl(t, device, nstreams, cfgs, tc);
+    if (err) *err = rc;
+    if (rc) { tlb_tick_destroy(t); return nullptr; }
+    return t;
+}
+
+int16_t *tlb_tick_pcm(tlb_tick *t) { return t ? t->h_inter : nullptr; }
+uint8_t *tlb_tick_xpad(tlb_tick *t) { return t && t->with_xpad ? t->h_xpad : nullptr; }
+int32_t *tlb_tick_xpad_len(tlb_tick *t) { return t && t->with_xpad ? t->h_xl : nullptr; }
+const int16_t *tlb_tick_peaks(const tlb_tick *t) { return t ? t->h_peaks : nullptr; }
+long tlb_tick_count(const tlb_tick *t) { return t ? t->ticks : 0; }
+int tlb_tick_set_gain_db(tlb_tick *t, int stream, double gain_db)
+{
+    if (!t || stream < -1 || stream >= t->nstreams) return TLB_ERR_ARG;
+    for (auto &G : t->groups) {
+        if (stream >= 0 && (stream < G.first || stream >= G.first + G.n)) continue;
+        if (int rc = tlb_set_gain_db(G.b, stream < 0 ? -1 : stream - G.first, gain_db)) return rc;
+    }
+    return TLB_OK;
+}
+
+// egress of the frames sitting in G.d_frames + copy-out, queued on s_run / s_out
+static int tick_egress(tlb_tick *t, TickGroup &G, bool have_frames)
+{
+    const size_t n = (size_t)G.n, slots = n * (size_t)G.max_upf;
+    if (have_frames && t->egress != TLB_TICK_FRAMES) {
+        if (int rc = tlb_edi_af_device(G.b, G.d_frames, G.d_peaks, 1, G.d_state, t->version, t->version_len, G.d_pkts, G.d_plen, t->s_run)) return rc;
+        if (t->egress == TLB_TICK_EDI_PFT)
+            if (int rc = tlb_edi_pft_device(G.b, G.d_pkts, G.d_plen, G.max_upf, G.af_stride, G.d_pseq, t->fec, t->chunk_len, t->transport, t->addr_source, t->dest_port,
+                                            G.d_frags, G.d_fraglen, G.d_nfrag, G.max_frags, G.frag_stride, t->s_run)) return rc;
+    }
+    HIPCHK(hipEventRecord(G.ev_run, t->s_run));
+    HIPCHK(hipStreamWaitEvent(t->s_out, G.ev_run, 0));
+    HIPCHK(hipMemcpyAsync(t->h_peaks + (size_t)G.first * 2, G.d_peaks, n * 4, hipMemcpyDeviceToHost, t->s_out));
+    if (!have_frames) return TLB_OK;                                 // very first tick: no frame is final yet (lengths stay 0)
+    if (t->egress == TLB_TICK_FRAMES) {
+        HIPCHK(hipMemcpyAsync(G.h_frames, G.d_frames, n * (size_t)G.out_stride, hipMemcpyDeviceToHost, t->s_out));
+        HIPCHK(hipMemcpyAsync(G.h_flen, G.d_flen, n * 4, hipMemcpyDeviceToHost, t->s_out));
+    } else if (t->egress == TLB_TICK_EDI_AF) {
+        HIPCHK(hipMemcpyAsync(G.h_pkts, G.d_pkts, slots * (size_t)G.af_stride, hipMemcpyDeviceToHost, t->s_out));
+        HIPCHK(hipMemcpyAsync(G.h_plen, G.d_plen, slots * 4, hipMemcpyDeviceToHost, t->s_out));
+    } else {
+        HIPCHK(hipMemcpyAsync(G.h_frags, G.d_frags, slots * (size_t)G.max_frags * (size_t)G.frag_stride, hipMemcpyDeviceToHost, t->s_out));
+        HIPCHK(hipMemcpyAsync(G.h_fraglen, G.d_fraglen, slots * (size_t)G.max_frags * 4, hipMemcpyDeviceToHost, t->s_out));
+        HIPCHK(hipMemcpyAsync(G.h_nfrag, G.d_nfrag, slots * 4, hipMemcpyDeviceToHost, t->s_out));
+    }
+    return TLB_OK;
+}
+
+static void tick_drain(tlb_tick *t) { (void)hipStreamSynchronize(t->s_in); (void)hipStreamSynchronize(t->s_run); (void)hipStreamSynchronize(t->s_out); }
+
+int tlb_tick_run(tlb_tick *t)
+{
+    if (!t || t->finished) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    HIPCHK(hipEventRecord(t->ev0, t->s_in));
+    for (auto &G : t->groups) {
+        const size_t n = (size_t)G.n;
+        int rc = TLB_OK;
+        hipError_t e = hipMemcpyAsync(G.d_inter, t->h_inter + (size_t)G.first * 2304, n * 2304 * sizeof(int16_t), hipMemcpyHostToDevice, t->s_in);
+        if (e == hipSuccess && t->with_xpad) e = hipMemcpyAsync(G.d_xpad, t->h_xpad + (size_t)G.first * TL_MAX_XPAD, n * TL_MAX_XPAD, hipMemcpyHostToDevice, t->s_in);
+        if (e == hipSuccess && t->with_xpad) e = hipMemcpyAsync(G.d_xl, t->h_xl + G.first, n * sizeof(int32_t), hipMemcpyHostToDevice, t->s_in);
+        if (e == hipSuccess) e = hipEventRecord(G.ev_in, t->s_in);
+        if (e == hipSuccess) e = hipStreamWaitEvent(t->s_run, G.ev_in, 0);
+        if (e != hipSuccess) rc = TLB_ERR_HIP;
+        if (!rc) rc = tlb_ingest_device(G.b, G.d_inter, 1, G.d_pcm, G.d_peaks, t->s_run);
+        if (!rc) rc = tlb_launch(G.b, G.d_pcm, 1, t->with_xpad ? G.d_xpad : nullptr, t->with_xpad ? G.d_xl : nullptr, G.d_frames, nullptr, t->s_run, nullptr, G.d_flen);
+        if (!rc) rc = tick_egress(t, G, t->ticks > 0);
+        if (rc) { tick_drain(t); return rc; }
+    }
+    hipError_t e = hipEventRecord(t->ev1, t->s_out);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->s_out);
+    if (e != hipSuccess) { tick_drain(t); return TLB_ERR_HIP; }
+    t->ticks++;
+    return TLB_OK;
+}
+
+// end of the streams (toolame_finish): the pending frame of every stream through the egress stage; no further run
+int tlb_tick_finish(tlb_tick *t)
+{
+    if (!t || t->finished || t->ticks == 0) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(t->device));
+    for (auto &G : t->groups) {
+        int rc = tlb_flush_device_len(G.b, G.d_frames, G.d_flen, t->s_run);
+        if (!rc) rc = tick_egress(t, G, true);
+        if (rc) { tick_drain(t); return rc; }
+    }
+    if (hipStreamSynchronize(t->s_out) != hipSuccess) { tick_drain(t); return TLB_ERR_HIP; }
+    t->finished = true;
+    return TLB_OK;
+}
+
+int tlb_tick_units(const tlb_tick *t, int stream)
+{
+    if (!t || stream < 0 || stream >= t->nstreams) return 0;
+    const TickGroup &G = t->groups[(size_t)t->group_of[(size_t)stream]];
+    if (t->egress == TLB_TICK_FRAMES) return 1;
+    return tlb_egress_units_per_frame(G.b, stream - G.first);
+}
+const uint8_t *tlb_tick_frame(const tlb_tick *t, int stream, int *len)
+{
+    if (!t || stream < 0 || stream >= t->nstreams || t->egress != TLB_TICK_FRAMES) return nullptr;
+    const TickGroup &G = t->groups[(size_t)t->group_of[(size_t)stream]];
+    if (len) *len = G.h_flen[stream - G.first];
+    return G.h_frames + (size_t)(stream - G.first) * (size_t)G.out_stride;
+}
+const uint8_t *tlb_tick_packet(const tlb_tick *t, int stream, int unit, int *len)
+{
+    if (!t || stream < 0 || stream >= t->nstreams || t->egress != TLB_TICK_EDI_AF) return nullptr;
+    const TickGroup &G = t->groups[(size_t)t->group_of[(size_t)stream]];
+    if (unit < 0 || unit >= G.max_upf) return nullptr;
+    const size_t slot = (size_t)unit * (size_t)G.n + (size_t)(stream - G.first);
+    if (len) *len = G.h_plen[slot];
+    return G.h_pkts + slot * (size_t)G.af_stride;
+}
+int tlb_tick_fragments(const tlb_tick *t, int stream, int unit)
+{
+    if (!t || stream < 0 || stream >= t->nstreams || t->egress != TLB_TICK_EDI_PFT) return 0;
+    const TickGroup &G = t->groups[(size_t)t->group_of[(size_t)stream]];
+    if (unit < 0 || unit >= G.max_upf) return 0;
+    return G.h_nfrag[(size_t)unit * (size_t)G.n + (size_t)(stream - G.first)];
+}
+const uint8_t *tlb_tick_fragment(const tlb_tick *t, int stream, int unit, int k, int *len)
+{
+    if (k < 0 || k >= tlb_tick_fragments(t, stream, unit)) return nullptr;
+    const TickGroup &G = t->groups[(size_t)t->group_of[(size_t)stream]];
+    const size_t slot = (size_t)unit * (size_t)G.n + (size_t)(stream - G.first);
+    if (len) *len = G.h_fraglen[slot * (size_t)G.max_frags + (size_t)k];
+    return G.h_frags + (slot * (size_t)G.max_frags + (size_t)k) * (size_t)G.frag_stride;
+}
+float tlb_tick_last_ms(tlb_tick *t)
+{   // first copy-in queued -> last copy-out done, on the device's clock
+    float ms = -1.0f;
+    if (!t || !t->ticks || hipSetDevice(t->device) != hipSuccess || hipEventSynchronize(t->ev1) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, t->ev0, t->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// legacy nine-function ABI: stream 0 of a private one-stream batch (libtoolame-dab/toolame.h:13-48)
+
+// The reference hands bytes back only when its 4096-byte bit buffer fills (bitstream.c:46-71): about nine calls in ten return 0.
+// The shim knows that cadence arithmetically (frame lengths are a function of the configuration), so it DEFERS the GPU work:
+// a call that returns nothing only files its PCM and X-PAD away (pinned host memory); the call on which a burst is due
+// encodes every frame filed so far as ONE launch -- frames of a stream are independent (stream, frame) units, so ten frames
+// cost one frame's latency -- with one copy in and one copy out.  What the caller sees (return values, bytes, their timing in
+// calls) is unchanged: tests/test_hip_parity.py::test_legacy_abi_burst_cadence on every golden case.
 struct Legacy {
     bool inited = false;
     long samplerate = 48000;       // the reference leaves the rate at its zero-initialised default until set
@@ -1054,9 +1345,36 @@ struct Legacy {
     double frac = 0, lag = 0;                    // the slot recurrence on the host (availbits.c:49-62): length of the frame being encoded
     long frame_num = 0;
     std::deque<unsigned char> fifo;              // final bytes not yet handed to the caller
-    std::vector<unsigned char> frame;            // one frame from the device
+    // deferred frames: pinned host staging for up to kDefer frames (a burst is due long before: 4096 bytes are 78 of the
+    // shortest legal frames), filled call by call, encoded when a burst is due or the staging is full
+    static const int kDefer = 96;
+    int ndefer = 0, stride = 0;
+    int16_t *h_pcm = nullptr; uint8_t *h_xpad = nullptr; int32_t *h_xl = nullptr; uint8_t *h_out = nullptr; int32_t *h_len = nullptr;
+    void release()
+    {
+        tlb_host_free(h_pcm); tlb_host_free(h_xpad); tlb_host_free(h_xl); tlb_host_free(h_out); tlb_host_free(h_len);
+        h_pcm = nullptr; h_xpad = nullptr; h_xl = nullptr; h_out = nullptr; h_len = nullptr;
+    }
 };
 static Legacy g_legacy;
+
+// encode the deferred frames: slot f of the launch carries the frame that became final while frame f was analysed
+static void legacy_run_deferred()
+{
+    Legacy &g = g_legacy;
+    if (!g.ndefer) return;
+    if (int rc = tlb_encode_host_len(g.batch, g.h_pcm, g.ndefer, g.h_xpad, g.h_xl, g.h_out, g.h_len, nullptr)) {
+        // the reference has no error return from this call (it exit()s on its own fatal errors, mem.c:28); losing frames
+        // silently would be worse than stopping
+        fprintf(stderr, "libtoolame-dab-hip: encoding on the GPU failed (error %d)\n", rc);
+        exit(-1);
+    }
+    for (int f = 0; f < g.ndefer; f++) {
+        const unsigned char *p = g.h_out + (size_t)f * (size_t)g.stride;
+        g.fifo.insert(g.fifo.end(), p, p + g.h_len[f]);             // (slot 0 of the very first launch: length 0)
+    }
+    g.ndefer = 0;
+}
 
 static const int kLegacyBuf = 4096;       // common.h BUFFER_SIZE
 
@@ -1077,6 +1395,7 @@ extern "C" {
 int toolame_init(void)
 {
     if (g_legacy.batch) { tlb_destroy(g_legacy.batch); g_legacy.batch = nullptr; }
+    g_legacy.release();
     g_legacy = Legacy();
     g_legacy.inited = true;
     return 0;
@@ -1136,35 +1455,41 @@ int toolame_encode_frame(short buffer[2][1152], unsigned char *xpad_data, size_t
         }
         g.lg_frame = tlb_frame_bytes(g.batch, 0);
         g.frac = g.batch->h_configs[0].pad_frac; g.lag = 0;
-        g.frame.assign((size_t)tlb_out_stride(g.batch), 0);
+        g.stride = tlb_out_stride(g.batch);
+        g.h_pcm = (int16_t *)tlb_host_alloc((size_t)Legacy::kDefer * 2304 * sizeof(int16_t));
+        g.h_xpad = (uint8_t *)tlb_host_alloc((size_t)Legacy::kDefer * TLB_MAX_XPAD);
+        g.h_xl = (int32_t *)tlb_host_alloc((size_t)Legacy::kDefer * sizeof(int32_t));
+        g.h_out = (uint8_t *)tlb_host_alloc((size_t)Legacy::kDefer * (size_t)g.stride);
+        g.h_len = (int32_t *)tlb_host_alloc((size_t)Legacy::kDefer * sizeof(int32_t));
+        if (!g.h_pcm || !g.h_xpad || !g.h_xl || !g.h_out || !g.h_len) { fprintf(stderr, "libtoolame-dab-hip: out of pinned host memory\n"); exit(-1); }
     }
-    // length of THIS frame (the reference's bit buffer fills with it now; its bytes come out of the GPU one call later)
+    // length of THIS frame (the reference's bit buffer fills with it now; its bytes come out of the GPU later)
     int cur_len = g.lg_frame;
     if (g.frac != 0) { if (g.lag > (g.frac - 1.0)) g.lag -= g.frac; else { cur_len++; g.lag += (1 - g.frac); } }
     if (g.frame_num == 0) g.minimum = cur_len + 4;           // toolame.c:298-300: frame 1's length
-    unsigned char xrec[TLB_MAX_XPAD];
+    // file the frame away
+    memcpy(g.h_pcm + (size_t)g.ndefer * 2304, &buffer[0][0], 2304 * sizeof(int16_t));
+    unsigned char *xrec = g.h_xpad + (size_t)g.ndefer * TLB_MAX_XPAD;
     int32_t xl = 0;
-    memset(xrec, 0, sizeof xrec);
+    memset(xrec, 0, TLB_MAX_XPAD);
     if (xpad_len >= 2 && xpad_data && xpad_len <= (size_t)TLB_MAX_XPAD && (int)xpad_len <= g.pad_len) {
         xl = (int32_t)xpad_len;                            // bytes [dab_length-xpad_len, dab_length) in transmission order
         memcpy(xrec, xpad_data + g.pad_len - (int)xpad_len, xpad_len);
     }
-    // the batch keeps its device staging buffers between calls: no allocation per frame after the first
-    int32_t prev_len = 0;
-    if (int rc = tlb_encode_host_len(g.batch, &buffer[0][0], 1, xrec, &xl, g.frame.data(), &prev_len, nullptr)) {
-        // the reference has no error return from this call (it exit()s on its own fatal errors, mem.c:28); losing frames
-        // silently would be worse than stopping
-        fprintf(stderr, "libtoolame-dab-hip: encoding on the GPU failed (error %d)\n", rc);
-        exit(-1);
-    }
+    g.h_xl[g.ndefer] = xl;
+    g.ndefer++;
     g.frame_num++;
-    if (g.frame_num > 1) g.fifo.insert(g.fifo.end(), g.frame.begin(), g.frame.begin() + prev_len);   // frame n-1 is final now
-    // bitstream.c:46-71: when the 4096-byte buffer fills, everything but the newest `minimum` bytes is handed out
+    // bitstream.c:46-71: when the 4096-byte buffer fills, everything but the newest `minimum` bytes is handed out -- bytes of
+    // frames up to the one before this, which are final once this frame's ScF-CRC is known: the deferred frames run now
     int written = 0;
     if (g.fill + cur_len >= kLegacyBuf) {
+        legacy_run_deferred();
         written = legacy_emit(output_buffer, output_buffer_size, (size_t)(kLegacyBuf - g.minimum));
         g.fill = g.minimum + (g.fill + cur_len - kLegacyBuf);
-    } else g.fill += cur_len;
+    } else {
+        g.fill += cur_len;
+        if (g.ndefer == Legacy::kDefer) legacy_run_deferred();
+    }
     return written;
 }
 
@@ -1172,6 +1497,7 @@ int toolame_finish(unsigned char *output_buffer, size_t output_buffer_size)
 {
     Legacy &g = g_legacy;
     if (!g.batch) return 0;
+    legacy_run_deferred();                                   // frames filed since the last burst
     std::vector<unsigned char> last((size_t)tlb_out_stride(g.batch));
     if (g.frame_num > 0) {
         int32_t last_len = 0;
@@ -1181,6 +1507,7 @@ int toolame_finish(unsigned char *output_buffer, size_t output_buffer_size)
     int n = legacy_emit(output_buffer, output_buffer_size, g.fifo.size());
     tlb_destroy(g.batch);
     g.batch = nullptr;
+    g.release();
     g.fill = 0; g.frame_num = 0;
     return n;
 }

@@ -104,6 +104,28 @@ def load_library():
     L.tlb_edi_pft_shape.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.tlb_edi_pft_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int] * 2
     L.tlb_edi_pft_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int] * 2 + [C.c_void_p]
+    L.tlb_tick_create.restype = C.c_void_p
+    L.tlb_tick_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    L.tlb_tick_destroy.argtypes = [C.c_void_p]
+    L.tlb_tick_destroy.restype = None
+    for f in ("tlb_tick_pcm", "tlb_tick_xpad", "tlb_tick_xpad_len", "tlb_tick_peaks"):
+        getattr(L, f).restype = C.c_void_p
+        getattr(L, f).argtypes = [C.c_void_p]
+    for f in ("tlb_tick_run", "tlb_tick_finish"):
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.tlb_tick_count.argtypes = [C.c_void_p]
+    L.tlb_tick_count.restype = C.c_long
+    L.tlb_tick_set_gain_db.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.tlb_tick_units.argtypes = [C.c_void_p, C.c_int]
+    L.tlb_tick_frame.restype = C.c_void_p
+    L.tlb_tick_frame.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.tlb_tick_packet.restype = C.c_void_p
+    L.tlb_tick_packet.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.tlb_tick_fragments.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.tlb_tick_fragment.restype = C.c_void_p
+    L.tlb_tick_fragment.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.tlb_tick_last_ms.argtypes = [C.c_void_p]
+    L.tlb_tick_last_ms.restype = C.c_float
     L.toolame_set_samplerate.argtypes = [C.c_long]
     L.toolame_set_channel_mode.argtypes = [C.c_char]
     L.toolame_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -146,6 +168,110 @@ TAPS_DTYPE = np.dtype([
 ])
 
 
+def _config_array(configs):
+    arr = (_CConfig * len(configs))()
+    for i, c in enumerate(configs):
+        arr[i].samplerate = c.samplerate
+        arr[i].mode = c.mode.encode()[:1]
+        arr[i].bitrate = c.bitrate
+        arr[i].psy_model = c.psy_model
+        arr[i].pad_len = c.pad_len
+    return arr
+
+
+class _CTickConfig(C.Structure):
+    _fields_ = [("egress", C.c_int), ("ngroups", C.c_int), ("with_xpad", C.c_int), ("version", C.c_char_p), ("version_len", C.c_int),
+                ("now_s", C.c_longlong), ("delay_ms", C.c_uint), ("tist", C.c_int), ("tai_utc_offset", C.c_int),
+                ("fec", C.c_int), ("chunk_len", C.c_int), ("transport", C.c_int), ("addr_source", C.c_int), ("dest_port", C.c_int)]
+
+
+class Tick:
+    """tlb_tick_*: the caller's loop body -- ingest, encode, EDI egress -- as one call per tick for every stream of a GPU
+    (src/odr-audioenc.cpp:1030-1051,1139-1163,1208-1225, src/Outputs.cpp:194-261).  `pcm` (and `xpad`, `xpad_len`) are numpy
+    views of the object's pinned host buffers: fill them, run(), read packets()."""
+    EGRESS = {"frames": 0, "af": 1, "pft": 2}
+
+    def __init__(self, configs, egress="af", ngroups=0, with_xpad=False, version=b"", now_s=1700000000, delay_ms=0, tist=False,
+                 tai_utc_offset=37, fec=0, chunk_len=207, transport=False, addr_source=0, dest_port=0, device=0):
+        self.L = load_library()
+        configs = list(configs)
+        self.nstreams = len(configs)
+        self._version = bytes(version)
+        tc = _CTickConfig(self.EGRESS[egress], ngroups, 1 if with_xpad else 0, self._version, len(self._version), int(now_s), int(delay_ms),
+                          1 if tist else 0, int(tai_utc_offset), fec, chunk_len, 1 if transport else 0, addr_source, dest_port)
+        err = C.c_int(0)
+        self.h = self.L.tlb_tick_create(device, self.nstreams, _config_array(configs), C.byref(tc), C.byref(err))
+        if not self.h:
+            raise ToolameError(err.value, "tlb_tick_create")
+        self.egress = egress
+        n = self.nstreams
+        self.pcm = np.ctypeslib.as_array((C.c_int16 * (n * 2 * SAMPLES)).from_address(self.L.tlb_tick_pcm(self.h))).reshape(n, 2 * SAMPLES)
+        self.peaks = np.ctypeslib.as_array((C.c_int16 * (n * 2)).from_address(self.L.tlb_tick_peaks(self.h))).reshape(n, 2)
+        self.xpad = self.xpad_len = None
+        if with_xpad:
+            self.xpad = np.ctypeslib.as_array((C.c_uint8 * (n * MAX_XPAD)).from_address(self.L.tlb_tick_xpad(self.h))).reshape(n, MAX_XPAD)
+            self.xpad_len = np.ctypeslib.as_array((C.c_int32 * n).from_address(self.L.tlb_tick_xpad_len(self.h)))
+        self.units = [self.L.tlb_tick_units(self.h, s) for s in range(n)]
+
+    def set_gain_db(self, gain_db, stream=-1):
+        rc = self.L.tlb_tick_set_gain_db(self.h, stream, float(gain_db))
+        if rc:
+            raise ToolameError(rc, "tlb_tick_set_gain_db")
+
+    def run(self):
+        rc = self.L.tlb_tick_run(self.h)
+        if rc:
+            raise ToolameError(rc, "tlb_tick_run")
+
+    def finish(self):
+        rc = self.L.tlb_tick_finish(self.h)
+        if rc:
+            raise ToolameError(rc, "tlb_tick_finish")
+
+    def last_ms(self):
+        return float(self.L.tlb_tick_last_ms(self.h))
+
+    def frame(self, s):
+        n = C.c_int(0)
+        p = self.L.tlb_tick_frame(self.h, s, C.byref(n))
+        return C.string_at(p, n.value) if p and n.value else b""
+
+    def packets(self, s):
+        """the AF packets of stream s from the last run, one per unit (empty list: none this tick)"""
+        out = []
+        for u in range(self.units[s]):
+            n = C.c_int(0)
+            p = self.L.tlb_tick_packet(self.h, s, u, C.byref(n))
+            if p and n.value:
+                out.append(C.string_at(p, n.value))
+        return out
+
+    def fragments(self, s):
+        """per unit: the list of PFT fragments of stream s from the last run"""
+        out = []
+        for u in range(self.units[s]):
+            fr = []
+            for k in range(self.L.tlb_tick_fragments(self.h, s, u)):
+                n = C.c_int(0)
+                p = self.L.tlb_tick_fragment(self.h, s, u, k, C.byref(n))
+                fr.append(C.string_at(p, n.value))
+            if fr:
+                out.append(fr)
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.pcm = self.peaks = self.xpad = self.xpad_len = None
+            self.L.tlb_tick_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Batch:
     """N independent DAB MP2 encoders on one MI355X (one wavefront per stream)."""
 
@@ -154,13 +280,7 @@ class Batch:
         configs = list(configs)
         if not configs:
             raise ToolameError(18, "empty batch")
-        arr = (_CConfig * len(configs))()
-        for i, c in enumerate(configs):
-            arr[i].samplerate = c.samplerate
-            arr[i].mode = c.mode.encode()[:1]
-            arr[i].bitrate = c.bitrate
-            arr[i].psy_model = c.psy_model
-            arr[i].pad_len = c.pad_len
+        arr = _config_array(configs)
         err = C.c_int(0)
         self.h = self.L.tlb_create(device, len(configs), arr, C.byref(err))
         if not self.h:

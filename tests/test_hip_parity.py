@@ -505,6 +505,32 @@ def test_legacy_abi_burst_cadence(M, path):
     assert b"".join(chunks) == g["data"].tobytes()
 
 
+@pytest.mark.parametrize("fs,mode,kbps,psy,nframes", [(48000, "j", 128, 1, 700), (22050, "m", 8, 1, 400), (24000, "s", 64, 3, 250),
+                                                      (44100, "s", 384, 2, 60), (48000, "s", 192, 0, 300)])
+def test_legacy_abi_deferred_launches(M, fs, mode, kbps, psy, nframes):
+    """The shim files frames away on the calls that return nothing and encodes them in one launch when a burst is due
+    (toolame_hip.hip, Legacy): over hundreds of frames -- many bursts, up to 78 deferred frames per launch at 8 kbps, frames of
+    two lengths at 44.1 / 22.05 kHz, psy 2's chained state across deferred frames -- every call returns what the oracle's
+    bit-buffer emulation returns (bitstream.c:46-71), byte for byte, and toolame_finish hands out the rest."""
+    import ctypes as C
+    L = M.legacy_api()
+    assert L.toolame_init() == 0 and L.toolame_set_samplerate(fs) == 0 and L.toolame_set_psy_model(psy) == 0
+    assert L.toolame_set_channel_mode(mode.encode()) == 0 and L.toolame_set_bitrate(kbps) == 0 and L.toolame_set_pad(0) == 0
+    pcm = gen_pcm(77, 0, 0, nframes)
+    ref, ref_lens = O.oracle_stream(pcm, samplerate=fs, mode=mode, kbps=kbps, psy=psy)
+    out = (C.c_ubyte * 4096)()
+    got, lens = [], []
+    for i in range(nframes):
+        n = L.toolame_encode_frame(np.ascontiguousarray(pcm[i]).ctypes.data, None, 0, out, 4096)
+        got.append(bytes(out[:n]))
+        lens.append(n)
+    n = L.toolame_finish(out, 4096)
+    got.append(bytes(out[:n]))
+    lens.append(n)
+    assert lens == ref_lens and b"".join(got) == ref
+    assert sum(1 for x in lens[:-1] if x) >= 2                     # several bursts were crossed
+
+
 def test_legacy_setters_validate(M):
     """toolame_set_bitrate refuses an illegal rate at the setter, for the MPEG version the sample rate selected
     (toolame.c:212-237 -> BitrateIndex, common.c:95-116), and a too-small output buffer truncates with a message
@@ -639,6 +665,76 @@ def test_edi_af_packets(M):
         assert M.edi_state_init(2, now, delay, tist, 37).tobytes() == E.init_state(2, now, delay, tist, 37).astype(M.EDI_STATE_DTYPE).tobytes()
 
 
+EDI_TICK_CASES = {
+    "48k": [(48000, "j", 128, 1), (48000, "s", 192, 3), (48000, "m", 64, 1), (48000, "s", 128, 0), (48000, "m", 32, 2), (48000, "j", 96, 4)],
+    "mixed_lsf": [(48000, "s", 128, 1), (24000, "s", 64, 1), (24000, "m", 32, 3), (16000, "m", 24, 1)],      # E.CASE_STREAMS shape: 1, 2, 2, 3 units per frame
+}
+
+
+@pytest.mark.parametrize("case", sorted(EDI_TICK_CASES))
+@pytest.mark.parametrize("egress,ngroups", [("af", 1), ("af", 3), ("pft", 2), ("frames", 2)])
+def test_tick_pipeline_equals_stage_by_stage(M, case, egress, ngroups):
+    """tlb_tick_run -- PCIe in, ingest, encode, EDI AF (PFT), PCIe out as ONE call per tick, streams split into groups on three
+    HIP streams -- against the same stages called one by one through the golden-pinned entry points (tlb_ingest_host,
+    tlb_encode_host, tlb_edi_af_host, tlb_edi_pft_host): identical packets / fragments / frames tick by tick, gain applied,
+    the version packet (ODRv) included, the last frame through tlb_tick_finish."""
+    streams = EDI_TICK_CASES[case]
+    cfgs = [M.StreamConfig(samplerate=r, mode=m, bitrate=k, psy_model=p) for r, m, k, p in streams]
+    ns, T = len(cfgs), 14
+    rng = np.random.default_rng(11)
+    inter = np.stack([np.stack([gen_pcm(900 + s, (0, 7, 5, 4)[s % 4], 0, T)[f].T.reshape(-1) for s in range(ns)]) for f in range(T)])   # [T, ns, 2304] L R L R
+    gains = [0.0, -3.0, 0.0, 6.0, 0.0, -9.5][:ns]
+    version = b"odr-audioenc_amd tick"
+    kw = dict(now_s=1712345678, delay_ms=370, tist=True, tai_utc_offset=37)
+    pft = dict(fec=2, chunk_len=207, transport=True, addr_source=4711, dest_port=12000)
+    # ---- stage by stage
+    b = M.Batch(cfgs)
+    for s, g in enumerate(gains):
+        b.set_gain_db(g, s)
+    pcm, peaks = b.ingest(inter)
+    lens = np.zeros((T, ns), dtype=np.int32)
+    frames = np.zeros((T, ns, b.out_stride), dtype=np.uint8)
+    assert b.L.tlb_encode_host_len(b.h, pcm.ctypes.data, T, None, None, frames.ctypes.data, lens.ctypes.data, None) == 0
+    last = np.zeros((1, ns, b.out_stride), dtype=np.uint8)
+    assert b.L.tlb_flush_host(b.h, last[0].ctypes.data) == 0
+    # what leaves on tick f: the frame in output slot f (input frame f-1) with THIS tick's peaks; the finish sends the pending frame with the last peaks
+    fr = np.concatenate([frames[1:], last])
+    lv = np.concatenate([peaks[1:], peaks[-1:]])
+    want_frames = [[fr[f, s, :b.frame_bytes[s]].tobytes() for s in range(ns)] for f in range(T)]
+    if egress != "frames":
+        state = M.edi_state_init(ns, kw["now_s"], kw["delay_ms"], kw["tist"], kw["tai_utc_offset"])
+        pk, pl = b.edi_af(fr, lv, state, version)
+        if egress == "pft":
+            pseq = np.zeros(ns, dtype=np.uint16)
+            fg, fl, nf = b.edi_pft(pk, pl, pseq, **pft)
+    # ---- the pipeline
+    t = M.Tick(cfgs, egress=egress, ngroups=ngroups, version=version, **kw, **(pft if egress == "pft" else {}))
+    for s, g in enumerate(gains):
+        t.set_gain_db(g, s)
+    for f in range(T + 1):
+        if f < T:
+            t.pcm[:] = inter[f]
+            t.run()
+            assert np.array_equal(t.peaks, peaks[f])
+            if f == 0:
+                assert all(not t.packets(s) and not t.fragments(s) and not t.frame(s) for s in range(ns))
+                continue
+        else:
+            t.finish()
+        k = f - 1
+        for s in range(ns):
+            if egress == "frames":
+                assert t.frame(s) == want_frames[k][s], (f, s)
+            elif egress == "af":
+                want = [pk[k * b.max_upf + u, s, :pl[k * b.max_upf + u, s]].tobytes() for u in range(b.units_per_frame[s])]
+                assert t.packets(s) == want, (f, s)
+            else:
+                want = [[fg[k * b.max_upf + u, s, i, :fl[k * b.max_upf + u, s, i]].tobytes() for i in range(nf[k * b.max_upf + u, s])] for u in range(b.units_per_frame[s])]
+                assert t.fragments(s) == want, (f, s)
+    t.close()
+    b.close()
+
+
 def test_edi_pft_fragments(M):
     """SURVEY 8f N2 (PFT part): fragments through the C-ABI equal the golden vectors (reference Reed-Solomon + CRC code under
     the restated PFT.cpp logic, tests/golden/make_golden_edi.py); Pseq carried across calls."""
@@ -663,3 +759,23 @@ def test_edi_pft_fragments(M):
         if E.pft_ref_lib() is not None:
             E.check_reassembly(af, af_len, frags, flen, nfrag, kw["fec"])
         b.close()
+
+
+def test_bench_two_ranks_on_the_gpu():
+    """The multi-rank path of bench.py on real hardware (BASELINE configs[3]): `--gpus 2` starts two fresh rank
+    processes that share this box's one GPU (gloo carries the barriers and the gather; with one GPU per rank it is RCCL), each
+    encodes its own 16384 psy-3 streams, rank 0 prints the line.  What an 8-GPU driver run exercises has then already run on
+    a GPU: process start before any GPU call, sharding, barriers, max over ranks, gather, the post-run oracle check per rank."""
+    import json
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--no-also",
+                        "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["world_size_observed"] == 2 and line["scaling"] == "weak"
+    assert len(line["per_gpu_frames_per_s"]) == 2 and all(v > 0 for v in line["per_gpu_frames_per_s"])
+    assert line["config"]["baseline_config"] == 3 and "configs[3]" in line["config"]["workload"] and line["config"]["streams_per_gpu"] == 16384
+    assert line["value"] > 0 and line["steps"] == 3 and line["output_check"]["checked"]
+    assert line["roofline"]["achieved"] > 0

@@ -13,7 +13,7 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import odr_audioenc_amd as M
 from pcmgen import gen_pcm
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 L = M.legacy_api()
 L.toolame_set_samplerate.argtypes = [C.c_long]
 L.toolame_set_channel_mode.argtypes = [C.c_char]
@@ -27,6 +27,10 @@ for i in range(n):
     t = time.perf_counter()
     L.toolame_encode_frame(pcm[i & 63].ctypes.data, None, 0, out, 4096)
     ts.append(time.perf_counter() - t)
-ts = np.array(ts[20:]) * 1e3
-print(f"toolame_encode_frame, 48 kHz joint stereo 128 kbps psy 1: median {np.median(ts):.3f} ms, p99 {np.percentile(ts, 99):.3f} ms, max {ts.max():.3f} ms "
-      f"per call over {len(ts)} calls (a frame is 24 ms of audio)")
+ts = np.array(ts[32:]) * 1e3
+# the shim defers: calls that return nothing only file the frame away, the call on which the reference's 4096-byte buffer
+# fills (about one in 10.7 here) encodes all filed frames in one launch -- so the MEAN is what a file-to-file run pays per frame
+burst = ts[ts > 10 * np.median(ts)]
+print(f"toolame_encode_frame, 48 kHz joint stereo 128 kbps psy 1: mean {ts.mean():.4f} ms per call ({1e3 / ts.mean():.0f} frames/s through the "
+      f"unchanged ABI), median {np.median(ts):.4f} ms, p99 {np.percentile(ts, 99):.3f} ms, max {ts.max():.3f} ms over {len(ts)} calls; "
+      f"{len(burst)} burst calls, mean {burst.mean() if len(burst) else 0:.3f} ms each (a frame is 24 ms of audio)")
