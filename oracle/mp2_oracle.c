@@ -1047,6 +1047,27 @@ int mp2o_get_table(const mp2o_enc *e, const char *name, double *out, int n)
     else if (!strcmp(name, "p3_ath")) { src = e->p3_ath; len = 513; }
     else if (!strcmp(name, "p3_cbidx")) { for (int i = 0; i <= e->p3_cbands; i++) tmp[i] = e->p3_cbidx[i]; src = tmp; len = e->p3_cbands + 1; }
     else if (!strcmp(name, "p3_subset")) { for (int i = 0; i < 136; i++) tmp[i] = e->p3_subset[i]; src = tmp; len = 136; }
+    /* the psy-1 tables of the encoder's sample rate (entry 0 of ltg[] is never written by the reference) and the allocation
+       tables, as they come out of csrc/mp2_tables.inc: compared with the reference's memory in tests/test_oracle_golden.py */
+    else if (!strcmp(name, "p1_cbound")) { for (int i = 0; i < e->p1_ncb; i++) tmp[i] = e->p1_cbound[i]; src = tmp; len = e->p1_ncb; }
+    else if (!strcmp(name, "p1_line")) { for (int i = 1; i < e->p1_sub; i++) tmp[i - 1] = e->p1_ltg[i].line; src = tmp; len = e->p1_sub - 1; }
+    else if (!strcmp(name, "p1_bark")) { for (int i = 1; i < e->p1_sub; i++) tmp[i - 1] = e->p1_ltg[i].bark; src = tmp; len = e->p1_sub - 1; }
+    else if (!strcmp(name, "p1_hear")) { for (int i = 1; i < e->p1_sub; i++) tmp[i - 1] = e->p1_ltg[i].hear; src = tmp; len = e->p1_sub - 1; }
+    else if (!strcmp(name, "alloc_snr")) { for (int i = 0; i < 18; i++) tmp[i] = (double)TL_SNR_E2[i] / 100.0; src = tmp; len = 18; }
+    else if (!strcmp(name, "alloc_bits")) { for (int i = 0; i < 18; i++) tmp[i] = TL_BITS[i]; src = tmp; len = 18; }
+    else if (!strcmp(name, "alloc_group")) { for (int i = 0; i < 18; i++) tmp[i] = TL_GROUP[i]; src = tmp; len = 18; }
+    else if (!strcmp(name, "alloc_steps")) { for (int i = 0; i < 18; i++) tmp[i] = TL_STEPS[i]; src = tmp; len = 18; }
+    else if (!strcmp(name, "alloc_steps2n")) { for (int i = 0; i < 18; i++) tmp[i] = TL_STEPS2N[i]; src = tmp; len = 18; }
+    else if (!strcmp(name, "alloc_nbal")) { for (int i = 0; i < 9; i++) tmp[i] = TL_NBAL[i]; src = tmp; len = 9; }
+    else if (!strcmp(name, "alloc_table_sblimit")) { for (int i = 0; i < 5; i++) tmp[i] = TL_TABLE_SBLIMIT[i]; src = tmp; len = 5; }
+    else if (!strcmp(name, "alloc_step_index")) { static double big[144]; for (int i = 0; i < 144; i++) big[i] = TL_STEP_INDEX[i]; src = big; len = 144; }
+    else if (!strcmp(name, "alloc_line")) { static double big2[160]; for (int i = 0; i < 160; i++) big2[i] = TL_LINE[i] == 255 ? -1.0 : (double)TL_LINE[i]; src = big2; len = 160; }
+    else if (!strcmp(name, "p2_absthr")) {
+        static double a[513];
+        const int idx = e->fs_idx == 0 ? 1 : e->fs_idx == 1 ? 2 : 0;      /* psycho_2.c:291-306: 32/16 kHz -> 0, 44.1/22.05 -> 1, 48/24 -> 2 */
+        for (int j = 0; j < 513; j++) a[j] = (double)TL_PSY2_ABSTHR_E2[idx * 513 + j] / 100.0;
+        src = a; len = 513;
+    }
     else return -1;
     if (n < len) return -1;
     memcpy(out, src, (size_t)len * sizeof(double));

@@ -86,6 +86,55 @@ pickle.dump(d, open(sys.argv[2], 'wb'))
 """
 
 
+# Every table the product shares with the oracle through csrc/mp2_tables.inc, read out of the REFERENCE's memory after its own
+# init code ran (oracle/Makefile TABLE_TAPS makes the statics visible): psy-1 threshold / critical-band tables and the psy-2
+# absolute threshold per sample rate, the allocation tables once.
+_RATE_CHILD = r"""
+import ctypes as C, sys, numpy as np, pickle
+L = C.CDLL(sys.argv[1]); fs = int(sys.argv[3]); psy = int(sys.argv[4])
+L.toolame_set_samplerate.argtypes = [C.c_long]; L.toolame_set_channel_mode.argtypes = [C.c_char]
+L.toolame_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+L.toolame_init(); L.toolame_set_samplerate(fs); L.toolame_set_psy_model(psy)
+L.toolame_set_channel_mode(b's'); L.toolame_set_bitrate(128 if fs >= 32000 else 64); L.toolame_set_pad(0)
+pcm = ((np.arange(2304) * 7919) % 2001 - 1000).astype(np.int16).reshape(2,1152); out = (C.c_ubyte*4096)()
+L.toolame_encode_frame(pcm.ctypes.data, None, 0, out, 4096)
+d = {}
+if psy == 1:
+    n = C.c_int.in_dll(L, 'sub_size').value; ncb = C.c_int.in_dll(L, 'crit_band').value
+    class G(C.Structure): _fields_ = [('line', C.c_int), ('bark', C.c_double), ('hear', C.c_double), ('x', C.c_double)]
+    ltg = C.cast(C.c_void_p.in_dll(L, 'tlref_tab_ltg').value, C.POINTER(G))
+    d['p1_line'] = np.array([ltg[i].line for i in range(1, n)], dtype=np.int32)
+    d['p1_bark'] = np.array([ltg[i].bark for i in range(1, n)]); d['p1_hear'] = np.array([ltg[i].hear for i in range(1, n)])
+    cb = C.cast(C.c_void_p.in_dll(L, 'cbound').value, C.POINTER(C.c_int))
+    d['p1_cbound'] = np.array([cb[i] for i in range(ncb)], dtype=np.int32)
+    g = lambda name, ct, n: np.ctypeslib.as_array((ct*n).in_dll(L, 'tlref_tab_' + name)).copy()
+    d.update(alloc_snr=g('SNR', C.c_double, 18), alloc_bits=g('bits', C.c_int, 18), alloc_group=g('group', C.c_int, 18),
+             alloc_steps=g('steps', C.c_int, 18), alloc_steps2n=g('steps2n', C.c_int, 18), alloc_nbal=g('nbal', C.c_int, 9),
+             alloc_table_sblimit=g('table_sblimit', C.c_int, 5), alloc_step_index=g('step_index', C.c_int, 144), alloc_line=g('line', C.c_int, 160))
+else:
+    a = C.cast(C.c_void_p.in_dll(L, 'tlref_tab_absthr').value, C.POINTER(C.c_double))
+    d['p2_absthr'] = np.array([a[i] for i in range(513)])
+pickle.dump(d, open(sys.argv[2], 'wb'))
+"""
+RATES = (48000, 44100, 32000, 24000, 22050, 16000)
+
+
+def make_rate_tables():
+    d = {}
+    for fs in RATES:
+        for psy in (1, 2):
+            tmp = HERE / f"_rt{fs}_{psy}.pkl"
+            subprocess.run([sys.executable, "-c", _RATE_CHILD, str(O.REF_SO), str(tmp), str(fs), str(psy)], check=True, stderr=subprocess.DEVNULL)
+            for k, v in pickle.load(open(tmp, "rb")).items():
+                if k.startswith("alloc_"):
+                    assert k not in d or np.array_equal(d[k], v)
+                    d[k] = v
+                else:
+                    d[f"{k}_{fs}"] = v
+            tmp.unlink()
+    np.savez_compressed(HERE / "tables_rates.npz", **d)
+
+
 def make_tables():
     d = {}
     for psy in ("1", "3"):
@@ -101,6 +150,9 @@ def main():
     if not O.REF_SO.exists():
         subprocess.run(["make", "-C", str(O.ORACLE_DIR), "ref"], check=True)
     make_tables()
+    make_rate_tables()
+    if "--tables-only" in sys.argv:
+        return
     total = 0
     for case in cases():
         if "--only-missing" in sys.argv and (HERE / (case["name"] + ".npz")).exists():

@@ -85,6 +85,26 @@ def test_tables_match_reference(golden_dir):
     assert np.array_equal(_bits(g["multiple"]), _bits(g["scalefactor"]))
 
 
+@pytest.mark.parametrize("fs", (48000, 44100, 32000, 24000, 22050, 16000))
+def test_shared_tables_match_reference_memory(golden_dir, fs):
+    """csrc/mp2_tables.inc is shared by the product and the oracle, so end-to-end bytes alone would not notice a table both got
+    wrong where no test signal reaches.  Every such table -- psy-1 threshold (line, bark, hear) and critical-band tables and the
+    psy-2 absolute threshold of all six sample rates, the allocation tables -- against what the REFERENCE holds in memory after
+    its own init code ran (tests/golden/make_golden.py make_rate_tables; critband.h, freqtable.h, absthr.h, encode_new.c:16-100)."""
+    g = np.load(golden_dir / "tables_rates.npz")
+    e = O.OracleEncoder(samplerate=fs, kbps=128 if fs >= 32000 else 64, psy=1)
+    L = O.lib()
+    L.mp2o_get_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+    buf = np.zeros(1024, dtype=np.float64)
+    names = ["p1_line", "p1_bark", "p1_hear", "p1_cbound", "p2_absthr"] + sorted(k for k in g.files if k.startswith("alloc_"))
+    for name in names:
+        ref = np.asarray(g[name if name.startswith("alloc_") else f"{name}_{fs}"], dtype=np.float64).ravel()
+        n = L.mp2o_get_table(e.h, name.encode(), buf.ctypes.data, 1024)
+        assert n == len(ref), (name, n, len(ref))
+        assert np.array_equal(_bits(buf[:n]), _bits(ref)), name
+    assert len(g["p2_absthr_48000"]) == 513 and len(names) == 14
+
+
 def test_burst_cadence_128k():
     """0 bytes for 10 calls, 3708 on the 11th, ... and finish() flushes the rest."""
     pcm = gen_pcm(1, 0, 0, 24)
