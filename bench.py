@@ -503,23 +503,23 @@ def main():
             n1 = 16384
             r1 = GpuRun(M, torch, np, gen_pcm, [0], n1 // 2, args.mode, psy, local_rank)
             e1, _, k1 = r1.timed(None, shard, 2, 6)
-            r1.check()
+            chk1 = r1.check()
             r1.close()
             also["one_stream"] = {"workload": f"1 stream x {n1 // 2} frames per launch (48 kHz stereo 128 kbps, psy {psy}, mode '{args.mode}'; BASELINE configs[0] "
                                               "is this stream on the CPU reference)", "value": round((n1 // 2) * 6 / e1, 1), "unit": "frames/s",
-                                  "x_realtime": round((n1 // 2) * 6 / e1 / (FS / 1152.0), 1), "kernel_ms": round(k1, 4)}
+                                  "x_realtime": round((n1 // 2) * 6 / e1 / (FS / 1152.0), 1), "kernel_ms": round(k1, 4), "output_check": chk1}
         except Exception as ex:  # noqa: BLE001
             also["one_stream"] = {"value": None, "error": str(ex)}
         try:     # the whole population of BASELINE configs[3] (131072 streams, psy 3) on ONE GPU, one 24-ms frame each per launch
             nt = 131072
             rt = GpuRun(M, torch, np, gen_pcm, list(range(nt)), 1, args.mode, 3, local_rank, distinct=4096)
             et, _, kt = rt.timed(None, shard, 2, 6)
-            rt.check()
+            chkt = rt.check()
             rt.close()
             also["tick_131072"] = {"workload": f"{nt} streams x 1 frame per launch on one GPU (48 kHz stereo 128 kbps, psy 3, mode '{args.mode}'): "
                                                "one real-time tick of everything BASELINE configs[3] spreads over 8 GPUs; 4096 distinct signals, repeated",
                                    "value": round(nt * 6 / et, 1), "unit": "frames/s", "kernel_ms": round(kt, 4),
-                                   "share_of_the_24_ms_tick": round(kt / 24.0, 4)}
+                                   "share_of_the_24_ms_tick": round(kt / 24.0, 4), "output_check": chkt}
         except Exception as ex:  # noqa: BLE001
             also["tick_131072"] = {"value": None, "error": str(ex)}
         try:

@@ -147,7 +147,14 @@ int tlb_silence_host(tlb_batch *b, const int16_t *peaks, int nframes, uint32_t *
  * out by SLOT v = frame * tlb_egress_max_units_per_frame() + unit: [nframes * max_upf][nstreams][...]; a stream with fewer
  * units per frame than the batch's maximum leaves its surplus slots absent (length / datasize 0).  For an all-48-kHz batch
  * max_upf is 1 and a slot is a frame.  32 kHz (1.5 units per frame) is not a DAB rate (odr-audioenc.cpp:560-563); a batch
- * that contains it has max_upf 0 and the egress calls return TLB_ERR_SAMPLERATE. */
+ * that contains it has max_upf 0 and the egress calls return TLB_ERR_SAMPLERATE.
+ * TIMING AND LEVELS differ from the reference's send loop in one documented way: odr-audioenc.cpp:1213 drains its deque with
+ * `while (toolame_buffer.size() > frame_len)` -- strictly greater -- so one unit is always held back until more bytes arrive, and
+ * every send_frame() carries the peak levels current at SEND time.  The batch calls emit every unit of a frame in that frame's
+ * slots with the levels the caller passes for that slot (tlb_tick_run passes the run's own peaks, i.e. levels current at send
+ * time like the reference, but does not hold a unit back).  Payload bytes, their order, DLFC / SEQ / timestamps per unit are
+ * identical; a byte-compare against a live ZMQ / EDI capture of the reference therefore lines up on everything except which
+ * audio-level pair rides with which unit (off by the reference's one-unit lag). */
 int tlb_egress_unit_bytes(const tlb_batch *b, int stream);          /* 3 * kbps */
 int tlb_egress_units_per_frame(const tlb_batch *b, int stream);     /* 1, 2, 3; 0 = not a whole number */
 int tlb_egress_max_units_per_frame(const tlb_batch *b);

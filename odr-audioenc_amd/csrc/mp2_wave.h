@@ -1853,8 +1853,8 @@ TL_FN void tl_psy3_stereo(TlPsyLds &w, const TlTables *TL_RESTRICT T, const doub
 // Line-parallel: FFT, unpredictability (sincos/atan2/sqrt per line), thresholds; partition-parallel:
 // grouping, spreading, SNR.  Every sum is one lane's sequential chain in the reference's order.
 TL_FN void tl_psy2(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_RESTRICT P,
-                   TlPsy2State *TL_RESTRICT S, const TlPcmView &pv, int ch, long long *sp, double *smr_out)
-{
+                   TlPsy2State *TL_RESTRICT S, const TlPcmView &pv, int ch, long long *sp, double *smr_out, const uint64_t *sct)
+{   // sct: glibc's __sincostab (tl_libm.h), the workgroup's LDS copy on the device
     double *x = w.u.fft;
     double *cw = w.px, *ge = w.u.fft + 520;  // c[] (unpredictability), then fthr[]; partition sums in the
     double *gc = ge + 64, *ecb = gc + 64, *nb = ecb + 64;   // dead upper half of the FHT buffer
@@ -1912,43 +1912,69 @@ TL_FN void tl_psy2(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
         TL_LANES_BEGIN
         L(r_o) = S->r[ch][old][lane]; L(r_n) = S->r[ch][nw][lane]; L(p_o) = S->phi[ch][old][lane]; L(p_n) = S->phi[ch][nw][lane];
         TL_LANES_END
-        for (int it = 0; it < 9; it++) {
-            PV(double, xa); PV(double, xb);
+        // Lines 0..511 are eight full steps of the wave; line 512 would be a ninth with ONE lane at work, at the price of a full
+        // step (two sincos, an atan2, two square roots for every lane).  It needs no arctangent of its own (its phase is 0 or pi,
+        // fft.c:1274) and line 0 needs none either and no sincos of its phase (phi = 0, fft.c:1257-1259), so in step 0 lane 0 puts
+        // line 512's PREDICTED phase through its first sincos slot and finishes that line with a few extra operations.
+        PV(double, e512);
+        for (int it = 0; it < 8; it++) {
+            PV(double, xa); PV(double, xb); PV(double, xc);
             TL_LANES_BEGIN
             const int j = lane + 64 * it;
-            L(xa) = j <= 512 ? x[TL_FX(j)] : 0.0;
-            L(xb) = (j >= 1 && j < 512) ? x[TL_FX(1024 - j)] : 0.0;
+            L(xa) = x[TL_FX(j)];
+            L(xb) = j >= 1 ? x[TL_FX(1024 - j)] : 0.0;
+            L(xc) = it == 0 ? x[TL_FX(512)] : 0.0;
             TL_LANES_END
             TL_LANES_BEGIN
             const int j = lane + 64 * it;
-            if (j <= 512) {
-                const int jn = j + 64 <= 512 ? j + 64 : j;
+            {
+                const bool first = j == 0;                           // lane 0 of step 0: lines 0 and 512
+                const int jn = j + 64 <= 511 ? j + 64 : j;
                 const double r_o2 = S->r[ch][old][jn], r_n2 = S->r[ch][nw][jn], p_o2 = S->phi[ch][old][jn], p_n2 = S->phi[ch][nw][jn];
-                double e, phi;
-                if (j == 0) { e = L(xa) * L(xa); phi = 0.0; }
-                else if (j == 512) { e = L(xa) * L(xa); phi = tlm_atan2_sl(0.0, L(xa), tlm_atan_cij); }
-                else {
-                    const double a = L(xa), b = L(xb);
-                    e = (a * a + b * b) / 2.0;
-                    if (e < 0.0005) { e = 0.0005; phi = 0; }
-                    else phi = tlm_atan2_sl(-a, b, tlm_atan_cij) + 3.14159265358979 / 4;
-                }
+                double r_o5 = 0, r_n5 = 0, p_o5 = 0, p_n5 = 0;      // state of line 512
+                if (it == 0) { const int jl = first ? 512 : j; r_o5 = S->r[ch][old][jl]; r_n5 = S->r[ch][nw][jl]; p_o5 = S->phi[ch][old][jl]; p_n5 = S->phi[ch][nw][jl]; }
+                const double a = L(xa), b = L(xb);
+                double e = (a * a + b * b) / 2.0;
+                const bool low = e < 0.0005;
+                double phi = tlm_atan2_sl<false>(-a, b, tlm_atan_cij) + 3.14159265358979 / 4;
+                e = TL_SELECT(low, 0.0005, e); phi = TL_SELECT(low, 0.0, phi);
+                e = TL_SELECT(first, a * a, e); phi = TL_SELECT(first, 0.0, phi);      // line 0: energy x_real[0]^2, phase 0
                 const double r_prime = 2.0 * L(r_o) - L(r_n);
                 const double phi_prime = 2.0 * L(p_o) - L(p_n);
                 const double rn = sqrt(e);
                 S->r[ch][nw][j] = rn; S->phi[ch][nw][j] = phi;
                 double sp, cp, spp, cpp;
-                tlm_sincos_sl(phi, &sp, &cp, tlm_sincostab);
-                tlm_sincos_sl(phi_prime, &spp, &cpp, tlm_sincostab);
+                tlm_sincos_sl(TL_SELECT(first, 2.0 * p_o5 - p_n5, phi), &sp, &cp, sct);
+                tlm_sincos_sl(phi_prime, &spp, &cpp, sct);
+                const double spp5 = sp, cpp5 = cp;                   // sincos of line 512's predicted phase (lane 0 of step 0)
+                sp = TL_SELECT(first, 0.0, sp); cp = TL_SELECT(first, 1.0, cp);         // sincos(0.0)
                 const double t1 = rn * cp - r_prime * cpp;
                 const double t2 = rn * sp - r_prime * spp;
                 const double t3 = rn + fabs(r_prime);
                 cw[j] = t3 != 0 ? sqrt(t1 * t1 + t2 * t2) / t3 : 0;
                 x[j] = e;
+                if (it == 0) {                                       // line 512 (psycho_2.c:110-140 with fft.c:1274's phase), finished by lane 0
+                    const double c5 = L(xc);
+                    const double e5 = c5 * c5;
+                    const bool neg5 = (tl_d2u(c5) >> 63) != 0;       // atan2(+0.0, x) = pi for x < 0 and x = -0, else +0
+                    const double phi5 = neg5 ? tl_u2d(0x400921fb54442d18ull) : 0.0;
+                    const double sp5 = neg5 ? tl_u2d(0x3ca1a62633145c07ull) : 0.0, cp5 = neg5 ? -1.0 : 1.0;   // glibc's sincos of that pi / of 0
+                    const double rn5 = sqrt(e5);
+                    const double r_prime5 = 2.0 * r_o5 - r_n5;
+                    const double t15 = rn5 * cp5 - r_prime5 * cpp5;
+                    const double t25 = rn5 * sp5 - r_prime5 * spp5;
+                    const double t35 = rn5 + fabs(r_prime5);
+                    const double c512 = t35 != 0 ? sqrt(t15 * t15 + t25 * t25) / t35 : 0;
+                    if (first) { S->r[ch][nw][512] = rn5; S->phi[ch][nw][512] = phi5; cw[512] = c512; }
+                    L(e512) = e5;                                    // slot 512 of the transform buffer still holds a point step 7 reads
+                }
                 L(r_o) = r_o2; L(r_n) = r_n2; L(p_o) = p_o2; L(p_n) = p_n2;
             }
             TL_LANES_END
         }
+        TL_LANES_BEGIN
+        if (lane == 0) x[512] = L(e512);
+        TL_LANES_END
         TL_STAMP(sq, 2);
         const double *energy = x;
         // grouped energy / weighted unpredictability per partition (psycho_2.c:146-155)
@@ -2783,7 +2809,7 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
 // Models 2 and 4 on the split path.  The model carries r/phi of the two previous passes per channel (psycho_2.c:300-306), so
 // the frames of a channel are a chain -- but the two channels of a stream share nothing: one unit = all frames of the launch
 // of ONE channel of one stream, in order.  It leaves the SMR itself in TlPsyOut::a (the model's last line needs no scalefactors).
-TL_FN void tl_psy2_chain(TlPsy2Lds &w, const TlLaunch &A, int s, int ch)
+TL_FN void tl_psy2_chain(TlPsy2Lds &w, const TlLaunch &A, int s, int ch, const uint64_t *sct)
 {
     const TlConfig *C = &A.configs[A.stream_cfg[s]];
     if (ch >= C->nch) return;
@@ -2791,7 +2817,7 @@ TL_FN void tl_psy2_chain(TlPsy2Lds &w, const TlLaunch &A, int s, int ch)
         const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
         const TlPcmView pv = tl_pcm_view(A, &A.state[s], s, f);
         tl_psy2(w, A.tables, &A.psy2_tables[C->psy2_tab], &A.psy2_state[s], pv, ch,
-                A.stamps ? A.stamps + slot * 32 + 8 + 8 * ch : nullptr, &A.psy_out[slot].a[ch][0]);
+                A.stamps ? A.stamps + slot * 32 + 8 + 8 * ch : nullptr, &A.psy_out[slot].a[ch][0], sct);
     }
 }
 

@@ -86,7 +86,7 @@ TLM_HD double tlm_log_main(uint64_t ix, TAB tab)
                  A3 = tlm_u2d(tlm_log_poly[3]), A4 = tlm_u2d(tlm_log_poly[4]);
     const uint64_t tmp = ix - 0x3fe6000000000000ull;
     const int i = (int)(tmp >> 45) & 127;
-    const int k = (int)((int64_t)tmp >> 52);
+    const int k = (int32_t)(uint32_t)(tmp >> 32) >> 20;            // (int64_t)tmp >> 52, from the high word (one shift, one 32-bit convert)
     const uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
     const double invc = tlm_u2d(tab[2 * i]), logc = tlm_u2d(tab[2 * i + 1]);
     const double z = tlm_u2d(iz);
@@ -243,7 +243,7 @@ TLM_HD double tlm_pow_log(uint64_t ix, double *tail)
                  A6 = tlm_u2d(tlm_powlog_head[8]);
     const uint64_t tmp = ix - 0x3fe6955500000000ull;
     const int i = (int)(tmp >> 45) & 127;
-    const int k = (int)((int64_t)tmp >> 52);
+    const int k = (int32_t)(uint32_t)(tmp >> 32) >> 20;            // (int64_t)tmp >> 52, from the high word (one shift, one 32-bit convert)
     const uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
     const double z = tlm_u2d(iz), kd = (double)k;
     const double invc = tlm_u2d(tlm_powlog_tab[4 * i]), logc = tlm_u2d(tlm_powlog_tab[4 * i + 2]),
@@ -556,7 +556,11 @@ TLM_HD void tlm_sincos_sl(double x, double *sinx, double *cosx, TAB tab)
 
 // atan2 for finite arguments: one quotient / remainder pair, both evaluation forms (polynomial below 1/16, table row
 // above), the four quadrant combinations selected at the end.
-template <typename TAB>
+// SCALE = false leaves out e_atan2.c's rescaling of operands below 2^-500 / above 2^500.  That is the same function wherever
+// max(|y|, |x|) lies in [2^-443, 2^500]: an operand below 2^-500 is then more than 57 binades from the other, the result comes
+// from the extreme-ratio branches (which use the unscaled operands) and the quotient path's value is discarded.  The encoder's
+// spectra qualify (|.| < 2^25, and the call is only made when a*a + b*b >= 0.001).
+template <bool SCALE = true, typename TAB>
 TLM_HD double tlm_atan2_sl(double y, double x, TAB cij)
 {
     const double hpi = TLM_D(0x3ff921fb54442d18), hpi1 = TLM_D(0x3c91a62633145c07), opi = TLM_D(0x400921fb54442d18),
@@ -569,10 +573,12 @@ TLM_HD double tlm_atan2_sl(double y, double x, TAB cij)
     double ax = tlm_u2d(bx & 0x7fffffffffffffffull), ay = tlm_u2d(by & 0x7fffffffffffffffull);
     const double ax0 = ax, ay0 = ay;
     const int32_t de = (uy & 0x7ff00000) - (ux & 0x7ff00000);
-    const bool dn = ax < 0x1p-500 || ay < 0x1p-500;
-    ax = dn ? ax * 0x1p500 : ax; ay = dn ? ay * 0x1p500 : ay;
-    const bool up = ax > 0x1p500 || ay > 0x1p500;
-    ax = up ? ax * 0x1p-500 : ax; ay = up ? ay * 0x1p-500 : ay;
+    if (SCALE) {
+        const bool dn = ax < 0x1p-500 || ay < 0x1p-500;
+        ax = dn ? ax * 0x1p500 : ax; ay = dn ? ay * 0x1p500 : ay;
+        const bool up = ax > 0x1p500 || ay > 0x1p500;
+        ax = up ? ax * 0x1p-500 : ax; ay = up ? ay * 0x1p-500 : ay;
+    }
     const bool ylx = ay < ax;
     const double num = ylx ? ay : ax, den = ylx ? ax : ay;
     const double u = num / den;

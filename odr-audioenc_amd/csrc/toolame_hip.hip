@@ -106,15 +106,18 @@ static __device__ __forceinline__ bool tl_take_unit(int32_t *heads, int nlist, i
 #ifndef TL_PSY2_WAVES
 #define TL_PSY2_WAVES 12
 #endif
-static_assert((TL_PSY2_WAVES * sizeof(TlPsy2Lds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "twelve psy-2 waves per CU");
+static_assert((TL_PSY2_WAVES * sizeof(TlPsy2Lds) + 440 * 8 + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "twelve psy-2 waves per CU");
 __global__ void __launch_bounds__(64 * TL_PSY2_WAVES) __attribute__((amdgpu_waves_per_eu(TL_PSY2_WAVES / 4, TL_PSY2_WAVES / 4))) tl_psy2_kernel(TlLaunch A)
 {
     __shared__ TlPsy2Lds lds[TL_PSY2_WAVES];
+    __shared__ __attribute__((aligned(16))) uint64_t sct[440];      // glibc's sincos table: two 16-byte gathers per sincos stay on the CU
+    for (int i = (int)threadIdx.x; i < 440; i += 64 * TL_PSY2_WAVES) sct[i] = tlm_sincostab[i];
+    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nunits = 2 * A.nlist, nwaves = (int)gridDim.x * TL_PSY2_WAVES;
     for (int u = (int)blockIdx.x * TL_PSY2_WAVES + wave; u < nunits; u = nwaves + tl_next_unit(&A.work[0])) {
         const int ch = u >= A.nlist ? 1 : 0, k = u - ch * A.nlist;
-        tl_psy2_chain(lds[wave], A, __builtin_amdgcn_readfirstlane(A.stream_list[k]), ch);
+        tl_psy2_chain(lds[wave], A, __builtin_amdgcn_readfirstlane(A.stream_list[k]), ch, sct);
     }
 }
 

@@ -95,7 +95,7 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
     auto model = [&](int s) { return e->configs[e->stream_cfg[s]].psy; };
     for (int ch = 1; ch >= 0; ch--)
         for (int s = 0; s < A.nstreams; s++)
-            if (model(s) == 2 || model(s) == 4) tl_psy2_chain(wq, A, s, ch);
+            if (model(s) == 2 || model(s) == 4) tl_psy2_chain(wq, A, s, ch, tlm_sincostab);
     if (pads) for (int s = 0; s < A.nstreams; s++) tl_slots_stream(A, s);
     for (int s = 0; s < A.nstreams; s++)
         for (int f = nframes - 1; f >= 0; f--) {

@@ -51,7 +51,7 @@ struct Tally {
 
 static Tally T_log{"log"}, T_log10{"log10"}, T_log10pn{"log10 (straight-line form, positive normal)"}, T_exp{"exp"},
     T_pow10{"pow(10, y)"}, T_pow{"pow(x > 0, y)"}, T_sin{"sincos: sin"}, T_cos{"sincos: cos"}, T_atan2{"atan2"},
-    T_sinsl{"sincos, straight-line form: sin"}, T_cossl{"sincos, straight-line form: cos"}, T_atan2sl{"atan2, straight-line form"}, T_expsl{"exp, straight-line form (|x| < 512)"},
+    T_sinsl{"sincos, straight-line form: sin"}, T_cossl{"sincos, straight-line form: cos"}, T_atan2sl{"atan2, straight-line form"}, T_atan2ns{"atan2, straight-line, no rescaling (max|.| in [2^-443, 2^500])"}, T_expsl{"exp, straight-line form (|x| < 512)"},
     T_pow10sl{"pow(10, y), straight-line form (|y| < 222)"};
 
 static void chk1(Tally &t, double x, double got, double want)
@@ -148,6 +148,12 @@ static void worker(int id, uint64_t per_fn, uint64_t seed)
             T_atan2sl.n++;
             const double got2 = tlm_atan2_sl(y, xx, tlm_atan_cij);
             if (!same(got2, want)) T_atan2sl.miss("y=%a x=%a got %a want %a", y, xx, got2, want);
+            const double big = fabs(y) > fabs(xx) ? fabs(y) : fabs(xx);
+            if (big >= 0x1p-443 && big <= 0x1p500) {          // the domain of the form without operand rescaling
+                T_atan2ns.n++;
+                const double got3 = tlm_atan2_sl<false>(y, xx, tlm_atan_cij);
+                if (!same(got3, want)) T_atan2ns.miss("y=%a x=%a got %a want %a", y, xx, got3, want);
+            }
         }
     }
 }
@@ -169,11 +175,19 @@ int main(int argc, char **argv)
                (unsigned long long)tlm_d2u(hi), (unsigned long long)tlm_d2u(lo), ok ? "match" : "DO NOT MATCH");
         if (!ok) return 1;
     }
+    {   // the constants line 512 of psy model 2 uses (mp2_wave.h tl_psy2): sincos of the double nearest pi, atan2(+0, x < 0)
+        double s0, c0;
+        sincos(3.141592653589793116, &s0, &c0);
+        const bool ok = tlm_d2u(s0) == 0x3ca1a62633145c07ull && tlm_d2u(c0) == 0xbff0000000000000ull &&
+                        tlm_d2u(atan2(0.0, -1.0)) == 0x400921fb54442d18ull && tlm_d2u(atan2(0.0, -0.0)) == 0x400921fb54442d18ull && atan2(0.0, 2.0) == 0.0;
+        printf("sincos(pi) = (%a, %a), atan2(+0, -1) = %a: constants in mp2_wave.h %s\n", s0, c0, atan2(0.0, -1.0), ok ? "match" : "DO NOT MATCH");
+        if (!ok) return 1;
+    }
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nthreads; t++) th.emplace_back(worker, (int)t, per, seed);
     for (auto &t : th) t.join();
     uint64_t bad = 0;
-    for (Tally *t : {&T_log, &T_log10, &T_log10pn, &T_exp, &T_pow10, &T_pow, &T_sin, &T_cos, &T_atan2, &T_sinsl, &T_cossl, &T_atan2sl, &T_expsl, &T_pow10sl}) {
+    for (Tally *t : {&T_log, &T_log10, &T_log10pn, &T_exp, &T_pow10, &T_pow, &T_sin, &T_cos, &T_atan2, &T_sinsl, &T_cossl, &T_atan2sl, &T_atan2ns, &T_expsl, &T_pow10sl}) {
         printf("%-48s %12llu arguments  %llu differ (%.4f %% bit-equal)\n", t->name, (unsigned long long)t->n.load(),
                (unsigned long long)t->bad.load(), 100.0 * (double)(t->n - t->bad) / (double)t->n);
         for (auto &e : t->examples) printf("    %s\n", e.c_str());
