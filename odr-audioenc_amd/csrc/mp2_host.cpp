@@ -1,5 +1,6 @@
 // mp2_host.cpp -- see mp2_host.h.  Compiled with -ffp-contract=off.
 #include "mp2_host.h"
+#include "tl_libm.h"
 
 #include <math.h>
 #include <string.h>
@@ -133,6 +134,8 @@ void tl_build_tables(TlTables *T)
         T->shared.dbtable[i] = T->dbtable[i];
     }
     T->shared.dbtable[1000] = -0.0; T->shared.dbtable[1001] = -0.0;
+    for (int i = 0; i < 1002; i++) T->dblog[i] = T->shared.dbtable[i];
+    for (int i = 0; i < 256; i++) T->dblog[1002 + i] = tlm_u2d(tlm_log_tab[i]);
     // Buneman recurrence of fft.c:1139-1149 unrolled into a table (passes k = 2,4,6,8)
     int n = 0;
     for (int k = 2; k <= 8; k += 2) {

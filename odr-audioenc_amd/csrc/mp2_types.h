@@ -57,6 +57,8 @@ struct TlTables {
     uint8_t rs_log[256], rs_exp[512];   // GF(2^8), field polynomial 0x11d: log (255 for 0) and antilog (doubled, no modulo)
     uint8_t rs_mlog[207][48];    // log of M[i][j]: parity byte j of the RS(255,207) codeword of the unit chunk e_i (csrc/edi_pft.h)
     uint16_t edi_xpow8[2048];    // x^(8k) mod (x^16+x^12+x^5+1): AF-packet CRC chunks (csrc/edi_af.h; contrib/crc.c:247-255)
+    double dblog[1002 + 256];    // what the model phase keeps in LDS: the dB-sum table as in `shared` ([0..1001]) followed by glibc's log table
+                                 // (tl_libm.h tlm_log_tab, 128 x {invc, logc} as bit patterns): TL_LOGTAB(db)
     TlBlockShared shared;
 };
 

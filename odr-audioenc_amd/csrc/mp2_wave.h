@@ -688,10 +688,11 @@ TL_FN void tl_psy_spectrum(TlPsyLds &w, const TlTables *TL_RESTRICT T, const TlP
 // The logarithm is glibc 2.35's own (tl_libm.h: table-driven log, no division, then e_log10.c's recombination) -- bit-equal to
 // the reference's libm by construction.  That matters: on degenerate spectra (a lone impulse: hundreds of lines of nearly
 // equal level) the tone tests and the allocation compare values that differ in the last bits (GPU soak, round 2).
-TL_FN double tl_power_db(double e)
+#define TL_LOGTAB(db) ((const uint64_t *)((db) + 1002))     /* the log table rides behind the dB-sum table in the workgroup's LDS block (TlTables::dblog) */
+TL_FN double tl_power_db(double e, const uint64_t *lt)
 {
     const bool tiny = e < 1E-20;
-    const double v = 10 * tlm_log10_pn(TL_SELECT(tiny, 1.0, e), tlm_log_tab) + TL_POWERNORM;
+    const double v = 10 * tlm_log10_pn(TL_SELECT(tiny, 1.0, e), lt) + TL_POWERNORM;
     return TL_SELECT(tiny, -200.0 + TL_POWERNORM, v);
 }
 TL_FN int tl_run_psy1(int c) { return (c < 3 || c > 500) ? 0 : c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 12; }   // psycho_1.c:289-298
@@ -770,7 +771,7 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int q = 0; q < 4; q++) v[q] = tl_power_db(e[q]);
+        for (int q = 0; q < 4; q++) v[q] = tl_power_db(e[q], TL_LOGTAB(db));
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
@@ -793,7 +794,7 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
 #pragma unroll
 #endif
         for (int j = 0; j < 16; j++) sum += 1073741824 * e[j];
-        const double spk = 10.0 * tlm_log10_pn(sum, tlm_log_tab);
+        const double spk = 10.0 * tlm_log10_pn(sum, TL_LOGTAB(db));
         L(rec)[ch] = spk;                                           // final as it is: straight to the record (nothing to park)
     } else if (lane < 32) L(rec)[ch] = 0.0;
     TL_LANES_END
@@ -1454,7 +1455,7 @@ TL_FN int tl_psy3_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int q = 0; q < 4; q++) v[q] = tl_power_db(e[q]);
+        for (int q = 0; q < 4; q++) v[q] = tl_power_db(e[q], TL_LOGTAB(db));
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
@@ -1484,7 +1485,7 @@ TL_FN int tl_psy3_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double
         TL_LANES_END
     }
     TL_LANES_BEGIN
-    if (lane == 0) px[512] = tl_power_db(energy[512]);
+    if (lane == 0) px[512] = tl_power_db(energy[512], TL_LOGTAB(db));
     TL_LANES_END
     // ---- tone labelling (psycho_3.c:186-247) ----
     // (1) local maxima 2..499 whose right-hand neighbours are >= 7 dB down, compacted ascending

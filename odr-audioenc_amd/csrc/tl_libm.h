@@ -30,7 +30,7 @@
 #include <string.h>
 
 #if defined(__HIPCC__)
-#define TLM_HD __host__ __device__ __forceinline__
+#define TLM_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define TLM_HD static inline
 #endif

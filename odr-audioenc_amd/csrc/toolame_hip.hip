@@ -155,15 +155,15 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
 // the filterbank fills its 72 sample registers (round 1's fused kernel ran it in the middle: 256).  LDS: the union of the
 // two phases' blocks; both table sets (dB sums 7.8 KB, encoder 12.1 KB) once per workgroup.  The PCM the model read is still
 // in L2 when the encoder stages it.
-static_assert((sizeof(double) * 1002 + sizeof(TlMainShared) + TL_MAIN_WAVES * sizeof(TlFrameLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "the workgroup fits a CU");
+static_assert((sizeof(double) * 1258 + sizeof(TlMainShared) + TL_MAIN_WAVES * sizeof(TlFrameLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "the workgroup fits a CU");
 template <int PSY>
 __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_waves_per_eu(TL_MAIN_WPE, TL_MAIN_WPE))) tl_frame_kernel(TlLaunch A)
 {
-    __shared__ double dbt[1002];
+    __shared__ __attribute__((aligned(16))) double dbt[1258];     // dB-sum table + glibc's log table (TlTables::dblog)
     __shared__ TlMainShared sh;
     __shared__ TlFrameLds lds[TL_MAIN_WAVES];
     {
-        for (int i = (int)threadIdx.x; i < 1002; i += 64 * TL_MAIN_WAVES) dbt[i] = A.tables->shared.dbtable[i];
+        for (int i = (int)threadIdx.x; i < 1258; i += 64 * TL_MAIN_WAVES) dbt[i] = A.tables->dblog[i];
         const double *src = (const double *)&A.tables->shared.scalefactor[0];
         double *dst = (double *)&sh.bytes[0];
         for (int i = (int)threadIdx.x; i < (int)(sizeof(sh.bytes) / 8); i += 64 * TL_MAIN_WAVES) dst[i] = src[i];

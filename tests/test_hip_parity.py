@@ -779,3 +779,15 @@ def test_bench_two_ranks_on_the_gpu():
     assert line["config"]["baseline_config"] == 3 and "configs[3]" in line["config"]["workload"] and line["config"]["streams_per_gpu"] == 16384
     assert line["value"] > 0 and line["steps"] == 3 and line["output_check"]["checked"]
     assert line["roofline"]["achieved"] > 0
+
+
+def test_this_hosts_libm_is_the_one_tl_libm_restates(tmp_path):
+    """The oracle on THIS box links this box's libm; csrc/tl_libm.h restates glibc 2.35's FMA-path routines.  Same sweep as
+    tests/test_libm_agree.py (CPU suite, build container), run where the GPU tests run: 2 M arguments per function, 0 differ."""
+    import subprocess
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "libm_agree"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-pthread", "-I", str(root / "odr-audioenc_amd" / "csrc"),
+                    str(root / "tools" / "libm_agree.cpp"), "-o", str(exe), "-lm"], check=True)
+    r = subprocess.run([str(exe), "2", "8", "11"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
