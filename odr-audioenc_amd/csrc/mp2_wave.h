@@ -188,6 +188,19 @@ TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
 #define TL_LAUNDER(p) asm volatile("" : "+s"(p))       /* keeps loads through p inside the frame loop (no hoisting into long-lived VGPRs) */
 #endif
 
+// Issue priority of the wave (s_setprio 0..3).  A wave inside a serial, latency-bound piece (a dB-sum chain: one table look-up
+// and six dependent operations per step, two to four lanes alive) has ONE instruction ready at a time; behind the long
+// independent streams of the other waves of its SIMD every step waits for an issue slot it could have had at once.  Raising
+// the priority for such pieces shortens them towards their uncontended latency and costs the throughput phases nothing they
+// can notice (they always have another instruction to issue).  TL_PRIO_CHAIN=0 builds without it (measurement).
+#ifndef TL_PRIO_CHAIN
+#define TL_PRIO_CHAIN 3
+#endif
+#ifdef TL_EMULATE
+#define TL_PRIO(n) ((void)0)
+#else
+#define TL_PRIO(n) do { if (TL_PRIO_CHAIN) __builtin_amdgcn_s_setprio((n) ? TL_PRIO_CHAIN : 0); } while (0)
+#endif
 #ifdef TL_EMULATE
 #define TL_STAMP(sp, k) ((void)0)
 #else
@@ -1326,7 +1339,7 @@ TL_FN void tl_psy1_finish(TlPsyLds &w, const double *TL_RESTRICT db, const TlCon
 {
     const int nbands = C->p1_ncb - 1;
     PV(double, wt); PV(double, bsum);
-    tl_psy1_chain(w, db, nbands, bsum, wt);
+    TL_PRIO(1); tl_psy1_chain(w, db, nbands, bsum, wt); TL_PRIO(0);
     tl_psy1_centres(w, C, nbands, bsum, wt);
     if (st.dead_head) tl_psy1_deadhead(w, db, C, ch, st, rec, sp); else tl_psy1_back(w, db, C, ch, st, rec, sp);
 }
@@ -1392,7 +1405,7 @@ TL_FN void tl_psy1_stereo(TlPsyLds &w, const TlTables *TL_RESTRICT T, const doub
         TL_LANES_BEGIN
         for (int i = lane; i < 504; i += 64) { uint64_t z = 0; TL_KEEP(z); w.u.fft[i] = tl_u2d(z); }   // (a zero made here, not a register kept through the frame)
         TL_LANES_END
-        tl_psy1_chain(w, db, nbands, bsum, wdummy);
+        TL_PRIO(1); tl_psy1_chain(w, db, nbands, bsum, wdummy); TL_PRIO(0);
     } else {
         // ---- both chains: channel 1's weight sums first (its terms sit where channel 0's levels go) ----
         if (TL_EXP_LEVEL < 3) tl_psy1_weights(w, nbands, wt1);
@@ -1403,7 +1416,7 @@ TL_FN void tl_psy1_stereo(TlPsyLds &w, const TlTables *TL_RESTRICT T, const doub
         for (int k = 0; k < 8; k++) if (lane + 64 * k < 504) w.u.fft[lane + 64 * k] = L(pvp)[k];
         TL_LANES_END
         TL_STAMP(sp1, 4);
-        if (TL_EXP_LEVEL < 3) tl_psy1_chain2(w, db, nbands, r0, r1, bsum);
+        if (TL_EXP_LEVEL < 3) { TL_PRIO(1); tl_psy1_chain2(w, db, nbands, r0, r1, bsum); TL_PRIO(0); }
         // ---- back(1): its sums move from lanes 32+b to lanes b ----
         PV(double, bsum1);
 #ifdef TL_EMULATE
@@ -1798,7 +1811,7 @@ TL_FN void tl_psy3(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double *TL_
 {
     const int nconf = tl_psy3_front(w, T, db, C, pv, ch, rec, sp);
     PV(double, bsum); PV(double, es); PV(double, cg);
-    tl_psy3_chain(w, db, C->p3_cbands, bsum, es, cg);
+    TL_PRIO(1); tl_psy3_chain(w, db, C->p3_cbands, bsum, es, cg); TL_PRIO(0);
     tl_psy3_back(w, db, C, ch, nconf, bsum, es, cg, rec, sp);
 }
 
@@ -1832,7 +1845,7 @@ TL_FN void tl_psy3_stereo(TlPsyLds &w, const TlTables *TL_RESTRICT T, const doub
 #endif
     for (int k = 0; k < 8; k++) w.u.fft[lane + 64 * k] = L(pvp)[k];   // channel 1's energies are summed: the buffer's lower half is free
     TL_LANES_END
-    tl_psy3_chain2(w, db, nb, r0, r1, bsum);
+    TL_PRIO(1); tl_psy3_chain2(w, db, nb, r0, r1, bsum); TL_PRIO(0);
 #ifdef TL_EMULATE
     for (int lane = 0; lane < 64; ++lane) bsum1[lane] = bsum[(lane + 32) & 63];
 #else
