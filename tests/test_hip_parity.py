@@ -735,6 +735,60 @@ def test_tick_pipeline_equals_stage_by_stage(M, case, egress, ngroups):
     b.close()
 
 
+def test_tick_pipeline_with_xpad(M):
+    """The tick's X-PAD side input (SURVEY 8f N3 through tlb_tick_xpad / tlb_tick_xpad_len): raw frames out of the pipeline
+    equal the oracle's byte stream, frame by frame, for streams with different pad_len and a changing X-PAD length per tick."""
+    cfgs = [M.StreamConfig(mode="j", bitrate=128, psy_model=1, pad_len=58), M.StreamConfig(mode="s", bitrate=192, psy_model=3, pad_len=34),
+            M.StreamConfig(mode="m", bitrate=64, psy_model=1, pad_len=0)]
+    T, ns = 10, len(cfgs)
+    rng = np.random.default_rng(21)
+    pcm = [gen_pcm(500 + s, 0, 0, T) for s in range(ns)]
+    lens = [[58, 10, 2, 0, 34, 58, 58, 0, 20, 58], [34, 0, 2, 34, 8, 34, 0, 34, 34, 6], [0] * T]
+    full = [[bytes(rng.integers(0, 256, cfgs[s].pad_len + 1, dtype=np.uint8)) for _ in range(T)] for s in range(ns)]   # the reference's xpad_data layout
+    refs = []
+    for s, c in enumerate(cfgs):
+        e = O.OracleEncoder(samplerate=c.samplerate, mode=c.mode, kbps=c.bitrate, psy=c.psy_model, pad_len=c.pad_len)
+        out = b"".join(e.encode(pcm[s][f], full[s][f], lens[s][f]) for f in range(T)) + e.finish()
+        e.close()
+        refs.append(out)
+    t = M.Tick(cfgs, egress="frames", ngroups=2, with_xpad=True)
+    got = [b""] * ns
+    for f in range(T):
+        for s in range(ns):
+            t.pcm[s] = pcm[s][f].T.reshape(-1) if cfgs[s].mode != "m" else np.concatenate([pcm[s][f][0], np.zeros(1152, dtype=np.int16)])
+            t.xpad[s] = E.pack_xpad(full[s][f], lens[s][f], cfgs[s].pad_len)
+            t.xpad_len[s] = lens[s][f]
+        t.run()
+        got = [g + t.frame(s) for s, g in enumerate(got)]
+    t.finish()
+    got = [g + t.frame(s) for s, g in enumerate(got)]
+    t.close()
+    assert got == refs
+
+
+def test_long_runs_carry_no_drift(M):
+    """3000 frames of one stream per model (psy 1 joint, psy 3, psy 2 and psy 4 with their chained prediction state, a padded
+    44.1 kHz stream) in 7 calls of ragged length: equal to the oracle to the last byte -- nothing accumulates over 72 s of audio."""
+    jobs = [(48000, "j", 128, 1), (48000, "s", 192, 3), (48000, "s", 160, 2), (32000, "m", 64, 4), (44100, "s", 128, 1)]
+    nframes = 3000
+    cfgs = [M.StreamConfig(samplerate=fs, mode=m, bitrate=k, psy_model=p) for fs, m, k, p in jobs]
+    pcm = np.stack([gen_pcm(4200 + s, (0, 7, 0, 5, 0)[s], 0, nframes) for s in range(len(jobs))], axis=1)
+    b = M.Batch(cfgs)
+    out, pos = [b""] * len(jobs), 0
+    for n in (1, 7, 300, 692, 1000, 999, 1):
+        got, _ = b.encode(pcm[pos:pos + n])
+        out = [x + y for x, y in zip(out, got)]
+        pos += n
+    assert pos == nframes
+    tail = b.flush()
+    b.close()
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(5) as ex:
+        refs = list(ex.map(lambda s: O.oracle_stream(pcm[:, s], samplerate=jobs[s][0], mode=jobs[s][1], kbps=jobs[s][2], psy=jobs[s][3])[0], range(len(jobs))))
+    for s in range(len(jobs)):
+        assert out[s] + tail[s] == refs[s], jobs[s]
+
+
 def test_edi_pft_fragments(M):
     """SURVEY 8f N2 (PFT part): fragments through the C-ABI equal the golden vectors (reference Reed-Solomon + CRC code under
     the restated PFT.cpp logic, tests/golden/make_golden_edi.py); Pseq carried across calls."""
