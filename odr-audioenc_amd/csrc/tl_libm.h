@@ -436,7 +436,7 @@ TLM_HD double tlm_atan2_t(double y, double x, TAB cij)
         v = u * u;
         zz = TLM_FMA(TLM_FMA(TLM_FMA(TLM_FMA(TLM_FMA(d13, v, d11), v, d9), v, d7), v, d5), v, d3);
     } else {
-        const int i = (int)(TLM_FMA(u, 256.0, 0x1p52) - 0x1p52) - 16;
+        const int i = (int)(uint32_t)tlm_d2u(TLM_FMA(u, 256.0, 0x1p52)) - 16;     // (TWO52 + TWO8*u) - TWO52 as an integer: the low word of the sum
         // row i of cij: {x_i, atan(x_i), c2..c6}
         const double c0 = tlm_u2d(cij[7 * i]);
         if (x > 0 && ylx) {                                     // (i): EADD(u - c0, du) keeps the low word
@@ -589,7 +589,7 @@ TLM_HD double tlm_atan2_sl(double y, double x, TAB cij)
     const double pa = TLM_FMA(TLM_FMA(TLM_FMA(TLM_FMA(TLM_FMA(d13, v, d11), v, d9), v, d7), v, d5), v, d3);
     const double uv = u * v;
     // form B: table row
-    int i = (int)(TLM_FMA(u, 256.0, 0x1p52) - 0x1p52) - 16;
+    int i = (int)(uint32_t)tlm_d2u(TLM_FMA(u, 256.0, 0x1p52)) - 16;       // the low word of TWO52 + TWO8*u (defined for the NaN of 0/0 too: the lane's result is discarded)
     i = i < 0 ? 0 : i > 240 ? 240 : i;                                    // (only form A's lanes can leave the table)
     const double c0 = tlm_u2d(cij[7 * i]), c1 = tlm_u2d(cij[7 * i + 1]), c2 = tlm_u2d(cij[7 * i + 2]), c3 = tlm_u2d(cij[7 * i + 3]),
                  c4 = tlm_u2d(cij[7 * i + 4]), c5 = tlm_u2d(cij[7 * i + 5]), c6 = tlm_u2d(cij[7 * i + 6]);
