@@ -739,11 +739,12 @@ def test_tick_pipeline_with_xpad(M):
     """The tick's X-PAD side input (SURVEY 8f N3 through tlb_tick_xpad / tlb_tick_xpad_len): raw frames out of the pipeline
     equal the oracle's byte stream, frame by frame, for streams with different pad_len and a changing X-PAD length per tick."""
     cfgs = [M.StreamConfig(mode="j", bitrate=128, psy_model=1, pad_len=58), M.StreamConfig(mode="s", bitrate=192, psy_model=3, pad_len=34),
-            M.StreamConfig(mode="m", bitrate=64, psy_model=1, pad_len=0)]
+            M.StreamConfig(mode="m", bitrate=64, psy_model=1, pad_len=0),
+            M.StreamConfig(samplerate=44100, mode="s", bitrate=128, psy_model=1, pad_len=0)]       # frames of two lengths (padding slots)
     T, ns = 10, len(cfgs)
     rng = np.random.default_rng(21)
     pcm = [gen_pcm(500 + s, 0, 0, T) for s in range(ns)]
-    lens = [[58, 10, 2, 0, 34, 58, 58, 0, 20, 58], [34, 0, 2, 34, 8, 34, 0, 34, 34, 6], [0] * T]
+    lens = [[58, 10, 2, 0, 34, 58, 58, 0, 20, 58], [34, 0, 2, 34, 8, 34, 0, 34, 34, 6], [0] * T, [0] * T]
     full = [[bytes(rng.integers(0, 256, cfgs[s].pad_len + 1, dtype=np.uint8)) for _ in range(T)] for s in range(ns)]   # the reference's xpad_data layout
     refs = []
     for s, c in enumerate(cfgs):
