@@ -409,7 +409,7 @@ int tlb_lds_bytes_per_stream(void)
     if (sizeof(TlPsy2Lds) > m) m = sizeof(TlPsy2Lds);
     return (int)m;
 }
-const char *tlb_version(void) { return "odr-audioenc_amd 0.2 (gfx950, a wavefront per (stream, frame), fp64)"; }
+const char *tlb_version(void) { return "odr-audioenc_amd 0.3 (gfx950, a wavefront per (stream, frame), fp64, glibc 2.35 transcendentals)"; }
 
 void tlb_destroy(tlb_batch *b)
 {
