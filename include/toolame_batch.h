@@ -233,11 +233,13 @@ int tlb_edi_pft_host(tlb_batch *b, const uint8_t *af, const int32_t *af_len, int
  * time (odr-audioenc.cpp:1213-1219).  tlb_tick_finish() pushes the last (pending) frame of every stream through the same
  * egress stage (toolame_finish at stream end); after it the object only answers the read accessors.
  * egress: TLB_TICK_FRAMES (raw MP2 frames, any sample rate), TLB_TICK_EDI_AF (AF packets, tlb_edi_af_device),
- * TLB_TICK_EDI_PFT (PFT fragments of those packets, tlb_edi_pft_device).  The EDI sender state of every stream starts as
+ * TLB_TICK_EDI_PFT (PFT fragments of those packets, tlb_edi_pft_device), TLB_TICK_ZMQ (ZeroMQ messages, tlb_zmq_frame_device).
+ * Every run also advances the per-stream silence counter of src/odr-audioenc.cpp:1053-1079 (tlb_tick_silence_ms()).  The EDI sender state of every stream starts as
  * tlb_edi_state_init(now_s, delay_ms, tist, tai_utc_offset) and lives on the device. */
 #define TLB_TICK_FRAMES 0
 #define TLB_TICK_EDI_AF 1
 #define TLB_TICK_EDI_PFT 2
+#define TLB_TICK_ZMQ 3             /* ODR-DabMux ZeroMQ messages (tlb_zmq_frame_device): zmq_frame_header_t + unit */
 typedef struct tlb_tick tlb_tick;
 typedef struct {
     int egress;                    /* TLB_TICK_* */
@@ -260,6 +262,8 @@ const int16_t *tlb_tick_peaks(const tlb_tick *t);
 int tlb_tick_units(const tlb_tick *t, int stream);
 const uint8_t *tlb_tick_frame(const tlb_tick *t, int stream, int *len);
 const uint8_t *tlb_tick_packet(const tlb_tick *t, int stream, int unit, int *len);
+const uint8_t *tlb_tick_message(const tlb_tick *t, int stream, int unit, int *len);      /* TLB_TICK_ZMQ */
+const uint32_t *tlb_tick_silence_ms(const tlb_tick *t);      /* uint32 [nstreams]: the caller's silence counter (tlb_silence_device), after the run */
 int tlb_tick_fragments(const tlb_tick *t, int stream, int unit);
 const uint8_t *tlb_tick_fragment(const tlb_tick *t, int stream, int unit, int k, int *len);
 float tlb_tick_last_ms(tlb_tick *t);           /* first copy-in queued -> last copy-out done of the last run, device clock */

@@ -1067,6 +1067,9 @@ struct TickGroup {
     uint8_t *d_frames = nullptr; int32_t *d_flen = nullptr;
     tlb_edi_state *d_state = nullptr; uint8_t *d_pkts = nullptr; int32_t *d_plen = nullptr;
     uint16_t *d_pseq = nullptr; uint8_t *d_frags = nullptr; int32_t *d_fraglen = nullptr, *d_nfrag = nullptr;
+    uint8_t *d_msgs = nullptr; int msg_stride = 0;              // ZeroMQ egress
+    uint32_t *d_silence = nullptr;                              // milliseconds of digital silence so far, per stream
+    uint8_t *h_msgs = nullptr;
     // this group's slices of the pinned host outputs
     uint8_t *h_frames = nullptr; int32_t *h_flen = nullptr; uint8_t *h_pkts = nullptr; int32_t *h_plen = nullptr;
     uint8_t *h_frags = nullptr; int32_t *h_fraglen = nullptr, *h_nfrag = nullptr;
@@ -1079,6 +1082,7 @@ struct tlb_tick {
     std::vector<TickGroup> groups;
     std::vector<int> group_of;                   // stream -> group
     int16_t *h_inter = nullptr, *h_peaks = nullptr; uint8_t *h_xpad = nullptr; int32_t *h_xl = nullptr;
+    uint32_t *h_silence = nullptr;
     std::vector<void *> pinned, dev;
     hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1111,7 +1115,7 @@ void tlb_tick_destroy(tlb_tick *t)
 static int tick_create_impl(tlb_tick *t, int device, int nstreams, const tlb_stream_config *cfgs, const tlb_tick_config *tc)
 {
     t->device = device; t->nstreams = nstreams; t->egress = tc->egress; t->with_xpad = tc->with_xpad ? 1 : 0;
-    if (tc->egress < TLB_TICK_FRAMES || tc->egress > TLB_TICK_EDI_PFT || tc->version_len < 0 || tc->version_len > TL_EDI_MAX_VERSION ||
+    if (tc->egress < TLB_TICK_FRAMES || tc->egress > TLB_TICK_ZMQ || tc->version_len < 0 || tc->version_len > TL_EDI_MAX_VERSION ||
         (tc->version_len && !tc->version)) return TLB_ERR_ARG;
     t->version_len = tc->version_len;
     if (tc->version_len) memcpy(t->version, tc->version, (size_t)tc->version_len);
@@ -1120,7 +1124,7 @@ static int tick_create_impl(tlb_tick *t, int device, int nstreams, const tlb_str
     if (ng > nstreams) ng = nstreams;
     t->groups.resize((size_t)ng);
     t->group_of.resize((size_t)nstreams);
-    size_t n_frames = 0, n_pkts = 0, n_slots = 0, n_frags = 0, n_fragslots = 0;
+    size_t n_frames = 0, n_pkts = 0, n_slots = 0, n_frags = 0, n_fragslots = 0, n_msgs = 0;
     for (int g = 0; g < ng; g++) {
         TickGroup &G = t->groups[(size_t)g];
         G.first = (int)((long)nstreams * g / ng); G.n = (int)((long)nstreams * (g + 1) / ng) - G.first;
@@ -1129,7 +1133,10 @@ static int tick_create_impl(tlb_tick *t, int device, int nstreams, const tlb_str
         G.b = tlb_create(device, G.n, cfgs + G.first, &err);
         if (!G.b) return err ? err : TLB_ERR_HIP;
         G.out_stride = G.b->out_stride; G.max_upf = G.b->max_upf;
-        if (tc->egress != TLB_TICK_FRAMES) {
+        if (tc->egress == TLB_TICK_ZMQ) {
+            if (!G.max_upf) return TLB_ERR_SAMPLERATE;
+            G.msg_stride = tlb_zmq_msg_stride(G.b);
+        } else if (tc->egress != TLB_TICK_FRAMES) {
             if (!G.max_upf) return TLB_ERR_SAMPLERATE;
             G.af_stride = tlb_edi_af_stride(G.b, tc->version_len);
             if (tc->egress == TLB_TICK_EDI_PFT)
@@ -1138,6 +1145,7 @@ static int tick_create_impl(tlb_tick *t, int device, int nstreams, const tlb_str
         n_frames += (size_t)G.n * (size_t)G.out_stride;
         n_slots += (size_t)G.n * (size_t)G.max_upf;
         n_pkts += (size_t)G.n * (size_t)G.max_upf * (size_t)G.af_stride;
+        n_msgs += (size_t)G.n * (size_t)G.max_upf * (size_t)G.msg_stride;
         n_fragslots += (size_t)G.n * (size_t)G.max_upf * (size_t)G.max_frags;
         n_frags += (size_t)G.n * (size_t)G.max_upf * (size_t)G.max_frags * (size_t)G.frag_stride;
     }
@@ -1148,12 +1156,14 @@ static int tick_create_impl(tlb_tick *t, int device, int nstreams, const tlb_str
     t->h_peaks = (int16_t *)pin((size_t)nstreams * 2 * sizeof(int16_t));
     t->h_xpad = (uint8_t *)pin(t->with_xpad ? (size_t)nstreams * TL_MAX_XPAD : 0);
     t->h_xl = (int32_t *)pin(t->with_xpad ? (size_t)nstreams * sizeof(int32_t) : 0);
+    t->h_silence = (uint32_t *)pin((size_t)nstreams * sizeof(uint32_t));
+    uint8_t *h_msgs = (uint8_t *)pin(n_msgs);
     uint8_t *h_frames = (uint8_t *)pin(n_frames); int32_t *h_flen = (int32_t *)pin((size_t)nstreams * sizeof(int32_t));
     uint8_t *h_pkts = (uint8_t *)pin(n_pkts); int32_t *h_plen = (int32_t *)pin(n_slots * sizeof(int32_t));
     uint8_t *h_frags = (uint8_t *)pin(n_frags); int32_t *h_fraglen = (int32_t *)pin(n_fragslots * sizeof(int32_t)), *h_nfrag = (int32_t *)pin(n_slots * sizeof(int32_t));
-    if (!t->h_inter || !t->h_peaks || !t->h_xpad || !t->h_xl || !h_frames || !h_flen || !h_pkts || !h_plen || !h_frags || !h_fraglen || !h_nfrag) return TLB_ERR_HIP;
+    if (!t->h_inter || !t->h_peaks || !t->h_xpad || !t->h_xl || !t->h_silence || !h_msgs || !h_frames || !h_flen || !h_pkts || !h_plen || !h_frags || !h_fraglen || !h_nfrag) return TLB_ERR_HIP;
     std::vector<tlb_edi_state> st0;
-    size_t o_frames = 0, o_slots = 0, o_pkts = 0, o_frags = 0, o_fragslots = 0;
+    size_t o_frames = 0, o_slots = 0, o_pkts = 0, o_frags = 0, o_fragslots = 0, o_msgs = 0;
     for (auto &G : t->groups) {
         const size_t n = (size_t)G.n, slots = n * (size_t)G.max_upf;
         G.d_inter = (int16_t *)dev(n * 2304 * 2); G.d_pcm = (int16_t *)dev(n * 2304 * 2); G.d_peaks = (int16_t *)dev(n * 4);
@@ -1162,6 +1172,9 @@ static int tick_create_impl(tlb_tick *t, int device, int nstreams, const tlb_str
         G.d_state = (tlb_edi_state *)dev(n * sizeof(tlb_edi_state));
         G.d_pkts = (uint8_t *)dev(slots * (size_t)G.af_stride); G.d_plen = (int32_t *)dev(slots * 4);
         G.d_pseq = (uint16_t *)dev(n * 2);
+        G.d_msgs = (uint8_t *)dev(slots * (size_t)G.msg_stride); G.d_silence = (uint32_t *)dev(n * 4);
+        if (!G.d_msgs || !G.d_silence) return TLB_ERR_HIP;
+        G.h_msgs = h_msgs + o_msgs; o_msgs += slots * (size_t)G.msg_stride;
         G.d_frags = (uint8_t *)dev(slots * (size_t)G.max_frags * (size_t)G.frag_stride); G.d_fraglen = (int32_t *)dev(slots * (size_t)G.max_frags * 4); G.d_nfrag = (int32_t *)dev(slots * 4);
         if (!G.d_inter || !G.d_pcm || !G.d_peaks || !G.d_xpad || !G.d_xl || !G.d_frames || !G.d_flen || !G.d_state || !G.d_pkts || !G.d_plen || !G.d_pseq ||
             !G.d_frags || !G.d_fraglen || !G.d_nfrag) return TLB_ERR_HIP;
@@ -1209,10 +1222,13 @@ int tlb_tick_set_gain_db(tlb_tick *t, int stream, double gain_db)
 }
 
 // egress of the frames sitting in G.d_frames + copy-out, queued on s_run / s_out
-static int tick_egress(tlb_tick *t, TickGroup &G, bool have_frames)
+static int tick_egress(tlb_tick *t, TickGroup &G, bool have_frames, bool new_input = true)
 {
     const size_t n = (size_t)G.n, slots = n * (size_t)G.max_upf;
-    if (have_frames && t->egress != TLB_TICK_FRAMES) {
+    if (new_input) if (int rc = tlb_silence_device(G.b, G.d_peaks, 1, G.d_silence, t->s_run)) return rc;       // odr-audioenc.cpp:1053-1079 (the decision stays with the caller)
+    if (have_frames && t->egress == TLB_TICK_ZMQ) {
+        if (int rc = tlb_zmq_frame_device(G.b, G.d_frames, G.d_peaks, 1, G.d_msgs, t->s_run)) return rc;
+    } else if (have_frames && t->egress != TLB_TICK_FRAMES) {
         if (int rc = tlb_edi_af_device(G.b, G.d_frames, G.d_peaks, 1, G.d_state, t->version, t->version_len, G.d_pkts, G.d_plen, t->s_run)) return rc;
         if (t->egress == TLB_TICK_EDI_PFT)
             if (int rc = tlb_edi_pft_device(G.b, G.d_pkts, G.d_plen, G.max_upf, G.af_stride, G.d_pseq, t->fec, t->chunk_len, t->transport, t->addr_source, t->dest_port,
@@ -1221,10 +1237,13 @@ static int tick_egress(tlb_tick *t, TickGroup &G, bool have_frames)
     HIPCHK(hipEventRecord(G.ev_run, t->s_run));
     HIPCHK(hipStreamWaitEvent(t->s_out, G.ev_run, 0));
     HIPCHK(hipMemcpyAsync(t->h_peaks + (size_t)G.first * 2, G.d_peaks, n * 4, hipMemcpyDeviceToHost, t->s_out));
+    HIPCHK(hipMemcpyAsync(t->h_silence + G.first, G.d_silence, n * 4, hipMemcpyDeviceToHost, t->s_out));
     if (!have_frames) return TLB_OK;                                 // very first tick: no frame is final yet (lengths stay 0)
     if (t->egress == TLB_TICK_FRAMES) {
         HIPCHK(hipMemcpyAsync(G.h_frames, G.d_frames, n * (size_t)G.out_stride, hipMemcpyDeviceToHost, t->s_out));
         HIPCHK(hipMemcpyAsync(G.h_flen, G.d_flen, n * 4, hipMemcpyDeviceToHost, t->s_out));
+    } else if (t->egress == TLB_TICK_ZMQ) {
+        HIPCHK(hipMemcpyAsync(G.h_msgs, G.d_msgs, slots * (size_t)G.msg_stride, hipMemcpyDeviceToHost, t->s_out));
     } else if (t->egress == TLB_TICK_EDI_AF) {
         HIPCHK(hipMemcpyAsync(G.h_pkts, G.d_pkts, slots * (size_t)G.af_stride, hipMemcpyDeviceToHost, t->s_out));
         HIPCHK(hipMemcpyAsync(G.h_plen, G.d_plen, slots * 4, hipMemcpyDeviceToHost, t->s_out));
@@ -1271,7 +1290,7 @@ int tlb_tick_finish(tlb_tick *t)
     HIPCHK(hipSetDevice(t->device));
     for (auto &G : t->groups) {
         int rc = tlb_flush_device_len(G.b, G.d_frames, G.d_flen, t->s_run);
-        if (!rc) rc = tick_egress(t, G, true);
+        if (!rc) rc = tick_egress(t, G, true, false);
         if (rc) { tick_drain(t); return rc; }
     }
     if (hipStreamSynchronize(t->s_out) != hipSuccess) { tick_drain(t); return TLB_ERR_HIP; }
@@ -1279,6 +1298,17 @@ int tlb_tick_finish(tlb_tick *t)
     return TLB_OK;
 }
 
+const uint32_t *tlb_tick_silence_ms(const tlb_tick *t) { return t ? t->h_silence : nullptr; }
+const uint8_t *tlb_tick_message(const tlb_tick *t, int stream, int unit, int *len)
+{   // ZeroMQ message = zmq_frame_header_t + unit; the header's datasize field says how much follows (0: absent)
+    if (!t || stream < 0 || stream >= t->nstreams || t->egress != TLB_TICK_ZMQ) return nullptr;
+    const TickGroup &G = t->groups[(size_t)t->group_of[(size_t)stream]];
+    if (unit < 0 || unit >= G.max_upf) return nullptr;
+    const uint8_t *m = G.h_msgs + ((size_t)unit * (size_t)G.n + (size_t)(stream - G.first)) * (size_t)G.msg_stride;
+    uint32_t ds; memcpy(&ds, m + 4, 4);
+    if (len) *len = (t->ticks > 0 && ds) ? (int)(12 + ds) : 0;
+    return m;
+}
 int tlb_tick_units(const tlb_tick *t, int stream)
 {
     if (!t || stream < 0 || stream >= t->nstreams) return 0;

@@ -121,6 +121,10 @@ def load_library():
     L.tlb_tick_frame.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.tlb_tick_packet.restype = C.c_void_p
     L.tlb_tick_packet.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.tlb_tick_message.restype = C.c_void_p
+    L.tlb_tick_message.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.tlb_tick_silence_ms.restype = C.c_void_p
+    L.tlb_tick_silence_ms.argtypes = [C.c_void_p]
     L.tlb_tick_fragments.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.tlb_tick_fragment.restype = C.c_void_p
     L.tlb_tick_fragment.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
@@ -189,7 +193,7 @@ class Tick:
     """tlb_tick_*: the caller's loop body -- ingest, encode, EDI egress -- as one call per tick for every stream of a GPU
     (src/odr-audioenc.cpp:1030-1051,1139-1163,1208-1225, src/Outputs.cpp:194-261).  `pcm` (and `xpad`, `xpad_len`) are numpy
     views of the object's pinned host buffers: fill them, run(), read packets()."""
-    EGRESS = {"frames": 0, "af": 1, "pft": 2}
+    EGRESS = {"frames": 0, "af": 1, "pft": 2, "zmq": 3}
 
     def __init__(self, configs, egress="af", ngroups=0, with_xpad=False, version=b"", now_s=1700000000, delay_ms=0, tist=False,
                  tai_utc_offset=37, fec=0, chunk_len=207, transport=False, addr_source=0, dest_port=0, device=0):
@@ -212,6 +216,7 @@ class Tick:
             self.xpad = np.ctypeslib.as_array((C.c_uint8 * (n * MAX_XPAD)).from_address(self.L.tlb_tick_xpad(self.h))).reshape(n, MAX_XPAD)
             self.xpad_len = np.ctypeslib.as_array((C.c_int32 * n).from_address(self.L.tlb_tick_xpad_len(self.h)))
         self.units = [self.L.tlb_tick_units(self.h, s) for s in range(n)]
+        self.silence_ms = np.ctypeslib.as_array((C.c_uint32 * n).from_address(self.L.tlb_tick_silence_ms(self.h)))
 
     def set_gain_db(self, gain_db, stream=-1):
         rc = self.L.tlb_tick_set_gain_db(self.h, stream, float(gain_db))
@@ -246,6 +251,16 @@ class Tick:
                 out.append(C.string_at(p, n.value))
         return out
 
+    def messages(self, s):
+        """the ZeroMQ messages (header + unit) of stream s from the last run"""
+        out = []
+        for u in range(self.units[s]):
+            n = C.c_int(0)
+            p = self.L.tlb_tick_message(self.h, s, u, C.byref(n))
+            if p and n.value:
+                out.append(C.string_at(p, n.value))
+        return out
+
     def fragments(self, s):
         """per unit: the list of PFT fragments of stream s from the last run"""
         out = []
@@ -261,7 +276,7 @@ class Tick:
 
     def close(self):
         if getattr(self, "h", None):
-            self.pcm = self.peaks = self.xpad = self.xpad_len = None
+            self.pcm = self.peaks = self.xpad = self.xpad_len = self.silence_ms = None
             self.L.tlb_tick_destroy(self.h)
             self.h = None
 

@@ -672,7 +672,7 @@ EDI_TICK_CASES = {
 
 
 @pytest.mark.parametrize("case", sorted(EDI_TICK_CASES))
-@pytest.mark.parametrize("egress,ngroups", [("af", 1), ("af", 3), ("pft", 2), ("frames", 2)])
+@pytest.mark.parametrize("egress,ngroups", [("af", 1), ("af", 3), ("pft", 2), ("frames", 2), ("zmq", 2)])
 def test_tick_pipeline_equals_stage_by_stage(M, case, egress, ngroups):
     """tlb_tick_run -- PCIe in, ingest, encode, EDI AF (PFT), PCIe out as ONE call per tick, streams split into groups on three
     HIP streams -- against the same stages called one by one through the golden-pinned entry points (tlb_ingest_host,
@@ -683,8 +683,10 @@ def test_tick_pipeline_equals_stage_by_stage(M, case, egress, ngroups):
     ns, T = len(cfgs), 14
     rng = np.random.default_rng(11)
     inter = np.stack([np.stack([gen_pcm(900 + s, (0, 7, 5, 4)[s % 4], 0, T)[f].T.reshape(-1) for s in range(ns)]) for f in range(T)])   # [T, ns, 2304] L R L R
+    inter[3:6, 1] = 0                                    # three silent frames in stream 1: its silence counter runs and resets
     gains = [0.0, -3.0, 0.0, 6.0, 0.0, -9.5][:ns]
     version = b"odr-audioenc_amd tick"
+    import ctypes as C
     kw = dict(now_s=1712345678, delay_ms=370, tist=True, tai_utc_offset=37)
     pft = dict(fec=2, chunk_len=207, transport=True, addr_source=4711, dest_port=12000)
     # ---- stage by stage
@@ -701,7 +703,9 @@ def test_tick_pipeline_equals_stage_by_stage(M, case, egress, ngroups):
     fr = np.concatenate([frames[1:], last])
     lv = np.concatenate([peaks[1:], peaks[-1:]])
     want_frames = [[fr[f, s, :b.frame_bytes[s]].tobytes() for s in range(ns)] for f in range(T)]
-    if egress != "frames":
+    if egress == "zmq":
+        msgs = b.zmq_frames(fr, lv)
+    elif egress != "frames":
         state = M.edi_state_init(ns, kw["now_s"], kw["delay_ms"], kw["tist"], kw["tai_utc_offset"])
         pk, pl = b.edi_af(fr, lv, state, version)
         if egress == "pft":
@@ -711,13 +715,20 @@ def test_tick_pipeline_equals_stage_by_stage(M, case, egress, ngroups):
     t = M.Tick(cfgs, egress=egress, ngroups=ngroups, version=version, **kw, **(pft if egress == "pft" else {}))
     for s, g in enumerate(gains):
         t.set_gain_db(g, s)
+    OL = O.lib()
+    OL.mp2o_silence_ms.restype = C.c_uint
+    OL.mp2o_silence_ms.argtypes = [C.c_uint, C.c_void_p, C.c_int, C.c_long]
+    silence = [0] * ns
     for f in range(T + 1):
         if f < T:
             t.pcm[:] = inter[f]
             t.run()
             assert np.array_equal(t.peaks, peaks[f])
+            for s in range(ns):
+                silence[s] = OL.mp2o_silence_ms(silence[s], np.ascontiguousarray(t.peaks[s]).ctypes.data, 1 if cfgs[s].mode == "m" else 2, cfgs[s].samplerate)
+            assert list(t.silence_ms) == silence, f
             if f == 0:
-                assert all(not t.packets(s) and not t.fragments(s) and not t.frame(s) for s in range(ns))
+                assert all(not t.packets(s) and not t.fragments(s) and not t.frame(s) and not t.messages(s) for s in range(ns))
                 continue
         else:
             t.finish()
@@ -725,6 +736,9 @@ def test_tick_pipeline_equals_stage_by_stage(M, case, egress, ngroups):
         for s in range(ns):
             if egress == "frames":
                 assert t.frame(s) == want_frames[k][s], (f, s)
+            elif egress == "zmq":
+                U = b.unit_bytes[s]
+                assert t.messages(s) == [msgs[k * b.max_upf + u, s, :12 + U].tobytes() for u in range(b.units_per_frame[s])], (f, s)
             elif egress == "af":
                 want = [pk[k * b.max_upf + u, s, :pl[k * b.max_upf + u, s]].tobytes() for u in range(b.units_per_frame[s])]
                 assert t.packets(s) == want, (f, s)
