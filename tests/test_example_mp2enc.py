@@ -13,17 +13,52 @@ import oraclelib as O
 from pcmgen import gen_pcm
 
 
-def build(tmp_path):
+def build(tmp_path, name="mp2enc"):
     import odr_audioenc_amd as M
     M.build()
-    exe = tmp_path / "mp2enc"
-    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", str(ROOT / "examples" / "mp2enc.cpp"), "-I" + str(ROOT / "include"),
+    exe = tmp_path / name
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", str(ROOT / "examples" / (name + ".cpp")), "-I" + str(ROOT / "include"),
                     "-L" + str(ROOT / "odr-audioenc_amd"), "-ltoolame_dab_hip", "-Wl,-rpath," + str(ROOT / "odr-audioenc_amd"), "-o", str(exe)], check=True)
     return exe
 
 
 def test_example_builds_with_a_host_compiler(tmp_path):
     assert build(tmp_path).exists()
+    assert build(tmp_path, "editick").exists()               # the tick API (tlb_tick_*) from plain C++
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fs,channels,mode,kbps,psy,nstreams", [(48000, 2, "j", 128, 1, 3), (24000, 1, "m", 64, 1, 2)])
+def test_editick_packets_equal_the_binding(tmp_path, fs, channels, mode, kbps, psy, nstreams):
+    """examples/editick.cpp (tlb_tick_* from C++: PCIe in, ingest, encode, EDI AF, PCIe out per tick) writes the same AF packets
+    for stream 0 as the Python binding's Tick object driven with the same PCM."""
+    import struct
+    import odr_audioenc_amd as M
+    exe = build(tmp_path, "editick")
+    nframes = 40
+    pcm = gen_pcm(91, 0, 0, nframes)
+    inter = pcm[:, :channels].transpose(0, 2, 1).reshape(nframes, -1).astype("<i2")
+    (tmp_path / "in.pcm").write_bytes(inter.tobytes())
+    r = subprocess.run([str(exe), str(tmp_path / "in.pcm"), str(tmp_path / "out.af"), "-r", str(fs), "-c", str(channels), "-b", str(kbps),
+                        "-m", mode, "-p", str(psy), "-n", str(nstreams), "-t", "1712345678"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    blob, got, o = (tmp_path / "out.af").read_bytes(), [], 0
+    while o < len(blob):
+        n = struct.unpack_from("<I", blob, o)[0]
+        got.append(blob[o + 4:o + 4 + n])
+        o += 4 + n
+    t = M.Tick([M.StreamConfig(samplerate=fs, mode=mode, bitrate=kbps, psy_model=psy)] * nstreams, egress="af", version=b"editick example",
+               now_s=1712345678, delay_ms=0, tist=True, tai_utc_offset=37)
+    want = []
+    for f in range(nframes):
+        t.pcm[:, :inter.shape[1]] = inter[f]
+        t.run()
+        want += t.packets(0)
+    t.finish()
+    want += t.packets(0)
+    t.close()
+    upf = 2 if fs == 24000 else 1
+    assert got == want and len(got) == nframes * upf and all(p[:2] == b"AF" for p in got)
 
 
 @pytest.mark.gpu
