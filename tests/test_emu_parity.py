@@ -85,6 +85,18 @@ def test_known_bad_streams_of_round2():
         assert out == O.oracle_stream(pcm, samplerate=fs, mode=mode, kbps=kbps, psy=psy)[0], (fs, mode, kbps, psy, kind, seed)
 
 
+def test_edge_spectra_all_models():
+    """tools/fuzz_psy2_edge.py in the suite: DC, Nyquist, lone impulses, exact-bin sinusoids and squares, one-LSB noise, sparse
+    frames ... -- spectra that reach the special branches of the restated glibc routines (zero operands and extreme ratios in
+    atan2, sincos at multiples of pi/4, the 0.0005 energy clamp) and the degenerate paths of the tone labelling -- every
+    model except psy 3 (whose reference crashes on silent spectra), kernel source (emulation) against the oracle."""
+    import sys
+    sys.path.insert(0, str(E.ROOT / "tools"))
+    import fuzz_psy2_edge as Fz
+    n, bad = Fz.run(per_kind=16, seed=5, models=(2, 4, 2, 4, 1, 0), workers=4)
+    assert n == 160 and bad == []
+
+
 def test_emulated_log10_pow10_accuracy():
     """csrc/tl_libm.h against this machine's glibc: the same bits over the encoder's ranges (the wide sweep over every
     function is tests/test_libm_agree.py / tools/libm_agree.cpp)."""
