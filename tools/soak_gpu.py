@@ -49,7 +49,11 @@ def main():
         fs, mode, kbps = combos[rng.integers(len(combos))] if rng.random() < 0.5 else (48000, "sj"[rng.integers(2)], (128, 192)[rng.integers(2)])
         psy = int(rng.choice(MODELS))
         s = int(rng.integers(1 << 30))
-        if rng.random() < 0.4:
+        if os.environ.get("TL_SOAK_EDGE"):                # the edge spectra of tools/fuzz_psy2_edge.py (6 frames each, repeated to F)
+            import fuzz_psy2_edge as Fz
+            e = Fz.make(Fz.KINDS[int(rng.integers(len(Fz.KINDS)))], s)
+            pcm = np.concatenate([e] * ((F + 5) // 6))[:F]
+        elif rng.random() < 0.4:
             pcm = crafted(s)[:F] if F <= 6 else np.concatenate([crafted(s + i) for i in range((F + 5) // 6)])[:F]
         else:
             kind = int(rng.integers(8))                    # incl. psy 3 on silence / impulse: the reference crashes there, the oracle defines it
