@@ -339,10 +339,19 @@ def configs4_share(M, torch, np, gen_pcm, psy, local_rank, S=16384, F=8, steps=2
     b.close()
     audio_s = (S // 2) * F * steps * (1152 / 32000 + 1152 / 48000)      # a 32 kHz frame is 36 ms of audio, a 48 kHz frame 24 ms
     algo = (S // 2) * F * ((1152 * 2 + 144000 * 64 // 32000) + (2 * 1152 * 2 + 144000 * 192 // 48000))
+    traffic, traffic_source = None, None
+    try:      # committed PMC measurement of this very workload (tools/pmc_configs4.sh), never measured inside a bench run
+        tag = (ROOT / "profiles" / "LATEST").read_text().split()[0]
+        pm = json.load(open(ROOT / "profiles" / f"{tag}_pmc_traffic_configs4_psy{psy}.json"))
+        if (pm["workload"]["streams"], pm["workload"]["frames_per_step"], pm["workload"]["psy"]) == (S, F, psy):
+            traffic, traffic_source = pm["hbm_bytes_per_launch"], f"profiles/{tag}_pmc_traffic_configs4_psy{psy}.json (committed rocprofv3 --pmc measurement, not this run)"
+    except Exception:  # noqa: BLE001
+        pass
     return {"workload": f"{S} streams, even 32 kHz mono 64 kbps / odd 48 kHz stereo 192 kbps in one batch, psy {psy}, {F} frames/stream/launch "
                         "(BASELINE configs[4], one GPU's share)", "value": round(S * F * steps / dt, 1), "unit": "frames/s",
             "ms_per_launch": round(dt / steps * 1e3, 3), "streams_at_realtime": round(audio_s / dt),
-            "roofline_frac_hbm": round(algo / (dt / steps) / 1e9 / HBM_PEAK_GBS, 6), "output_check": "4 streams x the last launch's frames equal the oracle"}
+            "roofline_frac_hbm": round(algo / (dt / steps) / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": algo,
+            "traffic": traffic, "traffic_source": traffic_source, "output_check": "4 streams x the last launch's frames equal the oracle"}
 
 
 def tick_pipeline(M, np, gen_pcm, nstreams, psy, mode, local_rank, ticks=1000, egress="af", ngroups=0):
