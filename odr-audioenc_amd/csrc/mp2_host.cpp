@@ -162,6 +162,30 @@ void tl_build_tables(TlTables *T)
     }
 }
 
+// A run of frames that does not start at the launch's first frame pays two seed passes (transform + square root + arctangent:
+// about half a full pass each, csrc/mp2_wave.h tl_psy2_pass<true>), i.e. about half a frame.  Whole chains fill the complete
+// rounds of waves; the chains of the last, partly filled round are cut so that its waves finish together.  Cost of a plan in
+// frame times: complete rounds * nframes + rounds of runs * (plen + 0.5).
+int tl_psy2_plan(int nchain, int nframes, int slots, int *nwhole, int *k, int *plen)
+{
+    if (slots < 1) slots = 1;
+    int whole = (nchain / slots) * slots, rem = nchain - whole;
+    int best_k = 1;
+    if (rem > 0 && nframes > 1) {
+        double best = (double)nframes;                               // k = 1: the last round takes a whole chain's time
+        for (int kk = 2; kk <= nframes; kk++) {
+            const int pl = (nframes + kk - 1) / kk;
+            if ((long)pl * (kk - 1) >= nframes) continue;            // the last run would be empty: same cut as a smaller k
+            const long units = (long)rem * kk;
+            const double t = (double)((units + slots - 1) / slots) * ((double)pl + 0.5);
+            if (t < best - 1e-9) { best = t; best_k = kk; }
+        }
+    }
+    if (best_k == 1) { *nwhole = nchain; *k = 1; *plen = nframes; return nchain; }
+    *nwhole = whole; *k = best_k; *plen = (nframes + best_k - 1) / best_k;
+    return whole + rem * best_k;
+}
+
 int tl_psy2_slot(long samplerate)
 {   // one table set per distinct rate the device path supports (TL_PSY2_SLOTS)
     switch (samplerate) { case 48000: return 0; case 32000: return 1; case 24000: return 2; case 16000: return 3; case 44100: return 4; default: return 5; }

@@ -24,4 +24,8 @@ void tl_build_tables(TlTables *T);
 int tl_psy2_slot(long samplerate);
 void tl_build_psy2_tables(TlPsy2Tables *P, long samplerate);
 void tl_build_psy4_tables(TlPsy2Tables *P, long samplerate);   // psy model 4 mapped onto the psy-2 record
+// Work list of the psy-2 kernel for a launch of `nchain` (stream, channel) chains of `nframes` frames on `slots` resident waves:
+// chains [0, *nwhole) are one unit each, every later chain is cut into *k runs of *plen frames (tl_psy2_unit in mp2_wave.h).
+// Returns the number of units.
+int tl_psy2_plan(int nchain, int nframes, int slots, int *nwhole, int *k, int *plen);
 int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, int pad_len);

@@ -155,12 +155,15 @@ struct TlLaunch {
     TlTaps *taps;                     // [nframes][nstreams] or null
     long long *stamps;                // [nframes][nstreams][32] cycle stamps (diagnostic builds) or null
     const TlPsy2Tables *psy2_tables;  // [*] indexed by TlConfig::psy2_tab, or null when no stream uses psy 2
-    TlPsy2State *psy2_state;          // [nstreams] or null
+    TlPsy2State *psy2_state;          // [nstreams][2] or null: two copies per stream, a launch reads copy psy2_flip and leaves the state in the other
     TlPsyOut *psy_out;                // [nframes][nstreams] psy-2 kernel -> encode kernel (models 2 and 4), or null
     uint8_t *scfcrc;                  // [nframes][nstreams][4] ScF-CRC bytes of each frame (split path: encode kernel -> finish kernel)
     uint32_t *newpend;                // [nstreams][TL_MAX_FRAME_WORDS] last frame of the launch, before it becomes the pending one
     uint8_t *padbits;                 // [nframes][nstreams] padding slot of each frame (tl_slots_stream), or null: no stream of the launch pads
     double *newlag;                   // [nstreams] the slot recurrence's state after the launch (with padbits)
     int32_t *work;                    // unit counters of the persistent kernels: [0] psy-2 kernel, [32 (1 + q)] list q of the eight per-XCD lists of (stream, frame) units
+    const int32_t *chain_list;        // [nchain] psy-2 kernel: stream id | channel << 30 of each (stream, channel) chain of the launch
     int32_t nstreams, nframes, out_stride, nlist;
+    int32_t nchain, p2_nwhole, p2_k, p2_plen;    // psy-2 kernel's work list (tl_psy2_unit): whole chains, then runs of p2_plen frames
+    int32_t psy2_flip, pad_;
 };

@@ -1861,20 +1861,29 @@ TL_FN void tl_psy3_stereo(TlPsyLds &w, const TlTables *TL_RESTRICT T, const doub
 }
 
 // ------------------------------------------------------------------------------------------
-// psy model 2 (psycho_2.c:52-254, psycho_2_fft fft.c:1230-1275) for channel `ch`; result in w.smr[ch][0..32).
-// Two 576-sample passes per frame; a pass needs the 480 samples before its 544 new ones -- the stream's
-// PCM history on pass 0, samples 96..575 of the frame on pass 1 (the reference's savebuf shift by 576).
+// psy model 2 (psycho_2.c:52-254, psycho_2_fft fft.c:1230-1275), one 576-sample pass of channel `ch`.
+// Two passes per frame; a pass needs the 480 samples before its 544 new ones -- the stream's PCM history on pass 0,
+// samples 96..575 of the frame on pass 1 (the reference's savebuf shift by 576).
 // Line-parallel: FFT, unpredictability (sincos/atan2/sqrt per line), thresholds; partition-parallel:
 // grouping, spreading, SNR.  Every sum is one lane's sequential chain in the reference's order.
-TL_FN void tl_psy2(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_RESTRICT P,
-                   TlPsy2State *TL_RESTRICT S, const TlPcmView &pv, int ch, long long *sp, double *smr_out, const uint64_t *sct)
+//
+// The prediction state.  The reference keeps r = sqrt(energy) and phi of the two previous passes per line
+// (psycho_2.c:111-116, 300-306) -- but there is no recurrence in it: both are functions of that pass's transform alone
+// (`lthr`, the one true feedback of the model, is dead for Layer II, psycho_2.c:214-224).  So a run of passes can start
+// anywhere: two SEED passes (transform, square root, arctangent -- no unpredictability, nothing after it) over the 1152
+// samples before it rebuild exactly the state the chain would have carried there.  During a run the state lives in the wave's
+// REGISTERS: line lane + 64 it in slot `it` of r1/p1 (previous pass) and r2/p2 (the pass before), line 512 in four LDS words.
+#define TL_P2_L512(w) ((w).px + 516)     /* r1, r2, p1, p2 of line 512 (c[] / fthr[] end at px[512]) */
+template <bool SEED>
+TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_RESTRICT P, const TlPcmView &pv, int ch, int pass,
+                        PARGA(double, r1, 8), PARGA(double, r2, 8), PARGA(double, p1, 8), PARGA(double, p2, 8),
+                        PARG(double, snr0), double *smr_out, const uint64_t *sct, long long *sq)
 {   // sct: glibc's __sincostab (tl_libm.h), the workgroup's LDS copy on the device
     double *x = w.u.fft;
     double *cw = w.px, *ge = w.u.fft + 520;  // c[] (unpredictability), then fthr[]; partition sums in the
     double *gc = ge + 64, *ecb = gc + 64, *nb = ecb + 64;   // dead upper half of the FHT buffer
-    PV(double, snr0);
-    for (int pass = 0; pass < 2; pass++) {
-        long long *sq = pass == 0 ? sp : nullptr;                  // stage stamps of the first pass
+    double *l5 = TL_P2_L512(w);
+    {
         TL_STAMP(sq, 0);
         PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
         TL_LANES_BEGIN
@@ -1917,20 +1926,17 @@ TL_FN void tl_psy2(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
         TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
         TL_LANES_BEGIN tl_fht_pass<8>(x, L(twa), lane); TL_LANES_END
         TL_STAMP(sq, 1);
-        // energy + phase (fft.c:1246-1275), unpredictability (psycho_2.c:119-140); ages: new = 1-pass, old = pass.
+        // energy + phase (fft.c:1246-1275), unpredictability (psycho_2.c:119-140).
         // 64 lines per step: the transform is read through the layout map first, then the step's energies are written in
-        // natural order (their slots hold nothing a later step reads).  The prediction state of the line handled next
-        // is fetched while the current line's transcendentals run.
-        const int nw = 1 - pass, old = pass;
-        PV(double, r_o); PV(double, r_n); PV(double, p_o); PV(double, p_n);
-        TL_LANES_BEGIN
-        L(r_o) = S->r[ch][old][lane]; L(r_n) = S->r[ch][nw][lane]; L(p_o) = S->phi[ch][old][lane]; L(p_n) = S->phi[ch][nw][lane];
-        TL_LANES_END
+        // natural order (their slots hold nothing a later step reads).
         // Lines 0..511 are eight full steps of the wave; line 512 would be a ninth with ONE lane at work, at the price of a full
         // step (two sincos, an atan2, two square roots for every lane).  It needs no arctangent of its own (its phase is 0 or pi,
         // fft.c:1274) and line 0 needs none either and no sincos of its phase (phi = 0, fft.c:1257-1259), so in step 0 lane 0 puts
         // line 512's PREDICTED phase through its first sincos slot and finishes that line with a few extra operations.
         PV(double, e512);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
         for (int it = 0; it < 8; it++) {
             PV(double, xa); PV(double, xb); PV(double, xc);
             TL_LANES_BEGIN
@@ -1943,49 +1949,53 @@ TL_FN void tl_psy2(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tabl
             const int j = lane + 64 * it;
             {
                 const bool first = j == 0;                           // lane 0 of step 0: lines 0 and 512
-                const int jn = j + 64 <= 511 ? j + 64 : j;
-                const double r_o2 = S->r[ch][old][jn], r_n2 = S->r[ch][nw][jn], p_o2 = S->phi[ch][old][jn], p_n2 = S->phi[ch][nw][jn];
                 double r_o5 = 0, r_n5 = 0, p_o5 = 0, p_n5 = 0;      // state of line 512
-                if (it == 0) { const int jl = first ? 512 : j; r_o5 = S->r[ch][old][jl]; r_n5 = S->r[ch][nw][jl]; p_o5 = S->phi[ch][old][jl]; p_n5 = S->phi[ch][nw][jl]; }
+                if (it == 0) { r_o5 = l5[0]; r_n5 = l5[1]; p_o5 = l5[2]; p_n5 = l5[3]; }
                 const double a = L(xa), b = L(xb);
                 double e = (a * a + b * b) / 2.0;
                 const bool low = e < 0.0005;
                 double phi = tlm_atan2_sl<false>(-a, b, tlm_atan_cij) + 3.14159265358979 / 4;
                 e = TL_SELECT(low, 0.0005, e); phi = TL_SELECT(low, 0.0, phi);
                 e = TL_SELECT(first, a * a, e); phi = TL_SELECT(first, 0.0, phi);      // line 0: energy x_real[0]^2, phase 0
-                const double r_prime = 2.0 * L(r_o) - L(r_n);
-                const double phi_prime = 2.0 * L(p_o) - L(p_n);
                 const double rn = sqrt(e);
-                S->r[ch][nw][j] = rn; S->phi[ch][nw][j] = phi;
-                double sp, cp, spp, cpp;
-                tlm_sincos_sl(TL_SELECT(first, 2.0 * p_o5 - p_n5, phi), &sp, &cp, sct);
-                tlm_sincos_sl(phi_prime, &spp, &cpp, sct);
-                const double spp5 = sp, cpp5 = cp;                   // sincos of line 512's predicted phase (lane 0 of step 0)
-                sp = TL_SELECT(first, 0.0, sp); cp = TL_SELECT(first, 1.0, cp);         // sincos(0.0)
-                const double t1 = rn * cp - r_prime * cpp;
-                const double t2 = rn * sp - r_prime * spp;
-                const double t3 = rn + fabs(r_prime);
-                cw[j] = t3 != 0 ? sqrt(t1 * t1 + t2 * t2) / t3 : 0;
-                x[j] = e;
+                double spp5 = 0, cpp5 = 0;
+                if (!SEED) {
+                    const double r_prime = 2.0 * L(r1)[it] - L(r2)[it];
+                    const double phi_prime = 2.0 * L(p1)[it] - L(p2)[it];
+                    double sp, cp, spp, cpp;
+                    tlm_sincos_sl(TL_SELECT(first, 2.0 * p_o5 - p_n5, phi), &sp, &cp, sct);
+                    tlm_sincos_sl(phi_prime, &spp, &cpp, sct);
+                    spp5 = sp; cpp5 = cp;                                // sincos of line 512's predicted phase (lane 0 of step 0)
+                    sp = TL_SELECT(first, 0.0, sp); cp = TL_SELECT(first, 1.0, cp);         // sincos(0.0)
+                    const double t1 = rn * cp - r_prime * cpp;
+                    const double t2 = rn * sp - r_prime * spp;
+                    const double t3 = rn + fabs(r_prime);
+                    cw[j] = t3 != 0 ? sqrt(t1 * t1 + t2 * t2) / t3 : 0;
+                    x[j] = e;
+                }
+                L(r2)[it] = L(r1)[it]; L(r1)[it] = rn; L(p2)[it] = L(p1)[it]; L(p1)[it] = phi;
                 if (it == 0) {                                       // line 512 (psycho_2.c:110-140 with fft.c:1274's phase), finished by lane 0
                     const double c5 = L(xc);
                     const double e5 = c5 * c5;
                     const bool neg5 = (tl_d2u(c5) >> 63) != 0;       // atan2(+0.0, x) = pi for x < 0 and x = -0, else +0
                     const double phi5 = neg5 ? tl_u2d(0x400921fb54442d18ull) : 0.0;
-                    const double sp5 = neg5 ? tl_u2d(0x3ca1a62633145c07ull) : 0.0, cp5 = neg5 ? -1.0 : 1.0;   // glibc's sincos of that pi / of 0
                     const double rn5 = sqrt(e5);
-                    const double r_prime5 = 2.0 * r_o5 - r_n5;
-                    const double t15 = rn5 * cp5 - r_prime5 * cpp5;
-                    const double t25 = rn5 * sp5 - r_prime5 * spp5;
-                    const double t35 = rn5 + fabs(r_prime5);
-                    const double c512 = t35 != 0 ? sqrt(t15 * t15 + t25 * t25) / t35 : 0;
-                    if (first) { S->r[ch][nw][512] = rn5; S->phi[ch][nw][512] = phi5; cw[512] = c512; }
+                    double c512 = 0;
+                    if (!SEED) {
+                        const double sp5 = neg5 ? tl_u2d(0x3ca1a62633145c07ull) : 0.0, cp5 = neg5 ? -1.0 : 1.0;   // glibc's sincos of that pi / of 0
+                        const double r_prime5 = 2.0 * r_o5 - r_n5;
+                        const double t15 = rn5 * cp5 - r_prime5 * cpp5;
+                        const double t25 = rn5 * sp5 - r_prime5 * spp5;
+                        const double t35 = rn5 + fabs(r_prime5);
+                        c512 = t35 != 0 ? sqrt(t15 * t15 + t25 * t25) / t35 : 0;
+                    }
+                    if (first) { l5[0] = rn5; l5[1] = r_o5; l5[2] = phi5; l5[3] = p_o5; if (!SEED) cw[512] = c512; }
                     L(e512) = e5;                                    // slot 512 of the transform buffer still holds a point step 7 reads
                 }
-                L(r_o) = r_o2; L(r_n) = r_n2; L(p_o) = p_o2; L(p_n) = p_n2;
             }
             TL_LANES_END
         }
+        if (SEED) return;
         TL_LANES_BEGIN
         if (lane == 0) x[512] = L(e512);
         TL_LANES_END
@@ -2820,19 +2830,79 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
     TL_STAMP(sp, 23);                                                 // unit end
 }
 
-// Models 2 and 4 on the split path.  The model carries r/phi of the two previous passes per channel (psycho_2.c:300-306), so
-// the frames of a channel are a chain -- but the two channels of a stream share nothing: one unit = all frames of the launch
-// of ONE channel of one stream, in order.  It leaves the SMR itself in TlPsyOut::a (the model's last line needs no scalefactors).
-TL_FN void tl_psy2_chain(TlPsy2Lds &w, const TlLaunch &A, int s, int ch, const uint64_t *sct)
+// Models 2 and 4 on the split path.  One unit = frames [f0, f1) of ONE channel of one stream, in order (the two channels of a
+// stream share nothing).  The r/phi prediction state of the run lives in the wave's registers (tl_psy2_pass).  Where a run starts
+// at the launch's first frame the state comes from the stream's record (what the previous launch left; the passes before it
+// are PCM this launch cannot see); anywhere else two seed passes over frame f0 - 1 rebuild it.  The run that ends the launch
+// leaves the state for the next one -- in the OTHER of the record's two copies, so that it can never be read by a run of the
+// same launch that starts at frame 0 and is scheduled later.  It leaves the SMR itself in TlPsyOut::a (the model's last line
+// needs no scalefactors).
+TL_FN void tl_psy2_chain(TlPsy2Lds &w, const TlLaunch &A, int s, int ch, int f0, int f1, const uint64_t *sct)
 {
     const TlConfig *C = &A.configs[A.stream_cfg[s]];
-    if (ch >= C->nch) return;
-    for (int f = 0; f < A.nframes; f++) {
+    if (ch >= C->nch || f0 >= f1) return;
+    const TlPsy2Tables *P = &A.psy2_tables[C->psy2_tab];
+    PA(double, r1, 8); PA(double, r2, 8); PA(double, p1, 8); PA(double, p2, 8); PV(double, snr0);
+    double *l5 = TL_P2_L512(w);
+    if (f0 == 0) {
+        const TlPsy2State *S = &A.psy2_state[2 * (size_t)s + (size_t)A.psy2_flip];
+        TL_LANES_BEGIN
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int it = 0; it < 8; it++) {
+            const int j = lane + 64 * it;
+            L(r1)[it] = S->r[ch][0][j]; L(r2)[it] = S->r[ch][1][j]; L(p1)[it] = S->phi[ch][0][j]; L(p2)[it] = S->phi[ch][1][j];
+        }
+        if (lane == 0) { l5[0] = S->r[ch][0][512]; l5[1] = S->r[ch][1][512]; l5[2] = S->phi[ch][0][512]; l5[3] = S->phi[ch][1][512]; }
+        L(snr0) = 0.0;
+        TL_LANES_END
+    } else {
+        TL_LANES_BEGIN
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int it = 0; it < 8; it++) { L(r1)[it] = 0.0; L(r2)[it] = 0.0; L(p1)[it] = 0.0; L(p2)[it] = 0.0; }
+        if (lane == 0) { l5[0] = 0.0; l5[1] = 0.0; l5[2] = 0.0; l5[3] = 0.0; }
+        L(snr0) = 0.0;
+        TL_LANES_END
+        const TlPcmView pv = tl_pcm_view(A, &A.state[s], s, f0 - 1);
+        tl_psy2_pass<true>(w, A.tables, P, pv, ch, 0, r1, r2, p1, p2, snr0, nullptr, sct, nullptr);
+        tl_psy2_pass<true>(w, A.tables, P, pv, ch, 1, r1, r2, p1, p2, snr0, nullptr, sct, nullptr);
+    }
+    for (int f = f0; f < f1; f++) {
         const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
         const TlPcmView pv = tl_pcm_view(A, &A.state[s], s, f);
-        tl_psy2(w, A.tables, &A.psy2_tables[C->psy2_tab], &A.psy2_state[s], pv, ch,
-                A.stamps ? A.stamps + slot * 32 + 8 + 8 * ch : nullptr, &A.psy_out[slot].a[ch][0], sct);
+        long long *sp = A.stamps ? A.stamps + slot * 32 + 8 + 8 * ch : nullptr;
+        tl_psy2_pass<false>(w, A.tables, P, pv, ch, 0, r1, r2, p1, p2, snr0, &A.psy_out[slot].a[ch][0], sct, sp);
+        tl_psy2_pass<false>(w, A.tables, P, pv, ch, 1, r1, r2, p1, p2, snr0, &A.psy_out[slot].a[ch][0], sct, nullptr);
     }
+    if (f1 == A.nframes) {
+        TlPsy2State *S = &A.psy2_state[2 * (size_t)s + (size_t)(1 - A.psy2_flip)];
+        TL_LANES_BEGIN
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int it = 0; it < 8; it++) {
+            const int j = lane + 64 * it;
+            S->r[ch][0][j] = L(r1)[it]; S->r[ch][1][j] = L(r2)[it]; S->phi[ch][0][j] = L(p1)[it]; S->phi[ch][1][j] = L(p2)[it];
+        }
+        if (lane == 0) { S->r[ch][0][512] = l5[0]; S->r[ch][1][512] = l5[1]; S->phi[ch][0][512] = l5[2]; S->phi[ch][1][512] = l5[3]; }
+        TL_LANES_END
+    }
+}
+// Unit u of the psy-2 kernel's work list -> (chain, first frame, end frame).  The launch's chains (TlLaunch::chain_list: first
+// channels of the list's streams, then the second channels of its stereo streams) are dealt to the waves longest first: chains
+// [0, p2_nwhole) as ONE unit each, every chain after them cut into p2_k runs of p2_plen frames -- so that the last round of
+// waves is as full as the ones before it (the host picks the cut, tl_psy2_plan in mp2_host.cpp).
+TL_FN bool tl_psy2_unit(const TlLaunch &A, int u, int &chain, int &f0, int &f1)
+{
+    if (u < A.p2_nwhole) { chain = u; f0 = 0; f1 = A.nframes; return true; }
+    const int v = u - A.p2_nwhole, k = A.p2_k;
+    chain = A.p2_nwhole + v / k;
+    f0 = (v - (v / k) * k) * A.p2_plen;
+    f1 = f0 + A.p2_plen < A.nframes ? f0 + A.p2_plen : A.nframes;
+    return f0 < f1;
 }
 
 // [history | frame] -> LDS in 8-byte pieces, 120 + 288 per channel.  All of a lane's loads are issued before the first LDS

@@ -100,9 +100,10 @@ static __device__ __forceinline__ bool tl_take_unit(int32_t *heads, int nlist, i
 #define TL_MAIN_WPE 3
 #endif
 #define TL_LDS_GRANULE 1280u
-// psy kernel of models 2 and 4: a unit = one channel of one stream through the frames of the launch (tl_psy2_chain); units
-// [0, nlist) are the first channels, [nlist, 2 nlist) the second ones (mono streams: nothing to do).  No table in LDS (the
-// model's tables are read through the caches), 12.1 KB per wave: twelve waves per CU like the other psy kernels.
+// psy kernel of models 2 and 4: a unit = a run of frames of one channel of one stream (tl_psy2_unit: whole chains first, then
+// the chains of the last round of waves cut into runs, so that one stream with many frames fills the chip as well as many
+// streams do); the run's r/phi prediction state stays in the wave's registers (tl_psy2_chain).  No table in LDS but glibc's
+// sincos table (the model's own tables are read through the caches), 12.1 KB per wave: twelve waves per CU like the other kernels.
 #ifndef TL_PSY2_WAVES
 #define TL_PSY2_WAVES 12
 #endif
@@ -114,10 +115,12 @@ __global__ void __launch_bounds__(64 * TL_PSY2_WAVES) __attribute__((amdgpu_wave
     for (int i = (int)threadIdx.x; i < 440; i += 64 * TL_PSY2_WAVES) sct[i] = tlm_sincostab[i];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nunits = 2 * A.nlist, nwaves = (int)gridDim.x * TL_PSY2_WAVES;
+    const int nunits = A.p2_nwhole + (A.nchain - A.p2_nwhole) * A.p2_k, nwaves = (int)gridDim.x * TL_PSY2_WAVES;
     for (int u = (int)blockIdx.x * TL_PSY2_WAVES + wave; u < nunits; u = nwaves + tl_next_unit(&A.work[0])) {
-        const int ch = u >= A.nlist ? 1 : 0, k = u - ch * A.nlist;
-        tl_psy2_chain(lds[wave], A, __builtin_amdgcn_readfirstlane(A.stream_list[k]), ch, sct);
+        int c, f0, f1;
+        if (!tl_psy2_unit(A, u, c, f0, f1)) continue;
+        const int e = __builtin_amdgcn_readfirstlane(A.chain_list[c]);
+        tl_psy2_chain(lds[wave], A, e & 0x3fffffff, e >> 30, f0, f1, sct);
     }
 }
 
@@ -354,7 +357,10 @@ struct tlb_batch {
     int32_t *d_list[4] = {nullptr, nullptr, nullptr, nullptr};   // stream ids per psy model
     int n_list[4] = {0, 0, 0, 0};
     TlPsy2Tables *d_psy2_tables = nullptr;     // 2 * TL_PSY2_SLOTS tables (psy 2 per sample rate, then psy 4 per sample rate; tl_psy2_slot), only when a stream uses psy 2 / 4
-    TlPsy2State *d_psy2_state = nullptr;
+    TlPsy2State *d_psy2_state = nullptr;       // two copies per stream; a launch reads copy psy2_flip and writes the other (tl_psy2_chain)
+    int psy2_flip = 0;
+    int32_t *d_chain = nullptr;                // psy-2 kernel: (stream, channel) chains of the launch, first channels first
+    int n_chain = 0;
     uint8_t *d_edi_version = nullptr;            // EDI: ODRv string and per-stream frame sizes (allocated on first use)
     int32_t *d_frame_bytes = nullptr, *d_unit_bytes = nullptr;
     int max_upf = 1;                             // egress units (3 * kbps bytes) per frame: 1 at 48 kHz, 2 at 24 kHz, 3 at 16 kHz; 0 = a stream's frames are no whole number of units
@@ -436,6 +442,7 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_newlag) (void)hipFree(b->d_newlag);
     if (b->d_psy2_tables) (void)hipFree(b->d_psy2_tables);
     if (b->d_psy2_state) (void)hipFree(b->d_psy2_state);
+    if (b->d_chain) (void)hipFree(b->d_chain);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->ev_mid) (void)hipEventDestroy(b->ev_mid);
@@ -512,8 +519,17 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
         }
         HIPCHK(hipMalloc(&b->d_psy2_tables, sizeof(TlPsy2Tables) * ht2.size()));
         HIPCHK(hipMemcpy(b->d_psy2_tables, ht2.data(), sizeof(TlPsy2Tables) * ht2.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMalloc(&b->d_psy2_state, sizeof(TlPsy2State) * (size_t)nstreams));
-        HIPCHK(hipMemset(b->d_psy2_state, 0, sizeof(TlPsy2State) * (size_t)nstreams));
+        HIPCHK(hipMalloc(&b->d_psy2_state, sizeof(TlPsy2State) * 2 * (size_t)nstreams));
+        HIPCHK(hipMemset(b->d_psy2_state, 0, sizeof(TlPsy2State) * 2 * (size_t)nstreams));
+        std::vector<int32_t> chains;
+        for (int ch = 0; ch < 2; ch++)
+            for (int s2 = 0; s2 < nstreams; s2++) {
+                const TlConfig &c = b->h_configs[b->h_stream_cfg[s2]];
+                if ((c.psy == 2 || c.psy == 4) && ch < c.nch) chains.push_back(s2 | (ch << 30));
+            }
+        b->n_chain = (int)chains.size();
+        HIPCHK(hipMalloc(&b->d_chain, sizeof(int32_t) * chains.size()));
+        HIPCHK(hipMemcpy(b->d_chain, chains.data(), sizeof(int32_t) * chains.size(), hipMemcpyHostToDevice));
     }
     {
         HIPCHK(hipMalloc(&b->d_newpend, sizeof(uint32_t) * TL_MAX_FRAME_WORDS * (size_t)nstreams));
@@ -543,7 +559,7 @@ int tlb_reset(tlb_batch *b)
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemset(b->d_state, 0, sizeof(TlStreamState) * (size_t)b->nstreams));
-    if (b->d_psy2_state) HIPCHK(hipMemset(b->d_psy2_state, 0, sizeof(TlPsy2State) * (size_t)b->nstreams));
+    if (b->d_psy2_state) HIPCHK(hipMemset(b->d_psy2_state, 0, sizeof(TlPsy2State) * 2 * (size_t)b->nstreams));
     b->frames = 0;
     return TLB_OK;
 }
@@ -583,8 +599,14 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         A.padbits = b->pads[p] ? (uint8_t *)b->stage[7] : nullptr; A.newlag = b->d_newlag;
         if (b->pads[p]) { hipLaunchKernelGGL(tl_slots_kernel, dim3((unsigned)((b->n_list[p] + 255) / 256)), dim3(256), 0, st, A); HIPCHK(hipGetLastError()); }
         HIPCHK(hipMemsetAsync(b->d_work, 0, sizeof(int32_t) * TL_HEAD_STRIDE * 9, st));
-        long qb = (2L * b->n_list[p] + TL_PSY2_WAVES - 1) / TL_PSY2_WAVES;
-        if (qb > b->num_cu) qb = b->num_cu;
+        long qb = 0;
+        if (p == 2) {
+            A.chain_list = b->d_chain; A.nchain = b->n_chain; A.psy2_flip = b->psy2_flip;
+            const int nunits = tl_psy2_plan(b->n_chain, nframes, b->num_cu * TL_PSY2_WAVES, &A.p2_nwhole, &A.p2_k, &A.p2_plen);
+            qb = ((long)nunits + TL_PSY2_WAVES - 1) / TL_PSY2_WAVES;
+            if (qb > b->num_cu) qb = b->num_cu;
+            b->psy2_flip ^= 1;
+        }
         if (p == 1 || p == 3) {                                      // psy model and encoder in one kernel
             long mb1 = (units + TL_MAIN_WAVES - 1) / TL_MAIN_WAVES;
             if (mb1 > b->num_cu) mb1 = b->num_cu;

@@ -23,6 +23,7 @@ struct Emu {
     std::vector<TlStreamState> state;
     std::vector<TlPsy2Tables> psy2_tables;
     std::vector<TlPsy2State> psy2_state;
+    int psy2_flip = 0;
 };
 
 extern "C" {
@@ -48,8 +49,8 @@ void *emu_create(int nstreams, const long *fs, const char *mode, const int *kbps
             tl_build_psy2_tables(&e->psy2_tables[tl_psy2_slot(rates[i])], rates[i]);
             tl_build_psy4_tables(&e->psy2_tables[TL_PSY2_SLOTS + tl_psy2_slot(rates[i])], rates[i]);
         }
-        e->psy2_state.resize(nstreams);
-        memset(e->psy2_state.data(), 0, sizeof(TlPsy2State) * nstreams);
+        e->psy2_state.resize(2 * (size_t)nstreams);                 // two copies per stream (tl_psy2_chain)
+        memset(e->psy2_state.data(), 0, sizeof(TlPsy2State) * 2 * (size_t)nstreams);
     }
     if (err) *err = 0;
     return e;
@@ -93,9 +94,24 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
     for (int s = 0; s < A.nstreams; s++) pads |= e->configs[e->stream_cfg[s]].pad_frac != 0;
     if (pads) { A.padbits = padbits.data(); A.newlag = newlag.data(); }
     auto model = [&](int s) { return e->configs[e->stream_cfg[s]].psy; };
-    for (int ch = 1; ch >= 0; ch--)
-        for (int s = 0; s < A.nstreams; s++)
-            if (model(s) == 2 || model(s) == 4) tl_psy2_chain(wq, A, s, ch, tlm_sincostab);
+    {   // the psy-2 kernel's work list as on the device, planned for a machine of `slots` waves (EMU_PSY2_SLOTS, default 3: the
+        // last round is cut into runs in nearly every shape) and run in DESCENDING unit order: runs of a chain are independent
+        std::vector<int32_t> chains;
+        for (int ch = 0; ch < 2; ch++)
+            for (int s = 0; s < A.nstreams; s++)
+                if ((model(s) == 2 || model(s) == 4) && ch < e->configs[e->stream_cfg[s]].nch) chains.push_back(s | (ch << 30));
+        if (!chains.empty()) {
+            const char *env = getenv("EMU_PSY2_SLOTS");
+            A.chain_list = chains.data(); A.nchain = (int)chains.size(); A.psy2_flip = e->psy2_flip;
+            const int nunits = tl_psy2_plan(A.nchain, nframes, env ? atoi(env) : 3, &A.p2_nwhole, &A.p2_k, &A.p2_plen);
+            for (int u = nunits - 1; u >= 0; u--) {
+                int c, f0, f1;
+                if (!tl_psy2_unit(A, u, c, f0, f1)) continue;
+                tl_psy2_chain(wq, A, chains[c] & 0x3fffffff, chains[c] >> 30, f0, f1, tlm_sincostab);
+            }
+            e->psy2_flip ^= 1;
+        }
+    }
     if (pads) for (int s = 0; s < A.nstreams; s++) tl_slots_stream(A, s);
     for (int s = 0; s < A.nstreams; s++)
         for (int f = nframes - 1; f >= 0; f--) {
@@ -106,6 +122,23 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
         }
     for (int s = 0; s < A.nstreams; s++) tl_finish_stream(A, s);
     return 0;
+}
+// The psy-2 kernel's work list for a launch shape: units[nunits][3] = (chain, first frame, end frame); returns nunits (<= cap).
+int emu_psy2_units(int nchain, int nframes, int slots, int32_t *units, int cap)
+{
+    TlLaunch A;
+    memset(&A, 0, sizeof A);
+    A.nchain = nchain; A.nframes = nframes;
+    const int n = tl_psy2_plan(nchain, nframes, slots, &A.p2_nwhole, &A.p2_k, &A.p2_plen);
+    if (n != A.p2_nwhole + (nchain - A.p2_nwhole) * A.p2_k) return -1;
+    int m = 0;
+    for (int u = 0; u < n; u++) {
+        int c, f0, f1;
+        if (!tl_psy2_unit(A, u, c, f0, f1)) { f0 = f1 = 0; }
+        if (m < cap) { units[3 * m] = c; units[3 * m + 1] = f0; units[3 * m + 2] = f1; }
+        m++;
+    }
+    return m;
 }
 int emu_pending(void *h, int s, uint8_t *out)
 {

@@ -55,3 +55,37 @@ def test_every_unit_exactly_once(nlist, nframes):
         got = run_launch(nlist, nframes, grid, wpb, rng)
         assert len(got) == nlist * nframes and len(set(got)) == len(got), (grid, wpb)
         assert set(got) == {(k, f) for k in range(nlist) for f in range(nframes)}
+
+
+# ---- the psy-2 kernel's work list (csrc/mp2_host.cpp tl_psy2_plan, csrc/mp2_wave.h tl_psy2_unit): whole chains, then runs of frames ----
+@pytest.mark.parametrize("slots", [1, 3, 12, 3072])
+def test_psy2_runs_cover_every_frame_of_every_chain_once(slots):
+    import ctypes as C
+    import numpy as np
+    import emulib
+    L = emulib.lib()
+    L.emu_psy2_units.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    rng = random.Random(slots)
+    shapes = [(1, 1), (2, 1), (2, 16), (2, 8192), (5, 7), (8192, 32), (8192, 1), (3073, 8), (4096, 3), (24576, 8), (6144, 32), (7, 33)]
+    shapes += [(rng.randrange(1, 9000), rng.randrange(1, 70)) for _ in range(40)]
+    for nchain, nframes in shapes:
+        cap = nchain * max(1, nframes)
+        units = np.zeros((cap, 3), dtype=np.int32)
+        n = L.emu_psy2_units(nchain, nframes, slots, units.ctypes.data, cap)
+        assert 0 < n <= cap, (nchain, nframes, slots, n)
+        u = units[:n]
+        u = u[u[:, 2] > u[:, 1]]                               # empty runs are skipped by the kernel
+        assert (u[:, 1] >= 0).all() and (u[:, 2] <= nframes).all() and (u[:, 0] >= 0).all() and (u[:, 0] < nchain).all()
+        cover = np.zeros((nchain, nframes + 1), dtype=np.int32)
+        np.add.at(cover, (u[:, 0], u[:, 1]), 1)
+        np.add.at(cover, (u[:, 0], u[:, 2]), -1)
+        assert (np.cumsum(cover, axis=1)[:, :nframes] == 1).all(), (nchain, nframes, slots)
+        # longest first: whole chains come before every run, and no plan is slower than one unit per chain
+        lens = (units[:n, 2] - units[:n, 1])
+        whole = lens == nframes
+        assert not whole[np.argmin(whole):].any() or whole.all()
+        rounds = lambda k: -(-k // slots)
+        t_plain = rounds(nchain) * nframes
+        nw = int(whole.sum()) if not whole.all() else nchain
+        t_plan = rounds(nw) * nframes if whole.all() else (nw // slots) * nframes + rounds(n - nw) * (lens[~whole].max() + 0.5)
+        assert t_plan <= t_plain + 1e-9, (nchain, nframes, slots, t_plan, t_plain)
