@@ -66,6 +66,7 @@ TL_FN void tlh_incl_xscan_u32(uint32_t (&d)[64], const uint32_t (&v)[64]) { uint
 #define TL_SELECT(c, a, b) ((c) ? (a) : (b))
 #define TL_LAUNDER(p) ((void)0)
 #define TL_KEEP(x) ((void)0)
+#define TL_PIN(x) ((void)0)
 #else
 #define TL_FN __device__ __forceinline__
 #define TL_LANES_BEGIN { int lane_ = (int)(threadIdx.x & 63u); asm volatile("" : "+v"(lane_)); __builtin_assume(lane_ >= 0 && lane_ < 64); const int lane = lane_;
@@ -186,6 +187,8 @@ TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
 #define TL_SELECT(c, a, b) (__builtin_unpredictable(c) ? (a) : (b))      /* a v_cndmask, never a divergent branch */
 #define TL_KEEP(x) asm volatile("" : : "v"(x))             /* x is computed (a load: issued) here, not sunk into a later branch */
 #define TL_LAUNDER(p) asm volatile("" : "+s"(p))       /* keeps loads through p inside the frame loop (no hoisting into long-lived VGPRs) */
+#define TL_PIN(x) asm volatile("" : "+v"(x))           /* a constant made once, here, in a vector register: machine LICM is off (csrc/Makefile), so a literal used inside a hot loop
+                                                          is otherwise re-made by a v_mov on every trip */
 #endif
 
 // Issue priority of the wave (s_setprio 0..3).  A wave inside a serial, latency-bound piece (a dB-sum chain: one table look-up
@@ -212,13 +215,21 @@ TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
 #include <stdlib.h>
 #define TL_DBG_DUMP(tag, ch, nt, nn, x, b) do { if (getenv("TL_DUMP")) { printf("%s ch%d ntone %d nnoise %d:", tag, ch, nt, nn); \
     for (int i_ = 0; i_ < (nt) + (nn); i_++) printf(" (%.17g,%.6f)", (x)[i_], (b)[i_]); printf("\n"); } } while (0)
+#define TL_DBG_WALK(ch, lane, cnt) do { if (getenv("TL_DUMP_WALK")) printf("walk ch%d lane %d cnt %d\n", ch, lane, cnt); } while (0)
 #else
 #define TL_DBG_DUMP(tag, ch, nt, nn, x, b) ((void)0)
+#define TL_DBG_WALK(ch, lane, cnt) ((void)0)
 #endif
 // Diagnostic builds only (tools/instr_budget.sh): TL_EXP_LEVEL = n removes the last n stages of psy model 1 (results are then
 // wrong on purpose); the VALU-instruction counters of successive levels attribute the instructions to the stages.
 #ifndef TL_EXP_LEVEL
 #define TL_EXP_LEVEL 0
+#endif
+// The same for the encoder phase (tools/class_budget.sh): TL_ENC_LEVEL = n removes its last n stages -- 1: CRC-16 / ScF-CRC / X-PAD,
+// 2: + quantiser and sample packing, 3: + header / bit_alloc / scalefactor fields, 4: + bit allocation, 5: + scalefactors, SMR line and
+// transmission pattern (the filterbank alone is left; its samples are kept alive by an empty asm statement).
+#ifndef TL_ENC_LEVEL
+#define TL_ENC_LEVEL 0
 #endif
 #define TL_DBMIN (-200.0)
 #define TL_POWERNORM 90.3090
@@ -293,8 +304,11 @@ struct TlPsyLds {
 #define TL_MK_BARK(w) ((w).u.fft + TL_MASKER_MAX)      /* [TL_MASKER_MAX] */
 #define TL_LTG(w) ((w).u.fft + 2 * TL_MASKER_MAX)      /* [136] */
 // per-masker constants of the threshold loops, computed once per masker instead of once per (masker, line)
-struct alignas(16) TlMasker { double bark, av, g, n; };    // av = level term (psycho_1.c:493,512), g = 0.4x+6, n = 17-0.15x
-#define TL_MK4(w) ((TlMasker *)((w).u.fft + 2 * TL_MASKER_MAX + 136))   /* [TL_MASKER_MAX], ends at fft[904] */
+// av = level term (psycho_1.c:493,512), g = 0.4x+6, n = 17-0.15x; c17 = 17.0 sits BETWEEN g and n so that the pair of slopes a
+// line needs is one 16-byte window of the record: (g, 17) for a masker above the line, (17, n) for one below (tl_mask_term_w)
+struct TlMasker { double bark, av, g, c17, n; };
+#define TL_MK4(w) ((TlMasker *)((w).u.fft + 2 * TL_MASKER_MAX + 136))   /* [TL_MASKER_MAX], ends at fft[1032] */
+static_assert(2 * TL_MASKER_MAX + 136 + 5 * TL_MASKER_MAX <= TL_FFT_WORDS, "masker records fit the transform buffer");
 
 
 
@@ -322,6 +336,16 @@ TL_FN void tl_add_db2(const double *TL_RESTRICT dbtable, double &a0, double b0, 
     const double t0 = dbtable[i0], t1 = dbtable[i1];
     a0 = s0 + t0; a1 = s1 + t1;
 }
+TL_FN void tl_add_db2_k(const double *TL_RESTRICT dbtable, int k1000, double &a0, double b0, double &a1, double b1)
+{
+    const double f0 = 10.0 * (a0 - b0), f1 = 10.0 * (a1 - b1);
+    const double g0 = __builtin_fabs(f0), g1 = __builtin_fabs(f1);
+    int i0 = TL_SELECT(g0 > 990.0, k1000, (int)g0), i1 = TL_SELECT(g1 > 990.0, k1000, (int)g1);
+    const double s0 = TL_SELECT(f0 > -1.0, a0, b0), s1 = TL_SELECT(f1 > -1.0, a1, b1);
+    TL_KEEP(i0); TL_KEEP(i1);
+    const double t0 = dbtable[i0], t1 = dbtable[i1];
+    a0 = s0 + t0; a1 = s1 + t1;
+}
 TL_FN uint64_t tl_mnr_key(double mnr)
 {   // order-preserving map double -> u64 for the allocation arg-min; ~0 = never chosen (encode_new.c:1068: small = 999999.0)
     uint64_t u = tl_d2u(mnr + 0.0);
@@ -337,6 +361,15 @@ TL_FN uint64_t tl_mnr_key(double mnr)
 // C is the inside A times B (a product with 0.0 or 1.0 is exact): 64-bit selects cost two instructions, a product one.
 // A masker out of reach (dz outside [-3, 8)) enters the dB sum as a level below -65536 dB, which leaves the sum as it
 // is (|difference| > 99 dB: the reference returns the larger operand, tl_add_db adds its -0.0 entry).
+// The literals of the threshold walk, made once per walk (TL_PIN) instead of once per masker and line.
+struct TlMaskK { uint32_t c17_hi, one_hi, far_hi; int k1000; };
+TL_FN TlMaskK tl_mask_consts()
+{
+    TlMaskK k;
+    k.c17_hi = 0x40310000u; k.one_hi = 0x3ff00000u; k.far_hi = 0xC0F00000u; k.k1000 = 1000;
+    TL_PIN(k.c17_hi); TL_PIN(k.one_hi); TL_PIN(k.far_hi); TL_PIN(k.k1000);
+    return k;
+}
 TL_FN double tl_mask_term(double dz, double av, double g, double n, bool live = true)
 {
     const double ad = __builtin_fabs(dz);
@@ -349,9 +382,58 @@ TL_FN double tl_mask_term(double dz, double av, double g, double n, bool live = 
     const uint32_t hi = TL_SELECT(in, (uint32_t)(tu >> 32), 0xC0F00000u);
     return tl_u2d(((uint64_t)hi << 32) | (tu & 0xffffffffull));
 }
-TL_FN double tl_mask_step(const double *TL_RESTRICT db, double x, double dz, double av, double g, double n)
+// The same term with the walk's pinned literals.  Same operations on the same values: 17.0 = {c17_hi, 0}, 1.0 = {one_hi, 0}.
+TL_FN double tl_mask_term_k(const TlMaskK &k, double dz, double av, double g, double n, bool live = true)
 {
-    return tl_add_db(db, x, tl_mask_term(dz, av, g, n));
+    const double ad = __builtin_fabs(dz);
+    const bool s = dz < 0.0, o = ad >= 1.0;
+    const uint64_t gu = tl_d2u(g), nu = tl_d2u(n);
+    const uint32_t Gh = TL_SELECT(s, (uint32_t)(gu >> 32), k.c17_hi), Gl = TL_SELECT(s, (uint32_t)gu, 0u);
+    const uint32_t Hh = TL_SELECT(s, k.c17_hi, (uint32_t)(nu >> 32)), Hl = TL_SELECT(s, 0u, (uint32_t)nu);
+    const uint32_t Ah = TL_SELECT(o, Hh, Gh), Al = TL_SELECT(o, Hl, Gl);
+    const double G = tl_u2d(((uint64_t)Gh << 32) | Gl), A = tl_u2d(((uint64_t)Ah << 32) | Al);
+    const double Bc = tl_u2d((uint64_t)TL_SELECT(o, k.one_hi, 0u) << 32);
+    const double term = av - (A * (ad - Bc) + G * Bc);
+    const bool in = live && dz >= -3.0 && dz < 8.0;
+    const uint64_t tu = tl_d2u(term);
+    const uint32_t hi = TL_SELECT(in, (uint32_t)(tu >> 32), k.far_hi);
+    return tl_u2d(((uint64_t)hi << 32) | (tu & 0xffffffffull));
+}
+// 1 for a negative x, else 0.  On the device one shift of the high word, opaque to the compiler (which otherwise folds it into the
+// address arithmetic that follows as shift + and + add: three instructions where shift + shift-add do).
+TL_FN int tl_sign_bit(double x)
+{
+#ifdef TL_EMULATE
+    return (int)(tl_d2u(x) >> 63);
+#else
+    int r;
+    asm("v_lshrrev_b32 %0, 31, %1" : "=v"(r) : "v"((uint32_t)(tl_d2u(x) >> 32)));
+    return r;
+#endif
+}
+// The same term without a select for its shape.  dzp = masker bark - line bark = -dz (exactly: negation commutes with rounding).
+//  * which pair of slopes (inner G, outer H): dz < 0 -> (g, 17), else (17, n) -- the 16-byte window of the masker's record at
+//    &g + (dzp < 0): one address computed from the sign bit, one LDS read.  At dz = 0 either window serves (both products are 0).
+//  * inside / outside |dz| = 1:  A (ad - Bc) + G Bc  with  (A, Bc) = (H, 1) outside, (G, 0) inside  is  H max(ad - 1, 0) + G min(ad, 1):
+//    outside the very same operations (ad - 1.0; G * 1.0 == G); inside G * ad plus a zero in either form, and adding a zero of
+//    either sign to a sum changes no bit of it unless the sum is itself a zero -- in which case the term is av - (+-0) = av
+//    in either form, av never being -0.0 (a sum of finite non-zero values never rounds to -0).
+//  * the reach test -3 <= dz < 8 is -8 < dzp <= 3.
+TL_FN double tl_mask_term_w(const TlMasker *TL_RESTRICT m, double dzp, double av, uint32_t far_hi, bool live = true)
+{
+    const double ad = __builtin_fabs(dzp);
+    const double *gh = &m->g + tl_sign_bit(dzp);
+    const double G = gh[0], H = gh[1];
+    const double t1 = __builtin_fmax(ad - 1.0, 0.0), t2 = __builtin_fmin(ad, 1.0);
+    const double term = av - (H * t1 + G * t2);
+    const bool in = live && dzp <= 3.0 && dzp > -8.0;
+    const uint64_t tu = tl_d2u(term);
+    const uint32_t hi = TL_SELECT(in, (uint32_t)(tu >> 32), far_hi);
+    return tl_u2d(((uint64_t)hi << 32) | (tu & 0xffffffffull));
+}
+TL_FN double tl_mask_step(const double *TL_RESTRICT db, double x, const TlMasker *TL_RESTRICT m, double dzp, double av, uint32_t far_hi)
+{
+    return tl_add_db(db, x, tl_mask_term_w(m, dzp, av, far_hi));
 }
 TL_FN void tl_masker_consts(TlMasker *TL_RESTRICT mk, const double *TL_RESTRICT mx, const double *TL_RESTRICT mbk, int t, bool tonal)
 {
@@ -359,6 +441,7 @@ TL_FN void tl_masker_consts(TlMasker *TL_RESTRICT mk, const double *TL_RESTRICT 
     mk[t].bark = mb;
     mk[t].av = tonal ? -1.525 - 0.275 * mb - 4.5 + x : -1.525 - 0.175 * mb - 0.5 + x;
     mk[t].g = 0.4 * x + 6;
+    mk[t].c17 = 17.0;
     mk[t].n = 17 - 0.15 * x;
 }
 // s / d given r = RN(1/d): two residual corrections with fused multiply-adds.  After the first, q is a faithful
@@ -1102,15 +1185,18 @@ TL_FN void tl_psy1_thresholds(TlPsyLds &w, const double *TL_RESTRICT db, const T
             double x0 = TL_DBMIN, x1 = TL_DBMIN;
             const int nt = a1 >= a0 ? a1 - a0 + 1 : 0, cnt = nt + (b1 >= b0 ? b1 - b0 + 1 : 0);
             int t = nt ? a0 : b0;
+            TL_DBG_WALK(ch, lane, cnt);
+            const TlMaskK kk = tl_mask_consts();
             for (int i = 0; i < cnt; i += 2) {
                 const int tA = t, tB = tA == a1 ? b0 : tA + 1;
                 t = tB == a1 ? b0 : tB + 1;
-                const TlMasker A = mk[tA & (TL_MASKER_MAX - 1)], Bm = mk[tB & (TL_MASKER_MAX - 1)];
+                const TlMasker *pA = &mk[tA & (TL_MASKER_MAX - 1)], *pB = &mk[tB & (TL_MASKER_MAX - 1)];
+                const double bA = pA->bark, avA = pA->av, bB = pB->bark, avB = pB->av;
                 const bool two = i + 1 < cnt;                           // an odd walk ends with a masker that reaches nothing
-                const double mA0 = tl_mask_term(bk0 - A.bark, A.av, A.g, A.n), mA1 = tl_mask_term(bk1 - A.bark, A.av, A.g, A.n);
-                const double mB0 = tl_mask_term(bk0 - Bm.bark, Bm.av, Bm.g, Bm.n, two), mB1 = tl_mask_term(bk1 - Bm.bark, Bm.av, Bm.g, Bm.n, two);
-                tl_add_db2(db, x0, mA0, x1, mA1);
-                tl_add_db2(db, x0, mB0, x1, mB1);
+                const double mA0 = tl_mask_term_w(pA, bA - bk0, avA, kk.far_hi), mA1 = tl_mask_term_w(pA, bA - bk1, avA, kk.far_hi);
+                const double mB0 = tl_mask_term_w(pB, bB - bk0, avB, kk.far_hi, two), mB1 = tl_mask_term_w(pB, bB - bk1, avB, kk.far_hi, two);
+                tl_add_db2_k(db, kk.k1000, x0, mA0, x1, mA1);
+                tl_add_db2_k(db, kk.k1000, x0, mB0, x1, mB1);
             }
             TL_LTG(w)[k0] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k0] : C->p1_hear[k0] - 12.0, x0);
             if (h1) TL_LTG(w)[k1] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k1] : C->p1_hear[k1] - 12.0, x1);
@@ -1753,15 +1839,17 @@ TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
         int ta0, ta1, tb0, tb1;
         tl_mask_spans(mk, ntone + nnoise, ntone, (b0 < b1 ? b0 : b1) - 8.0, (b0 < b1 ? b1 : b0) + 3.0, ta0, ta1, tb0, tb1);
         double lt0 = TL_DBMIN, ln0 = TL_DBMIN, lt1 = TL_DBMIN, ln1 = TL_DBMIN;
+        uint32_t far_hi = 0xC0F00000u;
+        TL_PIN(far_hi);
         for (int t = ta0; t <= ta1; t++) {
-            const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, n = mk[t].n;
-            lt0 = tl_mask_step(db, lt0, b0 - mb, av, g, n);
-            lt1 = tl_mask_step(db, lt1, b1 - mb, av, g, n);
+            const double mb = mk[t].bark, av = mk[t].av;
+            lt0 = tl_mask_step(db, lt0, &mk[t], mb - b0, av, far_hi);
+            lt1 = tl_mask_step(db, lt1, &mk[t], mb - b1, av, far_hi);
         }
         for (int t = tb0; t <= tb1; t++) {
-            const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, n = mk[t].n;
-            ln0 = tl_mask_step(db, ln0, b0 - mb, av, g, n);
-            ln1 = tl_mask_step(db, ln1, b1 - mb, av, g, n);
+            const double mb = mk[t].bark, av = mk[t].av;
+            ln0 = tl_mask_step(db, ln0, &mk[t], mb - b0, av, far_hi);
+            ln1 = tl_mask_step(db, ln1, &mk[t], mb - b1, av, far_hi);
         }
         const double g0 = tl_add_db(db, ln0, lt0), g1 = tl_add_db(db, ln1, lt1);
         TL_LTG(w)[j0] = tl_add_db(db, C->br_per_ch < 96 ? ath[line0] : ath[line0] - 12.0, g0);
@@ -1779,9 +1867,11 @@ TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
         tl_mask_spans(mk, ntone + nnoise, ntone, bj - 8.0, bj + 3.0, ta0, ta1, tb0, tb1);
         const int t0 = lane < 8 ? ta0 : tb0, t1 = lane < 8 ? ta1 : tb1;
         double acc = TL_DBMIN;
+        uint32_t far_hi = 0xC0F00000u;
+        TL_PIN(far_hi);
         for (int t = t0; t <= t1; t++) {
-            const double mb = mk[t].bark, av = mk[t].av, g = mk[t].g, n = mk[t].n;
-            acc = tl_mask_step(db, acc, bj - mb, av, g, n);
+            const double mb = mk[t].bark, av = mk[t].av;
+            acc = tl_mask_step(db, acc, &mk[t], mb - bj, av, far_hi);
         }
         w.nsum[lane] = acc;
     }
@@ -2218,10 +2308,15 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     }
 
     TL_STAMP(sp, 1);
+#if !defined(TL_EMULATE) && TL_ENC_LEVEL >= 5
+    for (int b = 0; b < 36; b++) TL_KEEP(smp[b]);
+    scf[0] = scf[1] = scf[2] = 0;
+#endif
     // ---- K2: scalefactors (encode_new.c:179-230) + find_sf_max (:260-277) ----
     TL_LANES_BEGIN
     const int c = lane & 1, sb = lane >> 1;
-    if (c < nch && sb < sblimit) {
+    if (TL_ENC_LEVEL >= 5) { }
+    else if (c < nch && sb < sblimit) {
         unsigned lo = 63;
         for (int gr = 0; gr < 3; gr++) {
             double m = fabs(L(smp)[gr * 12 + 11]);
@@ -2239,7 +2334,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     TL_LANES_END
 
     // joint stereo: scalefactors of .5*(L+R) (toolame.c:332-337, encode_new.c:237-246)
-    if (C->mode0 == 1) {
+    if (TL_ENC_LEVEL < 5 && C->mode0 == 1) {
         for (int gr = 0; gr < 3; gr++) {
             PV(double, jm);
             TL_LANES_BEGIN L(jm) = 0.0; TL_LANES_END
@@ -2276,7 +2371,8 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
 
     TL_STAMP(sp, 2);
     // ---- K3/K4: psychoacoustic model -> SMR (toolame.c:361-452) ----
-    if constexpr (PSY == 0) {                                    // psycho_0.c:52-68
+    if constexpr (TL_ENC_LEVEL >= 5) { }
+    else if constexpr (PSY == 0) {                                    // psycho_0.c:52-68
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
         if (c < nch) {
@@ -2311,7 +2407,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     // ---- sf_transmission_pattern (encode_new.c:288-354, ISO Table C.4) ----
     TL_LANES_BEGIN
     const int c = lane & 1, sb = lane >> 1;
-    if (c < nch && sb < sblimit) {
+    if (TL_ENC_LEVEL < 5 && c < nch && sb < sblimit) {
         int s0 = L(scf)[0], s1 = L(scf)[1], s2 = L(scf)[2];
         int d0 = s0 - s1, d1 = s1 - s2;
         int c0 = d0 <= -3 ? 0 : d0 < 0 ? 1 : d0 == 0 ? 2 : d0 < 3 ? 3 : 4;
@@ -2348,7 +2444,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     L(a_smr) = live ? w.smr[c][sb] : 0.0;
     L(a_smr_o) = (live && nch == 2) ? w.smr[1 - c][sb] : 0.0;
     TL_LANES_END
-    if (C->mode0 == 1) {
+    if (TL_ENC_LEVEL < 4 && C->mode0 == 1) {
         // try plain stereo, then jsbound 16, 12, 8, 4 (encode_new.c:803-819).  What a cell needs for "no audible noise"
         // (bits_for_nonoise_new, encode_new.c:634-705) does not depend on the trial: the SNR column of an allocation line
         // is increasing, so the first allocation that masks the cell's own SMR is the number of allocations that do not,
@@ -2429,7 +2525,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
         const int ad = adb - (bbal + 16 + 32);
         int spent = 0;                                              // bspl + bscf + bsel
         const bool any_pair = nch == 2 && jsbound < sblimit;
-        for (;;) {                                                  // rounds
+        for (; TL_ENC_LEVEL < 4;) {                                 // rounds
             PV(uint64_t, keff); PV(uint64_t, k2eff);
             TL_LANES_BEGIN L(keff) = L(ukey); L(k2eff) = L(ukey2); TL_LANES_END
             if (any_pair) {                                         // a pair acts at the smaller of its two keys
@@ -2488,7 +2584,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
             TL_LANES_END
             if (last_round) break;
         }
-        for (;;) {                                                  // one event at a time
+        for (; TL_ENC_LEVEL < 4;) {                                 // one event at a time
             // maxmnr_new (encode_new.c:1061-1077): smallest mnr, first in (ch, sb) order
             PV(uint64_t, key);
             TL_LANES_BEGIN
@@ -2541,6 +2637,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     const int n_scf = TL_WAVE_SUM_I32(f_scf), n_smp = TL_WAVE_SUM_I32(f_smp);
     const int p_ba = 48, p_sel = p_ba + n_ba, p_scf = p_sel + n_sel, p_smp = p_scf + n_scf;
 
+    if (TL_ENC_LEVEL < 3) {
     TL_LANES_BEGIN
     const int c = lane & 1, sb = lane >> 1;
     if (lane == 0) {     // write_header (encode_new.c:356-373)
@@ -2561,9 +2658,10 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
         tl_put_bits48(frame, p_scf + L(o_scf), si == 0 ? f3 : si == 2 ? s0 : f2, L(f_scf));
     }
     TL_LANES_END
+    }
 
     // quantise (encode_new.c:479-547) + write_samples_new (:560-598): 12 rounds of 3 samples
-    {
+    if (TL_ENC_LEVEL < 2) {
         const bool any_joint = (nch == 2) && jsbound < sblimit;      // joint-coded subbands exist in this frame
         // per-lane constants of the frame: quantiser class and its coefficients, the three scalefactors
         PV(int, q_ba); PV(int, q_nb); PV(int, q_grp); PV(int, q_s2n); PV(int, q_steps);
@@ -2632,7 +2730,8 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     // (I(x) x^n + M(x) x^16) mod P -- linear over GF(2) -- so every lane takes one byte of M (a byte of the frame: the message is
     // byte aligned in it) and adds up bit_k * x^(16 + bits after the byte + k) mod P, starting from a table value and
     // multiplying by x per step; the two bytes of the preset ride on lanes 62/63; one XOR-reduce.
-    unsigned crc16;
+    unsigned crc16 = 0;
+    if (TL_ENC_LEVEL < 1) {
     {
         const int n = 16 + (p_scf - 48);
         PV(uint32_t, part);
@@ -2736,6 +2835,11 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     }
     TL_LANES_END
 
+    } else {
+        TL_LANES_BEGIN
+        if (lane < 4) w.ncentre[lane] = 0;
+        TL_LANES_END
+    }
     if (taps) {
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
