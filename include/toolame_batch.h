@@ -76,7 +76,24 @@ int tlb_device_count(void);
  * code in *err (if err != NULL). */
 tlb_batch *tlb_create(int device, int nstreams, const tlb_stream_config *cfgs, int *err);
 void tlb_destroy(tlb_batch *b);
-int tlb_reset(tlb_batch *b);                       /* back to the state right after tlb_create() */
+int tlb_reset(tlb_batch *b);                       /* every stream back to the state right after tlb_create() */
+
+/* Life cycle of ONE stream inside a live batch.  The reference's unit of restart is the stream -- toolame_init() zeroes one encoder
+ * (toolame.c:120-153), toolame_finish() ends one (:155-166), the six setters reconfigure one (toolame.h:13-48), and odr-audioenc
+ * restarts a failed input without touching anything else (src/odr-audioenc.cpp:875-902).  With thousands of streams in one batch the
+ * same three operations exist per stream.  Each waits for the launches already queued on the batch, then acts; none changes a byte
+ * any OTHER stream produces.  After any of them the stream is as right after tlb_create(): its next input frame is its frame 0
+ * (history of zeros, no pending frame: the output slot of the call that analyses it is empty, length 0 in the _len variants).
+ *   tlb_stream_reset        = toolame_init(): drops the pending frame.
+ *   tlb_stream_finish       = toolame_finish(): copies the pending frame (the bytes still inside the encoder) to out, returns their
+ *                             number (0: none yet; a too small buffer gets a truncated copy like the reference's); < 0: -TLB_ERR_*.
+ *   tlb_stream_reconfigure  = the setters + toolame_init(): a new sample rate / mode / bitrate / psy model / PAD length.  The frames
+ *                             of the new configuration must fit tlb_out_stride() and its units per frame tlb_egress_max_units_per_frame()
+ *                             as the batch was created with (else TLB_ERR_ARG / TLB_ERR_SAMPLERATE, nothing changed); illegal settings
+ *                             return the setter's error code. */
+int tlb_stream_reset(tlb_batch *b, int stream);
+int tlb_stream_finish(tlb_batch *b, int stream, uint8_t *out, size_t out_size);
+int tlb_stream_reconfigure(tlb_batch *b, int stream, const tlb_stream_config *cfg);
 
 int tlb_nstreams(const tlb_batch *b);
 int tlb_frame_bytes(const tlb_batch *b, int stream);   /* 144000*kbps/fs: 384 @128k/48k, 576 @192k/48k ...; at 44.1 / 22.05 kHz the frames
@@ -252,6 +269,12 @@ typedef struct {
 tlb_tick *tlb_tick_create(int device, int nstreams, const tlb_stream_config *cfgs, const tlb_tick_config *tc, int *err);
 void tlb_tick_destroy(tlb_tick *t);
 int tlb_tick_set_gain_db(tlb_tick *t, int stream, double gain_db);
+/* tlb_stream_reset / _finish / _reconfigure for one stream of a tick object, between two runs.  The stream's EDI sender state (SEQ,
+ * DLFC, timestamps) keeps running -- one continuous sender whose encoder restarted; until the stream's next frame is final its
+ * packets / messages / frame have length 0. */
+int tlb_tick_stream_reset(tlb_tick *t, int stream);
+int tlb_tick_stream_finish(tlb_tick *t, int stream, uint8_t *out, size_t out_size);
+int tlb_tick_stream_reconfigure(tlb_tick *t, int stream, const tlb_stream_config *cfg);
 int16_t *tlb_tick_pcm(tlb_tick *t);
 uint8_t *tlb_tick_xpad(tlb_tick *t);
 int32_t *tlb_tick_xpad_len(tlb_tick *t);

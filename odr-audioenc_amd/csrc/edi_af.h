@@ -45,6 +45,8 @@ struct TlEdiArgs {
     const int32_t *unit_bytes;       // [nstreams] 3 * kbps: what one send_frame() carries (divides frame_bytes)
     uint8_t *pkts;                   // [nframes * max_upf][nstreams][pkt_stride]
     int32_t *pkt_len;                // [nframes * max_upf][nstreams]; 0 = absent slot
+    const int32_t *frame_len;        // [nframes][nstreams] length of the frame in each input slot, 0 = the stream has no frame there (just created,
+                                     // reset or reconfigured: tlb_encode_device_len's d_out_len), or null = every slot holds a frame
     int32_t nstreams, nframes, out_stride, pkt_stride, version_len, max_upf;
 };
 #define TL_EDI_XPOW 2048             // longest AF packet: 10 + 16 + 18 + 11 + 1728 + 12 + 12 + version < 2048 bytes
@@ -127,13 +129,33 @@ TL_FN void tl_edi_af_packet(const TlEdiArgs &A, int s, int v)
     const uint32_t n = (uint32_t)A.unit_bytes[s];
     const int upf = A.frame_bytes[s] / (int)n, f = v / A.max_upf, u = v - f * A.max_upf;
     const size_t pslot = (size_t)v * (size_t)A.nstreams + (size_t)s;
-    if (u >= upf) {                                                   // this stream has no unit here
+    // frames of this stream that exist: before frame f, and frame f itself (a slot without a frame sends nothing and leaves the
+    // sender state -- SEQ, DLFC, timestamp -- where it is)
+    int before = f; bool present = true;
+    if (A.frame_len) {
+        before = 0;
+        for (int k = 0; k < f; k++) before += A.frame_len[(size_t)k * (size_t)A.nstreams + (size_t)s] != 0 ? 1 : 0;
+        present = A.frame_len[(size_t)f * (size_t)A.nstreams + (size_t)s] != 0;
+    }
+    if (u >= upf || !present) {                                       // this stream has no unit here
         TL_LANES_BEGIN
         if (lane == 0) A.pkt_len[pslot] = 0;
         TL_LANES_END
+        if (!present && f == A.nframes - 1 && u == upf - 1) {         // ... but the call's last slot still owes the state after the call
+            for (int k = 0; k < before * upf; k++) {
+                st.timestamp += 24u << 14;
+                if (st.timestamp > 0xf9FFffu) { st.timestamp -= 0xfa0000u; st.edi_time += 1; st.num_seconds_sent++; }
+                st.dlfc = (uint16_t)((st.dlfc + 1) % 5000);
+                if (st.send_version_at_time < st.edi_time) st.send_version_at_time += 10;
+                st.seq = (uint16_t)(st.seq + 1);
+            }
+            TL_LANES_BEGIN
+            if (lane == 0) A.state_out[s] = st;
+            TL_LANES_END
+        }
         return;
     }
-    const int e = f * upf + u;                                        // units of this stream before this one, in this call
+    const int e = before * upf + u;                                   // units of this stream before this one, in this call
     {
         const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
         // ---- sender state, Outputs.cpp:214-257; units 0..e-1 only advance it ----

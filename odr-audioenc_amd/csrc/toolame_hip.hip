@@ -284,7 +284,8 @@ __global__ void tl_silence_kernel(const int16_t *__restrict__ peaks, uint32_t *_
 // [u * unit, (u + 1) * unit) of frame f; a stream with fewer units per frame leaves its surplus slots empty (datasize 0 in an
 // all-zero header).  msgs [nframes * max_upf][nstreams][msg_stride]; one block per slot.
 __global__ void tl_zmq_frame_kernel(const uint8_t *__restrict__ frames, const int16_t *__restrict__ peaks, uint8_t *__restrict__ msgs,
-                                    const TlConfig *configs, const int32_t *stream_cfg, int nstreams, int out_stride, int msg_stride, int max_upf)
+                                    const TlConfig *configs, const int32_t *stream_cfg, int nstreams, int out_stride, int msg_stride, int max_upf,
+                                    const int32_t *__restrict__ frame_len)
 {
     const size_t pslot = blockIdx.x;
     const int s = (int)(pslot % (size_t)nstreams), v = (int)(pslot / (size_t)nstreams), f = v / max_upf, u = v - f * max_upf;
@@ -292,7 +293,7 @@ __global__ void tl_zmq_frame_kernel(const uint8_t *__restrict__ frames, const in
     const TlConfig &c = configs[stream_cfg[s]];
     const int n = 3 * c.kbps, upf = c.frame_bytes / n;
     uint8_t *m = msgs + pslot * (size_t)msg_stride;
-    if (u >= upf) { if (threadIdx.x < 3) ((uint32_t *)m)[threadIdx.x] = 0u; return; }
+    if (u >= upf || (frame_len && frame_len[slot] == 0)) { if (threadIdx.x < 3) ((uint32_t *)m)[threadIdx.x] = 0u; return; }   // no unit here / no frame in this slot
     if (threadIdx.x < 3) {
         const int pl = peaks ? peaks[slot * 2] : 0, pr = peaks ? peaks[slot * 2 + 1] : 0;
         const uint32_t w = threadIdx.x == 0 ? (1u | (2u << 16)) : threadIdx.x == 1 ? (uint32_t)n
@@ -347,6 +348,8 @@ struct tlb_batch {
     int device = 0, nstreams = 0, out_stride = 0;
     long frames = 0;
     std::vector<TlConfig> h_configs;
+    std::vector<tlb_stream_config> h_uniq;       // the six knobs of h_configs[i]
+    size_t cfg_cap = 0;                          // records d_configs has room for
     std::vector<int32_t> h_stream_cfg;
     TlTables *d_tables = nullptr;
     TlConfig *d_configs = nullptr;
@@ -362,6 +365,8 @@ struct tlb_batch {
     int32_t *d_chain = nullptr;                // psy-2 kernel: (stream, channel) chains of the launch, first channels first
     int n_chain = 0;
     uint8_t *d_edi_version = nullptr;            // EDI: ODRv string and per-stream frame sizes (allocated on first use)
+    char h_edi_version[TL_EDI_MAX_VERSION] = {}; // the string d_edi_version holds
+    int edi_version_len = -1;
     int32_t *d_frame_bytes = nullptr, *d_unit_bytes = nullptr;
     int max_upf = 1;                             // egress units (3 * kbps bytes) per frame: 1 at 48 kHz, 2 at 24 kHz, 3 at 16 kHz; 0 = a stream's frames are no whole number of units
     TlEdiState *d_edi_state_tmp = nullptr;
@@ -449,6 +454,52 @@ void tlb_destroy(tlb_batch *b)
     delete b;
 }
 
+// Everything that follows from WHICH stream has WHICH configuration: the per-model stream lists of the kernels, the psy-2 kernel's
+// chains, the padding flags, and -- allocated the first time a stream needs them -- the psy 2/4 tables and state and the slot
+// recurrence's scratch.  Called at creation and again when a stream is reconfigured (tlb_stream_reconfigure).
+static int batch_build_lists(tlb_batch *b)
+{
+    const int nstreams = b->nstreams;
+    for (int p = 0; p < 4; p++) {
+        std::vector<int32_t> ids;
+        b->pads[p] = false;
+        // kernel p serves psy model p; model 4 runs the psy-2 kernel on its own tables (mp2_host.cpp: tl_build_psy4_tables)
+        for (int s2 = 0; s2 < nstreams; s2++) { const int m = b->h_configs[b->h_stream_cfg[s2]].psy; if ((m == 4 ? 2 : m) == p) { ids.push_back(s2); b->pads[p] |= b->h_configs[b->h_stream_cfg[s2]].pad_frac != 0; } }
+        b->n_list[p] = (int)ids.size();
+        if (ids.empty()) continue;
+        if (!b->d_list[p]) HIPCHK(hipMalloc(&b->d_list[p], sizeof(int32_t) * (size_t)nstreams));       // room for every stream: a list only changes its content later
+        HIPCHK(hipMemcpy(b->d_list[p], ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice));
+    }
+    if (b->n_list[2]) {
+        if (!b->d_psy2_tables) {
+            const long rates[TL_PSY2_SLOTS] = {48000, 32000, 24000, 16000, 44100, 22050};
+            std::vector<TlPsy2Tables> ht2(2 * TL_PSY2_SLOTS);            // psy 2 per rate, then psy 4 per rate
+            for (int i = 0; i < TL_PSY2_SLOTS; i++) {
+                tl_build_psy2_tables(&ht2[tl_psy2_slot(rates[i])], rates[i]);
+                tl_build_psy4_tables(&ht2[TL_PSY2_SLOTS + tl_psy2_slot(rates[i])], rates[i]);
+            }
+            HIPCHK(hipMalloc(&b->d_psy2_tables, sizeof(TlPsy2Tables) * ht2.size()));
+            HIPCHK(hipMemcpy(b->d_psy2_tables, ht2.data(), sizeof(TlPsy2Tables) * ht2.size(), hipMemcpyHostToDevice));
+            HIPCHK(hipMalloc(&b->d_psy2_state, sizeof(TlPsy2State) * 2 * (size_t)nstreams));
+            HIPCHK(hipMemset(b->d_psy2_state, 0, sizeof(TlPsy2State) * 2 * (size_t)nstreams));
+            HIPCHK(hipMalloc(&b->d_chain, sizeof(int32_t) * 2 * (size_t)nstreams));
+        }
+        std::vector<int32_t> chains;
+        for (int ch = 0; ch < 2; ch++)
+            for (int s2 = 0; s2 < nstreams; s2++) {
+                const TlConfig &c = b->h_configs[b->h_stream_cfg[s2]];
+                if ((c.psy == 2 || c.psy == 4) && ch < c.nch) chains.push_back(s2 | (ch << 30));
+            }
+        b->n_chain = (int)chains.size();
+        HIPCHK(hipMemcpy(b->d_chain, chains.data(), sizeof(int32_t) * chains.size(), hipMemcpyHostToDevice));
+    } else b->n_chain = 0;
+    if ((b->pads[0] || b->pads[1] || b->pads[2] || b->pads[3]) && !b->d_newlag) {
+        HIPCHK(hipMalloc(&b->d_newlag, sizeof(double) * (size_t)nstreams));
+        HIPCHK(hipMemset(b->d_newlag, 0, sizeof(double) * (size_t)nstreams));
+    }
+    return TLB_OK;
+}
+
 static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_stream_config *cfgs)
 {
     int ndev = 0;
@@ -457,7 +508,7 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
     b->nstreams = nstreams;
     b->h_stream_cfg.resize(nstreams);
     // streams sharing the six knobs share one config record (keeps the tables L2/L1 resident)
-    std::vector<tlb_stream_config> uniq;
+    std::vector<tlb_stream_config> &uniq = b->h_uniq;
     for (int s = 0; s < nstreams; s++) {
         int found = -1;
         for (size_t u = 0; u < uniq.size(); u++)
@@ -490,7 +541,8 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
     if (e == hipSuccess) e = hipMemcpy(b->d_tables, ht, sizeof(TlTables), hipMemcpyHostToDevice);
     delete ht;
     HIPCHK(e);
-    HIPCHK(hipMalloc(&b->d_configs, sizeof(TlConfig) * b->h_configs.size()));
+    b->cfg_cap = b->h_configs.size() + 8;                             // room for a few reconfigurations before the array has to move
+    HIPCHK(hipMalloc(&b->d_configs, sizeof(TlConfig) * b->cfg_cap));
     HIPCHK(hipMemcpy(b->d_configs, b->h_configs.data(), sizeof(TlConfig) * b->h_configs.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&b->d_stream_cfg, sizeof(int32_t) * nstreams));
     HIPCHK(hipMemcpy(b->d_stream_cfg, b->h_stream_cfg.data(), sizeof(int32_t) * nstreams, hipMemcpyHostToDevice));
@@ -499,43 +551,11 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
     b->h_gain.assign((size_t)nstreams, 1.0);
     HIPCHK(hipMalloc(&b->d_gain, sizeof(double) * (size_t)nstreams));
     HIPCHK(hipMemcpy(b->d_gain, b->h_gain.data(), sizeof(double) * (size_t)nstreams, hipMemcpyHostToDevice));
-    for (int p = 0; p < 4; p++) {
-        std::vector<int32_t> ids;
-        // kernel p serves psy model p; model 4 runs the psy-2 kernel on its own tables (mp2_host.cpp: tl_build_psy4_tables)
-        for (int s2 = 0; s2 < nstreams; s2++) { const int m = b->h_configs[b->h_stream_cfg[s2]].psy; if ((m == 4 ? 2 : m) == p) { ids.push_back(s2); b->pads[p] |= b->h_configs[b->h_stream_cfg[s2]].pad_frac != 0; } }
-        b->n_list[p] = (int)ids.size();
-        if (ids.empty()) continue;
-        HIPCHK(hipMalloc(&b->d_list[p], sizeof(int32_t) * ids.size()));
-        HIPCHK(hipMemcpy(b->d_list[p], ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice));
-    }
-    bool any2 = false;
-    for (auto &c : b->h_configs) any2 |= c.psy == 2 || c.psy == 4;
-    if (any2) {
-        const long rates[TL_PSY2_SLOTS] = {48000, 32000, 24000, 16000, 44100, 22050};
-        std::vector<TlPsy2Tables> ht2(2 * TL_PSY2_SLOTS);            // psy 2 per rate, then psy 4 per rate
-        for (int i = 0; i < TL_PSY2_SLOTS; i++) {
-            tl_build_psy2_tables(&ht2[tl_psy2_slot(rates[i])], rates[i]);
-            tl_build_psy4_tables(&ht2[TL_PSY2_SLOTS + tl_psy2_slot(rates[i])], rates[i]);
-        }
-        HIPCHK(hipMalloc(&b->d_psy2_tables, sizeof(TlPsy2Tables) * ht2.size()));
-        HIPCHK(hipMemcpy(b->d_psy2_tables, ht2.data(), sizeof(TlPsy2Tables) * ht2.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMalloc(&b->d_psy2_state, sizeof(TlPsy2State) * 2 * (size_t)nstreams));
-        HIPCHK(hipMemset(b->d_psy2_state, 0, sizeof(TlPsy2State) * 2 * (size_t)nstreams));
-        std::vector<int32_t> chains;
-        for (int ch = 0; ch < 2; ch++)
-            for (int s2 = 0; s2 < nstreams; s2++) {
-                const TlConfig &c = b->h_configs[b->h_stream_cfg[s2]];
-                if ((c.psy == 2 || c.psy == 4) && ch < c.nch) chains.push_back(s2 | (ch << 30));
-            }
-        b->n_chain = (int)chains.size();
-        HIPCHK(hipMalloc(&b->d_chain, sizeof(int32_t) * chains.size()));
-        HIPCHK(hipMemcpy(b->d_chain, chains.data(), sizeof(int32_t) * chains.size(), hipMemcpyHostToDevice));
-    }
+    if (int rc = batch_build_lists(b)) return rc;
     {
         HIPCHK(hipMalloc(&b->d_newpend, sizeof(uint32_t) * TL_MAX_FRAME_WORDS * (size_t)nstreams));
         HIPCHK(hipMemset(b->d_newpend, 0, sizeof(uint32_t) * TL_MAX_FRAME_WORDS * (size_t)nstreams));
         HIPCHK(hipMalloc(&b->d_work, sizeof(int32_t) * TL_HEAD_STRIDE * 9));
-        if (b->pads[0] || b->pads[1] || b->pads[2] || b->pads[3]) HIPCHK(hipMalloc(&b->d_newlag, sizeof(double) * (size_t)nstreams));
     }
     HIPCHK(hipEventCreate(&b->ev0));
     HIPCHK(hipEventCreate(&b->ev1));
@@ -553,15 +573,98 @@ tlb_batch *tlb_create(int device, int nstreams, const tlb_stream_config *cfgs, i
     return b;
 }
 
+// state of streams [s0, s0 + n) back to what tlb_create() left: the PCM history, the pending frame, the frame counter and the slot
+// recurrence (TlStreamState), the psy 2/4 prediction state (both copies), the launch scratch that is per stream
+static int batch_clear_streams(tlb_batch *b, int s0, int n)
+{
+    HIPCHK(hipMemset(b->d_state + s0, 0, sizeof(TlStreamState) * (size_t)n));
+    if (b->d_psy2_state) HIPCHK(hipMemset(b->d_psy2_state + 2 * (size_t)s0, 0, sizeof(TlPsy2State) * 2 * (size_t)n));
+    HIPCHK(hipMemset(b->d_newpend + (size_t)s0 * TL_MAX_FRAME_WORDS, 0, sizeof(uint32_t) * TL_MAX_FRAME_WORDS * (size_t)n));
+    if (b->d_newlag) HIPCHK(hipMemset(b->d_newlag + s0, 0, sizeof(double) * (size_t)n));
+    if (b->d_edi_state_tmp) HIPCHK(hipMemset(b->d_edi_state_tmp + s0, 0, sizeof(TlEdiState) * (size_t)n));
+    if (b->d_pseq_tmp) HIPCHK(hipMemset(b->d_pseq_tmp + s0, 0, sizeof(uint16_t) * (size_t)n));
+    return TLB_OK;
+}
+
 int tlb_reset(tlb_batch *b)
 {
     if (!b) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemset(b->d_state, 0, sizeof(TlStreamState) * (size_t)b->nstreams));
-    if (b->d_psy2_state) HIPCHK(hipMemset(b->d_psy2_state, 0, sizeof(TlPsy2State) * 2 * (size_t)b->nstreams));
+    if (int rc = batch_clear_streams(b, 0, b->nstreams)) return rc;
     b->frames = 0;
     return TLB_OK;
+}
+
+// ---- life cycle of ONE stream inside a live batch (include/toolame_batch.h) ----
+// The reference's unit of restart is the stream: toolame_init() zeroes one encoder (toolame.c:120-153), toolame_finish() ends one
+// (:155-166).  Here thousands share a batch, so the same three operations exist per stream; each waits for the batch's queued
+// launches first (they are rare events next to 41.7 frames per second and stream) and touches nothing of any other stream.
+int tlb_stream_reset(tlb_batch *b, int stream)
+{
+    if (!b || stream < 0 || stream >= b->nstreams) return TLB_ERR_ARG;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipDeviceSynchronize());
+    return batch_clear_streams(b, stream, 1);
+}
+
+int tlb_stream_finish(tlb_batch *b, int stream, uint8_t *out, size_t out_size)
+{   // toolame_finish(): the bytes still inside the encoder -- here the one pending frame -- then the encoder is as after toolame_init()
+    if (!b || stream < 0 || stream >= b->nstreams || (!out && out_size)) return -TLB_ERR_ARG;
+    if (hipSetDevice(b->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -TLB_ERR_HIP;
+    TlStreamState *st = new TlStreamState;
+    hipError_t e = hipMemcpy(st, b->d_state + stream, sizeof(TlStreamState), hipMemcpyDeviceToHost);
+    int n = 0;
+    if (e == hipSuccess && st->frames_done > 0) {
+        n = st->pending_len;
+        if ((size_t)n > out_size) n = (int)out_size;                 // a too small buffer gets a truncated copy, like the reference's (bitstream.c:54-58)
+        for (int i = 0; i < n; i++) out[i] = (uint8_t)(st->pending[i >> 2] >> (24 - 8 * (i & 3)));
+    }
+    delete st;
+    if (e != hipSuccess) return -TLB_ERR_HIP;
+    if (int rc = batch_clear_streams(b, stream, 1)) return -rc;
+    return n;
+}
+
+int tlb_stream_reconfigure(tlb_batch *b, int stream, const tlb_stream_config *cfg)
+{   // the setters of toolame.h:13-48 followed by toolame_init() for ONE stream: new sample rate / mode / bitrate / model / PAD length
+    if (!b || !cfg || stream < 0 || stream >= b->nstreams) return TLB_ERR_ARG;
+    int found = -1;
+    for (size_t u = 0; u < b->h_uniq.size(); u++)
+        if (b->h_uniq[u].samplerate == cfg->samplerate && b->h_uniq[u].mode == cfg->mode && b->h_uniq[u].bitrate == cfg->bitrate &&
+            b->h_uniq[u].psy_model == cfg->psy_model && b->h_uniq[u].pad_len == cfg->pad_len) { found = (int)u; break; }
+    TlConfig c;
+    if (found < 0) { if (int rc = tl_build_config(&c, cfg->samplerate, cfg->mode, cfg->bitrate, cfg->psy_model, cfg->pad_len)) return rc; }
+    else c = b->h_configs[(size_t)found];
+    // the caller's buffers were sized from tlb_out_stride() and tlb_egress_max_units_per_frame(): the new configuration must fit them
+    if (((c.frame_bytes + (c.pad_frac != 0 ? 1 : 0) + 3) & ~3) > b->out_stride) return TLB_ERR_ARG;
+    {
+        const int unit = 3 * c.kbps, upf = c.frame_bytes % unit ? 0 : c.frame_bytes / unit;
+        if (b->max_upf && (upf == 0 || upf > b->max_upf)) return TLB_ERR_SAMPLERATE;
+    }
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (found < 0) {
+        b->h_uniq.push_back(*cfg); b->h_configs.push_back(c);
+        found = (int)b->h_configs.size() - 1;
+        if (b->h_configs.size() > b->cfg_cap) {
+            TlConfig *nd = nullptr;
+            const size_t cap = 2 * b->h_configs.size();
+            HIPCHK(hipMalloc(&nd, sizeof(TlConfig) * cap));
+            (void)hipFree(b->d_configs);
+            b->d_configs = nd; b->cfg_cap = cap;
+            HIPCHK(hipMemcpy(b->d_configs, b->h_configs.data(), sizeof(TlConfig) * b->h_configs.size(), hipMemcpyHostToDevice));
+        } else HIPCHK(hipMemcpy(b->d_configs + found, &b->h_configs[(size_t)found], sizeof(TlConfig), hipMemcpyHostToDevice));
+    }
+    b->h_stream_cfg[(size_t)stream] = found;
+    HIPCHK(hipMemcpy(b->d_stream_cfg + stream, &b->h_stream_cfg[(size_t)stream], sizeof(int32_t), hipMemcpyHostToDevice));
+    if (int rc = batch_build_lists(b)) return rc;
+    if (b->d_frame_bytes) {                                          // EDI egress: per-stream frame and unit sizes
+        const int32_t fb = c.frame_bytes, ub = 3 * c.kbps;
+        HIPCHK(hipMemcpy(b->d_frame_bytes + stream, &fb, sizeof fb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b->d_unit_bytes + stream, &ub, sizeof ub, hipMemcpyHostToDevice));
+    }
+    return batch_clear_streams(b, stream, 1);
 }
 
 int tlb_nstreams(const tlb_batch *b) { return b ? b->nstreams : 0; }
@@ -824,13 +927,19 @@ int tlb_egress_units_per_frame(const tlb_batch *b, int s)
 }
 int tlb_egress_max_units_per_frame(const tlb_batch *b) { return b ? b->max_upf : 0; }
 
+static int zmq_frame_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_peaks, int nframes, uint8_t *d_msgs, void *hip_stream, const int32_t *d_frame_len);
 int tlb_zmq_frame_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_peaks, int nframes, uint8_t *d_msgs, void *hip_stream)
+{
+    return zmq_frame_device(b, d_frames, d_peaks, nframes, d_msgs, hip_stream, nullptr);
+}
+// d_frame_len: int32 [nframes][nstreams] or null -- 0 marks a slot without a frame (a stream just reset inside a tick object): no message
+static int zmq_frame_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_peaks, int nframes, uint8_t *d_msgs, void *hip_stream, const int32_t *d_frame_len)
 {
     if (!b || !d_frames || !d_msgs || nframes <= 0) return TLB_ERR_ARG;
     if (!b->max_upf) return TLB_ERR_SAMPLERATE;
     HIPCHK(hipSetDevice(b->device));
     hipLaunchKernelGGL(tl_zmq_frame_kernel, dim3((unsigned)((size_t)nframes * (size_t)b->max_upf * (size_t)b->nstreams)), dim3(128), 0, (hipStream_t)hip_stream,
-                       d_frames, d_peaks, d_msgs, b->d_configs, b->d_stream_cfg, b->nstreams, b->out_stride, 12 + b->out_stride, b->max_upf);
+                       d_frames, d_peaks, d_msgs, b->d_configs, b->d_stream_cfg, b->nstreams, b->out_stride, 12 + b->out_stride, b->max_upf, d_frame_len);
     HIPCHK(hipGetLastError());
     return TLB_OK;
 }
@@ -875,8 +984,16 @@ int tlb_edi_af_stride(const tlb_batch *b, int version_len)
     return (10 + 16 + 18 + 11 + b->out_stride + 12 + 12 + version_len + 2 + 3) & ~3;
 }
 
+static int edi_af_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_levels, int nframes, tlb_edi_state *d_state,
+                         const char *version, int version_len, uint8_t *d_pkts, int32_t *d_pkt_len, void *hip_stream, const int32_t *d_frame_len);
 int tlb_edi_af_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_levels, int nframes, tlb_edi_state *d_state,
                       const char *version, int version_len, uint8_t *d_pkts, int32_t *d_pkt_len, void *hip_stream)
+{
+    return edi_af_device(b, d_frames, d_levels, nframes, d_state, version, version_len, d_pkts, d_pkt_len, hip_stream, nullptr);
+}
+// d_frame_len: int32 [nframes][nstreams] or null -- 0 marks a slot without a frame: no packet, sender state untouched (csrc/edi_af.h)
+static int edi_af_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_levels, int nframes, tlb_edi_state *d_state,
+                         const char *version, int version_len, uint8_t *d_pkts, int32_t *d_pkt_len, void *hip_stream, const int32_t *d_frame_len)
 {
     if (!b || !d_frames || !d_state || !d_pkts || !d_pkt_len || nframes <= 0 || nframes > 65535 || version_len < 0 || version_len > TL_EDI_MAX_VERSION ||
         (version_len && !version) || (long)nframes * (b->max_upf ? b->max_upf : 1) > 65535) return TLB_ERR_ARG;
@@ -898,8 +1015,15 @@ int tlb_edi_af_device(tlb_batch *b, const uint8_t *d_frames, const int16_t *d_le
         guard_.v.clear();
         b->d_edi_version = d_v; b->d_frame_bytes = d_fb; b->d_unit_bytes = d_ub; b->d_edi_state_tmp = d_st;
     }
-    if (version_len) HIPCHK(hipMemcpyAsync(b->d_edi_version, version, (size_t)version_len, hipMemcpyHostToDevice, st));
+    // the ODRv string goes to the device when it changes, not on every call (an asynchronous copy from pageable memory may be
+    // staged or run synchronously: it would serialise the groups of a tick)
+    if (version_len && (version_len != b->edi_version_len || memcmp(b->h_edi_version, version, (size_t)version_len) != 0)) {
+        memcpy(b->h_edi_version, version, (size_t)version_len); b->edi_version_len = version_len;
+        HIPCHK(hipMemcpyAsync(b->d_edi_version, b->h_edi_version, (size_t)version_len, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));                            // once per string: the host copy may change after this call returns
+    }
     TlEdiArgs A;
+    A.frame_len = d_frame_len;
     A.frames = d_frames; A.levels = d_levels; A.state = (const TlEdiState *)d_state; A.state_out = b->d_edi_state_tmp; A.version = b->d_edi_version;
     A.xpow8 = b->d_tables->edi_xpow8; A.frame_bytes = b->d_frame_bytes; A.unit_bytes = b->d_unit_bytes; A.pkts = d_pkts; A.pkt_len = d_pkt_len;
     A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride; A.max_upf = b->max_upf;
@@ -1243,15 +1367,45 @@ int tlb_tick_set_gain_db(tlb_tick *t, int stream, double gain_db)
     return TLB_OK;
 }
 
+// Life cycle of one stream of a tick object (tlb_stream_reset / _finish / _reconfigure of its group's batch).  The EDI sender state
+// of the stream (SEQ, DLFC, timestamps) is NOT touched: the receiver sees one continuous sender whose encoder was restarted, as
+// with the reference, whose output object outlives an encoder re-initialisation.  Until the stream's next frame is final its
+// slots are empty (length 0).
+static TickGroup *tick_group_of(tlb_tick *t, int stream, int *local)
+{
+    if (!t || stream < 0 || stream >= t->nstreams) return nullptr;
+    TickGroup &G = t->groups[(size_t)t->group_of[(size_t)stream]];
+    *local = stream - G.first;
+    return &G;
+}
+int tlb_tick_stream_reset(tlb_tick *t, int stream)
+{
+    int k; TickGroup *G = tick_group_of(t, stream, &k);
+    if (!G || t->finished) return TLB_ERR_ARG;
+    return tlb_stream_reset(G->b, k);
+}
+int tlb_tick_stream_finish(tlb_tick *t, int stream, uint8_t *out, size_t out_size)
+{
+    int k; TickGroup *G = tick_group_of(t, stream, &k);
+    if (!G || t->finished) return -TLB_ERR_ARG;
+    return tlb_stream_finish(G->b, k, out, out_size);
+}
+int tlb_tick_stream_reconfigure(tlb_tick *t, int stream, const tlb_stream_config *cfg)
+{
+    int k; TickGroup *G = tick_group_of(t, stream, &k);
+    if (!G || t->finished) return TLB_ERR_ARG;
+    return tlb_stream_reconfigure(G->b, k, cfg);
+}
+
 // egress of the frames sitting in G.d_frames + copy-out, queued on s_run / s_out
 static int tick_egress(tlb_tick *t, TickGroup &G, bool have_frames, bool new_input = true)
 {
     const size_t n = (size_t)G.n, slots = n * (size_t)G.max_upf;
     if (new_input) if (int rc = tlb_silence_device(G.b, G.d_peaks, 1, G.d_silence, t->s_run)) return rc;       // odr-audioenc.cpp:1053-1079 (the decision stays with the caller)
     if (have_frames && t->egress == TLB_TICK_ZMQ) {
-        if (int rc = tlb_zmq_frame_device(G.b, G.d_frames, G.d_peaks, 1, G.d_msgs, t->s_run)) return rc;
+        if (int rc = zmq_frame_device(G.b, G.d_frames, G.d_peaks, 1, G.d_msgs, t->s_run, G.d_flen)) return rc;
     } else if (have_frames && t->egress != TLB_TICK_FRAMES) {
-        if (int rc = tlb_edi_af_device(G.b, G.d_frames, G.d_peaks, 1, G.d_state, t->version, t->version_len, G.d_pkts, G.d_plen, t->s_run)) return rc;
+        if (int rc = edi_af_device(G.b, G.d_frames, G.d_peaks, 1, G.d_state, t->version, t->version_len, G.d_pkts, G.d_plen, t->s_run, G.d_flen)) return rc;
         if (t->egress == TLB_TICK_EDI_PFT)
             if (int rc = tlb_edi_pft_device(G.b, G.d_pkts, G.d_plen, G.max_upf, G.af_stride, G.d_pseq, t->fec, t->chunk_len, t->transport, t->addr_source, t->dest_port,
                                             G.d_frags, G.d_fraglen, G.d_nfrag, G.max_frags, G.frag_stride, t->s_run)) return rc;

@@ -104,6 +104,12 @@ def load_library():
     L.tlb_edi_pft_shape.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.tlb_edi_pft_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int] * 2
     L.tlb_edi_pft_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int] * 2 + [C.c_void_p]
+    L.tlb_stream_reset.argtypes = [C.c_void_p, C.c_int]
+    L.tlb_stream_finish.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.tlb_stream_reconfigure.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.tlb_tick_stream_reset.argtypes = [C.c_void_p, C.c_int]
+    L.tlb_tick_stream_finish.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.tlb_tick_stream_reconfigure.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.tlb_tick_create.restype = C.c_void_p
     L.tlb_tick_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     L.tlb_tick_destroy.argtypes = [C.c_void_p]
@@ -222,6 +228,25 @@ class Tick:
         rc = self.L.tlb_tick_set_gain_db(self.h, stream, float(gain_db))
         if rc:
             raise ToolameError(rc, "tlb_tick_set_gain_db")
+
+    # -- life cycle of one stream between two runs (toolame_init / toolame_finish / the setters, per stream) --
+    def stream_reset(self, s):
+        rc = self.L.tlb_tick_stream_reset(self.h, s)
+        if rc:
+            raise ToolameError(rc, "tlb_tick_stream_reset")
+
+    def stream_finish(self, s):
+        buf = (C.c_uint8 * 2048)()
+        n = self.L.tlb_tick_stream_finish(self.h, s, buf, 2048)
+        if n < 0:
+            raise ToolameError(-n, "tlb_tick_stream_finish")
+        return bytes(buf[:n])
+
+    def stream_reconfigure(self, s, config):
+        rc = self.L.tlb_tick_stream_reconfigure(self.h, s, _config_array([config]))
+        if rc:
+            raise ToolameError(rc, "tlb_tick_stream_reconfigure")
+        self.units[s] = self.L.tlb_tick_units(self.h, s)
 
     def run(self):
         rc = self.L.tlb_tick_run(self.h)
@@ -346,6 +371,36 @@ class Batch:
         if rc:
             raise ToolameError(rc, "tlb_flush_host_len")
         return [out[s, : lens[s]].tobytes() for s in range(self.nstreams)]
+
+    def reset(self):
+        rc = self.L.tlb_reset(self.h)
+        if rc:
+            raise ToolameError(rc, "tlb_reset")
+
+    # -- life cycle of one stream inside the live batch (toolame.c:120-166 per stream) --------
+    def stream_reset(self, s):
+        """toolame_init() for stream s alone: its next frame is its frame 0; no other stream notices"""
+        rc = self.L.tlb_stream_reset(self.h, s)
+        if rc:
+            raise ToolameError(rc, "tlb_stream_reset")
+
+    def stream_finish(self, s):
+        """toolame_finish() for stream s alone: its pending frame (bytes), then as after stream_reset()"""
+        buf = (C.c_uint8 * 2048)()
+        n = self.L.tlb_stream_finish(self.h, s, buf, 2048)
+        if n < 0:
+            raise ToolameError(-n, "tlb_stream_finish")
+        return bytes(buf[:n])
+
+    def stream_reconfigure(self, s, config):
+        """the six setters + toolame_init() for stream s alone"""
+        rc = self.L.tlb_stream_reconfigure(self.h, s, _config_array([config]))
+        if rc:
+            raise ToolameError(rc, "tlb_stream_reconfigure")
+        self.configs[s] = config
+        self.frame_bytes[s] = self.L.tlb_frame_bytes(self.h, s)
+        self.unit_bytes[s] = self.L.tlb_egress_unit_bytes(self.h, s)
+        self.units_per_frame[s] = self.L.tlb_egress_units_per_frame(self.h, s)
 
     # -- device-resident path (bench, production) -------------------------------------------
     def encode_device(self, d_pcm_ptr, nframes, d_out_ptr, d_xpad_ptr=None, d_xpad_len_ptr=None, stream=None):

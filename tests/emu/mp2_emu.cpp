@@ -162,7 +162,7 @@ int emu_edi_af(const uint8_t *frames, const int16_t *levels, int nframes, int ns
     std::vector<TlEdiState> next((size_t)nstreams);
     A.frames = frames; A.levels = levels; A.state = state; A.state_out = next.data(); A.version = version; A.xpow8 = T.edi_xpow8; A.frame_bytes = frame_bytes;
     A.pkts = pkts; A.pkt_len = pkt_len; A.nstreams = nstreams; A.nframes = nframes; A.out_stride = out_stride;
-    A.pkt_stride = pkt_stride; A.version_len = version_len; A.unit_bytes = unit_bytes; A.max_upf = max_upf;
+    A.pkt_stride = pkt_stride; A.version_len = version_len; A.unit_bytes = unit_bytes; A.max_upf = max_upf; A.frame_len = nullptr;
     for (int v = 0; v < nframes * max_upf; v++)
         for (int s = 0; s < nstreams; s++) tl_edi_af_packet(A, s, v);
     memcpy(state, next.data(), sizeof(TlEdiState) * (size_t)nstreams);

@@ -781,6 +781,133 @@ def test_tick_pipeline_with_xpad(M):
     assert got == refs
 
 
+# ---- life cycle of ONE stream inside a live batch (tlb_stream_reset / _finish / _reconfigure; toolame.c:120-166 per stream) ----
+_LIFE_POOL = [(48000, "s", 128, 1), (48000, "j", 192, 3), (48000, "m", 64, 1), (24000, "m", 64, 3), (48000, "s", 160, 2), (48000, "j", 128, 4),
+              (48000, "d", 96, 0), (44100, "s", 128, 1), (22050, "m", 32, 3), (32000, "m", 64, 4), (48000, "s", 384, 1), (16000, "m", 24, 2)]
+
+
+def _life_oracle(pcm_seg, cfg):
+    return O.oracle_stream(pcm_seg, samplerate=cfg.samplerate, mode=cfg.mode, kbps=cfg.bitrate, psy=cfg.psy_model)[0]
+
+
+def test_stream_life_cycle_in_a_live_batch(M):
+    """64 streams of twelve configurations (all psy models, padded rates, LSF) run for 14 frames in ragged calls; between calls single
+    streams are reset (toolame_init), finished (toolame_finish: the pending frame comes back) or reconfigured (new rate / mode /
+    bitrate / model).  Every stream equals the oracle: the untouched ones over the whole run, restarted ones per life, each life an
+    encoder of its own that starts with its first frame."""
+    rng = np.random.default_rng(5)
+    ns, T = 64, 14
+    cfgs = [M.StreamConfig(samplerate=r, mode=m, bitrate=k, psy_model=p) for r, m, k, p in (_LIFE_POOL[s % len(_LIFE_POOL)] for s in range(ns))]
+    pcm = np.stack([gen_pcm(4200 + s, (0, 7, 4, 0)[s % 4], 0, T) for s in range(ns)], axis=1)
+    new_cfg = lambda q: M.StreamConfig(samplerate=q[0], mode=q[1], bitrate=q[2], psy_model=q[3])
+    # frame index -> events applied BEFORE that frame is fed
+    events = {3: [("reset", 5, None), ("finish", 17, None)],
+              6: [("reconf", 9, new_cfg((48000, "s", 224, 2))),          # a configuration the batch has not seen
+                  ("reconf", 30, new_cfg(_LIFE_POOL[1])),                # one it has
+                  ("reset", 5, None)],                                   # the same stream again
+              7: [("finish", 63, None), ("reconf", 40, new_cfg((24000, "s", 160, 4)))],
+              11: [("reconf", 9, new_cfg((48000, "m", 192, 1))), ("finish", 0, None)]}
+    b = M.Batch(cfgs)
+    lives = {s: [dict(cfg=cfgs[s], start=0, got=b"", tail=None)] for s in range(ns)}      # per stream: its lives
+    f = 0
+    for n in (3, 1, 2, 1, 4, 3):                                                         # call boundaries = every event frame
+        for kind, s, c in events.get(f, []):
+            cur = lives[s][-1]
+            cur["end"] = f
+            if kind == "reset":
+                b.stream_reset(s); cur["tail"] = None
+            elif kind == "finish":
+                cur["tail"] = b.stream_finish(s)
+            else:
+                cur["tail"] = None
+                b.stream_reconfigure(s, c)
+            lives[s].append(dict(cfg=c or cur["cfg"], start=f, got=b"", tail=None))
+        got, _ = b.encode(pcm[f:f + n])
+        for s in range(ns):
+            lives[s][-1]["got"] += got[s]
+        f += n
+    assert f == T
+    tail = b.flush()
+    for s in range(ns):
+        lives[s][-1]["end"] = T; lives[s][-1]["tail"] = tail[s]
+        for life in lives[s]:
+            if life["end"] == life["start"]:
+                assert life["got"] == b"" and not life["tail"]
+                continue
+            want = _life_oracle(pcm[life["start"]:life["end"], s], life["cfg"])
+            have = life["got"] + (life["tail"] or b"")
+            if life["tail"] is None:                                    # reset / reconfigured away: the pending frame was dropped
+                assert len(have) < len(want) and want.startswith(have) and len(want) - len(have) <= 1729, (s, life["start"])
+            else:
+                assert have == want, (s, life["start"], life["cfg"])
+    # refused reconfigurations change nothing: a frame longer than the batch's stride, an illegal bitrate
+    with pytest.raises(M.ToolameError):
+        b.stream_reconfigure(1, M.StreamConfig(samplerate=16000, mode="s", bitrate=160, psy_model=1))     # 1440-byte frames > stride
+    with pytest.raises(M.ToolameError):
+        b.stream_reconfigure(1, M.StreamConfig(samplerate=48000, mode="s", bitrate=100, psy_model=1))
+    # tlb_reset: the whole batch as new (scratch included) -- the same PCM gives the same bytes as the first life of every stream
+    b.reset()
+    cur = [lives[s][-1]["cfg"] for s in range(ns)]
+    got, _ = b.encode(pcm[:5])
+    tail = b.flush()
+    for s in range(0, ns, 7):
+        assert got[s] + tail[s] == _life_oracle(pcm[:5, s], cur[s]), s
+    b.close()
+
+
+@pytest.mark.parametrize("egress", ["frames", "af"])
+def test_tick_stream_life_cycle(M, egress):
+    """The same three operations on a tick object, between runs: the restarted stream's slots stay empty until its next frame is
+    final, its frames equal a fresh encoder's, nobody else's output moves, and the EDI sender of the stream keeps counting (SEQ has
+    no gap and no repeat)."""
+    cfgs = [M.StreamConfig(samplerate=r, mode=m, bitrate=k, psy_model=p) for r, m, k, p in
+            [(48000, "s", 128, 1), (48000, "j", 128, 3), (24000, "m", 64, 1), (48000, "s", 192, 2), (48000, "m", 96, 4), (16000, "m", 32, 3)]]
+    ns, T = len(cfgs), 12
+    pcm = np.stack([gen_pcm(5100 + s, 0, 0, T) for s in range(ns)], axis=1)               # [T, ns, 2, 1152]
+    inter = np.ascontiguousarray(pcm.transpose(0, 1, 3, 2)).reshape(T, ns, 2304)          # L R L R ... (mono: the first 1152 values are channel 0)
+    for s, c in enumerate(cfgs):
+        if c.mode == "m":
+            inter[:, s, :1152] = pcm[:, s, 0]
+    events = {4: ("reset", 1, None), 6: ("reconf", 3, M.StreamConfig(samplerate=48000, mode="s", bitrate=160, psy_model=1)), 8: ("finish", 4, None)}
+    t = M.Tick(cfgs, egress=egress, ngroups=2, version=b"v", now_s=1712345678)
+    lives = {s: [dict(cfg=cfgs[s], start=0, got=b"", tail=None)] for s in range(ns)}
+    seqs = {s: [] for s in range(ns)}
+    for f in range(T):
+        if f in events:
+            kind, s, c = events[f]
+            cur = lives[s][-1]; cur["end"] = f
+            if kind == "reset":
+                t.stream_reset(s)
+            elif kind == "finish":
+                cur["tail"] = t.stream_finish(s)
+            else:
+                t.stream_reconfigure(s, c)
+            lives[s].append(dict(cfg=c or cur["cfg"], start=f, got=b"", tail=None))
+        t.pcm[:] = inter[f]
+        t.run()
+        for s in range(ns):
+            if egress == "frames":
+                lives[s][-1]["got"] += t.frame(s)
+            else:
+                for pk in t.packets(s):
+                    seqs[s].append(int.from_bytes(pk[6:8], "big"))                          # AF header: "AF", LEN(4), SEQ(2)
+                    unit = 3 * lives[s][-1]["cfg"].bitrate
+                    at = pk.find(b"ss\x00\x01")                                            # TAG item ss0001: name(4) + length(4) + 3 bytes header + the unit
+                    lives[s][-1]["got"] += pk[at + 11:at + 11 + unit]
+            if f in events and events[f][1] == s:
+                assert not t.frame(s) and not t.packets(s), (f, s)                          # the run right after the restart has nothing for it
+    for s in range(ns):
+        lives[s][-1]["end"] = T
+        for life in lives[s]:
+            want = _life_oracle(pcm[life["start"]:life["end"], s], life["cfg"])
+            have = life["got"] + (life["tail"] or b"")
+            assert want.startswith(have) and (life["tail"] is None or have == want), (s, life["start"])
+            assert len(want) - len(have) <= 1729
+        if egress == "af" and seqs[s]:
+            assert seqs[s] == [(seqs[s][0] + i) & 0xffff for i in range(len(seqs[s]))], s
+    t.close()
+
+
 def test_long_runs_carry_no_drift(M):
     """3000 frames of one stream per model (psy 1 joint, psy 3, psy 2 and psy 4 with their chained prediction state, a padded
     44.1 kHz stream) in 7 calls of ragged length: equal to the oracle to the last byte -- nothing accumulates over 72 s of audio."""
