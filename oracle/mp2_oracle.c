@@ -1068,6 +1068,29 @@ int mp2o_get_table(const mp2o_enc *e, const char *name, double *out, int n)
         for (int j = 0; j < 513; j++) a[j] = (double)TL_PSY2_ABSTHR_E2[idx * 513 + j] / 100.0;
         src = a; len = 513;
     }
+    /* the derived tables of psy 2 / psy 4 as this restatement built them (mp2_oracle_psy2.inc psy2_init, mp2_oracle_psy4.inc psy4_init):
+       compared with the arrays the reference's own init code filled (tests/golden/tables_rates.npz) */
+    else if ((name[0] == 'p' && name[1] == '2' && e->psy == 2) || (name[0] == 'p' && name[1] == '4' && e->psy == 4)) {
+        static double big[64 * 64];
+        const char *f = name + 3;
+        const int four = e->psy == 4;
+        const psy2_state *P2 = (const psy2_state *)e->psy2; const psy4_state *P4 = (const psy4_state *)e->psy2;
+        if (!e->psy2) return -1;
+#define P24(field) (four ? (const void *)P4->field : (const void *)P2->field)
+        if (!strcmp(f, "partition")) { const int *q = P24(partition); for (int i = 0; i < 513; i++) big[i] = q[i]; src = big; len = 513; }
+        else if (!strcmp(f, "numlines")) { const int *q = P24(numlines); for (int i = 0; i < 64; i++) big[i] = q[i]; src = big; len = 64; }
+        else if (!strcmp(f, "cbval")) { src = P24(cbval); len = 64; }
+        else if (!strcmp(f, "rnorm")) { src = P24(rnorm); len = 64; }
+        else if (!strcmp(f, "tmn")) { src = P24(tmn); len = 64; }
+        else if (!strcmp(f, "s")) { src = P24(s); len = 64 * 64; }
+        else if (!strcmp(f, "window")) { src = P24(window); len = 1024; }
+        else if (four && !strcmp(f, "ath")) { src = P4->ath; len = 513; }
+        else if (four && !strcmp(f, "bark")) { src = P4->bark; len = 513; }
+        else if (four && !strcmp(f, "minval")) { src = kMinval4; len = 27; }
+        else if (!four && !strcmp(f, "bmax")) { src = kBmax; len = 27; }
+        else return -1;
+#undef P24
+    }
     else return -1;
     if (n < len) return -1;
     memcpy(out, src, (size_t)len * sizeof(double));

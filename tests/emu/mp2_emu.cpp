@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <string>
 #include <vector>
 
 #include "../../odr-audioenc_amd/csrc/mp2_host.h"
@@ -122,6 +123,32 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
         }
     for (int s = 0; s < A.nstreams; s++) tl_finish_stream(A, s);
     return 0;
+}
+// The PRODUCT's host-built psy 2 / psy 4 tables (csrc/mp2_host.cpp tl_build_psy2_tables / tl_build_psy4_tables, what the device path uploads)
+// by field name, as doubles: window[1024], absthr[513], s[64*64] (s[j][k], i.e. s_t transposed back), tmn / bmaxk / den / part_lo /
+// part_hi [64], partition[513], npart[1].  tests/test_oracle_golden.py compares them with the reference's memory.
+int emu_psy2_table(long samplerate, int psy, const char *name, double *out, int n)
+{
+    static TlPsy2Tables P;
+    if (psy == 4) tl_build_psy4_tables(&P, samplerate); else tl_build_psy2_tables(&P, samplerate);
+    int len = 0;
+    std::vector<double> v;
+    std::string f(name);
+    if (f == "window") v.assign(P.window, P.window + 1024);
+    else if (f == "absthr") v.assign(P.absthr, P.absthr + 513);
+    else if (f == "s") { v.resize(64 * 64); for (int j = 0; j < 64; j++) for (int k = 0; k < 64; k++) v[(size_t)j * 64 + k] = P.s_t[k][j]; }
+    else if (f == "tmn") v.assign(P.tmn, P.tmn + 64);
+    else if (f == "bmaxk") v.assign(P.bmaxk, P.bmaxk + 64);
+    else if (f == "den") v.assign(P.den, P.den + 64);
+    else if (f == "part_lo") v.assign(P.part_lo, P.part_lo + 64);
+    else if (f == "part_hi") v.assign(P.part_hi, P.part_hi + 64);
+    else if (f == "partition") v.assign(P.partition, P.partition + 513);
+    else if (f == "npart") v.assign(1, (double)P.npart);
+    else return -1;
+    len = (int)v.size();
+    if (n < len) return -1;
+    memcpy(out, v.data(), sizeof(double) * v.size());
+    return len;
 }
 // The psy-2 kernel's work list for a launch shape: units[nunits][3] = (chain, first frame, end frame); returns nunits (<= cap).
 int emu_psy2_units(int nchain, int nframes, int slots, int32_t *units, int cap)

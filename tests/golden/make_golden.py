@@ -94,7 +94,8 @@ import ctypes as C, sys, numpy as np, pickle
 L = C.CDLL(sys.argv[1]); fs = int(sys.argv[3]); psy = int(sys.argv[4])
 L.toolame_set_samplerate.argtypes = [C.c_long]; L.toolame_set_channel_mode.argtypes = [C.c_char]
 L.toolame_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
-L.toolame_init(); L.toolame_set_samplerate(fs); L.toolame_set_psy_model(psy)
+L.toolame_init(); L.toolame_set_samplerate(fs); L.toolame_set_psy_model(min(psy, 3))
+if psy > 3: C.c_int.in_dll(L, 'tlref_model').value = psy      # the setter refuses model 4 (toolame.c:204-207); `model` is exposed by oracle/Makefile
 L.toolame_set_channel_mode(b's'); L.toolame_set_bitrate(128 if fs >= 32000 else 64); L.toolame_set_pad(0)
 pcm = ((np.arange(2304) * 7919) % 2001 - 1000).astype(np.int16).reshape(2,1152); out = (C.c_ubyte*4096)()
 L.toolame_encode_frame(pcm.ctypes.data, None, 0, out, 4096)
@@ -112,8 +113,22 @@ if psy == 1:
              alloc_steps=g('steps', C.c_int, 18), alloc_steps2n=g('steps2n', C.c_int, 18), alloc_nbal=g('nbal', C.c_int, 9),
              alloc_table_sblimit=g('table_sblimit', C.c_int, 5), alloc_step_index=g('step_index', C.c_int, 144), alloc_line=g('line', C.c_int, 160))
 else:
-    a = C.cast(C.c_void_p.in_dll(L, 'tlref_tab_absthr').value, C.POINTER(C.c_double))
-    d['p2_absthr'] = np.array([a[i] for i in range(513)])
+    # the DERIVED tables of psy 2 / psy 4: file-scope pointers the init code filled (psycho_2.c:337-403, psycho_4.c:330-413)
+    pre = 'p2' if psy == 2 else 'p4'
+    def through(name, ct, n):
+        p = C.cast(C.c_void_p.in_dll(L, 'tlref_tab_%s_%s' % (pre, name)).value, C.POINTER(ct))
+        return np.array([p[i] for i in range(n)], dtype=np.int32 if ct is C.c_int else np.float64)
+    if psy == 2:
+        a = C.cast(C.c_void_p.in_dll(L, 'tlref_tab_absthr').value, C.POINTER(C.c_double))
+        d['p2_absthr'] = np.array([a[i] for i in range(513)])
+        d['p2_bmax'] = np.ctypeslib.as_array((C.c_double * 27).in_dll(L, 'tlref_tab_p2_bmax')).copy()
+    else:
+        d['p4_minval'] = np.ctypeslib.as_array((C.c_double * 27).in_dll(L, 'tlref_tab_p4_minval')).copy()
+        d['p4_ath'] = through('ath', C.c_double, 513); d['p4_bark'] = through('bark', C.c_double, 513)
+    d[pre + '_partition'] = through('partition', C.c_int, 513); d[pre + '_numlines'] = through('numlines', C.c_int, 64)
+    d[pre + '_cbval'] = through('cbval', C.c_double, 64); d[pre + '_rnorm'] = through('rnorm', C.c_double, 64)
+    d[pre + '_tmn'] = through('tmn', C.c_double, 64); d[pre + '_s'] = through('s', C.c_double, 64 * 64).reshape(64, 64)
+    d[pre + '_window'] = through('window', C.c_double, 1024)
 pickle.dump(d, open(sys.argv[2], 'wb'))
 """
 RATES = (48000, 44100, 32000, 24000, 22050, 16000)
@@ -122,11 +137,11 @@ RATES = (48000, 44100, 32000, 24000, 22050, 16000)
 def make_rate_tables():
     d = {}
     for fs in RATES:
-        for psy in (1, 2):
+        for psy in (1, 2, 4):
             tmp = HERE / f"_rt{fs}_{psy}.pkl"
             subprocess.run([sys.executable, "-c", _RATE_CHILD, str(O.REF_SO), str(tmp), str(fs), str(psy)], check=True, stderr=subprocess.DEVNULL)
             for k, v in pickle.load(open(tmp, "rb")).items():
-                if k.startswith("alloc_"):
+                if k.startswith("alloc_") or k in ("p2_bmax", "p4_minval"):
                     assert k not in d or np.array_equal(d[k], v)
                     d[k] = v
                 else:

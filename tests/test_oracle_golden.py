@@ -105,6 +105,57 @@ def test_shared_tables_match_reference_memory(golden_dir, fs):
     assert len(g["p2_absthr_48000"]) == 513 and len(names) == 14
 
 
+@pytest.mark.parametrize("psy", [2, 4])
+@pytest.mark.parametrize("fs", [48000, 44100, 32000, 24000, 22050, 16000])
+def test_psy2_psy4_derived_tables_match_reference_memory(golden_dir, fs, psy):
+    """The partition map, lines per partition, bark value / normalisation / tone-masking-noise value per partition, spreading function and
+    analysis window of psy 2 and psy 4 are built by init code that the oracle AND the product restate (oracle/mp2_oracle_psy2.inc,
+    mp2_oracle_psy4.inc; csrc/mp2_host.cpp tl_build_psy2_tables / tl_build_psy4_tables) -- two copies of one text, which end-to-end bytes
+    alone would not tell from the reference's.  Both copies against the arrays the REFERENCE's own psycho_2_init / psycho_4_init filled
+    (file-scope pointers made visible by oracle/Makefile TABLE_TAPS, read through in tests/golden/make_golden.py), bit for bit."""
+    import emulib
+    g = np.load(golden_dir / "tables_rates.npz")
+    pre = f"p{psy}"
+    ref = {k: np.asarray(g[f"{pre}_{k}_{fs}"]) for k in ("partition", "numlines", "cbval", "rnorm", "tmn", "s", "window")}
+    # ---- the oracle's copy
+    e = O.OracleEncoder(samplerate=fs, kbps=128 if fs >= 32000 else 64, psy=psy)
+    L = O.lib()
+    L.mp2o_get_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+    buf = np.zeros(64 * 64, dtype=np.float64)
+    names = list(ref) + (["ath", "bark", "minval"] if psy == 4 else ["bmax"])
+    for k in names:
+        want = np.asarray(g[f"{pre}_{k}" if k in ("bmax", "minval") else f"{pre}_{k}_{fs}"], dtype=np.float64).ravel()
+        n = L.mp2o_get_table(e.h, f"{pre}_{k}".encode(), buf.ctypes.data, buf.size)
+        assert n == len(want), (k, n, len(want))
+        assert np.array_equal(_bits(buf[:n]), _bits(want)), (fs, psy, k)
+    # ---- the product's copy (host code of the device path, compiled into the emulation library)
+    E = emulib.lib()
+    E.emu_psy2_table.argtypes = [C.c_long, C.c_int, C.c_char_p, C.c_void_p, C.c_int]
+    def prod(name):
+        n = E.emu_psy2_table(fs, psy, name.encode(), buf.ctypes.data, buf.size)
+        assert n > 0, name
+        return buf[:n].copy()
+    assert np.array_equal(_bits(prod("window")), _bits(ref["window"]))
+    assert np.array_equal(_bits(prod("s")), _bits(ref["s"].ravel()))
+    assert np.array_equal(_bits(prod("tmn")), _bits(ref["tmn"]))
+    assert np.array_equal(prod("partition").astype(np.int32), ref["partition"])
+    npart = int(ref["partition"][512]) + 1
+    assert int(prod("npart")[0]) == npart
+    lo, hi = prod("part_lo").astype(int), prod("part_hi").astype(int)
+    for j in range(npart):
+        lines = np.nonzero(ref["partition"] == j)[0]
+        assert (lo[j], hi[j]) == (lines[0], lines[-1] + 1) and hi[j] - lo[j] == ref["numlines"][j], j
+    # rnorm[j] * numlines[j], the divisor of psycho_2.c:200-204 (0 where the reference skips the division)
+    den = np.where((ref["rnorm"] != 0) & (ref["numlines"] != 0), ref["rnorm"] * ref["numlines"], 0.0)
+    assert np.array_equal(_bits(prod("den")), _bits(den))
+    if psy == 2:       # bmax[(int)(cbval + 0.5)], psycho_2.c:188-189
+        assert np.array_equal(_bits(prod("bmaxk")), _bits(np.asarray(g["p2_bmax"])[(ref["cbval"] + 0.5).astype(int)]))
+        assert np.array_equal(_bits(prod("absthr")), _bits(np.asarray(g[f"p2_absthr_{fs}"])))
+    else:              # minval[(int)cbval], psycho_4.c:262; the threshold in quiet as energy (ath[], :352-361)
+        assert np.array_equal(_bits(prod("bmaxk")), _bits(np.asarray(g["p4_minval"])[ref["cbval"].astype(int)]))
+        assert np.array_equal(_bits(prod("absthr")), _bits(np.asarray(g[f"p4_ath_{fs}"])))
+
+
 def test_burst_cadence_128k():
     """0 bytes for 10 calls, 3708 on the 11th, ... and finish() flushes the rest."""
     pcm = gen_pcm(1, 0, 0, 24)
