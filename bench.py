@@ -9,6 +9,9 @@ Workload
           (never inside it) the same process also times mode 'j', configs[2] (16384 streams, psy 3) and the
           PCIe-inclusive rate (pinned host buffers through tlb_encode_host) and reports them under "also".
   N > 1 : BASELINE.json configs[3] -- 16384 streams PER GPU, psy model 3 (131072 streams on 8 GPUs), weak scaling.
+  --config 4 (any N): BASELINE.json configs[4] -- per GPU 16384 streams, even 32 kHz mono 64 kbps / odd 48 kHz stereo 192 kbps in ONE
+          batch, psy model 4 as `value`, psy model 2 (its sibling the reference's setter accepts) as `also.configs4_psy2`; both sharded
+          over the N ranks with the same barriers, per-GPU and aggregate rates, an oracle check on every rank.
 
 A "step" = one launch of the hot path: every stream encodes --frames-per-step consecutive frames (default: 131072 (stream,
 frame) units per launch, i.e. 32 frames at 4096 streams, 8 at 16384; the kernels' ramp-up and tail are paid once per launch).  One process per GPU; streams shard with no data-path collective; RCCL carries only the
@@ -40,7 +43,8 @@ FS, KBPS = 48000, 128
 ALGO_BYTES_PER_FRAME = 2 * 1152 * 2 + 144000 * KBPS // FS      # PCM in + bitstream out = 4992
 HBM_PEAK_GBS = 8000.0                                           # MI355X_MICROARCH.md: 8 TB/s HBM3E
 # BASELINE.json configs[k] -> (streams per GPU, psy model)
-CONFIGS = {1: (4096, 1), 2: (16384, 3), 3: (16384, 3)}
+CONFIGS = {1: (4096, 1), 2: (16384, 3), 3: (16384, 3), 4: (16384, 4)}
+SIMD_CYCLES_PER_VALU = 4        # a wave64 vector instruction occupies its SIMD's issue for 4 cycles (16 lanes / cycle; profiles/instr_rates_r04.txt)
 
 
 def parse_args(argv=None):
@@ -50,6 +54,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=None, help="streams per GPU (default: the BASELINE config of this N)")
     ap.add_argument("--frames-per-step", type=int, default=None, help="frames per stream per launch (default: 131072 (stream, frame) units per launch: 32 at 4096 streams, 8 at 16384)")
+    ap.add_argument("--config", type=int, default=None, choices=(1, 2, 3, 4), help="BASELINE.json configs[k] (default: 1 at --gpus 1, 3 above)")
     ap.add_argument("--psy", type=int, default=None)
     ap.add_argument("--mode", default="s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,7 +95,24 @@ def spawn_ranks(args, argv):
     return 0
 
 
-def workload_label(streams, psy, mode, frames_per_step, world):
+def stream_configs(M, S, psy, mode, mixed):
+    """the S stream configurations of one GPU: BASELINE configs[4]'s interleaved mix, or S times the metric's configuration"""
+    if mixed:
+        return [M.StreamConfig(samplerate=32000, mode="m", bitrate=64, psy_model=psy) if s % 2 == 0 else
+                M.StreamConfig(samplerate=48000, mode="s", bitrate=192, psy_model=psy) for s in range(S)]
+    return [M.StreamConfig(samplerate=FS, mode=mode, bitrate=KBPS, psy_model=psy)] * S
+
+
+def algo_bytes(c):
+    """PCM in + bitstream out per frame of configuration c"""
+    return (1 if c.mode == "m" else 2) * 1152 * 2 + 144000 * c.bitrate // c.samplerate
+
+
+def workload_label(streams, psy, mode, frames_per_step, world, mixed=False):
+    if mixed:
+        total = f", {streams * world} streams in total" if world > 1 else ""
+        return (f"{streams} streams/GPU, even 32 kHz mono 64 kbps / odd 48 kHz stereo 192 kbps interleaved in one batch, psy {psy}, full encode "
+                f"(BASELINE configs[4]{total}), {frames_per_step} frames/stream/step"), 4
     k = None
     if (streams, psy) == CONFIGS[1] and world == 1:
         k = 1
@@ -165,7 +187,7 @@ print(n / dt)
                       f"{'libtoolame-dab compiled from the reference sources' if kind == 'reference' else 'oracle/mp2_oracle.c'}, gcc -O2, 1 thread"}
 
 
-def committed_counters(S, F, psy, mode):
+def committed_counters(S, F, psy, mode, mixed=False):
     """HBM bytes per launch (PMC: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes) and the SQ issue counters of THIS
     workload, from the files the last profiling round committed (profiles/LATEST names the tag; tools/profile_round3.sh): quoted
     only when (streams, frames per step, psy model, mode) match; never measured inside a bench run."""
@@ -178,7 +200,7 @@ def committed_counters(S, F, psy, mode):
         try:
             pm = json.load(open(f))
             wl = pm["workload"]
-            if (wl["streams"], wl["frames_per_step"], wl["psy"], wl["mode"]) == (S, F, psy, mode):
+            if (wl["streams"], wl["frames_per_step"], wl["psy"], wl["mode"], bool(wl.get("mixed"))) == (S, F, psy, mode, mixed):
                 traffic = pm["hbm_bytes_per_launch"]
                 source = (f"profiles/{f.name} (committed rocprofv3 --pmc measurement of this workload, summed over the launch's kernels: "
                           + ", ".join(f"{k} {v['hbm_bytes_per_launch']}" for k, v in pm["kernels"].items()) + "; not measured in this run)")
@@ -189,10 +211,11 @@ def committed_counters(S, F, psy, mode):
         try:
             sq = json.load(open(f))
             wl = sq["workload"]
-            if (wl["streams"], wl["frames_per_step"], wl["psy"], wl["mode"]) == (S, F, psy, mode):
+            if (wl["streams"], wl["frames_per_step"], wl["psy"], wl["mode"], bool(wl.get("mixed"))) == (S, F, psy, mode, mixed):
                 valu = {k: {"valu_busy_per_simd": c["derived"]["valu_busy_per_simd"], "waves_per_simd": c["derived"]["waves_per_simd"],
                             "wave_cycles_waiting": c["derived"]["waiting_share"], "valu_instructions_per_frame": c["derived"]["per_frame"]["valu"]}
                         for k, c in sq["kernels"].items()}
+                valu["clock_ghz"] = next((c["derived"].get("clock_ghz") for c in sq["kernels"].values() if c["derived"].get("clock_ghz")), None)
                 valu["source"] = f"profiles/{f.name} (committed rocprofv3 --pmc SQ counters of this workload, not this run)"
                 break
         except Exception:  # noqa: BLE001
@@ -204,7 +227,7 @@ class GpuRun:
     """One workload resident on this rank's GPU: two alternating PCM buffers (frames [0,F) and [F,2F) of every stream), the
     batch, the output buffer.  step(i) = one launch."""
 
-    def __init__(self, M, torch, np, gen_pcm, stream_ids, F, mode, psy, local_rank, distinct=None):
+    def __init__(self, M, torch, np, gen_pcm, stream_ids, F, mode, psy, local_rank, distinct=None, mixed=False):
         S = len(stream_ids)
         host = np.empty((2 * F, S, 2, 1152), dtype=np.int16)
         nd = S if distinct is None else min(S, distinct)
@@ -216,8 +239,10 @@ class GpuRun:
         self.check_streams = sorted({0, S - 1})
         self.check_pcm = {k: host[:, k].copy() for k in self.check_streams}      # the 2F frames stream k loops over
         self.launches = 0
-        self.cfg = (mode, psy)
-        self.batch = M.Batch([M.StreamConfig(samplerate=FS, mode=mode, bitrate=KBPS, psy_model=psy)] * S, device=local_rank)
+        self.cfgs = stream_configs(M, S, psy, mode, mixed)
+        self.algo_bytes_per_launch = sum(algo_bytes(c) for c in self.cfgs) * F
+        self.audio_s_per_launch = sum(1152.0 / c.samplerate for c in self.cfgs) * F
+        self.batch = M.Batch(self.cfgs, device=local_rank)
         self.out = torch.zeros((F, S, self.batch.out_stride), dtype=torch.uint8, device="cuda")
         self.stream = torch.cuda.current_stream()
         self.F, self.S, self.torch, self.np = F, S, torch, np
@@ -246,6 +271,14 @@ class GpuRun:
         self.stage_ms = self.batch.last_stage_ms()      # (psy-2 kernel, encode + finish kernels) of the last launch: batches of models 2/4 only
         return elapsed, own, kernel_ms
 
+    def check_flag(self):
+        """check() that never raises: a failing rank must still reach the collectives the other ranks wait in (the flag travels with
+        the gathered floats, the line reports it per rank and the process exits non-zero afterwards)"""
+        try:
+            return self.check()
+        except AssertionError as ex:
+            return {"checked": True, "failed": str(ex)}
+
     def check(self, max_oracle_frames=12000):
         """After the timed region: what the LAST timed launch wrote is what the reference writes.  The oracle (TEST-ONLY CPU
         restatement, pinned against the compiled reference) encodes the same looped PCM of the first and the last stream from the
@@ -257,13 +290,12 @@ class GpuRun:
         total = self.launches * self.F
         if total > max_oracle_frames:
             return {"checked": False, "why": f"{total} frames per stream since the first launch: beyond the oracle budget of this check"}
-        mode, psy = self.cfg
-        fb = self.batch.frame_bytes[0]
         out = self.out.cpu().numpy()
         for k in self.check_streams:
+            c, fb = self.cfgs[k], self.batch.frame_bytes[k]
             loop = self.check_pcm[k]
             pcm = self.np.concatenate([loop] * (self.launches // 2 + 1))[:total]
-            ref = O.oracle_stream(pcm, samplerate=FS, mode=mode, kbps=KBPS, psy=psy)[0]
+            ref = O.oracle_stream(pcm, samplerate=c.samplerate, mode=c.mode, kbps=c.bitrate, psy=c.psy_model)[0]
             first = (self.launches - 1) * self.F - 1                    # global index of the frame in slot 0
             for f in range(self.F):
                 g = first + f
@@ -303,55 +335,6 @@ def pcie_inclusive(M, np, gen_pcm, F, psy, mode, local_rank, streams, reps=3):
             f"{n_in / 1e6:.0f} MB PCM in + {n_out / 1e6:.0f} MB frames out over PCIe per call (copy-in, kernels and copy-out of four chunks of frames "
             "overlapped on three streams inside the library; the call returns when everything is back on the host)", "streams": streams,
             "frames_per_call": F, "gbytes_per_s_over_pcie": round(reps * (n_in + n_out) / dt / 1e9, 2)}
-
-
-def configs4_share(M, torch, np, gen_pcm, psy, local_rank, S=16384, F=8, steps=20):
-    """One GPU's share of BASELINE configs[4]: even streams 32 kHz mono 64 kbps, odd streams 48 kHz stereo 192 kbps, interleaved in
-    ONE batch (mixed configurations share a launch), psy 4 (the model configs[4] names) or psy 2 (what the reference's setter allows)."""
-    cfgs = [M.StreamConfig(samplerate=32000, mode="m", bitrate=64, psy_model=psy) if s % 2 == 0 else
-            M.StreamConfig(samplerate=48000, mode="s", bitrate=192, psy_model=psy) for s in range(S)]
-    base = np.stack([gen_pcm(s, 0, 0, 2 * F) for s in range(256)], axis=1)
-    host = np.tile(base, (1, S // 256, 1, 1))
-    pcm = [torch.from_numpy(host[:F].copy()).cuda(), torch.from_numpy(host[F:].copy()).cuda()]
-    b = M.Batch(cfgs, device=local_rank)
-    out = torch.zeros((F, S, b.out_stride), dtype=torch.uint8, device="cuda")
-    st = torch.cuda.current_stream()
-    for i in range(2):
-        b.encode_device(pcm[i & 1].data_ptr(), F, out.data_ptr(), stream=st.cuda_stream)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        b.encode_device(pcm[i & 1].data_ptr(), F, out.data_ptr(), stream=st.cuda_stream)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    # parity of what was timed: two streams of each kind against the oracle on the same looped PCM
-    import oraclelib as O
-    got = out.cpu().numpy()
-    launches, total = 2 + steps, (2 + steps) * F
-    for k in (0, 1, S - 2, S - 1):
-        c = cfgs[k]
-        loop = host[:, k]
-        ref = O.oracle_stream(np.concatenate([loop] * (launches // 2 + 1))[:total], samplerate=c.samplerate, mode=c.mode, kbps=c.bitrate, psy=psy)[0]
-        fb = b.frame_bytes[k]
-        for f in range(F):
-            g = (launches - 1) * F - 1 + f
-            assert bytes(got[f, k, :fb]) == ref[g * fb:(g + 1) * fb], f"configs[4] share: stream {k} slot {f} differs from the oracle"
-    b.close()
-    audio_s = (S // 2) * F * steps * (1152 / 32000 + 1152 / 48000)      # a 32 kHz frame is 36 ms of audio, a 48 kHz frame 24 ms
-    algo = (S // 2) * F * ((1152 * 2 + 144000 * 64 // 32000) + (2 * 1152 * 2 + 144000 * 192 // 48000))
-    traffic, traffic_source = None, None
-    try:      # committed PMC measurement of this very workload (tools/pmc_configs4.sh), never measured inside a bench run
-        tag = (ROOT / "profiles" / "LATEST").read_text().split()[0]
-        pm = json.load(open(ROOT / "profiles" / f"{tag}_pmc_traffic_configs4_psy{psy}.json"))
-        if (pm["workload"]["streams"], pm["workload"]["frames_per_step"], pm["workload"]["psy"]) == (S, F, psy):
-            traffic, traffic_source = pm["hbm_bytes_per_launch"], f"profiles/{tag}_pmc_traffic_configs4_psy{psy}.json (committed rocprofv3 --pmc measurement, not this run)"
-    except Exception:  # noqa: BLE001
-        pass
-    return {"workload": f"{S} streams, even 32 kHz mono 64 kbps / odd 48 kHz stereo 192 kbps in one batch, psy {psy}, {F} frames/stream/launch "
-                        "(BASELINE configs[4], one GPU's share)", "value": round(S * F * steps / dt, 1), "unit": "frames/s",
-            "ms_per_launch": round(dt / steps * 1e3, 3), "streams_at_realtime": round(audio_s / dt),
-            "roofline_frac_hbm": round(algo / (dt / steps) / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": algo,
-            "traffic": traffic, "traffic_source": traffic_source, "output_check": "4 streams x the last launch's frames equal the oracle"}
 
 
 def tick_pipeline(M, np, gen_pcm, nstreams, psy, mode, local_rank, ticks=1000, egress="af", ngroups=0):
@@ -406,7 +389,9 @@ def main():
     from pcmgen import gen_pcm
 
     world = args.gpus
-    cfg_streams, cfg_psy = CONFIGS[1] if world == 1 else CONFIGS[3]
+    cfg_k_arg = args.config if args.config is not None else (1 if world == 1 else 3)
+    mixed = cfg_k_arg == 4
+    cfg_streams, cfg_psy = CONFIGS[cfg_k_arg]
     S = args.streams if args.streams is not None else cfg_streams
     psy = args.psy if args.psy is not None else cfg_psy
     F = args.frames_per_step if args.frames_per_step is not None else max(1, 131072 // S)
@@ -427,26 +412,71 @@ def main():
     cdev = "cuda" if args.backend == "nccl" else "cpu"          # where the collectives' few scalars live
     assert world_env == world
     observed_world = dist.get_world_size() if dist is not None else 1
+    num_simds = 4 * torch.cuda.get_device_properties(dev_index).multi_processor_count
 
-    run = GpuRun(M, torch, np, gen_pcm, shard.weak_stream_ids(rank, S), F, args.mode, psy, local_rank)
-    run.cdev = cdev
-    elapsed, own, kernel_ms = run.timed(dist, shard, args.warmup, args.steps)
-    last_ms = run.batch.last_kernel_ms()
-    checked = run.check()
-    # per-rank (frames, own seconds): the only exchanged payload besides barriers
-    per_rank = shard.gather_floats(dist, [S * F * args.steps, own], device=cdev)
-    run_stage_ms = run.stage_ms
-    run.close()
+    def sharded_run(psy_k):
+        """one workload on every rank: timed region between barriers, the oracle check on EVERY rank (its verdict travels as a flag
+        with the gathered floats: a rank whose check fails still takes part in the collectives), per-rank (frames, seconds)"""
+        r = GpuRun(M, torch, np, gen_pcm, shard.weak_stream_ids(rank, S), F, args.mode, psy_k, local_rank, mixed=mixed)
+        r.cdev = cdev
+        el, own_s, k_ms = r.timed(dist, shard, args.warmup, args.steps)
+        l_ms = r.batch.last_kernel_ms()
+        chk = r.check_flag()
+        pr = shard.gather_floats(dist, [S * F * args.steps, own_s, 0.0 if chk.get("failed") else 1.0], device=cdev)
+        out = dict(elapsed=el, kernel_ms=k_ms, last_ms=l_ms, checked=chk, per_rank=pr, stage_ms=r.stage_ms,
+                   algo=r.algo_bytes_per_launch, audio_s=r.audio_s_per_launch)
+        r.close()
+        return out
+
+    head = sharded_run(psy)
+    sib = sharded_run(2) if mixed and psy == 4 else None         # configs[4]: psy 2 next to psy 4, on every rank too
+    elapsed, kernel_ms, last_ms, checked, per_rank, run_stage_ms = (head[k] for k in ("elapsed", "kernel_ms", "last_ms", "checked", "per_rank", "stage_ms"))
     if dist is not None:          # nothing below is collective: the ranks part here, rank 0 goes on to its host-side legs alone
         dist.destroy_process_group()
         dist = None
     had_group = world > 1
+    all_ok = all(p[2] == 1.0 for p in per_rank) and (sib is None or all(p[2] == 1.0 for p in sib["per_rank"]))
+
+    def roofline(run_d, S_, F_, psy_k, mode_k):
+        """what limits the launch's dominant kernel, from THIS run's event times and the committed counters of this workload"""
+        k_ms = run_d["kernel_ms"]
+        traffic, traffic_source, valu = committed_counters(S_, F_, psy_k, mode_k, mixed)
+        hbm_ach = run_d["algo"] / (k_ms * 1e-3) / 1e9
+        rf = {"hbm": {"achieved": round(hbm_ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_ach / HBM_PEAK_GBS, 6),
+                      "algorithmic_bytes_per_launch": run_d["algo"], "traffic": traffic, "traffic_source": traffic_source},
+              "hbm_frac": round(hbm_ach / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
+              "kernel_ms": round(k_ms, 4), "last_kernel_ms_hip_events": round(run_d["last_ms"], 4)}
+        # issue slots: VALU instructions per frame (committed SQ counters of this workload) x frames/s of this run x 4 cycles
+        # over the chip's SIMD-cycles per second; the share of the SIMDs' issue time the launch's vector instructions occupy
+        vi = None
+        if valu:
+            per_frame = sum(v["valu_instructions_per_frame"] for k_, v in valu.items() if isinstance(v, dict))
+            clock = valu.get("clock_ghz") or 2.2
+            fps_k = S_ * F_ / (k_ms * 1e-3)
+            vi = per_frame * fps_k * SIMD_CYCLES_PER_VALU / (num_simds * clock * 1e9)
+            rf.update({"bound": "valu_issue", "achieved": round(per_frame * fps_k / 1e12, 4), "peak": round(num_simds * clock * 1e9 / SIMD_CYCLES_PER_VALU / 1e12, 4),
+                       "unit": "T wave-instructions/s", "frac": round(vi, 4), "valu_issue_frac": round(vi, 4),
+                       "valu_issue_basis": f"{per_frame} VALU instructions per frame (committed SQ_INSTS_VALU of this workload) x {fps_k:.0f} frames/s (this run, kernel time) x "
+                                           f"{SIMD_CYCLES_PER_VALU} cycles / ({num_simds} SIMDs x {clock} GHz, the clock of the committed profile run)"})
+        else:
+            rf.update({"bound": "valu_issue", "achieved": None, "peak": None, "unit": "T wave-instructions/s", "frac": None, "valu_issue_frac": None,
+                       "valu_issue_basis": "no committed SQ counters for this workload (profiles/LATEST)"})
+        rf["binding_resource"] = ("fp64 VALU issue (co-limited by the LDS pipe, ~55 % busy, and by dependent LDS / table chains) -- NOT HBM: 5 KB per 0.35 MFLOP frame "
+                                  "(SURVEY F9).  `frac` = share of the SIMDs' issue cycles the kernel's vector instructions occupy; `hbm_frac` is the figure BASELINE.json asks for")
+        rf["valu_issue"] = valu
+        return rf
+
+    def roofline_mixed(run_d, S_, F_, psy_k):
+        global_mixed = True
+        k_ms = run_d["kernel_ms"]
+        traffic, traffic_source, _ = committed_counters(S_, F_, psy_k, "s", global_mixed)
+        hbm_ach = run_d["algo"] / (k_ms * 1e-3) / 1e9
+        return {"hbm_frac": round(hbm_ach / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": run_d["algo"], "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": round(k_ms, 4)}
 
     res = None
     if rank == 0:
         frames = sum(int(p[0]) for p in per_rank)
         value = frames / elapsed
-        algo_bytes_per_launch = ALGO_BYTES_PER_FRAME * S * F
         pk = "tl_psy2_kernel" if psy in (2, 4) else None
         kname = (f"{pk} + tl_main_kernel<2> + tl_finish_kernel (the three kernels of one launch of the path)" if pk
                  else "tl_main_kernel<0> + tl_finish_kernel (model 0 has no psy kernel)" if psy == 0
@@ -455,35 +485,38 @@ def main():
         if pk and run_stage_ms:
             kernels = {pk: round(run_stage_ms[0], 4), "tl_main_kernel + tl_finish_kernel": round(run_stage_ms[1], 4),
                        "source": "hipEvents on the launch stream inside the library (tlb_last_stage_ms), last timed launch"}
-        traffic, traffic_source, valu = committed_counters(S, F, psy, args.mode)
-        achieved = algo_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        label, cfg_k = workload_label(S, psy, args.mode, F, world)
+        label, cfg_k = workload_label(S, psy, args.mode, F, world, mixed)
+        rf = roofline(head, S, F, psy, args.mode)
+        rf.update({"kernel": kname, "kernels_ms": kernels,
+                   "secondary_fp64": {"achieved_tflops": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 1e12, 3), "peak_tflops": 78.6,
+                                      "frac": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 78.6e12, 5),
+                                      "basis": "0.35 MFLOP algorithmic fp64 per stereo frame (SURVEY 8d), vector fp64 peak"}})
+        checked["per_rank_ok"] = [p[2] == 1.0 for p in per_rank]
         res = {
-            "metric": "real-time stereo DAB MP2 streams sustained (frames/s) @128 kbps/48 kHz",
+            "metric": "real-time stereo DAB MP2 streams sustained (frames/s) @128 kbps/48 kHz" if not mixed else
+                      "real-time DAB MP2 streams sustained (frames/s), BASELINE configs[4]: 32 kHz mono 64 kbps + 48 kHz stereo 192 kbps interleaved",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": label, "baseline_config": cfg_k, "streams_per_gpu": S, "frames_per_step": F,
                        "frames_per_stream_timed": F * args.steps, "frames_per_stream_warmup": F * args.warmup,
                        "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
-            "realtime_streams": round(value / (FS / 1152.0), 1),
+            "realtime_streams": round(head["audio_s"] * world * args.steps / elapsed, 1),
             "world_size_observed": observed_world, "collective_backend": ("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo (smoke test: ranks may share GPUs)") if had_group else None,
             "per_gpu_frames_per_s": [round(p[0] / p[1], 1) for p in per_rank],
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": kname, "kernel_ms": round(kernel_ms, 4), "last_kernel_ms_hip_events": round(last_ms, 4), "kernels_ms": kernels,
-                         "algorithmic_bytes_per_launch": algo_bytes_per_launch,
-                         "binding_resource": "fp64 VALU issue + LDS latency chains -- NOT HBM (4992 B per 0.35 MFLOP frame, SURVEY F9): `frac` is the HBM "
-                                             "fraction BASELINE.json asks for, the number that says how close the kernel is to ITS limit is valu_issue.*.valu_busy_per_simd",
-                         "secondary_fp64": {"achieved_tflops": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 1e12, 3), "peak_tflops": 78.6,
-                                            "frac": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 78.6e12, 5),
-                                            "basis": "0.35 MFLOP algorithmic fp64 per stereo frame (SURVEY 8d), vector fp64 peak"},
-                         "valu_issue": valu},
+            "roofline": rf,
             "lds_bytes_per_stream": M.lds_bytes_per_stream(),
             "output_check": checked,
         }
+        if sib is not None:
+            sib["checked"]["per_rank_ok"] = [p[2] == 1.0 for p in sib["per_rank"]]
+            res["also"] = {"configs4_psy2": {
+                "workload": workload_label(S, 2, args.mode, F, world, True)[0], "value": round(sum(int(p[0]) for p in sib["per_rank"]) / sib["elapsed"], 1),
+                "unit": "frames/s", "per_gpu_frames_per_s": [round(p[0] / p[1], 1) for p in sib["per_rank"]], "ms_per_step": round(sib["elapsed"] / args.steps * 1e3, 4),
+                "realtime_streams": round(sib["audio_s"] * world * args.steps / sib["elapsed"], 1), "roofline": roofline(sib, S, F, 2, args.mode),
+                "output_check": sib["checked"]}}
     # ---- secondary measurements, after (outside) the headline's timed region; single GPU only ----
-    if world == 1 and not args.no_also:
+    if world == 1 and not args.no_also and not mixed:
         also = {}
         F2 = max(1, 131072 // CONFIGS[2][0])        # 16384 streams x 8 frames = 604 MB of PCM per buffer
         # encoder_only_psy0: BASELINE configs[1] names "filterbank+quantise kernels only" -- that is the encoder without a psychoacoustic
@@ -535,11 +568,29 @@ def main():
             also["pcie_inclusive"] = pcie_inclusive(M, np, gen_pcm, 8, psy, args.mode, local_rank, S)
         except Exception as ex:  # noqa: BLE001
             also["pcie_inclusive"] = {"value": None, "error": str(ex)}
-        for p4 in (4, 2):        # BASELINE configs[4] names psy 4 (an extension of the batched API); psy 2 is its sibling the reference's setter accepts
+        for p4 in (4, 2):        # BASELINE configs[4] names psy 4 (an extension of the batched API); psy 2 is its sibling the reference's setter accepts.  (`--config 4` makes it the headline, at any N)
             try:
-                also[f"configs4_share_psy{p4}"] = configs4_share(M, torch, np, gen_pcm, p4, local_rank)
+                s4, f4 = CONFIGS[4][0], max(1, 131072 // CONFIGS[4][0])
+                r4 = GpuRun(M, torch, np, gen_pcm, range(s4), f4, "s", p4, local_rank, distinct=256, mixed=True)
+                e4, _, k4 = r4.timed(None, shard, 2, 20)
+                d4 = dict(kernel_ms=k4, last_ms=r4.batch.last_kernel_ms(), algo=r4.algo_bytes_per_launch)
+                also[f"configs4_share_psy{p4}"] = {"workload": workload_label(s4, p4, "s", f4, 1, True)[0] + " (one GPU's share)", "value": round(s4 * f4 * 20 / e4, 1), "unit": "frames/s",
+                                                   "ms_per_launch": round(e4 / 20 * 1e3, 3), "streams_at_realtime": round(r4.audio_s_per_launch * 20 / e4),
+                                                   "kernels_ms": r4.stage_ms, "roofline": roofline_mixed(d4, s4, f4, p4), "output_check": r4.check()}
+                r4.close()
             except Exception as ex:  # noqa: BLE001
                 also[f"configs4_share_psy{p4}"] = {"value": None, "error": str(ex)}
+        try:     # ONE stream with psy 2: runs of its frames seed themselves (csrc/mp2_wave.h tl_psy2_chain), so one stream fills the chip with this model too
+            n1 = 16384
+            r1 = GpuRun(M, torch, np, gen_pcm, [0], n1 // 2, args.mode, 2, local_rank)
+            e1, _, k1 = r1.timed(None, shard, 2, 6)
+            st1 = r1.stage_ms
+            chk1 = r1.check()
+            r1.close()
+            also["one_stream_psy2"] = {"workload": f"1 stream x {n1 // 2} frames per launch (48 kHz stereo 128 kbps, psy 2, mode '{args.mode}')", "value": round((n1 // 2) * 6 / e1, 1),
+                                       "unit": "frames/s", "x_realtime": round((n1 // 2) * 6 / e1 / (FS / 1152.0), 1), "kernel_ms": round(k1, 4), "kernels_ms": st1, "output_check": chk1}
+        except Exception as ex:  # noqa: BLE001
+            also["one_stream_psy2"] = {"value": None, "error": str(ex)}
         also["tick_pipeline"] = {}
         for nt2 in (16384, 131072):   # one GPU's share of BASELINE configs[3], and all of configs[3] on one GPU
             try:
@@ -554,6 +605,9 @@ def main():
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
+    if not all_ok:
+        print("bench.py: the oracle check failed on at least one rank (output_check.per_rank_ok)", file=sys.stderr)
+        return 3
     return 0
 
 

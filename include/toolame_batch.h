@@ -165,13 +165,16 @@ int tlb_silence_host(tlb_batch *b, const int16_t *peaks, int nframes, uint32_t *
  * units per frame than the batch's maximum leaves its surplus slots absent (length / datasize 0).  For an all-48-kHz batch
  * max_upf is 1 and a slot is a frame.  32 kHz (1.5 units per frame) is not a DAB rate (odr-audioenc.cpp:560-563); a batch
  * that contains it has max_upf 0 and the egress calls return TLB_ERR_SAMPLERATE.
- * TIMING AND LEVELS differ from the reference's send loop in one documented way: odr-audioenc.cpp:1213 drains its deque with
- * `while (toolame_buffer.size() > frame_len)` -- strictly greater -- so one unit is always held back until more bytes arrive, and
- * every send_frame() carries the peak levels current at SEND time.  The batch calls emit every unit of a frame in that frame's
- * slots with the levels the caller passes for that slot (tlb_tick_run passes the run's own peaks, i.e. levels current at send
- * time like the reference, but does not hold a unit back).  Payload bytes, their order, DLFC / SEQ / timestamps per unit are
- * identical; a byte-compare against a live ZMQ / EDI capture of the reference therefore lines up on everything except which
- * audio-level pair rides with which unit (off by the reference's one-unit lag). */
+ * TIMING AND LEVELS differ from the reference's send loop, by the reference's burst behaviour: toolame_encode_frame() returns bytes only on
+ * the calls on which its 4096-byte bit buffer fills, about one call in ten (bitstream.c:46-71), and odr-audioenc.cpp:1208-1225 then sends
+ * every unit but one of what it holds (`while (toolame_buffer.size() > frame_len)`, strictly greater) in one loop with the SAME peak_left /
+ * peak_right -- the values current on that call.  A live ZMQ / EDI capture of the reference therefore shows about ten units leaving
+ * back to back every ten frames, sharing one level pair, and one unit always held back.  The batch calls emit the units of a frame in that
+ * frame's slots with the levels the caller passes for that slot (tlb_tick_run: one frame per tick with that tick's peaks).  Payload bytes,
+ * their order, DLFC / SEQ / timestamps per unit are identical; send cadence and the level pair per unit are not.  For a capture-compare
+ * tlb_reference_send_schedule() gives the reference's schedule -- how many units it sends during each call -- so a caller can pass, for
+ * every unit, the levels of the call the reference sends it on (pure host arithmetic on the configuration, no GPU). */
+int tlb_reference_send_schedule(const tlb_stream_config *cfg, int ncalls, int32_t *units_sent);      /* -> bytes still held after the last call; < 0: -TLB_ERR_* */
 int tlb_egress_unit_bytes(const tlb_batch *b, int stream);          /* 3 * kbps */
 int tlb_egress_units_per_frame(const tlb_batch *b, int stream);     /* 1, 2, 3; 0 = not a whole number */
 int tlb_egress_max_units_per_frame(const tlb_batch *b);

@@ -260,14 +260,14 @@ __global__ void __launch_bounds__(256) tl_ingest_kernel(const int16_t *__restric
 // Silence accounting of the caller (src/odr-audioenc.cpp:1053-1079): a frame whose peaks are both 0
 // adds its duration (integer milliseconds, as the reference computes it) to the stream's counter, any other frame resets it.
 // One thread per stream, frames in order.
-__global__ void tl_silence_kernel(const int16_t *__restrict__ peaks, uint32_t *__restrict__ silence_ms, const TlConfig *configs,
-                                  const int32_t *stream_cfg, int nstreams, int nframes)
+__constant__ int32_t tl_fs_hz[2][3] = {{22050, 24000, 16000}, {44100, 48000, 32000}};     // [MPEG version][sampling_frequency index], common.c:118-144
+__global__ void __launch_bounds__(256) tl_silence_kernel(const int16_t *__restrict__ peaks, uint32_t *__restrict__ silence_ms, const TlConfig *configs,
+                                                          const int32_t *stream_cfg, int nstreams, int nframes)
 {
     const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (s >= nstreams) return;
     const TlConfig &c = configs[stream_cfg[s]];
-    const long fs_hz[2][3] = {{22050, 24000, 16000}, {44100, 48000, 32000}};
-    const unsigned long rate = (unsigned long)fs_hz[c.version][c.fs_idx], nch = (unsigned long)c.nch;
+    const unsigned long rate = (unsigned long)tl_fs_hz[c.version][c.fs_idx], nch = (unsigned long)c.nch;
     const uint32_t frame_ms = (uint32_t)(1000ul * (1152ul * 2ul * nch) / (2ul * nch * rate));
     uint32_t ms = silence_ms[s];
     for (int f = 0; f < nframes; f++) {
@@ -1171,6 +1171,33 @@ int tlb_flush_host_len(tlb_batch *b, uint8_t *out, int32_t *out_len)
 }
 int tlb_flush_host(tlb_batch *b, uint8_t *out) { return tlb_flush_host_len(b, out, nullptr); }
 
+// The reference's send schedule for one stream (host arithmetic, no GPU): toolame_encode_frame() hands bytes back only when its
+// 4096-byte bit buffer fills (bitstream.c:46-71), and odr-audioenc sends `while (toolame_buffer.size() > 3 * bitrate)`
+// (src/odr-audioenc.cpp:1208-1225) -- so units leave in bursts of about ten during ONE call, all with that call's peak levels, and one
+// unit always stays behind.  units_sent[i] = units the reference sends during call i (input frame i).
+int tlb_reference_send_schedule(const tlb_stream_config *cfg, int ncalls, int32_t *units_sent)
+{
+    if (!cfg || ncalls < 0 || (ncalls && !units_sent)) return -TLB_ERR_ARG;
+    TlConfig c;
+    if (int rc = tl_build_config(&c, cfg->samplerate, cfg->mode, cfg->bitrate, cfg->psy_model, cfg->pad_len)) return -rc;
+    const int unit = 3 * c.kbps, buf = 4096;
+    double lag = 0;
+    int fill = 0, minimum = 4, held = 0;
+    for (int i = 0; i < ncalls; i++) {
+        int cur = c.frame_bytes;                                     // availbits.c:49-62
+        if (c.pad_frac != 0) { if (lag > (c.pad_frac - 1.0)) lag -= c.pad_frac; else { cur++; lag += (1 - c.pad_frac); } }
+        if (i == 0) minimum = cur + 4;                               // toolame.c:298-300
+        int written = 0;
+        if (fill + cur >= buf) { written = buf - minimum; fill = minimum + (fill + cur - buf); }
+        else fill += cur;
+        held += written;
+        int n = 0;
+        while (held > unit) { held -= unit; n++; }                   // strictly greater: one unit is held back
+        units_sent[i] = n;
+    }
+    return held;
+}
+
 float tlb_last_kernel_ms(tlb_batch *b)
 {
     if (!b || !b->timed) return -1.0f;
@@ -1544,7 +1571,8 @@ float tlb_tick_last_ms(tlb_tick *t)
 // calls) is unchanged: tests/test_hip_parity.py::test_legacy_abi_burst_cadence on every golden case.
 struct Legacy {
     bool inited = false;
-    long samplerate = 48000;       // the reference leaves the rate at its zero-initialised default until set
+    long samplerate = 44100;       // toolame_init() sets header.version = MPEG-1 (toolame.c:141) and leaves sampling_frequency at its zero-initialised
+                                   // index 0, which is 44.1 kHz in MPEG-1 (common.c:118-144): what a caller gets who never calls toolame_set_samplerate()
     char mode = 's';
     int kbps = 0;
     int psy = 1;                   // DFLT_PSY, encoder.h:11

@@ -108,3 +108,43 @@ int main(void)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stderr)
+
+
+def test_reference_send_schedule_against_the_reference_s_own_burst_lengths():
+    """tlb_reference_send_schedule (host arithmetic, no GPU): how many 3*bitrate-byte units odr-audioenc's send loop
+    (src/odr-audioenc.cpp:1208-1225: `while (toolame_buffer.size() > frame_len)`) sends during each call, derived from the
+    configuration alone -- against the same loop run over the per-call return lengths the REAL reference produced (the `lens` of every
+    golden case without X-PAD; tests/golden/make_golden.py)."""
+    import numpy as np
+    import odr_audioenc_amd as M
+    from conftest import golden_cases
+    if not M.LIB_PATH.exists():
+        M.build()
+    lib = C.CDLL(str(M.LIB_PATH))
+
+    class Cfg(C.Structure):
+        _fields_ = [("samplerate", C.c_long), ("mode", C.c_char), ("bitrate", C.c_int), ("psy_model", C.c_int), ("pad_len", C.c_int)]
+    lib.tlb_reference_send_schedule.argtypes = [C.POINTER(Cfg), C.c_int, C.c_void_p]
+    seen = 0
+    for p in golden_cases():
+        g = np.load(p)
+        fs, mode, kbps, psy, kind, seed, pad_len, nframes = (int(v) for v in g["cfg"])
+        if pad_len:
+            continue
+        lens = [int(x) for x in g["lens"]][:nframes]                 # per toolame_encode_frame call (the last entry is toolame_finish)
+        unit, held, want = 3 * kbps, 0, []
+        for n in lens:
+            held += n
+            k = 0
+            while held > unit:
+                held -= unit; k += 1
+            want.append(k)
+        got = np.zeros(nframes, dtype=np.int32)
+        rest = lib.tlb_reference_send_schedule(C.byref(Cfg(fs, bytes([mode]), kbps, min(psy, 3), 0)), nframes, got.ctypes.data)
+        assert rest == held and list(got) == want, p.stem
+        seen += 1
+    assert seen > 80
+    # and over a long run at the metric's configuration: bursts of 9-10 units every ten calls, one unit always held
+    got = np.zeros(2000, dtype=np.int32)
+    rest = lib.tlb_reference_send_schedule(C.byref(Cfg(48000, b"s", 128, 1, 0)), 2000, got.ctypes.data)
+    assert rest > 0 and set(got[got > 0]) <= {9, 10} and 200 <= int((got > 0).sum()) <= 210 and int(got.sum()) * 384 + rest <= 2000 * 384

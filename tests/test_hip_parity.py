@@ -973,8 +973,27 @@ def test_bench_two_ranks_on_the_gpu():
     assert line["n_gpus"] == 2 and line["world_size_observed"] == 2 and line["scaling"] == "weak"
     assert len(line["per_gpu_frames_per_s"]) == 2 and all(v > 0 for v in line["per_gpu_frames_per_s"])
     assert line["config"]["baseline_config"] == 3 and "configs[3]" in line["config"]["workload"] and line["config"]["streams_per_gpu"] == 16384
-    assert line["value"] > 0 and line["steps"] == 3 and line["output_check"]["checked"]
-    assert line["roofline"]["achieved"] > 0
+    assert line["value"] > 0 and line["steps"] == 3 and line["output_check"]["checked"] and line["output_check"]["per_rank_ok"] == [True, True]
+    assert line["roofline"]["hbm"]["achieved"] > 0 and line["roofline"]["bound"] == "valu_issue"
+
+
+def test_bench_configs4_two_ranks_on_the_gpu():
+    """BASELINE configs[4] as a multi-rank run (`bench.py --gpus 2 --config 4`): every rank encodes its own interleaved 32 kHz mono /
+    48 kHz stereo batch with psy 4 (`value`) and with psy 2 (`also.configs4_psy2`), the oracle checks a mono and a stereo stream on
+    EVERY rank, the line has per-GPU and aggregate rates for both models."""
+    import json
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--config", "4", "--backend", "gloo", "--steps", "3", "--warmup", "1",
+                        "--streams", "4096", "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["world_size_observed"] == 2 and line["config"]["baseline_config"] == 4 and "configs[4]" in line["config"]["workload"]
+    assert len(line["per_gpu_frames_per_s"]) == 2 and all(v > 0 for v in line["per_gpu_frames_per_s"]) and line["value"] > 0
+    assert line["output_check"]["checked"] and line["output_check"]["per_rank_ok"] == [True, True]
+    sib = line["also"]["configs4_psy2"]
+    assert sib["value"] > 0 and len(sib["per_gpu_frames_per_s"]) == 2 and sib["output_check"]["per_rank_ok"] == [True, True]
 
 
 def test_this_hosts_libm_is_the_one_tl_libm_restates(tmp_path):
