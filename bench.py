@@ -338,16 +338,21 @@ def pcie_inclusive(M, np, gen_pcm, F, psy, mode, local_rank, streams, reps=3):
 
 
 def tick_pipeline(M, np, gen_pcm, nstreams, psy, mode, local_rank, ticks=1000, egress="af", ngroups=0):
-    """The composed real-time loop body (tlb_tick_run: pinned host PCM -> PCIe -> ingest -> encode -> EDI AF packets -> PCIe -> pinned
-    host), one call per 24-ms tick for `nstreams` streams; wall-clock latency per tick, PCIe-inclusive.  The input buffer is
-    filled once (in a deployment the capture side writes it); every tick moves and encodes all of it."""
+    """The composed real-time loop body (tlb_tick_*: pinned host PCM -> PCIe -> ingest -> encode -> EDI AF packets -> PCIe -> pinned
+    host), one tick per 24 ms for `nstreams` streams, PCIe-inclusive.  Two ways of driving it: tlb_tick_run (a tick start to end per call:
+    wall-clock LATENCY per tick) and tlb_tick_submit / tlb_tick_wait with one tick in flight behind the one being waited for (the next
+    tick's copy-in runs under this tick's kernels and copy-out: INTERVAL between finished ticks, and each tick's latency submit -> results).
+    The input buffers are filled once (in a deployment the capture side writes them); every tick moves and encodes all of them."""
     t = M.Tick([M.StreamConfig(samplerate=FS, mode=mode, bitrate=KBPS, psy_model=psy)] * nstreams, egress=egress, ngroups=ngroups,
                version=b"odr-audioenc_amd bench", device=local_rank)
     nd = min(nstreams, 1024)
     base = np.stack([gen_pcm(s, 0, 0, 1)[0].T.reshape(-1) for s in range(nd)])          # interleaved L R L R
-    for k in range(0, nstreams, nd):
-        t.pcm[k:k + nd] = base[:min(nd, nstreams - k)]
-    for _ in range(5):
+    for _ in range(2):                                                                  # both input sets
+        pcm = t.pcm
+        for k in range(0, nstreams, nd):
+            pcm[k:k + nd] = base[:min(nd, nstreams - k)]
+        t.run()
+    for _ in range(4):
         t.run()
     lat, dev = np.empty(ticks), np.empty(ticks)
     t0 = time.perf_counter()
@@ -360,8 +365,22 @@ def tick_pipeline(M, np, gen_pcm, nstreams, psy, mode, local_rank, ticks=1000, e
     pk = t.packets(0)
     assert len(pk) == 1 and pk[0][:2] == b"AF", "no AF packet came out of the tick"
     n_in, n_out = nstreams * 2304 * 2, nstreams * (len(pk[0]) + 4 + 4)
+    # overlapped: submit tick i + 1, then wait for tick i
+    done, sub = np.empty(ticks), np.empty(ticks + 1)
+    sub[0] = time.perf_counter()
+    t.submit()
+    for i in range(ticks):
+        sub[i + 1] = time.perf_counter()
+        t.submit()
+        t.wait()
+        done[i] = time.perf_counter()
+    t.wait()
+    pk2 = t.packets(0)
+    assert len(pk2) == 1 and pk2[0][:2] == b"AF"
     t.close()
     lat *= 1e3
+    iv = np.diff(done) * 1e3
+    olat = (done - sub[:ticks]) * 1e3
     p50, p99 = float(np.percentile(lat, 50)), float(np.percentile(lat, 99))
     return {"workload": f"{nstreams} streams x 1 frame per tick (48 kHz stereo {KBPS} kbps, psy {psy}, mode '{mode}'), tlb_tick_run: interleaved PCM in pinned host "
                         f"memory -> PCIe -> gain/peak/de-interleave -> encode -> EDI AF packet per stream -> PCIe -> pinned host memory; {ticks} ticks back to back",
@@ -369,7 +388,13 @@ def tick_pipeline(M, np, gen_pcm, nstreams, psy, mode, local_rank, ticks=1000, e
             "device_ms_mean": round(float(dev.mean()), 3), "budget_ms": 24.0, "p99_share_of_budget": round(p99 / 24.0, 4),
             "frames_per_s": round(nstreams * ticks / wall, 1), "mbytes_in_per_tick": round(n_in / 1e6, 1), "mbytes_out_per_tick": round(n_out / 1e6, 1),
             "pcie_gbytes_per_s_in": round(n_in / (float(lat.mean()) * 1e-3) / 1e9, 2),
-            "limit": "the host-to-device link: " + f"{n_in / 1e6:.0f} MB of PCM per tick" if p50 > 0.5 * 24 else "none near the budget"}
+            "overlapped": {"what": "tlb_tick_submit / tlb_tick_wait, the next tick submitted before this one is waited for: `interval` = time between finished ticks "
+                                   "(sustained rate), `latency` = submit -> results of the same tick (includes waiting behind the tick before it on the link)",
+                           "interval_p50_ms": round(float(np.percentile(iv, 50)), 3), "interval_p99_ms": round(float(np.percentile(iv, 99)), 3),
+                           "latency_p50_ms": round(float(np.percentile(olat, 50)), 3), "latency_p99_ms": round(float(np.percentile(olat, 99)), 3),
+                           "pcie_gbytes_per_s_in": round(n_in / (float(iv.mean()) * 1e-3) / 1e9, 2),
+                           "link_floor_ms": round(n_in / 57.6e9 * 1e3, 3), "link_floor_basis": "one 604 MB hipMemcpyAsync runs at 57.6 GB/s on this box (profiles/h2d_probe_r04.txt)"},
+            "limit": "the host-to-device link: " + f"{n_in / 1e6:.0f} MB of PCM per tick" if p50 > 0.4 * 24 else "none near the budget"}
 
 
 def main():

@@ -263,7 +263,7 @@ int tlb_edi_pft_host(tlb_batch *b, const uint8_t *af, const int32_t *af_len, int
 typedef struct tlb_tick tlb_tick;
 typedef struct {
     int egress;                    /* TLB_TICK_* */
-    int ngroups;                   /* 0 = pick (1 below 2048 streams, 2 below 8192, else 4) */
+    int ngroups;                   /* 0 = pick (1 below 2048 streams, 2 below 8192, 4 below 65536, else 8) */
     int with_xpad;                 /* X-PAD side input per tick */
     const char *version; int version_len;     /* ODRv string (EDI) */
     long long now_s; unsigned delay_ms; int tist; int tai_utc_offset;      /* tlb_edi_state_init() arguments */
@@ -281,7 +281,17 @@ int tlb_tick_stream_reconfigure(tlb_tick *t, int stream, const tlb_stream_config
 int16_t *tlb_tick_pcm(tlb_tick *t);
 uint8_t *tlb_tick_xpad(tlb_tick *t);
 int32_t *tlb_tick_xpad_len(tlb_tick *t);
-int tlb_tick_run(tlb_tick *t);
+int tlb_tick_run(tlb_tick *t);                 /* = tlb_tick_submit() + tlb_tick_wait() */
+/* Ticks overlapped: the object owns TWO sets of pinned host buffers.  tlb_tick_submit() queues a tick on the input set the caller has
+ * just filled and returns at once; from then on tlb_tick_pcm() / _xpad() / _xpad_len() point at the OTHER input set, which the caller
+ * fills while the submitted tick is on its way (odr-audioenc decouples capture from encoding with its input queue,
+ * src/odr-audioenc.cpp:904-986).  tlb_tick_wait() waits for the oldest submitted tick; the read accessors (tlb_tick_peaks, _frame,
+ * _packet, _message, _fragment, _silence_ms) then show ITS results until the next wait.  At most two ticks in flight: submit, submit,
+ * wait, submit, wait ...  Inside, tick t + 1's copy-in starts as soon as tick t's ingest kernel has consumed the device input buffer,
+ * so the host-to-device link -- the limit at large stream counts -- never idles between ticks.  The RE-FETCH rule: call tlb_tick_pcm()
+ * again after every submit / run, the pointer alternates. */
+int tlb_tick_submit(tlb_tick *t);
+int tlb_tick_wait(tlb_tick *t);
 int tlb_tick_finish(tlb_tick *t);
 long tlb_tick_count(const tlb_tick *t);
 const int16_t *tlb_tick_peaks(const tlb_tick *t);

@@ -117,7 +117,7 @@ def load_library():
     for f in ("tlb_tick_pcm", "tlb_tick_xpad", "tlb_tick_xpad_len", "tlb_tick_peaks"):
         getattr(L, f).restype = C.c_void_p
         getattr(L, f).argtypes = [C.c_void_p]
-    for f in ("tlb_tick_run", "tlb_tick_finish"):
+    for f in ("tlb_tick_run", "tlb_tick_finish", "tlb_tick_submit", "tlb_tick_wait"):
         getattr(L, f).argtypes = [C.c_void_p]
     L.tlb_tick_count.argtypes = [C.c_void_p]
     L.tlb_tick_count.restype = C.c_long
@@ -215,14 +215,47 @@ class Tick:
             raise ToolameError(err.value, "tlb_tick_create")
         self.egress = egress
         n = self.nstreams
-        self.pcm = np.ctypeslib.as_array((C.c_int16 * (n * 2 * SAMPLES)).from_address(self.L.tlb_tick_pcm(self.h))).reshape(n, 2 * SAMPLES)
-        self.peaks = np.ctypeslib.as_array((C.c_int16 * (n * 2)).from_address(self.L.tlb_tick_peaks(self.h))).reshape(n, 2)
-        self.xpad = self.xpad_len = None
-        if with_xpad:
-            self.xpad = np.ctypeslib.as_array((C.c_uint8 * (n * MAX_XPAD)).from_address(self.L.tlb_tick_xpad(self.h))).reshape(n, MAX_XPAD)
-            self.xpad_len = np.ctypeslib.as_array((C.c_int32 * n).from_address(self.L.tlb_tick_xpad_len(self.h)))
+        self.with_xpad = bool(with_xpad)
         self.units = [self.L.tlb_tick_units(self.h, s) for s in range(n)]
-        self.silence_ms = np.ctypeslib.as_array((C.c_uint32 * n).from_address(self.L.tlb_tick_silence_ms(self.h)))
+
+    # The object owns TWO sets of pinned host buffers (tlb_tick_submit / tlb_tick_wait): `pcm`, `xpad`, `xpad_len` are views of the
+    # input set to fill NEXT, `peaks`, `silence_ms` of the results of the tick waited for last -- fetched on every access.
+    def _view(self, fn, ctype, shape):
+        p = getattr(self.L, fn)(self.h)
+        cnt = int(np.prod(shape))
+        return np.ctypeslib.as_array((ctype * cnt).from_address(p)).reshape(shape) if p else None
+
+    @property
+    def pcm(self):
+        return self._view("tlb_tick_pcm", C.c_int16, (self.nstreams, 2 * SAMPLES))
+
+    @property
+    def xpad(self):
+        return self._view("tlb_tick_xpad", C.c_uint8, (self.nstreams, MAX_XPAD)) if self.with_xpad else None
+
+    @property
+    def xpad_len(self):
+        return self._view("tlb_tick_xpad_len", C.c_int32, (self.nstreams,)) if self.with_xpad else None
+
+    @property
+    def peaks(self):
+        return self._view("tlb_tick_peaks", C.c_int16, (self.nstreams, 2))
+
+    @property
+    def silence_ms(self):
+        return self._view("tlb_tick_silence_ms", C.c_uint32, (self.nstreams,))
+
+    def submit(self):
+        """queue one tick on the input set just filled and return at once; `pcm` then shows the other input set"""
+        rc = self.L.tlb_tick_submit(self.h)
+        if rc:
+            raise ToolameError(rc, "tlb_tick_submit")
+
+    def wait(self):
+        """wait for the oldest submitted tick; frame() / packets() / peaks ... then show its results"""
+        rc = self.L.tlb_tick_wait(self.h)
+        if rc:
+            raise ToolameError(rc, "tlb_tick_wait")
 
     def set_gain_db(self, gain_db, stream=-1):
         rc = self.L.tlb_tick_set_gain_db(self.h, stream, float(gain_db))
@@ -301,7 +334,6 @@ class Tick:
 
     def close(self):
         if getattr(self, "h", None):
-            self.pcm = self.peaks = self.xpad = self.xpad_len = self.silence_ms = None
             self.L.tlb_tick_destroy(self.h)
             self.h = None
 

@@ -855,6 +855,46 @@ def test_stream_life_cycle_in_a_live_batch(M):
     b.close()
 
 
+@pytest.mark.parametrize("egress,ngroups", [("af", 3), ("pft", 2), ("frames", 1)])
+def test_tick_submit_wait_equals_run(M, egress, ngroups):
+    """Ticks overlapped (tlb_tick_submit / tlb_tick_wait: the next tick is queued on the second set of pinned buffers before this one is
+    waited for, its copy-in running under this tick's kernels and copy-out) give, tick by tick, exactly what tlb_tick_run gives."""
+    streams = EDI_TICK_CASES[sorted(EDI_TICK_CASES)[-1]]
+    cfgs = [M.StreamConfig(samplerate=r, mode=m, bitrate=k, psy_model=p) for r, m, k, p in streams]
+    ns, T = len(cfgs), 11
+    inter = np.stack([np.stack([gen_pcm(1900 + s, (0, 7, 5, 4)[s % 4], 0, T)[f].T.reshape(-1) for s in range(ns)]) for f in range(T)])
+    kw = dict(egress=egress, ngroups=ngroups, version=b"v1", now_s=1712345678, delay_ms=370, tist=True)
+    if egress == "pft":
+        kw.update(fec=1, chunk_len=207)
+    snap = lambda t: [(t.frame(s), t.packets(s), t.fragments(s), tuple(t.peaks[s]), int(t.silence_ms[s])) for s in range(ns)]
+    a = M.Tick(cfgs, **kw)
+    want = []
+    for f in range(T):
+        a.pcm[:] = inter[f]
+        a.run()
+        want.append(snap(a))
+    a.finish()
+    want.append(snap(a))
+    b = M.Tick(cfgs, **kw)
+    got = []
+    b.pcm[:] = inter[0]
+    b.submit()
+    for f in range(1, T):
+        b.pcm[:] = inter[f]                                # the OTHER input set: filled while tick f - 1 is on its way
+        b.submit()
+        b.wait()
+        got.append(snap(b))
+    with pytest.raises(M.ToolameError):
+        b.wait(); b.wait()                                 # nothing left to wait for after the last one
+    got.append(snap(b))
+    b.finish()
+    got.append(snap(b))
+    assert len(got) == len(want) == T + 1
+    for f in range(T + 1):
+        assert got[f] == want[f], f
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("egress", ["frames", "af"])
 def test_tick_stream_life_cycle(M, egress):
     """The same three operations on a tick object, between runs: the restarted stream's slots stay empty until its next frame is
