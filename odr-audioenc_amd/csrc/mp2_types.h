@@ -162,6 +162,7 @@ struct TlLaunch {
     uint8_t *padbits;                 // [nframes][nstreams] padding slot of each frame (tl_slots_stream), or null: no stream of the launch pads
     double *newlag;                   // [nstreams] the slot recurrence's state after the launch (with padbits)
     int32_t *work;                    // unit counters of the persistent kernels: [0] psy-2 kernel, [32 (1 + q)] list q of the eight per-XCD lists of (stream, frame) units
+    const int32_t *partner;           // [nstreams] the mono stream of the same configuration a mono stream shares its waves with (tl_encode_pair), -1: none; or null
     const int32_t *chain_list;        // [nchain] psy-2 kernel: stream id | channel << 30 of each (stream, channel) chain of the launch
     int32_t nstreams, nframes, out_stride, nlist;
     int32_t nchain, p2_nwhole, p2_k, p2_plen;    // psy-2 kernel's work list (tl_psy2_unit): whole chains, then runs of p2_plen frames

@@ -262,7 +262,7 @@ struct TlMainLds {
     static constexpr int kFbBatch = TL_FB_BATCH_MAIN;
     union alignas(16) {
         struct { int16_t pcm[2][TL_HIST + 1152]; } fbk;
-        uint32_t frame[TL_MAX_FRAME_WORDS + 2];
+        uint32_t frame[2][TL_MAX_FRAME_WORDS + 2];         // the frame being packed (+ 2: tl_put_bits48); [1]: the second unit of a mono pair (tl_encode_pair)
     } u;
     double yp[TL_FB_BATCH_MAIN][2][34];
     double smr[2][32];                  // models 1 and 3: until the SMR line, the level of the model's record
@@ -660,7 +660,9 @@ TL_FN void tl_fht_pass(double *x, const double (&t)[8], int lane)
 // Leaves energy[i] in w.u.fft[TL_EX(i)], i = 0..512.
 // A stream's PCM as the kernel sees it in HBM: this frame (planar [2][1152]) and the 480 samples per
 // channel that precede it (the stream state on the first frame of a launch, the previous input frame after).
-struct TlPcmView { const int16_t *cur; const int16_t *hist; int hist_stride; };
+// Per "channel" c of the wave: the two channels of a stereo stream -- or, for a PAIR of mono streams sharing a wave (tl_frame_unit),
+// channel 0 of each of the two streams.
+struct TlPcmView { const int16_t *cur[2]; const int16_t *hist[2]; };
 
 TL_FN void tl_psy_spectrum(TlPsyLds &w, const TlTables *TL_RESTRICT T, const TlPcmView &pv, int ch, long long *sp)
 {
@@ -674,8 +676,8 @@ TL_FN void tl_psy_spectrum(TlPsyLds &w, const TlTables *TL_RESTRICT T, const TlP
         // sample i = lane + 64*it of the analysis window: the last 192 samples of the history (it < 3), then the
         // first 832 of the frame.  The loads are issued in batches ahead of their use.  Slot of i inside the lane's block
         // of sixteen: rev4(it).
-        const int16_t *hs = pv.hist + ch * pv.hist_stride + (TL_HIST - 192) + lane;
-        const int16_t *cs = pv.cur + ch * 1152 - 192 + lane;
+        const int16_t *hs = (ch ? pv.hist[1] : pv.hist[0]) + (TL_HIST - 192) + lane;      // (a select, not an indexed array: that would live in scratch)
+        const int16_t *cs = (ch ? pv.cur[1] : pv.cur[0]) - 192 + lane;
         const double *hann = T->hann;
         TL_LAUNDER(hann);
         tl_fht_twiddles<4>(L(twc), T, lane);
@@ -1982,6 +1984,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
             // of their use; slot of i inside the lane's block of sixteen: rev4(it) (see tl_fht_head)
             const double *win = P->window;
             TL_LAUNDER(win);
+            const int16_t *pvh = ch ? pv.hist[1] : pv.hist[0], *pvc = ch ? pv.cur[1] : pv.cur[0];
             tl_fht_twiddles<4>(L(twc), T, lane);
             double e[16];
 #ifndef TL_EMULATE
@@ -1994,8 +1997,8 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
 #endif
                 for (int q = 0; q < 8; q++) {
                     const int i = lane + 64 * (half + q);
-                    if (pass == 0) v[q] = i < TL_HIST ? pv.hist[ch * pv.hist_stride + i] : pv.cur[ch * 1152 + (i - TL_HIST)];
-                    else v[q] = pv.cur[ch * 1152 + 96 + i];
+                    if (pass == 0) v[q] = i < TL_HIST ? pvh[i] : pvc[i - TL_HIST];
+                    else v[q] = pvc[96 + i];
                     h[q] = win[i];
                 }
 #ifndef TL_EMULATE
@@ -2174,32 +2177,16 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// One frame of one stream.  lane = 2*sb + ch owns subband sb of channel ch.  PSY (the psy model) is a compile-time
-// parameter: one kernel per model keeps each kernel's code and register footprint to what that model needs.
-// Where a frame of the frame-parallel encode kernel goes (exactly one of bytes / words is set): the output slot it waits in
-// for its successor's ScF-CRC, or -- the last frame of a launch -- the batch's pending buffer (big-endian words like
-// TlStreamState::pending); and the slot for its own ScF-CRC bytes, which tl_finish_stream stores into the frame before it.
-struct TlFrameOut { uint8_t *bytes; uint32_t *words; uint8_t *scfcrc; };
-template <int PSY>
-TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
-                           const TlConfig *TL_RESTRICT C, const TlPsyOut *TL_RESTRICT PO,
-                           const TlPcmView &pv, int xpad_len, const TlFrameOut &fo,
-                           const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, int padding, TlTaps *taps, long long *sp)
+// ---- K1: polyphase filterbank (subband.c:201-310), 36 blocks of 32 samples, for the `nlan` channels staged in w.u.fbk.pcm ----
+// (the two channels of a stereo stream, one channel, or channel 0 of each of two mono streams sharing the wave)
+// Window stage: lane (ch,i) owns yprime[i] and computes exactly the two window outputs it is made of
+// (yprime[0]=y[16]; yprime[i]=y[i+16]+y[16-i], i<=16; y[i+16]-y[80-i], i>=17 -- every y is used by one
+// yprime only, so nothing is computed twice), each as the reference's ascending 8-tap chain.
+// Matrixing stage: lane (ch,sb) owns the even-k chain s0 (sb<16) or the odd-k chain s1 (sb>=16) of row
+// min(sb,31-sb); the two halves swap values (a move, not a re-association): s[i]=s0+s1, s[31-i]=s0-s1.
+TL_FN void tl_filterbank(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s, const int nch, PARGA(double, smp, 36))
 {
     constexpr int FB = TlMainLds::kFbBatch;
-    const int nch = C->nch, sblimit = C->sblimit;
-    PA(double, smp, 36);            // sb_sample[ch][gr][bl][sb] of this lane's (sb,ch), b = gr*12+bl
-    PA(int, scf, 3);
-
-    TL_STAMP(sp, 0);
-    // ---- K1: polyphase filterbank (subband.c:201-310), 36 blocks of 32 samples ----
-    // Window stage: lane (ch,i) owns yprime[i] and computes exactly the two window outputs it is made of
-    // (yprime[0]=y[16]; yprime[i]=y[i+16]+y[16-i], i<=16; y[i+16]-y[80-i], i>=17 -- every y is used by one
-    // yprime only, so nothing is computed twice), each as the reference's ascending 8-tap chain.
-    // Matrixing stage: lane (ch,sb) owns the even-k chain s0 (sb<16) or the odd-k chain s1 (sb>=16) of row
-    // min(sb,31-sb); the two halves swap values (a move, not a re-association): s[i]=s0+s1, s[31-i]=s0-s1.
-    {
         // the reference scales the sample, (pcm/32768)*C (subband.c:233,249); scaling the coefficient instead is the
         // same real product rounded once (2^-15 is exact, nothing underflows), so the bits are identical: enw_s = C / 32768
         // (host table; the encode kernel of the split path reads its workgroup's LDS copy).
@@ -2305,7 +2292,138 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
                 L(smp)[b0 + bb] = c < nch ? (sb < 16 ? L(part)[bb] + L(oth)[bb] : L(oth)[bb] - L(part)[bb]) : 0.0;
             TL_LANES_END
         }
+}
+
+// a_bit_allocation_new (encode_new.c:1078-1187) for the cells of the wave -- all of them (unit < 0: the one or two channels of a stream,
+// joint pairs included) or, for two mono streams sharing the wave, the cells of ONE of them (unit = 0 / 1: the lanes of that parity;
+// nch = 1, jsbound = sblimit).  adb: the frame's bits after header extension and PAD (toolame.c:292-301).  Returns the bits left over.
+TL_FN int tl_allocate(const TlBlockShared *TL_RESTRICT B, int adb, int nch, int sblimit, int jsbound, int unit, PARG(int, a_ln), PARG(int, a_nbal),
+                      PARG(int, a_sfs), PARG(int, a_sfs_o), PARG(double, a_smr), PARG(int, ba))
+{
+    PV(uint64_t, ukey); PV(uint64_t, ukey2); PV(int, nbits); PV(int, cost); PV(int, cost2);
+    PV(int, jpair);                                             // lane belongs to a joint-coded pair (steps with its partner)
+    TL_LANES_BEGIN
+    const int c = lane & 1, sb = lane >> 1;
+    const bool live = (unit < 0 ? c < nch : c == unit) && sb < sblimit;
+    const int maxa = (1 << L(a_nbal)) - 1;
+    L(ukey) = live ? tl_mnr_key(B->snr_line[L(a_ln)][0] - L(a_smr)) : ~0ull;
+    L(ukey2) = (live && 1 < maxa) ? tl_mnr_key(B->snr_line[L(a_ln)][1] - L(a_smr)) : ~0ull;
+    L(ba) = 0;
+    L(nbits) = (unit < 0 ? (sb < sblimit && c < (sb < jsbound ? nch : 1)) : live) ? L(a_nbal) : 0;
+    // first step of a cell: samples + scfsi + scalefactors (both channels above jsbound), :1139-1147
+    L(cost) = live ? B->bits12_line[L(a_ln)][1] + 2 + L(a_sfs) + ((nch == 2 && sb >= jsbound) ? 2 + L(a_sfs_o) : 0) : 0;
+    L(cost2) = live ? B->bits12_line[L(a_ln)][2] - B->bits12_line[L(a_ln)][1] : 0;
+    L(jpair) = (live && nch == 2 && sb >= jsbound) ? 1 : 0;
+    TL_LANES_END
+    const int bbal = TL_WAVE_SUM_I32(nbits);
+    const int ad = adb - (bbal + 16 + 32);
+    int spent = 0;                                              // bspl + bscf + bsel
+    const bool any_pair = nch == 2 && jsbound < sblimit;
+    for (; TL_ENC_LEVEL < 4;) {                                 // rounds
+        PV(uint64_t, keff); PV(uint64_t, k2eff);
+        TL_LANES_BEGIN L(keff) = L(ukey); L(k2eff) = L(ukey2); TL_LANES_END
+        if (any_pair) {                                         // a pair acts at the smaller of its two keys
+            PV(uint64_t, ok1); PV(uint64_t, ok2);
+            TL_SWAP1_U64(ok1, ukey); TL_SWAP1_U64(ok2, ukey2);
+            TL_LANES_BEGIN
+            if (L(jpair)) { if (L(ok1) < L(keff)) L(keff) = L(ok1); if (L(ok2) < L(k2eff)) L(k2eff) = L(ok2); }
+            TL_LANES_END
+        }
+        const uint64_t M = TL_WAVE_MIN_U64(k2eff);
+        PV(bool, inb); PV(int, bcost);
+        TL_LANES_BEGIN
+        L(inb) = L(keff) < M;
+        L(bcost) = (L(inb) && !(L(jpair) && (lane & 1))) ? L(cost) : 0;     // a pair pays once
+        TL_LANES_END
+        const uint64_t bm = TL_BALLOT(inb);
+        if (bm == 0ull) break;
+        const int csum = TL_WAVE_SUM_I32(bcost);
+        bool last_round = false;
+        if (csum > ad - spent) {
+            // The round does not fit as a whole: admit its events up to the first refusal.  Each cell adds up the
+            // prices of the round's events that come no later than its own (equal keys count as earlier, which can
+            // only shorten the admitted prefix); the prefix sums grow along the greedy order, so the cells whose
+            // sum still fits are exactly a prefix of it.  The event-by-event loop below deals with the rest.
+            PV(int, pre); PV(int, kh); PV(int, kl);
+            TL_LANES_BEGIN L(pre) = L(cost); L(kh) = (int)(uint32_t)(L(keff) >> 32); L(kl) = (int)(uint32_t)L(keff); TL_LANES_END
+            uint64_t pm = bm;
+            while (pm) {
+                const int j = __builtin_ctzll(pm);
+                pm &= pm - 1;
+                const int cj = TL_READLANE_I32(bcost, j);
+                if (cj == 0) continue;                          // the non-paying lane of a pair
+                const uint64_t kj = ((uint64_t)(uint32_t)TL_READLANE_I32(kh, j) << 32) | (uint32_t)TL_READLANE_I32(kl, j);
+                TL_LANES_BEGIN
+                const int own = L(jpair) ? (lane & ~1) : lane;
+                if (j != own && kj <= L(keff)) L(pre) += cj;
+                TL_LANES_END
+            }
+            TL_LANES_BEGIN
+            L(inb) = L(inb) && L(pre) <= ad - spent;
+            L(bcost) = L(inb) ? L(bcost) : 0;
+            TL_LANES_END
+            if (TL_BALLOT(inb) == 0ull) break;
+            spent += TL_WAVE_SUM_I32(bcost);
+            last_round = true;
+        } else spent += csum;
+        TL_LANES_BEGIN
+        if (L(inb)) {
+            const int nba = L(ba) + 1;
+            L(ba) = nba;
+            L(ukey) = L(ukey2);
+            L(cost) = L(cost2);
+            L(ukey2) = (nba + 1 >= (1 << L(a_nbal)) - 1) ? ~0ull : tl_mnr_key(B->snr_line[L(a_ln)][(nba + 1) & 15] - L(a_smr));
+            L(cost2) = B->bits12_line[L(a_ln)][(nba + 2) & 15] - B->bits12_line[L(a_ln)][(nba + 1) & 15];
+        }
+        TL_LANES_END
+        if (last_round) break;
     }
+    for (; TL_ENC_LEVEL < 4;) {                                 // one event at a time
+        // maxmnr_new (encode_new.c:1061-1077): smallest mnr, first in (ch, sb) order
+        PV(uint64_t, key);
+        TL_LANES_BEGIN
+        L(key) = L(cost) <= ad - spent ? L(ukey) : ~0ull;
+        TL_LANES_END
+        const int wl = TL_WAVE_ARGMIN_U64(key);                  // ch 0 first, then ascending sb
+        if (wl < 0) break;
+        const int min_sb = wl >> 1;
+        spent += TL_READLANE_I32(cost, wl);
+        const bool joint_pair = (min_sb >= jsbound && nch == 2);
+        TL_LANES_BEGIN
+        if (lane == wl || (joint_pair && (lane ^ 1) == wl)) {
+            const int nba = L(ba) + 1;
+            L(ba) = nba;
+            L(ukey) = L(ukey2);
+            L(cost) = L(cost2);
+            L(ukey2) = (nba + 1 >= (1 << L(a_nbal)) - 1) ? ~0ull : tl_mnr_key(B->snr_line[L(a_ln)][(nba + 1) & 15] - L(a_smr));
+            L(cost2) = B->bits12_line[L(a_ln)][(nba + 2) & 15] - B->bits12_line[L(a_ln)][(nba + 1) & 15];
+        }
+        TL_LANES_END
+    }
+    return ad - spent;
+}
+
+// ------------------------------------------------------------------------------------------
+// One frame of one stream.  lane = 2*sb + ch owns subband sb of channel ch.  PSY (the psy model) is a compile-time
+// parameter: one kernel per model keeps each kernel's code and register footprint to what that model needs.
+// Where a frame of the frame-parallel encode kernel goes (exactly one of bytes / words is set): the output slot it waits in
+// for its successor's ScF-CRC, or -- the last frame of a launch -- the batch's pending buffer (big-endian words like
+// TlStreamState::pending); and the slot for its own ScF-CRC bytes, which tl_finish_stream stores into the frame before it.
+struct TlFrameOut { uint8_t *bytes; uint32_t *words; uint8_t *scfcrc; };
+template <int PSY>
+TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
+                           const TlConfig *TL_RESTRICT C, const TlPsyOut *TL_RESTRICT PO,
+                           const TlPcmView &pv, int xpad_len, const TlFrameOut &fo,
+                           const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, int padding, TlTaps *taps, long long *sp)
+{
+    constexpr int FB = TlMainLds::kFbBatch;
+    const int nch = C->nch, sblimit = C->sblimit;
+    PA(double, smp, 36);            // sb_sample[ch][gr][bl][sb] of this lane's (sb,ch), b = gr*12+bl
+    PA(int, scf, 3);
+
+    TL_STAMP(sp, 0);
+    // ---- K1: polyphase filterbank ----
+    tl_filterbank(w, B, enw_s, nch, smp);
 
     TL_STAMP(sp, 1);
 #if !defined(TL_EMULATE) && TL_ENC_LEVEL >= 5
@@ -2506,107 +2624,8 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
         // whose next key is below M are exactly the greedy order's next events (no second step can come before
         // them).  If together they still fit, they are all taken in one round; the one-at-a-time loop takes over
         // when a round no longer fits (or is empty), so the refusal rule above is applied event by event.
-        PV(uint64_t, ukey); PV(uint64_t, ukey2); PV(int, ba); PV(int, nbits); PV(int, cost); PV(int, cost2);
-        PV(int, jpair);                                             // lane belongs to a joint-coded pair (steps with its partner)
-        TL_LANES_BEGIN
-        const int c = lane & 1, sb = lane >> 1;
-        const bool live = c < nch && sb < sblimit;
-        const int maxa = (1 << L(a_nbal)) - 1;
-        L(ukey) = live ? tl_mnr_key(B->snr_line[L(a_ln)][0] - L(a_smr)) : ~0ull;
-        L(ukey2) = (live && 1 < maxa) ? tl_mnr_key(B->snr_line[L(a_ln)][1] - L(a_smr)) : ~0ull;
-        L(ba) = 0;
-        L(nbits) = (sb < sblimit && c < (sb < jsbound ? nch : 1)) ? L(a_nbal) : 0;
-        // first step of a cell: samples + scfsi + scalefactors (both channels above jsbound), :1139-1147
-        L(cost) = live ? B->bits12_line[L(a_ln)][1] + 2 + L(a_sfs) + ((nch == 2 && sb >= jsbound) ? 2 + L(a_sfs_o) : 0) : 0;
-        L(cost2) = live ? B->bits12_line[L(a_ln)][2] - B->bits12_line[L(a_ln)][1] : 0;
-        L(jpair) = (live && nch == 2 && sb >= jsbound) ? 1 : 0;
-        TL_LANES_END
-        const int bbal = TL_WAVE_SUM_I32(nbits);
-        const int ad = adb - (bbal + 16 + 32);
-        int spent = 0;                                              // bspl + bscf + bsel
-        const bool any_pair = nch == 2 && jsbound < sblimit;
-        for (; TL_ENC_LEVEL < 4;) {                                 // rounds
-            PV(uint64_t, keff); PV(uint64_t, k2eff);
-            TL_LANES_BEGIN L(keff) = L(ukey); L(k2eff) = L(ukey2); TL_LANES_END
-            if (any_pair) {                                         // a pair acts at the smaller of its two keys
-                PV(uint64_t, ok1); PV(uint64_t, ok2);
-                TL_SWAP1_U64(ok1, ukey); TL_SWAP1_U64(ok2, ukey2);
-                TL_LANES_BEGIN
-                if (L(jpair)) { if (L(ok1) < L(keff)) L(keff) = L(ok1); if (L(ok2) < L(k2eff)) L(k2eff) = L(ok2); }
-                TL_LANES_END
-            }
-            const uint64_t M = TL_WAVE_MIN_U64(k2eff);
-            PV(bool, inb); PV(int, bcost);
-            TL_LANES_BEGIN
-            L(inb) = L(keff) < M;
-            L(bcost) = (L(inb) && !(L(jpair) && (lane & 1))) ? L(cost) : 0;     // a pair pays once
-            TL_LANES_END
-            const uint64_t bm = TL_BALLOT(inb);
-            if (bm == 0ull) break;
-            const int csum = TL_WAVE_SUM_I32(bcost);
-            bool last_round = false;
-            if (csum > ad - spent) {
-                // The round does not fit as a whole: admit its events up to the first refusal.  Each cell adds up the
-                // prices of the round's events that come no later than its own (equal keys count as earlier, which can
-                // only shorten the admitted prefix); the prefix sums grow along the greedy order, so the cells whose
-                // sum still fits are exactly a prefix of it.  The event-by-event loop below deals with the rest.
-                PV(int, pre); PV(int, kh); PV(int, kl);
-                TL_LANES_BEGIN L(pre) = L(cost); L(kh) = (int)(uint32_t)(L(keff) >> 32); L(kl) = (int)(uint32_t)L(keff); TL_LANES_END
-                uint64_t pm = bm;
-                while (pm) {
-                    const int j = __builtin_ctzll(pm);
-                    pm &= pm - 1;
-                    const int cj = TL_READLANE_I32(bcost, j);
-                    if (cj == 0) continue;                          // the non-paying lane of a pair
-                    const uint64_t kj = ((uint64_t)(uint32_t)TL_READLANE_I32(kh, j) << 32) | (uint32_t)TL_READLANE_I32(kl, j);
-                    TL_LANES_BEGIN
-                    const int own = L(jpair) ? (lane & ~1) : lane;
-                    if (j != own && kj <= L(keff)) L(pre) += cj;
-                    TL_LANES_END
-                }
-                TL_LANES_BEGIN
-                L(inb) = L(inb) && L(pre) <= ad - spent;
-                L(bcost) = L(inb) ? L(bcost) : 0;
-                TL_LANES_END
-                if (TL_BALLOT(inb) == 0ull) break;
-                spent += TL_WAVE_SUM_I32(bcost);
-                last_round = true;
-            } else spent += csum;
-            TL_LANES_BEGIN
-            if (L(inb)) {
-                const int nba = L(ba) + 1;
-                L(ba) = nba;
-                L(ukey) = L(ukey2);
-                L(cost) = L(cost2);
-                L(ukey2) = (nba + 1 >= (1 << L(a_nbal)) - 1) ? ~0ull : tl_mnr_key(B->snr_line[L(a_ln)][(nba + 1) & 15] - L(a_smr));
-                L(cost2) = B->bits12_line[L(a_ln)][(nba + 2) & 15] - B->bits12_line[L(a_ln)][(nba + 1) & 15];
-            }
-            TL_LANES_END
-            if (last_round) break;
-        }
-        for (; TL_ENC_LEVEL < 4;) {                                 // one event at a time
-            // maxmnr_new (encode_new.c:1061-1077): smallest mnr, first in (ch, sb) order
-            PV(uint64_t, key);
-            TL_LANES_BEGIN
-            L(key) = L(cost) <= ad - spent ? L(ukey) : ~0ull;
-            TL_LANES_END
-            const int wl = TL_WAVE_ARGMIN_U64(key);                  // ch 0 first, then ascending sb
-            if (wl < 0) break;
-            const int min_sb = wl >> 1;
-            spent += TL_READLANE_I32(cost, wl);
-            const bool joint_pair = (min_sb >= jsbound && nch == 2);
-            TL_LANES_BEGIN
-            if (lane == wl || (joint_pair && (lane ^ 1) == wl)) {
-                const int nba = L(ba) + 1;
-                L(ba) = nba;
-                L(ukey) = L(ukey2);
-                L(cost) = L(cost2);
-                L(ukey2) = (nba + 1 >= (1 << L(a_nbal)) - 1) ? ~0ull : tl_mnr_key(B->snr_line[L(a_ln)][(nba + 1) & 15] - L(a_smr));
-                L(cost2) = B->bits12_line[L(a_ln)][(nba + 2) & 15] - B->bits12_line[L(a_ln)][(nba + 1) & 15];
-            }
-            TL_LANES_END
-        }
-        adb_left = ad - spent;
+        PV(int, ba);
+        adb_left = tl_allocate(B, adb, nch, sblimit, jsbound, -1, a_ln, a_nbal, a_sfs, a_sfs_o, a_smr, ba);
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
         w.balloc[c][sb] = (uint8_t)((c < nch && sb < sblimit) ? L(ba) : 0);
@@ -2615,7 +2634,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
 
     TL_STAMP(sp, 4);
     // ---- K6: header, CRC, bit_alloc, scfsi, scalefactors, quantised samples -> LDS frame ----
-    uint32_t *frame = w.u.frame;
+    uint32_t *frame = w.u.frame[0];
     TL_LANES_BEGIN
     for (int i = lane; i < ((lg_frame + 3) >> 2) + 2; i += 64) frame[i] = 0;      // this frame's words (+ 2: tl_put_bits48)
     TL_LANES_END
@@ -2872,6 +2891,327 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
 }
 
 // ------------------------------------------------------------------------------------------
+// TWO mono streams of ONE configuration in one wave.  A lone mono frame leaves every second lane idle from the filterbank to the
+// packing (lane = 2*sb + ch, ch = 0 only) and costs as many instructions as a stereo frame; here lane = 2*sb + u owns subband sb of
+// UNIT u, the u-th of the two streams (same frame index f of the launch).  Filterbank, scalefactors, transmission pattern, quantiser
+// and packing run for both units at once; the bit allocation and the CRC folds go unit by unit.  What a unit produces is what
+// tl_encode_frame produces for it alone: the operations per cell are the same text, and every wave-level sum, scan and minimum is
+// taken over the unit's own lanes (a scan over both units carries unit 0 in the low and unit 1 in the high half of a word:
+// sums stay below 2^16, XORs never carry).  toolame.c:267-554 twice, the `nch` loop of toolame.c:308-312 turned into lanes.
+template <int PSY>
+TL_FN void tl_encode_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const TlConfig *TL_RESTRICT C, const TlPsyOut *const (&PO)[2],
+                          const int (&xpad_len)[2], const uint8_t *const (&xpad_src)[2], const TlFrameOut (&fo)[2],
+                          const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, const int (&padding)[2])
+{
+    const int sblimit = C->sblimit;
+    const int padpk = padding[0] | (padding[1] << 1);             // both units' padding bits in one scalar (an array indexed by the lane would live in scratch)
+    PA(double, smp, 36);
+    PA(int, scf, 3);
+    tl_filterbank(w, B, enw_s, 2, smp);
+    // ---- scalefactors (encode_new.c:179-230) + find_sf_max (:260-277) ----
+    TL_LANES_BEGIN
+    const int c = lane & 1, sb = lane >> 1;
+    if (sb < sblimit) {
+        unsigned lo = 63;
+        for (int gr = 0; gr < 3; gr++) {
+            double m = fabs(L(smp)[gr * 12 + 11]);
+            for (int j = 10; j >= 0; j--) { double t = fabs(L(smp)[gr * 12 + j]); if (t > m) m = t; }
+            unsigned idx = tl_sf_index(B->scalefactor, m);
+            L(scf)[gr] = (int)idx;
+            if (idx < lo) lo = idx;
+        }
+        w.minidx[c][sb] = (uint8_t)lo;
+    } else {
+        L(scf)[0] = L(scf)[1] = L(scf)[2] = 0;
+        w.minidx[c][sb] = 63;
+    }
+    TL_LANES_END
+    // ---- SMR (toolame.c:361-452), as in tl_encode_frame with c = the unit ----
+    TL_LANES_BEGIN
+    const int c = lane & 1, sb = lane >> 1;
+    if constexpr (PSY == 0) {
+        const int m = sb < sblimit ? (int)w.minidx[c][sb] : 0;
+        w.smr[c][sb] = 2.0 * (30.0 - m) - C->p0_athmin[sb];
+    } else if constexpr (PSY == 2) {
+        w.smr[c][sb] = (c ? PO[1] : PO[0])->a[0][sb];
+    } else {
+        const double a = w.smr[c][sb], m = w.psy_m[c][sb];
+        const double val = C->scale_db[w.minidx[c][sb]];
+        const double top = a > val ? a : val;
+        w.smr[c][sb] = top - m;
+    }
+    TL_LANES_END
+    // ---- sf_transmission_pattern (encode_new.c:288-354, ISO Table C.4) ----
+    TL_LANES_BEGIN
+    const int c = lane & 1, sb = lane >> 1;
+    if (sb < sblimit) {
+        int s0 = L(scf)[0], s1 = L(scf)[1], s2 = L(scf)[2];
+        int d0 = s0 - s1, d1 = s1 - s2;
+        int c0 = d0 <= -3 ? 0 : d0 < 0 ? 1 : d0 == 0 ? 2 : d0 < 3 ? 3 : 4;
+        int c1 = d1 <= -3 ? 0 : d1 < 0 ? 1 : d1 == 0 ? 2 : d1 < 3 ? 3 : 4;
+        const unsigned p = B->sfpat[c0 * 5 + c1];
+        const int m02 = s0 > s2 ? s2 : s0;
+        const unsigned q0 = p & 3u, q1 = (p >> 2) & 3u, q2 = (p >> 4) & 3u;
+        const int n0 = q0 == 0 ? s0 : q0 == 1 ? s1 : q0 == 2 ? s2 : m02;
+        const int n1 = q1 == 0 ? s0 : q1 == 1 ? s1 : q1 == 2 ? s2 : m02;
+        const int n2 = q2 == 0 ? s0 : q2 == 1 ? s1 : q2 == 2 ? s2 : m02;
+        L(scf)[0] = n0; L(scf)[1] = n1; L(scf)[2] = n2;
+        w.scfsi[c][sb] = (uint8_t)(p >> 6);
+    } else w.scfsi[c][sb] = 0;
+    w.balloc[c][sb] = 0;
+    TL_LANES_END
+    // ---- bit allocation (encode_new.c:733-886, :1061-1187): one unit after the other, each over its own lanes ----
+    int lg_frame[2];
+    {
+        PV(int, a_ln); PV(int, a_nbal); PV(int, a_sfs); PV(int, a_sfs_o); PV(double, a_smr); PV(int, ba);
+        TL_LANES_BEGIN
+        const int c = lane & 1, sb = lane >> 1;
+        const bool live = sb < sblimit;
+        L(a_ln) = live ? C->line[sb] : 0;
+        L(a_nbal) = live ? C->nbal[sb] : 0;
+        L(a_sfs) = live ? 6 * tl_sfs_count(w.scfsi[c][sb]) : 0;
+        L(a_sfs_o) = 0;
+        L(a_smr) = live ? w.smr[c][sb] : 0.0;
+        TL_LANES_END
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int u = 0; u < 2; u++) {
+            lg_frame[u] = C->frame_bytes + padding[u];                                       // availbits.c:64
+            const int adb = lg_frame[u] * 8 - (C->dab_ext * 8 + (xpad_len[u] ? xpad_len[u] : 2) * 8);    // toolame.c:292-301
+            (void)tl_allocate(B, adb, 1, sblimit, sblimit, u, a_ln, a_nbal, a_sfs, a_sfs_o, a_smr, ba);
+            TL_LANES_BEGIN
+            const int c = lane & 1, sb = lane >> 1;
+            if (c == u) w.balloc[c][sb] = (uint8_t)(sb < sblimit ? L(ba) : 0);
+            TL_LANES_END
+        }
+    }
+    // ---- header, bit_alloc, scfsi, scalefactors, quantised samples -> the two LDS frames ----
+    TL_LANES_BEGIN
+    for (int i = lane; i < ((lg_frame[0] + 3) >> 2) + 2; i += 64) w.u.frame[0][i] = 0;
+    for (int i = lane; i < ((lg_frame[1] + 3) >> 2) + 2; i += 64) w.u.frame[1][i] = 0;
+    TL_LANES_END
+    PV(int, f_ba); PV(int, f_sel); PV(int, f_scf); PV(int, f_smp); PV(int, a_ln2);
+    PV(int, o_ba); PV(int, o_sel); PV(int, o_scf); PV(int, o_smp);
+    TL_LANES_BEGIN
+    const int c = lane & 1, sb = lane >> 1;
+    const bool live = sb < sblimit;
+    const int ba = live ? w.balloc[c][sb] : 0, sh = 16 * c;
+    L(a_ln2) = live ? C->line[sb] : 0;
+    L(f_ba) = (live ? (int)C->nbal[sb] : 0) << sh;
+    L(f_sel) = (ba ? 2 : 0) << sh;
+    L(f_scf) = (ba ? 6 * tl_sfs_count(w.scfsi[c][sb]) : 0) << sh;
+    L(f_smp) = (ba ? B->bits12_line[L(a_ln2)][ba] / 12 : 0) << sh;
+    TL_LANES_END
+    TL_WAVE_EXSCAN_I32(o_ba, f_ba); TL_WAVE_EXSCAN_I32(o_sel, f_sel);
+    TL_WAVE_EXSCAN_I32(o_scf, f_scf); TL_WAVE_EXSCAN_I32(o_smp, f_smp);
+    const int s_ba = TL_WAVE_SUM_I32(f_ba), s_sel = TL_WAVE_SUM_I32(f_sel), s_scf = TL_WAVE_SUM_I32(f_scf), s_smp = TL_WAVE_SUM_I32(f_smp);
+    int p_sel[2], p_scf[2], p_smp[2], n_smp[2];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int u = 0; u < 2; u++) {
+        const int sh = 16 * u;
+        p_sel[u] = 48 + ((s_ba >> sh) & 0xffff); p_scf[u] = p_sel[u] + ((s_sel >> sh) & 0xffff); p_smp[u] = p_scf[u] + ((s_scf >> sh) & 0xffff);
+        n_smp[u] = (s_smp >> sh) & 0xffff;
+    }
+    TL_LANES_BEGIN
+    const int c = lane & 1, sb = lane >> 1, sh = 16 * c;
+    uint32_t *frame = w.u.frame[c];
+    if (lane < 2) {      // write_header (encode_new.c:356-373), lane u for unit u
+        uint32_t h = (0xfffu << 20) | ((uint32_t)C->version << 19) | (2u << 17) | (0u << 16)
+                   | ((uint32_t)C->br_idx << 12) | ((uint32_t)C->fs_idx << 10) | ((uint32_t)((padpk >> c) & 1) << 9) | (0u << 8)
+                   | ((uint32_t)C->mode0 << 6) | ((uint32_t)C->mode_ext0 << 4);
+        TL_ATOMIC_OR(&frame[0], h);
+    }
+    const bool live = sb < sblimit;
+    const int ba = live ? w.balloc[c][sb] : 0;
+    const int nb_ba = (L(f_ba) >> sh) & 0xffff;
+    if (nb_ba) tl_put_bits48(frame, 48 + ((L(o_ba) >> sh) & 0xffff), (uint64_t)ba, nb_ba);
+    if (ba) {
+        const unsigned si = w.scfsi[c][sb];
+        tl_put_bits48(frame, (c ? p_sel[1] : p_sel[0]) + ((L(o_sel) >> sh) & 0xffff), si, 2);
+        const unsigned s0 = (unsigned)L(scf)[0], s1 = (unsigned)L(scf)[1], s2 = (unsigned)L(scf)[2];
+        const unsigned f3 = (s0 << 12) | (s1 << 6) | s2, f2 = (s0 << 6) | s2;
+        tl_put_bits48(frame, (c ? p_scf[1] : p_scf[0]) + ((L(o_scf) >> sh) & 0xffff), si == 0 ? f3 : si == 2 ? s0 : f2, (L(f_scf) >> sh) & 0xffff);
+    }
+    TL_LANES_END
+    // quantise (encode_new.c:479-547) + write_samples_new (:560-598): 12 rounds of 3 samples
+    {
+        PV(int, q_ba); PV(int, q_nb); PV(int, q_grp); PV(int, q_s2n); PV(int, q_steps); PV(int, q_pos); PV(int, q_rstep);
+        PV(double, q_a); PV(double, q_b); PV(double, q_s2nf); PA(double, q_sf, 3); PA(double, q_rsf, 3);
+        TL_LANES_BEGIN
+        const int c = lane & 1, sb = lane >> 1, sh = 16 * c;
+        const int ba = sb < sblimit ? w.balloc[c][sb] : 0;
+        const unsigned qi = ba ? B->qinfo_line[L(a_ln2)][ba] : 0u;
+        const int q = (int)(qi & 31u);
+        L(q_ba) = ba; L(q_nb) = (int)((qi >> 5) & 31u); L(q_grp) = ((qi >> 10) & 1u) ? 3 : 1; L(q_s2n) = K->steps2n[q]; L(q_steps) = K->steps[q];
+        L(q_a) = K->qa[q]; L(q_b) = K->qb[q]; L(q_s2nf) = K->steps2n_f[q];
+        for (int gr = 0; gr < 3; gr++) {
+            L(q_sf)[gr] = B->scalefactor[L(scf)[gr]];
+            L(q_rsf)[gr] = 1.0 / L(q_sf)[gr];
+        }
+        L(q_pos) = (c ? p_smp[1] : p_smp[0]) + ((L(o_smp) >> sh) & 0xffff);
+        L(q_rstep) = c ? n_smp[1] : n_smp[0];
+        TL_LANES_END
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int r = 0; r < 12; r++) {
+            const int gr = r >> 2, j0 = (r & 3) * 3;
+            TL_LANES_BEGIN
+            if (L(q_ba)) {
+                const double sfv = L(q_sf)[gr], rsf = L(q_rsf)[gr];
+                unsigned v[3];
+                for (int x = 0; x < 3; x++) {
+                    double d = tl_div_by(L(smp)[gr * 12 + j0 + x], sfv, rsf);                // == s / sfv (encode_new.c:507,511)
+                    d = d * L(q_a) + L(q_b);
+                    const bool neg = !(d >= 0);                                            // encode_new.c:528-534
+                    d += TL_SELECT(neg, 1.0, 0.0);
+                    const unsigned qv = (unsigned)(d * L(q_s2nf));
+                    v[x] = qv | (neg ? 0u : (unsigned)L(q_s2n));
+                }
+                const int nb = L(q_nb);
+                const bool three = L(q_grp) == 3;
+                const unsigned y = (unsigned)L(q_steps);
+                const uint64_t sep = ((uint64_t)v[0] << (2 * nb)) | ((uint64_t)v[1] << nb) | (uint64_t)v[2];
+                const uint64_t grp = (uint64_t)(v[0] + y * (v[1] + y * v[2]));
+                tl_put_bits48(w.u.frame[lane & 1], L(q_pos) + r * L(q_rstep), TL_SELECT(three, sep, grp), three ? 3 * nb : nb);
+            }
+            TL_LANES_END
+        }
+    }
+    // ---- CRC-16 (crc.c:12-41) of both frames: lanes 0..31 fold unit 0's message bytes, lanes 32..63 unit 1's (a mono frame protects
+    //      at most 16 + 94 + 60 bits: 22 bytes; the preset's two bytes ride on lanes 30/31 of each half) ----
+    {
+        PV(uint32_t, part0); PV(uint32_t, part1);
+        TL_LANES_BEGIN
+        const int u = lane >> 5, l5 = lane & 31;
+        const uint32_t *frame = w.u.frame[u];
+        const int n = 16 + ((u ? p_scf[1] : p_scf[0]) - 48);
+        uint32_t acc = 0;
+        const bool preset = l5 >= 30;
+        const int first = 8 * l5;
+        if (first < n || preset) {
+            const int byte = l5 < 2 ? l5 + 2 : l5 + 4;
+            const int cnt = preset ? 8 : (n - first < 8 ? n - first : 8);
+            const int e0 = preset ? n + 8 * (31 - l5) : 16 + (n - first - cnt);
+            unsigned xp = K->crc_xpow[e0];
+            const unsigned v = preset ? 0xffu : ((frame[byte >> 2] >> (24 - 8 * (byte & 3))) & 0xffu) >> (8 - cnt);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int k = 0; k < 8; k++) {
+                acc ^= ((v >> k) & 1u) ? xp : 0u;
+                xp = ((xp << 1) & 0xffffu) ^ ((xp & 0x8000u) ? 0x8005u : 0u);
+            }
+        }
+        L(part0) = u == 0 ? acc : 0u; L(part1) = u == 1 ? acc : 0u;
+        TL_LANES_END
+        const unsigned crc0 = TL_WAVE_XOR_U32(part0) & 0xffffu, crc1 = TL_WAVE_XOR_U32(part1) & 0xffffu;
+        TL_LANES_BEGIN
+        if (lane < 2) tl_put_bits(w.u.frame[lane], 32, lane ? crc1 : crc0, 16);
+        TL_LANES_END
+    }
+    // ---- ScF-CRC (crc.c:58-97, toolame.c:527-542), both units through ONE sum scan and ONE XOR scan (unit u in bits 16u..16u+15) ----
+    {
+        PV(int, rlen); PV(uint32_t, rcrc); PV(int, rl2); PV(int, lex);
+        TL_LANES_BEGIN
+        const int c = lane & 1, sb = lane >> 1;
+        uint32_t rec = 0;
+        if (sb < sblimit && w.balloc[c][sb]) {
+            const uint32_t s0 = (uint32_t)L(scf)[0] >> 3, s1 = (uint32_t)L(scf)[1] >> 3, s2 = (uint32_t)L(scf)[2] >> 3;
+            switch (w.scfsi[c][sb]) {
+            case 0: rec = (9u << 16) | (s0 << 6) | (s1 << 3) | s2; break;
+            case 1: case 3: rec = (6u << 16) | (s0 << 3) | s2; break;
+            default: rec = (3u << 16) | s0; break;
+            }
+        }
+        L(rlen) = (int)(rec >> 16); L(rcrc) = rec & 0x1ffu; L(rl2) = L(rlen) << (16 * c);
+        TL_LANES_END
+        TL_WAVE_EXSCAN_I32(lex, rl2);
+        const int f[5] = {0, 4, 8, 16, 30};
+        int gend[4], gfirst[4], glast[4];
+        for (int g = 0; g < 4; g++) {
+            gfirst[g] = f[g]; glast[g] = f[g + 1] > sblimit ? sblimit : f[g + 1];
+            gend[g] = (g < C->dab_ext && glast[g] > gfirst[g]) ? TL_READLANE_I32(lex, 2 * glast[g]) : 0;      // both units' sums, packed; lane <= 60
+        }
+        PV(uint32_t, part); PV(uint32_t, pscan);
+        TL_LANES_BEGIN
+        const int c = lane & 1, sb = lane >> 1, sh = 16 * c;
+        const int g = sb < 4 ? 0 : sb < 8 ? 1 : sb < 16 ? 2 : 3;
+        const int ge = ((g == 0 ? gend[0] : g == 1 ? gend[1] : g == 2 ? gend[2] : gend[3]) >> sh) & 0xffff;
+        const int after = ge - ((L(lex) >> sh) & 0xffff) - L(rlen);
+        const int e0 = after + 8;
+        unsigned xp = K->crc8_xpow[e0 < 0 ? 0 : e0 > 319 ? 319 : e0];
+        unsigned acc = 0;
+        const unsigned rb = L(rcrc);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int b = 0; b < 9; b++) {
+            acc ^= ((rb >> b) & 1u) ? xp : 0u;
+            xp = ((xp << 1) & 0xffu) ^ ((xp & 0x80u) ? 0x1Du : 0u);
+        }
+        L(part) = (L(rlen) && sb < sblimit) ? acc << sh : 0u;
+        TL_LANES_END
+        TL_WAVE_INCL_XSCAN_U32(pscan, part);
+        unsigned c8g[4];                                             // per group: unit 0's CRC in bits 0..7, unit 1's in bits 16..23
+        for (int g = 0; g < 4; g++) {
+            c8g[g] = 0;
+            if (g < C->dab_ext && glast[g] > gfirst[g]) {
+                c8g[g] = (unsigned)TL_READLANE_I32(pscan, 2 * glast[g] - 1);
+                if (gfirst[g] > 0) c8g[g] ^= (unsigned)TL_READLANE_I32(pscan, 2 * gfirst[g] - 1);
+            }
+        }
+        TL_LANES_BEGIN
+        const int u = lane >> 5, l5 = lane & 31;
+        if (l5 < C->dab_ext) {
+            const int grp = C->dab_ext - 1 - l5;                     // transmission order: i = dab_ext-1 .. 0
+            const unsigned c8 = ((grp == 0 ? c8g[0] : grp == 1 ? c8g[1] : grp == 2 ? c8g[2] : c8g[3]) >> (16 * u)) & 0xffu;
+            const int tail = (u ? lg_frame[1] : lg_frame[0]) - 2 - C->dab_ext;
+            tl_put_bits(w.u.frame[u], (tail + l5) * 8, c8, 8);
+            w.ncentre[4 * u + l5] = (int16_t)c8;
+        }
+        TL_LANES_END
+    }
+    // ---- X-PAD + F-PAD bytes (toolame.c:515-524,544-551), straight from the launch's X-PAD records ----
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int u = 0; u < 2; u++)
+        if (xpad_len[u]) {
+            const int xl = xpad_len[u], xstart = lg_frame[u] - C->dab_ext - xl;
+            TL_LANES_BEGIN
+            for (int i = lane; i < xl; i += 64) {
+                const int bytepos = i < xl - 2 ? xstart + i : lg_frame[u] - 2 + (i - (xl - 2));
+                tl_put_bits(w.u.frame[u], bytepos * 8, xpad_src[u][i], 8);
+            }
+            TL_LANES_END
+        }
+    // ---- emit: each unit files its frame and its ScF-CRC (tl_finish_stream puts the CRC into the frame before it) ----
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int u = 0; u < 2; u++) {
+        const int nwords = (lg_frame[u] + 3) >> 2;
+        const uint32_t *frame = w.u.frame[u];
+        TL_LANES_BEGIN
+        for (int i = lane; i < nwords; i += 64) {
+            if (fo[u].words) fo[u].words[i] = frame[i];
+            else {
+                const uint32_t le = tl_bswap(frame[i]);
+                const int rem = lg_frame[u] - 4 * i;
+                if (rem >= 4) ((uint32_t *)fo[u].bytes)[i] = le;
+                else for (int b = 0; b < rem; b++) fo[u].bytes[4 * i + b] = (uint8_t)(le >> (8 * b));
+            }
+        }
+        if (lane < 4) fo[u].scfcrc[lane] = lane < C->dab_ext ? (uint8_t)w.ncentre[4 * u + lane] : 0;
+        TL_LANES_END
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // One step of the padding recurrence (availbits.c:49-62): does the next frame carry a padding slot?  fp64 as in the reference.
 TL_FN int tl_slot_step(double &lag, double frac)
 {
@@ -2896,9 +3236,18 @@ TL_FN TlPcmView tl_pcm_view(const TlLaunch &A, const TlStreamState *st, int s, i
 {
     const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
     TlPcmView pv;
-    pv.cur = A.pcm + slot * 2304;
-    if (f == 0) { pv.hist = &st->hist[0][0]; pv.hist_stride = TL_HIST; }
-    else { pv.hist = A.pcm + (slot - (size_t)A.nstreams) * 2304 + (1152 - TL_HIST); pv.hist_stride = 1152; }
+    pv.cur[0] = A.pcm + slot * 2304; pv.cur[1] = pv.cur[0] + 1152;
+    pv.hist[0] = f == 0 ? &st->hist[0][0] : A.pcm + (slot - (size_t)A.nstreams) * 2304 + (1152 - TL_HIST);
+    pv.hist[1] = f == 0 ? &st->hist[1][0] : pv.hist[0] + 1152;
+    return pv;
+}
+
+// The same for a PAIR of mono streams sharing a wave: "channel" u is channel 0 of stream s[u]
+TL_FN TlPcmView tl_pcm_view_pair(const TlLaunch &A, int s0, int s1, int f)
+{
+    const TlPcmView a = tl_pcm_view(A, &A.state[s0], s0, f), b = tl_pcm_view(A, &A.state[s1], s1, f);
+    TlPcmView pv;
+    pv.cur[0] = a.cur[0]; pv.hist[0] = a.hist[0]; pv.cur[1] = b.cur[0]; pv.hist[1] = b.hist[0];
     return pv;
 }
 
@@ -2906,15 +3255,15 @@ TL_FN TlPcmView tl_pcm_view(const TlLaunch &A, const TlStreamState *st, int s, i
 // nothing but PCM (the window of a frame: the last 192 samples before it and its first 832), so units are independent of each
 // other -- of other streams AND of other frames of the same stream -- and the kernel runs them in any order on any wave.
 template <int PSY>
-TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch &A, int s, int f, PARGA(double, rec, 4))
-{
+TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch &A, int s, int f, PARGA(double, rec, 4), int s2 = -1)
+{   // s2 >= 0: a PAIR of mono streams of one configuration -- the model runs its two-channel form on channel 0 of s and of s2
     // rec: the model's result per subband, in the registers of lane = subband: [ch] the level that competes with the scalefactor
     // level, [2 + ch] the minimum masking threshold (SMR = max(level, scale_db[min scalefactor index]) - threshold is the encoder's
     // line: psycho_1.c:568-581 with level = spike level; psycho_3.c:163-183,409-432 with level = strongest line of the subband)
     const TlTables *T = A.tables;
     const TlConfig *C = &A.configs[A.stream_cfg[s]];
     const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
-    const TlPcmView pv = tl_pcm_view(A, &A.state[s], s, f);
+    const TlPcmView pv = s2 >= 0 ? tl_pcm_view_pair(A, s, s2, f) : tl_pcm_view(A, &A.state[s], s, f);
     TL_LANES_BEGIN
     L(rec)[0] = 0.0; L(rec)[1] = 0.0; L(rec)[2] = 0.0; L(rec)[3] = 0.0;     // the model writes every subband of the channels it runs
     TL_LANES_END
@@ -2925,10 +3274,10 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
 #endif
     TL_STAMP(sp, 15);                                                 // unit begin (slots 8..14 / 16..22: the channels' stages, 24..30: FHT passes)
     if constexpr (PSY == 1) {
-        if (C->nch == 2) tl_psy1_stereo(w, T, db, C, pv, rec, sp);
+        if (C->nch == 2 || s2 >= 0) tl_psy1_stereo(w, T, db, C, pv, rec, sp);
         else tl_psy1(w, T, db, C, pv, 0, rec, sp ? sp + 8 : nullptr);
     } else {
-        if (C->nch == 2) tl_psy3_stereo(w, T, db, C, pv, rec, sp);
+        if (C->nch == 2 || s2 >= 0) tl_psy3_stereo(w, T, db, C, pv, rec, sp);
         else tl_psy3(w, T, db, C, pv, 0, rec, sp ? sp + 8 : nullptr);
     }
     TL_STAMP(sp, 23);                                                 // unit end
@@ -3023,8 +3372,7 @@ TL_FN void tl_stage_pcm(TlMainLds &w, const TlPcmView &pv, int nch)
             const int i = lane + 64 * it, ch = i >= PER ? 1 : 0, k = i - ch * PER;
             v[it] = 0;
             if (i < PER * nch)
-                v[it] = k < HP ? *(const uint64_t *)(pv.hist + ch * pv.hist_stride + 4 * k)
-                               : *(const uint64_t *)(pv.cur + ch * 1152 + 4 * (k - HP));
+                v[it] = k < HP ? *(const uint64_t *)((ch ? pv.hist[1] : pv.hist[0]) + 4 * k) : *(const uint64_t *)((ch ? pv.cur[1] : pv.cur[0]) + 4 * (k - HP));
         }
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
@@ -3077,16 +3425,44 @@ TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const 
                                 A.taps ? &A.taps[slot] : nullptr, sp);
 }
 
+// The same unit for a PAIR of mono streams s0, s1 of one configuration (TlLaunch::partner): frame f of both by one wave (tl_encode_pair)
+template <int PSY>
+TL_FN void tl_main_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, const TlLaunch &A, int s0, int s1, int f)
+{
+    const TlConfig *C = &A.configs[A.stream_cfg[s0]];
+    const int ss[2] = {s0, s1};
+    tl_stage_pcm(w, tl_pcm_view_pair(A, s0, s1, f), 2);
+    TlFrameOut fo[2];
+    const TlPsyOut *po[2];
+    const uint8_t *xsrc[2];
+    int xl[2], padding[2];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int u = 0; u < 2; u++) {
+        const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)ss[u];
+        fo[u].bytes = f + 1 < A.nframes ? A.out + (slot + (size_t)A.nstreams) * (size_t)A.out_stride : nullptr;
+        fo[u].words = f + 1 < A.nframes ? nullptr : A.newpend + (size_t)ss[u] * TL_MAX_FRAME_WORDS;
+        fo[u].scfcrc = A.scfcrc + slot * 4;
+        po[u] = PSY == 2 ? &A.psy_out[slot] : nullptr;
+        padding[u] = A.padbits ? (int)A.padbits[slot] : 0;
+        int x = A.xpad_len ? A.xpad_len[slot] : 0;                  // the contract of tl_stage_xpad
+        if (x < 2 || x > TL_MAX_XPAD || x > C->dab_length) x = 0;
+        xl[u] = x; xsrc[u] = A.xpad ? A.xpad + slot * TL_MAX_XPAD : nullptr;
+    }
+    tl_encode_pair<PSY>(w, B, C, po, xl, xsrc, fo, enw_s, K, padding);
+}
+
 // Models 1 and 3: one unit = frame f of stream s, psy model first, then the encoder, by the same wave.  The two phases
 // share the wave's LDS block (a union: the model's arrays are dead when the encoder starts) and nothing else but the
 // model's record, 4 values per subband, which waits in registers until the model is done.
 union TlFrameLds { TlPsyLds p; TlMainLds m; };
 template <int PSY>
 TL_FN void tl_frame_unit(TlFrameLds &w, const double *TL_RESTRICT db, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s,
-                         const TlPackTables *TL_RESTRICT K, const TlLaunch &Apsy, const TlLaunch &Amain, int s, int f)
-{
+                         const TlPackTables *TL_RESTRICT K, const TlLaunch &Apsy, const TlLaunch &Amain, int s, int f, int s2 = -1)
+{   // s2 >= 0: frame f of the two mono streams s and s2 (one configuration) as the two "channels" of the wave
     PA(double, rec, 4);
-    tl_psy_unit<PSY>(w.p, db, Apsy, s, f, rec);
+    tl_psy_unit<PSY>(w.p, db, Apsy, s, f, rec, s2);
     TL_SYNC();
     // the model's arrays are dead: its record goes where the encoder expects it (its own SMR array and the one beside it)
     TL_LANES_BEGIN
@@ -3095,7 +3471,25 @@ TL_FN void tl_frame_unit(TlFrameLds &w, const double *TL_RESTRICT db, const TlBl
         w.m.psy_m[0][lane] = L(rec)[2]; w.m.psy_m[1][lane] = L(rec)[3];
     }
     TL_LANES_END
-    tl_main_unit<TL_PSY_EXT>(w.m, B, enw_s, K, Amain, s, f);
+    if (s2 >= 0) tl_main_pair<TL_PSY_EXT>(w.m, B, enw_s, K, Amain, s, s2, f);
+    else tl_main_unit<TL_PSY_EXT>(w.m, B, enw_s, K, Amain, s, f);
+}
+
+// Which stream shares a wave with stream s?  TlLaunch::partner[s]: the other mono stream of s's configuration it is paired with, or -1.
+// The lower-numbered stream of a pair runs the unit for both (returns true, s2 = the partner), the higher one has nothing to do
+// (returns false).  Launches with stage taps or cycle stamps (diagnostics, per frame of one stream) run every stream alone.
+TL_FN bool tl_unit_partner(const TlLaunch &A, int s, int &s2)
+{
+    s2 = -1;
+#ifdef TL_NO_PAIRS
+    return true;                                                      // diagnostic build: every stream alone (what pairing is measured against)
+#endif
+    if (!A.partner || A.taps || A.stamps) return true;
+    const int p = A.partner[s];
+    if (p < 0) return true;
+    if (p < s) return false;
+    s2 = p;
+    return true;
 }
 
 // After the units of a launch: for stream s, hand out the frame that was pending before the launch (slot 0), store every

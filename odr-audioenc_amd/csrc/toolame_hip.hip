@@ -129,7 +129,10 @@ struct TlMainShared { double enw_s[512]; char bytes[sizeof(TlBlockShared) - offs
 static_assert(offsetof(TlBlockShared, dbtable) == 0 && offsetof(TlBlockShared, scalefactor) == sizeof(double) * 1002, "dbtable leads TlBlockShared");
 #define TL_MAIN_WAVES (4 * TL_MAIN_WPE)       // one workgroup per CU: one copy of the tables
 static_assert((sizeof(TlMainShared) + TL_MAIN_WAVES * sizeof(TlMainLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "the encode workgroup fits a CU");
-template <int PSY>     // 0: model 0 (no psy kernel); 2: models 2 and 4 (after tl_psy2_kernel)
+// PAIRS: the list contains mono streams that share waves in pairs (TlLaunch::partner, tl_encode_pair).  A second instantiation, so
+// that the kernel of lists without pairs -- every all-stereo batch -- carries none of the pair code (with it inline the register
+// allocation of the stereo path moved from 152 to 168 VGPRs and psy-1 stereo lost 1.1 %).
+template <int PSY, bool PAIRS>     // 0: model 0 (no psy kernel); 2: models 2 and 4 (after tl_psy2_kernel)
 __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_waves_per_eu(TL_MAIN_WPE, TL_MAIN_WPE))) tl_main_kernel(TlLaunch A)
 {
     __shared__ TlMainShared sh;
@@ -149,6 +152,12 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
     const int grp = (int)blockIdx.x & 7;
     for (int hop = 0, k, f, first = ((int)blockIdx.x >> 3) * TL_MAIN_WAVES + wave; tl_take_unit(A.work + TL_HEAD_STRIDE, A.nlist, A.nframes, grp, hop, k, f, first); first = -1) {
         const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
+        if constexpr (PAIRS) {
+            int s2;
+            if (!tl_unit_partner(A, s, s2)) continue;                // the partner's wave encodes this mono stream's frame with its own
+            s2 = __builtin_amdgcn_readfirstlane(s2);
+            if (s2 >= 0) { tl_main_pair<PSY>(lds[wave], B, sh.enw_s, &sh.pack, A, s, s2, f); continue; }
+        }
         tl_main_unit<PSY>(lds[wave], B, sh.enw_s, &sh.pack, A, s, f);
     }
 }
@@ -159,7 +168,7 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
 // two phases' blocks; both table sets (dB sums 7.8 KB, encoder 12.1 KB) once per workgroup.  The PCM the model read is still
 // in L2 when the encoder stages it.
 static_assert((sizeof(double) * 1258 + sizeof(TlMainShared) + TL_MAIN_WAVES * sizeof(TlFrameLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "the workgroup fits a CU");
-template <int PSY>
+template <int PSY, bool PAIRS>
 __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_waves_per_eu(TL_MAIN_WPE, TL_MAIN_WPE))) tl_frame_kernel(TlLaunch A)
 {
     __shared__ __attribute__((aligned(16))) double dbt[1258];     // dB-sum table + glibc's log table (TlTables::dblog)
@@ -187,7 +196,11 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
         asm volatile("" : "+s"(a1));
         asm volatile("" : "+s"(a2));
         const TlLaunch A1 = *a1, A2 = *a2;
-        tl_frame_unit<PSY>(lds[wave], dbt, B, sh.enw_s, &sh.pack, A1, A2, s, f);
+        if constexpr (PAIRS) {
+            int s2;
+            if (!tl_unit_partner(A, s, s2)) continue;                // the partner's wave encodes this mono stream's frame with its own
+            tl_frame_unit<PSY>(lds[wave], dbt, B, sh.enw_s, &sh.pack, A1, A2, s, f, __builtin_amdgcn_readfirstlane(s2));
+        } else tl_frame_unit<PSY>(lds[wave], dbt, B, sh.enw_s, &sh.pack, A1, A2, s, f);
 #endif
     }
 }
@@ -362,6 +375,7 @@ struct tlb_batch {
     TlPsy2Tables *d_psy2_tables = nullptr;     // 2 * TL_PSY2_SLOTS tables (psy 2 per sample rate, then psy 4 per sample rate; tl_psy2_slot), only when a stream uses psy 2 / 4
     TlPsy2State *d_psy2_state = nullptr;       // two copies per stream; a launch reads copy psy2_flip and writes the other (tl_psy2_chain)
     int psy2_flip = 0;
+    int32_t *d_partner = nullptr;              // [nstreams] mono streams of one configuration and model share waves in pairs (tl_encode_pair); -1: alone
     int32_t *d_chain = nullptr;                // psy-2 kernel: (stream, channel) chains of the launch, first channels first
     int n_chain = 0;
     uint8_t *d_edi_version = nullptr;            // EDI: ODRv string and per-stream frame sizes (allocated on first use)
@@ -384,6 +398,7 @@ struct tlb_batch {
     uint32_t *d_newpend = nullptr;               // split path: the launch's last frame of every stream
     double *d_newlag = nullptr;                  // split path, 44.1 / 22.05 kHz: slot recurrence state after the launch
     bool pads[4] = {false, false, false, false}; // some stream of the psy model's list has frames of two lengths
+    bool list_pairs[4] = {false, false, false, false};   // the model's list contains mono streams paired in one wave (kernel variant <.., true>)
     int32_t *d_work = nullptr;                   // unit counters of the persistent kernels
     int num_cu = 256;
 };
@@ -448,6 +463,7 @@ void tlb_destroy(tlb_batch *b)
     if (b->d_psy2_tables) (void)hipFree(b->d_psy2_tables);
     if (b->d_psy2_state) (void)hipFree(b->d_psy2_state);
     if (b->d_chain) (void)hipFree(b->d_chain);
+    if (b->d_partner) (void)hipFree(b->d_partner);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->ev_mid) (void)hipEventDestroy(b->ev_mid);
@@ -469,6 +485,21 @@ static int batch_build_lists(tlb_batch *b)
         if (ids.empty()) continue;
         if (!b->d_list[p]) HIPCHK(hipMalloc(&b->d_list[p], sizeof(int32_t) * (size_t)nstreams));       // room for every stream: a list only changes its content later
         HIPCHK(hipMemcpy(b->d_list[p], ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice));
+    }
+    {   // mono streams of the same configuration (hence the same model and kernel) in pairs: consecutive ones of the stream order
+        std::vector<int32_t> partner((size_t)nstreams, -1);
+        std::vector<int> open(b->h_configs.size(), -1);              // per configuration: a mono stream still waiting for a partner
+        for (int s2 = 0; s2 < nstreams; s2++) {
+            const int ci = b->h_stream_cfg[s2];
+            if (b->h_configs[(size_t)ci].nch != 1) continue;
+            if (open[(size_t)ci] < 0) open[(size_t)ci] = s2;
+            else { partner[(size_t)s2] = open[(size_t)ci]; partner[(size_t)open[(size_t)ci]] = s2; open[(size_t)ci] = -1; }
+        }
+        for (int p = 0; p < 4; p++) b->list_pairs[p] = false;
+        for (int s2 = 0; s2 < nstreams; s2++)
+            if (partner[(size_t)s2] >= 0) { const int m = b->h_configs[b->h_stream_cfg[s2]].psy; b->list_pairs[m == 4 ? 2 : m] = true; }
+        if (!b->d_partner) HIPCHK(hipMalloc(&b->d_partner, sizeof(int32_t) * (size_t)nstreams));
+        HIPCHK(hipMemcpy(b->d_partner, partner.data(), sizeof(int32_t) * (size_t)nstreams, hipMemcpyHostToDevice));
     }
     if (b->n_list[2]) {
         if (!b->d_psy2_tables) {
@@ -683,7 +714,7 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
     A.tables = b->d_tables; A.configs = b->d_configs; A.stream_cfg = b->d_stream_cfg; A.state = b->d_state;
     A.pcm = d_pcm; A.xpad = d_xpad_len ? d_xpad : nullptr; A.xpad_len = d_xpad ? d_xpad_len : nullptr;
     A.out = d_out; A.out_len = d_out_len; A.taps = d_taps; A.stamps = d_stamps;
-    A.psy2_tables = b->d_psy2_tables; A.psy2_state = b->d_psy2_state;
+    A.psy2_tables = b->d_psy2_tables; A.psy2_state = b->d_psy2_state; A.partner = b->d_partner;
     A.nstreams = b->nstreams; A.nframes = nframes; A.out_stride = b->out_stride;
     {   // TlPsyOut records of this launch (psy-2 kernel -> encode kernel, models 2 and 4 only) and ScF-CRC bytes, grow-only.  NOTE: one buffer per batch -- launches of
         // one batch are ordered on one stream (they share the stream state anyway)
@@ -713,8 +744,11 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         if (p == 1 || p == 3) {                                      // psy model and encoder in one kernel
             long mb1 = (units + TL_MAIN_WAVES - 1) / TL_MAIN_WAVES;
             if (mb1 > b->num_cu) mb1 = b->num_cu;
-            if (p == 1) hipLaunchKernelGGL(tl_frame_kernel<1>, dim3((unsigned)mb1), dim3(64 * TL_MAIN_WAVES), 0, st, A);
-            else hipLaunchKernelGGL(tl_frame_kernel<3>, dim3((unsigned)mb1), dim3(64 * TL_MAIN_WAVES), 0, st, A);
+            const bool pr = b->list_pairs[p] && !d_taps && !d_stamps;
+            if (p == 1 && pr) hipLaunchKernelGGL((tl_frame_kernel<1, true>), dim3((unsigned)mb1), dim3(64 * TL_MAIN_WAVES), 0, st, A);
+            else if (p == 1) hipLaunchKernelGGL((tl_frame_kernel<1, false>), dim3((unsigned)mb1), dim3(64 * TL_MAIN_WAVES), 0, st, A);
+            else if (pr) hipLaunchKernelGGL((tl_frame_kernel<3, true>), dim3((unsigned)mb1), dim3(64 * TL_MAIN_WAVES), 0, st, A);
+            else hipLaunchKernelGGL((tl_frame_kernel<3, false>), dim3((unsigned)mb1), dim3(64 * TL_MAIN_WAVES), 0, st, A);
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(tl_finish_kernel, dim3((unsigned)((b->n_list[p] + 3) / 4)), dim3(256), 0, st, A);
             HIPCHK(hipGetLastError());
@@ -725,8 +759,11 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         if (p == 2 && b->n_list[p] == b->nstreams) { HIPCHK(hipEventRecord(b->ev_mid, st)); b->have_mid = true; }      // models 2/4 only in the batch: psy | encode split of the time
         long mb = (units + TL_MAIN_WAVES - 1) / TL_MAIN_WAVES;
         if (mb > b->num_cu) mb = b->num_cu;
-        if (p == 0) hipLaunchKernelGGL(tl_main_kernel<0>, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);       // model 0: no psy kernel
-        else hipLaunchKernelGGL(tl_main_kernel<2>, dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);
+        const bool pr = b->list_pairs[p] && !d_taps && !d_stamps;
+        if (p == 0 && pr) hipLaunchKernelGGL((tl_main_kernel<0, true>), dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);       // model 0: no psy kernel
+        else if (p == 0) hipLaunchKernelGGL((tl_main_kernel<0, false>), dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);
+        else if (pr) hipLaunchKernelGGL((tl_main_kernel<2, true>), dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);
+        else hipLaunchKernelGGL((tl_main_kernel<2, false>), dim3((unsigned)mb), dim3(64 * TL_MAIN_WAVES), 0, st, A);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(tl_finish_kernel, dim3((unsigned)((b->n_list[p] + 3) / 4)), dim3(256), 0, st, A);
         HIPCHK(hipGetLastError());

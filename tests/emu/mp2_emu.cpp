@@ -114,8 +114,29 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
         }
     }
     if (pads) for (int s = 0; s < A.nstreams; s++) tl_slots_stream(A, s);
+    // mono streams of one configuration share waves in pairs, as the device path pairs them (toolame_hip.hip batch_build_lists)
+    std::vector<int32_t> partner((size_t)A.nstreams, -1);
+    {
+        std::vector<int> open(e->configs.size(), -1);
+        for (int s = 0; s < A.nstreams; s++) {
+            const int ci = e->stream_cfg[s];
+            if (e->configs[ci].nch != 1) continue;
+            if (open[ci] < 0) open[ci] = s;
+            else { partner[s] = open[ci]; partner[open[ci]] = s; open[ci] = -1; }
+        }
+        if (!getenv("EMU_NO_PAIRS")) A.partner = partner.data();
+    }
     for (int s = 0; s < A.nstreams; s++)
         for (int f = nframes - 1; f >= 0; f--) {
+            int s2;
+            if (!tl_unit_partner(A, s, s2)) continue;
+            if (s2 >= 0) {
+                if (model(s) == 0) tl_main_pair<0>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, s2, f);
+                else if (model(s) == 2 || model(s) == 4) tl_main_pair<2>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, s2, f);
+                else if (model(s) == 1) tl_frame_unit<1>(wf, e->tables.dblog, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, A, s, f, s2);
+                else tl_frame_unit<3>(wf, e->tables.dblog, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, A, s, f, s2);
+                continue;
+            }
             if (model(s) == 0) tl_main_unit<0>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, f);
             else if (model(s) == 2 || model(s) == 4) tl_main_unit<2>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, f);
             else if (model(s) == 1) tl_frame_unit<1>(wf, e->tables.dblog, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, A, s, f);

@@ -273,3 +273,53 @@ def test_padding_slot_rates_vs_oracle(fs, mode, kbps):
             whole = b.frame_bytes[0]
             assert len(ref) > nf * whole or (1152 * kbps * 125) % fs == 0      # some frames carry the extra slot
             b.close()
+
+
+def test_mono_streams_share_waves_in_pairs():
+    """Two mono streams of one configuration are encoded by ONE wave (csrc/mp2_wave.h tl_encode_pair: lane = 2*sb + unit; the batch
+    pairs consecutive mono streams of a configuration).  A batch with pairs of every psy model -- padded rates, LSF, X-PAD of different
+    lengths per stream and frame, an odd stream left alone, a stereo stream in between -- against the oracle stream by stream, frames
+    fed in ragged chunks; and the same batch with pairing switched off gives the same bytes."""
+    import os
+    cfgs = ([dict(samplerate=48000, mode="m", kbps=64, psy=1)] * 5 + [dict(samplerate=48000, mode="j", kbps=128, psy=1)] +
+            [dict(samplerate=24000, mode="m", kbps=32, psy=3)] * 3 + [dict(samplerate=44100, mode="m", kbps=64, psy=1)] * 2 +
+            [dict(samplerate=48000, mode="m", kbps=96, psy=0)] * 2 + [dict(samplerate=32000, mode="m", kbps=64, psy=4)] * 3 +
+            [dict(samplerate=48000, mode="m", kbps=128, psy=2)] * 2 + [dict(samplerate=22050, mode="m", kbps=32, psy=3)] * 2 +
+            [dict(samplerate=48000, mode="m", kbps=80, psy=3, pad_len=24)] * 4 + [dict(samplerate=16000, mode="m", kbps=8, psy=1)] * 2)
+    ns, nf = len(cfgs), 9
+    rng = np.random.default_rng(31)
+    pcm = np.stack([gen_pcm(3300 + s, (0, 7, 4, 5, 0, 2)[s % 6], 0, nf) for s in range(ns)], axis=1)
+    xp = rng.integers(0, 256, size=(nf, ns, E.TL_MAX_XPAD), dtype=np.uint8)
+    xl = np.zeros((nf, ns), dtype=np.int32)
+    for s, c in enumerate(cfgs):
+        if c.get("pad_len"):
+            xl[:, s] = rng.choice([0, 2, 6, 24, 17], size=nf)
+    want = []
+    for s, c in enumerate(cfgs):
+        e = O.OracleEncoder(**c)
+        pl = c.get("pad_len", 0)
+        chunks = []
+        for f in range(nf):
+            n = int(xl[f, s])
+            # reference layout: pad_len + 1 bytes, the n bytes that are sent sit at [pad_len - n, pad_len), the last byte = the valid length
+            chunks.append(e.encode(pcm[f, s], bytes(pl - n) + bytes(xp[f, s, :n]) + bytes([n]), n) if pl else e.encode(pcm[f, s]))
+        want.append(b"".join(chunks) + e.finish())
+        e.close()
+    def run():
+        b = E.EmuBatch(cfgs)
+        got, pos = [b""] * ns, 0
+        for n in (1, 3, 2, nf - 6):
+            g, _ = b.encode(pcm[pos:pos + n], xp[pos:pos + n], xl[pos:pos + n])
+            got = [a + c for a, c in zip(got, g)]
+            pos += n
+        tail = b.flush()
+        b.close()
+        return [a + c for a, c in zip(got, tail)]
+    got = run()
+    for s in range(ns):
+        assert got[s] == want[s], (s, cfgs[s])
+    os.environ["EMU_NO_PAIRS"] = "1"
+    try:
+        assert run() == got
+    finally:
+        del os.environ["EMU_NO_PAIRS"]
