@@ -314,6 +314,11 @@ float tlb_last_kernel_ms(tlb_batch *b);
  * recent launch of a batch whose streams all use these models; non-zero return for any other batch (models 1 and 3 run
  * model and encoder in one kernel, model 0 has no model kernel). */
 int tlb_last_stage_ms(tlb_batch *b, float *psy_ms, float *encode_ms);
+/* Deployment self-check (no GPU needed): the device computes the reference's transcendental calls with its own restatement of glibc
+ * 2.35's FMA-path routines (csrc/tl_libm.h), so bit-equality with a reference built on THIS host holds if this host's libm is that
+ * libm.  Compares the two on `nsamples` arguments per function (<= 0: 100 000); returns the number of differing results -- 0 means
+ * the reference compiled here and this library agree on log10 / pow / log / exp / sincos / atan2 bit for bit. */
+long tlb_selfcheck_libm(long nsamples);
 /* LDS bytes per wavefront: the largest per-wave block among the kernels (each holds 12 waves per CU). */
 int tlb_lds_bytes_per_stream(void);
 const char *tlb_version(void);

@@ -3273,7 +3273,8 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
     long long *sp = A.stamps ? A.stamps + slot * 32 : nullptr;
 #endif
     TL_STAMP(sp, 15);                                                 // unit begin (slots 8..14 / 16..22: the channels' stages, 24..30: FHT passes)
-    if constexpr (PSY == 1) {
+    if constexpr (TL_EXP_LEVEL >= 9) { }                              // diagnostic build: no model at all (tools/class_budget.sh: what the encoder phase alone issues)
+    else if constexpr (PSY == 1) {
         if (C->nch == 2 || s2 >= 0) tl_psy1_stereo(w, T, db, C, pv, rec, sp);
         else tl_psy1(w, T, db, C, pv, 0, rec, sp ? sp + 8 : nullptr);
     } else {

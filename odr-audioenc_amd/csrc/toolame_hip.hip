@@ -1235,6 +1235,30 @@ int tlb_reference_send_schedule(const tlb_stream_config *cfg, int ncalls, int32_
     return held;
 }
 
+// Is this host's libm the one csrc/tl_libm.h restates?  The reference's bytes depend on what the HOST libm returns for log10 / pow /
+// log / exp / sincos / atan2 (glibc 2.35 on an FMA-capable x86-64: the ifunc variants __log_fma, __exp_fma, __pow_fma, __atan2_fma);
+// the device computes those routines itself, so on a host with another libm the reference build and this library may part on
+// degenerate signals.  Compares the restated routines (their host forms, the very text the kernels compile) with libm on
+// `nsamples` arguments per function drawn from the encoder's ranges; returns how many results differ (0: this is that libm).
+long tlb_selfcheck_libm(long nsamples)
+{
+    if (nsamples <= 0) nsamples = 100000;
+    uint64_t st = 0x9e3779b97f4a7c15ull;
+    auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st * 0x2545f4914f6cdd1dull; };
+    auto unit = [&]() { return (double)(next() >> 11) * 0x1p-53; };
+    auto same = [](double a, double b) { uint64_t x, y; memcpy(&x, &a, 8); memcpy(&y, &b, 8); return (a != a && b != b) || x == y; };
+    long bad = 0;
+    for (long i = 0; i < nsamples; i++) {
+        const double e = ldexp(1.0 + unit(), (int)(next() % 90) - 70);            // energies 1e-21 .. 1e6
+        const double y = -30.0 + 60.0 * unit(), ph = -8.0 + 16.0 * unit(), ax = ldexp(unit() - 0.5, (int)(next() % 40) - 20), ay = ldexp(unit() - 0.5, (int)(next() % 40) - 20);
+        bad += !same(tlm_log10(e), log10(e)) + !same(tlm_log(e), log(e)) + !same(tlm_exp(y), exp(y)) + !same(tlm_pow10(y), pow(10.0, y)) + !same(tlm_atan2(ay, ax), atan2(ay, ax));
+        double s1, c1, s2, c2;
+        tlm_sincos(ph, &s1, &c1); sincos(ph, &s2, &c2);
+        bad += !same(s1, s2) + !same(c1, c2);
+    }
+    return bad;
+}
+
 float tlb_last_kernel_ms(tlb_batch *b)
 {
     if (!b || !b->timed) return -1.0f;

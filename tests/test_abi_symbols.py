@@ -148,3 +148,15 @@ def test_reference_send_schedule_against_the_reference_s_own_burst_lengths():
     got = np.zeros(2000, dtype=np.int32)
     rest = lib.tlb_reference_send_schedule(C.byref(Cfg(48000, b"s", 128, 1, 0)), 2000, got.ctypes.data)
     assert rest > 0 and set(got[got > 0]) <= {9, 10} and 200 <= int((got > 0).sum()) <= 210 and int(got.sum()) * 384 + rest <= 2000 * 384
+
+
+def test_selfcheck_libm_says_this_host_is_the_pinned_one():
+    """tlb_selfcheck_libm (host-only): the restated glibc routines against THIS host's libm; the build container and the GPU box run
+    Ubuntu glibc 2.35 on FMA-capable CPUs, where the answer is 0 differing results (a deployment elsewhere calls it to find out)."""
+    import odr_audioenc_amd as M
+    if not M.LIB_PATH.exists():
+        M.build()
+    lib = C.CDLL(str(M.LIB_PATH))
+    lib.tlb_selfcheck_libm.restype = C.c_long
+    lib.tlb_selfcheck_libm.argtypes = [C.c_long]
+    assert lib.tlb_selfcheck_libm(200000) == 0

@@ -781,6 +781,46 @@ def test_tick_pipeline_with_xpad(M):
     assert got == refs
 
 
+def test_mono_streams_share_waves_in_pairs_on_the_device(M):
+    """Two mono streams of one configuration are encoded by ONE wave (csrc/mp2_wave.h tl_encode_pair; kernel variants <.., true>): pairs of
+    every psy model, padded rates, LSF, X-PAD lengths that differ per stream and frame, odd streams left alone, stereo streams in
+    between -- device == host emulation == oracle stream by stream, frames in ragged launches."""
+    cfgs = ([dict(samplerate=48000, mode="m", kbps=64, psy=1)] * 5 + [dict(samplerate=48000, mode="j", kbps=128, psy=1)] +
+            [dict(samplerate=24000, mode="m", kbps=32, psy=3)] * 3 + [dict(samplerate=44100, mode="m", kbps=64, psy=1)] * 2 +
+            [dict(samplerate=48000, mode="m", kbps=96, psy=0)] * 2 + [dict(samplerate=32000, mode="m", kbps=64, psy=4)] * 3 +
+            [dict(samplerate=48000, mode="m", kbps=128, psy=2)] * 2 + [dict(samplerate=22050, mode="m", kbps=32, psy=3)] * 2 +
+            [dict(samplerate=48000, mode="m", kbps=80, psy=3, pad_len=24)] * 4 + [dict(samplerate=16000, mode="m", kbps=8, psy=1)] * 2 +
+            [dict(samplerate=48000, mode="s", kbps=192, psy=0)] + [dict(samplerate=48000, mode="m", kbps=192, psy=1)] * 36)
+    ns, nf = len(cfgs), 9
+    rng = np.random.default_rng(31)
+    pcm = np.stack([gen_pcm(3300 + s, (0, 7, 4, 5, 0, 2)[s % 6], 0, nf) for s in range(ns)], axis=1)
+    xp = rng.integers(0, 256, size=(nf, ns, E.TL_MAX_XPAD), dtype=np.uint8)
+    xl = np.zeros((nf, ns), dtype=np.int32)
+    for s, c in enumerate(cfgs):
+        if c.get("pad_len"):
+            xl[:, s] = rng.choice([0, 2, 6, 24, 17], size=nf)
+    def run(b):
+        got, pos = [b""] * ns, 0
+        for n in (1, 3, 2, nf - 6):
+            g, _ = b.encode(pcm[pos:pos + n], xp[pos:pos + n], xl[pos:pos + n])
+            got = [a + c for a, c in zip(got, g)]
+            pos += n
+        tail = b.flush()
+        b.close()
+        return [a + c for a, c in zip(got, tail)]
+    dev = run(M.Batch([M.StreamConfig(samplerate=c["samplerate"], mode=c["mode"], bitrate=c["kbps"], psy_model=c["psy"], pad_len=c.get("pad_len", 0)) for c in cfgs]))
+    emu = run(E.EmuBatch(cfgs))
+    assert dev == emu
+    for s in list(range(27)) + [ns - 1]:
+        c = cfgs[s]
+        e = O.OracleEncoder(**c)
+        pl = c.get("pad_len", 0)
+        want = b"".join(e.encode(pcm[f, s], bytes(pl - int(xl[f, s])) + bytes(xp[f, s, :int(xl[f, s])]) + bytes([int(xl[f, s])]), int(xl[f, s])) if pl
+                        else e.encode(pcm[f, s]) for f in range(nf)) + e.finish()
+        e.close()
+        assert dev[s] == want, (s, c)
+
+
 # ---- life cycle of ONE stream inside a live batch (tlb_stream_reset / _finish / _reconfigure; toolame.c:120-166 per stream) ----
 _LIFE_POOL = [(48000, "s", 128, 1), (48000, "j", 192, 3), (48000, "m", 64, 1), (24000, "m", 64, 3), (48000, "s", 160, 2), (48000, "j", 128, 4),
               (48000, "d", 96, 0), (44100, "s", 128, 1), (22050, "m", 32, 3), (32000, "m", 64, 4), (48000, "s", 384, 1), (16000, "m", 24, 2)]

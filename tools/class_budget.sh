@@ -1,6 +1,6 @@
 #!/bin/bash
 # Where do the VALU instructions of tl_frame_kernel<1> go, by STAGE and by CLASS?  Diagnostic builds that drop the last n stages of the
-# psy-1 model phase (TL_EXP_LEVEL = 1..8) or of the encoder phase (TL_ENC_LEVEL = 1..5), one SQ_INSTS_VALU_* counter pass each; the
+# psy-1 model phase (TL_EXP_LEVEL = 1..7, 9 = no model) or of the encoder phase (TL_ENC_LEVEL = 1..5), one SQ_INSTS_VALU_* counter pass each; the
 # difference of successive builds is a stage's DYNAMIC instruction count per class, per stereo frame of BASELINE configs[1].
 #   tools/class_budget.sh build     (here: 13 libraries under build/)
 #   tools/class_budget.sh run       (GPU box) -> gpurun_out/class_budget.txt   (copy to profiles/class_budget_rNN.txt)
@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -mllvm -disable-machine-licm -fno-strict-aliasing -fPIC -Wno-unused-function -Wno-unused-variable -Wno-pass-failed -shared"
 if [ "${1:-run}" = build ]; then
   mkdir -p build; i=0
-  for v in EXP:1 EXP:2 EXP:3 EXP:4 EXP:5 EXP:6 EXP:7 EXP:8 ENC:1 ENC:2 ENC:3 ENC:4 ENC:5; do
+  for v in EXP:1 EXP:2 EXP:3 EXP:4 EXP:5 EXP:6 EXP:7 EXP:9 ENC:1 ENC:2 ENC:3 ENC:4 ENC:5; do
     k=${v%%:*}; n=${v##*:}; i=$((i+1))
     (cd odr-audioenc_amd/csrc && /opt/rocm/bin/hipcc $FLAGS -o $R/build/lib_cb_${k}$n.so toolame_hip.hip -x hip mp2_host.cpp -DTL_${k}_LEVEL=$n ${EXTRA:-}) &
     if [ $((i % 5)) = 0 ]; then wait; fi
@@ -19,7 +19,7 @@ if [ "${1:-run}" = build ]; then
 fi
 export TMPDIR=/tmp; mkdir -p gpurun_out
 G="SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64"
-for v in BASE EXP1 EXP2 EXP3 EXP4 EXP5 EXP6 EXP7 EXP8 ENC1 ENC2 ENC3 ENC4 ENC5; do
+for v in BASE EXP1 EXP2 EXP3 EXP4 EXP5 EXP6 EXP7 EXP9 ENC1 ENC2 ENC3 ENC4 ENC5; do
   if [ $v = BASE ]; then unset TLB_LIB_PATH; else export TLB_LIB_PATH=$R/build/lib_cb_$v.so; fi
   rm -rf gpurun_out/cb_$v
   timeout 120 rocprofv3 --pmc $G --kernel-trace --output-format csv -d $R/gpurun_out/cb_$v -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also > gpurun_out/cb_$v.log 2>&1
@@ -47,11 +47,14 @@ row("whole frame", base)
 sub = lambda a, b: {k: a[k] - b[k] for k in cols}
 names = ["thresholds", "decimation", "dB-sum chains + weights + centres", "noise compaction", "tone walk + levels", "tone candidates", "power spectrum + spike levels", "spectrum (window + FHT)"]
 prev = base
-for n in range(1, 9):
+for n in range(1, 8):
     cur = load(f"EXP{n}")
     if not cur: print("EXP", n, "no data"); continue
     row("psy: " + names[n - 1], sub(prev, cur)); prev = cur
-row("(psy phase removed: what is left)", prev)
+enc = load("EXP9")          # no model at all: the encoder phase (the build without the spectrum alone is not meaningful: the stages after it then chew on garbage)
+if enc:
+    row("psy: " + names[7], sub(prev, enc))
+    row("(encoder phase: the model removed)", enc)
 names = ["CRC-16 + ScF-CRC + X-PAD", "quantiser + sample packing", "header / bit_alloc / scf fields", "bit allocation", "scalefactors + SMR + pattern"]
 prev = base
 for n in range(1, 6):
