@@ -164,6 +164,37 @@ def test_unit_lists_odd_shapes(M, nstreams):
                 assert data == chunks[s - 64] + tail[s - 64], (psy, nstreams, s)
 
 
+@pytest.mark.parametrize("nstreams,launches", [(1, (40, 3, 57)), (2, (33, 1)), (5, (7, 1, 12)), (3100, (5, 4))])
+def test_psy2_runs_of_frames_odd_shapes(M, nstreams, launches):
+    """Models 2 and 4: the psy-2 kernel's units are RUNS of frames of one channel (whole chains for the complete rounds of waves, the
+    last round's chains cut into runs that seed themselves from the PCM before them; csrc/mp2_host.cpp tl_psy2_plan).  Shapes that
+    make the planner cut differently -- one stream with many frames (2 chains on 3072 waves), a handful, mono and stereo mixed, more
+    chains than waves -- over several launches (the state passes through the stream's record between launches): bytes against the oracle."""
+    nframes = sum(launches)
+    for psy in (2, 4):
+        cfgs = [M.StreamConfig(mode=("s", "m", "j")[s % 3] if nstreams <= 5 else "s", bitrate=128 if s % 3 != 1 or nstreams > 5 else 64, psy_model=psy) for s in range(nstreams)]
+        base = [gen_pcm(8100 + s, (0, 7, 4, 5, 2)[s % 5], 0, nframes) for s in range(min(nstreams, 64))]
+        pcm = np.stack([base[s % 64] for s in range(nstreams)], axis=1)
+        b = M.Batch(cfgs)
+        chunks, pos = [b""] * nstreams, 0
+        for n in launches:
+            got, _ = b.encode(pcm[pos:pos + n])
+            chunks = [a + c for a, c in zip(chunks, got)]
+            pos += n
+        tail = b.flush()
+        b.close()
+        refs = {}
+        for s in (range(nstreams) if nstreams <= 5 else list(range(0, nstreams, 97)) + [nstreams - 1]):
+            c = cfgs[s]
+            key = (s % 64, c.mode, c.bitrate)
+            if key not in refs:
+                refs[key] = O.oracle_stream(pcm[:, s], mode=c.mode, kbps=c.bitrate, psy=psy)[0]
+            assert chunks[s] + tail[s] == refs[key], (psy, nstreams, s)
+        if nstreams > 64:
+            for s in range(64, nstreams):
+                assert chunks[s] + tail[s] == chunks[s - 64] + tail[s - 64], (psy, s)
+
+
 @pytest.mark.parametrize("nframes", [5, 6, 9, 13])
 def test_host_path_chunking(M, nframes):
     """tlb_encode_host cuts a big call (>= 8 MB of PCM) into up to four chunks of whole frames whose copies and kernels overlap;
