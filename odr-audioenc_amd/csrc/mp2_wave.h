@@ -907,42 +907,61 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
     for (int c8 = 4; c8 < 8; c8++) tl_cand_chunk<12, false>(w, c8, ncand);    // 255..510: run 12
     }
     TL_STAMP(sp, 2);
-    // (2) wave-uniform walk: which candidates become tones.  State of the reference's list walk that
-    //     matters: the last confirmed tone (`last`), its erasure reach R = last + run(last), and the
-    //     chain bookkeeping (last_but_one relinking, psycho_1.c:313-316).
+    // (2) which candidates become tones.  The reference walks its list once, in line order; what a candidate's fate depends on is the
+    //     walk's state -- the last confirmed tone (`last`), its run and whether its left neighbour was erased -- and that state only
+    //     changes at a CONFIRMATION.  So instead of one scalar iteration per candidate (sixty dependent scalar instructions each: the
+    //     walk was 9 % of a frame's cycles with every lane idle) the candidates sit in lanes and every round evaluates all of them
+    //     against the current state at once: the first one that passes is the next confirmed tone -- every candidate before it was
+    //     rejected under the same state, exactly as the sequential walk rejects them -- the state moves, the lanes after it go on.
+    //     One round per confirmed tone (+ 1) instead of one iteration per candidate.  The bookkeeping of the reference's list is
+    //     kept: the erasure reach R = last + run(last), the last_but_one relinking (psycho_1.c:313-316).
     int nconf = 0;
     bool any_erased;                                                  // a confirmed tone erased its predecessor: the chain order is not 0..nconf-1
     {
-        int last = -1, run_last = 0, R = -1, last_var = 0;
+        int last = -1, run_last = 0, last_var = 0;
         any_erased = false;
-        for (int kb = 0; kb < (TL_EXP_LEVEL >= 5 ? 0 : ncand); kb += 64) {                        // 64 records per LDS round trip, then lane reads
-        PV(int, crec);
-        TL_LANES_BEGIN L(crec) = (int)w.cinfo[kb + lane < TL_CAND_MAX ? kb + lane : 0]; TL_LANES_END
-        for (int k = kb; k < ncand && k < kb + 64; k++) {
-            const uint32_t info = (uint32_t)TL_READLANE_I32(crec, k - kb);
-            const int c = (int)(info & 511u);
-            if (last >= 0 && c - last <= run_last) continue;          // unlinked by the help loop, psycho_1.c:309-312
-            const int run = (int)(info >> 21);
-            const uint32_t lfail = (info >> 10) & 0x7ffu;
-            bool ok = true;
-            if (last < 0) { if (lfail) ok = false; }
+        for (int kb = 0; kb < (TL_EXP_LEVEL >= 5 ? 0 : ncand); kb += 64) {          // 64 candidates per pass (there are rarely more)
+        PV(int, cc); PV(int, crun); PV(int, clf); PV(double, cpx); PV(bool, act);
+        TL_LANES_BEGIN
+        const bool in = kb + lane < ncand;
+        const uint32_t info = w.cinfo[in ? kb + lane : 0];
+        L(cc) = (int)(info & 511u); L(crun) = (int)(info >> 21); L(clf) = (int)((info >> 10) & 0x7ffu);
+        L(cpx) = px[L(cc)];
+        L(act) = in;
+        TL_LANES_END
+        for (;;) {
+            PV(bool, okv); PV(bool, needx);
+            TL_LANES_BEGIN
+            const int c = L(cc), run = L(crun);
+            const uint32_t lfail = (uint32_t)L(clf);
+            bool ok, nx = false;
+            if (last < 0) ok = lfail == 0;
             else {
                 // neighbours c-j <= R were erased to DBMIN by `last` (they pass), except `last` itself,
                 // which carries its summed level; neighbours above R (or below last-run_last) are original
                 // bit j-2 set for j in [2, run] with c-j > R (j <= c-R-1) or c-j < last-run_last (j >= c-last+run_last+1)
-                const int hi_j = run < c - R - 1 ? run : c - R - 1;
-                const int lo_j = c - last + run_last + 1 > 2 ? c - last + run_last + 1 : 2;
+                const int d = c - last;
+                const int hi_j = run < d - run_last - 1 ? run : d - run_last - 1;
+                const int lo_j = d + run_last + 1 > 2 ? d + run_last + 1 : 2;
                 uint32_t orig = hi_j >= 2 ? (1u << (hi_j - 1)) - 1u : 0u;
                 if (lo_j <= run) orig |= ((1u << (run - 1)) - 1u) & ~((1u << (lo_j - 2)) - 1u);
-                if (lfail & orig) ok = false;
-                if (ok && c - last >= 2 && c - last <= run) {
-                    const double xl = tl_add_db(db, px[last], tl_add_db(db, last_var ? TL_DBMIN : px[last - 1], px[last + 1]));
-                    if (px[c] - 7 < xl) ok = false;
-                }
+                ok = d > run_last && !(lfail & orig);                // d <= run_last: unlinked by the help loop, psycho_1.c:309-312
+                nx = ok && d >= 2 && d <= run;                       // then `last` itself is among its neighbours, with its summed level
             }
-            if (!ok) continue;                                        // rejected: only unlinked, psycho_1.c:330-338
+            L(okv) = ok && L(act); L(needx) = nx && L(act);
+            TL_LANES_END
+            if (TL_BALLOT(needx) != 0ull) {                           // rare: a candidate within its run of the last tone
+                TL_LANES_BEGIN
+                const double xl = tl_add_db(db, px[last], tl_add_db(db, last_var ? TL_DBMIN : px[last - 1], px[last + 1]));
+                if (L(needx) && L(cpx) - 7 < xl) L(okv) = false;
+                TL_LANES_END
+            }
+            const uint64_t m = TL_BALLOT(okv);
+            if (m == 0ull) break;                                     // everything left of this pass is rejected (only unlinked, psycho_1.c:330-338)
+            const int wl = __builtin_ctzll(m);
+            const int c = TL_READLANE_I32(cc, wl), run = TL_READLANE_I32(crun, wl);
             // confirmed.  Its left neighbour c-1 was erased iff it is exactly the end of `last`'s reach.
-            const int var = (last >= 0 && run_last >= 1 && c - 1 == R) ? 1 : 0;
+            const int var = (last >= 0 && run_last >= 1 && c - 1 == last + run_last) ? 1 : 0;
             if (nconf < TL_TONE_MAX) {
                 const int i = nconf++;
                 w.conf_c[i] = (int16_t)(c | (var << 12));
@@ -956,7 +975,8 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
                     } else w.conf_nxt[i - 1] = (int16_t)i;
                 }
             }
-            last = c; run_last = run; R = c + run; last_var = var;
+            last = c; run_last = run; last_var = var;
+            TL_LANES_BEGIN L(act) = L(act) && lane > wl; TL_LANES_END
         }
         }
         TL_SYNC();
@@ -1596,25 +1616,35 @@ TL_FN int tl_psy3_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double
     for (int c8 = 2; c8 < 4; c8++) tl_cand_chunk<6, true>(w, c8, ncand);     // 127..254: run 6
     for (int c8 = 4; c8 < 8; c8++) tl_cand_chunk<12, true>(w, c8, ncand);    // 255..510: run 12
     TL_STAMP(sp, 2);
-    // (2) wave-uniform walk.  A confirmed tone k erases lines k-sr..k+sr (itself included) to DBMIN
-    //     (psycho_3.c:243-244); a later maximum inside that reach R has power DBMIN and always fails,
-    //     one above R sees erased left neighbours (always >= 7 dB down) and original ones beyond.
+    // (2) which candidates become tones: the candidates in lanes, one round per confirmed tone (see tl_psy1_front).  A confirmed tone k
+    //     erases lines k-sr..k+sr (itself included) to DBMIN (psycho_3.c:243-244); a later maximum inside that reach R has power
+    //     DBMIN and always fails, one above R sees erased left neighbours (always >= 7 dB down) and original ones beyond.
     int nconf = 0;
     {
         int R = -1;
-        for (int kb = 0; kb < ncand; kb += 64) {                        // 64 records per LDS round trip, then lane reads
-        PV(int, crec);
-        TL_LANES_BEGIN L(crec) = (int)w.cinfo[kb + lane < TL_CAND_MAX ? kb + lane : 0]; TL_LANES_END
-        for (int q = kb; q < ncand && q < kb + 64; q++) {
-            const uint32_t info = (uint32_t)TL_READLANE_I32(crec, q - kb);
-            const int k = (int)(info & 511u);
-            if (k <= R) continue;
-            const int sr = (int)(info >> 21);
+        for (int kb = 0; kb < ncand; kb += 64) {
+        PV(int, ck); PV(int, csr); PV(int, clf); PV(bool, act);
+        TL_LANES_BEGIN
+        const bool in = kb + lane < ncand;
+        const uint32_t info = w.cinfo[in ? kb + lane : 0];
+        L(ck) = (int)(info & 511u); L(csr) = (int)(info >> 21); L(clf) = (int)((info >> 10) & 0x7ffu);
+        L(act) = in;
+        TL_LANES_END
+        for (;;) {
+            PV(bool, okv);
+            TL_LANES_BEGIN
+            const int k = L(ck), sr = L(csr);
             const int hi_j = sr < k - R - 1 ? sr : k - R - 1;         // bit j-2 set for j in [2, sr] with k-j > R
             const uint32_t orig = hi_j >= 2 ? (1u << (hi_j - 1)) - 1u : 0u;
-            if (((info >> 10) & 0x7ffu) & orig) continue;
+            L(okv) = L(act) && k > R && !((uint32_t)L(clf) & orig);
+            TL_LANES_END
+            const uint64_t m = TL_BALLOT(okv);
+            if (m == 0ull) break;
+            const int wl = __builtin_ctzll(m);
+            const int k = TL_READLANE_I32(ck, wl), sr = TL_READLANE_I32(csr, wl);
             if (nconf < TL_TONE_MAX) w.conf_c[nconf++] = (int16_t)(k | ((k - 1 <= R) ? (1 << 12) : 0));
             R = k + sr;
+            TL_LANES_BEGIN L(act) = L(act) && lane > wl; TL_LANES_END
         }
         }
         TL_SYNC();
