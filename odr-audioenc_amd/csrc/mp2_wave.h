@@ -53,6 +53,13 @@ TL_FN void tlh_row16_max_f64(double (&d)[64], const double (&v)[64])
 #define TL_ROW16_MAX_F64(dst, src) tlh_row16_max_f64(dst, src)      /* valid in lane 15 of each row of 16 (all lanes here) */
 TL_FN void tlh_incl_xscan_u32(uint32_t (&d)[64], const uint32_t (&v)[64]) { uint32_t x = 0; for (int i = 0; i < 64; i++) { x ^= v[i]; d[i] = x; } }
 #define TL_WAVE_INCL_XSCAN_U32(dst, src) tlh_incl_xscan_u32(dst, src)
+// minimum / sum over the lanes of the caller's parity (the cells of one of two mono streams sharing the wave), delivered to each of them
+TL_FN void tlh_par_min_u64(uint64_t (&d)[64], const uint64_t (&v)[64])
+{ for (int p = 0; p < 2; p++) { uint64_t m = v[p]; for (int i = p; i < 64; i += 2) if (v[i] < m) m = v[i]; for (int i = p; i < 64; i += 2) d[i] = m; } }
+TL_FN void tlh_par_sum_i32(int (&d)[64], const int (&v)[64])
+{ for (int p = 0; p < 2; p++) { int m = 0; for (int i = p; i < 64; i += 2) m += v[i]; for (int i = p; i < 64; i += 2) d[i] = m; } }
+#define TL_PAR_MIN_U64(dst, src) tlh_par_min_u64(dst, src)
+#define TL_PAR_SUM_I32(dst, src) tlh_par_sum_i32(dst, src)
 #define TL_BALLOT(name) tlh_ballot(name)
 #define TL_SWAP1_U64(dst, src) do { for (int l_ = 0; l_ < 64; l_++) dst[l_] = src[l_ ^ 1]; } while (0)
 #define TL_WAVE_ARGMIN_U64(name) tlh_argmin_u64(name)
@@ -174,6 +181,37 @@ TL_FN uint32_t tld_incl_xscan_u32(uint32_t x)
     return (uint32_t)v;
 }
 #define TL_WAVE_INCL_XSCAN_U32(dst, src) dst = tld_incl_xscan_u32(src)
+// Butterflies over the 32 lanes of one parity, the result in every lane (no readlane, no scalar round trip): row_ror 2 / 4 / 8 inside
+// the rows of 16, then the two gfx950 row / half swaps (v_permlane16_swap, v_permlane32_swap: with both operands the same register
+// the two results hold each lane's value and its counterpart's in the other row / half).
+TL_FN uint32_t tld_par_min_u32(uint32_t v)
+{
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false); v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false); v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false); v = t < v ? t : v;
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); v = r[0] < r[1] ? r[0] : r[1];
+    const auto q = __builtin_amdgcn_permlane32_swap(v, v, false, false); v = q[0] < q[1] ? q[0] : q[1];
+    return v;
+}
+TL_FN uint64_t tld_par_min_u64(uint64_t v)
+{
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    const uint32_t mhi = tld_par_min_u32(hi);
+    const uint32_t mlo = tld_par_min_u32(hi == mhi ? lo : 0xffffffffu);
+    return ((uint64_t)mhi << 32) | mlo;
+}
+TL_FN int tld_par_sum_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); v = (int)(r[0] + r[1]);
+    const auto q = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); v = (int)(q[0] + q[1]);
+    return v;
+}
+#define TL_PAR_MIN_U64(dst, src) dst = tld_par_min_u64(src)
+#define TL_PAR_SUM_I32(dst, src) dst = tld_par_sum_i32(src)
 #define TL_BALLOT(name) ((uint64_t)__ballot(name))
 #define TL_SWAP1_U64(dst, src) dst = tl_d2u(tld_swap1_f64(tl_u2d(src)))
 #define TL_WAVE_ARGMIN_U64(name) tld_argmin_u64(name)
@@ -2324,22 +2362,21 @@ TL_FN void tl_filterbank(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const
         }
 }
 
-// a_bit_allocation_new (encode_new.c:1078-1187) for the cells of the wave -- all of them (unit < 0: the one or two channels of a stream,
-// joint pairs included) or, for two mono streams sharing the wave, the cells of ONE of them (unit = 0 / 1: the lanes of that parity;
-// nch = 1, jsbound = sblimit).  adb: the frame's bits after header extension and PAD (toolame.c:292-301).  Returns the bits left over.
-TL_FN int tl_allocate(const TlBlockShared *TL_RESTRICT B, int adb, int nch, int sblimit, int jsbound, int unit, PARG(int, a_ln), PARG(int, a_nbal),
+// a_bit_allocation_new (encode_new.c:1078-1187) for the cells of the wave: the one or two channels of a stream, joint pairs included.
+// adb: the frame's bits after header extension and PAD (toolame.c:292-301).  Returns the bits left over.
+TL_FN int tl_allocate(const TlBlockShared *TL_RESTRICT B, int adb, int nch, int sblimit, int jsbound, PARG(int, a_ln), PARG(int, a_nbal),
                       PARG(int, a_sfs), PARG(int, a_sfs_o), PARG(double, a_smr), PARG(int, ba))
 {
     PV(uint64_t, ukey); PV(uint64_t, ukey2); PV(int, nbits); PV(int, cost); PV(int, cost2);
     PV(int, jpair);                                             // lane belongs to a joint-coded pair (steps with its partner)
     TL_LANES_BEGIN
     const int c = lane & 1, sb = lane >> 1;
-    const bool live = (unit < 0 ? c < nch : c == unit) && sb < sblimit;
+    const bool live = c < nch && sb < sblimit;
     const int maxa = (1 << L(a_nbal)) - 1;
     L(ukey) = live ? tl_mnr_key(B->snr_line[L(a_ln)][0] - L(a_smr)) : ~0ull;
     L(ukey2) = (live && 1 < maxa) ? tl_mnr_key(B->snr_line[L(a_ln)][1] - L(a_smr)) : ~0ull;
     L(ba) = 0;
-    L(nbits) = (unit < 0 ? (sb < sblimit && c < (sb < jsbound ? nch : 1)) : live) ? L(a_nbal) : 0;
+    L(nbits) = (sb < sblimit && c < (sb < jsbound ? nch : 1)) ? L(a_nbal) : 0;
     // first step of a cell: samples + scfsi + scalefactors (both channels above jsbound), :1139-1147
     L(cost) = live ? B->bits12_line[L(a_ln)][1] + 2 + L(a_sfs) + ((nch == 2 && sb >= jsbound) ? 2 + L(a_sfs_o) : 0) : 0;
     L(cost2) = live ? B->bits12_line[L(a_ln)][2] - B->bits12_line[L(a_ln)][1] : 0;
@@ -2374,8 +2411,12 @@ TL_FN int tl_allocate(const TlBlockShared *TL_RESTRICT B, int adb, int nch, int 
             // prices of the round's events that come no later than its own (equal keys count as earlier, which can
             // only shorten the admitted prefix); the prefix sums grow along the greedy order, so the cells whose
             // sum still fits are exactly a prefix of it.  The event-by-event loop below deals with the rest.
-            PV(int, pre); PV(int, kh); PV(int, kl);
-            TL_LANES_BEGIN L(pre) = L(cost); L(kh) = (int)(uint32_t)(L(keff) >> 32); L(kl) = (int)(uint32_t)L(keff); TL_LANES_END
+            // The test is ONE compare, key of the event < the cell's own key + 1 (the key of a cell with an event is never ~0; a cell
+            // without one compares against 0 and its sum is not read).  A cell's own event passes it as well -- that is the cell's own
+            // price, so the sum starts at 0; the two cells of a joint pair share key and price (same allocation line, the two
+            // scalefactor selections added up either way round), and the pair's one event is the own event of both.
+            PV(int, pre); PV(int, kh); PV(int, kl); PV(uint64_t, kb);
+            TL_LANES_BEGIN L(pre) = 0; L(kh) = (int)(uint32_t)(L(keff) >> 32); L(kl) = (int)(uint32_t)L(keff); L(kb) = L(keff) + 1; TL_LANES_END
             uint64_t pm = bm;
             while (pm) {
                 const int j = __builtin_ctzll(pm);
@@ -2384,8 +2425,7 @@ TL_FN int tl_allocate(const TlBlockShared *TL_RESTRICT B, int adb, int nch, int 
                 if (cj == 0) continue;                          // the non-paying lane of a pair
                 const uint64_t kj = ((uint64_t)(uint32_t)TL_READLANE_I32(kh, j) << 32) | (uint32_t)TL_READLANE_I32(kl, j);
                 TL_LANES_BEGIN
-                const int own = L(jpair) ? (lane & ~1) : lane;
-                if (j != own && kj <= L(keff)) L(pre) += cj;
+                if (kj < L(kb)) L(pre) += cj;
                 TL_LANES_END
             }
             TL_LANES_BEGIN
@@ -2431,6 +2471,106 @@ TL_FN int tl_allocate(const TlBlockShared *TL_RESTRICT B, int adb, int nch, int 
         TL_LANES_END
     }
     return ad - spent;
+}
+
+// The same allocation for the two mono streams sharing a wave, BOTH AT ONCE: lane = 2*sb + u owns cell sb of unit u.  Every minimum and
+// sum is taken over the 32 lanes of one parity and lands in all of them (TL_PAR_*), so a unit's greedy loop advances on its own state
+// (`room` = bits it may still spend, `ph` = still in the rounds) held in its own lanes, and what a unit's lanes compute is what
+// tl_allocate(unit = u) computes for it; the wave leaves a loop when neither unit has anything left in it.
+TL_FN void tl_allocate_pair(const TlBlockShared *TL_RESTRICT B, int adb0, int adb1, int sblimit, PARG(int, a_ln), PARG(int, a_nbal),
+                            PARG(int, a_sfs), PARG(double, a_smr), PARG(int, ba))
+{
+    PV(uint64_t, ukey); PV(uint64_t, ukey2); PV(int, nbits); PV(int, cost); PV(int, cost2); PV(int, room); PV(int, ph); PV(int, bbal);
+    TL_LANES_BEGIN
+    const bool live = (lane >> 1) < sblimit;
+    const int maxa = (1 << L(a_nbal)) - 1;
+    L(ukey) = live ? tl_mnr_key(B->snr_line[L(a_ln)][0] - L(a_smr)) : ~0ull;
+    L(ukey2) = (live && 1 < maxa) ? tl_mnr_key(B->snr_line[L(a_ln)][1] - L(a_smr)) : ~0ull;
+    L(ba) = 0;
+    L(nbits) = live ? L(a_nbal) : 0;
+    L(cost) = live ? B->bits12_line[L(a_ln)][1] + 2 + L(a_sfs) : 0;
+    L(cost2) = live ? B->bits12_line[L(a_ln)][2] - B->bits12_line[L(a_ln)][1] : 0;
+    TL_LANES_END
+    TL_PAR_SUM_I32(bbal, nbits);
+    TL_LANES_BEGIN
+    L(room) = ((lane & 1) ? adb1 : adb0) - (L(bbal) + 16 + 32);
+    L(ph) = 0;
+    TL_LANES_END
+    for (; TL_ENC_LEVEL < 4;) {                                 // rounds, as in tl_allocate
+        PV(uint64_t, k2); PV(uint64_t, M); PV(bool, inb); PV(int, bcost); PV(int, csum); PV(bool, part);
+        TL_LANES_BEGIN L(k2) = L(ph) == 0 ? L(ukey2) : ~0ull; TL_LANES_END
+        TL_PAR_MIN_U64(M, k2);
+        TL_LANES_BEGIN
+        L(inb) = L(ph) == 0 && L(ukey) < L(M);
+        L(bcost) = L(inb) ? L(cost) | 0x10000 : 0;              // price, and one count per event (a round's prices stay far below 2^16)
+        TL_LANES_END
+        if (TL_BALLOT(inb) == 0ull) break;
+        TL_PAR_SUM_I32(csum, bcost);
+        TL_LANES_BEGIN L(part) = L(ph) == 0 && (L(csum) & 0xffff) > L(room); TL_LANES_END
+        if (TL_BALLOT(part) != 0ull) {                          // a unit's round does not fit as a whole: its events up to the first refusal
+            PV(int, pre); PV(int, kh); PV(int, kl); PV(bool, pin);
+            TL_LANES_BEGIN
+            L(pre) = 0; L(kh) = (int)(uint32_t)(L(ukey) >> 32); L(kl) = (int)(uint32_t)L(ukey); L(pin) = L(inb) && L(part);
+            TL_LANES_END
+            // Unit 0's events first, then unit 1's.  A cell counts event j when j's key is no later than its own and j belongs to its
+            // unit: ONE compare against its own key + 1 (no key of a live cell is ~0) or against 0 for the other unit's events; the
+            // cell's own event passes the test too, which is its own price (so the sum starts at 0; only cells with an event are read).
+            PV(uint64_t, kb);
+            for (int u = 0; u < 2; u++) {
+                TL_LANES_BEGIN L(kb) = (lane & 1) == u ? L(ukey) + 1 : 0ull; TL_LANES_END
+                uint64_t pm = TL_BALLOT(pin) & (0x5555555555555555ull << u);
+                while (pm) {
+                    const int j = __builtin_ctzll(pm);
+                    pm &= pm - 1;
+                    const int cj = TL_READLANE_I32(bcost, j) & 0xffff;
+                    const uint64_t kj = ((uint64_t)(uint32_t)TL_READLANE_I32(kh, j) << 32) | (uint32_t)TL_READLANE_I32(kl, j);
+                    TL_LANES_BEGIN
+                    if (kj < L(kb)) L(pre) += cj;
+                    TL_LANES_END
+                }
+            }
+            TL_LANES_BEGIN
+            if (L(part)) { L(inb) = L(inb) && L(pre) <= L(room); L(bcost) = L(inb) ? L(bcost) : 0; }
+            TL_LANES_END
+            TL_PAR_SUM_I32(csum, bcost);
+        }
+        TL_LANES_BEGIN
+        if (L(ph) == 0) {
+            L(room) -= L(csum) & 0xffff;
+            if ((L(csum) >> 16) == 0 || L(part)) L(ph) = 1;      // nothing admitted, or the partial round was the unit's last
+        }
+        if (L(inb)) {
+            const int nba = L(ba) + 1;
+            L(ba) = nba;
+            L(ukey) = L(ukey2);
+            L(cost) = L(cost2);
+            L(ukey2) = (nba + 1 >= (1 << L(a_nbal)) - 1) ? ~0ull : tl_mnr_key(B->snr_line[L(a_ln)][(nba + 1) & 15] - L(a_smr));
+            L(cost2) = B->bits12_line[L(a_ln)][(nba + 2) & 15] - B->bits12_line[L(a_ln)][(nba + 1) & 15];
+        }
+        TL_LANES_END
+    }
+    for (; TL_ENC_LEVEL < 4;) {                                 // one event per unit at a time
+        PV(uint64_t, key); PV(uint64_t, mk); PV(bool, win);
+        TL_LANES_BEGIN L(key) = L(cost) <= L(room) ? L(ukey) : ~0ull; TL_LANES_END
+        TL_PAR_MIN_U64(mk, key);
+        TL_LANES_BEGIN L(win) = L(key) == L(mk) && L(key) != ~0ull; TL_LANES_END
+        const uint64_t m = TL_BALLOT(win);
+        if (m == 0ull) break;
+        const uint64_t m0 = m & 0x5555555555555555ull, m1 = m & 0xaaaaaaaaaaaaaaaaull;
+        const int wl0 = m0 ? __builtin_ctzll(m0) : -1, wl1 = m1 ? __builtin_ctzll(m1) : -1;     // ascending sb (maxmnr_new, encode_new.c:1061-1077)
+        const int c0 = wl0 >= 0 ? TL_READLANE_I32(cost, wl0) : 0, c1 = wl1 >= 0 ? TL_READLANE_I32(cost, wl1) : 0;
+        TL_LANES_BEGIN
+        L(room) -= (lane & 1) ? c1 : c0;
+        if (lane == wl0 || lane == wl1) {
+            const int nba = L(ba) + 1;
+            L(ba) = nba;
+            L(ukey) = L(ukey2);
+            L(cost) = L(cost2);
+            L(ukey2) = (nba + 1 >= (1 << L(a_nbal)) - 1) ? ~0ull : tl_mnr_key(B->snr_line[L(a_ln)][(nba + 1) & 15] - L(a_smr));
+            L(cost2) = B->bits12_line[L(a_ln)][(nba + 2) & 15] - B->bits12_line[L(a_ln)][(nba + 1) & 15];
+        }
+        TL_LANES_END
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2655,7 +2795,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
         // them).  If together they still fit, they are all taken in one round; the one-at-a-time loop takes over
         // when a round no longer fits (or is empty), so the refusal rule above is applied event by event.
         PV(int, ba);
-        adb_left = tl_allocate(B, adb, nch, sblimit, jsbound, -1, a_ln, a_nbal, a_sfs, a_sfs_o, a_smr, ba);
+        adb_left = tl_allocate(B, adb, nch, sblimit, jsbound, a_ln, a_nbal, a_sfs, a_sfs_o, a_smr, ba);
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
         w.balloc[c][sb] = (uint8_t)((c < nch && sb < sblimit) ? L(ba) : 0);
@@ -2924,7 +3064,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
 // TWO mono streams of ONE configuration in one wave.  A lone mono frame leaves every second lane idle from the filterbank to the
 // packing (lane = 2*sb + ch, ch = 0 only) and costs as many instructions as a stereo frame; here lane = 2*sb + u owns subband sb of
 // UNIT u, the u-th of the two streams (same frame index f of the launch).  Filterbank, scalefactors, transmission pattern, quantiser
-// and packing run for both units at once; the bit allocation and the CRC folds go unit by unit.  What a unit produces is what
+// and packing run for both units at once, the bit allocation too (tl_allocate_pair); the CRC-16 folds use one half-wave per unit.  What a unit produces is what
 // tl_encode_frame produces for it alone: the operations per cell are the same text, and every wave-level sum, scan and minimum is
 // taken over the unit's own lanes (a scan over both units carries unit 0 in the low and unit 1 in the high half of a word:
 // sums stay below 2^16, XORs never carry).  toolame.c:267-554 twice, the `nch` loop of toolame.c:308-312 turned into lanes.
@@ -2990,31 +3130,31 @@ TL_FN void tl_encode_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, cons
     } else w.scfsi[c][sb] = 0;
     w.balloc[c][sb] = 0;
     TL_LANES_END
-    // ---- bit allocation (encode_new.c:733-886, :1061-1187): one unit after the other, each over its own lanes ----
+    // ---- bit allocation (encode_new.c:733-886, :1061-1187): both units at once, each over its own lanes ----
     int lg_frame[2];
     {
-        PV(int, a_ln); PV(int, a_nbal); PV(int, a_sfs); PV(int, a_sfs_o); PV(double, a_smr); PV(int, ba);
+        PV(int, a_ln); PV(int, a_nbal); PV(int, a_sfs); PV(double, a_smr); PV(int, ba);
         TL_LANES_BEGIN
         const int c = lane & 1, sb = lane >> 1;
         const bool live = sb < sblimit;
         L(a_ln) = live ? C->line[sb] : 0;
         L(a_nbal) = live ? C->nbal[sb] : 0;
         L(a_sfs) = live ? 6 * tl_sfs_count(w.scfsi[c][sb]) : 0;
-        L(a_sfs_o) = 0;
         L(a_smr) = live ? w.smr[c][sb] : 0.0;
         TL_LANES_END
+        int adb[2];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
         for (int u = 0; u < 2; u++) {
             lg_frame[u] = C->frame_bytes + padding[u];                                       // availbits.c:64
-            const int adb = lg_frame[u] * 8 - (C->dab_ext * 8 + (xpad_len[u] ? xpad_len[u] : 2) * 8);    // toolame.c:292-301
-            (void)tl_allocate(B, adb, 1, sblimit, sblimit, u, a_ln, a_nbal, a_sfs, a_sfs_o, a_smr, ba);
-            TL_LANES_BEGIN
-            const int c = lane & 1, sb = lane >> 1;
-            if (c == u) w.balloc[c][sb] = (uint8_t)(sb < sblimit ? L(ba) : 0);
-            TL_LANES_END
+            adb[u] = lg_frame[u] * 8 - (C->dab_ext * 8 + (xpad_len[u] ? xpad_len[u] : 2) * 8);    // toolame.c:292-301
         }
+        tl_allocate_pair(B, adb[0], adb[1], sblimit, a_ln, a_nbal, a_sfs, a_smr, ba);
+        TL_LANES_BEGIN
+        const int c = lane & 1, sb = lane >> 1;
+        w.balloc[c][sb] = (uint8_t)(sb < sblimit ? L(ba) : 0);
+        TL_LANES_END
     }
     // ---- header, bit_alloc, scfsi, scalefactors, quantised samples -> the two LDS frames ----
     TL_LANES_BEGIN

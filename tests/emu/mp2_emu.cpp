@@ -32,14 +32,22 @@ void *emu_create(int nstreams, const long *fs, const char *mode, const int *kbps
 {
     Emu *e = new Emu;
     tl_build_tables(&e->tables);
-    e->configs.resize(nstreams);
     e->stream_cfg.resize(nstreams);
     e->state.resize(nstreams);
     memset(e->state.data(), 0, sizeof(TlStreamState) * nstreams);
     for (int s = 0; s < nstreams; s++) {
-        int rc = tl_build_config(&e->configs[s], fs[s], mode[s], kbps[s], psy[s], pad[s]);
-        if (rc) { if (err) *err = rc; delete e; return nullptr; }
-        e->stream_cfg[s] = s;
+        // one TlConfig per DISTINCT configuration, as the device batch keeps them (toolame_hip.hip tlb_create): mono streams pair up by config index
+        int ci = -1;
+        for (int t = 0; t < s && ci < 0; t++)
+            if (fs[t] == fs[s] && mode[t] == mode[s] && kbps[t] == kbps[s] && psy[t] == psy[s] && pad[t] == pad[s]) ci = e->stream_cfg[t];
+        if (ci < 0) {
+            TlConfig c;
+            int rc = tl_build_config(&c, fs[s], mode[s], kbps[s], psy[s], pad[s]);
+            if (rc) { if (err) *err = rc; delete e; return nullptr; }
+            ci = (int)e->configs.size();
+            e->configs.push_back(c);
+        }
+        e->stream_cfg[s] = ci;
     }
     bool any2 = false;
     for (auto &c : e->configs) any2 |= c.psy == 2 || c.psy == 4;
@@ -57,8 +65,8 @@ void *emu_create(int nstreams, const long *fs, const char *mode, const int *kbps
     return e;
 }
 void emu_destroy(void *h) { delete (Emu *)h; }
-int emu_frame_bytes(void *h, int s) { return ((Emu *)h)->configs[s].frame_bytes; }
-int emu_max_frame_bytes(void *h, int s) { const TlConfig &c = ((Emu *)h)->configs[s]; return c.frame_bytes + (c.pad_frac != 0 ? 1 : 0); }
+int emu_frame_bytes(void *h, int s) { Emu *e = (Emu *)h; return e->configs[e->stream_cfg[s]].frame_bytes; }
+int emu_max_frame_bytes(void *h, int s) { Emu *e = (Emu *)h; const TlConfig &c = e->configs[e->stream_cfg[s]]; return c.frame_bytes + (c.pad_frac != 0 ? 1 : 0); }
 
 int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad, const int32_t *xpad_len, uint8_t *out,
                    int out_stride, TlTaps *taps, int32_t *out_len);
