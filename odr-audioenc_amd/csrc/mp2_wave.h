@@ -72,6 +72,7 @@ TL_FN void tlh_par_sum_i32(int (&d)[64], const int (&v)[64])
 #define TL_RESTRICT
 #define TL_SELECT(c, a, b) ((c) ? (a) : (b))
 #define TL_LAUNDER(p) ((void)0)
+#define TL_KARG const TlLaunch *
 #define TL_KEEP(x) ((void)0)
 #define TL_PIN(x) ((void)0)
 #else
@@ -224,6 +225,12 @@ TL_FN int tld_par_sum_i32(int v)
 #define TL_RESTRICT __restrict__
 #define TL_SELECT(c, a, b) (__builtin_unpredictable(c) ? (a) : (b))      /* a v_cndmask, never a divergent branch */
 #define TL_KEEP(x) asm volatile("" : : "v"(x))             /* x is computed (a load: issued) here, not sunk into a later branch */
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) struct TlLaunch *TlKArg;     /* the kernel-argument segment: scalar loads */
+#else
+typedef const struct TlLaunch *TlKArg;                                        /* host pass of the same translation unit */
+#endif
+#define TL_KARG TlKArg
 #define TL_LAUNDER(p) asm volatile("" : "+s"(p))       /* keeps loads through p inside the frame loop (no hoisting into long-lived VGPRs) */
 #define TL_PIN(x) asm volatile("" : "+v"(x))           /* a constant made once, here, in a vector register: machine LICM is off (csrc/Makefile), so a literal used inside a hot loop
                                                           is otherwise re-made by a v_mov on every trip */
@@ -3630,11 +3637,16 @@ TL_FN void tl_main_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const 
 union TlFrameLds { TlPsyLds p; TlMainLds m; };
 template <int PSY>
 TL_FN void tl_frame_unit(TlFrameLds &w, const double *TL_RESTRICT db, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s,
-                         const TlPackTables *TL_RESTRICT K, const TlLaunch &Apsy, const TlLaunch &Amain, int s, int f, int s2 = -1)
+                         const TlPackTables *TL_RESTRICT K, const TlLaunch &Apsy, TL_KARG Amain_p, int s, int f, int s2 = -1)
 {   // s2 >= 0: frame f of the two mono streams s and s2 (one configuration) as the two "channels" of the wave
     PA(double, rec, 4);
     tl_psy_unit<PSY>(w.p, db, Apsy, s, f, rec, s2);
     TL_SYNC();
+    // The encoder phase reads the launch record afresh (device: scalar loads from the kernel-argument segment, issued HERE) and
+    // re-derives its pointers from laundered copies of s / f / s2: nothing of the model phase's scalar state stays live across the
+    // phases, and nothing of the encoder's is loaded before the model has run.
+    TL_LAUNDER(Amain_p); TL_LAUNDER(s); TL_LAUNDER(f); TL_LAUNDER(s2);
+    const TlLaunch Amain = *Amain_p;
     // the model's arrays are dead: its record goes where the encoder expects it (its own SMR array and the one beside it)
     TL_LANES_BEGIN
     if (lane < 32) {

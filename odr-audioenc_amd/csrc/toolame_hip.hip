@@ -115,12 +115,15 @@ __global__ void __launch_bounds__(64 * TL_PSY2_WAVES) __attribute__((amdgpu_wave
     for (int i = (int)threadIdx.x; i < 440; i += 64 * TL_PSY2_WAVES) sct[i] = tlm_sincostab[i];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int wave_v = (int)(threadIdx.x >> 6);
+    asm volatile("" : "+v"(wave_v));
+    TlPsy2Lds &wl = lds[wave_v];
     const int nunits = A.p2_nwhole + (A.nchain - A.p2_nwhole) * A.p2_k, nwaves = (int)gridDim.x * TL_PSY2_WAVES;
     for (int u = (int)blockIdx.x * TL_PSY2_WAVES + wave; u < nunits; u = nwaves + tl_next_unit(&A.work[0])) {
         int c, f0, f1;
         if (!tl_psy2_unit(A, u, c, f0, f1)) continue;
         const int e = __builtin_amdgcn_readfirstlane(A.chain_list[c]);
-        tl_psy2_chain(lds[wave], A, e & 0x3fffffff, e >> 30, f0, f1, sct);
+        tl_psy2_chain(wl, A, e & 0x3fffffff, e >> 30, f0, f1, sct);
     }
 }
 
@@ -150,15 +153,18 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
     const TlBlockShared *B = (const TlBlockShared *)((const char *)&sh.bytes[0] - offsetof(TlBlockShared, scalefactor));
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int grp = (int)blockIdx.x & 7;
+    int wave_v = (int)(threadIdx.x >> 6);
+    asm volatile("" : "+v"(wave_v));
+    TlMainLds &wl = lds[wave_v];
     for (int hop = 0, k, f, first = ((int)blockIdx.x >> 3) * TL_MAIN_WAVES + wave; tl_take_unit(A.work + TL_HEAD_STRIDE, A.nlist, A.nframes, grp, hop, k, f, first); first = -1) {
         const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
         if constexpr (PAIRS) {
             int s2;
             if (!tl_unit_partner(A, s, s2)) continue;                // the partner's wave encodes this mono stream's frame with its own
             s2 = __builtin_amdgcn_readfirstlane(s2);
-            if (s2 >= 0) { tl_main_pair<PSY>(lds[wave], B, sh.enw_s, &sh.pack, A, s, s2, f); continue; }
+            if (s2 >= 0) { tl_main_pair<PSY>(wl, B, sh.enw_s, &sh.pack, A, s, s2, f); continue; }
         }
-        tl_main_unit<PSY>(lds[wave], B, sh.enw_s, &sh.pack, A, s, f);
+        tl_main_unit<PSY>(wl, B, sh.enw_s, &sh.pack, A, s, f);
     }
 }
 
@@ -186,21 +192,22 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
     const TlBlockShared *B = (const TlBlockShared *)((const char *)&sh.bytes[0] - offsetof(TlBlockShared, scalefactor));
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int grp = (int)blockIdx.x & 7;
+    int wave_v = (int)(threadIdx.x >> 6);
+    asm volatile("" : "+v"(wave_v));
+    TlFrameLds &wl = lds[wave_v];
     for (int hop = 0, k, f, first = ((int)blockIdx.x >> 3) * TL_MAIN_WAVES + wave; tl_take_unit(A.work + TL_HEAD_STRIDE, A.nlist, A.nframes, grp, hop, k, f, first); first = -1) {
         const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
 #if defined(__HIP_DEVICE_COMPILE__)
         // each phase reads the launch record afresh from the kernel-argument segment (scalar loads), so that nothing but s
         // and f lives in registers across the two
-        typedef const __attribute__((address_space(4))) TlLaunch *KArg;
-        KArg a1 = (KArg)__builtin_amdgcn_kernarg_segment_ptr(), a2 = a1;
+        TlKArg a1 = (TlKArg)__builtin_amdgcn_kernarg_segment_ptr(), a2 = a1;
         asm volatile("" : "+s"(a1));
-        asm volatile("" : "+s"(a2));
-        const TlLaunch A1 = *a1, A2 = *a2;
+        const TlLaunch A1 = *a1;
         if constexpr (PAIRS) {
             int s2;
             if (!tl_unit_partner(A, s, s2)) continue;                // the partner's wave encodes this mono stream's frame with its own
-            tl_frame_unit<PSY>(lds[wave], dbt, B, sh.enw_s, &sh.pack, A1, A2, s, f, __builtin_amdgcn_readfirstlane(s2));
-        } else tl_frame_unit<PSY>(lds[wave], dbt, B, sh.enw_s, &sh.pack, A1, A2, s, f);
+            tl_frame_unit<PSY>(wl, dbt, B, sh.enw_s, &sh.pack, A1, a2, s, f, __builtin_amdgcn_readfirstlane(s2));
+        } else tl_frame_unit<PSY>(wl, dbt, B, sh.enw_s, &sh.pack, A1, a2, s, f);
 #endif
     }
 }

@@ -141,14 +141,14 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
             if (s2 >= 0) {
                 if (model(s) == 0) tl_main_pair<0>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, s2, f);
                 else if (model(s) == 2 || model(s) == 4) tl_main_pair<2>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, s2, f);
-                else if (model(s) == 1) tl_frame_unit<1>(wf, e->tables.dblog, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, A, s, f, s2);
-                else tl_frame_unit<3>(wf, e->tables.dblog, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, A, s, f, s2);
+                else if (model(s) == 1) tl_frame_unit<1>(wf, e->tables.dblog, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, &A, s, f, s2);
+                else tl_frame_unit<3>(wf, e->tables.dblog, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, &A, s, f, s2);
                 continue;
             }
             if (model(s) == 0) tl_main_unit<0>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, f);
             else if (model(s) == 2 || model(s) == 4) tl_main_unit<2>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, f);
-            else if (model(s) == 1) tl_frame_unit<1>(wf, e->tables.dblog, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, A, s, f);
-            else tl_frame_unit<3>(wf, e->tables.dblog, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, A, s, f);
+            else if (model(s) == 1) tl_frame_unit<1>(wf, e->tables.dblog, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, &A, s, f);
+            else tl_frame_unit<3>(wf, e->tables.dblog, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, &A, s, f);
         }
     for (int s = 0; s < A.nstreams; s++) tl_finish_stream(A, s);
     return 0;
