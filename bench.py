@@ -120,7 +120,8 @@ def workload_label(streams, psy, mode, frames_per_step, world, mixed=False):
         k = 2 if world == 1 else 3
     tag = f"BASELINE configs[{k}]" if k is not None else "not a BASELINE config"
     total = f", {streams * world} streams in total" if world > 1 else ""
-    return (f"{streams} streams/GPU x 48 kHz stereo (mode '{mode}') x 128 kbps, psy {psy}, full encode ({tag}{total}), "
+    chans = "mono, two streams per wave" if mode == "m" else f"stereo (mode '{mode}')"
+    return (f"{streams} streams/GPU x 48 kHz {chans} x 128 kbps, psy {psy}, full encode ({tag}{total}), "
             f"{frames_per_step} frames/stream/step"), k
 
 
@@ -548,11 +549,17 @@ def main():
         # model, which the library offers as model 0 (filterbank, scalefactors, bit allocation, quantiser, packing); `value` is the FULL encode
         for name, (s2, p2, m2, f2) in {"mode_j": (S, psy, "j" if args.mode != "j" else "s", F),
                                        "configs2_psy3_16384": (CONFIGS[2][0], CONFIGS[2][1], "s", F2),
-                                       "encoder_only_psy0": (S, 0, args.mode, F)}.items():
+                                       "encoder_only_psy0": (S, 0, args.mode, F),
+                                       # the same workload with twice the frames per launch: what the fixed part of a launch (tail of the
+                                       # persistent waves, finish pass, launch gaps: ~0.09 ms) costs at F frames
+                                       "frames_per_launch_x2": (S, psy, args.mode, 2 * F),
+                                       # 128 kbps MONO streams, two per wave (tl_encode_pair)
+                                       "mono_pairs": (S, psy, "m", F)}.items():
             try:
                 r2 = GpuRun(M, torch, np, gen_pcm, range(s2), f2, m2, p2, local_rank)
                 e2, _, k2 = r2.timed(None, shard, max(2, args.warmup // 2), max(5, args.steps // 2))
                 chk2 = r2.check()
+                ab2 = r2.algo_bytes_per_launch
                 r2.close()
                 n2 = max(5, args.steps // 2)
                 wl2 = workload_label(s2, p2, m2, f2, 1)[0]
@@ -562,8 +569,8 @@ def main():
                 tr2, trs2, _ = committed_counters(s2, f2, p2, m2)
                 also[name] = {"workload": wl2, "value": round(s2 * f2 * n2 / e2, 1), "unit": "frames/s",
                               "steps": n2, "kernel_ms": round(k2, 4),
-                              "roofline_frac_hbm": round(ALGO_BYTES_PER_FRAME * s2 * f2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                              "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * s2 * f2, "traffic": tr2, "traffic_source": trs2, "output_check": chk2}
+                              "roofline_frac_hbm": round(ab2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                              "algorithmic_bytes_per_launch": ab2, "traffic": tr2, "traffic_source": trs2, "output_check": chk2}
             except Exception as ex:  # noqa: BLE001
                 also[name] = {"value": None, "error": str(ex)}
         try:     # BASELINE configs[0] on the GPU: ONE stream -- its frames are independent units for the kernels, so one stream fills the chip

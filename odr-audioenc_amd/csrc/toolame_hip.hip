@@ -223,6 +223,8 @@ __global__ void __launch_bounds__(256) tl_slots_kernel(TlLaunch A)
 // finish pass of the split path: one wave per stream (tl_finish_stream)
 __global__ void __launch_bounds__(256) tl_finish_kernel(TlLaunch A)
 {
+    // the unit counters of the list's persistent kernels are dead now: zero them for the next launch (instead of a memset per launch)
+    if (blockIdx.x == 0 && threadIdx.x < 9) A.work[threadIdx.x * TL_HEAD_STRIDE] = 0;
     const int k = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (k >= A.nlist) return;
     tl_finish_stream(A, __builtin_amdgcn_readfirstlane(A.stream_list[k]));
@@ -407,6 +409,7 @@ struct tlb_batch {
     bool pads[4] = {false, false, false, false}; // some stream of the psy model's list has frames of two lengths
     bool list_pairs[4] = {false, false, false, false};   // the model's list contains mono streams paired in one wave (kernel variant <.., true>)
     int32_t *d_work = nullptr;                   // unit counters of the persistent kernels
+    bool work_clean = false;                     // ... are zero (tl_finish_kernel zeroes them after use)
     int num_cu = 256;
 };
 
@@ -739,7 +742,8 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         const long units = (long)b->n_list[p] * nframes;
         A.padbits = b->pads[p] ? (uint8_t *)b->stage[7] : nullptr; A.newlag = b->d_newlag;
         if (b->pads[p]) { hipLaunchKernelGGL(tl_slots_kernel, dim3((unsigned)((b->n_list[p] + 255) / 256)), dim3(256), 0, st, A); HIPCHK(hipGetLastError()); }
-        HIPCHK(hipMemsetAsync(b->d_work, 0, sizeof(int32_t) * TL_HEAD_STRIDE * 9, st));
+        if (!b->work_clean) HIPCHK(hipMemsetAsync(b->d_work, 0, sizeof(int32_t) * TL_HEAD_STRIDE * 9, st));     // only after a launch that failed half way
+        b->work_clean = false;
         long qb = 0;
         if (p == 2) {
             A.chain_list = b->d_chain; A.nchain = b->n_chain; A.psy2_flip = b->psy2_flip;
@@ -759,6 +763,7 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
             HIPCHK(hipGetLastError());
             hipLaunchKernelGGL(tl_finish_kernel, dim3((unsigned)((b->n_list[p] + 3) / 4)), dim3(256), 0, st, A);
             HIPCHK(hipGetLastError());
+            b->work_clean = true;                                    // tl_finish_kernel leaves the counters at zero
             continue;
         }
         if (p == 2) hipLaunchKernelGGL(tl_psy2_kernel, dim3((unsigned)qb), dim3(64 * TL_PSY2_WAVES), 0, st, A);
@@ -774,6 +779,7 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(tl_finish_kernel, dim3((unsigned)((b->n_list[p] + 3) / 4)), dim3(256), 0, st, A);
         HIPCHK(hipGetLastError());
+        b->work_clean = true;
     }
     HIPCHK(hipEventRecord(b->ev1, st));
     b->last_stream = st; b->timed = true;

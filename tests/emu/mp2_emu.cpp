@@ -25,6 +25,7 @@ struct Emu {
     std::vector<TlPsy2Tables> psy2_tables;
     std::vector<TlPsy2State> psy2_state;
     int psy2_flip = 0;
+    long pair_units = 0;                       // (stream pair, frame) units run by tl_encode_pair so far: the pairing tests read it
 };
 
 extern "C" {
@@ -65,6 +66,7 @@ void *emu_create(int nstreams, const long *fs, const char *mode, const int *kbps
     return e;
 }
 void emu_destroy(void *h) { delete (Emu *)h; }
+long emu_pair_units(void *h) { return ((Emu *)h)->pair_units; }
 int emu_frame_bytes(void *h, int s) { Emu *e = (Emu *)h; return e->configs[e->stream_cfg[s]].frame_bytes; }
 int emu_max_frame_bytes(void *h, int s) { Emu *e = (Emu *)h; const TlConfig &c = e->configs[e->stream_cfg[s]]; return c.frame_bytes + (c.pad_frac != 0 ? 1 : 0); }
 
@@ -139,6 +141,7 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
             int s2;
             if (!tl_unit_partner(A, s, s2)) continue;
             if (s2 >= 0) {
+                e->pair_units++;
                 if (model(s) == 0) tl_main_pair<0>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, s2, f);
                 else if (model(s) == 2 || model(s) == 4) tl_main_pair<2>(wm, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, s, s2, f);
                 else if (model(s) == 1) tl_frame_unit<1>(wf, e->tables.dblog, &e->tables.shared, e->tables.enwindow_s, &e->tables.pack, A, &A, s, f, s2);

@@ -32,6 +32,7 @@ def lib():
         L.emu_create.restype = C.c_void_p
         L.emu_create.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.emu_destroy.argtypes = [C.c_void_p]
+        L.emu_pair_units.argtypes = [C.c_void_p]; L.emu_pair_units.restype = C.c_long
         L.emu_frame_bytes.argtypes = [C.c_void_p, C.c_int]
         L.emu_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.emu_encode_len.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -108,6 +109,10 @@ class EmuBatch:
             n = self.L.emu_pending(self.h, s, buf)
             res.append(bytes(buf[:n]))
         return res
+
+    def pair_units(self):
+        """(pair of mono streams, frame) units encoded by one wave so far (tl_encode_pair)"""
+        return int(self.L.emu_pair_units(self.h))
 
     def close(self):
         if self.h:

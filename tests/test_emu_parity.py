@@ -313,13 +313,17 @@ def test_mono_streams_share_waves_in_pairs():
             got = [a + c for a, c in zip(got, g)]
             pos += n
         tail = b.flush()
+        npair = b.pair_units()
         b.close()
-        return [a + c for a, c in zip(got, tail)]
-    got = run()
+        return [a + c for a, c in zip(got, tail)], npair
+    got, npair = run()
+    # 5 + 3 + 2 + 2 + 3 + 2 + 2 + 4 + 2 mono streams in groups of one configuration: 2 + 1 + 1 + 1 + 1 + 1 + 1 + 2 + 1 pairs, every frame of them
+    assert npair == 11 * nf, npair
     for s in range(ns):
         assert got[s] == want[s], (s, cfgs[s])
     os.environ["EMU_NO_PAIRS"] = "1"
     try:
-        assert run() == got
+        alone, none = run()
+        assert none == 0 and alone == got
     finally:
         del os.environ["EMU_NO_PAIRS"]
