@@ -244,10 +244,19 @@ typedef const struct TlLaunch *TlKArg;                                        /*
 #ifndef TL_PRIO_CHAIN
 #define TL_PRIO_CHAIN 3
 #endif
+#ifndef TL_PRIO_SERIAL
+#define TL_PRIO_SERIAL 2             // TL_PRIO_SERIAL=0 builds without it (measurement)
+#endif
 #ifdef TL_EMULATE
 #define TL_PRIO(n) ((void)0)
+#define TL_PRIO2(n) ((void)0)
 #else
-#define TL_PRIO(n) do { if (TL_PRIO_CHAIN) __builtin_amdgcn_s_setprio((n) ? TL_PRIO_CHAIN : 0); } while (0)
+// TL_PRIO(1) ... TL_PRIO(0): a dB-sum chain (highest); it falls back to the serial level, which is what surrounds every chain.
+// TL_PRIO2(1) / (0): a stage that is a dependent chain of look-ups, ballots and scans with few instructions to issue (tone labelling,
+// compaction, decimation, bit allocation, field writers, CRCs) / a stage that streams (transform, power spectrum, thresholds,
+// filterbank, quantiser).  Round 4, A/B on one box: + 0.9 % psy 1, + 1.0 % psy 3, + 1.8 % psy 0.
+#define TL_PRIO(n) do { if (TL_PRIO_CHAIN) __builtin_amdgcn_s_setprio((n) ? TL_PRIO_CHAIN : TL_PRIO_SERIAL); } while (0)
+#define TL_PRIO2(n) do { if (TL_PRIO_SERIAL) __builtin_amdgcn_s_setprio((n) ? TL_PRIO_SERIAL : 0); } while (0)
 #endif
 #ifdef TL_EMULATE
 #define TL_STAMP(sp, k) ((void)0)
@@ -897,6 +906,7 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
 {
     const double *energy = w.u.fft;                                   // line i at TL_EX(i)
     double *px = TL_PX(w);
+    TL_PRIO2(0);
     TL_STAMP(sp, 0);
     if (TL_EXP_LEVEL < 8) tl_psy_spectrum(w, T, pv, ch, sp);
     TL_STAMP(sp, 1);
@@ -941,6 +951,7 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
         L(rec)[ch] = spk;                                           // final as it is: straight to the record (nothing to park)
     } else if (lane < 32) L(rec)[ch] = 0.0;
     TL_LANES_END
+    TL_PRIO2(1);                                                      // from here to the thresholds: serial stages
 
     // ---- tonal components (psycho_1.c:267-340) ----
     // (1) local maxima 2..499 whose right-hand neighbours pass the 7 dB test, compacted ascending
@@ -1225,6 +1236,7 @@ TL_FN void tl_psy1_centres(TlPsyLds &w, const TlConfig *TL_RESTRICT C, int nband
 TL_FN void tl_psy1_thresholds(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, int ntone, int nnoise, PARGA(double, rec, 4), long long *sp)
 {
     TL_STAMP(sp, 5);
+    TL_PRIO2(0);                                                      // the thresholds stream
 
     TL_DBG_DUMP("psy1", ch, ntone, nnoise, TL_MK_X(w), TL_MK_BARK(w));
     // ---- individual + global masking thresholds on the table lines (psycho_1.c:480-532) ----
@@ -1602,6 +1614,7 @@ TL_FN int tl_psy3_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double
     const double *energy = w.u.fft;                                   // line i at TL_EX(i)
     double *px = TL_PX(w);
     const double *bark = C->p3_bark, *ath = C->p3_ath;
+    TL_PRIO2(0);
     TL_STAMP(sp, 0);
     tl_psy_spectrum(w, T, pv, ch, sp);
     TL_STAMP(sp, 1);
@@ -1653,6 +1666,7 @@ TL_FN int tl_psy3_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double
     TL_LANES_BEGIN
     if (lane == 0) px[512] = tl_power_db(energy[512], TL_LOGTAB(db));
     TL_LANES_END
+    TL_PRIO2(1);                                                      // from here to the thresholds: serial stages
     // ---- tone labelling (psycho_3.c:186-247) ----
     // (1) local maxima 2..499 whose right-hand neighbours are >= 7 dB down, compacted ascending
     int ncand = 0;
@@ -1901,6 +1915,7 @@ TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
     const int nnoise = __builtin_popcountll(mn);
     TL_STAMP(sp, 4);
     TL_STAMP(sp, 5);
+    TL_PRIO2(0);                                                      // the thresholds stream
     // ---- thresholds on the 136 subsampled lines (psycho_3.c:339-406) ----
     TL_LANES_BEGIN
     for (int t = lane; t < ntone + nnoise; t += 64) tl_masker_consts(TL_MK4(w), TL_MK_X(w), TL_MK_BARK(w), t, t < ntone);
@@ -2599,10 +2614,12 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     PA(int, scf, 3);
 
     TL_STAMP(sp, 0);
+    TL_PRIO2(0);
     // ---- K1: polyphase filterbank ----
     tl_filterbank(w, B, enw_s, nch, smp);
 
     TL_STAMP(sp, 1);
+    TL_PRIO2(1);
 #if !defined(TL_EMULATE) && TL_ENC_LEVEL >= 5
     for (int b = 0; b < 36; b++) TL_KEEP(smp[b]);
     scf[0] = scf[1] = scf[2] = 0;
@@ -2856,6 +2873,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     TL_LANES_END
     }
 
+    TL_PRIO2(0);
     // quantise (encode_new.c:479-547) + write_samples_new (:560-598): 12 rounds of 3 samples
     if (TL_ENC_LEVEL < 2) {
         const bool any_joint = (nch == 2) && jsbound < sblimit;      // joint-coded subbands exist in this frame
@@ -2921,6 +2939,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     }
 
     TL_STAMP(sp, 5);
+    TL_PRIO2(1);
     // CRC-16 over header bits 16..31, bit_alloc and scfsi fields (crc.c:12-41).
     // Protected message M = frame bits [16,32) then [48,p_scf), n bits.  The register after M with preset I is
     // (I(x) x^n + M(x) x^16) mod P -- linear over GF(2) -- so every lane takes one byte of M (a byte of the frame: the message is
@@ -3064,6 +3083,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     }
     if (lane < 4) fo.scfcrc[lane] = lane < C->dab_ext ? (uint8_t)w.ncentre[lane] : 0;
     TL_LANES_END
+    TL_PRIO2(0);
     TL_STAMP(sp, 7);
 }
 
@@ -3084,7 +3104,9 @@ TL_FN void tl_encode_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, cons
     const int padpk = padding[0] | (padding[1] << 1);             // both units' padding bits in one scalar (an array indexed by the lane would live in scratch)
     PA(double, smp, 36);
     PA(int, scf, 3);
+    TL_PRIO2(0);
     tl_filterbank(w, B, enw_s, 2, smp);
+    TL_PRIO2(1);
     // ---- scalefactors (encode_new.c:179-230) + find_sf_max (:260-277) ----
     TL_LANES_BEGIN
     const int c = lane & 1, sb = lane >> 1;
@@ -3213,6 +3235,7 @@ TL_FN void tl_encode_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, cons
         tl_put_bits48(frame, (c ? p_scf[1] : p_scf[0]) + ((L(o_scf) >> sh) & 0xffff), si == 0 ? f3 : si == 2 ? s0 : f2, (L(f_scf) >> sh) & 0xffff);
     }
     TL_LANES_END
+    TL_PRIO2(0);
     // quantise (encode_new.c:479-547) + write_samples_new (:560-598): 12 rounds of 3 samples
     {
         PV(int, q_ba); PV(int, q_nb); PV(int, q_grp); PV(int, q_s2n); PV(int, q_steps); PV(int, q_pos); PV(int, q_rstep);
@@ -3258,6 +3281,7 @@ TL_FN void tl_encode_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, cons
             TL_LANES_END
         }
     }
+    TL_PRIO2(1);
     // ---- CRC-16 (crc.c:12-41) of both frames: lanes 0..31 fold unit 0's message bytes, lanes 32..63 unit 1's (a mono frame protects
     //      at most 16 + 94 + 60 bits: 22 bytes; the preset's two bytes ride on lanes 30/31 of each half) ----
     {
@@ -3386,6 +3410,7 @@ TL_FN void tl_encode_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, cons
         if (lane < 4) fo[u].scfcrc[lane] = lane < C->dab_ext ? (uint8_t)w.ncentre[4 * u + lane] : 0;
         TL_LANES_END
     }
+    TL_PRIO2(0);
 }
 
 // ------------------------------------------------------------------------------------------
