@@ -244,6 +244,22 @@ typedef const struct TlLaunch *TlKArg;                                        /*
 #ifndef TL_PRIO_CHAIN
 #define TL_PRIO_CHAIN 3
 #endif
+// diagnostic: which of the streaming stages issue at the serial level (A/B builds)
+#ifndef TL_PS_FHT
+#define TL_PS_FHT 0
+#endif
+#ifndef TL_PS_THR
+#define TL_PS_THR 1          // the threshold walks too: + 0.4 % psy 1, + 0.9 % psy 3 (their trip counts differ from lane to lane)
+#endif
+#ifndef TL_PS_FB
+#define TL_PS_FB 0
+#endif
+#ifndef TL_PS_Q
+#define TL_PS_Q 0
+#endif
+#ifndef TL_PS_POW
+#define TL_PS_POW 0
+#endif
 #ifndef TL_PRIO_SERIAL
 #define TL_PRIO_SERIAL 2             // TL_PRIO_SERIAL=0 builds without it (measurement)
 #endif
@@ -253,8 +269,8 @@ typedef const struct TlLaunch *TlKArg;                                        /*
 #else
 // TL_PRIO(1) ... TL_PRIO(0): a dB-sum chain (highest); it falls back to the serial level, which is what surrounds every chain.
 // TL_PRIO2(1) / (0): a stage that is a dependent chain of look-ups, ballots and scans with few instructions to issue (tone labelling,
-// compaction, decimation, bit allocation, field writers, CRCs) / a stage that streams (transform, power spectrum, thresholds,
-// filterbank, quantiser).  Round 4, A/B on one box: + 0.9 % psy 1, + 1.0 % psy 3, + 1.8 % psy 0.
+// compaction, decimation, thresholds, bit allocation, field writers, CRCs) / a stage that streams (transform, power spectrum,
+// filterbank, quantiser).  Round 4, A/B on one box: + 1.9 % psy 1, + 1.9 % psy 3, + 1.8 % psy 0.
 #define TL_PRIO(n) do { if (TL_PRIO_CHAIN) __builtin_amdgcn_s_setprio((n) ? TL_PRIO_CHAIN : TL_PRIO_SERIAL); } while (0)
 #define TL_PRIO2(n) do { if (TL_PRIO_SERIAL) __builtin_amdgcn_s_setprio((n) ? TL_PRIO_SERIAL : 0); } while (0)
 #endif
@@ -906,10 +922,11 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
 {
     const double *energy = w.u.fft;                                   // line i at TL_EX(i)
     double *px = TL_PX(w);
-    TL_PRIO2(0);
+    TL_PRIO2(TL_PS_FHT);
     TL_STAMP(sp, 0);
     if (TL_EXP_LEVEL < 8) tl_psy_spectrum(w, T, pv, ch, sp);
     TL_STAMP(sp, 1);
+    TL_PRIO2(TL_PS_POW);
 
     // power density spectrum (psycho_1.c:241-248); spike (psycho_1.c:252-257)
     // The spike sums read 16 consecutive energies per lane; the energies' XOR layout keeps those reads off each other's
@@ -1236,7 +1253,7 @@ TL_FN void tl_psy1_centres(TlPsyLds &w, const TlConfig *TL_RESTRICT C, int nband
 TL_FN void tl_psy1_thresholds(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, int ntone, int nnoise, PARGA(double, rec, 4), long long *sp)
 {
     TL_STAMP(sp, 5);
-    TL_PRIO2(0);                                                      // the thresholds stream
+    TL_PRIO2(TL_PS_THR);
 
     TL_DBG_DUMP("psy1", ch, ntone, nnoise, TL_MK_X(w), TL_MK_BARK(w));
     // ---- individual + global masking thresholds on the table lines (psycho_1.c:480-532) ----
@@ -1614,10 +1631,11 @@ TL_FN int tl_psy3_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double
     const double *energy = w.u.fft;                                   // line i at TL_EX(i)
     double *px = TL_PX(w);
     const double *bark = C->p3_bark, *ath = C->p3_ath;
-    TL_PRIO2(0);
+    TL_PRIO2(TL_PS_FHT);
     TL_STAMP(sp, 0);
     tl_psy_spectrum(w, T, pv, ch, sp);
     TL_STAMP(sp, 1);
+    TL_PRIO2(TL_PS_POW);
 
     // power[1..512] (psycho_3.c:152-160); power[0] is an uninitialised slot in the reference, pinned
     // to 0.0 (oracle/mp2_oracle.c:psy3_run)
@@ -1915,7 +1933,7 @@ TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
     const int nnoise = __builtin_popcountll(mn);
     TL_STAMP(sp, 4);
     TL_STAMP(sp, 5);
-    TL_PRIO2(0);                                                      // the thresholds stream
+    TL_PRIO2(TL_PS_THR);
     // ---- thresholds on the 136 subsampled lines (psycho_3.c:339-406) ----
     TL_LANES_BEGIN
     for (int t = lane; t < ntone + nnoise; t += 64) tl_masker_consts(TL_MK4(w), TL_MK_X(w), TL_MK_BARK(w), t, t < ntone);
@@ -2614,7 +2632,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     PA(int, scf, 3);
 
     TL_STAMP(sp, 0);
-    TL_PRIO2(0);
+    TL_PRIO2(TL_PS_FB);
     // ---- K1: polyphase filterbank ----
     tl_filterbank(w, B, enw_s, nch, smp);
 
@@ -2873,7 +2891,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     TL_LANES_END
     }
 
-    TL_PRIO2(0);
+    TL_PRIO2(TL_PS_Q);
     // quantise (encode_new.c:479-547) + write_samples_new (:560-598): 12 rounds of 3 samples
     if (TL_ENC_LEVEL < 2) {
         const bool any_joint = (nch == 2) && jsbound < sblimit;      // joint-coded subbands exist in this frame
@@ -3104,7 +3122,7 @@ TL_FN void tl_encode_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, cons
     const int padpk = padding[0] | (padding[1] << 1);             // both units' padding bits in one scalar (an array indexed by the lane would live in scratch)
     PA(double, smp, 36);
     PA(int, scf, 3);
-    TL_PRIO2(0);
+    TL_PRIO2(TL_PS_FB);
     tl_filterbank(w, B, enw_s, 2, smp);
     TL_PRIO2(1);
     // ---- scalefactors (encode_new.c:179-230) + find_sf_max (:260-277) ----
@@ -3235,7 +3253,7 @@ TL_FN void tl_encode_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, cons
         tl_put_bits48(frame, (c ? p_scf[1] : p_scf[0]) + ((L(o_scf) >> sh) & 0xffff), si == 0 ? f3 : si == 2 ? s0 : f2, (L(f_scf) >> sh) & 0xffff);
     }
     TL_LANES_END
-    TL_PRIO2(0);
+    TL_PRIO2(TL_PS_Q);
     // quantise (encode_new.c:479-547) + write_samples_new (:560-598): 12 rounds of 3 samples
     {
         PV(int, q_ba); PV(int, q_nb); PV(int, q_grp); PV(int, q_s2n); PV(int, q_steps); PV(int, q_pos); PV(int, q_rstep);
