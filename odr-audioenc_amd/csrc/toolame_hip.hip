@@ -17,6 +17,7 @@
 #include "mp2_wave.h"
 #include "edi_af.h"
 #include "edi_pft.h"
+#include "tl_kernel_util.h"
 
 static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 
@@ -38,25 +39,6 @@ static_assert(TL_MAX_XPAD == TLB_MAX_XPAD, "xpad record size");
 // 2 waves per SIMD); round 2 first split model and encoder into two kernels (3 waves per SIMD each, but the PCM read twice and
 // a 1 KB record per frame through HBM), then put them back into one kernel one AFTER the other: the registers needed are the
 // maximum of the two phases, not the sum, the LDS blocks a union, the record four values per lane.
-// Next unit of a persistent kernel's work list: ONE returning device-scope atomic add per wave, issued by lane 0 alone.
-// The lane mask is narrowed inside the asm statement, not with an `if (lane == 0)`: LLVM threaded such a branch together
-// with the equal test of the diagnostic stamps at the end of the previous unit into a loop that some lanes never left; and
-// its wave-level atomic optimiser, which folds `atomicAdd(p, 1)` of 64 lanes into one add, only does so while it can prove the
-// address uniform -- when it cannot, the 64 adds of two waves interleave and units are handed out twice or never.
-// `counter` must be wave-uniform and the call site wave-uniform control flow (lane 0 active: its registers carry the operands).
-static __device__ __forceinline__ int tl_next_unit(int32_t *counter)
-{
-    int u;
-    uint64_t saved;
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_mov_b64 %1, exec\n\t"
-                 "s_mov_b64 exec, 1\n\t"
-                 "global_atomic_add %0, %2, %3, %4 sc0\n\t"
-                 "s_waitcnt vmcnt(0)\n\t"
-                 "s_mov_b64 exec, %1"
-                 : "=&v"(u), "=&s"(saved) : "v"(0), "v"(1), "s"(counter) : "memory");
-    return __builtin_amdgcn_readfirstlane(u);
-}
 // (stream, frame) units come off EIGHT lists, one per XCD (each XCD has its own L2).  The units of a launch, numbered stream by
 // stream with frames ascending (u = k * nframes + f), are dealt to the lists in blocks of 32 consecutive units: the waves of
 // an XCD work on consecutive frames of a few streams at a time, so the 480 samples of history a frame needs -- the tail of
@@ -99,34 +81,9 @@ static __device__ __forceinline__ bool tl_take_unit(int32_t *heads, int nlist, i
 #ifndef TL_MAIN_WPE
 #define TL_MAIN_WPE 3
 #endif
-#define TL_LDS_GRANULE 1280u
-// psy kernel of models 2 and 4: a unit = a run of frames of one channel of one stream (tl_psy2_unit: whole chains first, then
-// the chains of the last round of waves cut into runs, so that one stream with many frames fills the chip as well as many
-// streams do); the run's r/phi prediction state stays in the wave's registers (tl_psy2_chain).  No table in LDS but glibc's
-// sincos table (the model's own tables are read through the caches), 12.1 KB per wave: twelve waves per CU like the other kernels.
-#ifndef TL_PSY2_WAVES
-#define TL_PSY2_WAVES 12
-#endif
-static_assert((TL_PSY2_WAVES * sizeof(TlPsy2Lds) + 440 * 8 + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "twelve psy-2 waves per CU");
-__global__ void __launch_bounds__(64 * TL_PSY2_WAVES) __attribute__((amdgpu_waves_per_eu(TL_PSY2_WAVES / 4, TL_PSY2_WAVES / 4))) tl_psy2_kernel(TlLaunch A)
-{
-    __shared__ TlPsy2Lds lds[TL_PSY2_WAVES];
-    __shared__ __attribute__((aligned(16))) uint64_t sct[440];      // glibc's sincos table: two 16-byte gathers per sincos stay on the CU
-    for (int i = (int)threadIdx.x; i < 440; i += 64 * TL_PSY2_WAVES) sct[i] = tlm_sincostab[i];
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int wave_v = (int)(threadIdx.x >> 6);
-    asm volatile("" : "+v"(wave_v));
-    TlPsy2Lds &wl = lds[wave_v];
-    const int nunits = A.p2_nwhole + (A.nchain - A.p2_nwhole) * A.p2_k, nwaves = (int)gridDim.x * TL_PSY2_WAVES;
-    for (int u = (int)blockIdx.x * TL_PSY2_WAVES + wave; u < nunits; u = nwaves + tl_next_unit(&A.work[0])) {
-        int c, f0, f1;
-        if (!tl_psy2_unit(A, u, c, f0, f1)) continue;
-        const int e = __builtin_amdgcn_readfirstlane(A.chain_list[c]);
-        tl_psy2_chain(wl, A, e & 0x3fffffff, e >> 30, f0, f1, sct);
-    }
-}
-
+// psy kernel of models 2 and 4: csrc/toolame_psy2.hip, a translation unit of its own (it wants the IR load / store vectorizer the
+// other kernels are built without, see csrc/Makefile).  TL_PSY2_WAVES waves per workgroup.
+__global__ void tl_psy2_kernel(TlLaunch A);
 // encode kernel of the split path: the tables it needs on dependent-load chains (TlBlockShared without the dB-sum table)
 struct TlMainShared { double enw_s[512]; char bytes[sizeof(TlBlockShared) - offsetof(TlBlockShared, scalefactor)]; TlPackTables pack; };
 static_assert(offsetof(TlBlockShared, dbtable) == 0 && offsetof(TlBlockShared, scalefactor) == sizeof(double) * 1002, "dbtable leads TlBlockShared");

@@ -6,12 +6,11 @@
 #   tools/class_budget.sh run       (GPU box) -> gpurun_out/class_budget.txt   (copy to profiles/class_budget_rNN.txt)
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
-FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -mllvm -disable-machine-licm -fno-strict-aliasing -fPIC -Wno-unused-function -Wno-unused-variable -Wno-pass-failed -shared"
 if [ "${1:-run}" = build ]; then
   mkdir -p build; i=0
   for v in EXP:1 EXP:2 EXP:3 EXP:4 EXP:5 EXP:6 EXP:7 EXP:9 ENC:1 ENC:2 ENC:3 ENC:4 ENC:5; do
     k=${v%%:*}; n=${v##*:}; i=$((i+1))
-    (cd odr-audioenc_amd/csrc && /opt/rocm/bin/hipcc $FLAGS -o $R/build/lib_cb_${k}$n.so toolame_hip.hip -x hip mp2_host.cpp -DTL_${k}_LEVEL=$n ${EXTRA:-}) &
+    make -s -C odr-audioenc_amd/csrc OUT=$R/build/lib_cb_${k}$n.so OBJ=$R/build/obj_cb_${k}$n EXTRA="-DTL_${k}_LEVEL=$n -Wno-pass-failed ${EXTRA:-}" > /dev/null 2>&1 &
     if [ $((i % 5)) = 0 ]; then wait; fi
   done
   wait; ls build/ | grep lib_cb | wc -l

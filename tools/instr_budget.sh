@@ -6,8 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 if [ "${1:-run}" = build ]; then
   mkdir -p build
   for n in 1 2 3 4 5 6 7 8; do
-    (cd odr-audioenc_amd/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -mllvm -disable-machine-licm -fno-strict-aliasing -fPIC -Wno-unused-function \
-       -Wno-unused-variable -Wno-pass-failed -shared -o $R/build/lib_exp$n.so toolame_hip.hip -x hip mp2_host.cpp -DTL_EXP_LEVEL=$n) &
+    make -s -C odr-audioenc_amd/csrc OUT=$R/build/lib_exp$n.so OBJ=$R/build/obj_exp$n EXTRA="-DTL_EXP_LEVEL=$n -Wno-pass-failed" > /dev/null 2>&1 &
     if [ $((n % 4)) = 0 ]; then wait; fi
   done
   wait; ls -la build/
