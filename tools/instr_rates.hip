@@ -25,6 +25,8 @@
         int i0 = ia + threadIdx.x, i1 = ia * 3 + 1;                                                          \
         (void)c; (void)i0; (void)i1; (void)a; (void)b;                                                       \
         unsigned la = (threadIdx.x * 8u) & 8191u; (void)la;                                                  \
+        unsigned la16 = (threadIdx.x * 16u) & 8191u; (void)la16;                                             \
+        typedef double __attribute__((ext_vector_type(2))) d2_t; d2_t q[16]; for (int k = 0; k < 16; k++) { q[k].x = fa + k; q[k].y = fb; } \
         lds[threadIdx.x] = a; lds[threadIdx.x + 768] = b;                                                    \
         __syncthreads();                                                                                    \
         double d[16]; int e[16];                                                                            \
@@ -39,7 +41,7 @@
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
         long long t1 = __builtin_amdgcn_s_memtime();                                                        \
         double s = 0; int si = 0;                                                                           \
-        for (int k = 0; k < 16; k++) { s += d[k]; si += e[k]; }                                              \
+        for (int k = 0; k < 16; k++) { s += d[k] + q[k].x + q[k].y; si += e[k]; }                                              \
         if (s == 1.2345 && si == 77) out[1000] = 1;                                                          \
         if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = t1 - t0;                                       \
     }
@@ -165,6 +167,12 @@ KERNEL(mbcnt_lo, , )
 // ---- LDS (cycles of the wave's issue stream; the LDS pipe itself is shared by the CU)
 #define ds_read_b64_INS(k) asm volatile("ds_read_b64 %0, %1" : "+v"(d[k]) : "v"(la) : "memory");
 KERNEL(ds_read_b64, , )
+#define ds_read2_b64_INS(k) asm volatile("ds_read2_b64 %0, %1 offset1:1" : "+v"(q[k]) : "v"(la) : "memory");
+KERNEL(ds_read2_b64, , )
+#define ds_read_b64x2_INS(k) asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "+v"(d[k]), "+v"(d[(k + 1) & 15]) : "v"(la) : "memory");
+KERNEL(ds_read_b64x2, , )
+#define ds_read_b128_INS(k) asm volatile("ds_read_b128 %0, %1" : "+v"(q[k]) : "v"(la16) : "memory");
+KERNEL(ds_read_b128, , )
 #define ds_read_b32_INS(k) asm volatile("ds_read_b32 %0, %1" : "+v"(e[k]) : "v"(la) : "memory");
 KERNEL(ds_read_b32, , )
 #define ds_write_b64_INS(k) asm volatile("ds_write_b64 %0, %1" : : "v"(la), "v"(a) : "memory");
@@ -225,7 +233,7 @@ int main()
         E(mov_b32), E(mov_b32_dpp), E(mov_b32_dpp_row_shr), E(cndmask_b32), E(cndmask_b32_e64), E2(cmp_cnd2), E(or_b32), E(sub_u32), E(lshrrev_b32), E(lshlrev_b32_v), E(max_u32), E(mov_b64), E(cvt_u32_f64), E(perm_b32), E(and_or_b32), E(add_f64_lit), E(mul_f64_sgpr), E(add_f64_abs), E(add_u32), E(lshlrev_b32), E(and_b32), E(xor_b32), E(bfe_u32), E(lshl_or_b32), E(add3_u32),
         E(mul_lo_u32), E(mul_u32_u24), E(cmp_lt_u32), E(cmp_lt_u32_e64), E(readlane_b32), E(readfirstlane_b32), E(writelane_b32), E(add_f32), E(pk_add_f32), E(pk_mov_b32),
         E(cvt_i32_f32), E(ffbh_u32), E(bcnt_u32), E(mbcnt_lo),
-        E(ds_read_b64), E(ds_read_b32), E(ds_write_b64), E(ds_bpermute_b32), E(ds_or_b32), E(s_add_u32), E(s_nop),
+        E(ds_read_b64), E(ds_read2_b64), E2(ds_read_b64x2), E(ds_read_b128), E(ds_read_b32), E(ds_write_b64), E(ds_bpermute_b32), E(ds_or_b32), E(s_add_u32), E(s_nop),
         {"cmp_cnd3_vcc", cmp_cnd3_vcc, 3}, {"cmp_cnd3_sgpr", cmp_cnd3_sgpr, 3}, {"cmp_cnd5_vcc", cmp_cnd5_vcc, 5}, E2(add_cnd_vcc), {"add3_cnd_vcc", add3_cnd_vcc, 4}, E(fmac_f64), E2(add_f64_nop), E2(add_f64_nop1), E(readlane_rot), E(cmp_rot), E2(mul_add_dep), E2(mix_f64_b32), E2(mix_f64_salu), E2(mix_f64_lds),
     };
     printf("# cycles of SIMD time per wave-instruction (s_memtime ticks of the slowest wave / instructions issued on its SIMD); 100 MHz-independent: ticks are shader clocks\n");
