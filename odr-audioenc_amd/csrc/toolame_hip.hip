@@ -1722,6 +1722,17 @@ int toolame_init(void)
     g_legacy.release();
     g_legacy = Legacy();
     g_legacy.inited = true;
+    // Byte parity with the reference is parity with the reference AS BUILT AGAINST glibc 2.35's FMA-path libm (csrc/tl_libm.h).  A
+    // maintainer who swaps this library in on a host with another libm would see the CPU reference's bytes move on degenerate
+    // signals while these stay: say so once per process (host arithmetic only, a few milliseconds; TLB_NO_LIBM_CHECK silences it).
+    static bool checked = false;
+    if (!checked && !getenv("TLB_NO_LIBM_CHECK")) {
+        checked = true;
+        const long bad = tlb_selfcheck_libm(20000);
+        if (bad) fprintf(stderr, "libtoolame-dab-hip: note: this host's libm differs from glibc 2.35's FMA-path routines in %ld of 140000 sampled "
+                                 "results; the GPU encoder reproduces THAT libm's reference bytes, a reference built here may differ on degenerate signals "
+                                 "(INTEGRATION.md section 5)\n", bad);
+    }
     return 0;
 }
 int toolame_enable_byteswap(void) { return 0; }           // glopts.byteswap is never read on this path
