@@ -327,3 +327,41 @@ def test_mono_streams_share_waves_in_pairs():
         assert none == 0 and alone == got
     finally:
         del os.environ["EMU_NO_PAIRS"]
+
+
+def test_mono_pairs_random_configurations_equal_lone_streams():
+    """Random mono configurations (rates, bitrates, psy models, X-PAD) x signal kinds -- silence, impulses and square waves with their
+    allocation ties among them -- as pairs of streams per wave (tl_encode_pair, tl_allocate_pair: both units' greedy loops at once)
+    against the same batch with every stream alone (tl_allocate): the bytes must not depend on the pairing."""
+    import os
+    v1m = (32, 48, 56, 64, 80, 96, 112, 128, 160, 192); v2 = (8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160)
+    rng = np.random.default_rng(77)
+    nf, cfgs = 4, []
+    for _ in range(16):
+        fs = int(rng.choice([48000, 44100, 32000, 24000, 22050, 16000]))
+        c = dict(samplerate=fs, mode="m", kbps=int(rng.choice(v1m if fs >= 32000 else v2)), psy=int(rng.choice([0, 1, 1, 3, 2, 4])))
+        if rng.random() < 0.3: c["pad_len"] = 24
+        cfgs += [c] * 2
+    ns = len(cfgs)
+    kinds = [int(k) if not (cfgs[s]["psy"] == 3 and k in (1, 3)) else 0 for s, k in enumerate(rng.integers(0, 8, size=ns))]
+    pcm = np.stack([gen_pcm(int(rng.integers(1 << 30)), kinds[s], 0, nf) for s in range(ns)], axis=1)
+    xp = rng.integers(0, 256, size=(nf, ns, E.TL_MAX_XPAD), dtype=np.uint8)
+    xl = np.zeros((nf, ns), dtype=np.int32)
+    for s, c in enumerate(cfgs):
+        if c.get("pad_len"): xl[:, s] = rng.choice([0, 2, 6, 24, 17], size=nf)
+    def run():
+        b = E.EmuBatch(cfgs)
+        g, _ = b.encode(pcm, xp, xl)
+        t, n = b.flush(), b.pair_units()
+        b.close()
+        return [a + c for a, c in zip(g, t)], n
+    paired, npair = run()
+    assert npair == 16 * nf
+    os.environ["EMU_NO_PAIRS"] = "1"
+    try:
+        alone, none = run()
+    finally:
+        del os.environ["EMU_NO_PAIRS"]
+    assert none == 0
+    for s in range(ns):
+        assert paired[s] == alone[s], (s, cfgs[s], kinds[s])
