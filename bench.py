@@ -44,7 +44,18 @@ ALGO_BYTES_PER_FRAME = 2 * 1152 * 2 + 144000 * KBPS // FS      # PC
 HBM_PEAK_GBS = 8000.0                                           # MI355X_MICROARCH.md: 8 TB/s HBM3E
 # BASELINE.json configs[k] -> (streams per GPU, psy model)
 CONFIGS = {1: (4096, 1), 2: (16384, 3), 3: (16384, 3), 4: (16384, 4)}
-SIMD_CYCLES_PER_VALU = 4        # a wave64 vector instruction occupies its SIMD's issue for 4 cycles (16 lanes / cycle; profiles/instr_rates_r04.txt)
+FP64_PEAK_TFLOPS = 78.6          # MI355X vector fp64 (MI355X_MICROARCH.md); MFMA does not apply: no dense contraction, exact summation order
+# SURVEY 8(d) "algorithmic flops per frame", per CHANNEL-frame and stage, fp64: filterbank 72 x (512 + 512 MAC) / 2 ch = 73.7 k; encoder rest
+# (scalefactors, quantiser) 5 k; psy 1 / 3: one 1024-point FHT 25 k + model 50-75 k (taken as 62.5 k) + 544 log10 -> 0.35 MFLOP per STEREO
+# frame with the filterbank, the figure SURVEY quotes; psy 0: no model; psy 2 / 4 (psycho_2.c:52-254, two 576-sample passes per frame, each a
+# 1024-point FHT 25 k, polar form + prediction + unpredictability 513 x ~40 = 20 k, partition sums + 64 x 64 spreading x 2 = 18 k, thresholds 7 k)
+# = 140 k per channel-frame.  These are ALGORITHMIC counts (what the reference's arithmetic needs), not instructions issued.
+FLOPS_PER_CHANNEL_FRAME = {0: 78.7e3, 1: 175e3, 3: 175e3, 2: 78.7e3 + 140e3, 4: 78.7e3 + 140e3}
+# Issue cost of one wave64 vector instruction by class, SIMD cycles at 3 waves per SIMD (profiles/instr_rates_r04.txt: add / mul_f64 4.41,
+# fma_f64 5.20, rcp / sqrt_f64 16.3, cvt 4.3, plain 32-bit integer ops 2.84 and shifts / max / mul 4.3 -> 3.6 for the kernel's mix, 64-bit
+# integer 4.4, the rest -- moves 2.9, DPP / selects 4.4, compares and lane reads 5.4-5.5 -> 4.4)
+CLASS_COST = {"add_f64": 4.41, "mul_f64": 4.41, "fma_f64": 5.20, "trans_f64": 16.3, "cvt": 4.3, "int32": 3.6, "int64": 4.4, "other": 4.4}
+FLAT_COST = 4.3                  # no class split committed for the workload: every instruction at the mean cost
 
 
 def parse_args(argv=None):
@@ -60,6 +71,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements after the headline")
     ap.add_argument("--dry-run", action="store_true", help="CPU emulation over gloo: plumbing check only, not a measurement")
+    ap.add_argument("--force-group", action="store_true",
+                    help="build the process group even at world size 1, so that init_process_group / barrier / all_reduce / all_gather run through the "
+                         "chosen backend (RCCL with --backend nccl) on a one-GPU box")
+    ap.add_argument("--in-process", type=int, default=0, metavar="G",
+                    help="drive the product's node level (tlb_node_*, csrc/tlb_node.cpp) instead of one rank per GPU: G shards in THIS process, shard g on "
+                         "device g mod device count, one host thread each; reported under `node` beside the usual line of shard 0's workload")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="collective backend of the ranks; gloo (with ranks sharing GPUs: device = LOCAL_RANK mod device count) is for smoke-testing "
                          "the multi-rank path on a box with fewer GPUs than ranks -- its value is not a scaling measurement")
@@ -217,6 +234,9 @@ def committed_counters(S, F, psy, mode, mixed=False):
                             "wave_cycles_waiting": c["derived"]["waiting_share"], "valu_instructions_per_frame": c["derived"]["per_frame"]["valu"]}
                         for k, c in sq["kernels"].items()}
                 valu["clock_ghz"] = next((c["derived"].get("clock_ghz") for c in sq["kernels"].values() if c["derived"].get("clock_ghz")), None)
+                cls = [c["derived"]["classes_per_frame"] for c in sq["kernels"].values() if c["derived"].get("classes_per_frame")]
+                valu["classes_per_frame"] = {k: sum(c[k] for c in cls) for k in cls[0]} if cls and len(cls) == len(sq["kernels"]) else None
+                valu["lane_occupancy"] = {k: c["derived"].get("lane_occupancy") for k, c in sq["kernels"].items()}
                 valu["source"] = f"profiles/{f.name} (committed rocprofv3 --pmc SQ counters of this workload, not this run)"
                 break
         except Exception:  # noqa: BLE001
@@ -398,6 +418,61 @@ def tick_pipeline(M, np, gen_pcm, nstreams, psy, mode, local_rank, ticks=1000, e
             "limit": "the host-to-device link: " + f"{n_in / 1e6:.0f} MB of PCM per tick" if p50 > 0.4 * 24 else "none near the budget"}
 
 
+def node_in_process(M, np, gen_pcm, G, S, F, psy, mode, ndev, warmup, steps, mixed=False):
+    """The product's own multi-GPU object (include/toolame_batch.h part 3, csrc/tlb_node.cpp) driven from ONE process: G shards of S streams
+    each (weak scaling, like the ranks), shard g on device g mod `ndev`, one host thread per shard, BATCH plane (PCM resident in each shard's
+    HBM, two alternating buffers).  A step = tlb_node_encode_device() on every shard; the region ends with tlb_node_sync().  The oracle
+    then encodes the first stream of the first shard and the last stream of the last shard."""
+    import oraclelib as O
+    cfgs = []
+    for g in range(G):
+        cfgs += stream_configs(M, S, psy, mode, mixed)
+    nd = M.Node(cfgs, devices=[g % ndev for g in range(G)], plane="batch")
+    distinct = min(S, 1024)
+    base = np.stack([gen_pcm(k, 0, 0, 2 * F) for k in range(distinct)], axis=1)            # [2F][distinct][2][1152]
+    host = np.tile(base, (1, (G * S + distinct - 1) // distinct, 1, 1))[:, :G * S]
+    if mixed:
+        host = host.copy()
+    nd.upload(host[:F], slot=0)
+    nd.upload(host[F:], slot=1)
+    launches = 0
+    for i in range(warmup):
+        nd.encode_resident(slot=launches & 1)
+        launches += 1
+    nd.sync()
+    c0 = nd.counters()[1]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        nd.encode_resident(slot=launches & 1)
+        launches += 1
+    nd.sync()
+    dt = time.perf_counter() - t0
+    per, tot = nd.counters()
+    got = nd.download()
+    total = launches * F
+    checked = {"checked": False, "why": f"{total} frames per stream: beyond the oracle budget of this check"}
+    if total <= 12000:
+        for k in (0, G * S - 1):
+            c = cfgs[k]
+            fb = 144000 * c.bitrate // c.samplerate
+            pcm = np.concatenate([host[:, k]] * (launches // 2 + 1))[:total]
+            ref = O.oracle_stream(pcm, samplerate=c.samplerate, mode=c.mode, kbps=c.bitrate, psy=c.psy_model)[0]
+            first = (launches - 1) * F - 1
+            want = ref[max(first, 0) * fb:(first + F) * fb]
+            assert got[k][-len(want):] == want, f"node output differs from the oracle: stream {k}"
+        checked = {"checked": True, "streams": [0, G * S - 1], "frames_compared_per_stream": F,
+                   "what": "the last launch's output of the first and the last stream of the node against oracle/mp2_oracle.c"}
+    nd.close()
+    frames = G * S * F * steps
+    return {"what": f"tlb_node_* (csrc/tlb_node.cpp): {G} shards x {S} streams in ONE process, one host thread per shard, devices {[g % ndev for g in range(G)]}, "
+                    f"psy {psy}, {F} frames/stream/step, PCM resident per shard; no collective anywhere",
+            "shards": G, "devices": [g % ndev for g in range(G)], "value": round(frames / dt, 1), "unit": "frames/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt / steps * 1e3, 4), "frames_counted_by_the_node": tot["frames"] - c0["frames"],
+            "per_shard": [{"shard": p_["shard"], "device": p_["device"], "first": p_["first"], "nstreams": p_["nstreams"], "frames": p_["frames"],
+                           "busy_ms": round(p_["busy_ns"] / 1e6, 3)} for p_ in per],
+            "output_check": checked}
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -433,7 +508,7 @@ def main():
         raise SystemExit(f"bench.py: rank needs GPU {os.environ.get('LOCAL_RANK')} but the box has {ndev} (RCCL wants one GPU per rank)")
     dev_index = int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev)
     torch.cuda.set_device(dev_index)
-    rank, local_rank, world_env, dist = shard.init_from_env(args.backend, device_index=dev_index)      # "nccl" is RCCL on ROCm
+    rank, local_rank, world_env, dist = shard.init_from_env(args.backend, device_index=dev_index, force=args.force_group)      # "nccl" is RCCL on ROCm
     local_rank = dev_index
     cdev = "cuda" if args.backend == "nccl" else "cpu"          # where the collectives' few scalars live
     assert world_env == world
@@ -460,36 +535,55 @@ def main():
     if dist is not None:          # nothing below is collective: the ranks part here, rank 0 goes on to its host-side legs alone
         dist.destroy_process_group()
         dist = None
-    had_group = world > 1
+    had_group = world > 1 or args.force_group
     all_ok = all(p[2] == 1.0 for p in per_rank) and (sib is None or all(p[2] == 1.0 for p in sib["per_rank"]))
 
     def roofline(run_d, S_, F_, psy_k, mode_k):
-        """what limits the launch's dominant kernel, from THIS run's event times and the committed counters of this workload"""
+        """The SURVEY 8(d) fractions of the launch's dominant kernel from THIS run's event times: `frac` = algorithmic fp64 flops per second
+        over the vector-fp64 peak (the resource that binds this path), `hbm_frac` = algorithmic bytes per second over 8 TB/s (what
+        BASELINE.json asks for).  Beside them, clearly apart, how busy the kernel keeps the vector issue ports with its OWN instruction
+        stream: the counter value of the committed profile of this workload and the same figure recomputed for this run from the
+        committed instruction classes."""
         k_ms = run_d["kernel_ms"]
         traffic, traffic_source, valu = committed_counters(S_, F_, psy_k, mode_k, mixed)
         hbm_ach = run_d["algo"] / (k_ms * 1e-3) / 1e9
-        rf = {"hbm": {"achieved": round(hbm_ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_ach / HBM_PEAK_GBS, 6),
+        nch_ = 1 if mode_k == "m" else 2
+        fps_k = S_ * F_ / (k_ms * 1e-3)
+        flops_frame = FLOPS_PER_CHANNEL_FRAME[psy_k] * (1.5 if mixed else nch_)          # configs[4]: mono and stereo streams alternate
+        ach = flops_frame * fps_k / 1e12
+        rf = {"bound": "valu_fp64", "achieved": round(ach, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_PEAK_TFLOPS, 4),
+              "flops_per_frame": flops_frame,
+              "frac_basis": f"{flops_frame:.0f} algorithmic fp64 flops per frame (SURVEY 8d; FLOPS_PER_CHANNEL_FRAME in bench.py) x {fps_k:.0f} frames/s (this run, "
+                            f"HIP-event kernel time) / {FP64_PEAK_TFLOPS} TFLOP/s vector fp64.  The reference's arithmetic allows no FMA contraction (-ffp-contract=off), "
+                            "so a kernel of pure fp64 adds and multiplies tops out at half that peak",
+              "hbm": {"achieved": round(hbm_ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_ach / HBM_PEAK_GBS, 6),
                       "algorithmic_bytes_per_launch": run_d["algo"], "traffic": traffic, "traffic_source": traffic_source},
               "hbm_frac": round(hbm_ach / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
               "kernel_ms": round(k_ms, 4), "last_kernel_ms_hip_events": round(run_d["last_ms"], 4)}
-        # issue slots: VALU instructions per frame (committed SQ counters of this workload) x frames/s of this run x 4 cycles
-        # over the chip's SIMD-cycles per second; the share of the SIMDs' issue time the launch's vector instructions occupy
-        vi = None
+        util = {"what": "share of the SIMDs' issue cycles the launch's vector instructions occupy -- a utilisation of the kernel's own instruction stream, "
+                        "NOT a roofline fraction"}
         if valu:
-            per_frame = sum(v["valu_instructions_per_frame"] for k_, v in valu.items() if isinstance(v, dict))
             clock = valu.get("clock_ghz") or 2.2
-            fps_k = S_ * F_ / (k_ms * 1e-3)
-            vi = per_frame * fps_k * SIMD_CYCLES_PER_VALU / (num_simds * clock * 1e9)
-            rf.update({"bound": "valu_issue", "achieved": round(per_frame * fps_k / 1e12, 4), "peak": round(num_simds * clock * 1e9 / SIMD_CYCLES_PER_VALU / 1e12, 4),
-                       "unit": "T wave-instructions/s", "frac": round(vi, 4), "valu_issue_frac": round(vi, 4),
-                       "valu_issue_basis": f"{per_frame} VALU instructions per frame (committed SQ_INSTS_VALU of this workload) x {fps_k:.0f} frames/s (this run, kernel time) x "
-                                           f"{SIMD_CYCLES_PER_VALU} cycles / ({num_simds} SIMDs x {clock} GHz, the clock of the committed profile run)"})
+            per_frame = sum(v["valu_instructions_per_frame"] for k_, v in valu.items() if isinstance(v, dict))
+            classes = valu.get("classes_per_frame")
+            if classes:
+                cyc = sum(CLASS_COST[c] * n for c, n in classes.items())
+                basis = "committed class counts x CLASS_COST (bench.py; profiles/instr_rates_r04.txt, 3 waves per SIMD)"
+            else:
+                cyc = per_frame * FLAT_COST
+                basis = f"no class split committed for this workload: {per_frame} instructions per frame x {FLAT_COST} cycles"
+            util.update({"counter_valu_busy_per_simd": {k_: v["valu_busy_per_simd"] for k_, v in valu.items() if isinstance(v, dict)},
+                         "counter_lane_occupancy": valu.get("lane_occupancy"),
+                         "this_run_from_instruction_classes": round(cyc * fps_k / (num_simds * clock * 1e9), 4),
+                         "valu_instructions_per_frame": per_frame, "classes_per_frame": classes, "issue_cycles_per_frame": round(cyc),
+                         "basis": f"{basis} x {fps_k:.0f} frames/s / ({num_simds} SIMDs x {clock} GHz -- the clock rocprofv3 measured in the committed profile run, "
+                                  "not this run's)", "source": valu.get("source")})
         else:
-            rf.update({"bound": "valu_issue", "achieved": None, "peak": None, "unit": "T wave-instructions/s", "frac": None, "valu_issue_frac": None,
-                       "valu_issue_basis": "no committed SQ counters for this workload (profiles/LATEST)"})
-        rf["binding_resource"] = ("fp64 VALU issue (co-limited by the LDS pipe, ~55 % busy, and by dependent LDS / table chains) -- NOT HBM: 5 KB per 0.35 MFLOP frame "
-                                  "(SURVEY F9).  `frac` = share of the SIMDs' issue cycles the kernel's vector instructions occupy; `hbm_frac` is the figure BASELINE.json asks for")
-        rf["valu_issue"] = valu
+            util.update({"counter_valu_busy_per_simd": None, "this_run_from_instruction_classes": None, "basis": "no committed SQ counters for this workload (profiles/LATEST)"})
+        rf["valu_issue_utilisation"] = util
+        rf["binding_resource"] = ("the vector ALU: 5 KB of compulsory HBM traffic per 0.35 MFLOP frame (SURVEY F9) leaves HBM at ~2 % of its peak.  `frac` is the "
+                                  "algorithmic fp64 fraction; the gap between it and `valu_issue_utilisation` is instructions that are not algorithmic fp64 arithmetic "
+                                  "(selects, compares, moves, integer and address work, division and logarithm expansions: DESIGN.md section 4)")
         return rf
 
     def roofline_mixed(run_d, S_, F_, psy_k):
@@ -513,10 +607,7 @@ def main():
                        "source": "hipEvents on the launch stream inside the library (tlb_last_stage_ms), last timed launch"}
         label, cfg_k = workload_label(S, psy, args.mode, F, world, mixed)
         rf = roofline(head, S, F, psy, args.mode)
-        rf.update({"kernel": kname, "kernels_ms": kernels,
-                   "secondary_fp64": {"achieved_tflops": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 1e12, 3), "peak_tflops": 78.6,
-                                      "frac": round(0.35e6 * (S * F / (kernel_ms * 1e-3)) / 78.6e12, 5),
-                                      "basis": "0.35 MFLOP algorithmic fp64 per stereo frame (SURVEY 8d), vector fp64 peak"}})
+        rf.update({"kernel": kname, "kernels_ms": kernels})
         checked["per_rank_ok"] = [p[2] == 1.0 for p in per_rank]
         res = {
             "metric": "real-time stereo DAB MP2 streams sustained (frames/s) @128 kbps/48 kHz" if not mixed else
@@ -630,7 +721,16 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 also["tick_pipeline"][str(nt2)] = {"value": None, "error": str(ex)}
         res["also"] = also
+    if rank == 0 and world == 1 and args.in_process > 0:
+        try:
+            res["node"] = node_in_process(M, np, gen_pcm, args.in_process, S, F, psy, args.mode, ndev, args.warmup, args.steps, mixed)
+        except AssertionError:
+            raise
+        except Exception as ex:  # noqa: BLE001
+            res["node"] = {"value": None, "error": str(ex)}
     if rank == 0:
+        if had_group:
+            res["collectives_executed"] = ["init_process_group(device_id)", "barrier", "all_reduce(MAX)", "all_gather"]
         res["setup_s"] = round(time.time() - t0, 1)
         if not args.no_cpu_baseline:         # rank 0's host cores, after every rank's timed region (N > 1: the configs[3] model, psy 3)
             res["cpu_baseline"] = cpu_baseline(psy, args.mode)
@@ -647,7 +747,7 @@ def dry_run(args, shard, np, gen_pcm, world, S, psy, F):
     """The same rank plumbing (env, process group, barriers, max-over-ranks, gather, rank-0 line) with the TEST-ONLY
     emulation of the kernel standing in for the GPU, over gloo.  Not a measurement."""
     import emulib as E
-    rank, local_rank, world_env, dist = shard.init_from_env("gloo")
+    rank, local_rank, world_env, dist = shard.init_from_env("gloo", force=args.force_group)
     assert world_env == world
     ids = list(shard.weak_stream_ids(rank, S))
     pcm = np.stack([gen_pcm(i, 0, 0, 2 * F) for i in ids], axis=1)

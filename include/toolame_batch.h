@@ -43,7 +43,7 @@ int toolame_encode_frame(short buffer[2][1152], unsigned char *xpad_data, size_t
 /* ---------------------------------------------------------------------------------------------
  * (2) batched API
  * ------------------------------------------------------------------------------------------ */
-#define TLB_MAX_XPAD 200           /* X-PAD + F-PAD bytes per frame */
+#define TLB_MAX_XPAD 256           /* X-PAD + F-PAD bytes per frame: every padlen the caller accepts, 0..255 (src/odr-audioenc.cpp:566) */
 #define TLB_SAMPLES_PER_FRAME 1152
 
 enum {
@@ -76,15 +76,20 @@ int tlb_device_count(void);
  * code in *err (if err != NULL). */
 tlb_batch *tlb_create(int device, int nstreams, const tlb_stream_config *cfgs, int *err);
 void tlb_destroy(tlb_batch *b);
-int tlb_reset(tlb_batch *b);                       /* every stream back to the state right after tlb_create() */
+int tlb_reset(tlb_batch *b);                       /* every stream back to the state right after tlb_create(); also the way out after a launch
+                                                      failed half way (TLB_ERR_HIP from an encode call: the batch refuses work until reset) */
 
 /* Life cycle of ONE stream inside a live batch.  The reference's unit of restart is the stream -- toolame_init() zeroes one encoder
  * (toolame.c:120-153), toolame_finish() ends one (:155-166), the six setters reconfigure one (toolame.h:13-48), and odr-audioenc
  * restarts a failed input without touching anything else (src/odr-audioenc.cpp:875-902).  With thousands of streams in one batch the
  * same three operations exist per stream.  Each waits for the launches already queued on the batch, then acts; none changes a byte
- * any OTHER stream produces.  After any of them the stream is as right after tlb_create(): its next input frame is its frame 0
+ * any OTHER stream produces.  After any of them the stream is as right after tlb_create() -- the bytes of a reference process started
+ * afresh, not those of an in-process toolame_init() --: its next input frame is its frame 0
  * (history of zeros, no pending frame: the output slot of the call that analyses it is empty, length 0 in the _len variants).
- *   tlb_stream_reset        = toolame_init(): drops the pending frame.
+ *   tlb_stream_reset        = a freshly started reference PROCESS for that stream: drops the pending frame, zeroes filterbank and
+ *                             model history.  (The reference's own toolame_init(), toolame.c:120-153, called a second time inside one
+ *                             process, keeps the file-scope statics of psycho_1/2 -- savebuf, r, phi_sav, lthr, init -- and the
+ *                             filterbank FIFO: a re-initialised reference encoder remembers its past, this one does not.)
  *   tlb_stream_finish       = toolame_finish(): copies the pending frame (the bytes still inside the encoder) to out, returns their
  *                             number (0: none yet; a too small buffer gets a truncated copy like the reference's); < 0: -TLB_ERR_*.
  *   tlb_stream_reconfigure  = the setters + toolame_init(): a new sample rate / mode / bitrate / psy model / PAD length.  The frames
@@ -282,12 +287,14 @@ int16_t *tlb_tick_pcm(tlb_tick *t);
 uint8_t *tlb_tick_xpad(tlb_tick *t);
 int32_t *tlb_tick_xpad_len(tlb_tick *t);
 int tlb_tick_run(tlb_tick *t);                 /* = tlb_tick_submit() + tlb_tick_wait() */
-/* Ticks overlapped: the object owns TWO sets of pinned host buffers.  tlb_tick_submit() queues a tick on the input set the caller has
+/* Ticks overlapped: the object owns TWO sets of pinned host input buffers (and three of outputs).  tlb_tick_submit() queues a tick on the input set the caller has
  * just filled and returns at once; from then on tlb_tick_pcm() / _xpad() / _xpad_len() point at the OTHER input set, which the caller
  * fills while the submitted tick is on its way (odr-audioenc decouples capture from encoding with its input queue,
  * src/odr-audioenc.cpp:904-986).  tlb_tick_wait() waits for the oldest submitted tick; the read accessors (tlb_tick_peaks, _frame,
- * _packet, _message, _fragment, _silence_ms) then show ITS results until the next wait.  At most two ticks in flight: submit, submit,
- * wait, submit, wait ...  Inside, tick t + 1's copy-in starts as soon as tick t's ingest kernel has consumed the device input buffer,
+ * _packet, _message, _fragment, _silence_ms) then show ITS results until the next wait -- the object keeps THREE sets of output buffers, so
+ * neither of the two submits that may come before that wait touches them (a sender thread may ship them zero-copy).  Inputs: while two
+ * ticks are in flight both input sets belong to queued copies and tlb_tick_pcm() / _xpad() / _xpad_len() return NULL; after the wait
+ * the set of the retired tick is handed out again.  At most two ticks in flight: submit, submit, wait, submit, wait ...  Inside, tick t + 1's copy-in starts as soon as tick t's ingest kernel has consumed the device input buffer,
  * so the host-to-device link -- the limit at large stream counts -- never idles between ticks.  The RE-FETCH rule: call tlb_tick_pcm()
  * again after every submit / run, the pointer alternates. */
 int tlb_tick_submit(tlb_tick *t);
@@ -303,6 +310,96 @@ const uint32_t *tlb_tick_silence_ms(const tlb_tick *t);      /* uint32 [nstreams
 int tlb_tick_fragments(const tlb_tick *t, int stream, int unit);
 const uint8_t *tlb_tick_fragment(const tlb_tick *t, int stream, int unit, int k, int *len);
 float tlb_tick_last_ms(tlb_tick *t);           /* first copy-in queued -> last copy-out done of the last run, device clock */
+
+/* ---------------------------------------------------------------------------------------------
+ * (3) node level: every GPU of one host behind one handle (csrc/tlb_node.cpp)
+ *
+ * odr-audioenc is one process per service: AudioEnc::run() (src/odr-audioenc.cpp:819-1276) owns one input, one encoder, one set
+ * of outputs.  A head-end that carries a fleet of services on one machine needs the step above: N streams cut into contiguous
+ * blocks, block g = streams [g*N/G, (g+1)*N/G) on GPU g (section 8e), one host thread and one tlb_tick (or tlb_batch) per block,
+ * nothing shared between blocks -- streams are independent, there is no collective on the data path -- and the counters added up.
+ * A "shard" is such a block; `devices[g]` names the HIP device of shard g, and the same device may appear more than once (two
+ * shards on one GPU behave as on two).  Every call below that acts on all shards runs on the shards' own threads in parallel and
+ * returns when all of them have returned; the first non-zero code wins.  A stream keeps its node-wide index in every accessor.
+ *
+ * Two planes, chosen at creation:
+ *   TLB_NODE_TICK   the real-time loop: a tlb_tick per shard, host buffers in, packets out (everything of tlb_tick_* per stream).
+ *   TLB_NODE_BATCH  device-resident buffers: a tlb_batch per shard, tlb_node_encode_device() takes one device pointer per shard.
+ * ------------------------------------------------------------------------------------------ */
+#define TLB_NODE_TICK 0
+#define TLB_NODE_BATCH 1
+typedef struct tlb_node tlb_node;
+typedef struct {
+    int plane;                     /* TLB_NODE_TICK / TLB_NODE_BATCH */
+    tlb_tick_config tick;          /* TICK plane: egress, groups per shard, X-PAD, EDI / PFT parameters (as for tlb_tick_create) */
+} tlb_node_config;
+typedef struct {
+    int shard, device;             /* total record: shard = -1, device = -1 */
+    int first, nstreams;           /* the block [first, first + nstreams) */
+    long steps;                    /* ticks waited for (TICK) / encode calls completed by tlb_node_sync (BATCH) */
+    long frames;                   /* (stream, frame) pairs encoded: sum over steps of nstreams * frames per step */
+    double busy_ns;                /* host clock, this shard: submit (encode call) -> its results waited for (synced), summed; two ticks in flight overlap */
+    double device_ms;              /* device clock: tlb_tick_last_ms() / tlb_last_kernel_ms() summed over the steps */
+    double wall_ns;                /* total record only: first submit -> last wait as the node saw them, summed over steps */
+} tlb_node_counter;
+
+/* Pure arithmetic, no GPU: the block of shard g, and what tlb_create() will make of it -- the number of distinct configurations,
+ * the streams per kernel list (psy model 0, 1, 2 (with 4), 3: each list is one homogeneous launch) and the mono streams that share
+ * waves in pairs.  Returns 0, or the TLB_ERR_* code of the first illegal configuration in the block. */
+void tlb_node_partition(int nstreams, int nshards, int shard, int *first, int *n);
+int tlb_node_plan_shard(int nstreams, const tlb_stream_config *cfgs, int nshards, int shard,
+                        int *first, int *n, int *nconfigs, int list_sizes[4], int *mono_pairs);
+
+tlb_node *tlb_node_create(int nshards, const int *devices, int nstreams, const tlb_stream_config *cfgs, const tlb_node_config *nc, int *err);
+void tlb_node_destroy(tlb_node *nd);
+int tlb_node_nshards(const tlb_node *nd);
+int tlb_node_nstreams(const tlb_node *nd);
+int tlb_node_shard_of(const tlb_node *nd, int stream);
+/* per_shard: [nshards] records or NULL; total: the sum (frames, steps of shard 0, max busy_ns, wall_ns) or NULL */
+int tlb_node_counters(const tlb_node *nd, tlb_node_counter *per_shard, tlb_node_counter *total);
+/* Run fn(ctx, shard, first, n) once per shard ON THAT SHARD'S THREAD, all at once, and wait: the caller's own per-block work --
+ * filling the pinned PCM of a block from its inputs, shipping a block's packets -- parallel over the shards without a second pool. */
+int tlb_node_parallel(tlb_node *nd, void (*fn)(void *ctx, int shard, int first, int n), void *ctx);
+
+/* TICK plane.  tlb_node_pcm(stream) is that stream's int16[2304] slot (interleaved s16le) in its shard's current input set, NULL
+ * while two ticks are in flight (see tlb_tick_pcm); the shards tick in lockstep, so submit / wait / run / finish follow the rules
+ * of tlb_tick_submit / _wait / _run / _finish.  The read accessors are tlb_tick_*'s with node-wide stream indices. */
+int16_t *tlb_node_pcm(tlb_node *nd, int stream);
+uint8_t *tlb_node_xpad(tlb_node *nd, int stream);            /* uint8[TLB_MAX_XPAD] */
+int32_t *tlb_node_xpad_len(tlb_node *nd, int stream);
+int tlb_node_submit(tlb_node *nd);
+int tlb_node_wait(tlb_node *nd);
+int tlb_node_run(tlb_node *nd);
+int tlb_node_finish(tlb_node *nd);
+int tlb_node_units(const tlb_node *nd, int stream);
+const int16_t *tlb_node_peaks(const tlb_node *nd, int stream);          /* int16[2] */
+uint32_t tlb_node_silence_ms(const tlb_node *nd, int stream);
+const uint8_t *tlb_node_frame(const tlb_node *nd, int stream, int *len);
+const uint8_t *tlb_node_packet(const tlb_node *nd, int stream, int unit, int *len);
+const uint8_t *tlb_node_message(const tlb_node *nd, int stream, int unit, int *len);
+int tlb_node_fragments(const tlb_node *nd, int stream, int unit);
+const uint8_t *tlb_node_fragment(const tlb_node *nd, int stream, int unit, int k, int *len);
+/* both planes: gain and the life cycle of one stream (tlb_stream_* / tlb_tick_stream_* of its shard) */
+int tlb_node_set_gain_db(tlb_node *nd, int stream, double gain_db);     /* stream = -1: all */
+int tlb_node_stream_reset(tlb_node *nd, int stream);
+int tlb_node_stream_finish(tlb_node *nd, int stream, uint8_t *out, size_t out_size);
+int tlb_node_stream_reconfigure(tlb_node *nd, int stream, const tlb_stream_config *cfg);
+
+/* BATCH plane.  tlb_node_batch(shard) is the shard's tlb_batch (sizes: tlb_out_stride, tlb_frame_bytes; do not encode on it
+ * directly).  Device memory of a shard's GPU for callers without a HIP toolchain: tlb_node_device_alloc / _free / _copy_in / _copy_out
+ * (synchronous).  tlb_node_encode_device(): element g of every pointer array is shard g's buffer, laid out as tlb_encode_device_len
+ * wants it for THAT shard's streams ([nframes][n_g]...); d_xpad / d_xpad_len / d_out_len may be NULL (or hold NULL elements).  Each
+ * shard's launch is queued on the shard's own HIP stream by the shard's thread; the call returns when all are queued,
+ * tlb_node_sync() when all have finished.  tlb_node_flush_device(): the pending frames, tlb_flush_device_len per shard. */
+tlb_batch *tlb_node_batch(tlb_node *nd, int shard);
+void *tlb_node_device_alloc(tlb_node *nd, int shard, size_t bytes);
+void tlb_node_device_free(tlb_node *nd, int shard, void *d_ptr);
+int tlb_node_copy_in(tlb_node *nd, int shard, void *d_dst, const void *src, size_t bytes);
+int tlb_node_copy_out(tlb_node *nd, int shard, void *dst, const void *d_src, size_t bytes);
+int tlb_node_encode_device(tlb_node *nd, const int16_t *const *d_pcm, int nframes, const uint8_t *const *d_xpad,
+                           const int32_t *const *d_xpad_len, uint8_t *const *d_out, int32_t *const *d_out_len);
+int tlb_node_flush_device(tlb_node *nd, uint8_t *const *d_out, int32_t *const *d_out_len);
+int tlb_node_sync(tlb_node *nd);
 
 /* Diagnostic only: per-stage cycle stamps [nframes][nstreams][32] (csrc/mp2_wave.h TL_STAMP), host buffers. */
 int tlb_encode_host_stamps(tlb_batch *b, const int16_t *pcm, int nframes, long long *stamps);

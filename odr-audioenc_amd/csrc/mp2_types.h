@@ -10,7 +10,7 @@
 #define TL_MAX_FRAME_BYTES 1728      // 384 kbps @ 32 kHz
 #define TL_MAX_FRAME_WORDS (TL_MAX_FRAME_BYTES / 4)
 #define TL_HIST 480                  // filterbank history (512-32); psy-1/3 need the last 192
-#define TL_MAX_XPAD 200              // X-PAD + F-PAD bytes per frame handled on device
+#define TL_MAX_XPAD 256              // X-PAD + F-PAD bytes per frame handled on device (the caller accepts padlen 0..255, src/odr-audioenc.cpp:566)
 
 // The part of the common tables that sits on dependent-load chains (dB sums, scalefactor search,
 // allocation loop): copied once per workgroup into LDS and shared by its waves.

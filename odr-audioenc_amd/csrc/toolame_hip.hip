@@ -367,6 +367,8 @@ struct tlb_batch {
     bool list_pairs[4] = {false, false, false, false};   // the model's list contains mono streams paired in one wave (kernel variant <.., true>)
     int32_t *d_work = nullptr;                   // unit counters of the persistent kernels
     bool work_clean = false;                     // ... are zero (tl_finish_kernel zeroes them after use)
+    bool broken = false;                         // a launch or a reconfiguration failed half way: stream state, psy-2 state copies and lists may disagree;
+                                                 // every further launch is refused (TLB_ERR_HIP) until tlb_reset() has put all streams back to zero
     int num_cu = 256;
 };
 
@@ -402,7 +404,15 @@ int tlb_lds_bytes_per_stream(void)
     if (sizeof(TlPsy2Lds) > m) m = sizeof(TlPsy2Lds);
     return (int)m;
 }
-const char *tlb_version(void) { return "odr-audioenc_amd 0.3 (gfx950, a wavefront per (stream, frame), fp64, glibc 2.35 transcendentals)"; }
+#define TLB_STR2(x) #x
+#define TLB_STR(x) TLB_STR2(x)
+// names the toolchain the kernels came out of: their shape (registers, LDS instruction forms) depends on compiler internals that
+// csrc/Makefile sets and tools/check_isa.py verifies on the linked code objects at build time
+const char *tlb_version(void)
+{
+    return "odr-audioenc_amd 0.5 (gfx950, a wavefront per (stream, frame), fp64, glibc 2.35 transcendentals; built with HIP "
+           TLB_STR(HIP_VERSION_MAJOR) "." TLB_STR(HIP_VERSION_MINOR) "." TLB_STR(HIP_VERSION_PATCH) ", clang " __clang_version__ ", ISA guard passed)";
+}
 
 void tlb_destroy(tlb_batch *b)
 {
@@ -590,7 +600,7 @@ int tlb_reset(tlb_batch *b)
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipDeviceSynchronize());
     if (int rc = batch_clear_streams(b, 0, b->nstreams)) return rc;
-    b->frames = 0;
+    b->frames = 0; b->psy2_flip = 0; b->work_clean = false; b->broken = false;
     return TLB_OK;
 }
 
@@ -642,21 +652,35 @@ int tlb_stream_reconfigure(tlb_batch *b, int stream, const tlb_stream_config *cf
     }
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipDeviceSynchronize());
+    // "nothing changed" on failure: the device side of a NEW record is prepared first -- a bigger array filled completely before the
+    // old one is let go, or the record written into a free slot no stream refers to yet -- and only then do the host lists learn of it.
     if (found < 0) {
-        b->h_uniq.push_back(*cfg); b->h_configs.push_back(c);
-        found = (int)b->h_configs.size() - 1;
-        if (b->h_configs.size() > b->cfg_cap) {
+        const size_t n_old = b->h_configs.size();
+        if (n_old + 1 > b->cfg_cap) {
             TlConfig *nd = nullptr;
-            const size_t cap = 2 * b->h_configs.size();
+            const size_t cap = 2 * (n_old + 1);
             HIPCHK(hipMalloc(&nd, sizeof(TlConfig) * cap));
-            (void)hipFree(b->d_configs);
+            hipError_t e = hipMemcpy(nd, b->h_configs.data(), sizeof(TlConfig) * n_old, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(nd + n_old, &c, sizeof(TlConfig), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { (void)hipFree(nd); HIPCHK(e); }
+            (void)hipFree(b->d_configs);                             // (the device is idle: hipDeviceSynchronize above)
             b->d_configs = nd; b->cfg_cap = cap;
-            HIPCHK(hipMemcpy(b->d_configs, b->h_configs.data(), sizeof(TlConfig) * b->h_configs.size(), hipMemcpyHostToDevice));
-        } else HIPCHK(hipMemcpy(b->d_configs + found, &b->h_configs[(size_t)found], sizeof(TlConfig), hipMemcpyHostToDevice));
+        } else HIPCHK(hipMemcpy(b->d_configs + n_old, &c, sizeof(TlConfig), hipMemcpyHostToDevice));
+        b->h_uniq.push_back(*cfg); b->h_configs.push_back(c);
+        found = (int)n_old;
     }
+    {
+        const int32_t f32 = found;
+        HIPCHK(hipMemcpy(b->d_stream_cfg + stream, &f32, sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    const int32_t before = b->h_stream_cfg[(size_t)stream];
     b->h_stream_cfg[(size_t)stream] = found;
-    HIPCHK(hipMemcpy(b->d_stream_cfg + stream, &b->h_stream_cfg[(size_t)stream], sizeof(int32_t), hipMemcpyHostToDevice));
-    if (int rc = batch_build_lists(b)) return rc;
+    if (int rc = batch_build_lists(b)) {
+        // the lists are rebuilt from the host table: put the stream back and rebuild; if even that fails the batch is marked broken
+        b->h_stream_cfg[(size_t)stream] = before;
+        if (hipMemcpy(b->d_stream_cfg + stream, &before, sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess || batch_build_lists(b)) b->broken = true;
+        return rc;
+    }
     if (b->d_frame_bytes) {                                          // EDI egress: per-stream frame and unit sizes
         const int32_t fb = c.frame_bytes, ub = 3 * c.kbps;
         HIPCHK(hipMemcpy(b->d_frame_bytes + stream, &fb, sizeof fb, hipMemcpyHostToDevice));
@@ -675,7 +699,12 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
 {
     if (!b || !d_pcm || !d_out || nframes <= 0) return TLB_ERR_ARG;
     for (int p = 0; p < 4; p++) if ((long)b->n_list[p] * nframes > (1L << 30)) return TLB_ERR_ARG;   // unit indices are 32-bit; checked for every model before anything is queued
+    if (b->broken) { fprintf(stderr, "libtoolame-dab-hip: this batch had a launch fail half way; tlb_reset() it before encoding on\n"); return TLB_ERR_HIP; }
     HIPCHK(hipSetDevice(b->device));
+    // From the first kernel on the streams' state is in motion.  If anything below fails, the psy-2 state copy the next launch would
+    // read may never have been written and the unit counters may be non-zero: the flip is taken back, the counters are re-zeroed by
+    // the next launch, and the batch refuses further work until tlb_reset().
+    struct Guard { tlb_batch *b; int flip; bool ok; ~Guard() { if (!ok) { b->psy2_flip = flip; b->work_clean = false; b->broken = true; } } } guard_{b, b->psy2_flip, false};
     TlLaunch A;
     memset(&A, 0, sizeof A);
     A.tables = b->d_tables; A.configs = b->d_configs; A.stream_cfg = b->d_stream_cfg; A.state = b->d_state;
@@ -707,7 +736,6 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
             const int nunits = tl_psy2_plan(b->n_chain, nframes, b->num_cu * TL_PSY2_WAVES, &A.p2_nwhole, &A.p2_k, &A.p2_plen);
             qb = ((long)nunits + TL_PSY2_WAVES - 1) / TL_PSY2_WAVES;
             if (qb > b->num_cu) qb = b->num_cu;
-            b->psy2_flip ^= 1;
         }
         if (p == 1 || p == 3) {                                      // psy model and encoder in one kernel
             long mb1 = (units + TL_MAIN_WAVES - 1) / TL_MAIN_WAVES;
@@ -739,6 +767,8 @@ static int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uin
         b->work_clean = true;
     }
     HIPCHK(hipEventRecord(b->ev1, st));
+    if (b->n_list[2]) b->psy2_flip ^= 1;         // only now: every kernel that writes the other copy has been queued
+    guard_.ok = true;
     b->last_stream = st; b->timed = true;
     b->frames += nframes;
     return TLB_OK;
@@ -1273,10 +1303,12 @@ struct TickGroup {
     uint16_t *d_pseq = nullptr; uint8_t *d_frags = nullptr; int32_t *d_fraglen = nullptr, *d_nfrag = nullptr;
     uint8_t *d_msgs = nullptr; int msg_stride = 0;              // ZeroMQ egress
     uint32_t *d_silence = nullptr;                              // milliseconds of digital silence so far, per stream
-    // this group's slices of the pinned host outputs, two sets: a tick's results land in set (tick & 1) while the caller may still read the other
-    uint8_t *h_frames[2] = {}; int32_t *h_flen[2] = {}; uint8_t *h_pkts[2] = {}; int32_t *h_plen[2] = {};
-    uint8_t *h_frags[2] = {}; int32_t *h_fraglen[2] = {}, *h_nfrag[2] = {};
-    uint8_t *h_msgs[2] = {};
+    // this group's slices of the pinned host outputs, THREE sets: tick n's results land in set n % 3.  With two ticks in flight the
+    // caller is still reading tick n (valid until the next wait) while tick n + 1 is on its way and tick n + 2 is being submitted:
+    // three sets make "until the next wait" true without a copy (two sets let submit n + 2 overwrite what tick n showed)
+    uint8_t *h_frames[3] = {}; int32_t *h_flen[3] = {}; uint8_t *h_pkts[3] = {}; int32_t *h_plen[3] = {};
+    uint8_t *h_frags[3] = {}; int32_t *h_fraglen[3] = {}, *h_nfrag[3] = {};
+    uint8_t *h_msgs[3] = {};
     hipEvent_t ev_in = nullptr, ev_run = nullptr;
     hipEvent_t ev_ingested = nullptr, ev_encoded = nullptr, ev_out = nullptr;   // the group's device buffers are single: the next tick's copy-in waits for this tick's
                                                                                 // ingest (d_inter) / encode (X-PAD), its kernels for this tick's copy-out
@@ -1287,15 +1319,16 @@ struct tlb_tick {
     int fec = 0, chunk_len = 207, transport = 0, addr_source = 0, dest_port = 0;
     std::vector<TickGroup> groups;
     std::vector<int> group_of;                   // stream -> group
-    // pinned host buffers in two sets (tlb_tick_submit / tlb_tick_wait): the caller fills input set `in_set` while the tick submitted
-    // before is still on its way; results are read from `out_set`, the set of the tick waited for last
-    int16_t *h_inter[2] = {}, *h_peaks[2] = {}; uint8_t *h_xpad[2] = {}; int32_t *h_xl[2] = {};
-    uint32_t *h_silence[2] = {};
+    // pinned host buffers (tlb_tick_submit / tlb_tick_wait): two INPUT sets -- the caller fills input set `in_set` while the tick
+    // submitted before is still on its way (with two ticks in flight neither set is free: the input accessors return NULL) -- and
+    // three OUTPUT sets; results are read from `out_set`, the set of the tick waited for last
+    int16_t *h_inter[2] = {}, *h_peaks[3] = {}; uint8_t *h_xpad[2] = {}; int32_t *h_xl[2] = {};
+    uint32_t *h_silence[3] = {};
     int in_set = 0, out_set = 0;
     long waited = 0;                             // ticks whose results have been waited for (ticks: submitted)
     std::vector<void *> pinned, dev;
     hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
-    hipEvent_t ev0[2] = {}, ev1[2] = {};
+    hipEvent_t ev0[3] = {}, ev1[3] = {};          // per output set: first copy-in queued / last copy-out done
     long ticks = 0;
     bool finished = false;
 };
@@ -1320,7 +1353,7 @@ void tlb_tick_destroy(tlb_tick *t)
     if (t->s_in) (void)hipStreamDestroy(t->s_in);
     if (t->s_run) (void)hipStreamDestroy(t->s_run);
     if (t->s_out) (void)hipStreamDestroy(t->s_out);
-    for (int k = 0; k < 2; k++) { if (t->ev0[k]) (void)hipEventDestroy(t->ev0[k]); if (t->ev1[k]) (void)hipEventDestroy(t->ev1[k]); }
+    for (int k = 0; k < 3; k++) { if (t->ev0[k]) (void)hipEventDestroy(t->ev0[k]); if (t->ev1[k]) (void)hipEventDestroy(t->ev1[k]); }
     delete t;
 }
 
@@ -1364,18 +1397,21 @@ static int tick_create_impl(tlb_tick *t, int device, int nstreams, const tlb_str
     HIPCHK(hipSetDevice(device));
     auto pin = [&](size_t bytes) -> void * { void *p = nullptr; if (hipHostMalloc(&p, bytes ? bytes : 4, hipHostMallocDefault) != hipSuccess) return nullptr; memset(p, 0, bytes ? bytes : 4); t->pinned.push_back(p); return p; };
     auto dev = [&](size_t bytes) -> void * { void *p = nullptr; if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr; (void)hipMemset(p, 0, bytes ? bytes : 4); t->dev.push_back(p); return p; };
-    uint8_t *h_msgs[2], *h_frames[2], *h_pkts[2], *h_frags[2]; int32_t *h_flen[2], *h_plen[2], *h_fraglen[2], *h_nfrag[2];
+    uint8_t *h_msgs[3], *h_frames[3], *h_pkts[3], *h_frags[3]; int32_t *h_flen[3], *h_plen[3], *h_fraglen[3], *h_nfrag[3];
     for (int k = 0; k < 2; k++) {
         t->h_inter[k] = (int16_t *)pin((size_t)nstreams * 2304 * sizeof(int16_t));
-        t->h_peaks[k] = (int16_t *)pin((size_t)nstreams * 2 * sizeof(int16_t));
         t->h_xpad[k] = (uint8_t *)pin(t->with_xpad ? (size_t)nstreams * TL_MAX_XPAD : 0);
         t->h_xl[k] = (int32_t *)pin(t->with_xpad ? (size_t)nstreams * sizeof(int32_t) : 0);
+        if (!t->h_inter[k] || !t->h_xpad[k] || !t->h_xl[k]) return TLB_ERR_HIP;
+    }
+    for (int k = 0; k < 3; k++) {
+        t->h_peaks[k] = (int16_t *)pin((size_t)nstreams * 2 * sizeof(int16_t));
         t->h_silence[k] = (uint32_t *)pin((size_t)nstreams * sizeof(uint32_t));
         h_msgs[k] = (uint8_t *)pin(n_msgs);
         h_frames[k] = (uint8_t *)pin(n_frames); h_flen[k] = (int32_t *)pin((size_t)nstreams * sizeof(int32_t));
         h_pkts[k] = (uint8_t *)pin(n_pkts); h_plen[k] = (int32_t *)pin(n_slots * sizeof(int32_t));
         h_frags[k] = (uint8_t *)pin(n_frags); h_fraglen[k] = (int32_t *)pin(n_fragslots * sizeof(int32_t)); h_nfrag[k] = (int32_t *)pin(n_slots * sizeof(int32_t));
-        if (!t->h_inter[k] || !t->h_peaks[k] || !t->h_xpad[k] || !t->h_xl[k] || !t->h_silence[k] || !h_msgs[k] || !h_frames[k] || !h_flen[k] || !h_pkts[k] || !h_plen[k] ||
+        if (!t->h_peaks[k] || !t->h_silence[k] || !h_msgs[k] || !h_frames[k] || !h_flen[k] || !h_pkts[k] || !h_plen[k] ||
             !h_frags[k] || !h_fraglen[k] || !h_nfrag[k]) return TLB_ERR_HIP;
     }
     std::vector<tlb_edi_state> st0;
@@ -1390,12 +1426,12 @@ static int tick_create_impl(tlb_tick *t, int device, int nstreams, const tlb_str
         G.d_pseq = (uint16_t *)dev(n * 2);
         G.d_msgs = (uint8_t *)dev(slots * (size_t)G.msg_stride); G.d_silence = (uint32_t *)dev(n * 4);
         if (!G.d_msgs || !G.d_silence) return TLB_ERR_HIP;
-        for (int k = 0; k < 2; k++) G.h_msgs[k] = h_msgs[k] + o_msgs;
+        for (int k = 0; k < 3; k++) G.h_msgs[k] = h_msgs[k] + o_msgs;
         o_msgs += slots * (size_t)G.msg_stride;
         G.d_frags = (uint8_t *)dev(slots * (size_t)G.max_frags * (size_t)G.frag_stride); G.d_fraglen = (int32_t *)dev(slots * (size_t)G.max_frags * 4); G.d_nfrag = (int32_t *)dev(slots * 4);
         if (!G.d_inter || !G.d_pcm || !G.d_peaks || !G.d_xpad || !G.d_xl || !G.d_frames || !G.d_flen || !G.d_state || !G.d_pkts || !G.d_plen || !G.d_pseq ||
             !G.d_frags || !G.d_fraglen || !G.d_nfrag) return TLB_ERR_HIP;
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < 3; k++) {
             G.h_frames[k] = h_frames[k] + o_frames; G.h_flen[k] = h_flen[k] + G.first; G.h_pkts[k] = h_pkts[k] + o_pkts; G.h_plen[k] = h_plen[k] + o_slots;
             G.h_frags[k] = h_frags[k] + o_frags; G.h_fraglen[k] = h_fraglen[k] + o_fragslots; G.h_nfrag[k] = h_nfrag[k] + o_slots;
         }
@@ -1413,7 +1449,7 @@ static int tick_create_impl(tlb_tick *t, int device, int nstreams, const tlb_str
     HIPCHK(hipStreamCreateWithFlags(&t->s_in, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&t->s_run, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&t->s_out, hipStreamNonBlocking));
-    for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreate(&t->ev0[k])); HIPCHK(hipEventCreate(&t->ev1[k])); }
+    for (int k = 0; k < 3; k++) { HIPCHK(hipEventCreate(&t->ev0[k])); HIPCHK(hipEventCreate(&t->ev1[k])); }
     return TLB_OK;
 }
 
@@ -1427,9 +1463,13 @@ tlb_tick *tlb_tick_create(int device, int nstreams, const tlb_stream_config *cfg
     return t;
 }
 
-int16_t *tlb_tick_pcm(tlb_tick *t) { return t ? t->h_inter[t->in_set] : nullptr; }
-uint8_t *tlb_tick_xpad(tlb_tick *t) { return t && t->with_xpad ? t->h_xpad[t->in_set] : nullptr; }
-int32_t *tlb_tick_xpad_len(tlb_tick *t) { return t && t->with_xpad ? t->h_xl[t->in_set] : nullptr; }
+// The input accessors hand out the set the NEXT submit will read.  With two ticks in flight both sets belong to queued copy-ins (the
+// set these would name is the one the older tick's host-to-device copy may still be reading): NULL until tlb_tick_wait() has
+// retired that tick -- no submit is possible in that state anyway.
+static bool tick_input_free(const tlb_tick *t) { return t && !t->finished && t->ticks - t->waited < 2; }
+int16_t *tlb_tick_pcm(tlb_tick *t) { return tick_input_free(t) ? t->h_inter[t->in_set] : nullptr; }
+uint8_t *tlb_tick_xpad(tlb_tick *t) { return tick_input_free(t) && t->with_xpad ? t->h_xpad[t->in_set] : nullptr; }
+int32_t *tlb_tick_xpad_len(tlb_tick *t) { return tick_input_free(t) && t->with_xpad ? t->h_xl[t->in_set] : nullptr; }
 const int16_t *tlb_tick_peaks(const tlb_tick *t) { return t ? t->h_peaks[t->out_set] : nullptr; }
 long tlb_tick_count(const tlb_tick *t) { return t ? t->ticks : 0; }
 int tlb_tick_set_gain_db(tlb_tick *t, int stream, double gain_db)
@@ -1521,7 +1561,8 @@ int tlb_tick_submit(tlb_tick *t)
     if (!t || t->finished || t->ticks - t->waited >= 2) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(t->device));
     const int set = (int)(t->ticks & 1);                             // == in_set: ticks and input sets alternate together
-    HIPCHK(hipEventRecord(t->ev0[set], t->s_in));
+    const int oset = (int)(t->ticks % 3);                            // output set: the caller may still be reading tick - 2's
+    HIPCHK(hipEventRecord(t->ev0[oset], t->s_in));
     for (auto &G : t->groups) {
         const size_t n = (size_t)G.n;
         int rc = TLB_OK;
@@ -1539,21 +1580,22 @@ int tlb_tick_submit(tlb_tick *t)
         if (!rc && hipEventRecord(G.ev_ingested, t->s_run) != hipSuccess) rc = TLB_ERR_HIP;
         if (!rc) rc = tlb_launch(G.b, G.d_pcm, 1, t->with_xpad ? G.d_xpad : nullptr, t->with_xpad ? G.d_xl : nullptr, G.d_frames, nullptr, t->s_run, nullptr, G.d_flen);
         if (!rc && hipEventRecord(G.ev_encoded, t->s_run) != hipSuccess) rc = TLB_ERR_HIP;
-        if (!rc) rc = tick_egress(t, G, t->ticks > 0, set);
+        if (!rc) rc = tick_egress(t, G, t->ticks > 0, oset);
         if (rc) { tick_drain(t); return rc; }
     }
-    if (hipEventRecord(t->ev1[set], t->s_out) != hipSuccess) { tick_drain(t); return TLB_ERR_HIP; }
+    if (hipEventRecord(t->ev1[oset], t->s_out) != hipSuccess) { tick_drain(t); return TLB_ERR_HIP; }
     t->ticks++;
     t->in_set = (int)(t->ticks & 1);
     return TLB_OK;
 }
 
-// Wait for the oldest submitted tick; the read accessors then show ITS results (until the next wait).
+// Wait for the oldest submitted tick; the read accessors then show ITS results until the next wait (three output sets: neither
+// of the two ticks that can be submitted before that wait writes the set this one's results are in).
 int tlb_tick_wait(tlb_tick *t)
 {
     if (!t || t->waited >= t->ticks) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(t->device));
-    const int set = (int)(t->waited & 1);
+    const int set = (int)(t->waited % 3);
     if (hipEventSynchronize(t->ev1[set]) != hipSuccess) { tick_drain(t); return TLB_ERR_HIP; }
     t->out_set = set;
     t->waited++;
@@ -1572,7 +1614,7 @@ int tlb_tick_finish(tlb_tick *t)
 {
     if (!t || t->finished || t->ticks == 0 || t->ticks != t->waited) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(t->device));
-    const int set = (int)(t->ticks & 1);
+    const int set = (int)(t->ticks % 3);
     for (auto &G : t->groups) {
         int rc = hipStreamWaitEvent(t->s_run, G.ev_out, 0) == hipSuccess ? TLB_OK : TLB_ERR_HIP;
         if (!rc) rc = tlb_flush_device_len(G.b, G.d_frames, G.d_flen, t->s_run);
@@ -1640,7 +1682,7 @@ float tlb_tick_last_ms(tlb_tick *t)
 {   // first copy-in queued -> last copy-out done, on the device's clock
     float ms = -1.0f;
     if (!t || !t->waited || hipSetDevice(t->device) != hipSuccess) return -1.0f;
-    const int set = (int)((t->waited - 1) & 1);                      // the tick waited for last
+    const int set = (int)((t->waited - 1) % 3);                      // the tick waited for last
     if (hipEventSynchronize(t->ev1[set]) != hipSuccess || hipEventElapsedTime(&ms, t->ev0[set], t->ev1[set]) != hipSuccess) return -1.0f;
     return ms;
 }
@@ -1771,6 +1813,10 @@ int toolame_set_samplerate(long sample_rate)
 int toolame_set_pad(int pad_len)
 {
     if (pad_len < 0) { fprintf(stderr, "Invalid XPAD length specified\n"); return 1; }
+    // The caller accepts padlen 0..255 (src/odr-audioenc.cpp:566) and every one of them is encoded (TLB_MAX_XPAD = 256).  The reference's
+    // setter takes any non-negative number (toolame.c:250-262); a length the device record cannot hold is refused HERE, loudly --
+    // never a frame that silently goes out without its PAD.
+    if (pad_len > TLB_MAX_XPAD) { fprintf(stderr, "libtoolame-dab-hip: XPAD length %d exceeds the %d bytes this library carries per frame\n", pad_len, TLB_MAX_XPAD); return 1; }
     if (pad_len) g_legacy.pad_len = pad_len;
     return 0;
 }
@@ -1780,7 +1826,7 @@ int toolame_encode_frame(short buffer[2][1152], unsigned char *xpad_data, size_t
 {
     Legacy &g = g_legacy;
     if (!g.batch) {
-        tlb_stream_config c = {g.samplerate, g.mode, g.kbps, g.psy, g.pad_len > TLB_MAX_XPAD ? TLB_MAX_XPAD : g.pad_len};
+        tlb_stream_config c = {g.samplerate, g.mode, g.kbps, g.psy, g.pad_len};      // (toolame_set_pad has refused what the record cannot hold)
         int err = 0;
         g.batch = tlb_create(0, 1, &c, &err);
         if (!g.batch) {
@@ -1807,9 +1853,14 @@ int toolame_encode_frame(short buffer[2][1152], unsigned char *xpad_data, size_t
     unsigned char *xrec = g.h_xpad + (size_t)g.ndefer * TLB_MAX_XPAD;
     int32_t xl = 0;
     memset(xrec, 0, TLB_MAX_XPAD);
-    if (xpad_len >= 2 && xpad_data && xpad_len <= (size_t)TLB_MAX_XPAD && (int)xpad_len <= g.pad_len) {
+    if (xpad_len >= 2 && xpad_data && (int)xpad_len <= g.pad_len) {
         xl = (int32_t)xpad_len;                            // bytes [dab_length-xpad_len, dab_length) in transmission order
         memcpy(xrec, xpad_data + g.pad_len - (int)xpad_len, xpad_len);
+    } else if (xpad_len) {
+        // outside the contract of toolame.c:515-524 (the reference asserts on 1 and reads before xpad_data[] when xpad_len exceeds
+        // toolame_set_pad()'s length): the frame goes out without PAD, and says so
+        static bool warned = false;
+        if (!warned) { warned = true; fprintf(stderr, "libtoolame-dab-hip: xpad_len %zu outside 2..%d (toolame_set_pad), frame sent without PAD\n", xpad_len, g.pad_len); }
     }
     g.h_xl[g.ndefer] = xl;
     g.ndefer++;

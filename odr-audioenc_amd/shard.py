@@ -6,16 +6,24 @@ import os
 import time
 
 
-def init_from_env(backend=None, device_index=None):
-    """-> (rank, local_rank, world, dist or None).  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*."""
+def init_from_env(backend=None, device_index=None, force=False):
+    """-> (rank, local_rank, world, dist or None).  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.
+    force: build the process group at world size 1 too -- a one-rank group is still a group: init_process_group, barrier, all_reduce and
+    all_gather go through the backend's code (RCCL for "nccl"), which is how the collective path gets executed on a one-GPU box."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and not force:
         return rank, local_rank, world, None
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:          # only a forced one-rank group gets here without a launcher's port
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        s.close()
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if not dist.is_initialized():

@@ -16,7 +16,7 @@ import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("TLB_LIB_PATH") or PKG_DIR / "libtoolame_dab_hip.so")     # TLB_LIB_PATH: kernel experiments (tools/) only
-MAX_XPAD = 200
+MAX_XPAD = 256
 SAMPLES = 1152
 
 _ERR = {1: "illegal sample rate (48000/44100/32000/24000/22050/16000 Hz; the egress calls: no 32/44.1/22.05 kHz)", 2: "bad channel mode", 3: "invalid PSY model",
@@ -50,7 +50,7 @@ _lib = None
 
 def build(verbose=False):
     """Compile csrc/ for gfx950 into libtoolame_dab_hip.so (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", str(PKG_DIR / "csrc")], capture_output=not verbose, text=True)
+    r = subprocess.run(["make", "-j4", "-C", str(PKG_DIR / "csrc")], capture_output=not verbose, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc build failed:\n" + (r.stdout or "") + (r.stderr or ""))
     return LIB_PATH
@@ -136,6 +136,47 @@ def load_library():
     L.tlb_tick_fragment.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.tlb_tick_last_ms.argtypes = [C.c_void_p]
     L.tlb_tick_last_ms.restype = C.c_float
+    # node level (include/toolame_batch.h part 3)
+    L.tlb_node_partition.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.tlb_node_partition.restype = None
+    L.tlb_node_plan_shard.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 3 + [C.c_void_p, C.POINTER(C.c_int)]
+    L.tlb_node_create.restype = C.c_void_p
+    L.tlb_node_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    L.tlb_node_destroy.argtypes = [C.c_void_p]
+    L.tlb_node_destroy.restype = None
+    for f in ("tlb_node_nshards", "tlb_node_nstreams", "tlb_node_submit", "tlb_node_wait", "tlb_node_run", "tlb_node_finish", "tlb_node_sync"):
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.tlb_node_shard_of.argtypes = [C.c_void_p, C.c_int]
+    L.tlb_node_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tlb_node_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    for f in ("tlb_node_pcm", "tlb_node_xpad", "tlb_node_xpad_len", "tlb_node_peaks"):
+        getattr(L, f).restype = C.c_void_p
+        getattr(L, f).argtypes = [C.c_void_p, C.c_int]
+    L.tlb_node_units.argtypes = [C.c_void_p, C.c_int]
+    L.tlb_node_silence_ms.argtypes = [C.c_void_p, C.c_int]
+    L.tlb_node_silence_ms.restype = C.c_uint32
+    L.tlb_node_frame.restype = C.c_void_p
+    L.tlb_node_frame.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    for f in ("tlb_node_packet", "tlb_node_message"):
+        getattr(L, f).restype = C.c_void_p
+        getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.tlb_node_fragments.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.tlb_node_fragment.restype = C.c_void_p
+    L.tlb_node_fragment.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.tlb_node_set_gain_db.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.tlb_node_stream_reset.argtypes = [C.c_void_p, C.c_int]
+    L.tlb_node_stream_finish.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.tlb_node_stream_reconfigure.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.tlb_node_batch.restype = C.c_void_p
+    L.tlb_node_batch.argtypes = [C.c_void_p, C.c_int]
+    L.tlb_node_device_alloc.restype = C.c_void_p
+    L.tlb_node_device_alloc.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    L.tlb_node_device_free.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.tlb_node_device_free.restype = None
+    L.tlb_node_copy_in.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.tlb_node_copy_out.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.tlb_node_encode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tlb_node_flush_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.toolame_set_samplerate.argtypes = [C.c_long]
     L.toolame_set_channel_mode.argtypes = [C.c_char]
     L.toolame_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -554,3 +595,269 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------------------------------
+# node level: every GPU of one host behind one handle (include/toolame_batch.h part 3, csrc/tlb_node.cpp)
+class _CNodeConfig(C.Structure):
+    _fields_ = [("plane", C.c_int), ("tick", _CTickConfig)]
+
+
+class _CNodeCounter(C.Structure):
+    _fields_ = [("shard", C.c_int), ("device", C.c_int), ("first", C.c_int), ("nstreams", C.c_int), ("steps", C.c_long), ("frames", C.c_long),
+                ("busy_ns", C.c_double), ("device_ms", C.c_double), ("wall_ns", C.c_double)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def node_partition(nstreams, nshards):
+    """[(first, n)] per shard: streams [g*N/G, (g+1)*N/G); pure arithmetic, no GPU"""
+    L = load_library()
+    out = []
+    for g in range(nshards):
+        f, n = C.c_int(0), C.c_int(0)
+        L.tlb_node_partition(nstreams, nshards, g, C.byref(f), C.byref(n))
+        out.append((f.value, n.value))
+    return out
+
+
+def node_plan(configs, nshards):
+    """per shard: dict(first, n, nconfigs, lists = streams per kernel list (psy 0, 1, 2+4, 3), mono_pairs) -- what tlb_create() will make
+    of each block; raises ToolameError on the first illegal configuration.  No GPU needed."""
+    L = load_library()
+    configs = list(configs)
+    arr = _config_array(configs)
+    out = []
+    for g in range(nshards):
+        f, n, nc, mp = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        ls = (C.c_int * 4)()
+        rc = L.tlb_node_plan_shard(len(configs), arr, nshards, g, C.byref(f), C.byref(n), C.byref(nc), ls, C.byref(mp))
+        if rc:
+            raise ToolameError(rc, "tlb_node_plan_shard")
+        out.append(dict(first=f.value, n=n.value, nconfigs=nc.value, lists=list(ls), mono_pairs=mp.value))
+    return out
+
+
+class Node:
+    """tlb_node_*: N streams over the shards of one host (one tlb_tick or tlb_batch + one host thread per shard; `devices[g]` is the HIP
+    device of shard g and may repeat).  plane "tick": fill pcm(s), run() / submit() + wait(), read frame(s) / packets(s) ...;
+    plane "batch": device-resident buffers per shard, encode(pcm) with pcm int16 [nframes][nstreams][2][1152] split by the wrapper."""
+
+    def __init__(self, configs, devices=(0,), plane="tick", egress="frames", ngroups=0, with_xpad=False, version=b"", now_s=1700000000,
+                 delay_ms=0, tist=False, tai_utc_offset=37, fec=0, chunk_len=207, transport=False, addr_source=0, dest_port=0):
+        self.L = load_library()
+        configs = list(configs)
+        self.configs = configs
+        self.nstreams = len(configs)
+        self.plane = plane
+        self.with_xpad = bool(with_xpad)
+        self._version = bytes(version)
+        nc = _CNodeConfig()
+        nc.plane = 0 if plane == "tick" else 1
+        nc.tick = _CTickConfig(Tick.EGRESS[egress], ngroups, 1 if with_xpad else 0, self._version, len(self._version), int(now_s), int(delay_ms),
+                               1 if tist else 0, int(tai_utc_offset), fec, chunk_len, 1 if transport else 0, addr_source, dest_port)
+        devs = (C.c_int * len(devices))(*devices)
+        err = C.c_int(0)
+        self.h = self.L.tlb_node_create(len(devices), devs, self.nstreams, _config_array(configs), C.byref(nc), C.byref(err))
+        if not self.h:
+            raise ToolameError(err.value, "tlb_node_create")
+        self.nshards = self.L.tlb_node_nshards(self.h)
+        self.blocks = node_partition(self.nstreams, self.nshards)
+        self._dev = {}          # BATCH plane: (shard, tag) -> (device pointer, bytes)
+        if plane == "tick":
+            self.units = [self.L.tlb_node_units(self.h, s) for s in range(self.nstreams)]
+
+    def close(self):
+        if self.h:
+            for (g, _), (p, _) in list(self._dev.items()):
+                self.L.tlb_node_device_free(self.h, g, p)
+            self._dev.clear()
+            self.L.tlb_node_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _rc(self, rc, what):
+        if rc:
+            raise ToolameError(rc, what)
+
+    def counters(self):
+        per = (_CNodeCounter * self.nshards)()
+        tot = _CNodeCounter()
+        self._rc(self.L.tlb_node_counters(self.h, per, C.byref(tot)), "tlb_node_counters")
+        return [p.asdict() for p in per], tot.asdict()
+
+    # ---- TICK plane ----
+    def pcm(self, s):
+        p = self.L.tlb_node_pcm(self.h, s)
+        return np.ctypeslib.as_array((C.c_int16 * (2 * SAMPLES)).from_address(p)) if p else None
+
+    def set_pcm(self, inter):
+        """inter int16 [nstreams][2304]: every stream's interleaved frame into the current input set (block copies per shard)"""
+        for f, n in self.blocks:
+            p = self.L.tlb_node_pcm(self.h, f)
+            if not p:
+                raise ToolameError(18, "tlb_node_pcm: no input set is free (two ticks in flight)")
+            np.ctypeslib.as_array((C.c_int16 * (n * 2 * SAMPLES)).from_address(p)).reshape(n, 2 * SAMPLES)[:] = inter[f:f + n]
+
+    def set_xpad(self, s, rec, length):
+        p, q = self.L.tlb_node_xpad(self.h, s), self.L.tlb_node_xpad_len(self.h, s)
+        np.ctypeslib.as_array((C.c_uint8 * MAX_XPAD).from_address(p))[:] = rec
+        C.c_int32.from_address(q).value = int(length)
+
+    def submit(self):
+        self._rc(self.L.tlb_node_submit(self.h), "tlb_node_submit")
+
+    def wait(self):
+        self._rc(self.L.tlb_node_wait(self.h), "tlb_node_wait")
+
+    def run(self):
+        self._rc(self.L.tlb_node_run(self.h), "tlb_node_run")
+
+    def finish(self):
+        self._rc(self.L.tlb_node_finish(self.h), "tlb_node_finish")
+
+    def peaks(self, s):
+        p = self.L.tlb_node_peaks(self.h, s)
+        return tuple(np.ctypeslib.as_array((C.c_int16 * 2).from_address(p))) if p else None
+
+    def silence_ms(self, s):
+        return int(self.L.tlb_node_silence_ms(self.h, s))
+
+    def frame(self, s):
+        n = C.c_int(0)
+        p = self.L.tlb_node_frame(self.h, s, C.byref(n))
+        return C.string_at(p, n.value) if p and n.value else b""
+
+    def _units(self, fn, s):
+        out = []
+        for u in range(self.units[s]):
+            n = C.c_int(0)
+            p = fn(self.h, s, u, C.byref(n))
+            if p and n.value:
+                out.append(C.string_at(p, n.value))
+        return out
+
+    def packets(self, s):
+        return self._units(self.L.tlb_node_packet, s)
+
+    def messages(self, s):
+        return self._units(self.L.tlb_node_message, s)
+
+    def fragments(self, s):
+        out = []
+        for u in range(self.units[s]):
+            fr = []
+            for k in range(self.L.tlb_node_fragments(self.h, s, u)):
+                n = C.c_int(0)
+                p = self.L.tlb_node_fragment(self.h, s, u, k, C.byref(n))
+                fr.append(C.string_at(p, n.value))
+            if fr:
+                out.append(fr)
+        return out
+
+    # ---- both planes ----
+    def set_gain_db(self, gain_db, stream=-1):
+        self._rc(self.L.tlb_node_set_gain_db(self.h, stream, float(gain_db)), "tlb_node_set_gain_db")
+
+    def stream_reset(self, s):
+        self._rc(self.L.tlb_node_stream_reset(self.h, s), "tlb_node_stream_reset")
+
+    def stream_finish(self, s):
+        buf = (C.c_uint8 * 2048)()
+        n = self.L.tlb_node_stream_finish(self.h, s, buf, 2048)
+        if n < 0:
+            raise ToolameError(-n, "tlb_node_stream_finish")
+        return bytes(buf[:n])
+
+    def stream_reconfigure(self, s, config):
+        self._rc(self.L.tlb_node_stream_reconfigure(self.h, s, _config_array([config])), "tlb_node_stream_reconfigure")
+        if self.plane == "tick":
+            self.units[s] = self.L.tlb_node_units(self.h, s)
+
+    # ---- BATCH plane ----
+    def out_stride(self, g):
+        return self.L.tlb_out_stride(self.L.tlb_node_batch(self.h, g))
+
+    def _buf(self, g, tag, nbytes):
+        cur = self._dev.get((g, tag))
+        if cur and cur[1] >= nbytes:
+            return cur[0]
+        if cur:
+            self.L.tlb_node_device_free(self.h, g, cur[0])
+        p = self.L.tlb_node_device_alloc(self.h, g, nbytes)
+        if not p:
+            raise ToolameError(17, "tlb_node_device_alloc")
+        self._dev[(g, tag)] = (p, nbytes)
+        return p
+
+    def upload(self, pcm, slot=0):
+        """pcm int16 [nframes][nstreams][2][1152] -> one device buffer per shard (the shard's streams, [nframes][n_g][2][1152]);
+        `slot` names the buffer set (a caller alternating two resident inputs uploads slot 0 and slot 1 once)"""
+        nf = pcm.shape[0]
+        ptrs = (C.c_void_p * self.nshards)()
+        for g, (f, n) in enumerate(self.blocks):
+            blk = np.ascontiguousarray(pcm[:, f:f + n], dtype=np.int16)
+            ptrs[g] = self._buf(g, ("pcm", slot), blk.nbytes)
+            self._rc(self.L.tlb_node_copy_in(self.h, g, ptrs[g], blk.ctypes.data, blk.nbytes), "tlb_node_copy_in")
+        self._pcm_ptrs = getattr(self, "_pcm_ptrs", {})
+        self._pcm_ptrs[slot] = (ptrs, nf)
+        return ptrs
+
+    def encode_resident(self, slot=0, want_len=True):
+        """queue one encode call on every shard over the PCM uploaded as `slot`; returns at once (sync() waits)"""
+        ptrs, nf = self._pcm_ptrs[slot]
+        outs, lens = (C.c_void_p * self.nshards)(), (C.c_void_p * self.nshards)()
+        for g, (f, n) in enumerate(self.blocks):
+            outs[g] = self._buf(g, "out", nf * n * self.out_stride(g))
+            lens[g] = self._buf(g, "len", nf * n * 4)
+        self._rc(self.L.tlb_node_encode_device(self.h, ptrs, nf, None, None, outs, lens if want_len else None), "tlb_node_encode_device")
+        self._out_ptrs, self._len_ptrs, self._nf = outs, lens, nf
+
+    def sync(self):
+        self._rc(self.L.tlb_node_sync(self.h), "tlb_node_sync")
+
+    def download(self, nframes=None):
+        """-> per stream: the bytes of output slots 0..nframes-1 concatenated (slot lengths from the _len variant)"""
+        nf = nframes or self._nf
+        out = [b""] * self.nstreams
+        for g, (f, n) in enumerate(self.blocks):
+            st = self.out_stride(g)
+            fr = np.empty((nf, n, st), dtype=np.uint8)
+            ln = np.empty((nf, n), dtype=np.int32)
+            self._rc(self.L.tlb_node_copy_out(self.h, g, fr.ctypes.data, self._out_ptrs[g], fr.nbytes), "tlb_node_copy_out")
+            self._rc(self.L.tlb_node_copy_out(self.h, g, ln.ctypes.data, self._len_ptrs[g], ln.nbytes), "tlb_node_copy_out")
+            for k in range(n):
+                out[f + k] = b"".join(fr[i, k, :ln[i, k]].tobytes() for i in range(nf))
+        return out
+
+    def encode(self, pcm):
+        """upload + encode + sync + download (the convenience path of the parity tests)"""
+        self.upload(pcm)
+        self.encode_resident()
+        self.sync()
+        return self.download()
+
+    def flush(self):
+        """the pending (last) frame of every stream"""
+        outs, lens = (C.c_void_p * self.nshards)(), (C.c_void_p * self.nshards)()
+        for g, (f, n) in enumerate(self.blocks):
+            outs[g] = self._buf(g, "fout", n * self.out_stride(g))
+            lens[g] = self._buf(g, "flen", n * 4)
+        self._rc(self.L.tlb_node_flush_device(self.h, outs, lens), "tlb_node_flush_device")
+        self.sync()
+        out = [b""] * self.nstreams
+        for g, (f, n) in enumerate(self.blocks):
+            st = self.out_stride(g)
+            fr = np.empty((n, st), dtype=np.uint8)
+            ln = np.empty((n,), dtype=np.int32)
+            self._rc(self.L.tlb_node_copy_out(self.h, g, fr.ctypes.data, outs[g], fr.nbytes), "tlb_node_copy_out")
+            self._rc(self.L.tlb_node_copy_out(self.h, g, ln.ctypes.data, lens[g], ln.nbytes), "tlb_node_copy_out")
+            for k in range(n):
+                out[f + k] = fr[k, :ln[k]].tobytes()
+        return out

@@ -18,7 +18,7 @@ TAPS_DTYPE = np.dtype([
     ("scfcrc", np.uint8, (4,)), ("pad_", np.int32, (2,)),
 ])
 
-TL_MAX_XPAD = 200
+TL_MAX_XPAD = 256
 _lib = None
 
 

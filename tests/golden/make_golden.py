@@ -52,6 +52,16 @@ def cases():
                         seed=300 + psy + kbps, pad_len=0))
     out.append(dict(name="p1_48k_j_128_xpad", samplerate=48000, mode="j", kbps=128, psy=1, kind=0, seed=42, pad_len=58))
     out.append(dict(name="p3_48k_s_192_xpad", samplerate=48000, mode="s", kbps=192, psy=3, kind=0, seed=43, pad_len=58))
+    # round 5: the DAB maximum (196 bytes), the largest length the caller accepts (255, src/odr-audioenc.cpp:566), and a small frame
+    # whose PAD eats most of its bit budget (48 kHz mono 32 kbps: 96-byte frames, 80 of them PAD; `adb` of toolame.c:301)
+    out.append(dict(name="p1_48k_s_192_xpad196", samplerate=48000, mode="s", kbps=192, psy=1, kind=0, seed=44, pad_len=196,
+                    lens=[196, 10, 2, 0, 100, 196]))
+    out.append(dict(name="p3_48k_j_192_xpad255", samplerate=48000, mode="j", kbps=192, psy=3, kind=0, seed=45, pad_len=255,
+                    lens=[255, 201, 2, 0, 230, 255]))
+    out.append(dict(name="p1_48k_m_32_xpad80", samplerate=48000, mode="m", kbps=32, psy=1, kind=0, seed=46, pad_len=80,
+                    lens=[80, 10, 2, 0, 34, 80]))
+    out.append(dict(name="p2_24k_m_32_xpad40", samplerate=24000, mode="m", kbps=32, psy=2, kind=0, seed=47, pad_len=40,
+                    lens=[40, 10, 2, 0, 34, 40]))
     return out
 
 
@@ -59,7 +69,7 @@ def xpads_for(case):
     if not case["pad_len"]:
         return None
     rng = np.random.default_rng(case["seed"])
-    lens = [58, 10, 2, 0, 34, 58]
+    lens = case.get("lens", [58, 10, 2, 0, 34, 58])
     return [(bytes(rng.integers(0, 256, case["pad_len"] + 1, dtype=np.uint8)), lens[i % 6]) for i in range(NFRAMES)]
 
 

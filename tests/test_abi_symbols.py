@@ -160,3 +160,22 @@ def test_selfcheck_libm_says_this_host_is_the_pinned_one():
     lib.tlb_selfcheck_libm.restype = C.c_long
     lib.tlb_selfcheck_libm.argtypes = [C.c_long]
     assert lib.tlb_selfcheck_libm(200000) == 0
+
+
+def test_isa_guard_on_the_linked_library():
+    """tools/check_isa.py (run by csrc/Makefile after every link) on the library as it ships: the persistent encode kernels fit three
+    waves per SIMD (<= 168 VGPRs, no vector spills), their workgroup fits a CU's LDS, and the compiler has not merged adjacent 8-byte
+    LDS accesses into ds_read2_b64 / ds_write2_b64 -- the symptoms of the build flags being dropped."""
+    import json
+    import subprocess
+    import sys
+    import odr_audioenc_amd as M
+    if not M.LIB_PATH.exists():
+        M.build()
+    js = ROOT / "build" / "isa" / "test_summary.json"
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "check_isa.py"), str(M.LIB_PATH), "--json", str(js)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    summary = json.loads(js.read_text())
+    fk = [v for k, v in summary.items() if "tl_frame_kernel" in k]
+    assert len(fk) == 4 and all(v["vgpr"] <= 168 and v["vgpr_spill"] == 0 and v["lds"] <= 163840 and v["pairs2_frac"] <= 0.08 for v in fk)
+    assert "HIP 7." in M.load_library().tlb_version().decode() or "HIP " in M.load_library().tlb_version().decode()

@@ -25,6 +25,7 @@ def build(tmp_path, name="mp2enc"):
 def test_example_builds_with_a_host_compiler(tmp_path):
     assert build(tmp_path).exists()
     assert build(tmp_path, "editick").exists()               # the tick API (tlb_tick_*) from plain C++
+    assert build(tmp_path, "nodetick").exists()              # the node level (tlb_node_*): a fleet of services over the host's GPUs
 
 
 @pytest.mark.gpu
@@ -74,3 +75,43 @@ def test_example_output_equals_oracle(tmp_path, fs, channels, mode, kbps, psy, n
     assert r.returncode == 0, r.stderr
     ref, _ = O.oracle_stream(pcm if channels == 2 else pcm[:, :1].repeat(2, axis=1), samplerate=fs, mode=mode, kbps=kbps, psy=psy)
     assert (tmp_path / "out.mp2").read_bytes() == ref
+
+
+@pytest.mark.gpu
+def test_nodetick_fleet_two_shards_equal_the_binding(tmp_path):
+    """examples/nodetick.cpp: 37 services over two shards on this box's GPU ("-d 0,0"), ticks overlapped, fill and ship on the shards'
+    own threads.  The AF packets of the LAST service (it lives in shard 1) equal those of a single Tick object fed the same PCM, the
+    node's counters add up, and a run with ONE shard ships exactly as many packets and bytes."""
+    import json
+    import struct
+    import odr_audioenc_amd as M
+    exe = build(tmp_path, "nodetick")
+    nin, ns, ticks = 60, 37, 25
+    pcm = gen_pcm(123, 0, 0, nin)
+    inter = pcm.transpose(0, 2, 1).reshape(nin, 2304).astype("<i2")
+    (tmp_path / "in.pcm").write_bytes(inter.tobytes())
+    outs = {}
+    for d in ("0,0", "0"):
+        r = subprocess.run([str(exe), str(tmp_path / "in.pcm"), "-n", str(ns), "-d", d, "-k", str(ticks), "-p", "3", "-o", str(tmp_path / f"out_{len(d)}.af")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs[d] = json.loads(r.stdout.strip().splitlines()[-1])
+    two, one = outs["0,0"], outs["0"]
+    assert two["shards"] == 2 and one["shards"] == 1 and two["frames"] == one["frames"] == ns * ticks
+    assert two["packets"] == one["packets"] == ns * ticks and two["bytes"] == one["bytes"]
+    blob, got, o = (tmp_path / "out_3.af").read_bytes(), [], 0
+    while o < len(blob):
+        n = struct.unpack_from("<I", blob, o)[0]
+        got.append(blob[o + 4:o + 4 + n])
+        o += 4 + n
+    assert (tmp_path / "out_1.af").read_bytes() == blob
+    t = M.Tick([M.StreamConfig(mode="j", bitrate=128, psy_model=3)], egress="af", version=b"nodetick example", now_s=1712345678, delay_ms=0, tist=True, tai_utc_offset=37)
+    want = []
+    for f in range(ticks):
+        t.pcm[0] = inter[(ns - 1 + f) % nin]
+        t.run()
+        want += t.packets(0)
+    t.finish()
+    want += t.packets(0)
+    t.close()
+    assert got == want and len(got) == ticks

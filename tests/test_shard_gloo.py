@@ -115,3 +115,19 @@ def test_bench_workload_labels():
     assert bench.workload_label(4096, 3, "s", 8, 1)[1] is None
     a = bench.parse_args(["--gpus", "8"])
     assert a.gpus == 8 and a.streams is None and a.psy is None
+
+
+def test_forced_one_rank_group_runs_the_collectives():
+    """`--force-group`: at world size 1 the harness still builds a process group, so barrier / all_reduce / all_gather run
+    through the backend's code -- gloo here, RCCL on the GPU box (tests/test_node_gpu.py::test_bench_forced_rccl_group_on_one_gpu)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--dry-run", "--force-group", "--steps", "1"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["collective_backend"] == "gloo" and line["world_size_observed"] == 1 and line["n_gpus"] == 1
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--dry-run", "--steps", "1"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert json.loads(r.stdout.strip().splitlines()[-1])["collective_backend"] is None          # without the flag: no group at world size 1

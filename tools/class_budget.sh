@@ -10,7 +10,7 @@ if [ "${1:-run}" = build ]; then
   mkdir -p build; i=0
   for v in EXP:1 EXP:2 EXP:3 EXP:4 EXP:5 EXP:6 EXP:7 EXP:9 ENC:1 ENC:2 ENC:3 ENC:4 ENC:5; do
     k=${v%%:*}; n=${v##*:}; i=$((i+1))
-    make -s -C odr-audioenc_amd/csrc OUT=$R/build/lib_cb_${k}$n.so OBJ=$R/build/obj_cb_${k}$n EXTRA="-DTL_${k}_LEVEL=$n -Wno-pass-failed ${EXTRA:-}" > /dev/null 2>&1 &
+    make -s -C odr-audioenc_amd/csrc OUT=$R/build/lib_cb_${k}$n.so OBJ=$R/build/obj_cb_${k}$n ISA_GUARD=--no-fail EXTRA="-DTL_${k}_LEVEL=$n -Wno-pass-failed ${EXTRA:-}" > /dev/null 2>&1 &
     if [ $((i % 5)) = 0 ]; then wait; fi
   done
   wait; ls build/ | grep lib_cb | wc -l

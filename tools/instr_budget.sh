@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 if [ "${1:-run}" = build ]; then
   mkdir -p build
   for n in 1 2 3 4 5 6 7 8; do
-    make -s -C odr-audioenc_amd/csrc OUT=$R/build/lib_exp$n.so OBJ=$R/build/obj_exp$n EXTRA="-DTL_EXP_LEVEL=$n -Wno-pass-failed" > /dev/null 2>&1 &
+    make -s -C odr-audioenc_amd/csrc OUT=$R/build/lib_exp$n.so OBJ=$R/build/obj_exp$n ISA_GUARD=--no-fail EXTRA="-DTL_EXP_LEVEL=$n -Wno-pass-failed" > /dev/null 2>&1 &
     if [ $((n % 4)) = 0 ]; then wait; fi
   done
   wait; ls -la build/
