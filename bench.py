@@ -230,9 +230,9 @@ def committed_counters(S, F, psy, mode, mixed=False):
             sq = json.load(open(f))
             wl = sq["workload"]
             if (wl["streams"], wl["frames_per_step"], wl["psy"], wl["mode"], bool(wl.get("mixed"))) == (S, F, psy, mode, mixed):
-                valu = {k: {"valu_busy_per_simd": c["derived"]["valu_busy_per_simd"], "waves_per_simd": c["derived"]["waves_per_simd"],
-                            "wave_cycles_waiting": c["derived"]["waiting_share"], "valu_instructions_per_frame": c["derived"]["per_frame"]["valu"]}
-                        for k, c in sq["kernels"].items()}
+                valu = {"kernels": {k: {"valu_busy_per_simd": c["derived"]["valu_busy_per_simd"], "waves_per_simd": c["derived"]["waves_per_simd"],
+                                        "wave_cycles_waiting": c["derived"]["waiting_share"], "valu_instructions_per_frame": c["derived"]["per_frame"]["valu"]}
+                                    for k, c in sq["kernels"].items()}}
                 valu["clock_ghz"] = next((c["derived"].get("clock_ghz") for c in sq["kernels"].values() if c["derived"].get("clock_ghz")), None)
                 cls = [c["derived"]["classes_per_frame"] for c in sq["kernels"].values() if c["derived"].get("classes_per_frame")]
                 valu["classes_per_frame"] = {k: sum(c[k] for c in cls) for k in cls[0]} if cls and len(cls) == len(sq["kernels"]) else None
@@ -564,7 +564,7 @@ def main():
                         "NOT a roofline fraction"}
         if valu:
             clock = valu.get("clock_ghz") or 2.2
-            per_frame = sum(v["valu_instructions_per_frame"] for k_, v in valu.items() if isinstance(v, dict))
+            per_frame = sum(v["valu_instructions_per_frame"] for v in valu["kernels"].values())
             classes = valu.get("classes_per_frame")
             if classes:
                 cyc = sum(CLASS_COST[c] * n for c, n in classes.items())
@@ -572,7 +572,7 @@ def main():
             else:
                 cyc = per_frame * FLAT_COST
                 basis = f"no class split committed for this workload: {per_frame} instructions per frame x {FLAT_COST} cycles"
-            util.update({"counter_valu_busy_per_simd": {k_: v["valu_busy_per_simd"] for k_, v in valu.items() if isinstance(v, dict)},
+            util.update({"counter_valu_busy_per_simd": {k_: v["valu_busy_per_simd"] for k_, v in valu["kernels"].items()},
                          "counter_lane_occupancy": valu.get("lane_occupancy"),
                          "this_run_from_instruction_classes": round(cyc * fps_k / (num_simds * clock * 1e9), 4),
                          "valu_instructions_per_frame": per_frame, "classes_per_frame": classes, "issue_cycles_per_frame": round(cyc),

@@ -17,22 +17,31 @@ if [ "${1:-run}" = build ]; then
   exit 0
 fi
 export TMPDIR=/tmp; mkdir -p gpurun_out
+G2="SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM"
 G="SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64"
 for v in BASE EXP1 EXP2 EXP3 EXP4 EXP5 EXP6 EXP7 EXP9 ENC1 ENC2 ENC3 ENC4 ENC5; do
   if [ $v = BASE ]; then unset TLB_LIB_PATH; else export TLB_LIB_PATH=$R/build/lib_cb_$v.so; fi
   rm -rf gpurun_out/cb_$v
   timeout 120 rocprofv3 --pmc $G --kernel-trace --output-format csv -d $R/gpurun_out/cb_$v -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also > gpurun_out/cb_$v.log 2>&1
+  # second pass: lane occupancy of the vector instructions (thread-cycles over instruction-cycles x 64) and the LDS / scalar counts
+  rm -rf gpurun_out/cbo_$v
+  timeout 120 rocprofv3 --pmc $G2 --kernel-trace --output-format csv -d $R/gpurun_out/cbo_$v -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-also > gpurun_out/cbo_$v.log 2>&1
 done
 python3 - <<'PY' | tee gpurun_out/class_budget.txt
 import csv, glob, collections
-def load(v):
+def load(v, pre="cb"):
     acc = collections.defaultdict(list)
-    for f in glob.glob(f"gpurun_out/cb_{v}/**/*counter_collection.csv", recursive=True):
+    for f in glob.glob(f"gpurun_out/{pre}_{v}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             if "tl_frame_kernel" in row["Kernel_Name"]: acc[row["Counter_Name"].replace("SQ_INSTS_VALU_", "").replace("SQ_INSTS_", "")].append(float(row["Counter_Value"]))
     return {k: sum(x) / len(x) / 131072 for k, x in acc.items()}
+def occ(v):
+    d = load(v, "cbo")
+    return d if d and "THREAD_CYCLES_VALU" in d else None
 cols = ["VALU", "ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "CVT", "INT32", "INT64"]
-def row(name, d):
+OCC = {}
+def row(name, d, o=None):
+    if o: OCC[name] = o
     f64 = d["ADD_F64"] + d["MUL_F64"] + d["FMA_F64"] + d["TRANS_F64"]
     other = d["VALU"] - f64 - d["CVT"] - d["INT32"] - d["INT64"]
     ratio = d["VALU"] / f64 if f64 > 0 else float("nan")
@@ -61,4 +70,33 @@ for n in range(1, 6):
     if not cur: print("ENC", n, "no data"); continue
     row("enc: " + names[n - 1], sub(prev, cur)); prev = cur
 row("(psy phase + filterbank + staging)", prev)
+# ---- lane occupancy by stage: thread-cycles of the vector instructions over (instruction-cycles x 64) ----
+print()
+print("# lane occupancy of the vector instructions by stage (second counter pass per build: SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64);")
+print("# both in units of 4 cycles per wave-instruction), with the stage's scalar and LDS instruction counts per frame")
+print(f"{'stage':34s} {'VALU':>7s} {'lanes':>6s} {'SALU':>6s} {'LDS':>6s} {'VMEM':>6s}")
+ocols = ["THREAD_CYCLES_VALU", "ACTIVE_INST_VALU", "VALU", "SALU", "LDS", "VMEM"]
+def orow(name, d):
+    lanes = d["THREAD_CYCLES_VALU"] / d["ACTIVE_INST_VALU"] if d["ACTIVE_INST_VALU"] > 0 else float("nan")
+    print(f"{name:34s} {d['VALU']:7.0f} {lanes:6.1f} {d['SALU']:6.0f} {d['LDS']:6.0f} {d['VMEM']:6.0f}")
+osub = lambda a, b: {k: a[k] - b[k] for k in ocols}
+ob = occ("BASE")
+if ob:
+    orow("whole frame", ob)
+    names = ["thresholds", "decimation", "dB-sum chains + weights + centres", "noise compaction", "tone walk + levels", "tone candidates", "power spectrum + spike levels", "spectrum (window + FHT)"]
+    prev = ob
+    for n in range(1, 8):
+        cur = occ(f"EXP{n}")
+        if not cur: continue
+        orow("psy: " + names[n - 1], osub(prev, cur)); prev = cur
+    e9 = occ("EXP9")
+    if e9:
+        orow("psy: " + names[7], osub(prev, e9)); orow("(encoder phase: the model removed)", e9)
+    names = ["CRC-16 + ScF-CRC + X-PAD", "quantiser + sample packing", "header / bit_alloc / scf fields", "bit allocation", "scalefactors + SMR + pattern"]
+    prev = ob
+    for n in range(1, 6):
+        cur = occ(f"ENC{n}")
+        if not cur: continue
+        orow("enc: " + names[n - 1], osub(prev, cur)); prev = cur
+    orow("(psy phase + filterbank + staging)", prev)
 PY
