@@ -508,7 +508,12 @@ def main():
         raise SystemExit(f"bench.py: rank needs GPU {os.environ.get('LOCAL_RANK')} but the box has {ndev} (RCCL wants one GPU per rank)")
     dev_index = int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev)
     torch.cuda.set_device(dev_index)
+    if int(os.environ.get("RANK", "0")) != 0:
+        # rank 0 alone owns stdout (ONE JSON line): librccl announces itself there with printf ("Librccl path : ..."), buffered until exit
+        sys.stdout.flush()
+        os.dup2(2, 1)
     rank, local_rank, world_env, dist = shard.init_from_env(args.backend, device_index=dev_index, force=args.force_group)      # "nccl" is RCCL on ROCm
+    C.CDLL(None).fflush(None)                    # ... and rank 0's copy of that line goes out now, not after the JSON line
     local_rank = dev_index
     cdev = "cuda" if args.backend == "nccl" else "cpu"          # where the collectives' few scalars live
     assert world_env == world
@@ -736,6 +741,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(psy, args.mode)
         else:
             res["cpu_baseline"] = None
+        C.CDLL(None).fflush(None)
         print(json.dumps(res), flush=True)
     if not all_ok:
         print("bench.py: the oracle check failed on at least one rank (output_check.per_rank_ok)", file=sys.stderr)

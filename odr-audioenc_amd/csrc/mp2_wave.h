@@ -286,9 +286,12 @@ typedef const struct TlLaunch *TlKArg;                                        /*
 #define TL_DBG_DUMP(tag, ch, nt, nn, x, b) do { if (getenv("TL_DUMP")) { printf("%s ch%d ntone %d nnoise %d:", tag, ch, nt, nn); \
     for (int i_ = 0; i_ < (nt) + (nn); i_++) printf(" (%.17g,%.6f)", (x)[i_], (b)[i_]); printf("\n"); } } while (0)
 #define TL_DBG_WALK(ch, lane, cnt) do { if (getenv("TL_DUMP_WALK")) printf("walk ch%d lane %d cnt %d\n", ch, lane, cnt); } while (0)
+static long tl_dbg_rounds = 0;
+#define TL_DBG_ROUND() (tl_dbg_rounds++)
 #else
 #define TL_DBG_DUMP(tag, ch, nt, nn, x, b) ((void)0)
 #define TL_DBG_WALK(ch, lane, cnt) ((void)0)
+#define TL_DBG_ROUND() ((void)0)
 #endif
 // Diagnostic builds only (tools/instr_budget.sh): TL_EXP_LEVEL = n removes the last n stages of psy model 1 (results are then
 // wrong on purpose); the VALU-instruction counters of successive levels attribute the instructions to the stages.
@@ -844,12 +847,11 @@ TL_FN void tl_psy_spectrum(TlPsyLds &w, const TlTables *TL_RESTRICT T, const TlP
 }
 
 // ------------------------------------------------------------------------------------------
-// Candidate record used by the tone labelling of psy 1 and psy 3: bits 0-8 line index,
-// bits 10.. = "left neighbour j fails" for j = 2.. (bit 10 + j - 2).  Only candidates whose RIGHT
-// neighbours pass are recorded: the right side of a candidate is never touched by an earlier tone
-// (the erasure reach of every earlier tone ends below the candidate), so that half of the test can be
-// decided in parallel from the original spectrum; the left half depends on which earlier candidates
-// were confirmed and is resolved by a short wave-uniform walk over the records.
+// Candidate record used by the tone labelling of psy 1 and psy 3: bits 0-8 line index, bits 21.. the line's run.  Only candidates
+// whose RIGHT neighbours pass are recorded: the right side of a candidate is never touched by an earlier tone (the erasure reach
+// of every earlier tone ends below the candidate), so that half of the test is decided in parallel from the original spectrum,
+// for all 500 lines.  The left half depends on which earlier candidates were confirmed: the walk that follows reads the left
+// neighbours of the CANDIDATES (tl_cand_left: "neighbour j fails" as bit j - 2) and resolves them against its state.
 
 // power density in dB of one line (psycho_1.c:241-248, psycho_3.c:152-160), straight-line so that several lines' logarithms
 // (long dependent chains) can be in flight together
@@ -881,31 +883,55 @@ TL_FN void tl_cand_chunk(TlPsyLds &w, int c8, int &ncand)
     const int ii = inr ? i : 16;
     // every neighbour is read before the first test (TL_KEEP: otherwise the compiler reads each one only if the
     // tests so far passed -- a chain of dependent LDS round trips)
-    double a[RMAX + 1], b[RMAX + 1];
-    const double pk = px[ii];
+    double a[RMAX + 1];
+    const double pk = px[ii], b1 = px[ii - 1];
 #pragma unroll
-    for (int j = 1; j <= RMAX; j++) { a[j] = px[ii + j]; b[j] = px[ii - j < 0 ? 0 : ii - j]; }
+    for (int j = 1; j <= RMAX; j++) a[j] = px[ii + j];
 #pragma unroll
-    for (int j = 1; j <= RMAX; j++) { TL_KEEP(a[j]); TL_KEEP(b[j]); }
-    bool cnd = inr && pk > b[1] && (PSY3 ? pk > a[1] : pk >= a[1]);
+    for (int j = 1; j <= RMAX; j++) TL_KEEP(a[j]);
+    bool cnd = inr && pk > b1 && (PSY3 ? pk > a[1] : pk >= a[1]);
+    // the run of a line inside the chunk is the chunk's RMAX (the chunks are cut where the run changes), or 0 (psycho_1's lines
+    // below 3): one per-lane flag instead of a `j <= run` per neighbour
     const int run = PSY3 ? tl_run_psy3(ii) : tl_run_psy1(ii);
+    const bool has = run != 0;
     const double max = pk - 7;
-    uint32_t r = (uint32_t)i;
+    bool fail = false;
 #pragma unroll
-    for (int j = 2; j <= RMAX; j++) {
-        const bool in = j <= run;
-        const bool fa = PSY3 ? (pk - a[j]) < 7.0 : max < a[j];
-        const bool fb = PSY3 ? (pk - b[j]) < 7.0 : max < b[j];
-        cnd = cnd && !(in && fa);
-        r |= (in && fb) ? 1u << (10 + j - 2) : 0u;
-    }
-    L(isc) = cnd; L(rec) = r | ((uint32_t)run << 21);             // line | left-fail mask << 10 | run << 21
+    for (int j = 2; j <= RMAX; j++) fail = fail || (PSY3 ? (pk - a[j]) < 7.0 : max < a[j]);
+    cnd = cnd && !(has && fail);
+    // The LEFT-hand neighbours are not looked at here: what they decide depends on the walk, and the walk looks at them for the
+    // candidates alone (tl_cand_left) -- a few dozen lines instead of five hundred.
+    L(isc) = cnd; L(rec) = (uint32_t)i | ((uint32_t)run << 21);     // line | run << 21
     TL_LANES_END
     const uint64_t m = TL_BALLOT(isc);
     TL_LANES_BEGIN
     if ((m >> lane) & 1ull) w.cinfo[ncand + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = L(rec);
     TL_LANES_END
     ncand += __builtin_popcountll(m);
+}
+// "left neighbour j fails the 7 dB test" for j = 2..run of candidate line c with level pk, bit j - 2 (psycho_1.c:289-300,
+// psycho_3.c:217-226), from the still-original spectrum.  All eleven neighbours are read whatever the run is (px[] sits behind
+// the transform buffer: c - 12 is inside the wave's block for every c >= 2, and what lies there are finite energies); the bits
+// beyond the run are masked off.
+template <bool PSY3>
+TL_FN uint32_t tl_cand_left(const double *px, int c, int run, double pk)
+{
+    double b[11];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int j = 2; j <= 12; j++) b[j - 2] = px[c - j];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int j = 2; j <= 12; j++) TL_KEEP(b[j - 2]);
+    const double max = pk - 7;
+    uint32_t lf = 0;
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int j = 2; j <= 12; j++) lf |= (PSY3 ? (pk - b[j - 2]) < 7.0 : max < b[j - 2]) ? 1u << (j - 2) : 0u;
+    return lf & (run >= 2 ? (1u << (run - 1)) - 1u : 0u);
 }
 
 // psy model 1 (psycho_1.c:22-87, :215-581); result in w.smr[ch][0..sblimit).
@@ -994,13 +1020,21 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
         int last = -1, run_last = 0, last_var = 0;
         any_erased = false;
         for (int kb = 0; kb < (TL_EXP_LEVEL >= 5 ? 0 : ncand); kb += 64) {          // 64 candidates per pass (there are rarely more)
-        PV(int, cc); PV(int, crun); PV(int, clf); PV(double, cpx); PV(bool, act);
+        PV(int, cc); PV(int, crun); PV(int, clf); PV(double, cpx); PV(bool, act); PV(bool, dep);
         TL_LANES_BEGIN
         const bool in = kb + lane < ncand;
         const uint32_t info = w.cinfo[in ? kb + lane : 0];
-        L(cc) = (int)(info & 511u); L(crun) = (int)(info >> 21); L(clf) = (int)((info >> 10) & 0x7ffu);
+        const uint32_t pinfo = w.cinfo[in && kb + lane > 0 ? kb + lane - 1 : 0];    // the candidate before this one
+        L(cc) = (int)(info & 511u); L(crun) = (int)(info >> 21);
         L(cpx) = px[L(cc)];
+        L(clf) = (int)tl_cand_left<false>(px, L(cc), L(crun), L(cpx));
         L(act) = in;
+        // A candidate at least run(previous candidate) + run(its own) + 1 lines above the candidate before it is out of every earlier
+        // tone's reach whatever the walk's state is when it gets there: `last` is at or below that previous candidate and runs grow
+        // with the line, so d - run_last - 1 >= run, every one of its left neighbours is original, and its fate is lfail == 0 -- the
+        // value the test below gives it under ANY earlier state (d > run, so neither the summed-level test nor an erasure applies,
+        // and its left neighbour is not the end of a reach: var = 0).  Such candidates need no round of their own.
+        L(dep) = in && kb + lane > 0 && L(cc) - (int)(pinfo & 511u) < (int)(pinfo >> 21) + L(crun) + 1;
         TL_LANES_END
         for (;;) {
             PV(bool, okv); PV(bool, needx);
@@ -1035,21 +1069,36 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
             const int c = TL_READLANE_I32(cc, wl), run = TL_READLANE_I32(crun, wl);
             // confirmed.  Its left neighbour c-1 was erased iff it is exactly the end of `last`'s reach.
             const int var = (last >= 0 && run_last >= 1 && c - 1 == last + run_last) ? 1 : 0;
-            if (nconf < TL_TONE_MAX) {
-                const int i = nconf++;
-                w.conf_c[i] = (int16_t)(c | (var << 12));
-                w.conf_nxt[i] = TL_LAST;
-                if (i > 0) {
-                    if (c - last <= run) {                            // erases the previous tone, psycho_1.c:313-316,322-326
-                        any_erased = true;
-                        w.conf_nxt[i - 1] = TL_STOP;
-                        w.conf_c[i - 1] = (int16_t)(w.conf_c[i - 1] | (1 << 13));
-                        if (i >= 2) w.conf_nxt[i - 2] = (int16_t)i;
-                    } else w.conf_nxt[i - 1] = (int16_t)i;
+            // With it, in the same round: every passing candidate between it and the next state-DEPENDENT candidate still to be
+            // decided (see `dep` above) -- their verdicts under the state of this round are their verdicts under any state.
+            PV(bool, depact);
+            TL_LANES_BEGIN L(depact) = L(dep) && L(act) && lane > wl; TL_LANES_END
+            const uint64_t dm = TL_BALLOT(depact);
+            const uint64_t upto = dm ? (1ull << __builtin_ctzll(dm)) - 1ull : ~0ull;     // lanes below the next dependent one
+            const uint64_t batch = m & upto;                           // wl and the independent passing candidates after it
+            const int nb = __builtin_popcountll(batch), wlast = 63 - __builtin_clzll(batch);
+            const int i0 = nconf;
+            TL_LANES_BEGIN
+            if ((batch >> lane) & 1ull) {
+                const int i = i0 + __builtin_popcountll(batch & ((1ull << lane) - 1ull));
+                if (i < TL_TONE_MAX) {
+                    w.conf_c[i] = (int16_t)(L(cc) | ((lane == wl ? var : 0) << 12));
+                    w.conf_nxt[i] = (int16_t)((lane == wlast || i + 1 >= TL_TONE_MAX) ? TL_LAST : i + 1);
                 }
             }
-            last = c; run_last = run; last_var = var;
-            TL_LANES_BEGIN L(act) = L(act) && lane > wl; TL_LANES_END
+            TL_LANES_END
+            if (i0 < TL_TONE_MAX && i0 > 0) {                         // the round's first tone against the tone before it
+                if (c - last <= run) {                                // erases the previous tone, psycho_1.c:313-316,322-326
+                    any_erased = true;
+                    w.conf_nxt[i0 - 1] = TL_STOP;
+                    w.conf_c[i0 - 1] = (int16_t)(w.conf_c[i0 - 1] | (1 << 13));
+                    if (i0 >= 2) w.conf_nxt[i0 - 2] = (int16_t)i0;
+                } else w.conf_nxt[i0 - 1] = (int16_t)i0;
+            }
+            nconf = i0 + nb < TL_TONE_MAX ? i0 + nb : (i0 < TL_TONE_MAX ? TL_TONE_MAX : i0);
+            last = TL_READLANE_I32(cc, wlast); run_last = TL_READLANE_I32(crun, wlast); last_var = wlast == wl ? var : 0;
+            TL_LANES_BEGIN L(act) = L(act) && lane > wlast; TL_LANES_END
+            TL_DBG_ROUND();
         }
         }
         TL_SYNC();
@@ -1700,12 +1749,17 @@ TL_FN int tl_psy3_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double
     {
         int R = -1;
         for (int kb = 0; kb < ncand; kb += 64) {
-        PV(int, ck); PV(int, csr); PV(int, clf); PV(bool, act);
+        PV(int, ck); PV(int, csr); PV(int, clf); PV(bool, act); PV(bool, dep);
         TL_LANES_BEGIN
         const bool in = kb + lane < ncand;
         const uint32_t info = w.cinfo[in ? kb + lane : 0];
-        L(ck) = (int)(info & 511u); L(csr) = (int)(info >> 21); L(clf) = (int)((info >> 10) & 0x7ffu);
+        const uint32_t pinfo = w.cinfo[in && kb + lane > 0 ? kb + lane - 1 : 0];    // the candidate before this one
+        L(ck) = (int)(info & 511u); L(csr) = (int)(info >> 21);
+        L(clf) = (int)tl_cand_left<true>(px, L(ck), L(csr), px[L(ck)]);
         L(act) = in;
+        // state-independent candidates as in tl_psy1_front: at least sr(previous candidate) + sr + 1 lines above the candidate before
+        // it, a candidate is above every earlier reach R with all its left neighbours original -- its verdict is clf == 0 under any R
+        L(dep) = in && kb + lane > 0 && L(ck) - (int)(pinfo & 511u) < (int)(pinfo >> 21) + L(csr) + 1;
         TL_LANES_END
         for (;;) {
             PV(bool, okv);
@@ -1718,10 +1772,23 @@ TL_FN int tl_psy3_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double
             const uint64_t m = TL_BALLOT(okv);
             if (m == 0ull) break;
             const int wl = __builtin_ctzll(m);
-            const int k = TL_READLANE_I32(ck, wl), sr = TL_READLANE_I32(csr, wl);
-            if (nconf < TL_TONE_MAX) w.conf_c[nconf++] = (int16_t)(k | ((k - 1 <= R) ? (1 << 12) : 0));
-            R = k + sr;
-            TL_LANES_BEGIN L(act) = L(act) && lane > wl; TL_LANES_END
+            // the first passing candidate, and with it every passing state-independent one up to the next dependent candidate
+            PV(bool, depact);
+            TL_LANES_BEGIN L(depact) = L(dep) && L(act) && lane > wl; TL_LANES_END
+            const uint64_t dm = TL_BALLOT(depact);
+            const uint64_t batch = m & (dm ? (1ull << __builtin_ctzll(dm)) - 1ull : ~0ull);
+            const int nb = __builtin_popcountll(batch), wlast = 63 - __builtin_clzll(batch);
+            const int i0 = nconf, Rold = R;
+            TL_LANES_BEGIN
+            if ((batch >> lane) & 1ull) {
+                const int i = i0 + __builtin_popcountll(batch & ((1ull << lane) - 1ull));
+                if (i < TL_TONE_MAX) w.conf_c[i] = (int16_t)(L(ck) | ((lane == wl && L(ck) - 1 <= Rold) ? (1 << 12) : 0));
+            }
+            TL_LANES_END
+            nconf = i0 + nb < TL_TONE_MAX ? i0 + nb : (i0 < TL_TONE_MAX ? TL_TONE_MAX : i0);
+            R = TL_READLANE_I32(ck, wlast) + TL_READLANE_I32(csr, wlast);
+            TL_LANES_BEGIN L(act) = L(act) && lane > wlast; TL_LANES_END
+            TL_DBG_ROUND();
         }
         }
         TL_SYNC();

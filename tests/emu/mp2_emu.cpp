@@ -301,3 +301,8 @@ long emu_div_by_check(const double *s, const double *d, long n)
     return bad;
 }
 }
+
+#ifdef TL_DEBUG_DUMP
+// diagnostic builds only (-DTL_DEBUG_DUMP): rounds of the tone walks since the process started (tl_psy1_front / tl_psy3_front)
+extern "C" long emu_walk_rounds(void) { return tl_dbg_rounds; }
+#endif

@@ -29,6 +29,15 @@ def _cfgs(M, streams):
     return [M.StreamConfig(samplerate=r, mode=m, bitrate=k, psy_model=p) for r, m, k, p in streams]
 
 
+def _planar(inter_s, c):
+    """what the ingest stage makes of a stream's interleaved frames [T][2304]: L R L R ... -> [T][2][1152]; a MONO stream is its first
+    1152 values (include/toolame_batch.h, tlb_ingest_device)"""
+    T = inter_s.shape[0]
+    if c.mode == "m":
+        return np.repeat(inter_s[:, None, :1152], 2, axis=1)
+    return inter_s.reshape(T, 1152, 2).transpose(0, 2, 1)
+
+
 def _oracle(pcm_s, c):
     return O.oracle_stream(pcm_s, samplerate=c.samplerate, mode=c.mode, kbps=c.bitrate, psy=c.psy_model)[0]
 
@@ -103,9 +112,8 @@ def test_tick_plane_two_shards_equal_one_tick(M, egress):
             assert got[f][s] == want[f][s], (f, s)
     assert tot["frames"] == ns * T and all(p["steps"] == T for p in per)
     if egress == "frames":
-        pcm = inter.reshape(T, ns, 1152, 2).transpose(0, 1, 3, 2)
         for s in range(ns):
-            assert b"".join(got[f][s][0] for f in range(T + 1)) == _oracle(pcm[:, s], cfgs[s]), s
+            assert b"".join(got[f][s][0] for f in range(T + 1)) == _oracle(_planar(inter[:, s], cfgs[s]), cfgs[s]), s
 
 
 def test_tick_results_stay_valid_until_the_next_wait(M):
@@ -132,8 +140,8 @@ def test_tick_results_stay_valid_until_the_next_wait(M):
 def test_node_life_cycle_and_gain_route_to_the_owning_shard(M):
     cfgs = _cfgs(M, [(48000, "s", 128, 1), (48000, "j", 128, 3), (48000, "s", 192, 2), (48000, "m", 96, 4), (48000, "m", 96, 4)])
     ns, T = len(cfgs), 6
-    pcm = np.stack([gen_pcm(7300 + s, 0, 0, T) for s in range(ns)], axis=1)
-    inter = pcm.transpose(0, 1, 3, 2).reshape(T, ns, 2304)
+    inter = np.stack([gen_pcm(7300 + s, 0, 0, T) for s in range(ns)], axis=1).transpose(0, 1, 3, 2).reshape(T, ns, 2304)
+    pcm = np.stack([_planar(inter[:, s], cfgs[s]) for s in range(ns)], axis=1)
     nd = M.Node(cfgs, devices=(0, 0), plane="tick", egress="frames")
     got = [b""] * ns
     for f in range(3):
@@ -189,7 +197,9 @@ def _bench(*args, timeout=900):
     root = Path(__file__).resolve().parent.parent
     r = subprocess.run([sys.executable, str(root / "bench.py")] + list(args), cwd=root, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1].startswith("{"), lines[-3:]                    # the JSON line is the LAST thing on stdout (librccl's own printf comes before it)
+    return json.loads(lines[-1])
 
 
 def test_bench_forced_rccl_group_on_one_gpu():

@@ -36,7 +36,7 @@ def load(v, pre="cb"):
             if "tl_frame_kernel" in row["Kernel_Name"]: acc[row["Counter_Name"].replace("SQ_INSTS_VALU_", "").replace("SQ_INSTS_", "")].append(float(row["Counter_Value"]))
     return {k: sum(x) / len(x) / 131072 for k, x in acc.items()}
 def occ(v):
-    d = load(v, "cbo")
+    d = {k[3:] if k.startswith("SQ_") else k: x for k, x in load(v, "cbo").items()}
     return d if d and "THREAD_CYCLES_VALU" in d else None
 cols = ["VALU", "ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "CVT", "INT32", "INT64"]
 OCC = {}
