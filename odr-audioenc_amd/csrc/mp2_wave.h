@@ -560,6 +560,43 @@ TL_FN void tl_mask_spans(const TlMasker *mk, int nm, int ntone, double blo, doub
         b0 = (mn && fn < b0) ? fn : b0; b1 = mn ? ln : b1;
     }
 }
+// The same spans when both lists are ascending in bark -- they are, except after the dead-head replay: tones come in chain order
+// (ascending lines), noise components in band order, and bark grows with the line -- by bisection instead of a look at every masker:
+// count(B <= v) for v = blo and bhi on the tones mb[0, ntone) and on the noise components mb[ntone, ntone + nnoise), the four
+// searches side by side (four reads in flight per level).  STEPS_T / STEPS_N: highest power of two of a count (64: up to 127, 32: up to 63).
+// tl_maskers_sorted() decides, wave-uniformly, whether this form may be used.
+template <int STEPS_T, int STEPS_N>
+TL_FN void tl_mask_spans_sorted(const double *TL_RESTRICT mb, int ntone, int nnoise, double blo, double bhi, int &a0, int &a1, int &b0, int &b1)
+{
+    int tl = 0, th = 0, nl = 0, nh = 0;
+    const double *nbk = mb + ntone;
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int step = STEPS_T > STEPS_N ? STEPS_T : STEPS_N; step; step >>= 1) {
+        const bool dt = step <= STEPS_T, dn = step <= STEPS_N;
+        const int qtl = tl + step, qth = th + step, qnl = nl + step, qnh = nh + step;
+        // reads past a list's end stay inside the wave's transform buffer (the masker arrays lie at its start) and are gated by the count tests
+        const double vtl = dt ? mb[qtl - 1] : 0.0, vth = dt ? mb[qth - 1] : 0.0;                // (index <= 2 * STEPS_T - 2)
+        const double vnl = dn ? nbk[qnl - 1] : 0.0, vnh = dn ? nbk[qnh - 1] : 0.0;
+        if (dt) { tl = (qtl <= ntone && vtl <= blo) ? qtl : tl; th = (qth <= ntone && vth <= bhi) ? qth : th; }
+        if (dn) { nl = (qnl <= nnoise && vnl <= blo) ? qnl : nl; nh = (qnh <= nnoise && vnh <= bhi) ? qnh : nh; }
+    }
+    const int nm = ntone + nnoise;
+    a0 = th > tl ? tl : nm; a1 = th > tl ? th - 1 : -1;
+    b0 = nh > nl ? ntone + nl : nm; b1 = nh > nl ? ntone + nh - 1 : -1;
+}
+// Are both masker lists ascending in bark?  (wave-uniform; not inside a lanes block)
+TL_FN bool tl_maskers_sorted(const double *TL_RESTRICT mb, int ntone, int nnoise)
+{
+    PV(bool, bad);
+    TL_LANES_BEGIN
+    bool b = false;
+    for (int q = 1 + lane; q < ntone + nnoise; q += 64) b = b || (q != ntone && mb[q] < mb[q - 1]);
+    L(bad) = b;
+    TL_LANES_END
+    return TL_BALLOT(bad) == 0ull;
+}
 // Running minimum over rows [j0, j0 + n) in the reference's order and with its comparison (`if (m > v) m = v`), four rows
 // per LDS round trip; a short last group repeats the last row, which changes nothing.  take_first: m starts as row j0.
 TL_FN double tl_min_rows(const double *ltg, int j0, int n, double m, bool take_first)
@@ -1114,10 +1151,26 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
     for (int i = lane; i < nconf; i += 64) { const int c = w.conf_c[i] & 511; px[c] = w.tone_x[i]; w.ptype[c] = TL_T_TONE; }
     TL_LANES_END
     // (4) erasures (psycho_1.c:322-326); a tone erased by its successor ends up DBMIN / not TONE
+    //     Straight-line: a tone's run is 2, 3, 6 or 12 (it is a line 3..499), so the stores are four nested groups behind three tests,
+    //     each store at a constant offset from ONE address per array (px + c - 12 is inside the wave's block: px[] lies behind the
+    //     transform) -- instead of a loop of `run` trips with four address computations each.
     TL_LANES_BEGIN
     for (int i = lane; i < nconf; i += 64) {
         const int c = w.conf_c[i] & 511, run = tl_run_psy1(c);
-        for (int j = 1; j <= run; j++) { px[c - j] = TL_DBMIN; px[c + j] = TL_DBMIN; w.ptype[c - j] = 0; w.ptype[c + j] = 0; }
+        double *pb = px + (c - 12);
+        uint8_t *tb = w.ptype;
+#define TL_ERASE1(j) do { pb[12 - (j)] = TL_DBMIN; pb[12 + (j)] = TL_DBMIN; tb[c - (j)] = 0; tb[c + (j)] = 0; } while (0)
+        if (run >= 2) {
+            TL_ERASE1(1); TL_ERASE1(2);
+            if (run >= 3) {
+                TL_ERASE1(3);
+                if (run >= 6) {
+                    TL_ERASE1(4); TL_ERASE1(5); TL_ERASE1(6);
+                    if (run >= 12) { TL_ERASE1(7); TL_ERASE1(8); TL_ERASE1(9); TL_ERASE1(10); TL_ERASE1(11); TL_ERASE1(12); }
+                }
+            }
+        }
+#undef TL_ERASE1
     }
     TL_LANES_END
     // (5) the tone list in chain order (psycho_1.c list head `*tone`): walk the links, then decimate
@@ -1314,6 +1367,7 @@ TL_FN void tl_psy1_thresholds(TlPsyLds &w, const double *TL_RESTRICT db, const T
     // reaches lines with -3 <= dz < 8 bark, so a lane first finds the first and last masker (tones, then noise, in list
     // order) that reaches either of its lines and walks only that span; the per-line range test stays in the walk, so
     // nothing depends on the lists being sorted.
+    const bool srt = ntone < 128 && nnoise < 64 && tl_maskers_sorted(TL_MK_BARK(w), ntone, nnoise);
     for (int base = 1; base < (TL_EXP_LEVEL >= 1 ? 0 : sub); base += 128) {       // 126..132 lines: one full pass + a 4-line tail at most
         TL_LANES_BEGIN
         const int k0 = base + 2 * lane, k1 = k0 + 1;
@@ -1324,7 +1378,8 @@ TL_FN void tl_psy1_thresholds(TlPsyLds &w, const double *TL_RESTRICT db, const T
             const TlMasker *mk = TL_MK4(w);
             const int nm = ntone + nnoise;
             int a0, a1, b0, b1;                                     // spans inside the tone part and inside the noise part
-            tl_mask_spans(mk, nm, ntone, blo, bhi, a0, a1, b0, b1);
+            if (srt) tl_mask_spans_sorted<64, 32>(TL_MK_BARK(w), ntone, nnoise, blo, bhi, a0, a1, b0, b1);
+            else tl_mask_spans(mk, nm, ntone, blo, bhi, a0, a1, b0, b1);
             // one walk over the tone span, then the noise span, two maskers per trip: their four masking terms do not depend on
             // the running sums and are computed while the masker reads and the previous table look-ups are under way
             double x0 = TL_DBMIN, x1 = TL_DBMIN;
@@ -1804,9 +1859,19 @@ TL_FN int tl_psy3_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double
     TL_LANES_END
     // (4) erasures
     TL_LANES_BEGIN
-    for (int i = lane; i < nconf; i += 64) {
+    for (int i = lane; i < nconf; i += 64) {                         // straight-line, as in tl_psy1_front: sr is 2, 3, 6 or 12
         const int k = w.conf_c[i] & 511, sr = tl_run_psy3(k);
-        for (int j = -sr; j <= sr; j++) px[k + j] = TL_DBMIN;
+        double *pb = px + (k - 12);
+#define TL_ERASE3(j) do { pb[12 - (j)] = TL_DBMIN; pb[12 + (j)] = TL_DBMIN; } while (0)
+        pb[12] = TL_DBMIN; TL_ERASE3(1); TL_ERASE3(2);
+        if (sr >= 3) {
+            TL_ERASE3(3);
+            if (sr >= 6) {
+                TL_ERASE3(4); TL_ERASE3(5); TL_ERASE3(6);
+                if (sr >= 12) { TL_ERASE3(7); TL_ERASE3(8); TL_ERASE3(9); TL_ERASE3(10); TL_ERASE3(11); TL_ERASE3(12); }
+            }
+        }
+#undef TL_ERASE3
     }
     TL_LANES_END
     TL_STAMP(sp, 3);
@@ -2005,6 +2070,7 @@ TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
     TL_LANES_BEGIN
     for (int t = lane; t < ntone + nnoise; t += 64) tl_masker_consts(TL_MK4(w), TL_MK_X(w), TL_MK_BARK(w), t, t < ntone);
     TL_LANES_END
+    const bool srt = ntone < 128 && nnoise < 64 && tl_maskers_sorted(TL_MK_BARK(w), ntone, nnoise);
     // lines 0..127: every lane folds the maskers into two ADJACENT lines (two independent dB-sum chains at a time) and
     // walks only the maskers that can reach one of them (-3 <= dz < 8 bark; the exact test stays in the step)
     TL_LANES_BEGIN
@@ -2014,7 +2080,8 @@ TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
         const double b0 = bark[line0], b1 = bark[line1];
         const TlMasker *mk = TL_MK4(w);
         int ta0, ta1, tb0, tb1;
-        tl_mask_spans(mk, ntone + nnoise, ntone, (b0 < b1 ? b0 : b1) - 8.0, (b0 < b1 ? b1 : b0) + 3.0, ta0, ta1, tb0, tb1);
+        if (srt) tl_mask_spans_sorted<64, 32>(TL_MK_BARK(w), ntone, nnoise, (b0 < b1 ? b0 : b1) - 8.0, (b0 < b1 ? b1 : b0) + 3.0, ta0, ta1, tb0, tb1);
+        else tl_mask_spans(mk, ntone + nnoise, ntone, (b0 < b1 ? b0 : b1) - 8.0, (b0 < b1 ? b1 : b0) + 3.0, ta0, ta1, tb0, tb1);
         double lt0 = TL_DBMIN, ln0 = TL_DBMIN, lt1 = TL_DBMIN, ln1 = TL_DBMIN;
         uint32_t far_hi = 0xC0F00000u;
         TL_PIN(far_hi);
@@ -2041,7 +2108,8 @@ TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
         const double bj = bark[line];
         const TlMasker *mk = TL_MK4(w);
         int ta0, ta1, tb0, tb1;                                       // only the maskers that can reach the line (it is one of the top eight)
-        tl_mask_spans(mk, ntone + nnoise, ntone, bj - 8.0, bj + 3.0, ta0, ta1, tb0, tb1);
+        if (srt) tl_mask_spans_sorted<64, 32>(TL_MK_BARK(w), ntone, nnoise, bj - 8.0, bj + 3.0, ta0, ta1, tb0, tb1);
+        else tl_mask_spans(mk, ntone + nnoise, ntone, bj - 8.0, bj + 3.0, ta0, ta1, tb0, tb1);
         const int t0 = lane < 8 ? ta0 : tb0, t1 = lane < 8 ? ta1 : tb1;
         double acc = TL_DBMIN;
         uint32_t far_hi = 0xC0F00000u;
