@@ -896,11 +896,12 @@ TL_FN void tl_psy_spectrum(TlPsyLds &w, const TlTables *TL_RESTRICT T, const TlP
 // the reference's libm by construction.  That matters: on degenerate spectra (a lone impulse: hundreds of lines of nearly
 // equal level) the tone tests and the allocation compare values that differ in the last bits (GPU soak, round 2).
 #define TL_LOGTAB(db) ((const uint64_t *)((db) + 1002))     /* the log table rides behind the dB-sum table in the workgroup's LDS block (TlTables::dblog) */
+// The floor (`energy < 1E-20 ? -200 + POWERNORM : ...`, psycho_1.c:243-246) is one maximum: log10 of the double 1E-20 is exactly -20.0
+// in glibc and in its restatement here (tests/test_libm_agree.py pins it), so 10 * log10(max(e, 1E-20)) + POWERNORM is the reference's
+// value on either side of the test -- (-200.0 + POWERNORM) is the same sum -- and the argument of the logarithm is always normal.
 TL_FN double tl_power_db(double e, const uint64_t *lt)
 {
-    const bool tiny = e < 1E-20;
-    const double v = 10 * tlm_log10_pn(TL_SELECT(tiny, 1.0, e), lt) + TL_POWERNORM;
-    return TL_SELECT(tiny, -200.0 + TL_POWERNORM, v);
+    return 10 * tlm_log10_pn(__builtin_fmax(e, 1E-20), lt) + TL_POWERNORM;
 }
 TL_FN int tl_run_psy1(int c) { return (c < 3 || c > 500) ? 0 : c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 12; }   // psycho_1.c:289-298
 TL_FN int tl_run_psy3(int c) { return c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 12; }                            // psycho_3.c:212-215
@@ -3040,7 +3041,10 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
         const unsigned qi = ba ? B->qinfo_line[L(a_ln)][ba] : 0u;   // class, bits and grouping from the shared LDS copy
         const int q = (int)(qi & 31u);
         const bool joint = any_joint && sb >= jsbound;
-        L(q_ba) = ba; L(q_nb) = (int)((qi >> 5) & 31u); L(q_grp) = ((qi >> 10) & 1u) ? 3 : 1; L(q_s2n) = K->steps2n[q]; L(q_steps) = K->steps[q];
+        // The field of a triple (encode_new.c:574-592) is ONE Horner form A + M (v1 + M C): three separate codewords of nb bits are
+        // v2 + 2^nb (v1 + 2^nb v0), a grouped codeword is v0 + steps (v1 + steps v2) -- M = 2^nb or steps, (A, C) = (v2, v0) or (v0, v2).
+        L(q_ba) = ba; L(q_nb) = (int)((qi >> 5) & 31u); L(q_grp) = ((qi >> 10) & 1u) ? 3 : 1; L(q_s2n) = K->steps2n[q];
+        L(q_steps) = ((qi >> 10) & 1u) ? 1 << L(q_nb) : K->steps[q];                                // M
         L(q_a) = K->qa[q]; L(q_b) = K->qb[q]; L(q_s2nf) = K->steps2n_f[q];
         for (int gr = 0; gr < 3; gr++) {
             L(q_sf)[gr] = B->scalefactor[joint ? w.jscale[gr][sb] : L(scf)[gr]];
@@ -3081,10 +3085,10 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
                 const int nb = L(q_nb);
                 const int pos = p_smp + r * n_smp + L(o_smp);
                 const bool three = L(q_grp) == 3;
-                const unsigned y = (unsigned)L(q_steps);
-                const uint64_t sep = ((uint64_t)v[0] << (2 * nb)) | ((uint64_t)v[1] << nb) | (uint64_t)v[2];
-                const uint64_t grp = (uint64_t)(v[0] + y * (v[1] + y * v[2]));
-                tl_put_bits48(frame, pos, TL_SELECT(three, sep, grp), three ? 3 * nb : nb);
+                const unsigned M = (unsigned)L(q_steps);
+                const unsigned fa = TL_SELECT(three, v[2], v[0]), fc = TL_SELECT(three, v[0], v[2]);
+                const unsigned inner = v[1] + M * fc;                                    // < 2^32: nb <= 16
+                tl_put_bits48(frame, pos, (uint64_t)fa + (uint64_t)M * (uint64_t)inner, L(q_grp) * nb);
             }
             if (taps) for (int x = 0; x < 3; x++) taps->subband[c][gr][j0 + x][sb] = (c < nch) ? v[x] : 0;
             TL_LANES_END
@@ -3398,7 +3402,8 @@ TL_FN void tl_encode_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, cons
         const int ba = sb < sblimit ? w.balloc[c][sb] : 0;
         const unsigned qi = ba ? B->qinfo_line[L(a_ln2)][ba] : 0u;
         const int q = (int)(qi & 31u);
-        L(q_ba) = ba; L(q_nb) = (int)((qi >> 5) & 31u); L(q_grp) = ((qi >> 10) & 1u) ? 3 : 1; L(q_s2n) = K->steps2n[q]; L(q_steps) = K->steps[q];
+        L(q_ba) = ba; L(q_nb) = (int)((qi >> 5) & 31u); L(q_grp) = ((qi >> 10) & 1u) ? 3 : 1; L(q_s2n) = K->steps2n[q];
+        L(q_steps) = ((qi >> 10) & 1u) ? 1 << L(q_nb) : K->steps[q];                                // M of the field's Horner form (tl_encode_frame)
         L(q_a) = K->qa[q]; L(q_b) = K->qb[q]; L(q_s2nf) = K->steps2n_f[q];
         for (int gr = 0; gr < 3; gr++) {
             L(q_sf)[gr] = B->scalefactor[L(scf)[gr]];
@@ -3426,10 +3431,10 @@ TL_FN void tl_encode_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, cons
                 }
                 const int nb = L(q_nb);
                 const bool three = L(q_grp) == 3;
-                const unsigned y = (unsigned)L(q_steps);
-                const uint64_t sep = ((uint64_t)v[0] << (2 * nb)) | ((uint64_t)v[1] << nb) | (uint64_t)v[2];
-                const uint64_t grp = (uint64_t)(v[0] + y * (v[1] + y * v[2]));
-                tl_put_bits48(w.u.frame[lane & 1], L(q_pos) + r * L(q_rstep), TL_SELECT(three, sep, grp), three ? 3 * nb : nb);
+                const unsigned M = (unsigned)L(q_steps);
+                const unsigned fa = TL_SELECT(three, v[2], v[0]), fc = TL_SELECT(three, v[0], v[2]);
+                const unsigned inner = v[1] + M * fc;
+                tl_put_bits48(w.u.frame[lane & 1], L(q_pos) + r * L(q_rstep), (uint64_t)fa + (uint64_t)M * (uint64_t)inner, L(q_grp) * nb);
             }
             TL_LANES_END
         }

@@ -37,3 +37,16 @@ def test_tables_are_this_libms_tables():
         body = body[body.index("{") + 1: body.index("}")]
         words = [int(w, 16) for w in re.findall(r"0x[0-9a-f]{16}", body)]
         assert len(words) == n and tuple(words) == struct.unpack_from(f"<{n}Q", libm, addr), name
+
+
+def test_log10_of_the_energy_floor_is_exactly_minus_twenty():
+    """csrc/mp2_wave.h tl_power_db() folds the reference's `energy < 1E-20 ? -200 + POWERNORM : 10 log10(energy) + POWERNORM`
+    (psycho_1.c:243-246, psycho_3.c:152-160) into 10 log10(max(energy, 1E-20)) + POWERNORM.  That is the same function exactly if
+    log10 of the double 1E-20 is -20.0 -- in the host's libm (what the reference runs) and in the restatement the device runs."""
+    import math
+    import sys
+    sys.path.insert(0, str(ROOT / "tests"))
+    import emulib as E
+    assert math.log10(1e-20) == -20.0
+    assert E.lib().emu_log10_pn(1e-20) == -20.0
+    assert 10 * math.log10(1e-20) + 90.3090 == -200.0 + 90.3090
