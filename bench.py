@@ -719,6 +719,23 @@ def main():
                                        "unit": "frames/s", "x_realtime": round((n1 // 2) * 6 / e1 / (FS / 1152.0), 1), "kernel_ms": round(k1, 4), "kernels_ms": st1, "output_check": chk1}
         except Exception as ex:  # noqa: BLE001
             also["one_stream_psy2"] = {"value": None, "error": str(ex)}
+        try:     # the real-time shape of models 2 / 4: ONE frame per launch, where the 16 KB per channel of r / phi prediction state is read and written per frame
+            st_, ft_ = CONFIGS[2][0], 1
+            rt2 = GpuRun(M, torch, np, gen_pcm, range(st_), ft_, args.mode, 2, local_rank, distinct=1024)
+            et2, _, kt2 = rt2.timed(None, shard, 4, 40)
+            d2 = dict(kernel_ms=kt2, last_ms=rt2.batch.last_kernel_ms(), algo=rt2.algo_bytes_per_launch)
+            tr2, trs2, _ = committed_counters(st_, ft_, 2, args.mode)
+            state_b = st_ * 2 * 2 * 2 * 513 * 8 * 2          # streams x channels x (r, phi) x two passes x 513 lines x 8 B, read + written
+            also["psy2_tick_shape"] = {"workload": f"{st_} streams x 1 frame per launch (48 kHz stereo 128 kbps, psy 2, mode '{args.mode}'): one GPU's share of a real-time tick with the model "
+                                                   "that carries prediction state from frame to frame (psycho_2.c:300-306)",
+                                       "value": round(st_ * ft_ * 40 / et2, 1), "unit": "frames/s", "kernel_ms": round(kt2, 4), "kernels_ms": rt2.stage_ms,
+                                       "share_of_the_24_ms_tick": round(kt2 / 24.0, 4), "algorithmic_bytes_per_launch": rt2.algo_bytes_per_launch,
+                                       "prediction_state_bytes_per_launch": state_b, "traffic": tr2, "traffic_source": trs2,
+                                       "traffic_over_algorithmic": round(tr2 / rt2.algo_bytes_per_launch, 2) if tr2 else None,
+                                       "hbm_time_of_the_state_ms": round(state_b / (HBM_PEAK_GBS * 1e9) * 1e3, 4), "output_check": rt2.check()}
+            rt2.close()
+        except Exception as ex:  # noqa: BLE001
+            also["psy2_tick_shape"] = {"value": None, "error": str(ex)}
         also["tick_pipeline"] = {}
         for nt2 in (16384, 131072):   # one GPU's share of BASELINE configs[3], and all of configs[3] on one GPU
             try:

@@ -1,0 +1,229 @@
+// mp2_psy24.h -- psy models 2 and 4 (psycho_2.c, psycho_4.c): one 576-sample pass of one channel (tl_psy2_pass).
+// Part of mp2_wave.h (included from there, in order; lane-SPMD source that compiles for gfx950 and, with TL_EMULATE, as a lane loop).
+#ifndef MP2_WAVE_PARTS
+#error "include mp2_wave.h"
+#endif
+// ------------------------------------------------------------------------------------------
+// psy model 2 (psycho_2.c:52-254, psycho_2_fft fft.c:1230-1275), one 576-sample pass of channel `ch`.
+// Two passes per frame; a pass needs the 480 samples before its 544 new ones -- the stream's PCM history on pass 0,
+// samples 96..575 of the frame on pass 1 (the reference's savebuf shift by 576).
+// Line-parallel: FFT, unpredictability (sincos/atan2/sqrt per line), thresholds; partition-parallel:
+// grouping, spreading, SNR.  Every sum is one lane's sequential chain in the reference's order.
+//
+// The prediction state.  The reference keeps r = sqrt(energy) and phi of the two previous passes per line
+// (psycho_2.c:111-116, 300-306) -- but there is no recurrence in it: both are functions of that pass's transform alone
+// (`lthr`, the one true feedback of the model, is dead for Layer II, psycho_2.c:214-224).  So a run of passes can start
+// anywhere: two SEED passes (transform, square root, arctangent -- no unpredictability, nothing after it) over the 1152
+// samples before it rebuild exactly the state the chain would have carried there.  During a run the state lives in the wave's
+// REGISTERS: line lane + 64 it in slot `it` of r1/p1 (previous pass) and r2/p2 (the pass before), line 512 in four LDS words.
+#define TL_P2_L512(w) ((w).px + 516)     /* r1, r2, p1, p2 of line 512 (c[] / fthr[] end at px[512]) */
+template <bool SEED>
+TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_RESTRICT P, const TlPcmView &pv, int ch, int pass,
+                        PARGA(double, r1, 8), PARGA(double, r2, 8), PARGA(double, p1, 8), PARGA(double, p2, 8),
+                        PARG(double, snr0), double *smr_out, const uint64_t *sct, long long *sq)
+{   // sct: glibc's __sincostab (tl_libm.h), the workgroup's LDS copy on the device
+    double *x = w.u.fft;
+    double *cw = w.px, *ge = w.u.fft + 520;  // c[] (unpredictability), then fthr[]; partition sums in the
+    double *gc = ge + 64, *ecb = gc + 64, *nb = ecb + 64;   // dead upper half of the FHT buffer
+    double *l5 = TL_P2_L512(w);
+    {
+        TL_STAMP(sq, 0);
+        PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
+        TL_LANES_BEGIN
+        {
+            // sample i = lane + 64*it of the pass's 1024-sample window (psycho_2.c:84-92); loads in batches of eight ahead
+            // of their use; slot of i inside the lane's block of sixteen: rev4(it) (see tl_fht_head)
+            const double *win = P->window;
+            TL_LAUNDER(win);
+            const int16_t *pvh = ch ? pv.hist[1] : pv.hist[0], *pvc = ch ? pv.cur[1] : pv.cur[0];
+            tl_fht_twiddles<4>(L(twc), T, lane);
+            double e[16];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int half = 0; half < 16; half += 8) {
+                int16_t v[8]; double h[8];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                for (int q = 0; q < 8; q++) {
+                    const int i = lane + 64 * (half + q);
+                    if (pass == 0) v[q] = i < TL_HIST ? pvh[i] : pvc[i - TL_HIST];
+                    else v[q] = pvc[96 + i];
+                    h[q] = win[i];
+                }
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                for (int q = 0; q < 8; q++) {
+                    const int it = half + q;
+                    const int r4 = ((it & 1) << 3) | ((it & 2) << 1) | ((it & 4) >> 1) | ((it & 8) >> 3);
+                    e[r4] = h[q] * (double)v[q];
+                }
+            }
+            tl_fht_twiddles<6>(L(twb), T, lane);
+            tl_fht_head(e, T->fht_tw);
+            tl_fht_store(x, lane, e);
+        }
+        TL_LANES_END
+        TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), T, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass<8>(x, L(twa), lane); TL_LANES_END
+        TL_STAMP(sq, 1);
+        // energy + phase (fft.c:1246-1275), unpredictability (psycho_2.c:119-140).
+        // 64 lines per step: the transform is read through the layout map first, then the step's energies are written in
+        // natural order (their slots hold nothing a later step reads).
+        // Lines 0..511 are eight full steps of the wave; line 512 would be a ninth with ONE lane at work, at the price of a full
+        // step (two sincos, an atan2, two square roots for every lane).  It needs no arctangent of its own (its phase is 0 or pi,
+        // fft.c:1274) and line 0 needs none either and no sincos of its phase (phi = 0, fft.c:1257-1259), so in step 0 lane 0 puts
+        // line 512's PREDICTED phase through its first sincos slot and finishes that line with a few extra operations.
+        PV(double, e512);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int it = 0; it < 8; it++) {
+            PV(double, xa); PV(double, xb); PV(double, xc);
+            TL_LANES_BEGIN
+            const int j = lane + 64 * it;
+            L(xa) = x[TL_FX(j)];
+            L(xb) = j >= 1 ? x[TL_FX(1024 - j)] : 0.0;
+            L(xc) = it == 0 ? x[TL_FX(512)] : 0.0;
+            TL_LANES_END
+            TL_LANES_BEGIN
+            const int j = lane + 64 * it;
+            {
+                const bool first = j == 0;                           // lane 0 of step 0: lines 0 and 512
+                double r_o5 = 0, r_n5 = 0, p_o5 = 0, p_n5 = 0;      // state of line 512
+                if (it == 0) { r_o5 = l5[0]; r_n5 = l5[1]; p_o5 = l5[2]; p_n5 = l5[3]; }
+                const double a = L(xa), b = L(xb);
+                double e = (a * a + b * b) / 2.0;
+                const bool low = e < 0.0005;
+                double phi = tlm_atan2_sl<false>(-a, b, tlm_atan_cij) + 3.14159265358979 / 4;
+                e = TL_SELECT(low, 0.0005, e); phi = TL_SELECT(low, 0.0, phi);
+                e = TL_SELECT(first, a * a, e); phi = TL_SELECT(first, 0.0, phi);      // line 0: energy x_real[0]^2, phase 0
+                const double rn = sqrt(e);
+                double spp5 = 0, cpp5 = 0;
+                if (!SEED) {
+                    const double r_prime = 2.0 * L(r1)[it] - L(r2)[it];
+                    const double phi_prime = 2.0 * L(p1)[it] - L(p2)[it];
+                    double sp, cp, spp, cpp;
+                    tlm_sincos_sl(TL_SELECT(first, 2.0 * p_o5 - p_n5, phi), &sp, &cp, sct);
+                    tlm_sincos_sl(phi_prime, &spp, &cpp, sct);
+                    spp5 = sp; cpp5 = cp;                                // sincos of line 512's predicted phase (lane 0 of step 0)
+                    sp = TL_SELECT(first, 0.0, sp); cp = TL_SELECT(first, 1.0, cp);         // sincos(0.0)
+                    const double t1 = rn * cp - r_prime * cpp;
+                    const double t2 = rn * sp - r_prime * spp;
+                    const double t3 = rn + fabs(r_prime);
+                    cw[j] = t3 != 0 ? sqrt(t1 * t1 + t2 * t2) / t3 : 0;
+                    x[j] = e;
+                }
+                L(r2)[it] = L(r1)[it]; L(r1)[it] = rn; L(p2)[it] = L(p1)[it]; L(p1)[it] = phi;
+                if (it == 0) {                                       // line 512 (psycho_2.c:110-140 with fft.c:1274's phase), finished by lane 0
+                    const double c5 = L(xc);
+                    const double e5 = c5 * c5;
+                    const bool neg5 = (tl_d2u(c5) >> 63) != 0;       // atan2(+0.0, x) = pi for x < 0 and x = -0, else +0
+                    const double phi5 = neg5 ? tl_u2d(0x400921fb54442d18ull) : 0.0;
+                    const double rn5 = sqrt(e5);
+                    double c512 = 0;
+                    if (!SEED) {
+                        const double sp5 = neg5 ? tl_u2d(0x3ca1a62633145c07ull) : 0.0, cp5 = neg5 ? -1.0 : 1.0;   // glibc's sincos of that pi / of 0
+                        const double r_prime5 = 2.0 * r_o5 - r_n5;
+                        const double t15 = rn5 * cp5 - r_prime5 * cpp5;
+                        const double t25 = rn5 * sp5 - r_prime5 * spp5;
+                        const double t35 = rn5 + fabs(r_prime5);
+                        c512 = t35 != 0 ? sqrt(t15 * t15 + t25 * t25) / t35 : 0;
+                    }
+                    if (first) { l5[0] = rn5; l5[1] = r_o5; l5[2] = phi5; l5[3] = p_o5; if (!SEED) cw[512] = c512; }
+                    L(e512) = e5;                                    // slot 512 of the transform buffer still holds a point step 7 reads
+                }
+            }
+            TL_LANES_END
+        }
+        if (SEED) return;
+        TL_LANES_BEGIN
+        if (lane == 0) x[512] = L(e512);
+        TL_LANES_END
+        TL_STAMP(sq, 2);
+        const double *energy = x;
+        // grouped energy / weighted unpredictability per partition (psycho_2.c:146-155)
+        TL_LANES_BEGIN
+        {
+            double e = 0, c = 0;
+            if (lane < P->npart) {
+                const int lo = P->part_lo[lane], hi = P->part_hi[lane];
+                int j = lo;
+                for (; j + 8 <= hi; j += 8) {                           // eight lines' operands per LDS round trip, summed in line order
+                    double ev[8], cv[8];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                    for (int q = 0; q < 8; q++) { ev[q] = energy[j + q]; cv[q] = cw[j + q]; }
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                    for (int q = 0; q < 8; q++) { e += ev[q]; c += ev[q] * cv[q]; }
+                }
+                for (; j < hi; j++) { e += energy[j]; c += energy[j] * cw[j]; }
+            }
+            ge[lane] = e; gc[lane] = c;
+        }
+        TL_LANES_END
+        TL_STAMP(sq, 3);
+        // spreading (psycho_2.c:161-175), required SNR (:181-193), permissible noise (:200-204)
+        TL_LANES_BEGIN
+        {
+            double e = 0, c = 0;
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int k0 = 0; k0 < 64; k0 += 16) {                   // sixteen coefficient loads in flight per round trip
+                double sv[16];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                for (int q = 0; q < 16; q++) sv[q] = P->s_t[k0 + q][lane];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                // the reference skips zero coefficients (psycho_2.c:165); adding their +-0 products leaves the sums unchanged
+                // bit for bit (finite operands, sums start at +0), so the test is dropped instead of branching 64 times
+                for (int q = 0; q < 16; q++) { e += sv[q] * ge[k0 + q]; c += sv[q] * gc[k0 + q]; }
+            }
+            double cb = e != 0 ? c / e : 0;
+            if (cb < .05) cb = 0.05; else if (cb > .5) cb = 0.5;
+            const double tb = -0.434294482 * tlm_log_pn(cb, tlm_log_tab) - 0.301029996;
+            double bc = P->tmn[lane] * tb + 5.5 * (1.0 - tb);
+            bc = bc > P->bmaxk[lane] ? bc : P->bmaxk[lane];
+            bc = tlm_exp_sl<false>(-bc * 0.2302585093, 0.0);
+            ecb[lane] = e;
+            nb[lane] = P->den[lane] != 0 ? e * bc / P->den[lane] : 0;
+        }
+        TL_LANES_END
+        TL_STAMP(sq, 4);
+        // threshold per line (psycho_2.c:205-224): c[] is dead, reuse it for fthr[]
+        TL_LANES_BEGIN
+        for (int j = lane; j <= 512; j += 64) {
+            const double t = nb[P->partition[j]], a = P->absthr[j];
+            cw[j] = t > a ? t : a;
+        }
+        TL_LANES_END
+        TL_STAMP(sq, 5);
+        // 32 subbands (psycho_2.c:227-246)
+        TL_LANES_BEGIN
+        if (lane < 32) {
+            const int j = 16 * lane;
+            double minthres = lane < 13 ? 60802371420160.0 : 0.0, sum_energy = 0.0;
+            for (int k = 0; k < 17; k++) {
+                if (lane < 13) { if (minthres > cw[j + k]) minthres = cw[j + k]; }
+                else minthres += cw[j + k];
+                sum_energy += energy[j + k];
+            }
+            double snr = lane < 13 ? sum_energy / (minthres * 17.0) : sum_energy / minthres;
+            snr = 4.342944819 * tlm_log_pn(snr, tlm_log_tab);
+            if (pass == 0) L(snr0) = snr;
+            else smr_out[lane] = L(snr0) > snr ? L(snr0) : snr;
+        }
+        TL_LANES_END
+        TL_STAMP(sq, 6);
+    }
+}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters per kernel of the split path (one rocprofv3 --pmc pass per counter group, kernel trace only).
+# SQ counters per kernel of the split path (one rocprofv3 --pmc pass per counter group -- four groups --, kernel trace only).
 # usage: tools/pmc_split.sh TAG [bench args...]     -> gpurun_out/sq_TAG.json
 set -u
 TAG=${1:-r02}; shift
@@ -7,8 +7,10 @@ R=$PWD; export TMPDIR=/tmp; mkdir -p gpurun_out
 G1="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"
 G2="SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES"
 G3="GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_F64"
+# round 5: the instruction classes (what the bench line's issue-cost model weighs) and the lane occupancy of the vector instructions
+G4="SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64"
 i=0
-for G in "$G1" "$G2" "$G3"; do
+for G in "$G1" "$G2" "$G3" "$G4"; do
   i=$((i+1))
   rm -rf $R/gpurun_out/sqs_${TAG}_$i
   rocprofv3 --pmc $G --kernel-trace --output-format csv -d $R/gpurun_out/sqs_${TAG}_$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also "$@" > gpurun_out/sqs_${TAG}_$i.log 2>&1
