@@ -13,23 +13,7 @@
 #pragma once
 #include <stdint.h>
 
-#define TL_PFT_MAX_CHUNKS 10          // AF packets < 2048 bytes, chunks of up to 207
-#define TL_PFT_PARITY 48
-
-struct TlPftArgs {
-    const uint8_t *af;                // [nframes][nstreams][af_stride] AF packets (tlb_edi_af_* output)
-    const int32_t *af_len;            // [nframes][nstreams]
-    const uint16_t *pseq;             // [nstreams] PFT::m_pseq before the first packet of this call
-    uint16_t *pseq_out;               // [nstreams] after the last one (a different array)
-    uint8_t *frags;                   // [nframes][nstreams][max_frags][frag_stride]: PF header + payload
-    int32_t *frag_len;                // [nframes][nstreams][max_frags]
-    int32_t *nfrag;                   // [nframes][nstreams]
-    int32_t nstreams, nframes, af_stride, max_frags, frag_stride;
-    int32_t fec;                      // m: fragments that can be lost (0 = no Reed-Solomon, fragmentation only)
-    int32_t chunk_len;                // k_max of the configuration (<= 207)
-    int32_t transport;                // 1: PF header carries source/destination
-    int32_t addr_source, dest_port;
-};
+#include "edi_types.h"
 
 TL_FN uint32_t tl_crc16_ccitt_byte(uint32_t r, uint32_t by)
 {
