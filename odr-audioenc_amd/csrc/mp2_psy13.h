@@ -185,7 +185,11 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
         const uint32_t pinfo = w.cinfo[in && kb + lane > 0 ? kb + lane - 1 : 0];    // the candidate before this one
         L(cc) = (int)(info & 511u); L(crun) = (int)(info >> 21);
         L(cpx) = px[L(cc)];
+#if defined(TL_WALK_SKIP) && (TL_WALK_SKIP & 1)
+        L(clf) = 0;                                                   // diagnostic build: what the left-neighbour tests cost
+#else
         L(clf) = (int)tl_cand_left<false>(px, L(cc), L(crun), L(cpx));
+#endif
         L(act) = in;
         // A candidate at least run(previous candidate) + run(its own) + 1 lines above the candidate before it is out of every earlier
         // tone's reach whatever the walk's state is when it gets there: `last` is at or below that previous candidate and runs grow
@@ -261,6 +265,12 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
         }
         TL_SYNC();
     }
+#if defined(TL_WALK_SKIP) && (TL_WALK_SKIP & 2)
+    nconf = 0;                                                        // diagnostic build: what levels, erasures and the list cost
+#endif
+#if defined(TL_WALK_SKIP) && (TL_WALK_SKIP & 4)
+    if (nconf > 1) nconf = 1;
+#endif
     // (3) levels of the confirmed tones from the still-original spectrum (psycho_1.c:317-321)
     TL_LANES_BEGIN
     for (int i = lane; i < nconf; i += 64) {
