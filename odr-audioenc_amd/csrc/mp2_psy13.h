@@ -376,7 +376,7 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
     // LAST): its line is no longer TONE, so a noise centre may land on it and splice the noise chain into the tone chain.
     // That (rare) case is replayed pointer by pointer (tl_psy1_deadhead); otherwise the chains are independent.
     r.dead_head = nconf > 0 && ((w.conf_c[0] >> 13) & 1);
-    TL_DBG_TONES(nconf, r.dead_head);
+    TL_DBG_TONES(nconf, r.dead_head); TL_DBG_CAND(ncand);
     return r;
 }
 

@@ -286,7 +286,8 @@ typedef const struct TlLaunch *TlKArg;                                        /*
 #define TL_DBG_DUMP(tag, ch, nt, nn, x, b) do { if (getenv("TL_DUMP")) { printf("%s ch%d ntone %d nnoise %d:", tag, ch, nt, nn); \
     for (int i_ = 0; i_ < (nt) + (nn); i_++) printf(" (%.17g,%.6f)", (x)[i_], (b)[i_]); printf("\n"); } } while (0)
 #define TL_DBG_WALK(ch, lane, cnt) do { if (getenv("TL_DUMP_WALK")) printf("walk ch%d lane %d cnt %d\n", ch, lane, cnt); } while (0)
-static long tl_dbg_rounds = 0, tl_dbg_tones = 0, tl_dbg_deadheads = 0, tl_dbg_fronts = 0;
+static long tl_dbg_rounds = 0, tl_dbg_tones = 0, tl_dbg_deadheads = 0, tl_dbg_fronts = 0, tl_dbg_cands = 0;
+#define TL_DBG_CAND(n) (tl_dbg_cands += (n))
 #define TL_DBG_ROUND() (tl_dbg_rounds++)
 #define TL_DBG_TONES(n, dh) (tl_dbg_tones += (n), tl_dbg_deadheads += (dh) ? 1 : 0, tl_dbg_fronts++)
 #else
@@ -294,6 +295,7 @@ static long tl_dbg_rounds = 0, tl_dbg_tones = 0, tl_dbg_deadheads = 0, tl_dbg_fr
 #define TL_DBG_WALK(ch, lane, cnt) ((void)0)
 #define TL_DBG_ROUND() ((void)0)
 #define TL_DBG_TONES(n, dh) ((void)0)
+#define TL_DBG_CAND(n) ((void)0)
 #endif
 // Diagnostic builds only (tools/instr_budget.sh): TL_EXP_LEVEL = n removes the last n stages of psy model 1 (results are then
 // wrong on purpose); the VALU-instruction counters of successive levels attribute the instructions to the stages.

@@ -305,5 +305,5 @@ long emu_div_by_check(const double *s, const double *d, long n)
 #ifdef TL_DEBUG_DUMP
 // diagnostic builds only (-DTL_DEBUG_DUMP): rounds of the tone walks since the process started (tl_psy1_front / tl_psy3_front)
 extern "C" long emu_walk_rounds(void) { return tl_dbg_rounds; }
-extern "C" void emu_walk_stats(long *out) { out[0] = tl_dbg_rounds; out[1] = tl_dbg_tones; out[2] = tl_dbg_deadheads; out[3] = tl_dbg_fronts; }
+extern "C" void emu_walk_stats(long *out) { out[0] = tl_dbg_rounds; out[1] = tl_dbg_tones; out[2] = tl_dbg_deadheads; out[3] = tl_dbg_fronts; out[4] = tl_dbg_cands; }
 #endif
