@@ -112,10 +112,15 @@ TL_FN void tl_filterbank(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const
                 for (int bb = 0; bb < FB; bb++) oth[bb] = __shfl(part[bb], partner, 64);
             }
 #endif
+            // s[i] = s0 + s1 on the lanes of the even chains, s[31 - i] = s0 - s1 on the others: two BRANCHES, so that each half of the wave
+            // runs one addition per block under its own execution mask -- as selects both results are computed for every lane and two
+            // v_cndmask per block pick one (4 instructions per block against 1 + 1)
             TL_LANES_BEGIN
             const int c = lane & 1, sb = lane >> 1;
-            for (int bb = 0; bb < FB; bb++)
-                L(smp)[b0 + bb] = c < nch ? (sb < 16 ? L(part)[bb] + L(oth)[bb] : L(oth)[bb] - L(part)[bb]) : 0.0;
+            if (c < nch) {
+                if (sb < 16) { for (int bb = 0; bb < FB; bb++) L(smp)[b0 + bb] = L(part)[bb] + L(oth)[bb]; }
+                else { for (int bb = 0; bb < FB; bb++) L(smp)[b0 + bb] = L(oth)[bb] - L(part)[bb]; }
+            } else for (int bb = 0; bb < FB; bb++) L(smp)[b0 + bb] = 0.0;
             TL_LANES_END
         }
 }
