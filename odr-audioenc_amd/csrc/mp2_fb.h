@@ -116,11 +116,10 @@ TL_FN void tl_filterbank(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const
             // runs one addition per block under its own execution mask -- as selects both results are computed for every lane and two
             // v_cndmask per block pick one (4 instructions per block against 1 + 1)
             TL_LANES_BEGIN
-            const int c = lane & 1, sb = lane >> 1;
-            if (c < nch) {
-                if (sb < 16) { for (int bb = 0; bb < FB; bb++) L(smp)[b0 + bb] = L(part)[bb] + L(oth)[bb]; }
-                else { for (int bb = 0; bb < FB; bb++) L(smp)[b0 + bb] = L(oth)[bb] - L(part)[bb]; }
-            } else for (int bb = 0; bb < FB; bb++) L(smp)[b0 + bb] = 0.0;
+            const int sb = lane >> 1;
+            // (lanes of a channel the stream does not have hold part = oth = +0.0 -- their chains were skipped -- and come out as +0.0 either way)
+            if (sb < 16) { for (int bb = 0; bb < FB; bb++) L(smp)[b0 + bb] = L(part)[bb] + L(oth)[bb]; }
+            else { for (int bb = 0; bb < FB; bb++) L(smp)[b0 + bb] = L(oth)[bb] - L(part)[bb]; }
             TL_LANES_END
         }
 }

@@ -125,7 +125,9 @@ TL_FN void tl_psy_spectrum(TlPsyLds &w, const TlTables *TL_RESTRICT T, const TlP
         // of sixteen: rev4(it).
         const int16_t *hs = (ch ? pv.hist[1] : pv.hist[0]) + (TL_HIST - 192) + lane;      // (a select, not an indexed array: that would live in scratch)
         const int16_t *cs = (ch ? pv.cur[1] : pv.cur[0]) - 192 + lane;
-        const double *hann = T->hann;
+        // (sample / 32768) * window (psycho_1.c:57-76) as sample * (window / 32768): the division by a power of two is exact on either
+        // factor and commutes with the rounding of the product (nothing near the subnormal range), so the bits are the same
+        const double *hann = T->hann_s;
         TL_LAUNDER(hann);
         tl_fht_twiddles<4>(L(twc), T, lane);
         double e[16];
@@ -144,7 +146,7 @@ TL_FN void tl_psy_spectrum(TlPsyLds &w, const TlTables *TL_RESTRICT T, const TlP
             for (int q = 0; q < 8; q++) {
                 const int it = half + q;
                 const int r4 = ((it & 1) << 3) | ((it & 2) << 1) | ((it & 4) >> 1) | ((it & 8) >> 3);
-                e[r4] = ((double)v[q] / 32768) * h[q];
+                e[r4] = (double)v[q] * h[q];
             }
         }
         tl_fht_head(e, T->fht_tw);

@@ -127,6 +127,7 @@ void tl_build_tables(TlTables *T)
     // Hann window with the sqrt(8/3)/N normalisation (psycho_1.c:225-233, psycho_3.c:135-141)
     const double sqrt_8_over_3 = pow(8.0 / 3.0, 0.5);
     for (int i = 0; i < 1024; i++) T->hann[i] = sqrt_8_over_3 * 0.5 * (1 - cos(2.0 * kRefPi * i / 1024)) / 1024;
+    for (int i = 0; i < 1024; i++) T->hann_s[i] = T->hann[i] / 32768;           // a power of two: exact
     // dB-sum table (psycho_1.c:170-178, psycho_3.c:249-257)
     for (int i = 0; i < 1000; i++) {
         double x = (double)i / 10.0;

@@ -143,12 +143,14 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
 #pragma unroll
 #endif
         for (int j = 0; j < 16; j++) e[j] = energy[16 * lane + (j ^ (lane & 15))];      // == energy[TL_EX(16 * lane + j)]
-        double sum = 1E-20;
+        // 1E-20 + sum of 2^30 e[j] in line order (psycho_1.c:252-257) as 2^30 times (1E-20 / 2^30 + sum of e[j]): scaling every operand of a
+        // chain of additions by a power of two scales every partial sum exactly (no operand is anywhere near the subnormal range)
+        double sum = 1E-20 * (1.0 / 1073741824);
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int j = 0; j < 16; j++) sum += 1073741824 * e[j];
-        const double spk = 10.0 * tlm_log10_pn(sum, TL_LOGTAB(db));
+        for (int j = 0; j < 16; j++) sum += e[j];
+        const double spk = 10.0 * tlm_log10_pn(1073741824 * sum, TL_LOGTAB(db));
         L(rec)[ch] = spk;                                           // final as it is: straight to the record (nothing to park)
     } else if (lane < 32) L(rec)[ch] = 0.0;
     TL_LANES_END

@@ -43,6 +43,7 @@ struct TlTables {
     double enwindow_s[512];      // enwindow / 32768: the filterbank scales the coefficient instead of the sample (exact, see mp2_wave.h K1)
     double dct[16][32];
     double hann[1024];
+    double hann_s[1024];          // hann[i] / 32768 (exact): the model's window with the sample scaling folded in (tl_psy_spectrum)
     double dbtable[1000];
     double fht_tw[166][4];       // (c1,s1,c2,s2) for passes k=2,4,6,8, i=1..kx-1
     double fht_tw_lane[3][128][4];   // the same rows in the order the lanes of passes k=4,6,8 use them: [pass][butterfly g][.]
