@@ -369,15 +369,19 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
             const int byte = lane < 2 ? lane + 2 : lane + 4;          // frame byte holding them
             const int cnt = preset ? 8 : (n - first < 8 ? n - first : 8);
             const int e0 = preset ? n + 8 * (63 - lane) : 16 + (n - first - cnt);     // exponent of the byte's last bit
-            unsigned xp = K->crc_xpow[e0];
+            // bit k of the byte contributes x^(e0 + k) mod P: eight reads of the power table (one address, constant offsets) and a masked
+            // XOR per bit -- instead of stepping x^e through the polynomial in registers (nine operations per bit)
+            const uint16_t *xt = &K->crc_xpow[e0];
             const unsigned v = preset ? 0xffu : ((frame[byte >> 2] >> (24 - 8 * (byte & 3))) & 0xffu) >> (8 - cnt);
+            unsigned x8[8];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-            for (int k = 0; k < 8; k++) {                             // bits past cnt are zero
-                acc ^= ((v >> k) & 1u) ? xp : 0u;
-                xp = ((xp << 1) & 0xffffu) ^ ((xp & 0x8000u) ? 0x8005u : 0u);
-            }
+            for (int k = 0; k < 8; k++) x8[k] = xt[k];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int k = 0; k < 8; k++) acc ^= (0u - ((v >> k) & 1u)) & x8[k];            // bits past cnt are zero
         }
         L(part) = acc;
         TL_LANES_END
@@ -709,15 +713,17 @@ TL_FN void tl_encode_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, cons
             const int byte = l5 < 2 ? l5 + 2 : l5 + 4;
             const int cnt = preset ? 8 : (n - first < 8 ? n - first : 8);
             const int e0 = preset ? n + 8 * (31 - l5) : 16 + (n - first - cnt);
-            unsigned xp = K->crc_xpow[e0];
+            const uint16_t *xt = &K->crc_xpow[e0];                   // as in tl_encode_frame: the power table instead of stepping x^e
             const unsigned v = preset ? 0xffu : ((frame[byte >> 2] >> (24 - 8 * (byte & 3))) & 0xffu) >> (8 - cnt);
+            unsigned x8[8];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-            for (int k = 0; k < 8; k++) {
-                acc ^= ((v >> k) & 1u) ? xp : 0u;
-                xp = ((xp << 1) & 0xffffu) ^ ((xp & 0x8000u) ? 0x8005u : 0u);
-            }
+            for (int k = 0; k < 8; k++) x8[k] = xt[k];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int k = 0; k < 8; k++) acc ^= (0u - ((v >> k) & 1u)) & x8[k];
         }
         L(part0) = u == 0 ? acc : 0u; L(part1) = u == 1 ? acc : 0u;
         TL_LANES_END
