@@ -62,6 +62,8 @@ void tl_build_tables(TlTables *T)
             T->shared.qinfo_line[l][b] = (uint16_t)(q | (TL_BITS[q] << 5) | ((TL_GROUP[q] == 3 ? 1 : 0) << 10));
         }
     for (int i = 0; i < 64; i++) T->shared.scalefactor[i] = T->scalefactor[i];
+    for (int i = 0; i < 63; i++) T->shared.scale_db[i] = 20 * log10(((double)TL_SCALEFACTOR_E14[i] / 1e14) * 32768) - 10;   // == TlConfig::scale_db (tl_build_config)
+    T->shared.scale_db[63] = 20 * log10(1e-20 * 32768) - 10;
     {   // sf_transmission_pattern: pattern[5][5] of encode_new.c:296-301 as (sources of the three scalefactors, scfsi)
         static const unsigned short pat[25] = {0x123, 0x122, 0x122, 0x133, 0x123, 0x113, 0x111, 0x111, 0x444, 0x113,
                                                0x111, 0x111, 0x111, 0x333, 0x113, 0x222, 0x222, 0x222, 0x333, 0x123,

@@ -32,6 +32,16 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     for (int b = 0; b < 36; b++) TL_KEEP(smp[b]);
     scf[0] = scf[1] = scf[2] = 0;
 #endif
+    // the lane's allocation line and field width come from the configuration record (HBM / L2): requested here, used by the allocation
+    PV(int, a_ln); PV(int, a_nbal);
+    TL_LANES_BEGIN
+    {
+        const int c = lane & 1, sb = lane >> 1;
+        const bool live = c < nch && sb < sblimit;
+        L(a_ln) = live ? C->line[sb] : 0;
+        L(a_nbal) = live ? C->nbal[sb] : 0;
+    }
+    TL_LANES_END
     // ---- K2: scalefactors (encode_new.c:179-230) + find_sf_max (:260-277) ----
     TL_LANES_BEGIN
     const int c = lane & 1, sb = lane >> 1;
@@ -116,7 +126,7 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
         const int c = lane & 1, sb = lane >> 1;
         if (c < nch) {
             const double a = w.smr[c][sb], m = w.psy_m[c][sb];
-            const double val = C->scale_db[w.minidx[c][sb]];
+            const double val = B->scale_db[w.minidx[c][sb]];
             const double top = a > val ? a : val;
             w.smr[c][sb] = top - m;
         }
@@ -153,12 +163,10 @@ TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const Tl
     int adb = lg_frame * 8 - (C->dab_ext * 8 + (xpad_len ? xpad_len : 2) * 8);     // toolame.c:292-301
     int mode = C->mode0, mode_ext = C->mode_ext0, jsbound = C->jsbound0;
     // per-lane constants of the allocation loops
-    PV(int, a_ln); PV(int, a_nbal); PV(int, a_sfs); PV(int, a_sfs_o); PV(double, a_smr); PV(double, a_smr_o);
+    PV(int, a_sfs); PV(int, a_sfs_o); PV(double, a_smr); PV(double, a_smr_o);
     TL_LANES_BEGIN
     const int c = lane & 1, sb = lane >> 1;
     const bool live = c < nch && sb < sblimit;
-    L(a_ln) = live ? C->line[sb] : 0;
-    L(a_nbal) = live ? C->nbal[sb] : 0;
     L(a_sfs) = live ? 6 * tl_sfs_count(w.scfsi[c][sb]) : 0;
     L(a_sfs_o) = (live && nch == 2) ? 6 * tl_sfs_count(w.scfsi[1 - c][sb]) : 0;
     L(a_smr) = live ? w.smr[c][sb] : 0.0;
@@ -550,7 +558,7 @@ TL_FN void tl_encode_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, cons
         w.smr[c][sb] = (c ? PO[1] : PO[0])->a[0][sb];
     } else {
         const double a = w.smr[c][sb], m = w.psy_m[c][sb];
-        const double val = C->scale_db[w.minidx[c][sb]];
+        const double val = B->scale_db[w.minidx[c][sb]];
         const double top = a > val ? a : val;
         w.smr[c][sb] = top - m;
     }

@@ -466,11 +466,19 @@ TL_FN void tl_psy1_chain2(TlPsyLds &w, const double *TL_RESTRICT db, int nbands,
 }
 
 // band centres (psycho_1.c:367-388) from the sums and weights of lanes b < nbands; needs ptype[] of the channel
-TL_FN void tl_psy1_centres(TlPsyLds &w, const TlConfig *TL_RESTRICT C, int nbands, PARG(double, bsum), PARG(double, wt))
+// the band limits of lane b (the configuration record is in HBM / L2: requested BEFORE the chains run, used by tl_psy1_centres after them)
+TL_FN void tl_psy1_limits(const TlConfig *TL_RESTRICT C, int nbands, PARG(int, blo), PARG(int, bhi))
+{
+    TL_LANES_BEGIN
+    const int b = lane < nbands ? lane : 0;
+    L(blo) = C->p1_cbound[b]; L(bhi) = C->p1_cbound[b + 1];
+    TL_LANES_END
+}
+TL_FN void tl_psy1_centres(TlPsyLds &w, int nbands, PARG(double, bsum), PARG(double, wt), PARG(int, blo), PARG(int, bhi))
 {
     TL_LANES_BEGIN
     if (lane < nbands) {
-        const int lo = C->p1_cbound[lane], hi = C->p1_cbound[lane + 1];
+        const int lo = L(blo), hi = L(bhi);
         const double sum = L(bsum), weight = L(wt);
         int centre;
         if (sum <= TL_DBMIN) centre = (hi + lo) / 2;
@@ -494,6 +502,17 @@ TL_FN void tl_psy1_thresholds(TlPsyLds &w, const double *TL_RESTRICT db, const T
     TL_DBG_DUMP("psy1", ch, ntone, nnoise, TL_MK_X(w), TL_MK_BARK(w));
     // ---- individual + global masking thresholds on the table lines (psycho_1.c:480-532) ----
     const int sub = C->p1_sub;
+    // the lane's table rows (bark and threshold in quiet of its two lines: the configuration record in HBM / L2) are requested before
+    // the masker records are built and the order test runs, so that their latency is not the first thing the walk waits for
+    PV(double, tb0); PV(double, tb1); PV(double, th0); PV(double, th1); PV(int, mmn); PV(int, mmj);
+    TL_LANES_BEGIN
+    {
+        const int k0 = 1 + 2 * lane, k1 = k0 + 1;
+        const int q0 = k0 < sub ? k0 : 0, q1 = k1 < sub ? k1 : q0;
+        L(tb0) = C->p1_bark[q0]; L(tb1) = C->p1_bark[q1]; L(th0) = C->p1_hear[q0]; L(th1) = C->p1_hear[q1];
+        L(mmn) = C->p1_mm_n[lane & 31]; L(mmj) = C->p1_mm_j0[lane & 31];          // rows of the subband's minimum (used at the very end)
+    }
+    TL_LANES_END
     TL_LANES_BEGIN
     for (int t = lane; t < ntone + nnoise; t += 64) tl_masker_consts(TL_MK4(w), TL_MK_X(w), TL_MK_BARK(w), t, t < ntone);
     TL_LANES_END
@@ -507,7 +526,10 @@ TL_FN void tl_psy1_thresholds(TlPsyLds &w, const double *TL_RESTRICT db, const T
         const int k0 = base + 2 * lane, k1 = k0 + 1;
         const bool h0 = k0 < sub, h1 = k1 < sub;
         if (h0) {
-            const double bk0 = C->p1_bark[k0], bk1 = C->p1_bark[h1 ? k1 : k0];
+            double bk0 = L(tb0), bk1 = L(tb1), hr0 = L(th0), hr1 = L(th1);      // the first pass uses the rows fetched above
+            if (base != 1) {                                         // (a second pass is a 4-line tail at most; the branch is wave-uniform)
+                bk0 = C->p1_bark[k0]; bk1 = C->p1_bark[h1 ? k1 : k0]; hr0 = C->p1_hear[k0]; hr1 = C->p1_hear[h1 ? k1 : k0];
+            }
             const double blo = (bk0 < bk1 ? bk0 : bk1) - 8.0, bhi = (bk0 < bk1 ? bk1 : bk0) + 3.0;
             const TlMasker *mk = TL_MK4(w);
             const int nm = ntone + nnoise;
@@ -532,8 +554,8 @@ TL_FN void tl_psy1_thresholds(TlPsyLds &w, const double *TL_RESTRICT db, const T
                 tl_add_db2_k(db, kk.k1000, x0, mA0, x1, mA1);
                 tl_add_db2_k(db, kk.k1000, x0, mB0, x1, mB1);
             }
-            TL_LTG(w)[k0] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k0] : C->p1_hear[k0] - 12.0, x0);
-            if (h1) TL_LTG(w)[k1] = tl_add_db(db, C->br_per_ch < 96 ? C->p1_hear[k1] : C->p1_hear[k1] - 12.0, x1);
+            TL_LTG(w)[k0] = tl_add_db(db, C->br_per_ch < 96 ? hr0 : hr0 - 12.0, x0);
+            if (h1) TL_LTG(w)[k1] = tl_add_db(db, C->br_per_ch < 96 ? hr1 : hr1 - 12.0, x1);
         }
         TL_LANES_END
     }
@@ -543,7 +565,7 @@ TL_FN void tl_psy1_thresholds(TlPsyLds &w, const double *TL_RESTRICT db, const T
     TL_LANES_BEGIN
     if (lane < C->sblimit) {
         double m;
-        int n = C->p1_mm_n[lane], j0 = C->p1_mm_j0[lane];
+        int n = L(mmn), j0 = L(mmj);
         if (n == 0) m = C->p1_hear[sub - 1];
         else {
             m = tl_min_rows(TL_LTG(w), j0, n, 0.0, true);
@@ -589,13 +611,22 @@ TL_FN void tl_psy1_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
 
     // ---- decimation (psycho_1.c:409-470) ----
     {
+        // the noise components' table values (bark and threshold in quiet of their centres) are requested NOW and used after the tones:
+        // the configuration lives in HBM / L2, and the tones' own table reads are then under way at the same time
+        PV(double, nbk0); PV(double, nhear0);
+        TL_LANES_BEGIN
+        const int c0 = lane < nbands ? L(ncen) : 1;
+        L(nbk0) = C->p1_lbark[c0]; L(nhear0) = C->p1_lhear[c0];
+        TL_LANES_END
         // tones: keep if not erased and not below the threshold in quiet (order preserved)
         for (int base = 0; base < nlist; base += 64) {
-            PV(bool, keep); PV(double, kx); PV(double, kb); PV(int, tline);
+            PV(bool, keep); PV(double, kx); PV(double, kb); PV(int, tline); PV(int, tcc); PV(double, tbk); PV(double, thr);
             TL_LANES_BEGIN
-            double x = 0; int c = -1000 - lane;
-            if (base + lane < nlist) { const int ti = w.tlist[base + lane]; c = w.conf_c[ti] & 511; x = w.tone_x[ti]; }
-            L(kx) = x; L(tline) = c;
+            double x = 0; int c = -1000 - lane, cc = 0;
+            if (base + lane < nlist) { const int ti = w.tlist[base + lane]; cc = w.conf_c[ti]; c = cc & 511; x = w.tone_x[ti]; }
+            L(kx) = x; L(tline) = c; L(tcc) = cc;
+            // the tone's table values are requested as soon as its line is known (the configuration record is in HBM / L2)
+            L(tbk) = C->p1_lbark[c < 0 ? 0 : c]; L(thr) = C->p1_lhear[c < 0 ? 0 : c];
             TL_LANES_END
             if (centre_on_tone)
                 for (int b = 0; b < nbands; b++) {                  // a band centre on the tone's line replaces its level
@@ -606,9 +637,8 @@ TL_FN void tl_psy1_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
             TL_LANES_BEGIN
             bool kp = false; double bk = 0;
             if (base + lane < nlist) {
-                const int cc = w.conf_c[w.tlist[base + lane]], c = cc & 511;
-                bk = C->p1_lbark[c];
-                kp = !((cc >> 13) & 1) && !(L(kx) < C->p1_lhear[c]);
+                bk = L(tbk);
+                kp = !((L(tcc) >> 13) & 1) && !(L(kx) < L(thr));
             }
             L(keep) = kp; L(kb) = bk;
             TL_LANES_END
@@ -650,9 +680,8 @@ TL_FN void tl_psy1_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
         TL_LANES_BEGIN
         bool kp = false; double x = 0, bk = 0;
         if (lane < nbands) {
-            const int c = L(ncen);
-            x = L(nlev); bk = C->p1_lbark[c];
-            kp = !(x < C->p1_lhear[c]);
+            x = L(nlev); bk = L(nbk0);
+            kp = !(x < L(nhear0));
         }
         L(keepn) = kp; L(nx) = x; L(nb) = bk;
         TL_LANES_END
@@ -758,9 +787,10 @@ TL_FN void tl_psy1_deadhead(TlPsyLds &w, const double *TL_RESTRICT db, const TlC
 TL_FN void tl_psy1_finish(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, PARGA(double, rec, 4), long long *sp)
 {
     const int nbands = C->p1_ncb - 1;
-    PV(double, wt); PV(double, bsum);
+    PV(double, wt); PV(double, bsum); PV(int, blo); PV(int, bhi);
+    tl_psy1_limits(C, nbands, blo, bhi);
     TL_PRIO(1); tl_psy1_chain(w, db, nbands, bsum, wt); TL_PRIO(0);
-    tl_psy1_centres(w, C, nbands, bsum, wt);
+    tl_psy1_centres(w, nbands, bsum, wt, blo, bhi);
     if (st.dead_head) tl_psy1_deadhead(w, db, C, ch, st, rec, sp); else tl_psy1_back(w, db, C, ch, st, rec, sp);
 }
 TL_FN void tl_psy1(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double *TL_RESTRICT db,
@@ -805,7 +835,8 @@ TL_FN void tl_psy1_stereo(TlPsyLds &w, const TlTables *TL_RESTRICT T, const doub
     TL_LANES_END
     // ---- channel 1's front; a dead-head channel 1 is finished in the plain order first ----
     const TlPsy1Ch s1 = tl_psy1_front(w, T, db, C, pv, 1, rec, sp1);
-    PV(double, bsum); PV(double, wt1);
+    PV(double, bsum); PV(double, wt1); PV(int, blo); PV(int, bhi);
+    tl_psy1_limits(C, nbands, blo, bhi);                              // (used after the chains, by both channels' centres)
     if (s1.dead_head) {
         tl_psy1_finish(w, db, C, 1, s1, rec, sp1);
         TL_LANES_BEGIN
@@ -844,7 +875,7 @@ TL_FN void tl_psy1_stereo(TlPsyLds &w, const TlTables *TL_RESTRICT T, const doub
 #else
         bsum1 = __shfl(bsum, (int)((threadIdx.x + 32u) & 63u), 64);
 #endif
-        if (TL_EXP_LEVEL < 3) tl_psy1_centres(w, C, nbands, bsum1, wt1);
+        if (TL_EXP_LEVEL < 3) tl_psy1_centres(w, nbands, bsum1, wt1, blo, bhi);
         tl_psy1_back(w, db, C, 1, s1, rec, sp1);
     }
     // ---- channel 0 returns to the LDS arrays ----
@@ -857,7 +888,7 @@ TL_FN void tl_psy1_stereo(TlPsyLds &w, const TlTables *TL_RESTRICT T, const doub
     TL_LANES_BEGIN
     for (int i = lane; i < s0.nconf; i += 64) { const int cc = w.conf_c[i]; if (!((cc >> 13) & 1)) w.ptype[cc & 511] = TL_T_TONE; }
     TL_LANES_END
-    if (TL_EXP_LEVEL < 3) tl_psy1_centres(w, C, nbands, bsum, wt0);
+    if (TL_EXP_LEVEL < 3) tl_psy1_centres(w, nbands, bsum, wt0, blo, bhi);
     tl_psy1_back(w, db, C, 0, s0, rec, sp0);
 }
 
@@ -1154,6 +1185,13 @@ TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
     const double *bark = C->p3_bark, *ath = C->p3_ath;
     const int nb = C->p3_cbands;
     PV(bool, keepn); PV(double, nx); PV(double, nbk);
+    // the first 64 tones' table values (bark, threshold in quiet: the configuration record in HBM / L2) are requested before the noise
+    // components' -- whose addresses are themselves table values -- so that the two chains of reads overlap
+    PV(double, tbk0); PV(double, tath0);
+    TL_LANES_BEGIN
+    const int k0 = lane < nconf ? (w.conf_c[lane] & 511) : 0;
+    L(tbk0) = bark[k0]; L(tath0) = ath[k0];
+    TL_LANES_END
     TL_LANES_BEGIN
     bool kp = false; double xn = 0, bk = 0;
     if (lane < nb) {
@@ -1175,9 +1213,9 @@ TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
         TL_LANES_BEGIN
         bool kp2 = false; double x = 0, bk2 = 0;
         if (base + lane < nconf) {
-            const int k = w.conf_c[base + lane] & 511;
-            x = w.tone_x[base + lane]; bk2 = bark[k];
-            kp2 = !(x < ath[k]);
+            x = w.tone_x[base + lane];
+            if (base == 0) { bk2 = L(tbk0); kp2 = !(x < L(tath0)); }
+            else { const int k = w.conf_c[base + lane] & 511; bk2 = bark[k]; kp2 = !(x < ath[k]); }
         }
         L(keep) = kp2; L(kx) = x; L(kb) = bk2;
         TL_LANES_END
@@ -1201,6 +1239,14 @@ TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
     TL_STAMP(sp, 5);
     TL_PRIO2(TL_PS_THR);
     // ---- thresholds on the 136 subsampled lines (psycho_3.c:339-406) ----
+    // the lane's two subset lines and their bark values (two DEPENDENT reads of the configuration record in HBM / L2) are requested
+    // before the masker records are built and the order test runs
+    PV(int, sl0); PV(int, sl1); PV(double, sb0); PV(double, sb1); PV(int, sbj); PV(int, sbn);
+    TL_LANES_BEGIN
+    L(sl0) = C->p3_subset[2 * lane]; L(sl1) = C->p3_subset[2 * lane + 1];
+    L(sb0) = bark[L(sl0)]; L(sb1) = bark[L(sl1)];
+    L(sbj) = C->p3_sb_j0[lane & 31]; L(sbn) = C->p3_sb_n[lane & 31];               // rows of the subband's minimum (used at the very end)
+    TL_LANES_END
     TL_LANES_BEGIN
     for (int t = lane; t < ntone + nnoise; t += 64) tl_masker_consts(TL_MK4(w), TL_MK_X(w), TL_MK_BARK(w), t, t < ntone);
     TL_LANES_END
@@ -1210,8 +1256,8 @@ TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
     TL_LANES_BEGIN
     {
         const int j0 = 2 * lane, j1 = j0 + 1;
-        const int line0 = C->p3_subset[j0], line1 = C->p3_subset[j1];
-        const double b0 = bark[line0], b1 = bark[line1];
+        const int line0 = L(sl0), line1 = L(sl1);
+        const double b0 = L(sb0), b1 = L(sb1);
         const TlMasker *mk = TL_MK4(w);
         int ta0, ta1, tb0, tb1;
         if (srt) tl_mask_spans_sorted<64, 32>(TL_MK_BARK(w), ntone, nnoise, (b0 < b1 ? b0 : b1) - 8.0, (b0 < b1 ? b1 : b0) + 3.0, ta0, ta1, tb0, tb1);
@@ -1267,7 +1313,7 @@ TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
     TL_LANES_BEGIN
     if (lane < 32) {
         double m = 999999.9;
-        const int j0 = C->p3_sb_j0[lane], n = C->p3_sb_n[lane];
+        const int j0 = L(sbj), n = L(sbn);
         m = tl_min_rows(TL_LTG(w), j0, n, m, false);
         L(rec)[2 + ch] = m;
     }

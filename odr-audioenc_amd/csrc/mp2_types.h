@@ -23,6 +23,8 @@ struct TlBlockShared {
     double dct_t[16][2][16];     // matrixing coefficients m[r][2k+par] stored [k][par][r]: one k = 32 consecutive doubles
     uint8_t sfpat[32];           // scalefactor transmission pattern of the class pair 5*c0+c1 (encode_new.c:296-301, ISO Table C.4):
                                  //   source of sf0 | sf1 << 2 | sf2 << 4 (0..2 = sf0..sf2, 3 = min(sf0, sf2)) | scfsi << 6
+    double scale_db[64];         // 20*log10(scalefactor[i]*32768) - 10 (psycho_1.c:575, psycho_3.c:180): the same for every configuration, so the
+                                 //   SMR line reads it from the workgroup's LDS copy instead of the configuration record in HBM (TlConfig::scale_db)
 };
 
 // Small tables of the packing stage that sit on dependent-load chains (quantiser class constants, CRC powers): the encode
