@@ -131,22 +131,33 @@ TL_FN void tl_psy_spectrum(TlPsyLds &w, const TlTables *TL_RESTRICT T, const TlP
         TL_LAUNDER(hann);
         tl_fht_twiddles<4>(L(twc), T, lane);
         double e[16];
+        // the sixteen PCM samples are this unit's first touch of its input (HBM, not L2): all of them are requested before anything is
+        // used; the window's coefficients (L2) follow in two batches of eight (sixteen doubles more in flight would spill)
+        int vs[16];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int half = 0; half < 16; half += 8) {                  // eight loads in flight (sixteen would spill)
-            int16_t v[8]; double h[8];
+        for (int it = 0; it < 16; it++) vs[it] = it < 3 ? hs[64 * it] : cs[64 * it];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-            for (int q = 0; q < 8; q++) { const int it = half + q; v[q] = it < 3 ? hs[64 * it] : cs[64 * it]; h[q] = hann[lane + 64 * it]; }
+        for (int it = 0; it < 16; it++) TL_KEEP(vs[it]);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int half = 0; half < 16; half += 8) {
+            double h[8];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 8; q++) h[q] = hann[lane + 64 * (half + q)];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
             for (int q = 0; q < 8; q++) {
                 const int it = half + q;
                 const int r4 = ((it & 1) << 3) | ((it & 2) << 1) | ((it & 4) >> 1) | ((it & 8) >> 3);
-                e[r4] = (double)v[q] * h[q];
+                e[r4] = (double)vs[it] * h[q];
             }
         }
         tl_fht_head(e, T->fht_tw);
