@@ -321,6 +321,11 @@ float tlb_tick_last_ms(tlb_tick *t);           /* first copy-in queued -> last c
  * A "shard" is such a block; `devices[g]` names the HIP device of shard g, and the same device may appear more than once (two
  * shards on one GPU behave as on two).  Every call below that acts on all shards runs on the shards' own threads in parallel and
  * returns when all of them have returned; the first non-zero code wins.  A stream keeps its node-wide index in every accessor.
+ * Threading: ONE caller thread drives a node handle (the shards' threads are the node's own; the mailbox of a shard holds one job).
+ * The function handed to tlb_node_parallel() runs on those threads and may use the accessors (tlb_node_pcm / _packet / ...), but
+ * none of the calls that themselves go to the shards' threads (submit / wait / run / finish / sync / encode / life cycle / gain / copies):
+ * they would wait for the thread they are running on.  A non-zero return of submit / wait / encode / sync means a shard's device call
+ * failed (TLB_ERR_HIP, ...) while others may have gone ahead: the shards are no longer in lockstep and the node is to be destroyed.
  *
  * Two planes, chosen at creation:
  *   TLB_NODE_TICK   the real-time loop: a tlb_tick per shard, host buffers in, packets out (everything of tlb_tick_* per stream).

@@ -395,7 +395,11 @@ void *tlb_node_device_alloc(tlb_node *nd, int shard, size_t bytes)
 {
     if (!nd || shard < 0 || shard >= (int)nd->shards.size() || !bytes) return nullptr;
     void *p = nullptr;
-    nd->one(shard, [&](Shard &s) { return hipSetDevice(s.device) == hipSuccess && hipMalloc(&p, bytes) == hipSuccess && hipMemset(p, 0, bytes) == hipSuccess ? 0 : (int)TLB_ERR_HIP; });
+    nd->one(shard, [&](Shard &s) {
+        if (hipSetDevice(s.device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; return (int)TLB_ERR_HIP; }
+        if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); p = nullptr; return (int)TLB_ERR_HIP; }   // never a buffer that is not zeroed
+        return 0;
+    });
     return p;
 }
 void tlb_node_device_free(tlb_node *nd, int shard, void *d_ptr)
