@@ -247,6 +247,53 @@ def committed_counters(S, F, psy, mode, mixed=False):
     return traffic, source, valu
 
 
+class SclkSampler:
+    """The GPU's shader clock WHILE the timed region runs: a host thread reads the driver's DPM table (sysfs pp_dpm_sclk: the line marked
+    '*' is the current level, what `rocm-smi --showclocks` prints) every 20 ms.  result(): {"median_mhz", "min_mhz", "max_mhz", "samples"}
+    or None where the file cannot be read.  (The clock the committed SQ counter profile derives -- GRBM_GUI_ACTIVE / kernel time under the
+    profiler -- comes out near 2.17 GHz; rocm-smi and this sampler see the kernels run at ~2.39 GHz of the 2.4 GHz peak, 1.1 kW of 1.4 kW:
+    tools/clock_probe.sh, profiles/clock_probe_r05.txt.)"""
+
+    def __init__(self, device_index=0):
+        import glob
+        self.vals, self.stop, self.th = [], False, None
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.path = cards[min(device_index, len(cards) - 1)] if cards else None
+
+    def _read(self):
+        try:
+            for ln in open(self.path).read().splitlines():
+                if ln.rstrip().endswith("*"):
+                    return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except Exception:  # noqa: BLE001
+            return None
+        return None
+
+    def __enter__(self):
+        import threading
+        if self.path:
+            def loop():
+                while not self.stop:
+                    v = self._read()
+                    if v:
+                        self.vals.append(v)
+                    time.sleep(0.02)
+            self.th = threading.Thread(target=loop, daemon=True)
+            self.th.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        if self.th:
+            self.th.join(timeout=1.0)
+
+    def result(self):
+        if not self.vals:
+            return None
+        v = sorted(self.vals)
+        return {"median_mhz": v[len(v) // 2], "min_mhz": v[0], "max_mhz": v[-1], "samples": len(v), "source": self.path}
+
+
 class GpuRun:
     """One workload resident on this rank's GPU: two alternating PCM buffers (frames [0,F) and [F,2F) of every stream), the
     batch, the output buffer.  step(i) = one launch."""
@@ -271,6 +318,7 @@ class GpuRun:
         self.stream = torch.cuda.current_stream()
         self.F, self.S, self.torch, self.np = F, S, torch, np
         self.cdev = "cuda"
+        self.dev, self.sclk_mhz = local_rank, None
 
     def step(self, i):
         assert (i & 1) == (self.launches & 1)          # the two PCM buffers alternate without a gap: each stream sees one looped signal
@@ -290,7 +338,9 @@ class GpuRun:
                 self.step(warmup + i)
                 evs[i][1].record(self.stream)
 
-        elapsed, own = shard.timed_region_detail(dist, run, device_sync=torch.cuda.synchronize, device=self.cdev)
+        with SclkSampler(self.dev) as sclk:
+            elapsed, own = shard.timed_region_detail(dist, run, device_sync=torch.cuda.synchronize, device=self.cdev)
+        self.sclk_mhz = sclk.result()
         kernel_ms = float(self.np.mean([a.elapsed_time(b) for a, b in evs]))
         self.stage_ms = self.batch.last_stage_ms()      # (psy-2 kernel, encode + finish kernels) of the last launch: batches of models 2/4 only
         return elapsed, own, kernel_ms
@@ -533,7 +583,7 @@ def main():
         chk = r.check_flag()
         pr = shard.gather_floats(dist, [S * F * args.steps, own_s, 0.0 if chk.get("failed") else 1.0], device=cdev)
         out = dict(elapsed=el, kernel_ms=k_ms, last_ms=l_ms, checked=chk, per_rank=pr, stage_ms=r.stage_ms,
-                   algo=r.algo_bytes_per_launch, audio_s=r.audio_s_per_launch)
+                   algo=r.algo_bytes_per_launch, audio_s=r.audio_s_per_launch, sclk=r.sclk_mhz)
         r.close()
         return out
 
@@ -571,7 +621,10 @@ def main():
         util = {"what": "share of the SIMDs' issue cycles the launch's vector instructions occupy -- a utilisation of the kernel's own instruction stream, "
                         "NOT a roofline fraction"}
         if valu:
-            clock = valu.get("clock_ghz") or 2.2
+            live = run_d.get("sclk")
+            clock = round(live["median_mhz"] / 1e3, 3) if live else (valu.get("clock_ghz") or 2.2)
+            clock_note = ("the shader clock sampled from the driver's DPM table while this run's timed region ran (SclkSampler)" if live else
+                          "the clock rocprofv3 measured in the committed profile run, not this run's")
             per_frame = sum(v["valu_instructions_per_frame"] for v in valu["kernels"].values())
             classes = valu.get("classes_per_frame")
             if classes:
@@ -584,8 +637,8 @@ def main():
                          "counter_lane_occupancy": valu.get("lane_occupancy"),
                          "this_run_from_instruction_classes": round(cyc * fps_k / (num_simds * clock * 1e9), 4),
                          "valu_instructions_per_frame": per_frame, "classes_per_frame": classes, "issue_cycles_per_frame": round(cyc),
-                         "basis": f"{basis} x {fps_k:.0f} frames/s / ({num_simds} SIMDs x {clock} GHz -- the clock rocprofv3 measured in the committed profile run, "
-                                  "not this run's)", "source": valu.get("source")})
+                         "basis": f"{basis} x {fps_k:.0f} frames/s / ({num_simds} SIMDs x {clock} GHz -- {clock_note})",
+                         "shader_clock": live, "source": valu.get("source")})
         else:
             util.update({"counter_valu_busy_per_simd": None, "this_run_from_instruction_classes": None, "basis": "no committed SQ counters for this workload (profiles/LATEST)"})
         rf["valu_issue_utilisation"] = util

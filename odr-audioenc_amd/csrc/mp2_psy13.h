@@ -23,6 +23,31 @@ TL_FN double tl_power_db(double e, const uint64_t *lt)
 {
     return 10 * tlm_log10_pn(__builtin_fmax(e, 1E-20), lt) + TL_POWERNORM;
 }
+// The 512 logarithms of a channel in two halves (tl_libm.h: tlm_log10_main_pn / tlm_log10_near1_pn).  About one argument in eleven takes
+// e_log.c's "close to 1.0" branch (26 operations the other ten have no use for -- and every wave of 64 has some): tl_power_db_main runs
+// the table branch and says which lanes it does not serve, their LINE NUMBERS are filed in a list (tl_power_defer: the candidate array,
+// not in use yet, as 512 16-bit slots), and tl_power_near1 puts up to 64 filed lines through the other branch at once -- energy re-read,
+// level overwritten.  One or two such passes per channel instead of eight.
+TL_FN double tl_power_db_main(double e, const uint64_t *lt, bool *near1)
+{
+    return 10 * tlm_log10_main_pn(__builtin_fmax(e, 1E-20), lt, near1) + TL_POWERNORM;
+}
+#define TL_DEFER(w) ((uint16_t *)(w).cinfo)
+TL_FN void tl_power_near1(TlPsyLds &w, int pos0, int cnt)
+{
+    TL_LANES_BEGIN
+    if (lane < cnt) {
+        const int i = TL_DEFER(w)[pos0 + lane];
+        const double e = w.u.fft[TL_EX(i)];
+        TL_PX(w)[i] = 10 * tlm_log10_near1_pn(__builtin_fmax(e, 1E-20)) + TL_POWERNORM;
+    }
+    TL_LANES_END
+}
+// lanes with `flag` append `line` to the list (lane order), ndef grows
+#define TL_POWER_DEFER(w, flag, line_expr, ndef) do { \
+    const uint64_t m_ = TL_BALLOT(flag); \
+    TL_LANES_BEGIN if (L(flag)) TL_DEFER(w)[(ndef) + __builtin_popcountll(m_ & ((1ull << lane) - 1ull))] = (uint16_t)(line_expr); TL_LANES_END \
+    (ndef) += __builtin_popcountll(m_); } while (0)
 TL_FN int tl_run_psy1(int c) { return (c < 3 || c > 500) ? 0 : c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 12; }   // psycho_1.c:289-298
 TL_FN int tl_run_psy3(int c) { return c < 63 ? 2 : c < 127 ? 3 : c < 255 ? 6 : 12; }                            // psycho_3.c:212-215
 
@@ -115,27 +140,40 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
     // power density spectrum (psycho_1.c:241-248); spike (psycho_1.c:252-257)
     // The spike sums read 16 consecutive energies per lane; the energies' XOR layout keeps those reads off each other's
     // LDS banks.  Only subbands below sblimit (<= 30) are ever used.
-    TL_LANES_BEGIN
-    for (int i0 = lane; i0 < (TL_EXP_LEVEL >= 7 ? 0 : 512); i0 += 256) {                     // four lines per lane at a time
-        double e[4], v[4];
+    int ndef = 0;                                                     // lines filed for the logarithm's other branch (tl_power_near1)
+    for (int h = 0; h < (TL_EXP_LEVEL >= 7 ? 0 : 2); h++) {           // four lines per lane at a time
+        PV(bool, n0); PV(bool, n1); PV(bool, n2); PV(bool, n3);
+        TL_LANES_BEGIN
+        {
+            const int i0 = lane + 256 * h;
+            double e[4], v[4];
+            bool nr[4];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int q = 0; q < 4; q++) e[q] = energy[TL_EX(i0 + 64 * q)];
+            for (int q = 0; q < 4; q++) e[q] = energy[TL_EX(i0 + 64 * q)];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int q = 0; q < 4; q++) v[q] = tl_power_db(e[q], TL_LOGTAB(db));
+            for (int q = 0; q < 4; q++) v[q] = tl_power_db_main(e[q], TL_LOGTAB(db), &nr[q]);
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int q = 0; q < 4; q++) {
-            const int i = i0 + 64 * q;
-            px[i] = v[q];
-            w.ptype[i] = 0;
+            for (int q = 0; q < 4; q++) {
+                const int i = i0 + 64 * q;
+                px[i] = v[q];                                           // (a filed line's value is overwritten by tl_power_near1)
+                w.ptype[i] = 0;
+            }
+            L(n0) = nr[0]; L(n1) = nr[1]; L(n2) = nr[2]; L(n3) = nr[3];
         }
+        TL_LANES_END
+        TL_POWER_DEFER(w, n0, lane + 256 * h, ndef);
+        TL_POWER_DEFER(w, n1, lane + 256 * h + 64, ndef);
+        TL_POWER_DEFER(w, n2, lane + 256 * h + 128, ndef);
+        TL_POWER_DEFER(w, n3, lane + 256 * h + 192, ndef);
+        while (ndef >= 64) { ndef -= 64; tl_power_near1(w, ndef, 64); }
     }
-    TL_LANES_END
+    if (ndef) tl_power_near1(w, 0, ndef);
     TL_LANES_BEGIN
     if (lane < (TL_EXP_LEVEL >= 7 ? 0 : 30)) {
         double e[16];
@@ -910,27 +948,44 @@ TL_FN int tl_psy3_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double
     // to 0.0 (oracle/mp2_oracle.c:psy3_run)
     // and the strongest line Xmax of each subband (psycho_3.c:163-183; line 512 is skipped, see oracle) -> the output record.  A subband's 16 lines sit in one row of
     // 16 lanes, so its maximum is a row reduction of the values just computed (no strided re-read of px).
+    // The logarithms in two halves as in tl_psy1_front (tl_power_db_main / tl_power_near1).  Line 0 has no logarithm (pinned), line 512 has one
+    // and no lane of its own: lane 0's first slot computes line 512 instead of line 0 (a ninth pass for one lane would cost what a pass of 64 does).
     PA(double, pxa, 8);
-    TL_LANES_BEGIN
+    int ndef = 0;
     for (int h = 0; h < 2; h++) {                                   // four lines per lane at a time
-        double e[4], v[4];
+        PV(bool, n0); PV(bool, n1); PV(bool, n2); PV(bool, n3);
+        TL_LANES_BEGIN
+        {
+            double e[4], v[4];
+            bool nr[4];
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int q = 0; q < 4; q++) e[q] = energy[TL_EX(lane + 64 * (4 * h + q))];
+            for (int q = 0; q < 4; q++) { const int i = lane + 64 * (4 * h + q); e[q] = energy[TL_EX(i == 0 ? 512 : i)]; }
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int q = 0; q < 4; q++) v[q] = tl_power_db(e[q], TL_LOGTAB(db));
+            for (int q = 0; q < 4; q++) v[q] = tl_power_db_main(e[q], TL_LOGTAB(db), &nr[q]);
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-        for (int q = 0; q < 4; q++) {
-            const int i = lane + 64 * (4 * h + q);
-            px[i] = i == 0 ? 0.0 : v[q];
-            L(pxa)[4 * h + q] = i == 0 ? TL_DBMIN : v[q];
+            for (int q = 0; q < 4; q++) { const int i = lane + 64 * (4 * h + q); px[i == 0 ? 512 : i] = v[q]; }
+            if (h == 0 && lane == 0) px[0] = 0.0;
+            L(n0) = nr[0]; L(n1) = nr[1]; L(n2) = nr[2]; L(n3) = nr[3];
         }
+        TL_LANES_END
+        TL_POWER_DEFER(w, n0, (h == 0 && lane == 0) ? 512 : lane + 256 * h, ndef);
+        TL_POWER_DEFER(w, n1, lane + 256 * h + 64, ndef);
+        TL_POWER_DEFER(w, n2, lane + 256 * h + 128, ndef);
+        TL_POWER_DEFER(w, n3, lane + 256 * h + 192, ndef);
+        while (ndef >= 64) { ndef -= 64; tl_power_near1(w, ndef, 64); }
     }
+    if (ndef) tl_power_near1(w, 0, ndef);
+    TL_LANES_BEGIN
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+    for (int k = 0; k < 8; k++) { const int i = lane + 64 * k; L(pxa)[k] = i == 0 ? TL_DBMIN : px[i]; }
     TL_LANES_END
 #ifndef TL_EMULATE
 #pragma unroll
@@ -950,9 +1005,6 @@ TL_FN int tl_psy3_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double
         }
         TL_LANES_END
     }
-    TL_LANES_BEGIN
-    if (lane == 0) px[512] = tl_power_db(energy[512], TL_LOGTAB(db));
-    TL_LANES_END
     TL_PRIO2(1);                                                      // from here to the thresholds: serial stages
     // ---- tone labelling (psycho_3.c:186-247) ----
     // (1) local maxima 2..499 whose right-hand neighbours are >= 7 dB down, compacted ascending

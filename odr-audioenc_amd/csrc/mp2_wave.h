@@ -258,7 +258,7 @@ typedef const struct TlLaunch *TlKArg;                                        /*
 #define TL_PS_Q 0
 #endif
 #ifndef TL_PS_POW
-#define TL_PS_POW 0
+#define TL_PS_POW 1          // the power spectrum since its logarithms come in two halves (filing ballots, one dependent pass per 64 filed lines): psy 1 +- 0, psy 3 + 0.3 %
 #endif
 #ifndef TL_PRIO_SERIAL
 #define TL_PRIO_SERIAL 2             // TL_PRIO_SERIAL=0 builds without it (measurement)

@@ -128,8 +128,9 @@ TLM_HD double tlm_log_pn(double x, TAB tab)
 {
     const uint64_t ix = tlm_d2u(x);
     const double a = tlm_log_near1(x), b = tlm_log_main(ix, tab);
-    const double r = tlm_log_is_near1(ix) ? a : b;
-    return ix == 0x3ff0000000000000ull ? 0.0 : r;
+    // (e_log.c returns 0 for x == 1.0 before anything else -- for the directed rounding modes; to nearest tlm_log_near1(1.0) is +0.0
+    // itself: r = +0 makes every product a zero and every sum +0.  tests/test_libm_agree.py pins it.)
+    return tlm_log_is_near1(ix) ? a : b;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -170,6 +171,38 @@ TLM_HD double tlm_log10_pn(double x, TAB tab)
     const uint64_t m = (hx & 0x000fffffffffffffull) | ((uint64_t)(0x3ff - i) << 52);
     const double y = (double)(k + i);
     const double z = y * log10_2lo + ivln10 * tlm_log_pn(tlm_u2d(m), tab);
+    return z + y * log10_2hi;
+}
+
+// The same function in two halves for callers that compute MANY logarithms per wave.  e_log.c's "close to 1.0" branch is taken by the
+// mantissas in [1 - 2^-4, 1 + 0x1.09p-4): about 9 % of all arguments -- so a wave of 64 lanes always has some, and tlm_log10_pn makes every
+// lane pay for both branches.  tlm_log10_main_pn runs the table branch alone and reports which lanes it was NOT the right one for;
+// the caller collects those arguments (a few dozen of five hundred) and puts them through tlm_log10_near1_pn together.  Per argument the
+// operations are those of tlm_log10_pn on the branch e_log.c takes for it.
+template <typename TAB>
+TLM_HD double tlm_log10_main_pn(double x, TAB tab, bool *near1)
+{
+    const double ivln10 = TLM_D(0x3fdbcb7b1526e50e), log10_2hi = TLM_D(0x3fd34413509f6000),
+                 log10_2lo = TLM_D(0x3d59fef311f12b36);
+    const uint64_t hx = tlm_d2u(x);
+    const int32_t k = (int32_t)(hx >> 52) - 1023;
+    const int32_t i = (int32_t)((uint32_t)k >> 31);
+    const uint64_t m = (hx & 0x000fffffffffffffull) | ((uint64_t)(0x3ff - i) << 52);
+    const double y = (double)(k + i);
+    *near1 = tlm_log_is_near1(m);
+    const double z = y * log10_2lo + ivln10 * tlm_log_main(m, tab);
+    return z + y * log10_2hi;
+}
+TLM_HD double tlm_log10_near1_pn(double x)
+{
+    const double ivln10 = TLM_D(0x3fdbcb7b1526e50e), log10_2hi = TLM_D(0x3fd34413509f6000),
+                 log10_2lo = TLM_D(0x3d59fef311f12b36);
+    const uint64_t hx = tlm_d2u(x);
+    const int32_t k = (int32_t)(hx >> 52) - 1023;
+    const int32_t i = (int32_t)((uint32_t)k >> 31);
+    const uint64_t m = (hx & 0x000fffffffffffffull) | ((uint64_t)(0x3ff - i) << 52);
+    const double y = (double)(k + i);
+    const double z = y * log10_2lo + ivln10 * tlm_log_near1(tlm_u2d(m));
     return z + y * log10_2hi;
 }
 

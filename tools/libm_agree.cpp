@@ -49,7 +49,7 @@ struct Tally {
     }
 };
 
-static Tally T_log{"log"}, T_log10{"log10"}, T_log10pn{"log10 (straight-line form, positive normal)"}, T_exp{"exp"},
+static Tally T_log{"log"}, T_log10{"log10"}, T_log10pn{"log10 (straight-line form, positive normal)"}, T_log10split{"log10 (table branch / near-1 branch apart, positive normal)"}, T_exp{"exp"},
     T_pow10{"pow(10, y)"}, T_pow{"pow(x > 0, y)"}, T_sin{"sincos: sin"}, T_cos{"sincos: cos"}, T_atan2{"atan2"},
     T_sinsl{"sincos, straight-line form: sin"}, T_cossl{"sincos, straight-line form: cos"}, T_atan2sl{"atan2, straight-line form"}, T_atan2ns{"atan2, straight-line, no rescaling (max|.| in [2^-443, 2^500])"}, T_expsl{"exp, straight-line form (|x| < 512)"},
     T_pow10sl{"pow(10, y), straight-line form (|y| < 222)"};
@@ -80,6 +80,11 @@ static void worker(int id, uint64_t per_fn, uint64_t seed)
         chk1(T_log10, x, tlm_log10(x), log10(x));
         if (tlm_d2u(x) >= 0x0010000000000000ull && tlm_d2u(x) < 0x7ff0000000000000ull)
             chk1(T_log10pn, x, tlm_log10_pn(x, tlm_log_tab), log10(x));
+        if (tlm_d2u(x) >= 0x0010000000000000ull && tlm_d2u(x) < 0x7ff0000000000000ull) {
+            bool near1;
+            const double a = tlm_log10_main_pn(x, tlm_log_tab, &near1);
+            chk1(T_log10split, x, near1 ? tlm_log10_near1_pn(x) : a, log10(x));
+        }
         // ---- exp
         switch (i % 6) {
         case 0: x = r.uniform(-750, 715); break;
@@ -187,7 +192,7 @@ int main(int argc, char **argv)
     for (unsigned t = 0; t < nthreads; t++) th.emplace_back(worker, (int)t, per, seed);
     for (auto &t : th) t.join();
     uint64_t bad = 0;
-    for (Tally *t : {&T_log, &T_log10, &T_log10pn, &T_exp, &T_pow10, &T_pow, &T_sin, &T_cos, &T_atan2, &T_sinsl, &T_cossl, &T_atan2sl, &T_atan2ns, &T_expsl, &T_pow10sl}) {
+    for (Tally *t : {&T_log, &T_log10, &T_log10pn, &T_log10split, &T_exp, &T_pow10, &T_pow, &T_sin, &T_cos, &T_atan2, &T_sinsl, &T_cossl, &T_atan2sl, &T_atan2ns, &T_expsl, &T_pow10sl}) {
         printf("%-48s %12llu arguments  %llu differ (%.4f %% bit-equal)\n", t->name, (unsigned long long)t->n.load(),
                (unsigned long long)t->bad.load(), 100.0 * (double)(t->n - t->bad) / (double)t->n);
         for (auto &e : t->examples) printf("    %s\n", e.c_str());
