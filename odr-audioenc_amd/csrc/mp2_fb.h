@@ -85,7 +85,7 @@ TL_FN void tl_filterbank(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const
                     L(xb)[q + (h & 7)] = nb[bb];
                     double t = (double)L(xb)[q + (h & 7)] * cf[0];
                     for (int j = 1; j < 8; j++) t += (double)L(xb)[q + ((h - j) & 7)] * cf[j];
-                    yp[bb][c][i] = ta[bb] + tl_u2d((tl_d2u(t) & keep) ^ flip);
+                    yp[bb][TL_YP_ROW * (2 * c + (i & 1)) + (i >> 1)] = ta[bb] + tl_u2d((tl_d2u(t) & keep) ^ flip);
                 }
             }
             TL_LANES_END
@@ -95,9 +95,14 @@ TL_FN void tl_filterbank(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const
             double acc[FB];
             for (int bb = 0; bb < FB; bb++) acc[bb] = 0.0;
             if (c < nch)
-                for (int k = 0; k < 16; k++) {
-                    const double m = B->dct_t[k][par][r];               // shared LDS copy, conflict-free per k
-                    for (int bb = 0; bb < FB; bb++) acc[bb] += m * yp[bb][c][2 * k + par];
+                for (int k = 0; k < 16; k += 2) {
+                    const double m0 = B->dct_t[k][par][r], m1 = B->dct_t[k + 1][par][r];      // shared LDS copy, conflict-free per k
+                    for (int bb = 0; bb < FB; bb++) {
+                        double y0, y1;                                  // yprime[2 k + par], yprime[2 (k + 1) + par]: neighbours in the lane's row
+                        TL_LD2(&yp[bb][TL_YP_ROW * (2 * c + par) + k], y0, y1);
+                        acc[bb] += m0 * y0;
+                        acc[bb] += m1 * y1;
+                    }
                 }
             for (int bb = 0; bb < FB; bb++) L(part)[bb] = acc[bb];
             TL_LANES_END

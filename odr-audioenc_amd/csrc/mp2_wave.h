@@ -75,6 +75,7 @@ TL_FN void tlh_par_sum_i32(int (&d)[64], const int (&v)[64])
 #define TL_KARG const TlLaunch *
 #define TL_KEEP(x) ((void)0)
 #define TL_PIN(x) ((void)0)
+#define TL_LD2(p, a, b) do { const double *p_ = (p); (a) = p_[0]; (b) = p_[1]; } while (0)
 #else
 #define TL_FN __device__ __forceinline__
 #define TL_LANES_BEGIN { int lane_ = (int)(threadIdx.x & 63u); asm volatile("" : "+v"(lane_)); __builtin_assume(lane_ >= 0 && lane_ < 64); const int lane = lane_;
@@ -225,6 +226,8 @@ TL_FN int tld_par_sum_i32(int v)
 #define TL_RESTRICT __restrict__
 #define TL_SELECT(c, a, b) (__builtin_unpredictable(c) ? (a) : (b))      /* a v_cndmask, never a divergent branch */
 #define TL_KEEP(x) asm volatile("" : : "v"(x))             /* x is computed (a load: issued) here, not sunk into a later branch */
+typedef double tl_f64x2 __attribute__((ext_vector_type(2)));
+#define TL_LD2(p, a, b) do { const tl_f64x2 v_ = *(const tl_f64x2 *)(p); (a) = v_.x; (b) = v_.y; } while (0)      /* two doubles, 16-byte aligned: one ds_read_b128 */
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const __attribute__((address_space(4))) struct TlLaunch *TlKArg;     /* the kernel-argument segment: scalar loads */
 #else
@@ -335,13 +338,17 @@ static long tl_dbg_rounds = 0, tl_dbg_tones = 0, tl_dbg_deadheads = 0, tl_dbg_fr
 #define TL_EX(i) ((i) ^ (((i) >> 4) & 15))
 // Per-wave LDS of the encode kernel (the psy models run in their own kernels): PCM staging / frame being
 // packed, the filterbank's window-output scratch and the small per-subband arrays.
+#define TL_YP_ROW 18
 struct TlMainLds {
     static constexpr int kFbBatch = TL_FB_BATCH_MAIN;
     union alignas(16) {
         struct { int16_t pcm[2][TL_HIST + 1152]; } fbk;
         uint32_t frame[2][TL_MAX_FRAME_WORDS + 2];         // the frame being packed (+ 2: tl_put_bits48); [1]: the second unit of a mono pair (tl_encode_pair)
     } u;
-    double yp[TL_FB_BATCH_MAIN][2][34];
+    // window outputs of a batch of blocks, dealt by (channel, parity of the index): row 2 c + (j & 1) holds yprime[j] at [j >> 1], rows 18 doubles
+    // apart (16-byte aligned, the four rows a wave reads at once on different banks) -- a matrixing lane reads TWO consecutive operands of its
+    // chain with one 16-byte load (mp2_fb.h)
+    alignas(16) double yp[TL_FB_BATCH_MAIN][TL_YP_ROW * 3 + 16];
     double smr[2][32];                  // models 1 and 3: until the SMR line, the level of the model's record
     double psy_m[2][32];                // models 1 and 3: minimum masking threshold of the model's record
     int16_t ncentre[32];                // (ScF-CRC scratch)
@@ -351,7 +358,7 @@ struct TlMainLds {
     uint8_t balloc[2][32];
     uint8_t minidx[2][32];
     uint8_t xpad[TL_MAX_XPAD];
-    typedef double (*YpRows)[2][34];
+    typedef double (*YpRows)[TL_YP_ROW * 3 + 16];
 #ifdef TL_EMULATE
     YpRows yp_rows() { return yp; }
 #else
