@@ -153,24 +153,46 @@ TL_FN bool tl_psy2_unit(const TlLaunch &A, int u, int &chain, int &f0, int &f1)
 
 // [history | frame] -> LDS in 8-byte pieces, 120 + 288 per channel.  All of a lane's loads are issued before the first LDS
 // write so the HBM latency is paid once per frame, not once per piece.
+// The pieces are dealt run by run -- history and frame of each channel, four runs with ONE base address each -- not as one index space
+// over all of them: piece lane + 64 it of a run is a load at base + 8 lane + 512 it (an immediate), stored at the run's LDS offset + the same,
+// and only a run's last, partial trip is predicated.  (One index space straddles the run boundaries inside every trip: a pointer select,
+// a bounds test and an execution-mask region per piece -- 290 vector and 200 scalar instructions per frame for 26 copies.)
 TL_FN void tl_stage_pcm(TlMainLds &w, const TlPcmView &pv, int nch)
 {
     TL_LANES_BEGIN
     {
-        constexpr int HP = TL_HIST / 4, CP = 1152 / 4, PER = HP + CP;      // pieces per channel
-        constexpr int NIT = (2 * PER + 63) / 64;
-        uint64_t v[NIT];
+        constexpr int HP = TL_HIST / 4, CP = 1152 / 4;                      // 120 + 288 pieces per channel
+        constexpr int HT = (HP + 63) / 64, CT = (CP + 63) / 64;             // trips per run: 2 and 5, the last ones partial (56 and 32 lanes)
+        uint64_t vh[2][HT], vc[2][CT];
+#ifndef TL_EMULATE
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int i = lane + 64 * it, ch = i >= PER ? 1 : 0, k = i - ch * PER;
-            v[it] = 0;
-            if (i < PER * nch)
-                v[it] = k < HP ? *(const uint64_t *)((ch ? pv.hist[1] : pv.hist[0]) + 4 * k) : *(const uint64_t *)((ch ? pv.cur[1] : pv.cur[0]) + 4 * (k - HP));
+#endif
+        for (int c = 0; c < 2; c++) {
+            if (c >= nch) break;                                            // (wave-uniform)
+            const uint64_t *h = (const uint64_t *)(c ? pv.hist[1] : pv.hist[0]), *q = (const uint64_t *)(c ? pv.cur[1] : pv.cur[0]);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int it = 0; it < HT; it++) { vh[c][it] = 0; if (64 * it + 64 <= HP || lane < HP - 64 * it) vh[c][it] = h[lane + 64 * it]; }
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int it = 0; it < CT; it++) { vc[c][it] = 0; if (64 * it + 64 <= CP || lane < CP - 64 * it) vc[c][it] = q[lane + 64 * it]; }
         }
+#ifndef TL_EMULATE
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int i = lane + 64 * it, ch = i >= PER ? 1 : 0, k = i - ch * PER;
-            if (i < PER * nch) *(uint64_t *)&w.u.fbk.pcm[ch][4 * k] = v[it];
+#endif
+        for (int c = 0; c < 2; c++) {
+            if (c >= nch) break;
+            uint64_t *d = (uint64_t *)&w.u.fbk.pcm[c][0];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int it = 0; it < HT; it++) if (64 * it + 64 <= HP || lane < HP - 64 * it) d[lane + 64 * it] = vh[c][it];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int it = 0; it < CT; it++) if (64 * it + 64 <= CP || lane < CP - 64 * it) d[HP + lane + 64 * it] = vc[c][it];
         }
     }
     TL_LANES_END
