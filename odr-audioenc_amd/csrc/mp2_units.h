@@ -65,6 +65,18 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
     long long *sp = A.stamps ? A.stamps + slot * 32 : nullptr;
 #endif
     TL_STAMP(sp, 15);                                                 // unit begin (slots 8..14 / 16..22: the channels' stages, 24..30: FHT passes)
+    // The unit's PCM is its first touch of HBM, and the model gets to its loads only after the configuration record has come in (two dependent
+    // round trips: record index, then the record's rows).  One load per 128-byte line of both channels' analysis windows is issued HERE, so
+    // that the lines travel while those round trips are under way: lanes 0..12 / 16..28 the frame's first 832 samples, 13..15 / 29..31 the
+    // last 192 of the history.  The values are not used (TL_KEEP after the model: the register is simply released there).
+    PV(int, touch);
+    TL_LANES_BEGIN
+    {
+        const int c = (lane >> 4) & 1, j = lane & 15;
+        const int16_t *p = j < 13 ? (c ? pv.cur[1] : pv.cur[0]) + 64 * j : (c ? pv.hist[1] : pv.hist[0]) + (TL_HIST - 192) + 64 * (j - 13);
+        L(touch) = lane < 32 ? (int)*p : 0;                              // (a mono stream's second half of the slot is allocated too: read, not used)
+    }
+    TL_LANES_END
     if constexpr (TL_EXP_LEVEL >= 9) { }                              // diagnostic build: no model at all (tools/class_budget.sh: what the encoder phase alone issues)
     else if constexpr (PSY == 1) {
         if (C->nch == 2 || s2 >= 0) tl_psy1_stereo(w, T, db, C, pv, rec, sp);
@@ -73,6 +85,7 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
         if (C->nch == 2 || s2 >= 0) tl_psy3_stereo(w, T, db, C, pv, rec, sp);
         else tl_psy3(w, T, db, C, pv, 0, rec, sp ? sp + 8 : nullptr);
     }
+    TL_LANES_BEGIN TL_KEEP(L(touch)); TL_LANES_END
     TL_STAMP(sp, 23);                                                 // unit end
 }
 

@@ -54,3 +54,10 @@ if st[..., 25].max() > 0:
 if st[..., 31].max() > 0:
     d = (st[..., 0] - st[..., 31]).mean()
     print(f"  PCM staging before stamp 0: {d:8.0f}  {100 * d / tot:5.1f}% (not in the total above)")
+if psy in (1, 3) and st[..., 31].max() > 0:
+    # the pieces of a unit outside the stage stamps: unit begin -> the first channel's spectrum (launch record, configuration record), model end ->
+    # encoder begin; what is then still missing to (kernel time x clock / units per wave) is taking the unit: the atomic, stream_list[k], the loop
+    a = (st[..., 8] - st[..., 15]).mean(); bgap = (st[..., 31] - st[..., 23]).mean()
+    whole = (st[..., 7] - st[..., 15]).mean()
+    print(f"  unit begin -> ch0 spectrum: {a:8.0f}   model end -> encoder begin: {bgap:8.0f}   unit begin -> emit done: {whole:8.0f} ticks")
+
