@@ -10,14 +10,14 @@
 // for its successor's ScF-CRC, or -- the last frame of a launch -- the batch's pending buffer (big-endian words like
 // TlStreamState::pending); and the slot for its own ScF-CRC bytes, which tl_finish_stream stores into the frame before it.
 struct TlFrameOut { uint8_t *bytes; uint32_t *words; uint8_t *scfcrc; };
-template <int PSY>
+template <int PSY, int NCH = 0>
 TL_FN void tl_encode_frame(TlMainLds &w, const TlTables *TL_RESTRICT T, const TlBlockShared *TL_RESTRICT B,
                            const TlConfig *TL_RESTRICT C, const TlPsyOut *TL_RESTRICT PO,
                            const TlPcmView &pv, int xpad_len, const TlFrameOut &fo,
                            const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, int padding, TlTaps *taps, long long *sp)
 {
     constexpr int FB = TlMainLds::kFbBatch;
-    const int nch = C->nch, sblimit = C->sblimit;
+    const int nch = NCH ? NCH : C->nch, sblimit = C->sblimit;
     PA(double, smp, 36);            // sb_sample[ch][gr][bl][sb] of this lane's (sb,ch), b = gr*12+bl
     PA(int, scf, 3);
 

@@ -46,7 +46,7 @@ TL_FN TlPcmView tl_pcm_view_pair(const TlLaunch &A, int s0, int s1, int f)
 // One unit of the psy kernel (models 1 and 3): both channels of frame f of stream s -> A.psy_out[f][s].  The model reads
 // nothing but PCM (the window of a frame: the last 192 samples before it and its first 832), so units are independent of each
 // other -- of other streams AND of other frames of the same stream -- and the kernel runs them in any order on any wave.
-template <int PSY>
+template <int PSY, int NCH = 0>     // NCH = 2: every stream of the launch's list is a two-channel stream (the kernel variant of all-stereo lists: no look at the configuration record before the first transform)
 TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch &A, int s, int f, PARGA(double, rec, 4), int s2 = -1)
 {   // s2 >= 0: a PAIR of mono streams of one configuration -- the model runs its two-channel form on channel 0 of s and of s2
     // rec: the model's result per subband, in the registers of lane = subband: [ch] the level that competes with the scalefactor
@@ -79,10 +79,10 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
     TL_LANES_END
     if constexpr (TL_EXP_LEVEL >= 9) { }                              // diagnostic build: no model at all (tools/class_budget.sh: what the encoder phase alone issues)
     else if constexpr (PSY == 1) {
-        if (C->nch == 2 || s2 >= 0) tl_psy1_stereo(w, T, db, C, pv, rec, sp);
+        if (NCH == 2 || C->nch == 2 || s2 >= 0) tl_psy1_stereo(w, T, db, C, pv, rec, sp);
         else tl_psy1(w, T, db, C, pv, 0, rec, sp ? sp + 8 : nullptr);
     } else {
-        if (C->nch == 2 || s2 >= 0) tl_psy3_stereo(w, T, db, C, pv, rec, sp);
+        if (NCH == 2 || C->nch == 2 || s2 >= 0) tl_psy3_stereo(w, T, db, C, pv, rec, sp);
         else tl_psy3(w, T, db, C, pv, 0, rec, sp ? sp + 8 : nullptr);
     }
     TL_LANES_BEGIN TL_KEEP(L(touch)); TL_LANES_END
@@ -229,7 +229,7 @@ TL_FN int tl_stage_xpad(TlMainLds &w, const TlLaunch &A, const TlConfig *C, size
 // independent of each other: the filterbank's history is PCM (the previous input frame, or the stream state before frame 0),
 // the SMR comes from the psy kernel's record, and the one thing a frame owes its predecessor -- its ScF-CRC, which travels in
 // the frame before (toolame.c:527-542) -- is filed aside and put in place by tl_finish_stream.
-template <int PSY>     // TL_PSY_EXT: SMR from the psy kernel's record (models 1 and 3); 2: the psy-2 kernel's SMR (models 2 and 4); 0: model 0, which needs nothing but this frame's scalefactors
+template <int PSY, int NCH = 0>     // TL_PSY_EXT: SMR from the psy kernel's record (models 1 and 3); 2: the psy-2 kernel's SMR (models 2 and 4); 0: model 0, which needs nothing but this frame's scalefactors
 TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, const TlLaunch &A, int s, int f)
 {
     const TlConfig *C = &A.configs[A.stream_cfg[s]];
@@ -242,14 +242,14 @@ TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const 
     long long *sp = A.stamps ? A.stamps + slot * 32 : nullptr;
 #endif
     TL_STAMP(sp, 31);
-    tl_stage_pcm(w, pv, C->nch);
+    tl_stage_pcm(w, pv, NCH ? NCH : C->nch);
     const int xl = tl_stage_xpad(w, A, C, slot);
     TlFrameOut fo;
     fo.bytes = f + 1 < A.nframes ? A.out + (slot + (size_t)A.nstreams) * (size_t)A.out_stride : nullptr;     // waits in the next slot
     fo.words = f + 1 < A.nframes ? nullptr : A.newpend + (size_t)s * TL_MAX_FRAME_WORDS;
     fo.scfcrc = A.scfcrc + slot * 4;
     const int padding = A.padbits ? (int)A.padbits[slot] : 0;
-    tl_encode_frame<PSY>(w, A.tables, B, C, PSY == 2 ? &A.psy_out[slot] : nullptr, pv, xl, fo, enw_s, K, padding,
+    tl_encode_frame<PSY, NCH>(w, A.tables, B, C, PSY == 2 ? &A.psy_out[slot] : nullptr, pv, xl, fo, enw_s, K, padding,
                                 A.taps ? &A.taps[slot] : nullptr, sp);
 }
 
@@ -285,12 +285,12 @@ TL_FN void tl_main_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const 
 // share the wave's LDS block (a union: the model's arrays are dead when the encoder starts) and nothing else but the
 // model's record, 4 values per subband, which waits in registers until the model is done.
 union TlFrameLds { TlPsyLds p; TlMainLds m; };
-template <int PSY>
+template <int PSY, int NCH = 0>
 TL_FN void tl_frame_unit(TlFrameLds &w, const double *TL_RESTRICT db, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s,
                          const TlPackTables *TL_RESTRICT K, const TlLaunch &Apsy, TL_KARG Amain_p, int s, int f, int s2 = -1)
 {   // s2 >= 0: frame f of the two mono streams s and s2 (one configuration) as the two "channels" of the wave
     PA(double, rec, 4);
-    tl_psy_unit<PSY>(w.p, db, Apsy, s, f, rec, s2);
+    tl_psy_unit<PSY, NCH>(w.p, db, Apsy, s, f, rec, s2);
     TL_SYNC();
     // The encoder phase reads the launch record afresh (device: scalar loads from the kernel-argument segment, issued HERE) and
     // re-derives its pointers from laundered copies of s / f / s2: nothing of the model phase's scalar state stays live across the
@@ -305,7 +305,7 @@ TL_FN void tl_frame_unit(TlFrameLds &w, const double *TL_RESTRICT db, const TlBl
     }
     TL_LANES_END
     if (s2 >= 0) tl_main_pair<TL_PSY_EXT>(w.m, B, enw_s, K, Amain, s, s2, f);
-    else tl_main_unit<TL_PSY_EXT>(w.m, B, enw_s, K, Amain, s, f);
+    else tl_main_unit<TL_PSY_EXT, NCH>(w.m, B, enw_s, K, Amain, s, f);
 }
 
 // Which stream shares a wave with stream s?  TlLaunch::partner[s]: the other mono stream of s's configuration it is paired with, or -1.

@@ -82,7 +82,11 @@ static int batch_build_lists(tlb_batch *b)
             if (open[(size_t)ci] < 0) open[(size_t)ci] = s2;
             else { partner[(size_t)s2] = open[(size_t)ci]; partner[(size_t)open[(size_t)ci]] = s2; open[(size_t)ci] = -1; }
         }
-        for (int p = 0; p < 4; p++) b->list_pairs[p] = false;
+        for (int p = 0; p < 4; p++) { b->list_pairs[p] = false; b->list_stereo[p] = b->n_list[p] > 0; }
+        for (int s2 = 0; s2 < nstreams; s2++) {
+            const TlConfig &c2 = b->h_configs[b->h_stream_cfg[s2]];
+            if (c2.nch != 2) b->list_stereo[c2.psy == 4 ? 2 : c2.psy] = false;
+        }
         for (int s2 = 0; s2 < nstreams; s2++)
             if (partner[(size_t)s2] >= 0) { const int m = b->h_configs[b->h_stream_cfg[s2]].psy; b->list_pairs[m == 4 ? 2 : m] = true; }
         if (!b->d_partner) HIPCHK(hipMalloc(&b->d_partner, sizeof(int32_t) * (size_t)nstreams));
@@ -352,7 +356,7 @@ int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d
             long mb1 = (units + TL_MAIN_WAVES - 1) / TL_MAIN_WAVES;
             if (mb1 > b->num_cu) mb1 = b->num_cu;
             const bool pr = b->list_pairs[p] && !d_taps && !d_stamps;
-            HIPCHK(tlk_frame(p, pr, (unsigned)mb1, st, A));
+            HIPCHK(tlk_frame(p, pr, b->list_stereo[p], (unsigned)mb1, st, A));
             HIPCHK(tlk_finish((unsigned)((b->n_list[p] + 3) / 4), st, A));
             b->work_clean = true;                                    // tl_finish_kernel leaves the counters at zero
             continue;

@@ -59,6 +59,7 @@ struct tlb_batch {
     double *d_newlag = nullptr;                  // split path, 44.1 / 22.05 kHz: slot recurrence state after the launch
     bool pads[4] = {false, false, false, false}; // some stream of the psy model's list has frames of two lengths
     bool list_pairs[4] = {false, false, false, false};   // the model's list contains mono streams paired in one wave (kernel variant <.., true>)
+    bool list_stereo[4] = {false, false, false, false};  // every stream of the model's list has two channels (kernel variant <.., false, 2>: models 1 and 3)
     int32_t *d_work = nullptr;                   // unit counters of the persistent kernels
     bool work_clean = false;                     // ... are zero (tl_finish_kernel zeroes them after use)
     bool broken = false;                         // a launch or a reconfiguration failed half way: stream state, psy-2 state copies and lists may disagree;

@@ -125,7 +125,8 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
 // two phases' blocks; both table sets (dB sums 7.8 KB, encoder 12.1 KB) once per workgroup.  The PCM the model read is still
 // in L2 when the encoder stages it.
 static_assert((sizeof(double) * 1258 + sizeof(TlMainShared) + TL_MAIN_WAVES * sizeof(TlFrameLds) + TL_LDS_GRANULE - 1) / TL_LDS_GRANULE <= 128, "the workgroup fits a CU");
-template <int PSY, bool PAIRS>
+template <int PSY, bool PAIRS, int NCH = 0>      // NCH = 2: the list holds two-channel streams only (tlb_batch.cpp: list_stereo) -- the mono paths are not in the kernel and a unit's
+                                                 // first transform does not wait for the stream's configuration record
 __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_waves_per_eu(TL_MAIN_WPE, TL_MAIN_WPE))) tl_frame_kernel(TlLaunch A)
 {
     __shared__ __attribute__((aligned(16))) double dbt[1258];     // dB-sum table + glibc's log table (TlTables::dblog)
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
             int s2;
             if (!tl_unit_partner(A, s, s2)) continue;                // the partner's wave encodes this mono stream's frame with its own
             tl_frame_unit<PSY>(wl, dbt, B, sh.enw_s, &sh.pack, A1, a2, s, f, __builtin_amdgcn_readfirstlane(s2));
-        } else tl_frame_unit<PSY>(wl, dbt, B, sh.enw_s, &sh.pack, A1, a2, s, f);
+        } else tl_frame_unit<PSY, NCH>(wl, dbt, B, sh.enw_s, &sh.pack, A1, a2, s, f);
 #endif
     }
 }
@@ -321,9 +322,11 @@ __global__ void tl_flush_kernel(const TlStreamState *state, const TlConfig *conf
 // launchers (tl_kernels.h): the only way the host translation units reach a kernel
 #define TLK_GO(...) do { hipLaunchKernelGGL(__VA_ARGS__); return hipGetLastError(); } while (0)
 hipError_t tlk_slots(unsigned blocks, hipStream_t st, const TlLaunch &A) { TLK_GO(tl_slots_kernel, dim3(blocks), dim3(256), 0, st, A); }
-hipError_t tlk_frame(int psy, bool pairs, unsigned blocks, hipStream_t st, const TlLaunch &A)
+hipError_t tlk_frame(int psy, bool pairs, bool stereo, unsigned blocks, hipStream_t st, const TlLaunch &A)
 {
     const dim3 g(blocks), t(64 * TL_MAIN_WAVES);
+    if (stereo && !pairs && psy == 1) TLK_GO((tl_frame_kernel<1, false, 2>), g, t, 0, st, A);
+    if (stereo && !pairs) TLK_GO((tl_frame_kernel<3, false, 2>), g, t, 0, st, A);
     if (psy == 1 && pairs) TLK_GO((tl_frame_kernel<1, true>), g, t, 0, st, A);
     if (psy == 1) TLK_GO((tl_frame_kernel<1, false>), g, t, 0, st, A);
     if (pairs) TLK_GO((tl_frame_kernel<3, true>), g, t, 0, st, A);
