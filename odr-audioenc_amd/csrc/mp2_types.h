@@ -148,7 +148,7 @@ struct TlLaunch {
     const TlTables *tables;
     const TlConfig *configs;          // [nconfigs]
     const int32_t *stream_cfg;        // [nstreams] -> config index
-    const int32_t *stream_list;       // [nlist] stream ids handled by this launch (the streams of one psy model)
+    const int32_t *stream_list;       // [nlist] stream ids handled by this launch (the streams of one psy model); NULL: all streams of the batch, position = id
     TlStreamState *state;             // [nstreams]
     const int16_t *pcm;               // [nframes][nstreams][2][1152]
     const uint8_t *xpad;              // [nframes][nstreams][TL_MAX_XPAD] or null

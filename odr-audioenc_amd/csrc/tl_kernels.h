@@ -20,7 +20,7 @@
 
 hipError_t tlk_slots(unsigned blocks, hipStream_t st, const TlLaunch &A);                         // tl_slots_kernel, 256 threads
 hipError_t tlk_frame(int psy, bool pairs, bool stereo, unsigned blocks, hipStream_t st, const TlLaunch &A);    // tl_frame_kernel<1|3, pairs, stereo ? 2 : 0>
-hipError_t tlk_main(int psy, bool pairs, unsigned blocks, hipStream_t st, const TlLaunch &A);     // tl_main_kernel<0|2, pairs>
+hipError_t tlk_main(int psy, bool pairs, bool stereo, unsigned blocks, hipStream_t st, const TlLaunch &A);     // tl_main_kernel<0|2, pairs, stereo ? 2 : 0>
 hipError_t tlk_psy2(unsigned blocks, hipStream_t st, const TlLaunch &A);                          // tl_psy2_kernel
 hipError_t tlk_finish(unsigned blocks, hipStream_t st, const TlLaunch &A);                        // tl_finish_kernel, 256 threads = 4 streams
 hipError_t tlk_ingest(unsigned blocks, hipStream_t st, const int16_t *in, int16_t *out, int16_t *peaks, const double *gain,

@@ -338,7 +338,7 @@ int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d
     b->have_mid = false;
     for (int p = 0; p < 4; p++) {
         if (!b->n_list[p]) continue;
-        A.stream_list = b->d_list[p]; A.nlist = b->n_list[p];
+        A.stream_list = b->n_list[p] == b->nstreams ? nullptr : b->d_list[p]; A.nlist = b->n_list[p];      // one model in the batch: the list is 0, 1, 2, ... and the kernels need no look at it
         // persistent waves, twelve per CU (three per SIMD) in every kernel; they take their units off a counter
         const long units = (long)b->n_list[p] * nframes;
         A.padbits = b->pads[p] ? (uint8_t *)b->stage[7] : nullptr; A.newlag = b->d_newlag;
@@ -366,7 +366,7 @@ int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d
         long mb = (units + TL_MAIN_WAVES - 1) / TL_MAIN_WAVES;
         if (mb > b->num_cu) mb = b->num_cu;
         const bool pr = b->list_pairs[p] && !d_taps && !d_stamps;
-        HIPCHK(tlk_main(p, pr, (unsigned)mb, st, A));                // model 0: no psy kernel before it
+        HIPCHK(tlk_main(p, pr, b->list_stereo[p], (unsigned)mb, st, A));                // model 0: no psy kernel before it
         HIPCHK(tlk_finish((unsigned)((b->n_list[p] + 3) / 4), st, A));
         b->work_clean = true;
     }

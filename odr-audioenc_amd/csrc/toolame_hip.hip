@@ -86,7 +86,7 @@ static_assert((sizeof(TlMainShared) + TL_MAIN_WAVES * sizeof(TlMainLds) + TL_LDS
 // PAIRS: the list contains mono streams that share waves in pairs (TlLaunch::partner, tl_encode_pair).  A second instantiation, so
 // that the kernel of lists without pairs -- every all-stereo batch -- carries none of the pair code (with it inline the register
 // allocation of the stereo path moved from 152 to 168 VGPRs and psy-1 stereo lost 1.1 %).
-template <int PSY, bool PAIRS>     // 0: model 0 (no psy kernel); 2: models 2 and 4 (after tl_psy2_kernel)
+template <int PSY, bool PAIRS, int NCH = 0>     // 0: model 0 (no psy kernel); 2: models 2 and 4 (after tl_psy2_kernel); NCH = 2: a list of two-channel streams only (as tl_frame_kernel)
 __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_waves_per_eu(TL_MAIN_WPE, TL_MAIN_WPE))) tl_main_kernel(TlLaunch A)
 {
     __shared__ TlMainShared sh;
@@ -108,14 +108,14 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
     asm volatile("" : "+v"(wave_v));
     TlMainLds &wl = lds[wave_v];
     for (int hop = 0, k, f, first = ((int)blockIdx.x >> 3) * TL_MAIN_WAVES + wave; tl_take_unit(A.work + TL_HEAD_STRIDE, A.nlist, A.nframes, grp, hop, k, f, first); first = -1) {
-        const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
+        const int s = A.stream_list ? __builtin_amdgcn_readfirstlane(A.stream_list[k]) : k;      // no list: the launch's streams are ALL streams, position = id (one round trip to L2 less per unit)
         if constexpr (PAIRS) {
             int s2;
             if (!tl_unit_partner(A, s, s2)) continue;                // the partner's wave encodes this mono stream's frame with its own
             s2 = __builtin_amdgcn_readfirstlane(s2);
             if (s2 >= 0) { tl_main_pair<PSY>(wl, B, sh.enw_s, &sh.pack, A, s, s2, f); continue; }
         }
-        tl_main_unit<PSY>(wl, B, sh.enw_s, &sh.pack, A, s, f);
+        tl_main_unit<PSY, NCH>(wl, B, sh.enw_s, &sh.pack, A, s, f);
     }
 }
 
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(64 * TL_MAIN_WAVES) __attribute__((amdgpu_wave
     asm volatile("" : "+v"(wave_v));
     TlFrameLds &wl = lds[wave_v];
     for (int hop = 0, k, f, first = ((int)blockIdx.x >> 3) * TL_MAIN_WAVES + wave; tl_take_unit(A.work + TL_HEAD_STRIDE, A.nlist, A.nframes, grp, hop, k, f, first); first = -1) {
-        const int s = __builtin_amdgcn_readfirstlane(A.stream_list[k]);
+        const int s = A.stream_list ? __builtin_amdgcn_readfirstlane(A.stream_list[k]) : k;      // no list: the launch's streams are ALL streams, position = id (one round trip to L2 less per unit)
 #if defined(__HIP_DEVICE_COMPILE__)
         // each phase reads the launch record afresh from the kernel-argument segment (scalar loads), so that nothing but s
         // and f lives in registers across the two
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) tl_slots_kernel(TlLaunch A)
 {
     const int k = (int)(blockIdx.x * 256 + threadIdx.x);
     if (k >= A.nlist) return;
-    tl_slots_stream(A, A.stream_list[k]);
+    tl_slots_stream(A, A.stream_list ? A.stream_list[k] : k);
 }
 
 // finish pass of the split path: one wave per stream (tl_finish_stream)
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) tl_finish_kernel(TlLaunch A)
     if (blockIdx.x == 0 && threadIdx.x < 9) A.work[threadIdx.x * TL_HEAD_STRIDE] = 0;
     const int k = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (k >= A.nlist) return;
-    tl_finish_stream(A, __builtin_amdgcn_readfirstlane(A.stream_list[k]));
+    tl_finish_stream(A, A.stream_list ? __builtin_amdgcn_readfirstlane(A.stream_list[k]) : k);
 }
 
 // Ingest glue of the caller (src/odr-audioenc.cpp:1030-1051 gain + peak, :1139-1152
@@ -332,9 +332,11 @@ hipError_t tlk_frame(int psy, bool pairs, bool stereo, unsigned blocks, hipStrea
     if (pairs) TLK_GO((tl_frame_kernel<3, true>), g, t, 0, st, A);
     TLK_GO((tl_frame_kernel<3, false>), g, t, 0, st, A);
 }
-hipError_t tlk_main(int psy, bool pairs, unsigned blocks, hipStream_t st, const TlLaunch &A)
+hipError_t tlk_main(int psy, bool pairs, bool stereo, unsigned blocks, hipStream_t st, const TlLaunch &A)
 {
     const dim3 g(blocks), t(64 * TL_MAIN_WAVES);
+    if (stereo && !pairs && psy == 0) TLK_GO((tl_main_kernel<0, false, 2>), g, t, 0, st, A);
+    if (stereo && !pairs) TLK_GO((tl_main_kernel<2, false, 2>), g, t, 0, st, A);
     if (psy == 0 && pairs) TLK_GO((tl_main_kernel<0, true>), g, t, 0, st, A);       // model 0: no psy kernel
     if (psy == 0) TLK_GO((tl_main_kernel<0, false>), g, t, 0, st, A);
     if (pairs) TLK_GO((tl_main_kernel<2, true>), g, t, 0, st, A);

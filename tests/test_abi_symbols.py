@@ -177,5 +177,5 @@ def test_isa_guard_on_the_linked_library():
     assert r.returncode == 0, r.stderr
     summary = json.loads(js.read_text())
     fk = [v for k, v in summary.items() if "tl_frame_kernel" in k]
-    assert len(fk) == 4 and all(v["vgpr"] <= 168 and v["vgpr_spill"] == 0 and v["lds"] <= 163840 and v["pairs2_frac"] <= 0.01 for v in fk)
+    assert len(fk) == 6 and all(v["vgpr"] <= 168 and v["vgpr_spill"] == 0 and v["lds"] <= 163840 and v["pairs2_frac"] <= 0.01 for v in fk)
     assert "HIP 7." in M.load_library().tlb_version().decode() or "HIP " in M.load_library().tlb_version().decode()
