@@ -47,13 +47,15 @@ TL_FN TlPcmView tl_pcm_view_pair(const TlLaunch &A, int s0, int s1, int f)
 // nothing but PCM (the window of a frame: the last 192 samples before it and its first 832), so units are independent of each
 // other -- of other streams AND of other frames of the same stream -- and the kernel runs them in any order on any wave.
 template <int PSY, int NCH = 0>     // NCH = 2: every stream of the launch's list is a two-channel stream (the kernel variant of all-stereo lists: no look at the configuration record before the first transform)
-TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch &A, int s, int f, PARGA(double, rec, 4), int s2 = -1)
+TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch &A, int s, int f, PARGA(double, rec, 4), int s2 = -1, int *ci_out = nullptr)
 {   // s2 >= 0: a PAIR of mono streams of one configuration -- the model runs its two-channel form on channel 0 of s and of s2
     // rec: the model's result per subband, in the registers of lane = subband: [ch] the level that competes with the scalefactor
     // level, [2 + ch] the minimum masking threshold (SMR = max(level, scale_db[min scalefactor index]) - threshold is the encoder's
     // line: psycho_1.c:568-581 with level = spike level; psycho_3.c:163-183,409-432 with level = strongest line of the subband)
     const TlTables *T = A.tables;
-    const TlConfig *C = &A.configs[A.stream_cfg[s]];
+    const int ci = TL_UNI_I(A.stream_cfg[s]);                         // (uniform by construction; said so, the record's address is a scalar and its rows are read base + lane offset)
+    if (ci_out) *ci_out = ci;                                                 // the encoder phase of the same unit takes it from here (one round trip less when it starts)
+    const TlConfig *C = &A.configs[ci];
     const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
     const TlPcmView pv = s2 >= 0 ? tl_pcm_view_pair(A, s, s2, f) : tl_pcm_view(A, &A.state[s], s, f);
     TL_LANES_BEGIN
@@ -230,9 +232,9 @@ TL_FN int tl_stage_xpad(TlMainLds &w, const TlLaunch &A, const TlConfig *C, size
 // the SMR comes from the psy kernel's record, and the one thing a frame owes its predecessor -- its ScF-CRC, which travels in
 // the frame before (toolame.c:527-542) -- is filed aside and put in place by tl_finish_stream.
 template <int PSY, int NCH = 0>     // TL_PSY_EXT: SMR from the psy kernel's record (models 1 and 3); 2: the psy-2 kernel's SMR (models 2 and 4); 0: model 0, which needs nothing but this frame's scalefactors
-TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, const TlLaunch &A, int s, int f)
-{
-    const TlConfig *C = &A.configs[A.stream_cfg[s]];
+TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, const TlLaunch &A, int s, int f, int ci = -1)
+{   // ci >= 0: the stream's configuration index, known to the caller (tl_frame_unit: the model phase has read it)
+    const TlConfig *C = &A.configs[ci >= 0 ? ci : TL_UNI_I(A.stream_cfg[s])];
     TlStreamState *st = &A.state[s];
     const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
     const TlPcmView pv = tl_pcm_view(A, st, s, f);
@@ -290,12 +292,13 @@ TL_FN void tl_frame_unit(TlFrameLds &w, const double *TL_RESTRICT db, const TlBl
                          const TlPackTables *TL_RESTRICT K, const TlLaunch &Apsy, TL_KARG Amain_p, int s, int f, int s2 = -1)
 {   // s2 >= 0: frame f of the two mono streams s and s2 (one configuration) as the two "channels" of the wave
     PA(double, rec, 4);
-    tl_psy_unit<PSY, NCH>(w.p, db, Apsy, s, f, rec, s2);
+    int ci = -1;
+    tl_psy_unit<PSY, NCH>(w.p, db, Apsy, s, f, rec, s2, &ci);
     TL_SYNC();
     // The encoder phase reads the launch record afresh (device: scalar loads from the kernel-argument segment, issued HERE) and
     // re-derives its pointers from laundered copies of s / f / s2: nothing of the model phase's scalar state stays live across the
     // phases, and nothing of the encoder's is loaded before the model has run.
-    TL_LAUNDER(Amain_p); TL_LAUNDER(s); TL_LAUNDER(f); TL_LAUNDER(s2);
+    TL_LAUNDER(Amain_p); TL_LAUNDER(s); TL_LAUNDER(f); TL_LAUNDER(s2); TL_LAUNDER(ci);
     const TlLaunch Amain = *Amain_p;
     // the model's arrays are dead: its record goes where the encoder expects it (its own SMR array and the one beside it)
     TL_LANES_BEGIN
@@ -305,7 +308,7 @@ TL_FN void tl_frame_unit(TlFrameLds &w, const double *TL_RESTRICT db, const TlBl
     }
     TL_LANES_END
     if (s2 >= 0) tl_main_pair<TL_PSY_EXT>(w.m, B, enw_s, K, Amain, s, s2, f);
-    else tl_main_unit<TL_PSY_EXT, NCH>(w.m, B, enw_s, K, Amain, s, f);
+    else tl_main_unit<TL_PSY_EXT, NCH>(w.m, B, enw_s, K, Amain, s, f, ci);
 }
 
 // Which stream shares a wave with stream s?  TlLaunch::partner[s]: the other mono stream of s's configuration it is paired with, or -1.
