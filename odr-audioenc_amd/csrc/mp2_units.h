@@ -100,9 +100,9 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
 // needs no scalefactors).
 TL_FN void tl_psy2_chain(TlPsy2Lds &w, const TlLaunch &A, int s, int ch, int f0, int f1, const uint64_t *sct)
 {
-    const TlConfig *C = &A.configs[A.stream_cfg[s]];
-    if (ch >= C->nch || f0 >= f1) return;
-    const TlPsy2Tables *P = &A.psy2_tables[C->psy2_tab];
+    const TlConfig *C = &A.configs[TL_UNI_I(A.stream_cfg[s])];       // (uniform by construction: said so, the record's and the tables' addresses are scalars)
+    if (ch >= TL_UNI_I(C->nch) || f0 >= f1) return;
+    const TlPsy2Tables *P = &A.psy2_tables[TL_UNI_I(C->psy2_tab)];
     PA(double, r1, 8); PA(double, r2, 8); PA(double, p1, 8); PA(double, p2, 8); PV(double, snr0);
     double *l5 = TL_P2_L512(w);
     if (f0 == 0) {
