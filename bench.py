@@ -248,21 +248,24 @@ def committed_counters(S, F, psy, mode, mixed=False):
 
 
 class SclkSampler:
-    """The GPU's shader clock WHILE the timed region runs: a host thread reads the driver's DPM table (sysfs pp_dpm_sclk: the line marked
-    '*' is the current level, what `rocm-smi --showclocks` prints) every 20 ms.  result(): {"median_mhz", "min_mhz", "max_mhz", "samples"}
-    or None where the file cannot be read.  (The clock the committed SQ counter profile derives -- GRBM_GUI_ACTIVE / kernel time under the
-    profiler -- comes out near 2.17 GHz; rocm-smi and this sampler see the kernels run at ~2.39 GHz of the 2.4 GHz peak, 1.1 kW of 1.4 kW:
-    tools/clock_probe.sh, profiles/clock_probe_r05.txt.)"""
+    """The GPU's shader clock WHILE the timed region runs: a host thread reads the driver's DPM tables (sysfs pp_dpm_sclk: the line marked
+    '*' is the current level, what `rocm-smi --showclocks` prints) every 20 ms.  A host may expose several cards in sysfs while the process
+    sees one GPU, and the numbering need not agree: every card is sampled and the one that ran fastest over the region -- the one under
+    load; idle cards sit near 150 MHz -- is reported.  result(): {"median_mhz", "min_mhz", "max_mhz", "samples", "source"} or None where
+    no table can be read or no card left its idle clocks (a region too short for the table to follow).  (The clock the committed SQ
+    counter profile derives -- GRBM_GUI_ACTIVE / kernel time under the profiler -- comes out near 2.17 GHz; rocm-smi and this sampler see
+    the kernels run at 2.39-2.41 GHz of the 2.4 GHz peak, 1.1 kW of 1.4 kW: tools/clock_probe.sh, profiles/clock_probe_r05.txt.)"""
 
     def __init__(self, device_index=0):
         import glob
-        self.vals, self.stop, self.th = [], False, None
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.path = cards[min(device_index, len(cards) - 1)] if cards else None
+        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.vals = {p_: [] for p_ in self.paths}
+        self.stop, self.th = False, None
 
-    def _read(self):
+    @staticmethod
+    def _read(path):
         try:
-            for ln in open(self.path).read().splitlines():
+            for ln in open(path).read().splitlines():
                 if ln.rstrip().endswith("*"):
                     return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
         except Exception:  # noqa: BLE001
@@ -271,12 +274,13 @@ class SclkSampler:
 
     def __enter__(self):
         import threading
-        if self.path:
+        if self.paths:
             def loop():
                 while not self.stop:
-                    v = self._read()
-                    if v:
-                        self.vals.append(v)
+                    for p_ in self.paths:
+                        v = self._read(p_)
+                        if v:
+                            self.vals[p_].append(v)
                     time.sleep(0.02)
             self.th = threading.Thread(target=loop, daemon=True)
             self.th.start()
@@ -288,10 +292,14 @@ class SclkSampler:
             self.th.join(timeout=1.0)
 
     def result(self):
-        if not self.vals:
-            return None
-        v = sorted(self.vals)
-        return {"median_mhz": v[len(v) // 2], "min_mhz": v[0], "max_mhz": v[-1], "samples": len(v), "source": self.path}
+        best = None
+        for p_, v in self.vals.items():
+            if v:
+                v = sorted(v)
+                r = {"median_mhz": v[len(v) // 2], "min_mhz": v[0], "max_mhz": v[-1], "samples": len(v), "source": p_}
+                if best is None or r["median_mhz"] > best["median_mhz"]:
+                    best = r
+        return best if best and best["median_mhz"] >= 1000.0 else None
 
 
 class GpuRun:
