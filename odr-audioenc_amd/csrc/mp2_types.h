@@ -147,7 +147,7 @@ struct TlTaps {
 struct TlLaunch {
     const TlTables *tables;
     const TlConfig *configs;          // [nconfigs]
-    const int32_t *stream_cfg;        // [nstreams] -> config index
+    const int32_t *stream_cfg;        // [nstreams] -> config index; NULL: every stream of the batch has configuration 0 (tl_cfg_index: one dependent load less per unit)
     const int32_t *stream_list;       // [nlist] stream ids handled by this launch (the streams of one psy model); NULL: all streams of the batch, position = id
     TlStreamState *state;             // [nstreams]
     const int16_t *pcm;               // [nframes][nstreams][2][1152]

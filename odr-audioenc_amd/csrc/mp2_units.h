@@ -4,6 +4,9 @@
 #error "include mp2_wave.h"
 #endif
 // ------------------------------------------------------------------------------------------
+// The configuration index of stream s.  A batch whose streams all share ONE configuration (a homogeneous fleet: the common case) passes no
+// table: the index is 0 and a unit does not begin with a load that everything else about its configuration depends on.
+TL_FN int tl_cfg_index(const TlLaunch &A, int s) { return A.stream_cfg ? A.stream_cfg[s] : 0; }
 // One step of the padding recurrence (availbits.c:49-62): does the next frame carry a padding slot?  fp64 as in the reference.
 TL_FN int tl_slot_step(double &lag, double frac)
 {
@@ -16,7 +19,7 @@ TL_FN int tl_slot_step(double &lag, double frac)
 // the launch's frames first and leaves every frame's padding bit for the units (and the state after the launch for the finish pass).
 TL_FN void tl_slots_stream(const TlLaunch &A, int s)
 {
-    const double frac = A.configs[A.stream_cfg[s]].pad_frac;
+    const double frac = A.configs[tl_cfg_index(A, s)].pad_frac;
     double lag = A.state[s].slot_lag;
     for (int f = 0; f < A.nframes; f++) A.padbits[(size_t)f * (size_t)A.nstreams + (size_t)s] = (uint8_t)tl_slot_step(lag, frac);
     A.newlag[s] = lag;
@@ -53,7 +56,7 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
     // level, [2 + ch] the minimum masking threshold (SMR = max(level, scale_db[min scalefactor index]) - threshold is the encoder's
     // line: psycho_1.c:568-581 with level = spike level; psycho_3.c:163-183,409-432 with level = strongest line of the subband)
     const TlTables *T = A.tables;
-    const int ci = TL_UNI_I(A.stream_cfg[s]);                         // (uniform by construction; said so, the record's address is a scalar and its rows are read base + lane offset)
+    const int ci = TL_UNI_I(tl_cfg_index(A, s));                        // (uniform by construction; said so, the record's address is a scalar and its rows are read base + lane offset)
     if (ci_out) *ci_out = ci;                                                 // the encoder phase of the same unit takes it from here (one round trip less when it starts)
     const TlConfig *C = &A.configs[ci];
     const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
@@ -100,7 +103,7 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
 // needs no scalefactors).
 TL_FN void tl_psy2_chain(TlPsy2Lds &w, const TlLaunch &A, int s, int ch, int f0, int f1, const uint64_t *sct)
 {
-    const TlConfig *C = &A.configs[TL_UNI_I(A.stream_cfg[s])];       // (uniform by construction: said so, the record's and the tables' addresses are scalars)
+    const TlConfig *C = &A.configs[TL_UNI_I(tl_cfg_index(A, s))];    // (uniform by construction: said so, the record's and the tables' addresses are scalars)
     if (ch >= TL_UNI_I(C->nch) || f0 >= f1) return;
     const TlPsy2Tables *P = &A.psy2_tables[TL_UNI_I(C->psy2_tab)];
     PA(double, r1, 8); PA(double, r2, 8); PA(double, p1, 8); PA(double, p2, 8); PV(double, snr0);
@@ -234,7 +237,7 @@ TL_FN int tl_stage_xpad(TlMainLds &w, const TlLaunch &A, const TlConfig *C, size
 template <int PSY, int NCH = 0>     // TL_PSY_EXT: SMR from the psy kernel's record (models 1 and 3); 2: the psy-2 kernel's SMR (models 2 and 4); 0: model 0, which needs nothing but this frame's scalefactors
 TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, const TlLaunch &A, int s, int f, int ci = -1)
 {   // ci >= 0: the stream's configuration index, known to the caller (tl_frame_unit: the model phase has read it)
-    const TlConfig *C = &A.configs[ci >= 0 ? ci : TL_UNI_I(A.stream_cfg[s])];
+    const TlConfig *C = &A.configs[ci >= 0 ? ci : TL_UNI_I(tl_cfg_index(A, s))];
     TlStreamState *st = &A.state[s];
     const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
     const TlPcmView pv = tl_pcm_view(A, st, s, f);
@@ -259,7 +262,7 @@ TL_FN void tl_main_unit(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const 
 template <int PSY>
 TL_FN void tl_main_pair(TlMainLds &w, const TlBlockShared *TL_RESTRICT B, const double *TL_RESTRICT enw_s, const TlPackTables *TL_RESTRICT K, const TlLaunch &A, int s0, int s1, int f)
 {
-    const TlConfig *C = &A.configs[A.stream_cfg[s0]];
+    const TlConfig *C = &A.configs[tl_cfg_index(A, s0)];
     const int ss[2] = {s0, s1};
     tl_stage_pcm(w, tl_pcm_view_pair(A, s0, s1, f), 2);
     TlFrameOut fo[2];
@@ -332,7 +335,7 @@ TL_FN bool tl_unit_partner(const TlLaunch &A, int s, int &s2)
 // frame's ScF-CRC into the frame before it, make the launch's last frame the pending one, roll the PCM history forward.
 TL_FN void tl_finish_stream(const TlLaunch &A, int s)
 {
-    const TlConfig *C = &A.configs[A.stream_cfg[s]];
+    const TlConfig *C = &A.configs[tl_cfg_index(A, s)];
     TlStreamState *st = &A.state[s];
     const int whole = C->frame_bytes, dab_ext = C->dab_ext, nch = C->nch;
     const bool have_prev = st->frames_done > 0;

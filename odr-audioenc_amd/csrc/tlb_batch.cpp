@@ -322,7 +322,7 @@ int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d
     struct Guard { tlb_batch *b; int flip; bool ok; ~Guard() { if (!ok) { b->psy2_flip = flip; b->work_clean = false; b->broken = true; } } } guard_{b, b->psy2_flip, false};
     TlLaunch A;
     memset(&A, 0, sizeof A);
-    A.tables = b->d_tables; A.configs = b->d_configs; A.stream_cfg = b->d_stream_cfg; A.state = b->d_state;
+    A.tables = b->d_tables; A.configs = b->d_configs; A.stream_cfg = b->h_configs.size() == 1 ? nullptr : b->d_stream_cfg; A.state = b->d_state;      // one configuration: index 0 for all, no table (tl_cfg_index)
     A.pcm = d_pcm; A.xpad = d_xpad_len ? d_xpad : nullptr; A.xpad_len = d_xpad ? d_xpad_len : nullptr;
     A.out = d_out; A.out_len = d_out_len; A.taps = d_taps; A.stamps = d_stamps;
     A.psy2_tables = b->d_psy2_tables; A.psy2_state = b->d_psy2_state; A.partner = b->d_partner;

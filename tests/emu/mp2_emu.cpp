@@ -83,7 +83,7 @@ int emu_encode_len(void *h, const int16_t *pcm, int nframes, const uint8_t *xpad
     Emu *e = (Emu *)h;
     TlLaunch A;
     memset(&A, 0, sizeof A);
-    A.tables = &e->tables; A.configs = e->configs.data(); A.stream_cfg = e->stream_cfg.data();
+    A.tables = &e->tables; A.configs = e->configs.data(); A.stream_cfg = e->configs.size() == 1 ? nullptr : e->stream_cfg.data();      // as the device path: one configuration, no table
     A.state = e->state.data(); A.pcm = pcm; A.xpad = xpad; A.xpad_len = xpad_len; A.out = out; A.out_len = out_len; A.taps = taps;
     A.psy2_tables = e->psy2_tables.empty() ? nullptr : e->psy2_tables.data();
     A.psy2_state = e->psy2_state.empty() ? nullptr : e->psy2_state.data();
