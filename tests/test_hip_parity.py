@@ -131,6 +131,42 @@ def test_many_streams_vs_oracle(M, psy, mode, nstreams, nframes):
     b.close()
 
 
+@pytest.mark.parametrize("psy", [0, 1, 2, 3])
+def test_kernel_variants_agree(M, psy):
+    """The host picks kernel VARIANTS from the composition of a batch (csrc/tlb_batch.cpp): a list of two-channel streams only runs the
+    kernels built with the channel count as a constant, a batch with one configuration passes no configuration-index table, a launch over
+    every stream of the batch passes no stream list.  The same stereo streams must come out byte for byte the same (a) alone in a batch --
+    every shortcut taken --, (b) next to one mono stream of another bitrate -- the generic kernels with pairs code, an index table -- and
+    (c) next to one stream of another psy model -- two lists, each with its stream list; and all of it equals the oracle."""
+    n, nframes = 24, 9
+    pcm = np.stack([gen_pcm(4000 + s, s % 8 if not (psy == 3 and s % 8 in (1, 3)) else 0, 0, nframes) for s in range(n)], axis=1)
+    extra = gen_pcm(4999, 2, 0, nframes)[:, None]
+    base = [M.StreamConfig(mode="j" if s % 2 else "s", psy_model=psy) for s in range(n)] if psy != 3 else [M.StreamConfig(mode="s", psy_model=3)] * n
+
+    def run(cfgs, data):
+        b = M.Batch(cfgs)
+        a, _ = b.encode(data[:4]); c, _ = b.encode(data[4:])
+        t = b.flush()
+        b.close()
+        return [x + y + z for x, y, z in zip(a, c, t)]
+
+    alone = run([M.StreamConfig(mode="s", psy_model=psy)] * n, pcm)                      # one configuration, one list, stereo only
+    two_cfg = run(base, pcm)                                                             # (for psy != 3: two configurations -> an index table)
+    with_mono = run([M.StreamConfig(mode="s", psy_model=psy)] * n + [M.StreamConfig(mode="m", bitrate=64, psy_model=psy)], np.concatenate([pcm, extra], axis=1))
+    other = 0 if psy != 0 else 1
+    with_other = run([M.StreamConfig(mode="s", psy_model=psy)] * n + [M.StreamConfig(mode="s", psy_model=other)], np.concatenate([pcm, extra], axis=1))
+    assert alone == with_mono[:n] == with_other[:n]
+    for s in range(n):
+        ref, _ = O.oracle_stream(pcm[:, s], mode="s", psy=psy)
+        assert alone[s] == ref, s
+        ref2, _ = O.oracle_stream(pcm[:, s], mode=base[s].mode, psy=psy)
+        assert two_cfg[s] == ref2, s
+    refm, _ = O.oracle_stream(extra[:, 0], mode="m", kbps=64, psy=psy)
+    assert with_mono[n] == refm
+    refo, _ = O.oracle_stream(extra[:, 0], mode="s", psy=other)
+    assert with_other[n] == refo
+
+
 @pytest.mark.parametrize("nstreams", [1, 7, 9, 37, 3100])
 def test_unit_lists_odd_shapes(M, nstreams):
     """The (stream, frame) units of a launch come off eight per-XCD lists (stream k on list k % 8; a wave's first unit is its rank,

@@ -35,9 +35,10 @@ for n in range(1, 8):
 e9 = load("EXP9")
 if e9:
     row("psy: " + names[7], sub(prev, e9)); row("(encoder phase: the model removed)", e9)
-    prev = e9
+    prev = base                                  # the ENC builds keep the model and drop encoder stages from the end
     for n in range(1, 6):
         cur = load(f"ENC{n}")
         if cur: row("enc: " + enc[n - 1], sub(prev, cur)); prev = cur
-    row("(filterbank + staging + unit glue)", prev)
+    row("(psy phase + filterbank + staging)", prev)
+    row("filterbank + staging + unit glue", sub(prev, sub(base, e9)))
 PY
