@@ -171,7 +171,7 @@ TL_FN TlPsy1Ch tl_psy1_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const d
         TL_POWER_DEFER(w, n1, lane + 256 * h + 64, ndef);
         TL_POWER_DEFER(w, n2, lane + 256 * h + 128, ndef);
         TL_POWER_DEFER(w, n3, lane + 256 * h + 192, ndef);
-        while (ndef >= 64) { ndef -= 64; tl_power_near1(w, ndef, 64); }
+        while (ndef >= 64) { ndef -= 64; TL_DBG_NEAR1_FULL(); tl_power_near1(w, ndef, 64); }
     }
     if (ndef) tl_power_near1(w, 0, ndef);
     TL_LANES_BEGIN
@@ -978,7 +978,7 @@ TL_FN int tl_psy3_front(TlPsyLds &w, const TlTables *TL_RESTRICT T, const double
         TL_POWER_DEFER(w, n1, lane + 256 * h + 64, ndef);
         TL_POWER_DEFER(w, n2, lane + 256 * h + 128, ndef);
         TL_POWER_DEFER(w, n3, lane + 256 * h + 192, ndef);
-        while (ndef >= 64) { ndef -= 64; tl_power_near1(w, ndef, 64); }
+        while (ndef >= 64) { ndef -= 64; TL_DBG_NEAR1_FULL(); tl_power_near1(w, ndef, 64); }
     }
     if (ndef) tl_power_near1(w, 0, ndef);
     TL_LANES_BEGIN

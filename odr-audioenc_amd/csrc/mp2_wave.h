@@ -396,6 +396,15 @@ static_assert(2 * TL_MASKER_MAX + 136 + 5 * TL_MASKER_MAX <= TL_FFT_WORDS, "mask
 
 
 
+// Emulation only: how often the power spectrum's deferral list ran FULL (64 filed lines put through the logarithm's other branch before the
+// line loop was done, mp2_psy13.h) -- tests/test_emu_parity.py crafts a spectrum that takes that path and wants to see that it did.
+#ifdef TL_EMULATE
+static long tl_emu_near1_full = 0;
+#define TL_DBG_NEAR1_FULL() (tl_emu_near1_full++)
+#else
+#define TL_DBG_NEAR1_FULL() ((void)0)
+#endif
+
 // ---- the stages, one file each.  They are FRAGMENTS of this header: they rely on the macros and LDS blocks above and on each
 // other in this order, and are not meant to be included on their own. ----
 #define MP2_WAVE_PARTS 1

@@ -302,6 +302,7 @@ long emu_div_by_check(const double *s, const double *d, long n)
 }
 }
 
+extern "C" long emu_near1_full_flushes(void) { return tl_emu_near1_full; }      // full passes of the power spectrum's deferral list so far (mp2_wave.h)
 #ifdef TL_DEBUG_DUMP
 // diagnostic builds only (-DTL_DEBUG_DUMP): rounds of the tone walks since the process started (tl_psy1_front / tl_psy3_front)
 extern "C" long emu_walk_rounds(void) { return tl_dbg_rounds; }

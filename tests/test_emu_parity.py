@@ -365,3 +365,27 @@ def test_mono_pairs_random_configurations_equal_lone_streams():
     assert none == 0
     for s in range(ns):
         assert paired[s] == alone[s], (s, cfgs[s], kinds[s])
+
+
+def test_power_spectrum_deferral_runs_full():
+    """The power spectrum computes the logarithm's table branch for all 512 lines and files the lines e_log.c sends through its close-to-1
+    branch (mp2_psy13.h: tl_power_db_main / tl_power_near1); 64 filed lines are processed at once.  On ordinary signals a channel files
+    ~47 lines, so the pass that runs while the line loop is still going never happens.  A lone impulse gives every line the SAME energy:
+    an amplitude whose energy has a mantissa just above 1 files all 512 lines of a frame -- eight full passes.  The kernel source has to
+    take that path (counter) and still equal the oracle."""
+    L = E.lib()
+    import ctypes
+    L.emu_near1_full_flushes.restype = ctypes.c_long
+    nframes, hits = 3, 0
+    for amp in range(2000, 32000, 37):
+        pcm = np.zeros((nframes, 2, 1152), dtype=np.int16)
+        pcm[1, :, 700] = amp                                          # one sample, both channels, inside frame 1's analysis window
+        before = L.emu_near1_full_flushes()
+        out, _ = _emu_stream(pcm, chunks=(nframes,), samplerate=48000, mode="s", kbps=128, psy=1)
+        if L.emu_near1_full_flushes() - before >= 8:
+            hits += 1
+            assert out == O.oracle_stream(pcm, samplerate=48000, mode="s", kbps=128, psy=1)[0], amp
+            if hits >= 3:
+                break
+    assert hits >= 3
+

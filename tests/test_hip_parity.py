@@ -167,6 +167,41 @@ def test_kernel_variants_agree(M, psy):
     assert with_other[n] == refo
 
 
+def test_power_spectrum_deferral_runs_full_on_the_device(M):
+    """tests/test_emu_parity.py::test_power_spectrum_deferral_runs_full on the device: lone impulses whose energy files all 512 lines of a
+    frame for the logarithm's close-to-1 branch (the amplitudes are found with the emulation's counter), next to ordinary streams in one batch."""
+    import ctypes
+    L = E.lib()
+    L.emu_near1_full_flushes.restype = ctypes.c_long
+    nframes, amps = 3, []
+    for amp in range(2000, 32000, 37):
+        pcm = np.zeros((nframes, 1, 2, 1152), dtype=np.int16)
+        pcm[1, 0, :, 700] = amp
+        before = L.emu_near1_full_flushes()
+        eb = E.EmuBatch([dict(psy=1)])
+        eb.encode(pcm)
+        eb.close()
+        if L.emu_near1_full_flushes() - before >= 8:
+            amps.append(amp)
+            if len(amps) >= 6:
+                break
+    assert len(amps) >= 3
+    pcms = []
+    for k, amp in enumerate(amps):
+        p = np.zeros((nframes, 2, 1152), dtype=np.int16)
+        p[1, :, 700] = amp
+        if k % 2:
+            p[1, 1, 700] = 0                                          # one channel only: the other one is digital silence
+        pcms.append(p)
+    pcms += [gen_pcm(77 + k, 0, 0, nframes) for k in range(3)]
+    b = M.Batch([M.StreamConfig(mode="s", psy_model=1)] * len(pcms))
+    got, _ = b.encode(np.stack(pcms, axis=1))
+    tail = b.flush()
+    b.close()
+    for s, p in enumerate(pcms):
+        assert got[s] + tail[s] == O.oracle_stream(p, mode="s", psy=1)[0], s
+
+
 @pytest.mark.parametrize("nstreams", [1, 7, 9, 37, 3100])
 def test_unit_lists_odd_shapes(M, nstreams):
     """The (stream, frame) units of a launch come off eight per-XCD lists (stream k on list k % 8; a wave's first unit is its rank,
