@@ -84,10 +84,10 @@ TL_FN void tl_psy_unit(TlPsyLds &w, const double *TL_RESTRICT db, const TlLaunch
     TL_LANES_END
     if constexpr (TL_EXP_LEVEL >= 9) { }                              // diagnostic build: no model at all (tools/class_budget.sh: what the encoder phase alone issues)
     else if constexpr (PSY == 1) {
-        if (NCH == 2 || C->nch == 2 || s2 >= 0) tl_psy1_stereo(w, T, db, C, pv, rec, sp);
+        if (NCH == 2 || s2 >= 0 || C->nch == 2) tl_psy1_stereo(w, T, db, C, pv, rec, sp);
         else tl_psy1(w, T, db, C, pv, 0, rec, sp ? sp + 8 : nullptr);
     } else {
-        if (NCH == 2 || C->nch == 2 || s2 >= 0) tl_psy3_stereo(w, T, db, C, pv, rec, sp);
+        if (NCH == 2 || s2 >= 0 || C->nch == 2) tl_psy3_stereo(w, T, db, C, pv, rec, sp);
         else tl_psy3(w, T, db, C, pv, 0, rec, sp ? sp + 8 : nullptr);
     }
     TL_LANES_BEGIN TL_KEEP(L(touch)); TL_LANES_END
