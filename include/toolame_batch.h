@@ -76,8 +76,10 @@ int tlb_device_count(void);
  * code in *err (if err != NULL). */
 tlb_batch *tlb_create(int device, int nstreams, const tlb_stream_config *cfgs, int *err);
 void tlb_destroy(tlb_batch *b);
-int tlb_reset(tlb_batch *b);                       /* every stream back to the state right after tlb_create(); also the way out after a launch
-                                                      failed half way (TLB_ERR_HIP from an encode call: the batch refuses work until reset) */
+int tlb_reset(tlb_batch *b);                       /* every stream back to the state right after tlb_create(); also the way out after a launch or a
+                                                      reconfiguration failed half way (TLB_ERR_HIP from an encode call: the batch refuses work until reset).
+                                                      It re-derives the device's stream tables, kernel lists and mono pairing from the host's first; if THAT
+                                                      fails it returns the code and the batch stays refused (tlb_destroy is then the way out) */
 
 /* Life cycle of ONE stream inside a live batch.  The reference's unit of restart is the stream -- toolame_init() zeroes one encoder
  * (toolame.c:120-153), toolame_finish() ends one (:155-166), the six setters reconfigure one (toolame.h:13-48), and odr-audioenc
@@ -297,8 +299,14 @@ int tlb_tick_run(tlb_tick *t);                 /* = tlb_tick_submit() + tlb_tick
  * the set of the retired tick is handed out again.  At most two ticks in flight: submit, submit, wait, submit, wait ...  Inside, tick t + 1's copy-in starts as soon as tick t's ingest kernel has consumed the device input buffer,
  * so the host-to-device link -- the limit at large stream counts -- never idles between ticks.  The RE-FETCH rule: call tlb_tick_pcm()
  * again after every submit / run, the pointer alternates. */
+/* ERRORS.  A device failure inside submit / wait / run / finish (TLB_ERR_HIP, ...; TLB_ERR_ARG for calls out of order is NOT one) leaves the
+ * object out of step with itself -- the stream groups queued before the failing one have advanced by a frame, the later ones have not --
+ * so it is marked broken and STAYS so: every later submit / wait / run / finish / stream life-cycle call returns TLB_ERR_HIP, the input
+ * accessors NULL; the read accessors keep showing the last tick that was waited for.  tlb_tick_status() = 0 or TLB_ERR_HIP.  The way
+ * out is tlb_tick_destroy() and a new object (one level up: tlb_node_shard_restart does exactly that for one GPU of a node). */
 int tlb_tick_submit(tlb_tick *t);
 int tlb_tick_wait(tlb_tick *t);
+int tlb_tick_status(const tlb_tick *t);
 int tlb_tick_finish(tlb_tick *t);
 long tlb_tick_count(const tlb_tick *t);
 const int16_t *tlb_tick_peaks(const tlb_tick *t);
@@ -324,8 +332,18 @@ float tlb_tick_last_ms(tlb_tick *t);           /* first copy-in queued -> last c
  * Threading: ONE caller thread drives a node handle (the shards' threads are the node's own; the mailbox of a shard holds one job).
  * The function handed to tlb_node_parallel() runs on those threads and may use the accessors (tlb_node_pcm / _packet / ...), but
  * none of the calls that themselves go to the shards' threads (submit / wait / run / finish / sync / encode / life cycle / gain / copies):
- * they would wait for the thread they are running on.  A non-zero return of submit / wait / encode / sync means a shard's device call
- * failed (TLB_ERR_HIP, ...) while others may have gone ahead: the shards are no longer in lockstep and the node is to be destroyed.
+ * they would wait for the thread they are running on.
+ *
+ * FAULT ISOLATION.  The reference restarts ONE failed input and nothing else (src/odr-audioenc.cpp:875-902, src/InputInterface.h:40);
+ * one level up the unit of failure is a GPU.  A shard whose device call fails inside submit / wait / run / finish / encode / flush /
+ * sync is marked BROKEN on the spot: its in-flight steps are dropped from the counters, every later node-wide call skips it, the
+ * accessors of its streams answer NULL / 0 / length 0, the life-cycle calls of its streams TLB_ERR_HIP.  ALL OTHER SHARDS COMPLETE THE
+ * CALL AND STAY IN LOCKSTEP -- their streams never notice.  The call in which a shard breaks returns that shard's code (the caller's
+ * cue; later calls return 0 again, or TLB_ERR_HIP once no shard is left alive); tlb_node_shard_status() says which shard, with which TLB_ERR_* and
+ * HIP's own error string; tlb_node_shard_restart() destroys the shard's object and makes a fresh one on the shard's own thread: its
+ * streams start "as a freshly started reference process" (tlb_stream_reset's contract for the whole block), with the configurations
+ * the streams have NOW and the caller's gains; it joins the lockstep at the next submit (first tick: nothing out, one frame of
+ * latency).  Restart is legal between steps (no tick in flight / after tlb_node_sync), also on a healthy shard.
  *
  * Two planes, chosen at creation:
  *   TLB_NODE_TICK   the real-time loop: a tlb_tick per shard, host buffers in, packets out (everything of tlb_tick_* per stream).
@@ -341,12 +359,31 @@ typedef struct {
 typedef struct {
     int shard, device;             /* total record: shard = -1, device = -1 */
     int first, nstreams;           /* the block [first, first + nstreams) */
-    long steps;                    /* ticks waited for (TICK) / encode calls completed by tlb_node_sync (BATCH) */
-    long frames;                   /* (stream, frame) pairs encoded: sum over steps of nstreams * frames per step */
-    double busy_ns;                /* host clock, this shard: submit (encode call) -> its results waited for (synced), summed; two ticks in flight overlap */
-    double device_ms;              /* device clock: tlb_tick_last_ms() / tlb_last_kernel_ms() summed over the steps */
+    long steps;                    /* COMPLETED steps: ticks waited for (TICK) / encode calls retired by tlb_node_sync (BATCH); total record: the minimum over the shards */
+    long frames;                   /* (stream, frame) pairs of the completed steps: sum of nstreams * frames per step (steps a shard lost by breaking are not counted) */
+    double busy_ns;                /* host clock, this shard: submit (TICK) / the oldest queued encode call (BATCH) -> its results waited for (synced), summed; two ticks in flight overlap; total: the maximum */
+    double device_ms;              /* device clock.  TICK: tlb_tick_last_ms() summed over the ticks.  BATCH: tlb_last_kernel_ms() of the MOST RECENT launch at
+                                      every tlb_node_sync -- a lower bound when several encode calls were queued per sync (one pair of events per batch).  total: the maximum */
     double wall_ns;                /* total record only: first submit -> last wait as the node saw them, summed over steps */
 } tlb_node_counter;
+/* health and identity of one shard (tlb_node_shard_status) */
+#define TLB_SHARD_OK 0
+#define TLB_SHARD_BROKEN 1
+#define TLB_NODE_WHAT_LEN 192
+#define TLB_NODE_NAME_LEN 64
+typedef struct {
+    int shard, device, first, nstreams;
+    int state;                     /* TLB_SHARD_OK / TLB_SHARD_BROKEN */
+    int last_err;                  /* TLB_ERR_* of the failure that broke it last (kept after a restart), 0 = never failed */
+    long failures, restarts;       /* times it broke / was restarted */
+    long lost_steps;               /* steps that were in flight when it broke (not in the counters) */
+    char what[TLB_NODE_WHAT_LEN];  /* the failing call, its code and HIP's error string of the shard's thread */
+    char device_name[TLB_NODE_NAME_LEN];   /* hipDeviceProp_t::name */
+    char pci[24];                  /* domain:bus:device.0 */
+    char uuid[36];                 /* hipDeviceProp_t::uuid as 32 hex digits: two shards on DISTINCT GPUs differ here */
+    int num_cu, num_xcd;           /* compute units, XCDs (hipDeviceAttributeNumberOfXccs) */
+    double hbm_gb;
+} tlb_node_shard_info;
 
 /* Pure arithmetic, no GPU: the block of shard g, and what tlb_create() will make of it -- the number of distinct configurations,
  * the streams per kernel list (psy model 0, 1, 2 (with 4), 3: each list is one homogeneous launch) and the mono streams that share
@@ -360,8 +397,17 @@ void tlb_node_destroy(tlb_node *nd);
 int tlb_node_nshards(const tlb_node *nd);
 int tlb_node_nstreams(const tlb_node *nd);
 int tlb_node_shard_of(const tlb_node *nd, int stream);
-/* per_shard: [nshards] records or NULL; total: the sum (frames, steps of shard 0, max busy_ns, wall_ns) or NULL */
+/* per_shard: [nshards] records or NULL; total: frames summed, steps = the minimum over the shards, busy_ns / device_ms = the maximum, wall_ns; or NULL */
 int tlb_node_counters(const tlb_node *nd, tlb_node_counter *per_shard, tlb_node_counter *total);
+/* One line per shard: device ordinal and name, CUs, XCDs, memory, PCI address, UUID, stream block -- what a log of a multi-GPU run
+ * should open with (also printed to stderr at creation when TLB_VERBOSE is set in the environment).  Valid until tlb_node_destroy. */
+const char *tlb_node_describe(const tlb_node *nd);
+/* Returns TLB_SHARD_OK / TLB_SHARD_BROKEN (negative: -TLB_ERR_ARG) and fills *info (may be NULL). */
+int tlb_node_shard_status(const tlb_node *nd, int shard, tlb_node_shard_info *info);
+/* Destroy + re-create one shard's object (see FAULT ISOLATION above).  now_s >= 0: the EDI timestamp origin of the restarted senders
+ * (TICK plane; < 0 keeps the creation-time value).  Returns 0, TLB_ERR_ARG while a step is in flight or after finish, or the code
+ * the re-creation failed with (the shard then stays broken and may be restarted again). */
+int tlb_node_shard_restart(tlb_node *nd, int shard, long long now_s);
 /* Run fn(ctx, shard, first, n) once per shard ON THAT SHARD'S THREAD, all at once, and wait: the caller's own per-block work --
  * filling the pinned PCM of a block from its inputs, shipping a block's packets -- parallel over the shards without a second pool. */
 int tlb_node_parallel(tlb_node *nd, void (*fn)(void *ctx, int shard, int first, int n), void *ctx);

@@ -11,5 +11,5 @@ library is missing or no GPU is visible.
 """
 from .toolame import (  # noqa: F401
     Batch, StreamConfig, ToolameError, LIB_PATH, build, load_library, lds_bytes_per_stream, legacy_api,
-    EDI_STATE_DTYPE, edi_state_init, Tick, Node, node_partition, node_plan,
+    EDI_STATE_DTYPE, edi_state_init, Tick, Node, node_partition, node_plan, load_fault_library, FAULT_LIB_PATH,
 )

@@ -3,6 +3,8 @@
 #include "tl_libm.h"
 
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "mp2_tables.inc"
@@ -194,6 +196,33 @@ int tl_psy2_slot(long samplerate)
     switch (samplerate) { case 48000: return 0; case 32000: return 1; case 24000: return 2; case 16000: return 3; case 44100: return 4; default: return 5; }
 }
 
+// The spreading function by bands (TlPsy2Tables::s_band): for partition j the first and last column of row j of s that is not zero
+// AMONG THE PARTITIONS THAT EXIST (columns >= npart carry coefficients too -- the reference fills all 64 x 64 from cbval[] = 0 -- but the
+// grouped energies they would multiply are exact +0: a product of +0 adds nothing to a sum of non-negative terms either),
+// the window [band_lo, band_lo + TL_P2_BAND) that holds them (pushed down where it would pass column 63), the coefficients of that
+// window.  A table whose rows do not fit the window would silently lose terms, so that is fatal here, at table build time.
+static void tl_psy2_band(TlPsy2Tables *P)
+{
+    int lo_[64], hi_[64];
+    P->band_w = 0;
+    for (int j = 0; j < 64; j++) {
+        int lo = 64, hi = -1;
+        for (int k = 0; k < P->npart; k++) if (P->s_t[k][j] != 0.0) { if (k < lo) lo = k; hi = k; }
+        if (hi < 0) { lo = 0; hi = 0; }
+        const int w = hi - lo + 1;
+        if (w > TL_P2_BAND) { fprintf(stderr, "libtoolame-dab-hip: spreading band of partition %d is %d wide (TL_P2_BAND %d)\n", j, w, TL_P2_BAND); abort(); }
+        if (w > P->band_w) P->band_w = w;
+        lo_[j] = lo; hi_[j] = hi;
+    }
+    // the device sums whole batches: the window is the table's widest band rounded up to batches, the same for every partition
+    const int window = (P->band_w + TL_P2_B - 1) / TL_P2_B * TL_P2_B;
+    for (int j = 0; j < 64; j++) {
+        const int lo = lo_[j] + window > 64 ? 64 - window : lo_[j];
+        P->band_lo[j] = (int16_t)lo;
+        for (int q = 0; q < TL_P2_BAND; q++) P->s_band[q][j] = q < window ? P->s_t[lo + q][j] : 0.0;
+    }
+}
+
 void tl_build_psy2_tables(TlPsy2Tables *P, long samplerate)
 {   // psycho_2_init, psycho_2.c:259-420
     static const double crit_band[27] = {0, 100, 200, 300, 400, 510, 630, 770, 920, 1080, 1270, 1480, 1720, 2000, 2320,
@@ -257,6 +286,7 @@ void tl_build_psy2_tables(TlPsy2Tables *P, long samplerate)
     }
     for (int j = 512; j >= 0; j--) { P->partition[j] = (uint8_t)partition[j]; P->part_lo[partition[j]] = (int16_t)j; }
     for (int j = 0; j < 513; j++) P->part_hi[partition[j]] = (int16_t)(j + 1);
+    tl_psy2_band(P);
 }
 
 void tl_build_psy4_tables(TlPsy2Tables *P, long samplerate)
@@ -303,6 +333,7 @@ void tl_build_psy4_tables(TlPsy2Tables *P, long samplerate)
     }
     for (int j = 512; j >= 0; j--) { P->partition[j] = (uint8_t)partition[j]; P->part_lo[partition[j]] = (int16_t)j; }
     for (int j = 0; j < 513; j++) P->part_hi[partition[j]] = (int16_t)(j + 1);
+    tl_psy2_band(P);
 }
 
 int tl_build_config(TlConfig *C, long samplerate, char mode, int kbps, int psy, int pad_len)

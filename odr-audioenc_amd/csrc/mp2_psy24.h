@@ -23,9 +23,10 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                         PARG(double, snr0), double *smr_out, const uint64_t *sct, long long *sq)
 {   // sct: glibc's __sincostab (tl_libm.h), the workgroup's LDS copy on the device
     double *x = w.u.fft;
-    double *cw = w.px, *ge = w.u.fft + 520;  // c[] (unpredictability), then fthr[]; partition sums in the
-    double *gc = ge + 64, *ecb = gc + 64, *nb = ecb + 64;   // dead upper half of the FHT buffer
+    double *cw = w.px, *ge = w.u.fft + 520;  // c[] (unpredictability), then fthr[]; partition sums in the dead upper half of the FHT buffer:
+    double *ecb = ge + 128, *nb = ecb + 64;  // ge[2 j], ge[2 j + 1] = grouped energy and weighted unpredictability of partition j (one 16-byte read per term of the spreading sums)
     double *l5 = TL_P2_L512(w);
+    if (TL_P2_LEVEL >= 7) return;                                    // diagnostic builds only (mp2_wave.h)
     {
         TL_STAMP(sq, 0);
         PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
@@ -96,25 +97,26 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                 double r_o5 = 0, r_n5 = 0, p_o5 = 0, p_n5 = 0;      // state of line 512
                 if (it == 0) { r_o5 = l5[0]; r_n5 = l5[1]; p_o5 = l5[2]; p_n5 = l5[3]; }
                 const double a = L(xa), b = L(xb);
+                if (TL_P2_LEVEL >= 6) { L(r1)[it] = a; L(p1)[it] = b; continue; }   // diagnostic: the transform alone, kept alive through the state
                 double e = (a * a + b * b) / 2.0;
                 const bool low = e < 0.0005;
-                double phi = tlm_atan2_sl<false>(-a, b, tlm_atan_cij) + 3.14159265358979 / 4;
+                double phi = (TL_P2_SUB == 3 ? b - a : tlm_atan2_sl<false>(-a, b, tlm_atan_cij)) + 3.14159265358979 / 4;
                 e = TL_SELECT(low, 0.0005, e); phi = TL_SELECT(low, 0.0, phi);
                 e = TL_SELECT(first, a * a, e); phi = TL_SELECT(first, 0.0, phi);      // line 0: energy x_real[0]^2, phase 0
-                const double rn = sqrt(e);
+                const double rn = TL_P2_SUB == 4 ? e + 1.0 : sqrt(e);
                 double spp5 = 0, cpp5 = 0;
-                if (!SEED) {
+                if (!SEED && TL_P2_LEVEL < 5) {
                     const double r_prime = 2.0 * L(r1)[it] - L(r2)[it];
                     const double phi_prime = 2.0 * L(p1)[it] - L(p2)[it];
                     double sp, cp, spp, cpp;
-                    tlm_sincos_sl(TL_SELECT(first, 2.0 * p_o5 - p_n5, phi), &sp, &cp, sct);
-                    tlm_sincos_sl(phi_prime, &spp, &cpp, sct);
+                    if (TL_P2_SUB == 2) { sp = phi; cp = rn; } else tlm_sincos_sl(TL_SELECT(first, 2.0 * p_o5 - p_n5, phi), &sp, &cp, sct);
+                    if (TL_P2_SUB == 1 || TL_P2_SUB == 2) { spp = phi_prime; cpp = r_prime; } else tlm_sincos_sl(phi_prime, &spp, &cpp, sct);
                     spp5 = sp; cpp5 = cp;                                // sincos of line 512's predicted phase (lane 0 of step 0)
                     sp = TL_SELECT(first, 0.0, sp); cp = TL_SELECT(first, 1.0, cp);         // sincos(0.0)
                     const double t1 = rn * cp - r_prime * cpp;
                     const double t2 = rn * sp - r_prime * spp;
                     const double t3 = rn + fabs(r_prime);
-                    cw[j] = t3 != 0 ? sqrt(t1 * t1 + t2 * t2) / t3 : 0;
+                    cw[j] = TL_P2_SUB == 4 ? t1 * t1 + t2 * t2 + t3 : t3 != 0 ? sqrt(t1 * t1 + t2 * t2) / t3 : 0;
                     x[j] = e;
                 }
                 L(r2)[it] = L(r1)[it]; L(r1)[it] = rn; L(p2)[it] = L(p1)[it]; L(p1)[it] = phi;
@@ -139,12 +141,30 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
             }
             TL_LANES_END
         }
-        if (SEED) return;
+        if (SEED || TL_P2_LEVEL >= 5) return;
         TL_LANES_BEGIN
         if (lane == 0) x[512] = L(e512);
         TL_LANES_END
         TL_STAMP(sq, 2);
+        if (TL_P2_LEVEL >= 4) {                                          // diagnostic: c[] and the energies kept alive through the record
+            TL_LANES_BEGIN
+            if (lane < 32) { if (pass == 0) L(snr0) = cw[lane] + x[lane + 64]; else smr_out[lane] = L(snr0) + cw[lane + 128] + x[lane + 192]; }
+            TL_LANES_END
+            return;
+        }
         const double *energy = x;
+        // the lane's first sixteen spreading coefficients (two batches of TL_P2_B), requested here, used after the partition sums
+        PA(double, sva, TL_P2_B); PA(double, svb, TL_P2_B);
+        TL_LANES_BEGIN
+        {
+            const double *sb = &P->s_band[0][0];
+            TL_LAUNDER(sb);                                              // (loads through it stay behind this point)
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < TL_P2_B; q++) { L(sva)[q] = sb[64 * q + lane]; L(svb)[q] = sb[64 * (TL_P2_B + q) + lane]; }
+        }
+        TL_LANES_END
         // grouped energy / weighted unpredictability per partition (psycho_2.c:146-155)
         TL_LANES_BEGIN
         {
@@ -165,30 +185,41 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                 }
                 for (; j < hi; j++) { e += energy[j]; c += energy[j] * cw[j]; }
             }
-            ge[lane] = e; gc[lane] = c;
+            ge[2 * lane] = e; ge[2 * lane + 1] = c;
         }
         TL_LANES_END
         TL_STAMP(sq, 3);
+        if (TL_P2_LEVEL >= 3) {
+            TL_LANES_BEGIN
+            if (lane < 32) { if (pass == 0) L(snr0) = ge[lane] + ge[lane + 64]; else smr_out[lane] = L(snr0) + ge[lane + 32] + ge[lane + 96]; }
+            TL_LANES_END
+            return;
+        }
         // spreading (psycho_2.c:161-175), required SNR (:181-193), permissible noise (:200-204)
+        // Row `lane` of the spreading function is zero outside a band of at most TL_P2_BAND partitions (TlPsy2Tables::s_band): the
+        // sums run over the band's window in ascending order -- the reference's order with its zero coefficients left out, which is
+        // what the reference does itself (:165).  Batches of TL_P2_B coefficients, two batches ahead of their use: the first two have been
+        // under way since before the partition sums, batch i + 2 is requested before batch i is summed (TL_TIE pins that order: the
+        // compiler otherwise requests all of them at once and spills the run's r / phi state).  A table whose band is narrower
+        // (model 4: 29) stops early.
         TL_LANES_BEGIN
         {
             double e = 0, c = 0;
-#ifndef TL_EMULATE
-#pragma unroll
-#endif
-            for (int k0 = 0; k0 < 64; k0 += 16) {                   // sixteen coefficient loads in flight per round trip
-                double sv[16];
-#ifndef TL_EMULATE
-#pragma unroll
-#endif
-                for (int q = 0; q < 16; q++) sv[q] = P->s_t[k0 + q][lane];
-#ifndef TL_EMULATE
-#pragma unroll
-#endif
-                // the reference skips zero coefficients (psycho_2.c:165); adding their +-0 products leaves the sums unchanged
-                // bit for bit (finite operands, sums start at +0), so the test is dropped instead of branching 64 times
-                for (int q = 0; q < 16; q++) { e += sv[q] * ge[k0 + q]; c += sv[q] * gc[k0 + q]; }
-            }
+            const double *gel = ge + 2 * P->band_lo[lane];
+            const int nbat = (P->band_w + TL_P2_B - 1) / TL_P2_B;         // (uniform)
+            double svc[TL_P2_B];
+#define TL_P2_LOAD(dst, i) do { if ((i) < nbat) { const double *sb_ = &P->s_band[(i) * TL_P2_B][0]; TL_TIE(sb_, e); \
+                                 _Pragma("unroll") for (int q = 0; q < TL_P2_B; q++) dst[q] = sb_[64 * q + lane]; } } while (0)
+#define TL_P2_SUM(src, i) do { if ((i) < nbat) { _Pragma("unroll") for (int q = 0; q < TL_P2_B; q++) { double ge_, gc_; TL_LD2(gel + 2 * ((i) * TL_P2_B + q), ge_, gc_); e += src[q] * ge_; c += src[q] * gc_; } } } while (0)
+            TL_P2_LOAD(svc, 2); TL_P2_SUM(L(sva), 0);
+            TL_P2_LOAD(L(sva), 3); TL_P2_SUM(L(svb), 1);
+            TL_P2_LOAD(L(svb), 4); TL_P2_SUM(svc, 2);
+            TL_P2_LOAD(svc, 5); TL_P2_SUM(L(sva), 3);
+            TL_P2_SUM(L(svb), 4);
+            TL_P2_SUM(svc, 5);
+#undef TL_P2_LOAD
+#undef TL_P2_SUM
+            static_assert(TL_P2_BAND == 6 * TL_P2_B, "six batches");
             double cb = e != 0 ? c / e : 0;
             if (cb < .05) cb = 0.05; else if (cb > .5) cb = 0.5;
             const double tb = -0.434294482 * tlm_log_pn(cb, tlm_log_tab) - 0.301029996;
@@ -200,6 +231,12 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
         }
         TL_LANES_END
         TL_STAMP(sq, 4);
+        if (TL_P2_LEVEL >= 2) {
+            TL_LANES_BEGIN
+            if (lane < 32) { if (pass == 0) L(snr0) = nb[lane] + ecb[lane + 32]; else smr_out[lane] = L(snr0) + nb[lane + 32] + ecb[lane]; }
+            TL_LANES_END
+            return;
+        }
         // threshold per line (psycho_2.c:205-224): c[] is dead, reuse it for fthr[]
         TL_LANES_BEGIN
         for (int j = lane; j <= 512; j += 64) {
@@ -208,6 +245,12 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
         }
         TL_LANES_END
         TL_STAMP(sq, 5);
+        if (TL_P2_LEVEL >= 1) {
+            TL_LANES_BEGIN
+            if (lane < 32) { if (pass == 0) L(snr0) = cw[lane] + cw[lane + 256]; else smr_out[lane] = L(snr0) + cw[lane + 64] + cw[lane + 448]; }
+            TL_LANES_END
+            return;
+        }
         // 32 subbands (psycho_2.c:227-246)
         TL_LANES_BEGIN
         if (lane < 32) {

@@ -99,15 +99,22 @@ struct TlConfig {
 };
 
 // psy model 2 tables; they depend on the sample rate only (psycho_2.c:259-420, absthr.h).
+#define TL_P2_BAND 48           /* the widest run of non-zero spreading coefficients the device path takes (tl_psy2_band checks every table: 43 at most) */
+#define TL_P2_B 8               /* ... requested in batches of eight, two batches ahead of their use (tl_psy2_pass) */
 struct TlPsy2Tables {
     double window[1024];         // 0.5*(1-cos(2*PI*(i-0.5)/1024)), psycho_2.c:318-319
     double absthr[513];
     double s_t[64][64];          // spreading function TRANSPOSED: s_t[k][j] = s[j][k]  (coalesced by partition j)
+    // The same function as each partition's BAND: row j of s is zero outside a run of at most TL_P2_BAND partitions (43 for model 2's
+    // -100 dB cut, 29 for model 4's -60 dB), and a zero coefficient adds +0 to a sum of non-negative terms -- nothing, bit for bit (the
+    // reference skips them, psycho_2.c:165).  s_band[q][j] = s[j][band_lo[j] + q], band_lo[j] + TL_P2_BAND <= 64 (tl_psy2_band, mp2_host.cpp).
+    double s_band[TL_P2_BAND][64];
+    int16_t band_lo[64];
     double tmn[64], bmaxk[64];   // tone-masking-noise, bmax[(int)(cbval+0.5)]
     double den[64];              // rnorm[j]*numlines[j]; 0 => nb[j] = 0  (psycho_2.c:200-204)
     int16_t part_lo[64], part_hi[64];   // FFT lines [lo,hi) of each partition (empty partitions: lo = hi)
     uint8_t partition[520];
-    int32_t npart, pad_;
+    int32_t npart, band_w;       // band_w: the widest run of this table (<= TL_P2_BAND)
 };
 // psy model 2 prediction state per stream: r and phi of the two previous 576-sample passes (psycho_2.c:300-306)
 struct TlPsy2State {

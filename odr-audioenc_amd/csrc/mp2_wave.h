@@ -75,6 +75,7 @@ TL_FN void tlh_par_sum_i32(int (&d)[64], const int (&v)[64])
 #define TL_KARG const TlLaunch *
 #define TL_KEEP(x) ((void)0)
 #define TL_PIN(x) ((void)0)
+#define TL_TIE(p, v) ((void)0)
 #define TL_LD2(p, a, b) do { const double *p_ = (p); (a) = p_[0]; (b) = p_[1]; } while (0)
 #else
 #define TL_FN __device__ __forceinline__
@@ -235,6 +236,7 @@ typedef const struct TlLaunch *TlKArg;                                        /*
 #endif
 #define TL_KARG TlKArg
 #define TL_LAUNDER(p) asm volatile("" : "+s"(p))       /* keeps loads through p inside the frame loop (no hoisting into long-lived VGPRs) */
+#define TL_TIE(p, v) asm volatile("" : "+s"(p), "+v"(v))   /* loads through p are requested after v has been computed, not before: a software pipeline's order, pinned */
 #define TL_PIN(x) asm volatile("" : "+v"(x))           /* a constant made once, here, in a vector register: machine LICM is off (csrc/Makefile), so a literal used inside a hot loop
                                                           is otherwise re-made by a v_mov on every trip */
 #endif
@@ -311,6 +313,17 @@ static long tl_dbg_rounds = 0, tl_dbg_tones = 0, tl_dbg_deadheads = 0, tl_dbg_fr
 #ifndef TL_ENC_LEVEL
 #define TL_ENC_LEVEL 0
 #endif
+// And for the psy-2 kernel (tools/class_budget_psy2.sh): TL_P2_LEVEL = n removes the last n stages of a full pass of tl_psy2_pass --
+// 1: the 32 subbands, 2: + the per-line thresholds, 3: + spreading / required SNR / permissible noise, 4: + the partition sums,
+// 5: + the unpredictability (two sincos, c[]): the pass is then a seed pass, 6: + the polar form (energy, square root, arctangent),
+// 7: the whole pass (window + transform too).  TL_P2_SUB picks ONE operation out of the line loop instead (levels 0 only):
+// 1: no sincos of the predicted phase, 2: no sincos at all, 3: no arctangent, 4: no square roots and no division.
+#ifndef TL_P2_LEVEL
+#define TL_P2_LEVEL 0
+#endif
+#ifndef TL_P2_SUB
+#define TL_P2_SUB 0
+#endif
 #define TL_DBMIN (-200.0)
 #define TL_POWERNORM 90.3090
 #define TL_T_NOISE 10
@@ -366,7 +379,7 @@ struct TlMainLds {
 #endif
 };
 // Per-wave LDS of the psy kernel of models 2 and 4: the transform / energies (partition sums in its dead upper half) and c[] / fthr[].
-struct TlPsy2Lds {
+struct alignas(16) TlPsy2Lds {       // (16: the partition sums are read as pairs, tl_psy2_pass)
     struct { double fft[1024]; } u;
     double px[520];
 };

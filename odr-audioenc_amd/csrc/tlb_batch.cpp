@@ -3,6 +3,7 @@
 // stream, flush, the reference's send schedule, the libm self-check and the timing accessors.  Host C++: the kernels are reached through
 // tl_kernels.h.
 #include "tlb_internal.h"
+#include "tlb_plan.h"
 #include "tl_libm.h"
 
 extern "C" {
@@ -74,14 +75,8 @@ static int batch_build_lists(tlb_batch *b)
         HIPCHK(hipMemcpy(b->d_list[p], ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice));
     }
     {   // mono streams of the same configuration (hence the same model and kernel) in pairs: consecutive ones of the stream order
-        std::vector<int32_t> partner((size_t)nstreams, -1);
-        std::vector<int> open(b->h_configs.size(), -1);              // per configuration: a mono stream still waiting for a partner
-        for (int s2 = 0; s2 < nstreams; s2++) {
-            const int ci = b->h_stream_cfg[s2];
-            if (b->h_configs[(size_t)ci].nch != 1) continue;
-            if (open[(size_t)ci] < 0) open[(size_t)ci] = s2;
-            else { partner[(size_t)s2] = open[(size_t)ci]; partner[(size_t)open[(size_t)ci]] = s2; open[(size_t)ci] = -1; }
-        }
+        std::vector<int32_t> partner;
+        tlb_plan_pairs(b->h_configs, b->h_stream_cfg, partner);                                  // (csrc/tlb_plan.h: the one statement of the pairing)
         for (int p = 0; p < 4; p++) { b->list_pairs[p] = false; b->list_stereo[p] = b->n_list[p] > 0; }
         for (int s2 = 0; s2 < nstreams; s2++) {
             const TlConfig &c2 = b->h_configs[b->h_stream_cfg[s2]];
@@ -130,21 +125,9 @@ static int tlb_create_impl(tlb_batch *b, int device, int nstreams, const tlb_str
     b->nstreams = nstreams;
     b->h_stream_cfg.resize(nstreams);
     // streams sharing the six knobs share one config record (keeps the tables L2/L1 resident)
-    std::vector<tlb_stream_config> &uniq = b->h_uniq;
+    if (int rc = tlb_plan_configs(nstreams, cfgs, b->h_uniq, b->h_configs, b->h_stream_cfg)) return rc;          // (csrc/tlb_plan.h)
     for (int s = 0; s < nstreams; s++) {
-        int found = -1;
-        for (size_t u = 0; u < uniq.size(); u++)
-            if (uniq[u].samplerate == cfgs[s].samplerate && uniq[u].mode == cfgs[s].mode && uniq[u].bitrate == cfgs[s].bitrate &&
-                uniq[u].psy_model == cfgs[s].psy_model && uniq[u].pad_len == cfgs[s].pad_len) { found = (int)u; break; }
-        if (found < 0) {
-            TlConfig c;
-            int rc = tl_build_config(&c, cfgs[s].samplerate, cfgs[s].mode, cfgs[s].bitrate, cfgs[s].psy_model, cfgs[s].pad_len);
-            if (rc) return rc;
-            uniq.push_back(cfgs[s]);
-            b->h_configs.push_back(c);
-            found = (int)uniq.size() - 1;
-        }
-        b->h_stream_cfg[s] = found;
+        const int found = b->h_stream_cfg[s];
         {
             const int longest = (b->h_configs[found].frame_bytes + (b->h_configs[found].pad_frac != 0 ? 1 : 0) + 3) & ~3;
             if (longest > b->out_stride) b->out_stride = longest;
@@ -213,6 +196,13 @@ int tlb_reset(tlb_batch *b)
     if (!b) return TLB_ERR_ARG;
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipDeviceSynchronize());
+    // `broken` has two causes: a launch that failed half way (stream state in motion) and a reconfiguration whose roll-back failed too
+    // (tlb_stream_reconfigure: the device's stream -> configuration table, the kernel lists and the mono pairing may then disagree with
+    // the host's).  So the device side of everything batch_build_lists() derives is rebuilt from the HOST tables first, and the flag
+    // only falls when that and the zeroing went through; otherwise the batch stays refused and tlb_destroy() is the way out.
+    HIPCHK(hipMemcpy(b->d_configs, b->h_configs.data(), sizeof(TlConfig) * b->h_configs.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_stream_cfg, b->h_stream_cfg.data(), sizeof(int32_t) * (size_t)b->nstreams, hipMemcpyHostToDevice));
+    if (int rc = batch_build_lists(b)) return rc;
     if (int rc = batch_clear_streams(b, 0, b->nstreams)) return rc;
     b->frames = 0; b->psy2_flip = 0; b->work_clean = false; b->broken = false;
     return TLB_OK;
@@ -251,10 +241,7 @@ int tlb_stream_finish(tlb_batch *b, int stream, uint8_t *out, size_t out_size)
 int tlb_stream_reconfigure(tlb_batch *b, int stream, const tlb_stream_config *cfg)
 {   // the setters of toolame.h:13-48 followed by toolame_init() for ONE stream: new sample rate / mode / bitrate / model / PAD length
     if (!b || !cfg || stream < 0 || stream >= b->nstreams) return TLB_ERR_ARG;
-    int found = -1;
-    for (size_t u = 0; u < b->h_uniq.size(); u++)
-        if (b->h_uniq[u].samplerate == cfg->samplerate && b->h_uniq[u].mode == cfg->mode && b->h_uniq[u].bitrate == cfg->bitrate &&
-            b->h_uniq[u].psy_model == cfg->psy_model && b->h_uniq[u].pad_len == cfg->pad_len) { found = (int)u; break; }
+    int found = tlb_find_config(b->h_uniq, *cfg);
     TlConfig c;
     if (found < 0) { if (int rc = tl_build_config(&c, cfg->samplerate, cfg->mode, cfg->bitrate, cfg->psy_model, cfg->pad_len)) return rc; }
     else c = b->h_configs[(size_t)found];
@@ -307,6 +294,9 @@ int tlb_nstreams(const tlb_batch *b) { return b ? b->nstreams : 0; }
 int tlb_frame_bytes(const tlb_batch *b, int s) { return (b && s >= 0 && s < b->nstreams) ? b->h_configs[b->h_stream_cfg[s]].frame_bytes : 0; }
 int tlb_out_stride(const tlb_batch *b) { return b ? b->out_stride : 0; }
 long tlb_frames_encoded(const tlb_batch *b) { return b ? b->frames : 0; }
+#ifdef TLB_FAULT_INJECT
+int tlb_debug_fail_next(tlb_batch *b, int nth) { if (!b || nth < 0) return TLB_ERR_ARG; b->fail_in = nth; return TLB_OK; }
+#endif
 
 }  // extern "C"
 int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d_xpad, const int32_t *d_xpad_len,
@@ -314,12 +304,16 @@ int tlb_launch(tlb_batch *b, const int16_t *d_pcm, int nframes, const uint8_t *d
 {
     if (!b || !d_pcm || !d_out || nframes <= 0) return TLB_ERR_ARG;
     for (int p = 0; p < 4; p++) if ((long)b->n_list[p] * nframes > (1L << 30)) return TLB_ERR_ARG;   // unit indices are 32-bit; checked for every model before anything is queued
-    if (b->broken) { fprintf(stderr, "libtoolame-dab-hip: this batch had a launch fail half way; tlb_reset() it before encoding on\n"); return TLB_ERR_HIP; }
+    if (b->broken) { fprintf(stderr, "libtoolame-dab-hip: a launch or a reconfiguration of this batch failed half way; tlb_reset() it before encoding on\n"); return TLB_ERR_HIP; }
     HIPCHK(hipSetDevice(b->device));
     // From the first kernel on the streams' state is in motion.  If anything below fails, the psy-2 state copy the next launch would
     // read may never have been written and the unit counters may be non-zero: the flip is taken back, the counters are re-zeroed by
     // the next launch, and the batch refuses further work until tlb_reset().
     struct Guard { tlb_batch *b; int flip; bool ok; ~Guard() { if (!ok) { b->psy2_flip = flip; b->work_clean = false; b->broken = true; } } } guard_{b, b->psy2_flip, false};
+#ifdef TLB_FAULT_INJECT
+    // test builds only (csrc/tlb_debug.h): the launch armed by tlb_debug_fail_next() fails here as a device call would -- the guard marks the batch broken
+    if (b->fail_in > 0 && --b->fail_in == 0) { fprintf(stderr, "libtoolame-dab-hip: injected fault (tlb_debug_fail_next)\n"); return TLB_ERR_HIP; }
+#endif
     TlLaunch A;
     memset(&A, 0, sizeof A);
     A.tables = b->d_tables; A.configs = b->d_configs; A.stream_cfg = b->h_configs.size() == 1 ? nullptr : b->d_stream_cfg; A.state = b->d_state;      // one configuration: index 0 for all, no table (tl_cfg_index)

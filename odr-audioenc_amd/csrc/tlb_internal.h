@@ -65,6 +65,7 @@ struct tlb_batch {
     bool broken = false;                         // a launch or a reconfiguration failed half way: stream state, psy-2 state copies and lists may disagree;
                                                  // every further launch is refused (TLB_ERR_HIP) until tlb_reset() has put all streams back to zero
     int num_cu = 256;
+    int fail_in = 0;                             // test builds only (-DTLB_FAULT_INJECT, csrc/tlb_debug.h): the fail_in-th launch from now fails
 };
 
 static inline hipError_t stage_reserve(tlb_batch *b, int k, size_t bytes)

@@ -48,7 +48,11 @@ struct tlb_tick {
     hipEvent_t ev0[3] = {}, ev1[3] = {};          // per output set: first copy-in queued / last copy-out done
     long ticks = 0;
     bool finished = false;
+    bool broken = false;                         // a device call of submit / wait / finish failed: the groups queued before the failing one have advanced by a frame,
+                                                 // the later ones have not -- the object is out of step with itself and every further call but destroy is refused (sticky)
 };
+// a failing submit / wait / finish: drain what was queued, mark the object, hand the code on
+static int tick_fail(tlb_tick *t, int rc);
 
 extern "C" {
 
@@ -183,7 +187,7 @@ tlb_tick *tlb_tick_create(int device, int nstreams, const tlb_stream_config *cfg
 // The input accessors hand out the set the NEXT submit will read.  With two ticks in flight both sets belong to queued copy-ins (the
 // set these would name is the one the older tick's host-to-device copy may still be reading): NULL until tlb_tick_wait() has
 // retired that tick -- no submit is possible in that state anyway.
-static bool tick_input_free(const tlb_tick *t) { return t && !t->finished && t->ticks - t->waited < 2; }
+static bool tick_input_free(const tlb_tick *t) { return t && !t->finished && !t->broken && t->ticks - t->waited < 2; }
 int16_t *tlb_tick_pcm(tlb_tick *t) { return tick_input_free(t) ? t->h_inter[t->in_set] : nullptr; }
 uint8_t *tlb_tick_xpad(tlb_tick *t) { return tick_input_free(t) && t->with_xpad ? t->h_xpad[t->in_set] : nullptr; }
 int32_t *tlb_tick_xpad_len(tlb_tick *t) { return tick_input_free(t) && t->with_xpad ? t->h_xl[t->in_set] : nullptr; }
@@ -214,18 +218,21 @@ int tlb_tick_stream_reset(tlb_tick *t, int stream)
 {
     int k; TickGroup *G = tick_group_of(t, stream, &k);
     if (!G || t->finished) return TLB_ERR_ARG;
+    if (t->broken) return TLB_ERR_HIP;
     return tlb_stream_reset(G->b, k);
 }
 int tlb_tick_stream_finish(tlb_tick *t, int stream, uint8_t *out, size_t out_size)
 {
     int k; TickGroup *G = tick_group_of(t, stream, &k);
     if (!G || t->finished) return -TLB_ERR_ARG;
+    if (t->broken) return -TLB_ERR_HIP;
     return tlb_stream_finish(G->b, k, out, out_size);
 }
 int tlb_tick_stream_reconfigure(tlb_tick *t, int stream, const tlb_stream_config *cfg)
 {
     int k; TickGroup *G = tick_group_of(t, stream, &k);
     if (!G || t->finished) return TLB_ERR_ARG;
+    if (t->broken) return TLB_ERR_HIP;
     return tlb_stream_reconfigure(G->b, k, cfg);
 }
 
@@ -266,6 +273,18 @@ static int tick_egress(tlb_tick *t, TickGroup &G, bool have_frames, int set, boo
 }
 
 static void tick_drain(tlb_tick *t) { (void)hipStreamSynchronize(t->s_in); (void)hipStreamSynchronize(t->s_run); (void)hipStreamSynchronize(t->s_out); }
+static int tick_fail(tlb_tick *t, int rc)
+{
+    tick_drain(t);
+    if (!t->broken) fprintf(stderr, "libtoolame-dab-hip: a tick failed half way (code %d): its stream groups are out of step, the tick object refuses further work; destroy it\n", rc);
+    t->broken = true;
+    return rc;
+}
+int tlb_tick_status(const tlb_tick *t) { return !t ? TLB_ERR_ARG : t->broken ? TLB_ERR_HIP : TLB_OK; }
+#ifdef TLB_FAULT_INJECT
+// test builds only (csrc/tlb_debug.h): the nth submit from now fails in its LAST group -- after the groups before it have been queued
+int tlb_debug_tick_fail_next(tlb_tick *t, int nth) { if (!t || nth < 0) return TLB_ERR_ARG; t->groups.back().b->fail_in = nth; return TLB_OK; }
+#endif
 
 // Queue one tick -- copy-in, ingest, encode, egress, copy-out of every group -- on the input set the caller has just filled, and
 // return at once.  tlb_tick_pcm() then points at the OTHER input set: the caller fills the next tick while this one is on its way
@@ -276,10 +295,11 @@ static void tick_drain(tlb_tick *t) { (void)hipStreamSynchronize(t->s_in); (void
 int tlb_tick_submit(tlb_tick *t)
 {
     if (!t || t->finished || t->ticks - t->waited >= 2) return TLB_ERR_ARG;
-    HIPCHK(hipSetDevice(t->device));
+    if (t->broken) return TLB_ERR_HIP;
+    if (hipSetDevice(t->device) != hipSuccess) return tick_fail(t, TLB_ERR_HIP);
     const int set = (int)(t->ticks & 1);                             // == in_set: ticks and input sets alternate together
     const int oset = (int)(t->ticks % 3);                            // output set: the caller may still be reading tick - 2's
-    HIPCHK(hipEventRecord(t->ev0[oset], t->s_in));
+    if (hipEventRecord(t->ev0[oset], t->s_in) != hipSuccess) return tick_fail(t, TLB_ERR_HIP);
     for (auto &G : t->groups) {
         const size_t n = (size_t)G.n;
         int rc = TLB_OK;
@@ -298,9 +318,9 @@ int tlb_tick_submit(tlb_tick *t)
         if (!rc) rc = tlb_launch(G.b, G.d_pcm, 1, t->with_xpad ? G.d_xpad : nullptr, t->with_xpad ? G.d_xl : nullptr, G.d_frames, nullptr, t->s_run, nullptr, G.d_flen);
         if (!rc && hipEventRecord(G.ev_encoded, t->s_run) != hipSuccess) rc = TLB_ERR_HIP;
         if (!rc) rc = tick_egress(t, G, t->ticks > 0, oset);
-        if (rc) { tick_drain(t); return rc; }
+        if (rc) return tick_fail(t, rc);
     }
-    if (hipEventRecord(t->ev1[oset], t->s_out) != hipSuccess) { tick_drain(t); return TLB_ERR_HIP; }
+    if (hipEventRecord(t->ev1[oset], t->s_out) != hipSuccess) return tick_fail(t, TLB_ERR_HIP);
     t->ticks++;
     t->in_set = (int)(t->ticks & 1);
     return TLB_OK;
@@ -311,9 +331,10 @@ int tlb_tick_submit(tlb_tick *t)
 int tlb_tick_wait(tlb_tick *t)
 {
     if (!t || t->waited >= t->ticks) return TLB_ERR_ARG;
-    HIPCHK(hipSetDevice(t->device));
+    if (t->broken) return TLB_ERR_HIP;
+    if (hipSetDevice(t->device) != hipSuccess) return tick_fail(t, TLB_ERR_HIP);
     const int set = (int)(t->waited % 3);
-    if (hipEventSynchronize(t->ev1[set]) != hipSuccess) { tick_drain(t); return TLB_ERR_HIP; }
+    if (hipEventSynchronize(t->ev1[set]) != hipSuccess) return tick_fail(t, TLB_ERR_HIP);
     t->out_set = set;
     t->waited++;
     return TLB_OK;
@@ -322,6 +343,7 @@ int tlb_tick_wait(tlb_tick *t)
 int tlb_tick_run(tlb_tick *t)
 {   // one tick start to end: the accessors show its results when the call returns
     if (!t || t->ticks != t->waited) return TLB_ERR_ARG;
+    if (t->broken) return TLB_ERR_HIP;
     if (int rc = tlb_tick_submit(t)) return rc;
     return tlb_tick_wait(t);
 }
@@ -330,7 +352,8 @@ int tlb_tick_run(tlb_tick *t)
 int tlb_tick_finish(tlb_tick *t)
 {
     if (!t || t->finished || t->ticks == 0 || t->ticks != t->waited) return TLB_ERR_ARG;
-    HIPCHK(hipSetDevice(t->device));
+    if (t->broken) return TLB_ERR_HIP;
+    if (hipSetDevice(t->device) != hipSuccess) return tick_fail(t, TLB_ERR_HIP);
     const int set = (int)(t->ticks % 3);
     for (auto &G : t->groups) {
         int rc = hipStreamWaitEvent(t->s_run, G.ev_out, 0) == hipSuccess ? TLB_OK : TLB_ERR_HIP;
@@ -338,9 +361,9 @@ int tlb_tick_finish(tlb_tick *t)
         if (!rc) {      // the egress sends the levels of the last run with the last frame (they are in the other host set; the device copy is current)
             rc = tick_egress(t, G, true, set, false);
         }
-        if (rc) { tick_drain(t); return rc; }
+        if (rc) return tick_fail(t, rc);
     }
-    if (hipStreamSynchronize(t->s_out) != hipSuccess) { tick_drain(t); return TLB_ERR_HIP; }
+    if (hipStreamSynchronize(t->s_out) != hipSuccess) return tick_fail(t, TLB_ERR_HIP);
     t->out_set = set;
     t->finished = true;
     return TLB_OK;

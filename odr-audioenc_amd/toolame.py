@@ -16,6 +16,7 @@ import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("TLB_LIB_PATH") or PKG_DIR / "libtoolame_dab_hip.so")     # TLB_LIB_PATH: kernel experiments (tools/) only
+FAULT_LIB_PATH = PKG_DIR / "libtoolame_dab_hip_fi.so"    # TEST build with fault injection (csrc/tlb_debug.h, `make fault`); never the product
 MAX_XPAD = 256
 SAMPLES = 1152
 
@@ -49,11 +50,31 @@ _lib = None
 
 
 def build(verbose=False):
-    """Compile csrc/ for gfx950 into libtoolame_dab_hip.so (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-j4", "-C", str(PKG_DIR / "csrc")], capture_output=not verbose, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc build failed:\n" + (r.stdout or "") + (r.stderr or ""))
+    """Compile csrc/ for gfx950 into libtoolame_dab_hip.so (hipcc cross-compiles without a GPU), and the fault-injection TEST build
+    of the same kernels beside it (libtoolame_dab_hip_fi.so: host files only, seconds)."""
+    for target in ([], ["fault"]):
+        r = subprocess.run(["make", "-j4", "-C", str(PKG_DIR / "csrc")] + target, capture_output=not verbose, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc build failed:\n" + (r.stdout or "") + (r.stderr or ""))
     return LIB_PATH
+
+
+_fault_lib = None
+
+
+def load_fault_library():
+    """The TEST build with fault injection (csrc/tlb_debug.h) as a second, independent library object: pass it as `lib=` to Batch / Tick /
+    Node.  Only tests use it -- the product library has no such entry points."""
+    global _fault_lib
+    if _fault_lib is None:
+        if not FAULT_LIB_PATH.exists():
+            raise ToolameError(16, f"{FAULT_LIB_PATH} is missing (make -C odr-audioenc_amd/csrc fault)")
+        L = _bind(C.CDLL(str(FAULT_LIB_PATH)))
+        L.tlb_debug_fail_next.argtypes = [C.c_void_p, C.c_int]
+        L.tlb_debug_tick_fail_next.argtypes = [C.c_void_p, C.c_int]
+        L.tlb_debug_node_fail_next.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        _fault_lib = L
+    return _fault_lib
 
 
 def load_library():
@@ -63,7 +84,12 @@ def load_library():
         return _lib
     if not LIB_PATH.exists():
         raise ToolameError(16, f"{LIB_PATH} is missing (run __graft_entry__.build())")
-    L = C.CDLL(str(LIB_PATH))
+    _lib = _bind(C.CDLL(str(LIB_PATH)))
+    return _lib
+
+
+def _bind(L):
+    """argument / result types of every entry point of include/toolame_batch.h"""
     L.tlb_create.restype = C.c_void_p
     L.tlb_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
     L.tlb_destroy.argtypes = [C.c_void_p]
@@ -181,7 +207,11 @@ def load_library():
     L.toolame_set_channel_mode.argtypes = [C.c_char]
     L.toolame_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.toolame_finish.argtypes = [C.c_void_p, C.c_size_t]
-    _lib = L
+    L.tlb_tick_status.argtypes = [C.c_void_p]
+    L.tlb_node_describe.argtypes = [C.c_void_p]
+    L.tlb_node_describe.restype = C.c_char_p
+    L.tlb_node_shard_status.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.tlb_node_shard_restart.argtypes = [C.c_void_p, C.c_int, C.c_longlong]
     return L
 
 
@@ -243,8 +273,8 @@ class Tick:
     EGRESS = {"frames": 0, "af": 1, "pft": 2, "zmq": 3}
 
     def __init__(self, configs, egress="af", ngroups=0, with_xpad=False, version=b"", now_s=1700000000, delay_ms=0, tist=False,
-                 tai_utc_offset=37, fec=0, chunk_len=207, transport=False, addr_source=0, dest_port=0, device=0):
-        self.L = load_library()
+                 tai_utc_offset=37, fec=0, chunk_len=207, transport=False, addr_source=0, dest_port=0, device=0, lib=None):
+        self.L = lib or load_library()
         configs = list(configs)
         self.nstreams = len(configs)
         self._version = bytes(version)
@@ -322,6 +352,14 @@ class Tick:
             raise ToolameError(rc, "tlb_tick_stream_reconfigure")
         self.units[s] = self.L.tlb_tick_units(self.h, s)
 
+    def status(self):
+        """0, or 17 (TLB_ERR_HIP) once a device failure has left the object out of step with itself (sticky: destroy it)"""
+        return self.L.tlb_tick_status(self.h)
+
+    def fail_next(self, nth=1):
+        """fault-injection TEST build only (lib=load_fault_library()): the nth submit from now fails in its last stream group"""
+        return self.L.tlb_debug_tick_fail_next(self.h, nth)
+
     def run(self):
         rc = self.L.tlb_tick_run(self.h)
         if rc:
@@ -388,8 +426,8 @@ class Tick:
 class Batch:
     """N independent DAB MP2 encoders on one MI355X (one wavefront per stream)."""
 
-    def __init__(self, configs, device=0):
-        self.L = load_library()
+    def __init__(self, configs, device=0, lib=None):
+        self.L = lib or load_library()
         configs = list(configs)
         if not configs:
             raise ToolameError(18, "empty batch")
@@ -407,6 +445,10 @@ class Batch:
         self.units_per_frame = [self.L.tlb_egress_units_per_frame(self.h, s) for s in range(self.nstreams)]
         self.max_upf = self.L.tlb_egress_max_units_per_frame(self.h)
         self._first = True
+
+    def fail_next(self, nth=1):
+        """fault-injection TEST build only (lib=load_fault_library()): the nth launch from now fails half way (csrc/tlb_debug.h)"""
+        return self.L.tlb_debug_fail_next(self.h, nth)
 
     # -- host-buffer path (tests, legacy-style callers) ------------------------------------
     def encode(self, pcm, xpad=None, xpad_len=None, want_taps=False):
@@ -603,6 +645,13 @@ class _CNodeConfig(C.Structure):
     _fields_ = [("plane", C.c_int), ("tick", _CTickConfig)]
 
 
+class _CNodeShardInfo(C.Structure):
+    _fields_ = [("shard", C.c_int), ("device", C.c_int), ("first", C.c_int), ("nstreams", C.c_int), ("state", C.c_int), ("last_err", C.c_int),
+                ("failures", C.c_long), ("restarts", C.c_long), ("lost_steps", C.c_long), ("what", C.c_char * 192),
+                ("device_name", C.c_char * 64), ("pci", C.c_char * 24), ("uuid", C.c_char * 36), ("num_cu", C.c_int), ("num_xcd", C.c_int),
+                ("hbm_gb", C.c_double)]
+
+
 class _CNodeCounter(C.Structure):
     _fields_ = [("shard", C.c_int), ("device", C.c_int), ("first", C.c_int), ("nstreams", C.c_int), ("steps", C.c_long), ("frames", C.c_long),
                 ("busy_ns", C.c_double), ("device_ms", C.c_double), ("wall_ns", C.c_double)]
@@ -645,8 +694,8 @@ class Node:
     plane "batch": device-resident buffers per shard, encode(pcm) with pcm int16 [nframes][nstreams][2][1152] split by the wrapper."""
 
     def __init__(self, configs, devices=(0,), plane="tick", egress="frames", ngroups=0, with_xpad=False, version=b"", now_s=1700000000,
-                 delay_ms=0, tist=False, tai_utc_offset=37, fec=0, chunk_len=207, transport=False, addr_source=0, dest_port=0):
-        self.L = load_library()
+                 delay_ms=0, tist=False, tai_utc_offset=37, fec=0, chunk_len=207, transport=False, addr_source=0, dest_port=0, lib=None):
+        self.L = lib or load_library()
         configs = list(configs)
         self.configs = configs
         self.nstreams = len(configs)
@@ -686,6 +735,37 @@ class Node:
         if rc:
             raise ToolameError(rc, what)
 
+    # ---- health: fault isolation per shard (include/toolame_batch.h, FAULT ISOLATION) ----
+    def describe(self):
+        """one line per shard: device name, CUs, XCDs, memory, PCI address, UUID, stream block"""
+        return self.L.tlb_node_describe(self.h).decode()
+
+    def shard_status(self, g):
+        info = _CNodeShardInfo()
+        st = self.L.tlb_node_shard_status(self.h, g, C.byref(info))
+        if st < 0:
+            raise ToolameError(-st, "tlb_node_shard_status")
+        d = {k: getattr(info, k) for k, _ in info._fields_}
+        for k in ("what", "device_name", "pci", "uuid"):
+            d[k] = d[k].decode(errors="replace")
+        d["ok"] = st == 0
+        return d
+
+    def shard_ok(self, g):
+        return self.L.tlb_node_shard_status(self.h, g, None) == 0
+
+    def shard_restart(self, g, now_s=-1):
+        self._rc(self.L.tlb_node_shard_restart(self.h, g, int(now_s)), "tlb_node_shard_restart")
+        if self.plane == "tick":
+            f, n = self.blocks[g]
+            for s in range(f, f + n):
+                self.units[s] = self.L.tlb_node_units(self.h, s)
+        # (the wrapper's device buffers belong to the device, not to the shard's object: they stay)
+
+    def fail_next(self, g, nth=1):
+        """fault-injection TEST build only (lib=load_fault_library()): the nth launch / tick of shard g from now fails"""
+        return self.L.tlb_debug_node_fail_next(self.h, g, nth)
+
     def counters(self):
         per = (_CNodeCounter * self.nshards)()
         tot = _CNodeCounter()
@@ -699,14 +779,18 @@ class Node:
 
     def set_pcm(self, inter):
         """inter int16 [nstreams][2304]: every stream's interleaved frame into the current input set (block copies per shard)"""
-        for f, n in self.blocks:
+        for g, (f, n) in enumerate(self.blocks):
             p = self.L.tlb_node_pcm(self.h, f)
             if not p:
+                if not self.shard_ok(g):
+                    continue                # a broken shard takes no input; its streams are off air until it is restarted
                 raise ToolameError(18, "tlb_node_pcm: no input set is free (two ticks in flight)")
             np.ctypeslib.as_array((C.c_int16 * (n * 2 * SAMPLES)).from_address(p)).reshape(n, 2 * SAMPLES)[:] = inter[f:f + n]
 
     def set_xpad(self, s, rec, length):
         p, q = self.L.tlb_node_xpad(self.h, s), self.L.tlb_node_xpad_len(self.h, s)
+        if not p or not q:
+            return
         np.ctypeslib.as_array((C.c_uint8 * MAX_XPAD).from_address(p))[:] = rec
         C.c_int32.from_address(q).value = int(length)
 
@@ -814,19 +898,25 @@ class Node:
         ptrs, nf = self._pcm_ptrs[slot]
         outs, lens = (C.c_void_p * self.nshards)(), (C.c_void_p * self.nshards)()
         for g, (f, n) in enumerate(self.blocks):
+            if not self.shard_ok(g):
+                continue                    # (the node skips a broken shard: its array elements are not read)
             outs[g] = self._buf(g, "out", nf * n * self.out_stride(g))
             lens[g] = self._buf(g, "len", nf * n * 4)
+        self._out_ptrs, self._len_ptrs, self._nf, self._have_len = outs, lens, nf, bool(want_len)
         self._rc(self.L.tlb_node_encode_device(self.h, ptrs, nf, None, None, outs, lens if want_len else None), "tlb_node_encode_device")
-        self._out_ptrs, self._len_ptrs, self._nf = outs, lens, nf
 
     def sync(self):
         self._rc(self.L.tlb_node_sync(self.h), "tlb_node_sync")
 
     def download(self, nframes=None):
         """-> per stream: the bytes of output slots 0..nframes-1 concatenated (slot lengths from the _len variant)"""
+        if not getattr(self, "_have_len", True):
+            raise ToolameError(18, "Node.download(): the last encode_resident() was queued with want_len=False -- no slot lengths to cut the frames by")
         nf = nframes or self._nf
         out = [b""] * self.nstreams
         for g, (f, n) in enumerate(self.blocks):
+            if not self.shard_ok(g):
+                continue                    # nothing of a broken shard is read (its buffers hold a half-finished step)
             st = self.out_stride(g)
             fr = np.empty((nf, n, st), dtype=np.uint8)
             ln = np.empty((nf, n), dtype=np.int32)
@@ -847,12 +937,16 @@ class Node:
         """the pending (last) frame of every stream"""
         outs, lens = (C.c_void_p * self.nshards)(), (C.c_void_p * self.nshards)()
         for g, (f, n) in enumerate(self.blocks):
+            if not self.shard_ok(g):
+                continue
             outs[g] = self._buf(g, "fout", n * self.out_stride(g))
             lens[g] = self._buf(g, "flen", n * 4)
         self._rc(self.L.tlb_node_flush_device(self.h, outs, lens), "tlb_node_flush_device")
         self.sync()
         out = [b""] * self.nstreams
         for g, (f, n) in enumerate(self.blocks):
+            if not self.shard_ok(g):
+                continue
             st = self.out_stride(g)
             fr = np.empty((n, st), dtype=np.uint8)
             ln = np.empty((n,), dtype=np.int32)
