@@ -134,11 +134,14 @@ def workload_label(streams, psy, mode, frames_per_step, world, mixed=False):
         return (f"{streams} streams/GPU, even 32 kHz mono 64 kbps / odd 48 kHz stereo 192 kbps interleaved in one batch, psy {psy}, full encode "
                 f"(BASELINE configs[4]{total}), {frames_per_step} frames/stream/step"), 4
     k = None
-    if (streams, psy) == CONFIGS[1] and world == 1:
-        k = 1
-    elif (streams, psy) == CONFIGS[2]:
-        k = 2 if world == 1 else 3
-    tag = f"BASELINE configs[{k}]" if k is not None else "not a BASELINE config"
+    if mode == "s":                                  # the BASELINE configurations are plain two-channel stereo: mono pairs, joint and dual channel are variants
+        if (streams, psy) == CONFIGS[1] and world == 1:
+            k = 1
+        elif (streams, psy) == CONFIGS[2]:
+            k = 2 if world == 1 else 3
+    near = {"m": "a mono variant of it", "j": "its joint-stereo variant", "d": "its dual-channel variant"}.get(mode)
+    is_shape = (streams, psy) in (CONFIGS[1], CONFIGS[2])
+    tag = f"BASELINE configs[{k}]" if k is not None else ("not a BASELINE config" + (f": {near}" if near and is_shape else ""))
     total = f", {streams * world} streams in total" if world > 1 else ""
     chans = "mono, two streams per wave" if mode == "m" else f"stereo (mode '{mode}')"
     return (f"{streams} streams/GPU x 48 kHz {chans} x 128 kbps, psy {psy}, full encode ({tag}{total}), "
@@ -247,6 +250,38 @@ def committed_counters(S, F, psy, mode, mixed=False):
     return traffic, source, valu
 
 
+def device_identity(torch, index):
+    """what this rank's GPU IS: UUID, PCI address, name -- gathered over the collective into `devices_observed`"""
+    d = {"index": int(index)}
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        d["name"] = str(pr.name)
+        u = getattr(pr, "uuid", None)
+        if u is not None:
+            d["uuid"] = str(u)
+        dom, bus, dev = (getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        if bus is not None:
+            d["pci_bus_id"] = "%04x:%02x:%02x.0" % (int(dom or 0), int(bus), int(dev or 0))
+        d["compute_units"] = int(pr.multi_processor_count)
+        d["hbm_gb"] = round(pr.total_memory / 1e9, 1)
+    except Exception as ex:  # noqa: BLE001
+        d["error"] = str(ex)
+    return d
+
+
+def observed_devices(shard, dist, ident, cdev, setup_s):
+    """-> the per-rank identity records, gathered with ONE all_gather over the run's backend, and how many DISTINCT GPUs they name"""
+    me = json.dumps(dict(ident, setup_s=round(setup_s, 1), host=socket.gethostname(), pid=os.getpid()), separators=(",", ":")).encode()
+    recs = []
+    for r, b in enumerate(shard.gather_bytes(dist, me, width=320, device=cdev)):
+        try:
+            recs.append(dict(json.loads(b.decode()), rank=r))
+        except Exception:  # noqa: BLE001
+            recs.append({"rank": r, "error": "unreadable identity record"})
+    keys = {(x.get("host"), x.get("uuid") or x.get("pci_bus_id") or ("index", x.get("index"))) for x in recs}
+    return recs, len(keys)
+
+
 class SclkSampler:
     """The GPU's shader clock WHILE the timed region runs: a host thread reads the driver's DPM tables (sysfs pp_dpm_sclk: the line marked
     '*' is the current level, what `rocm-smi --showclocks` prints) every 20 ms.  A host may expose several cards in sysfs while the process
@@ -254,11 +289,21 @@ class SclkSampler:
     load; idle cards sit near 150 MHz -- is reported.  result(): {"median_mhz", "min_mhz", "max_mhz", "samples", "source"} or None where
     no table can be read or no card left its idle clocks (a region too short for the table to follow).  (The clock the committed SQ
     counter profile derives -- GRBM_GUI_ACTIVE / kernel time under the profiler -- comes out near 2.17 GHz; rocm-smi and this sampler see
-    the kernels run at 2.39-2.41 GHz of the 2.4 GHz peak, 1.1 kW of 1.4 kW: tools/clock_probe.sh, profiles/clock_probe_r05.txt.)"""
+    the kernels run at 2.39-2.41 GHz of the 2.4 GHz peak, 1.1 kW of 1.4 kW: tools/clock_probe.sh, profiles/clock_probe_r05.txt.)
+    Round 6: the sampler no longer runs INSIDE the timed region (its thread competed for the GIL with the launching thread and
+    queried the SMU while the clock was being measured): GpuRun.timed() repeats a few launches after the region, untimed, and samples there;
+    and it reads the card whose PCI address is this rank's HIP device, so that another job's card on a shared host is never reported."""
 
-    def __init__(self, device_index=0):
+    def __init__(self, pci_bus_id=None):
+        """pci_bus_id ("0000:05:00.0", any case): only THAT card's table is read; None / no match: every card, the fastest one reported"""
         import glob
         self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.matched = False
+        if pci_bus_id:
+            want = str(pci_bus_id).lower()
+            hit = [p_ for p_ in self.paths if os.path.basename(os.path.realpath(os.path.dirname(p_))).lower() == want]
+            if hit:
+                self.paths, self.matched = hit[:1], True
         self.vals = {p_: [] for p_ in self.paths}
         self.stop, self.th = False, None
 
@@ -281,7 +326,7 @@ class SclkSampler:
                         v = self._read(p_)
                         if v:
                             self.vals[p_].append(v)
-                    time.sleep(0.02)
+                    time.sleep(0.005)
             self.th = threading.Thread(target=loop, daemon=True)
             self.th.start()
         return self
@@ -296,7 +341,9 @@ class SclkSampler:
         for p_, v in self.vals.items():
             if v:
                 v = sorted(v)
-                r = {"median_mhz": v[len(v) // 2], "min_mhz": v[0], "max_mhz": v[-1], "samples": len(v), "source": p_}
+                r = {"median_mhz": v[len(v) // 2], "min_mhz": v[0], "max_mhz": v[-1], "samples": len(v), "source": p_,
+                     "card_chosen_by": "the PCI address of this rank's HIP device" if self.matched else "the fastest card over the probe (no PCI match)",
+                     "when": "a separate untimed probe of the same launches right after the timed region (ADVICE r5: nothing but the launches runs inside it)"}
                 if best is None or r["median_mhz"] > best["median_mhz"]:
                     best = r
         return best if best and best["median_mhz"] >= 1000.0 else None
@@ -327,6 +374,7 @@ class GpuRun:
         self.F, self.S, self.torch, self.np = F, S, torch, np
         self.cdev = "cuda"
         self.dev, self.sclk_mhz = local_rank, None
+        self.pci = device_identity(torch, local_rank).get("pci_bus_id")
 
     def step(self, i):
         assert (i & 1) == (self.launches & 1)          # the two PCM buffers alternate without a gap: each stream sees one looped signal
@@ -346,11 +394,16 @@ class GpuRun:
                 self.step(warmup + i)
                 evs[i][1].record(self.stream)
 
-        with SclkSampler(self.dev) as sclk:
-            elapsed, own = shard.timed_region_detail(dist, run, device_sync=torch.cuda.synchronize, device=self.cdev)
-        self.sclk_mhz = sclk.result()
+        elapsed, own = shard.timed_region_detail(dist, run, device_sync=torch.cuda.synchronize, device=self.cdev)
         kernel_ms = float(self.np.mean([a.elapsed_time(b) for a, b in evs]))
         self.stage_ms = self.batch.last_stage_ms()      # (psy-2 kernel, encode + finish kernels) of the last launch: batches of models 2/4 only
+        # the shader clock under this load: an untimed probe of the same launches, AFTER the region (an even number: the buffers keep alternating)
+        probe = max(2, min(2 * (steps // 8), int(0.06 / max(own / max(steps, 1), 1e-6)) // 2 * 2))
+        with SclkSampler(self.pci) as sclk:
+            for i in range(probe):
+                self.step(warmup + steps + i)
+            torch.cuda.synchronize()
+        self.sclk_mhz = sclk.result()
         return elapsed, own, kernel_ms
 
     def check_flag(self):
@@ -385,7 +438,8 @@ class GpuRun:
                     continue
                 assert bytes(out[f, k, :fb]) == ref[g * fb:(g + 1) * fb], f"bench output differs from the oracle: stream {k}, slot {f}"
         return {"checked": True, "streams": self.check_streams, "frames_compared_per_stream": self.F, "frames_encoded_by_the_oracle_per_stream": total,
-                "what": "the last timed launch's output buffer, byte for byte against oracle/mp2_oracle.c on the same looped PCM"}
+                "what": "the last launch's output buffer (the timed launches and the short clock probe behind them are one uninterrupted sequence of the same "
+                        "launch), byte for byte against oracle/mp2_oracle.c on the same looped PCM"}
 
     def close(self):
         self.batch.close()
@@ -579,6 +633,8 @@ def main():
     cdev = "cuda" if args.backend == "nccl" else "cpu"          # where the collectives' few scalars live
     assert world_env == world
     observed_world = dist.get_world_size() if dist is not None else 1
+    # which GPU every rank REALLY has, gathered by the run's own collective (one all_gather): N ranks on N distinct devices is in the line, not inferred
+    devices_seen, n_distinct = observed_devices(shard, dist, device_identity(torch, dev_index), cdev, time.time() - t0)
     num_simds = 4 * torch.cuda.get_device_properties(dev_index).multi_processor_count
 
     def sharded_run(psy_k):
@@ -655,12 +711,16 @@ def main():
                                   "(selects, compares, moves, integer and address work, division and logarithm expansions: DESIGN.md section 4)")
         return rf
 
-    def roofline_mixed(run_d, S_, F_, psy_k):
-        global_mixed = True
-        k_ms = run_d["kernel_ms"]
-        traffic, traffic_source, _ = committed_counters(S_, F_, psy_k, "s", global_mixed)
-        hbm_ach = run_d["algo"] / (k_ms * 1e-3) / 1e9
-        return {"hbm_frac": round(hbm_ach / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": run_d["algo"], "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": round(k_ms, 4)}
+    def leg_roofline(S_, F_, psy_k, mode_k, k_ms, algo_b, mixed_k=False):
+        """the headline's two SURVEY 8(d) fractions for a secondary leg: fp64 `frac` and `hbm_frac` from THIS run's kernel time, the
+        committed HBM traffic of the same workload where a counter file exists (every leg, not only the headline)"""
+        tr, trs, _ = committed_counters(S_, F_, psy_k, mode_k, mixed_k)
+        fps_k = S_ * F_ / (k_ms * 1e-3)
+        ff = FLOPS_PER_CHANNEL_FRAME[psy_k] * (1.5 if mixed_k else (1 if mode_k == "m" else 2))
+        return {"bound": "valu_fp64", "frac": round(ff * fps_k / 1e12 / FP64_PEAK_TFLOPS, 4), "achieved": round(ff * fps_k / 1e12, 3), "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "flops_per_frame": ff, "hbm_frac": round(algo_b / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                "algorithmic_bytes_per_launch": algo_b, "traffic": tr, "traffic_source": trs,
+                "traffic_over_algorithmic": round(tr / algo_b, 2) if tr else None, "kernel_ms": round(k_ms, 4)}
 
     res = None
     if rank == 0:
@@ -688,6 +748,7 @@ def main():
                        "frames_per_stream_timed": F * args.steps, "frames_per_stream_warmup": F * args.warmup,
                        "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
             "realtime_streams": round(head["audio_s"] * world * args.steps / elapsed, 1),
+            "devices_observed": devices_seen, "distinct_devices_observed": n_distinct,
             "world_size_observed": observed_world, "collective_backend": ("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo (smoke test: ranks may share GPUs)") if had_group else None,
             "per_gpu_frames_per_s": [round(p[0] / p[1], 1) for p in per_rank],
             "roofline": rf,
@@ -726,11 +787,8 @@ def main():
                 if name == "encoder_only_psy0":
                     wl2 = (f"{s2} streams/GPU x 48 kHz stereo (mode '{m2}') x 128 kbps, psy 0 = the encoder without a psychoacoustic model: filterbank, "
                            f"scalefactors, bit allocation, quantiser, packing (what BASELINE configs[1] calls 'filterbank+quantise kernels only'), {f2} frames/stream/step")
-                tr2, trs2, _ = committed_counters(s2, f2, p2, m2)
                 also[name] = {"workload": wl2, "value": round(s2 * f2 * n2 / e2, 1), "unit": "frames/s",
-                              "steps": n2, "kernel_ms": round(k2, 4),
-                              "roofline_frac_hbm": round(ab2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                              "algorithmic_bytes_per_launch": ab2, "traffic": tr2, "traffic_source": trs2, "output_check": chk2}
+                              "steps": n2, "kernel_ms": round(k2, 4), "roofline": leg_roofline(s2, f2, p2, m2, k2, ab2), "output_check": chk2}
             except Exception as ex:  # noqa: BLE001
                 also[name] = {"value": None, "error": str(ex)}
         try:     # BASELINE configs[0] on the GPU: ONE stream -- its frames are independent units for the kernels, so one stream fills the chip
@@ -738,8 +796,9 @@ def main():
             r1 = GpuRun(M, torch, np, gen_pcm, [0], n1 // 2, args.mode, psy, local_rank)
             e1, _, k1 = r1.timed(None, shard, 2, 6)
             chk1 = r1.check()
+            ab1 = r1.algo_bytes_per_launch
             r1.close()
-            also["one_stream"] = {"workload": f"1 stream x {n1 // 2} frames per launch (48 kHz stereo 128 kbps, psy {psy}, mode '{args.mode}'; BASELINE configs[0] "
+            also["one_stream"] = {"roofline": leg_roofline(1, n1 // 2, psy, args.mode, k1, ab1), "workload": f"1 stream x {n1 // 2} frames per launch (48 kHz stereo 128 kbps, psy {psy}, mode '{args.mode}'; BASELINE configs[0] "
                                               "is this stream on the CPU reference)", "value": round((n1 // 2) * 6 / e1, 1), "unit": "frames/s",
                                   "x_realtime": round((n1 // 2) * 6 / e1 / (FS / 1152.0), 1), "kernel_ms": round(k1, 4), "output_check": chk1}
         except Exception as ex:  # noqa: BLE001
@@ -749,8 +808,9 @@ def main():
             rt = GpuRun(M, torch, np, gen_pcm, list(range(nt)), 1, args.mode, 3, local_rank, distinct=4096)
             et, _, kt = rt.timed(None, shard, 2, 6)
             chkt = rt.check()
+            abt = rt.algo_bytes_per_launch
             rt.close()
-            also["tick_131072"] = {"workload": f"{nt} streams x 1 frame per launch on one GPU (48 kHz stereo 128 kbps, psy 3, mode '{args.mode}'): "
+            also["tick_131072"] = {"roofline": leg_roofline(nt, 1, 3, args.mode, kt, abt), "workload": f"{nt} streams x 1 frame per launch on one GPU (48 kHz stereo 128 kbps, psy 3, mode '{args.mode}'): "
                                                "one real-time tick of everything BASELINE configs[3] spreads over 8 GPUs; 4096 distinct signals, repeated",
                                    "value": round(nt * 6 / et, 1), "unit": "frames/s", "kernel_ms": round(kt, 4),
                                    "share_of_the_24_ms_tick": round(kt / 24.0, 4), "output_check": chkt}
@@ -765,10 +825,9 @@ def main():
                 s4, f4 = CONFIGS[4][0], max(1, 131072 // CONFIGS[4][0])
                 r4 = GpuRun(M, torch, np, gen_pcm, range(s4), f4, "s", p4, local_rank, distinct=256, mixed=True)
                 e4, _, k4 = r4.timed(None, shard, 2, 20)
-                d4 = dict(kernel_ms=k4, last_ms=r4.batch.last_kernel_ms(), algo=r4.algo_bytes_per_launch)
                 also[f"configs4_share_psy{p4}"] = {"workload": workload_label(s4, p4, "s", f4, 1, True)[0] + " (one GPU's share)", "value": round(s4 * f4 * 20 / e4, 1), "unit": "frames/s",
                                                    "ms_per_launch": round(e4 / 20 * 1e3, 3), "streams_at_realtime": round(r4.audio_s_per_launch * 20 / e4),
-                                                   "kernels_ms": r4.stage_ms, "roofline": roofline_mixed(d4, s4, f4, p4), "output_check": r4.check()}
+                                                   "kernels_ms": r4.stage_ms, "roofline": leg_roofline(s4, f4, p4, "s", k4, r4.algo_bytes_per_launch, True), "output_check": r4.check()}
                 r4.close()
             except Exception as ex:  # noqa: BLE001
                 also[f"configs4_share_psy{p4}"] = {"value": None, "error": str(ex)}
@@ -778,8 +837,9 @@ def main():
             e1, _, k1 = r1.timed(None, shard, 2, 6)
             st1 = r1.stage_ms
             chk1 = r1.check()
+            ab1 = r1.algo_bytes_per_launch
             r1.close()
-            also["one_stream_psy2"] = {"workload": f"1 stream x {n1 // 2} frames per launch (48 kHz stereo 128 kbps, psy 2, mode '{args.mode}')", "value": round((n1 // 2) * 6 / e1, 1),
+            also["one_stream_psy2"] = {"roofline": leg_roofline(1, n1 // 2, 2, args.mode, k1, ab1), "workload": f"1 stream x {n1 // 2} frames per launch (48 kHz stereo 128 kbps, psy 2, mode '{args.mode}')", "value": round((n1 // 2) * 6 / e1, 1),
                                        "unit": "frames/s", "x_realtime": round((n1 // 2) * 6 / e1 / (FS / 1152.0), 1), "kernel_ms": round(k1, 4), "kernels_ms": st1, "output_check": chk1}
         except Exception as ex:  # noqa: BLE001
             also["one_stream_psy2"] = {"value": None, "error": str(ex)}
@@ -787,10 +847,9 @@ def main():
             st_, ft_ = CONFIGS[2][0], 1
             rt2 = GpuRun(M, torch, np, gen_pcm, range(st_), ft_, args.mode, 2, local_rank, distinct=1024)
             et2, _, kt2 = rt2.timed(None, shard, 4, 40)
-            d2 = dict(kernel_ms=kt2, last_ms=rt2.batch.last_kernel_ms(), algo=rt2.algo_bytes_per_launch)
             tr2, trs2, _ = committed_counters(st_, ft_, 2, args.mode)
             state_b = st_ * 2 * 2 * 2 * 513 * 8 * 2          # streams x channels x (r, phi) x two passes x 513 lines x 8 B, read + written
-            also["psy2_tick_shape"] = {"workload": f"{st_} streams x 1 frame per launch (48 kHz stereo 128 kbps, psy 2, mode '{args.mode}'): one GPU's share of a real-time tick with the model "
+            also["psy2_tick_shape"] = {"roofline": leg_roofline(st_, ft_, 2, args.mode, kt2, rt2.algo_bytes_per_launch), "workload": f"{st_} streams x 1 frame per launch (48 kHz stereo 128 kbps, psy 2, mode '{args.mode}'): one GPU's share of a real-time tick with the model "
                                                    "that carries prediction state from frame to frame (psycho_2.c:300-306)",
                                        "value": round(st_ * ft_ * 40 / et2, 1), "unit": "frames/s", "kernel_ms": round(kt2, 4), "kernels_ms": rt2.stage_ms,
                                        "share_of_the_24_ms_tick": round(kt2 / 24.0, 4), "algorithmic_bytes_per_launch": rt2.algo_bytes_per_launch,
@@ -836,6 +895,8 @@ def dry_run(args, shard, np, gen_pcm, world, S, psy, F):
     import emulib as E
     rank, local_rank, world_env, dist = shard.init_from_env("gloo", force=args.force_group)
     assert world_env == world
+    t0 = time.time()
+    devices_seen, n_distinct = observed_devices(shard, dist, {"index": rank, "name": "CPU emulation of the kernel (no GPU)"}, "cpu", 0.0)
     ids = list(shard.weak_stream_ids(rank, S))
     pcm = np.stack([gen_pcm(i, 0, 0, 2 * F) for i in ids], axis=1)
     b = E.EmuBatch([dict(mode=args.mode, psy=psy)] * S)
@@ -856,6 +917,7 @@ def dry_run(args, shard, np, gen_pcm, world, S, psy, F):
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "config": {"workload": label, "streams_per_gpu": S, "frames_per_step": F},
             "world_size_observed": dist.get_world_size() if dist is not None else 1, "collective_backend": "gloo" if dist is not None else None,
+            "devices_observed": devices_seen, "distinct_devices_observed": n_distinct,
             "per_gpu_frames_per_s": [round(p[0] / p[1], 1) for p in per_rank], "roofline": None, "cpu_baseline": None}), flush=True)
     b.close()
     if dist is not None:

@@ -45,7 +45,10 @@ static void fill(void *vctx, int g, int first, int n)
     Ctx &c = *(Ctx *)vctx;
     for (int s = first; s < first + n; s++) {
         int16_t *dst = tlb_node_pcm(c.nd, s);
-        if (!dst) die("no input set free", s);
+        if (!dst) {                                              // a BROKEN shard takes no input (its block is off air until it is restarted); anything else is a bug
+            if (tlb_node_shard_status(c.nd, g, nullptr) == TLB_SHARD_BROKEN) return;
+            die("no input set free", s);
+        }
         const size_t f = ((size_t)s + (size_t)c.tick) % c.nframes_in;
         std::memcpy(dst, c.pcm->data() + f * 2304, 2304 * sizeof(int16_t));
     }
@@ -148,22 +151,42 @@ int main(int argc, char **argv)
         }
     };
 
+    std::fputs(tlb_node_describe(nd), stderr);                            // which device every shard runs on (name, CUs, XCDs, PCI address, UUID)
+    // A GPU that fails takes ITS block off air, not the node (include/toolame_batch.h, FAULT ISOLATION): the call in which a shard
+    // breaks returns its code, every other shard has completed the call.  The caller's part: find out which shard, log why, restart it
+    // when no tick is in flight -- the reference's "restart the failed input, nothing else stops" (src/odr-audioenc.cpp:875-902) one level up.
+    long restarts = 0;
+    auto shard_failed = [&](const char *where, int rc) {
+        int alive = 0;
+        for (int g = 0; g < G; g++) {
+            tlb_node_shard_info info;
+            if (tlb_node_shard_status(nd, g, &info) == TLB_SHARD_BROKEN) std::fprintf(stderr, "nodetick: %s: shard %d on %s is down (%s)\n", where, g, info.device_name, info.what);
+            else alive++;
+        }
+        if (!alive) die(where, rc);                                       // nobody left: nothing to carry on with
+    };
     const auto t0 = std::chrono::steady_clock::now();
     // fill 0, submit 0; then per tick: fill t+1, submit t+1, wait t, ship t
     ctx.tick = 0;
     if (int rc = tlb_node_parallel(nd, fill, &ctx)) die("fill", rc);
-    if (int rc = tlb_node_submit(nd)) die("tlb_node_submit", rc);
+    if (int rc = tlb_node_submit(nd)) shard_failed("tlb_node_submit", rc);
+    bool in_flight2 = false;
     for (long t = 0; t < ticks; t++) {
+        in_flight2 = false;
         if (t + 1 < ticks) {
             ctx.tick = t + 1;
             if (int rc = tlb_node_parallel(nd, fill, &ctx)) die("fill", rc);
-            if (int rc = tlb_node_submit(nd)) die("tlb_node_submit", rc);
+            if (int rc = tlb_node_submit(nd)) shard_failed("tlb_node_submit", rc);
+            in_flight2 = true;
         }
-        if (int rc = tlb_node_wait(nd)) die("tlb_node_wait", rc);
+        if (int rc = tlb_node_wait(nd)) shard_failed("tlb_node_wait", rc);
         if (int rc = tlb_node_parallel(nd, ship, &ctx)) die("ship", rc);
         tap();
+        if (!in_flight2)                                                  // no tick in flight: the moment a broken shard may come back
+            for (int g = 0; g < G; g++)
+                if (tlb_node_shard_status(nd, g, nullptr) == TLB_SHARD_BROKEN && tlb_node_shard_restart(nd, g, -1) == TLB_OK) restarts++;
     }
-    if (int rc = tlb_node_finish(nd)) die("tlb_node_finish", rc);        // toolame_finish for every service: the pending last frame
+    if (int rc = tlb_node_finish(nd)) shard_failed("tlb_node_finish", rc); // toolame_finish for every service: the pending last frame
     if (int rc = tlb_node_parallel(nd, ship, &ctx)) die("ship", rc);
     tap();
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -182,7 +205,7 @@ int main(int argc, char **argv)
     // one line for scripts: frames, packets, bytes, a hash of everything shipped (independent of G only per shard -- so print per-stream-order-free totals)
     std::printf("{\"streams\": %d, \"shards\": %d, \"ticks\": %d, \"frames\": %ld, \"packets\": %ld, \"bytes\": %ld, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"realtime_x\": %.2f}\n",
                 nstreams, G, ticks, tot.frames, npk, nby, sec, sec > 0 ? tot.frames / sec : 0.0, sec > 0 ? ticks * 0.024 / sec : 0.0);
-    (void)all;
+    (void)all; (void)restarts;
     if (fo) std::fclose(fo);
     tlb_node_destroy(nd);
     return 0;

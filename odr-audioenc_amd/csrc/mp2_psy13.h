@@ -614,11 +614,13 @@ TL_FN void tl_psy1_thresholds(TlPsyLds &w, const double *TL_RESTRICT db, const T
 }
 
 // band levels, decimation (psycho_1.c:390-470) and everything after; the regular (not dead-head) case
-TL_FN void tl_psy1_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, PARGA(double, rec, 4), long long *sp)
+// (stamp4: the two-channel path stamps the chain stage itself -- channel 1's slot 4 = both chains begin, channel 0's slot 4 = both chains
+// end, tl_psy1_stereo -- so that a parked channel's waiting time is not booked as its "noise bands"; tools/stage_profile.py)
+TL_FN void tl_psy1_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, const TlPsy1Ch &st, PARGA(double, rec, 4), long long *sp, bool stamp4 = true)
 {
     const int nbands = C->p1_ncb - 1, nlist = st.nlist;
     int ntone = 0, nnoise = 0;
-    TL_STAMP(sp, 4);
+    if (stamp4) TL_STAMP(sp, 4);
     if (TL_EXP_LEVEL >= 2) { tl_psy1_thresholds(w, db, C, ch, 0, 0, rec, sp); return; }
     // The reference now writes every band's sum to power[centre] in band order -- a later band overwrites an earlier one
     // that chose the same line, and (through the centre+1 rule above) a centre may even land on a tone's line
@@ -906,6 +908,7 @@ TL_FN void tl_psy1_stereo(TlPsyLds &w, const TlTables *TL_RESTRICT T, const doub
         TL_LANES_END
         TL_STAMP(sp1, 4);
         if (TL_EXP_LEVEL < 3) { TL_PRIO(1); tl_psy1_chain2(w, db, nbands, r0, r1, bsum); TL_PRIO(0); }
+        TL_STAMP(sp0, 4);                                               // both channels' chains: sp1[4] -> sp0[4]
         // ---- back(1): its sums move from lanes 32+b to lanes b ----
         PV(double, bsum1);
 #ifdef TL_EMULATE
@@ -914,7 +917,7 @@ TL_FN void tl_psy1_stereo(TlPsyLds &w, const TlTables *TL_RESTRICT T, const doub
         bsum1 = __shfl(bsum, (int)((threadIdx.x + 32u) & 63u), 64);
 #endif
         if (TL_EXP_LEVEL < 3) tl_psy1_centres(w, nbands, bsum1, wt1, blo, bhi);
-        tl_psy1_back(w, db, C, 1, s1, rec, sp1);
+        tl_psy1_back(w, db, C, 1, s1, rec, sp1, false);
     }
     // ---- channel 0 returns to the LDS arrays ----
     TL_LANES_BEGIN
@@ -927,7 +930,7 @@ TL_FN void tl_psy1_stereo(TlPsyLds &w, const TlTables *TL_RESTRICT T, const doub
     for (int i = lane; i < s0.nconf; i += 64) { const int cc = w.conf_c[i]; if (!((cc >> 13) & 1)) w.ptype[cc & 511] = TL_T_TONE; }
     TL_LANES_END
     if (TL_EXP_LEVEL < 3) tl_psy1_centres(w, nbands, bsum, wt0, blo, bhi);
-    tl_psy1_back(w, db, C, 0, s0, rec, sp0);
+    tl_psy1_back(w, db, C, 0, s0, rec, sp0, s1.dead_head);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1232,7 +1235,7 @@ TL_FN void tl_psy3_chain2(TlPsyLds &w, const double *TL_RESTRICT db, int nb, PAR
 
 // band centres, decimation, thresholds, SMR (psycho_3.c:290-432) from the sums of lanes b < nb
 TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfig *TL_RESTRICT C, int ch, int nconf,
-                        PARG(double, bsum), PARG(double, es), PARG(double, cg), PARGA(double, rec, 4), long long *sp)
+                        PARG(double, bsum), PARG(double, es), PARG(double, cg), PARGA(double, rec, 4), long long *sp, bool stamp4 = true)
 {
     const double *bark = C->p3_bark, *ath = C->p3_ath;
     const int nb = C->p3_cbands;
@@ -1287,7 +1290,7 @@ TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
     }
     TL_LANES_END
     const int nnoise = __builtin_popcountll(mn);
-    TL_STAMP(sp, 4);
+    if (stamp4) TL_STAMP(sp, 4);                                      // (the two-channel path stamps its chain stage itself: tl_psy3_stereo)
     TL_STAMP(sp, 5);
     TL_PRIO2(TL_PS_THR);
     // ---- thresholds on the 136 subsampled lines (psycho_3.c:339-406) ----
@@ -1412,17 +1415,19 @@ TL_FN void tl_psy3_stereo(TlPsyLds &w, const TlTables *TL_RESTRICT T, const doub
 #endif
     for (int k = 0; k < 8; k++) w.u.fft[lane + 64 * k] = L(pvp)[k];   // channel 1's energies are summed: the buffer's lower half is free
     TL_LANES_END
+    TL_STAMP(sp1, 4);                                                   // both channels' chains: sp1[4] -> sp0[4] (tools/stage_profile.py)
     TL_PRIO(1); tl_psy3_chain2(w, db, nb, r0, r1, bsum); TL_PRIO(0);
+    TL_STAMP(sp0, 4);
 #ifdef TL_EMULATE
     for (int lane = 0; lane < 64; ++lane) bsum1[lane] = bsum[(lane + 32) & 63];
 #else
     bsum1 = __shfl(bsum, (int)((threadIdx.x + 32u) & 63u), 64);
 #endif
-    tl_psy3_back(w, db, C, 1, nconf1, bsum1, es1, cg1, rec, sp1);
+    tl_psy3_back(w, db, C, 1, nconf1, bsum1, es1, cg1, rec, sp1, false);
     TL_LANES_BEGIN
     const int hi = 64 + lane < TL_TONE_MAX ? 64 + lane : 0;
     w.conf_c[lane] = (int16_t)(L(pcc) & 0xffff); w.tone_x[lane] = L(ptx0);
     if (64 + lane < TL_TONE_MAX) { w.conf_c[hi] = (int16_t)((uint32_t)L(pcc) >> 16); w.tone_x[hi] = L(ptx1); }
     TL_LANES_END
-    tl_psy3_back(w, db, C, 0, nconf0, bsum, es0, cg0, rec, sp0);
+    tl_psy3_back(w, db, C, 0, nconf0, bsum, es0, cg0, rec, sp0, false);
 }

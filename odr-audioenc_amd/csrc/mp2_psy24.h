@@ -103,7 +103,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                 double phi = (TL_P2_SUB == 3 ? b - a : tlm_atan2_sl<false>(-a, b, tlm_atan_cij)) + 3.14159265358979 / 4;
                 e = TL_SELECT(low, 0.0005, e); phi = TL_SELECT(low, 0.0, phi);
                 e = TL_SELECT(first, a * a, e); phi = TL_SELECT(first, 0.0, phi);      // line 0: energy x_real[0]^2, phase 0
-                const double rn = TL_P2_SUB == 4 ? e + 1.0 : sqrt(e);
+                const double rn = TL_P2_SUB == 4 ? e + 1.0 : TL_P2_NS ? tlm_sqrt_ns(e) : sqrt(e);     // e >= 0.0005, or line 0's x^2 (zero included): far from the exponent limits
                 double spp5 = 0, cpp5 = 0;
                 if (!SEED && TL_P2_LEVEL < 5) {
                     const double r_prime = 2.0 * L(r1)[it] - L(r2)[it];
@@ -116,7 +116,9 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                     const double t1 = rn * cp - r_prime * cpp;
                     const double t2 = rn * sp - r_prime * spp;
                     const double t3 = rn + fabs(r_prime);
-                    cw[j] = TL_P2_SUB == 4 ? t1 * t1 + t2 * t2 + t3 : t3 != 0 ? sqrt(t1 * t1 + t2 * t2) / t3 : 0;
+                    // (t3 >= sqrt(0.0005) but for line 0; t1^2 + t2^2 is zero or above 1e-70: the unscaled square root and division, tl_libm.h)
+                    cw[j] = TL_P2_SUB == 4 ? t1 * t1 + t2 * t2 + t3 : !TL_P2_NS ? (t3 != 0 ? sqrt(t1 * t1 + t2 * t2) / t3 : 0) :
+                            TL_SELECT(t3 != 0, tlm_div_ns(tlm_sqrt_ns(t1 * t1 + t2 * t2), t3), 0.0);
                     x[j] = e;
                 }
                 L(r2)[it] = L(r1)[it]; L(r1)[it] = rn; L(p2)[it] = L(p1)[it]; L(p1)[it] = phi;
@@ -125,7 +127,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                     const double e5 = c5 * c5;
                     const bool neg5 = (tl_d2u(c5) >> 63) != 0;       // atan2(+0.0, x) = pi for x < 0 and x = -0, else +0
                     const double phi5 = neg5 ? tl_u2d(0x400921fb54442d18ull) : 0.0;
-                    const double rn5 = sqrt(e5);
+                    const double rn5 = TL_P2_NS ? tlm_sqrt_ns(e5) : sqrt(e5);
                     double c512 = 0;
                     if (!SEED) {
                         const double sp5 = neg5 ? tl_u2d(0x3ca1a62633145c07ull) : 0.0, cp5 = neg5 ? -1.0 : 1.0;   // glibc's sincos of that pi / of 0
@@ -133,7 +135,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                         const double t15 = rn5 * cp5 - r_prime5 * cpp5;
                         const double t25 = rn5 * sp5 - r_prime5 * spp5;
                         const double t35 = rn5 + fabs(r_prime5);
-                        c512 = t35 != 0 ? sqrt(t15 * t15 + t25 * t25) / t35 : 0;
+                        c512 = !TL_P2_NS ? (t35 != 0 ? sqrt(t15 * t15 + t25 * t25) / t35 : 0) : TL_SELECT(t35 != 0, tlm_div_ns(tlm_sqrt_ns(t15 * t15 + t25 * t25), t35), 0.0);
                     }
                     if (first) { l5[0] = rn5; l5[1] = r_o5; l5[2] = phi5; l5[3] = p_o5; if (!SEED) cw[512] = c512; }
                     L(e512) = e5;                                    // slot 512 of the transform buffer still holds a point step 7 reads
@@ -155,6 +157,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
         const double *energy = x;
         // the lane's first sixteen spreading coefficients (two batches of TL_P2_B), requested here, used after the partition sums
         PA(double, sva, TL_P2_B); PA(double, svb, TL_P2_B);
+        if (TL_P2_SPREAD_BAND) {
         TL_LANES_BEGIN
         {
             const double *sb = &P->s_band[0][0];
@@ -165,6 +168,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
             for (int q = 0; q < TL_P2_B; q++) { L(sva)[q] = sb[64 * q + lane]; L(svb)[q] = sb[64 * (TL_P2_B + q) + lane]; }
         }
         TL_LANES_END
+        }
         // grouped energy / weighted unpredictability per partition (psycho_2.c:146-155)
         TL_LANES_BEGIN
         {
@@ -205,6 +209,16 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
         TL_LANES_BEGIN
         {
             double e = 0, c = 0;
+#if !TL_P2_SPREAD_BAND
+#pragma unroll
+            for (int k0 = 0; k0 < 64; k0 += 16) {                   // (round 5's form, kept for A/B builds: all 64 coefficients, sixteen loads in flight per round trip)
+                double sv[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) sv[q] = P->s_t[k0 + q][lane];
+#pragma unroll
+                for (int q = 0; q < 16; q++) { e += sv[q] * ge[2 * (k0 + q)]; c += sv[q] * ge[2 * (k0 + q) + 1]; }
+            }
+#else
             const double *gel = ge + 2 * P->band_lo[lane];
             const int nbat = (P->band_w + TL_P2_B - 1) / TL_P2_B;         // (uniform)
             double svc[TL_P2_B];
@@ -220,6 +234,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
 #undef TL_P2_LOAD
 #undef TL_P2_SUM
             static_assert(TL_P2_BAND == 6 * TL_P2_B, "six batches");
+#endif
             double cb = e != 0 ? c / e : 0;
             if (cb < .05) cb = 0.05; else if (cb > .5) cb = 0.5;
             const double tb = -0.434294482 * tlm_log_pn(cb, tlm_log_tab) - 0.301029996;

@@ -324,6 +324,14 @@ static long tl_dbg_rounds = 0, tl_dbg_tones = 0, tl_dbg_deadheads = 0, tl_dbg_fr
 #ifndef TL_P2_SUB
 #define TL_P2_SUB 0
 #endif
+// A/B switches of the psy-2 kernel (tools/ab_libs.sh): the spreading sums over each partition's band (1) or over all 64 (0: round 5's form);
+// square roots and the division of the line loop without the compiler's exponent scaling (tl_libm.h, 1) or as sqrt() and `/` (0)
+#ifndef TL_P2_SPREAD_BAND
+#define TL_P2_SPREAD_BAND 1
+#endif
+#ifndef TL_P2_NS
+#define TL_P2_NS 1
+#endif
 #define TL_DBMIN (-200.0)
 #define TL_POWERNORM 90.3090
 #define TL_T_NOISE 10

@@ -47,7 +47,25 @@ TLM_HD double tlm_u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 TLM_HD uint64_t tl_d2u(double d) { return tlm_d2u(d); }       // the names the kernels use
 TLM_HD double tl_u2d(uint64_t u) { return tlm_u2d(u); }
 #define TLM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#ifndef TLM_ATAN_SCHED
+#define TLM_ATAN_SCHED 0
+#endif
 #define TLM_D(bits) tlm_u2d(bits##ull)
+// TLM_FMA_K(a, b, bits): fma(a, b, K) with a CONSTANT addend.  gfx950's three-operand fp64 instructions take no 64-bit literal, and the
+// compiler builds such a Horner step as two v_mov_b32 into the destination of a v_fmac_f64 -- three vector issue slots per coefficient
+// (it does so from a scalar register pair too: it prefers the two-address form).  Spelled out, the step is ONE v_fma_f64 whose addend
+// is a scalar pair (two s_mov_b32, which issue beside the vector stream).  v_fma_f64 is the IEEE fused multiply-add: the same bits.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline __attribute__((always_inline)) double tlm_fma_k_(double a, double b, double k)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+#define TLM_FMA_K(a, b, bits) tlm_fma_k_((a), (b), TLM_D(bits))
+#else
+#define TLM_FMA_K(a, b, bits) TLM_FMA((a), (b), TLM_D(bits))
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // log (e_log.c).  TAB = {invc, logc}[128] as bit patterns (global table or an LDS copy of it).
@@ -516,75 +534,144 @@ TLM_HD double tlm_atan2_t(double y, double x, TAB cij)
 TLM_HD double tlm_atan2(double y, double x) { return tlm_atan2_t(y, x, tlm_atan_cij); }
 
 // ------------------------------------------------------------------------------------------------------------
+// IEEE division and square root WITHOUT the exponent scaling (round 6).  The compiler expands an fp64 `/` into v_div_scale x 2, v_rcp,
+// two Newton steps on the reciprocal, a product, a residual, v_div_fmas, v_div_fixup (11 instructions) and sqrt() into a scale test,
+// v_ldexp, v_rsq, nine refinement steps, v_ldexp, a class test and two selects (18): the scale / fixup parts only matter for operands
+// within ~2^70 of the exponent limits, for zero and for infinities.  The forms below are the SAME refinement steps on unscaled
+// operands -- for every operand the scaled forms would leave unscaled they execute the same arithmetic, hence return the same bits,
+// i.e. the correctly rounded result (the final fused step sees the exact residual) -- and a reciprocal refined once serves every
+// quotient by the same divisor (e_atan2.c divides twice by max(|x|, |y|)).
+// Domain: divisor and square-root argument normal and in [2^-500, 2^500], dividend zero or in [2^-900, 2^500]; sqrt(+0) = +0 is a select.
+// The seed is v_rcp_f64 / v_rsq_f64 on the device; on the host (emulation, tools) the exact 1/d, 1/sqrt(x) rounded -- the refinement
+// converges to the same result from any seed good to ~2^-20 (tools/libm_agree.cpp perturbs the seed to show it, 1e8 operands each).
+TLM_HD double tlm_rcp_seed(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(d);
+#else
+    return 1.0 / d;
+#endif
+}
+TLM_HD double tlm_rsq_seed(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsq(x);
+#else
+    return 1.0 / __builtin_sqrt(x);
+#endif
+}
+TLM_HD double tlm_recip_from(double d, double r)
+{   // two Newton steps: r (1 + e) with e = 1 - d r
+    double e = TLM_FMA(-d, r, 1.0);
+    r = TLM_FMA(r, e, r);
+    e = TLM_FMA(-d, r, 1.0);
+    return TLM_FMA(r, e, r);
+}
+TLM_HD double tlm_div_by_recip(double n, double d, double r)
+{   // n / d with r = the refined reciprocal of d: quotient estimate, its exact residual, one fused correction
+    const double q = n * r;
+    const double e = TLM_FMA(-d, q, n);
+    return TLM_FMA(e, r, q);
+}
+TLM_HD double tlm_sqrt_from(double x, double y)
+{   // sqrt(x) from y ~ 1 / sqrt(x): g ~ sqrt(x), h ~ 1 / (2 sqrt(x)) refined together once, then g twice with its exact residual
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = TLM_FMA(-h, g, 0.5);
+    g = TLM_FMA(g, r, g);
+    h = TLM_FMA(h, r, h);
+    double d = TLM_FMA(-g, g, x);
+    g = TLM_FMA(d, h, g);
+    d = TLM_FMA(-g, g, x);
+    return TLM_FMA(d, h, g);
+}
+TLM_HD double tlm_div_ns(double n, double d) { return tlm_div_by_recip(n, d, tlm_recip_from(d, tlm_rcp_seed(d))); }
+TLM_HD double tlm_sqrt_ns(double x) { const double g = tlm_sqrt_from(x, tlm_rsq_seed(x)); return x == 0.0 ? x : g; }      // (x = 0: the seed is infinite)
+
+// ------------------------------------------------------------------------------------------------------------
 // Straight-line forms for the device: the lanes of a wave are spread over every branch of the routines above, so
 // the wave executes all of them anyway; here the branches' COMMON work is done once and the results are selected.
 // Same operations on the selected path, hence the same bits (tools/libm_agree.cpp checks these forms as well).
 
 // sincos for |x| < 105414350.  All four argument ranges end in do_sin(a, da) and do_cos(a, da) of some reduced
-// argument; the ranges differ in (a, da), in which output takes which value and in the signs.
+// argument; the ranges differ in (a, da), in which output takes which value and in the signs.  Round 6: the ranges are folded into
+// ONE quadrant number so that the outputs take two 64-bit selects instead of six, and a 64-bit select is two instructions:
+//   * |x| < 0.855469 is reduce_sincos with xn FORCED to +0 and n = 0: y = (x - 0) - 0 = x, every correction term is (x - x) - 0 = +0,
+//     so (a, da) = (x, +0) -- do_sin(x, 0.0) / do_cos(x, 0.0) as s_sincos.c calls them (x = -0.0 reduces to +0: a takes x's high word);
+//   * 0.855469 <= |x| < 2.426265 ("pi/2 - |x|") hands out sin = |cos(a)| with x's sign and cos = sin(a): that is quadrant 1 for
+//     x > 0 and quadrant 3 for x < 0 of the general rule (sin = +-cos(a), cos = sin(a)) because cos(a) >= cos(0.855469) > 0 there;
+//   * |x| < 2^-27 (sin = x, cos = 1.0 in s_sincos.c) needs no case: TAYLOR_SIN gives x + (p x) x^2 with |(p x) x^2| < 2^-56 |x|, which
+//     rounds to x (the sign of -0.0 comes back with the copysign below), and do_cos gives 1.0 - c with c <= x^2 / 2 < 2^-55, which rounds to 1.0 (row 0 of the table is sin 0, cos 1 exactly);
+//   * do_cos flips dx for a < 0, do_sin's table branch for a <= 0: they differ at a = +-0 only, where do_sin takes TAYLOR_SIN anyway,
+//     and for a = -0.0 the cosine does not depend on dx's sign (row 0: sn = ssn = ccs = 0, so cor = (0 - s*0 - c) - 0*s = -c either
+//     way) -- both use the sign BIT of a.
+// tools/libm_agree.cpp runs this form against the host's sincos (every range, every boundary, 1e8 arguments per round).
 template <typename TAB>
 TLM_HD void tlm_sincos_sl(double x, double *sinx, double *cosx, TAB tab)
 {
     const double hp0 = TLM_D(0x3ff921fb54442d18), hp1 = TLM_D(0x3c91a62633145c07);
     const double hpinv = TLM_D(0x3fe45f306dc9c883), toint = TLM_D(0x4338000000000000), mp1 = TLM_D(0x3ff921fb58000000),
                  mp2 = TLM_D(0xbe4dde973c000000), pp3 = TLM_D(0xbc8cb3b398000000), pp4 = TLM_D(0xbacd747f23e32ed7);
-    const uint64_t bx = tlm_d2u(x), sx = bx & 0x8000000000000000ull;
-    const int32_t k = (int32_t)(bx >> 32) & 0x7fffffff;
-    const double ax = tlm_u2d(bx ^ sx);
-    const bool p1 = k < 0x3feb6000, p2 = !p1 && k < 0x400368fd;
-    // range 3: reduce_sincos
+    const uint64_t bx = tlm_d2u(x);
+    const uint32_t hx = (uint32_t)(bx >> 32);
+    const int32_t k = (int32_t)(hx & 0x7fffffffu);
+    const double ax = tlm_u2d(bx & 0x7fffffffffffffffull);
+    const bool p1 = k < 0x3feb6000, p12 = k < 0x400368fd;
+    // reduce_sincos (xn = +0 in range 1)
     const double t = x * hpinv + toint;
-    const double xn = t - toint;
-    const int n = (int)(uint32_t)tlm_d2u(t) & 3;
+    const double xn = p1 ? 0.0 : t - toint;
+    const uint32_t n = (uint32_t)tlm_d2u(t) & 3u;
     const double y = (x - xn * mp1) - xn * mp2;
     const double t1 = xn * pp3;
     const double t2 = y - t1;
     const double t1b = xn * pp4;
     const double b = t2 - t1b;
     const double db = ((y - t2) - t1) + ((t2 - b) - t1b);
-    const uint64_t flip = (n == 1 || n == 2) ? 0x8000000000000000ull : 0;
+    // the quadrant: 0 in range 1; 1 / 3 in range 2 (x > 0 / x < 0); n in range 3, whose reduced argument is negated for n = 1, 2
+    const uint32_t q = p1 ? 0u : p12 ? (1u | (hx >> 30 & 2u)) : n;
+    const uint64_t flip = p12 ? 0ull : (uint64_t)((n + 1u) & 2u) << 62;
     // range 2: pi/2 - |x|
     const double yy = hp0 - ax;
     const double a2 = yy + hp1;
     const double da2 = (yy - a2) + hp1;
-    const double a = p1 ? x : p2 ? a2 : tlm_u2d(tlm_d2u(b) ^ flip);
-    const double da = p1 ? 0.0 : p2 ? da2 : tlm_u2d(tlm_d2u(db) ^ flip);
-    // do_sin / do_cos on (a, da): shared table row and first reduction
+    const bool p2 = p12 && !p1;
+    const uint64_t a23 = tlm_d2u(p2 ? a2 : tlm_u2d(tlm_d2u(b) ^ flip));
+    // (range 1: b = x for every x but -0.0, whose reduction comes out as +0 -- the high word is x's own there: one 32-bit select)
+    const double a = tlm_u2d((uint64_t)(p1 ? hx : (uint32_t)(a23 >> 32)) << 32 | (uint32_t)a23);
+    const double da = p2 ? da2 : tlm_u2d(tlm_d2u(db) ^ flip);
+    // do_sin / do_cos on (a, da): shared table row, first reduction and dx = da with a's sign
     const uint64_t sa = tlm_d2u(a) & 0x8000000000000000ull;
     const double aa = tlm_u2d(tlm_d2u(a) ^ sa);
     const double u = TLM_BIG + aa;
     const double xr = aa - (u - TLM_BIG);
     const int row = (int)(uint32_t)tlm_d2u(u) * 4;
     const double sn = tlm_u2d(tab[row]), ssn = tlm_u2d(tab[row + 1]), cs = tlm_u2d(tab[row + 2]), ccs = tlm_u2d(tab[row + 3]);
-    // do_cos: dx = a < 0 ? -da : da
+    const double dx = tlm_u2d(tlm_d2u(da) ^ sa);
     double cosv;
     {
-        const double dx = tlm_u2d(tlm_d2u(da) ^ (a < 0 ? 0x8000000000000000ull : 0));
         const double xc = xr + dx;
         const double xx = xc * xc;
         const double s = xc + (xc * xx) * (TLM_SN3 + xx * TLM_SN5);
         const double c = xx * (TLM_CS2 + xx * (TLM_CS4 + xx * TLM_CS6));
         cosv = cs + (((ccs - s * ssn) - cs * c) - sn * s);
     }
-    // do_sin: Taylor below 0.126, table above; dx = a <= 0 ? -da : da
     double sinv;
     {
         const double ty = tlm_taylor_sin(a * a, a, da);
-        const double dx = tlm_u2d(tlm_d2u(da) ^ (a <= 0 ? 0x8000000000000000ull : 0));
         const double xx = xr * xr;
         const double s = xr + (dx + (xr * xx) * (TLM_SN3 + xx * TLM_SN5));
         const double c = xr * dx + xx * (TLM_CS2 + xx * (TLM_CS4 + xx * TLM_CS6));
         const double r = sn + (((ssn + s * ccs) - sn * c) + cs * s);
-        const double tb = tlm_u2d((tlm_d2u(r) & 0x7fffffffffffffffull) | sa);
-        sinv = aa < 0.126 ? ty : tb;
+        // do_sin returns the table value with a's sign; TAYLOR_SIN's value has a's sign by itself -- except for a = -0.0, where it is
+        // +0 and s_sincos.c's own |x| < 2^-27 case returns x: one copysign after the select serves both
+        const double sel = aa < 0.126 ? ty : r;
+        sinv = tlm_u2d((tlm_d2u(sel) & 0x7fffffffffffffffull) | sa);
     }
-    // who gets what
-    const double c3 = (n & 2) ? -cosv : cosv;                                        // range 3
-    double so = p1 ? sinv : p2 ? tlm_u2d((tlm_d2u(cosv) & 0x7fffffffffffffffull) | sx) : (n & 1) ? c3 : sinv;
-    double co = p1 ? cosv : p2 ? sinv : (n & 1) ? sinv : c3;
-    const bool tiny = k < 0x3e400000;
-    *sinx = tiny ? x : so;
-    *cosx = tiny ? 1.0 : co;
+    // who gets what: odd quadrants swap, quadrants 2 and 3 negate the cosine
+    const double c3 = tlm_u2d(tlm_d2u(cosv) ^ ((uint64_t)(q & 2u) << 62));
+    const bool odd = (q & 1u) != 0;
+    *sinx = odd ? c3 : sinv;
+    *cosx = odd ? sinv : c3;
 }
 
 // atan2 for finite arguments: one quotient / remainder pair, both evaluation forms (polynomial below 1/16, table row
@@ -598,8 +685,6 @@ TLM_HD double tlm_atan2_sl(double y, double x, TAB cij)
 {
     const double hpi = TLM_D(0x3ff921fb54442d18), hpi1 = TLM_D(0x3c91a62633145c07), opi = TLM_D(0x400921fb54442d18),
                  opi1 = TLM_D(0x3ca1a62633145c07);
-    const double d3 = TLM_D(0xbfd5555555555555), d5 = TLM_D(0x3fc99999999997fd), d7 = TLM_D(0xbfc24924923f7603),
-                 d9 = TLM_D(0x3fbc71c6e5129a3b), d11 = TLM_D(0xbfb7458022b13c25), d13 = TLM_D(0x3fb375f08b31cbce);
     const uint64_t bx = tlm_d2u(x), by = tlm_d2u(y), sy = by & 0x8000000000000000ull;
     const int32_t ux = (int32_t)(bx >> 32), uy = (int32_t)(by >> 32);
     const bool xpos = !(bx >> 63);
@@ -614,18 +699,38 @@ TLM_HD double tlm_atan2_sl(double y, double x, TAB cij)
     }
     const bool ylx = ay < ax;
     const double num = ylx ? ay : ax, den = ylx ? ax : ay;
-    const double u = num / den;
-    const double pv = den * u;
-    const double du = ((num - pv) - TLM_FMA(den, u, -pv)) / den;
-    // form A: u < 1/16
-    const double v = u * u;
-    const double pa = TLM_FMA(TLM_FMA(TLM_FMA(TLM_FMA(TLM_FMA(d13, v, d11), v, d9), v, d7), v, d5), v, d3);
-    const double uv = u * v;
-    // form B: table row
+    double u, du, rd = 0;
+    if (SCALE) u = num / den;
+    else {
+        // both quotients by ONE refined reciprocal of den, without the divisions' exponent scaling (tlm_div_by_recip): den is in
+        // [2^-443, 2^500] by this form's contract; where num is more than 2^57 below it (or zero) the extreme-ratio branches below
+        // discard the quotients, whatever they are
+        rd = tlm_recip_from(den, tlm_rcp_seed(den));
+        u = tlm_div_by_recip(num, den, rd);
+    }
+    // form B's table row is requested as soon as the first quotient names it; the second quotient and all of form A run while it is
+    // on its way (TLM_ATAN_SCHED pins that order on the device: the compiler otherwise waits for the row before the second division)
     int i = (int)(uint32_t)tlm_d2u(TLM_FMA(u, 256.0, 0x1p52)) - 16;       // the low word of TWO52 + TWO8*u (defined for the NaN of 0/0 too: the lane's result is discarded)
     i = i < 0 ? 0 : i > 240 ? 240 : i;                                    // (only form A's lanes can leave the table)
     const double c0 = tlm_u2d(cij[7 * i]), c1 = tlm_u2d(cij[7 * i + 1]), c2 = tlm_u2d(cij[7 * i + 2]), c3 = tlm_u2d(cij[7 * i + 3]),
                  c4 = tlm_u2d(cij[7 * i + 4]), c5 = tlm_u2d(cij[7 * i + 5]), c6 = tlm_u2d(cij[7 * i + 6]);
+    {
+        const double pv = den * u;
+        const double res = (num - pv) - TLM_FMA(den, u, -pv);
+        du = SCALE ? res / den : tlm_div_by_recip(res, den, rd);
+    }
+    // form A: u < 1/16
+    const double v = u * u;
+    // (d13 .. d3 of e_atan2.c; the constant addends from scalar registers: TLM_FMA_K)
+    const double pa = TLM_FMA_K(TLM_FMA_K(TLM_FMA_K(TLM_FMA_K(TLM_FMA_K(TLM_D(0x3fb375f08b31cbce), v, 0xbfb7458022b13c25), v, 0x3fbc71c6e5129a3b), v,
+                                                    0xbfc24924923f7603), v, 0x3fc99999999997fd), v, 0xbfd5555555555555);
+    const double uv = u * v;
+    const double zA1 = u + TLM_FMA(uv, pa, du);
+    const double zz = uv * pa;
+#if defined(__HIP_DEVICE_COMPILE__) && TLM_ATAN_SCHED
+    __builtin_amdgcn_sched_barrier(0);                                    // everything above is issued before the first use of the row below
+#endif
+    // form B: table row
     const double t3 = u - c0;
     const double w = t3 + du;
     const double p3 = TLM_FMA(TLM_FMA(TLM_FMA(c6, w, c5), w, c4), w, c3);
@@ -636,14 +741,12 @@ TLM_HD double tlm_atan2_sl(double y, double x, TAB cij)
         const double at3 = t3 < 0 ? -t3 : t3, adu = du < 0 ? -du : du;
         const double dv = at3 > adu ? (t3 - w) + du : (du - w) + t3;
         const double zB1 = c1 + TLM_FMA(w, c2, TLM_FMA(dv, c2, (w * w) * p3));
-        const double zA1 = u + TLM_FMA(uv, pa, du);
         // (ii), (iii), (iv): pi/2 -, pi/2 +, pi - ; the three share their shape: base (-/+) u, base1 (-/+) stuff
         const double base = q3 || q2 ? hpi : opi, base1 = q3 || q2 ? hpi1 : opi1;
         const uint64_t sg = q3 ? 0 : 0x8000000000000000ull;              // (iii) adds, (ii) and (iv) subtract
         const double su = tlm_u2d(tlm_d2u(u) ^ sg), sdu = tlm_u2d(tlm_d2u(du) ^ sg);
         const double t2 = base + su;
         const double cor = (base - t2) + su;
-        const double zz = uv * pa;
         const double zA2 = (((cor + base1) + sdu) + tlm_u2d(tlm_d2u(zz) ^ sg)) + t2;
         const double zB2 = (base + tlm_u2d(tlm_d2u(c1) ^ sg)) + TLM_FMA(tlm_u2d(tlm_d2u(w) ^ sg), p2, base1);
         zA = q1 ? zA1 : zA2;

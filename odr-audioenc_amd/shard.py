@@ -84,6 +84,22 @@ def gather_floats(dist, values, device="cpu"):
     return [[float(x) for x in o.cpu().tolist()] for o in out]
 
 
+def gather_bytes(dist, payload, width=160, device="cpu"):
+    """all_gather of one short byte string per rank (padded / cut to `width`) -> [world] byte strings, over the SAME backend as the
+    barriers: how a record of a multi-GPU run shows which device every rank really ran on (a GPU's UUID and PCI address), gathered by
+    the collective itself rather than inferred from the launcher's environment."""
+    payload = bytes(payload)[:width]
+    if dist is None:
+        return [payload]
+    import torch
+    t = torch.zeros(width, dtype=torch.uint8, device=device)
+    if payload:
+        t[:len(payload)] = torch.tensor(list(payload), dtype=torch.uint8, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [bytes(o.cpu().tolist()).rstrip(b"\0") for o in out]
+
+
 def reduce_max(dist, value, device="cpu"):
     if dist is None:
         return float(value)

@@ -207,11 +207,12 @@ def _bind(L):
     L.toolame_set_channel_mode.argtypes = [C.c_char]
     L.toolame_encode_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.toolame_finish.argtypes = [C.c_void_p, C.c_size_t]
-    L.tlb_tick_status.argtypes = [C.c_void_p]
-    L.tlb_node_describe.argtypes = [C.c_void_p]
-    L.tlb_node_describe.restype = C.c_char_p
-    L.tlb_node_shard_status.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-    L.tlb_node_shard_restart.argtypes = [C.c_void_p, C.c_int, C.c_longlong]
+    if hasattr(L, "tlb_node_shard_status"):       # (an older build loaded through TLB_LIB_PATH for a kernel A/B has none of the round-6 entry points)
+        L.tlb_tick_status.argtypes = [C.c_void_p]
+        L.tlb_node_describe.argtypes = [C.c_void_p]
+        L.tlb_node_describe.restype = C.c_char_p
+        L.tlb_node_shard_status.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.tlb_node_shard_restart.argtypes = [C.c_void_p, C.c_int, C.c_longlong]
     return L
 
 

@@ -50,6 +50,10 @@ def cases():
                                 (1, 22050, "m", 32), (1, 22050, "s", 64), (3, 22050, "j", 96), (2, 22050, "m", 32)):
         out.append(dict(name=f"p{psy}_{fs // 1000}k_{mode}_{kbps}_k0", samplerate=fs, mode=mode, kbps=kbps, psy=psy, kind=0,
                         seed=300 + psy + kbps, pad_len=0))
+    # round 6: the lowest LSF rate (16 kHz, sampling-frequency index 2 of common.c:118-144) end to end, and dual channel below 48 kHz
+    for psy, fs, mode, kbps in ((1, 16000, "m", 32), (3, 16000, "s", 64), (2, 16000, "j", 48), (1, 24000, "d", 96), (4, 16000, "d", 80)):
+        out.append(dict(name=f"p{psy}_{fs // 1000}k_{mode}_{kbps}_k0", samplerate=fs, mode=mode, kbps=kbps, psy=psy, kind=0,
+                        seed=600 + psy + kbps, pad_len=0))
     out.append(dict(name="p1_48k_j_128_xpad", samplerate=48000, mode="j", kbps=128, psy=1, kind=0, seed=42, pad_len=58))
     out.append(dict(name="p3_48k_s_192_xpad", samplerate=48000, mode="s", kbps=192, psy=3, kind=0, seed=43, pad_len=58))
     # round 5: the DAB maximum (196 bytes), the largest length the caller accepts (255, src/odr-audioenc.cpp:566), and a small frame
@@ -174,8 +178,9 @@ def make_tables():
 def main():
     if not O.REF_SO.exists():
         subprocess.run(["make", "-C", str(O.ORACLE_DIR), "ref"], check=True)
-    make_tables()
-    make_rate_tables()
+    if "--no-tables" not in sys.argv:
+        make_tables()
+        make_rate_tables()
     if "--tables-only" in sys.argv:
         return
     total = 0

@@ -3,6 +3,7 @@ the TEST-ONLY emulation of the kernel (no GPU here); the union of the shards mus
 single-process result byte for byte (streams share no state), and the two scalars the benchmark
 exchanges (max elapsed, total frames) must reduce correctly."""
 import os
+import pickle
 import socket
 import subprocess
 import sys
@@ -99,6 +100,43 @@ def test_bench_gpus_spawns_ranks_dry_run():
     assert l1["n_gpus"] == 1 and l1["world_size_observed"] == 1 and len(l1["per_gpu_frames_per_s"]) == 1
 
 
+def test_bench_eight_ranks_dry_run_names_eight_devices():
+    """The driver's largest world size through the same plumbing: eight rank processes, one process group, and the
+    line carries `devices_observed` -- one identity record per rank gathered with ONE all_gather over the run's own backend -- so that a
+    record of a real 8-GPU run proves by itself that N ranks ran on N distinct devices."""
+    import json
+    r = _run_bench(["--gpus", "8", "--dry-run", "--steps", "1"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["world_size_observed"] == 8 and len(line["per_gpu_frames_per_s"]) == 8
+    dev = line["devices_observed"]
+    assert [d["rank"] for d in dev] == list(range(8)) and line["distinct_devices_observed"] == 8
+    assert len({d["pid"] for d in dev}) == 8 and all("host" in d and "setup_s" in d for d in dev)
+
+
+def test_gather_bytes_over_gloo(tmp_path):
+    """shard.gather_bytes: every rank's byte string comes back on every rank, in rank order, padding stripped"""
+    import odr_audioenc_amd.shard as shard
+    assert shard.gather_bytes(None, b"alone") == [b"alone"]
+    child = r"""
+import os, sys, pickle
+sys.path.insert(0, sys.argv[1])
+import odr_audioenc_amd.shard as shard
+rank, lr, world, dist = shard.init_from_env("gloo")
+got = shard.gather_bytes(dist, ("gpu-of-rank-%d" % rank).encode() * (rank + 1), width=64)
+pickle.dump(got, open(sys.argv[2] + str(rank), "wb"))
+dist.destroy_process_group()
+"""
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, "-c", child, str(ROOT), str(tmp_path / "gb")],
+                              env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+             for r in range(2)]
+    for p_ in procs:
+        assert p_.wait(timeout=240) == 0
+    for r in range(2):
+        assert pickle.load(open(str(tmp_path / "gb") + str(r), "rb")) == [b"gpu-of-rank-0", b"gpu-of-rank-1gpu-of-rank-1"]
+
+
 def test_bench_rejects_world_size_mismatch():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True, env=env, timeout=120)
@@ -113,6 +151,12 @@ def test_bench_workload_labels():
     lab, k = bench.workload_label(16384, 3, "s", 8, 8)
     assert k == 3 and "configs[3]" in lab and "131072 streams in total" in lab
     assert bench.workload_label(4096, 3, "s", 8, 1)[1] is None
+    # the BASELINE configurations are plain stereo -- mono pairs, joint stereo and dual channel are NOT configs[1] / [2]
+    for mode in ("m", "j", "d"):
+        lab, k = bench.workload_label(4096, 1, mode, 32, 1)
+        assert k is None and "not a BASELINE config" in lab and "BASELINE configs[" not in lab, lab
+        assert bench.workload_label(16384, 3, mode, 8, 8)[1] is None
+    assert "mono, two streams per wave" in bench.workload_label(4096, 1, "m", 32, 1)[0]
     a = bench.parse_args(["--gpus", "8"])
     assert a.gpus == 8 and a.streams is None and a.psy is None
 

@@ -52,7 +52,8 @@ struct Tally {
 static Tally T_log{"log"}, T_log10{"log10"}, T_log10pn{"log10 (straight-line form, positive normal)"}, T_log10split{"log10 (table branch / near-1 branch apart, positive normal)"}, T_exp{"exp"},
     T_pow10{"pow(10, y)"}, T_pow{"pow(x > 0, y)"}, T_sin{"sincos: sin"}, T_cos{"sincos: cos"}, T_atan2{"atan2"},
     T_sinsl{"sincos, straight-line form: sin"}, T_cossl{"sincos, straight-line form: cos"}, T_atan2sl{"atan2, straight-line form"}, T_atan2ns{"atan2, straight-line, no rescaling (max|.| in [2^-443, 2^500])"}, T_expsl{"exp, straight-line form (|x| < 512)"},
-    T_pow10sl{"pow(10, y), straight-line form (|y| < 222)"};
+    T_pow10sl{"pow(10, y), straight-line form (|y| < 222)"},
+    T_divns{"n / d by a refined reciprocal, no exponent scaling (seed perturbed by up to 2^-20)"}, T_sqrtns{"sqrt by refinement, no exponent scaling (seed perturbed by up to 2^-20)"};
 
 static void chk1(Tally &t, double x, double got, double want)
 {
@@ -153,6 +154,25 @@ static void worker(int id, uint64_t per_fn, uint64_t seed)
             T_atan2sl.n++;
             const double got2 = tlm_atan2_sl(y, xx, tlm_atan_cij);
             if (!same(got2, want)) T_atan2sl.miss("y=%a x=%a got %a want %a", y, xx, got2, want);
+            {   // the unscaled division / square root cores of round 6: any seed of hardware quality must give the correctly rounded result
+                double d, n;
+                switch (i % 5) {
+                case 0: d = r.binade(-500, 500); n = r.binade(-900, 500); break;                 // the stated domain
+                case 1: d = r.uniform(0.02, 4e7); n = d * r.uniform(0x1p-57, 1.0); break;            // atan2 of the encoder: num / den
+                case 2: d = r.mant(); n = r.mant() * (r.next() & 1 ? 1.0 : 0.5); break;
+                case 3: d = r.binade(-5, 30); n = d * r.mant() * 0x1p-106; break;                     // the second quotient: a residual over den
+                default: d = r.uniform(0.02, 4e9); n = r.uniform(0.0, 4e9); break;                   // c = sqrt(..) / (r + |r'|)
+                }
+                const double pert = 1.0 + r.uniform(-0x1p-20, 0x1p-20);
+                T_divns.n++;
+                const double q = tlm_div_by_recip(n, d, tlm_recip_from(d, (1.0 / d) * pert));
+                if (!same(q, n / d)) T_divns.miss("n=%a d=%a got %a want %a", n, d, q, n / d);
+                double x2;
+                switch (i % 3) { case 0: x2 = r.binade(-500, 500); break; case 1: x2 = r.uniform(0.0005, 1e18); break; default: x2 = r.mant() * (r.next() & 1 ? 1.0 : 2.0); break; }
+                T_sqrtns.n++;
+                const double sq = tlm_sqrt_from(x2, (1.0 / sqrt(x2)) * pert);
+                if (!same(sq, sqrt(x2))) T_sqrtns.miss("x=%a%.0s got %a want %a", x2, 0.0, sq, sqrt(x2));
+            }
             const double big = fabs(y) > fabs(xx) ? fabs(y) : fabs(xx);
             if (big >= 0x1p-443 && big <= 0x1p500) {          // the domain of the form without operand rescaling
                 T_atan2ns.n++;
@@ -192,7 +212,7 @@ int main(int argc, char **argv)
     for (unsigned t = 0; t < nthreads; t++) th.emplace_back(worker, (int)t, per, seed);
     for (auto &t : th) t.join();
     uint64_t bad = 0;
-    for (Tally *t : {&T_log, &T_log10, &T_log10pn, &T_log10split, &T_exp, &T_pow10, &T_pow, &T_sin, &T_cos, &T_atan2, &T_sinsl, &T_cossl, &T_atan2sl, &T_atan2ns, &T_expsl, &T_pow10sl}) {
+    for (Tally *t : {&T_log, &T_log10, &T_log10pn, &T_log10split, &T_exp, &T_pow10, &T_pow, &T_sin, &T_cos, &T_atan2, &T_sinsl, &T_cossl, &T_atan2sl, &T_atan2ns, &T_expsl, &T_pow10sl, &T_divns, &T_sqrtns}) {
         printf("%-48s %12llu arguments  %llu differ (%.4f %% bit-equal)\n", t->name, (unsigned long long)t->n.load(),
                (unsigned long long)t->bad.load(), 100.0 * (double)(t->n - t->bad) / (double)t->n);
         for (auto &e : t->examples) printf("    %s\n", e.c_str());

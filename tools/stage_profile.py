@@ -36,16 +36,40 @@ for i, n in enumerate(names):
 pn = ["spectrum(FHT)", "power+candidates", "tonal walk", "noise bands", "decimation", "threshold", "minmask+smr"]
 if psy in (2, 4):      # stamps of the first of the two 576-sample passes of a frame, in tl_psy2_kernel (shares: of the ENCODE kernel's ticks)
     pn = ["window+FHT", "energy/phase/unpred.", "partitions", "spreading+SNR", "line thresholds", "subbands", "-"]
-for ch in range(2):
-    base = 8 + 8 * ch
-    if st[..., base + 1].max() == 0:
-        continue
-    for i, n in enumerate(pn):
-        hi = st[..., base + i + 1] if i < 6 else None
-        if hi is None:
+def rows_per_channel():
+    for ch in range(2):
+        base = 8 + 8 * ch
+        if st[..., base + 1].max() == 0:
             continue
-        d = (hi - st[..., base + i]).mean()
-        print(f"    ch{ch} {n:18s} {d:10.0f}  {100 * d / tot:5.1f}%")
+        for i, n in enumerate(pn):
+            hi = st[..., base + i + 1] if i < 6 else None
+            if hi is None:
+                continue
+            d = (hi - st[..., base + i]).mean()
+            print(f"    ch{ch} {n:18s} {d:10.0f}  {100 * d / tot:5.1f}%")
+
+
+if psy in (1, 3) and mode != "m":
+    # Two-channel frames (tl_psy1_stereo / tl_psy3_stereo): channel 0 is PARKED after its front while channel 1's front uses the LDS arrays,
+    # then BOTH channels' dB-sum chains run side by side, then channel 1's back, then channel 0's.  The kernel stamps the chain stage itself
+    # (channel 1's slot 4 = chains begin, channel 0's slot 4 = chains end), so the rows below are the stages in the order they RUN -- a
+    # channel's waiting time is a row of its own, never part of its "noise bands" (round 5's table booked channel 1's
+    # front, both chains and channel 1's back under "ch0 noise bands").  (The rare dead-head frames take the plain per-channel order and
+    # blur the means slightly.)
+    c0, c1 = 8, 16
+    seq = [("ch0 spectrum (window + FHT)", c0 + 0, c0 + 1), ("ch0 power + candidates", c0 + 1, c0 + 2), ("ch0 tone walk", c0 + 2, c0 + 3),
+           ("ch0 compaction + weights, parked", c0 + 3, c1 + 0),
+           ("ch1 spectrum (window + FHT)", c1 + 0, c1 + 1), ("ch1 power + candidates", c1 + 1, c1 + 2), ("ch1 tone walk", c1 + 2, c1 + 3),
+           ("ch1 compaction + weights", c1 + 3, c1 + 4),
+           ("dB-sum chains, BOTH channels", c1 + 4, c0 + 4),
+           ("ch1 centres + decimation", c0 + 4, c1 + 5), ("ch1 thresholds", c1 + 5, c1 + 6),
+           ("ch0 resumed: centres + decimation", c1 + 6, c0 + 5), ("ch0 thresholds", c0 + 5, c0 + 6)]
+    print("  model phase in running order (ticks per unit, share of encode + psy):")
+    for n, a, b_ in seq:
+        d = (st[..., b_] - st[..., a]).mean()
+        print(f"    {n:36s} {d:10.0f}  {100 * d / tot:5.1f}%")
+else:
+    rows_per_channel()
 if st[..., 25].max() > 0:
     fn = ["window+scatter", "first pass", "pass k=2", "pass k=4", "pass k=6", "pass k=8"]
     for i, n in enumerate(fn):
