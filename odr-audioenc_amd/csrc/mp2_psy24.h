@@ -98,6 +98,60 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                 if (it == 0) { r_o5 = l5[0]; r_n5 = l5[1]; p_o5 = l5[2]; p_n5 = l5[3]; }
                 const double a = L(xa), b = L(xb);
                 if (TL_P2_LEVEL >= 6) { L(r1)[it] = a; L(p1)[it] = b; continue; }   // diagnostic: the transform alone, kept alive through the state
+#if TL_P2_PHASED
+                // The step in FIVE stretches with scheduling fences between them (tl_libm.h: tlm_atan2_head / _mid / _tail, tlm_sincos_reduce /
+                // _poly / _finish).  Every routine here ends in a table row -- the arctangent's in L1 / L2, the two sincos rows in LDS -- and the
+                // compiler, left alone, requests a row a handful of instructions before it waits for it: under the round-5 kernel a wave
+                // spent 53 % of this stage's cycles in s_waitcnt (profiles/class_budget_r06_psy2.txt), and three such waves leave a SIMD idle
+                // one cycle in six.  So: (1) the arctangent's first quotient and the PREDICTED phase's reduction, both rows requested;
+                // (2) the second quotient, form A, both polynomial sets of the predicted phase -- ~75 operations no row enters;
+                // (3) form B -> this pass's phase, the predicted phase's sine / cosine, the phase's own reduction, its row requested;
+                // (4) its polynomial sets and the square root of the energy; (5) its sine / cosine and the unpredictability measure.
+                constexpr bool full = !SEED && TL_P2_LEVEL < 5;
+                const TlmAtanA at = tlm_atan2_head(-a, b);
+                const uint64_t *arow = tlm_atan_cij + 7 * at.i;
+                const double c0 = tl_u2d(arow[0]), c1 = tl_u2d(arow[1]), c2 = tl_u2d(arow[2]), c3 = tl_u2d(arow[3]), c4 = tl_u2d(arow[4]),
+                             c5 = tl_u2d(arow[5]), c6 = tl_u2d(arow[6]);
+                double e = (a * a + b * b) / 2.0;
+                TlmSinCosA s2 = {}; TlmSinCosB v2 = {};
+                double q_sn = 0, q_ssn = 0, q_cs = 0, q_ccs = 0, r_prime = 0;
+                if (full) {
+                    s2 = tlm_sincos_reduce(2.0 * L(p1)[it] - L(p2)[it]);
+                    q_sn = tl_u2d(sct[s2.row]); q_ssn = tl_u2d(sct[s2.row + 1]); q_cs = tl_u2d(sct[s2.row + 2]); q_ccs = tl_u2d(sct[s2.row + 3]);
+                }
+                TLM_SCHED_FENCE();
+                const TlmAtanB am = tlm_atan2_mid(at);
+                if (full) { v2 = tlm_sincos_poly(s2); r_prime = 2.0 * L(r1)[it] - L(r2)[it]; }
+                TLM_SCHED_FENCE();
+                double phi = tlm_atan2_tail(at, am, c0, c1, c2, c3, c4, c5, c6) + 3.14159265358979 / 4;
+                const bool low = e < 0.0005;
+                e = tlm_sel(low, 0.0005, e); phi = tlm_sel(low, 0.0, phi);
+                e = tlm_sel(first, a * a, e); phi = tlm_sel(first, 0.0, phi);      // line 0: energy x_real[0]^2, phase 0
+                double spp = 0, cpp = 0, w_sn = 0, w_ssn = 0, w_cs = 0, w_ccs = 0;
+                TlmSinCosA s1 = {}; TlmSinCosB v1 = {};
+                if (full) {
+                    tlm_sincos_finish(s2, v2, q_sn, q_ssn, q_cs, q_ccs, &spp, &cpp);
+                    s1 = tlm_sincos_reduce(tlm_sel(first, 2.0 * p_o5 - p_n5, phi));
+                    w_sn = tl_u2d(sct[s1.row]); w_ssn = tl_u2d(sct[s1.row + 1]); w_cs = tl_u2d(sct[s1.row + 2]); w_ccs = tl_u2d(sct[s1.row + 3]);
+                }
+                TLM_SCHED_FENCE();
+                const double rn = tlm_sqrt_ns(e);                    // e >= 0.0005, or line 0's x^2 (zero included): far from the exponent limits
+                if (full) v1 = tlm_sincos_poly(s1);
+                TLM_SCHED_FENCE();
+                double spp5 = 0, cpp5 = 0;
+                if (full) {
+                    double sp, cp;
+                    tlm_sincos_finish(s1, v1, w_sn, w_ssn, w_cs, w_ccs, &sp, &cp);
+                    spp5 = sp; cpp5 = cp;                                // sincos of line 512's predicted phase (lane 0 of step 0)
+                    sp = tlm_sel(first, 0.0, sp); cp = tlm_sel(first, 1.0, cp);         // sincos(0.0)
+                    const double t1 = rn * cp - r_prime * cpp;
+                    const double t2 = rn * sp - r_prime * spp;
+                    const double t3 = rn + fabs(r_prime);
+                    // (t3 >= sqrt(0.0005) but for line 0; t1^2 + t2^2 is zero or above 1e-70: the unscaled square root and division, tl_libm.h)
+                    cw[j] = tlm_sel(t3 != 0, tlm_div_ns(tlm_sqrt_ns(t1 * t1 + t2 * t2), t3), 0.0);
+                    x[j] = e;
+                }
+#else
                 double e = (a * a + b * b) / 2.0;
                 const bool low = e < 0.0005;
                 double phi = (TL_P2_SUB == 3 ? b - a : tlm_atan2_sl<false>(-a, b, tlm_atan_cij)) + 3.14159265358979 / 4;
@@ -121,6 +175,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                             TL_SELECT(t3 != 0, tlm_div_ns(tlm_sqrt_ns(t1 * t1 + t2 * t2), t3), 0.0);
                     x[j] = e;
                 }
+#endif
                 L(r2)[it] = L(r1)[it]; L(r1)[it] = rn; L(p2)[it] = L(p1)[it]; L(p1)[it] = phi;
                 if (it == 0) {                                       // line 512 (psycho_2.c:110-140 with fft.c:1274's phase), finished by lane 0
                     const double c5 = L(xc);

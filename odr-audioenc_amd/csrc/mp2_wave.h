@@ -332,6 +332,10 @@ static long tl_dbg_rounds = 0, tl_dbg_tones = 0, tl_dbg_deadheads = 0, tl_dbg_fr
 #ifndef TL_P2_NS
 #define TL_P2_NS 1
 #endif
+// ... and the line loop's step in five stretches between scheduling fences (1) or as the plain sequence of the three routines (0)
+#ifndef TL_P2_PHASED
+#define TL_P2_PHASED 1
+#endif
 #define TL_DBMIN (-200.0)
 #define TL_POWERNORM 90.3090
 #define TL_T_NOISE 10

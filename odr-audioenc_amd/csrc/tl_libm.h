@@ -47,8 +47,33 @@ TLM_HD double tlm_u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 TLM_HD uint64_t tl_d2u(double d) { return tlm_d2u(d); }       // the names the kernels use
 TLM_HD double tl_u2d(uint64_t u) { return tlm_u2d(u); }
 #define TLM_FMA(a, b, c) __builtin_fma((a), (b), (c))
-#ifndef TLM_ATAN_SCHED
-#define TLM_ATAN_SCHED 0
+// A select that stays a select (v_cndmask) on the device.  As a FUNCTION: the arms are its parameters -- evaluated by the caller, plain
+// locals here -- so the front end emits a select instruction, not a branch with a phi.  (From `c ? f(x) : g(x)` it emits control flow;
+// the optimiser then sinks each arm's computation, loads included, into its side of the branch and nothing turns that back: a
+// divergent region in the middle of a routine, behind every scheduling fence the caller has set.)
+TLM_HD double tlm_sel(bool c, double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_unpredictable(c) ? a : b;
+#else
+    return c ? a : b;
+#endif
+}
+TLM_HD uint32_t tlm_sel_u32(bool c, uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_unpredictable(c) ? a : b;
+#else
+    return c ? a : b;
+#endif
+}
+#define TLM_SEL(c, a, b) tlm_sel((c), (a), (b))
+// a scheduling fence for callers that put a routine's phases apart (tlm_sincos_reduce / _poly / _finish, tlm_atan2_head / _mid / _tail):
+// nothing is moved across it, so a table row requested before it is not waited for until the work between the fences has been issued
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TLM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define TLM_SCHED_FENCE() ((void)0)
 #endif
 #define TLM_D(bits) tlm_u2d(bits##ull)
 // TLM_FMA_K(a, b, bits): fma(a, b, K) with a CONSTANT addend.  gfx950's three-operand fp64 instructions take no 64-bit literal, and the
@@ -586,7 +611,7 @@ TLM_HD double tlm_sqrt_from(double x, double y)
     return TLM_FMA(d, h, g);
 }
 TLM_HD double tlm_div_ns(double n, double d) { return tlm_div_by_recip(n, d, tlm_recip_from(d, tlm_rcp_seed(d))); }
-TLM_HD double tlm_sqrt_ns(double x) { const double g = tlm_sqrt_from(x, tlm_rsq_seed(x)); return x == 0.0 ? x : g; }      // (x = 0: the seed is infinite)
+TLM_HD double tlm_sqrt_ns(double x) { const double g = tlm_sqrt_from(x, tlm_rsq_seed(x)); return TLM_SEL(x == 0.0, x, g); }      // (x = 0: the seed is infinite)
 
 // ------------------------------------------------------------------------------------------------------------
 // Straight-line forms for the device: the lanes of a wave are spread over every branch of the routines above, so
@@ -606,12 +631,17 @@ TLM_HD double tlm_sqrt_ns(double x) { const double g = tlm_sqrt_from(x, tlm_rsq_
 //     and for a = -0.0 the cosine does not depend on dx's sign (row 0: sn = ssn = ccs = 0, so cor = (0 - s*0 - c) - 0*s = -c either
 //     way) -- both use the sign BIT of a.
 // tools/libm_agree.cpp runs this form against the host's sincos (every range, every boundary, 1e8 arguments per round).
-template <typename TAB>
-TLM_HD void tlm_sincos_sl(double x, double *sinx, double *cosx, TAB tab)
-{
+// The routine in three PHASES so that a caller can put other work between them (the psy-2 kernel's line loop, mp2_psy24.h): the table
+// row is requested at the end of phase one and first needed in phase three, and everything the row does not enter -- both polynomial
+// sets, about forty operations -- is phase two.  Left to itself the compiler requests the row eight instructions before it waits for it.
+struct TlmSinCosA { double a, da, aa, xr, dx; uint64_t sa; uint32_t q; int row; };
+struct TlmSinCosB { double cs_s, cs_c, ty, sn_s, sn_c; };
+TLM_HD TlmSinCosA tlm_sincos_reduce(double x)
+{   // phase one: the reduced argument (a, da), the quadrant, the table row
     const double hp0 = TLM_D(0x3ff921fb54442d18), hp1 = TLM_D(0x3c91a62633145c07);
     const double hpinv = TLM_D(0x3fe45f306dc9c883), toint = TLM_D(0x4338000000000000), mp1 = TLM_D(0x3ff921fb58000000),
                  mp2 = TLM_D(0xbe4dde973c000000), pp3 = TLM_D(0xbc8cb3b398000000), pp4 = TLM_D(0xbacd747f23e32ed7);
+    TlmSinCosA r;
     const uint64_t bx = tlm_d2u(x);
     const uint32_t hx = (uint32_t)(bx >> 32);
     const int32_t k = (int32_t)(hx & 0x7fffffffu);
@@ -619,7 +649,7 @@ TLM_HD void tlm_sincos_sl(double x, double *sinx, double *cosx, TAB tab)
     const bool p1 = k < 0x3feb6000, p12 = k < 0x400368fd;
     // reduce_sincos (xn = +0 in range 1)
     const double t = x * hpinv + toint;
-    const double xn = p1 ? 0.0 : t - toint;
+    const double xn = TLM_SEL(p1, 0.0, t - toint);
     const uint32_t n = (uint32_t)tlm_d2u(t) & 3u;
     const double y = (x - xn * mp1) - xn * mp2;
     const double t1 = xn * pp3;
@@ -628,50 +658,64 @@ TLM_HD void tlm_sincos_sl(double x, double *sinx, double *cosx, TAB tab)
     const double b = t2 - t1b;
     const double db = ((y - t2) - t1) + ((t2 - b) - t1b);
     // the quadrant: 0 in range 1; 1 / 3 in range 2 (x > 0 / x < 0); n in range 3, whose reduced argument is negated for n = 1, 2
-    const uint32_t q = p1 ? 0u : p12 ? (1u | (hx >> 30 & 2u)) : n;
+    r.q = p1 ? 0u : p12 ? (1u | (hx >> 30 & 2u)) : n;
     const uint64_t flip = p12 ? 0ull : (uint64_t)((n + 1u) & 2u) << 62;
     // range 2: pi/2 - |x|
     const double yy = hp0 - ax;
     const double a2 = yy + hp1;
     const double da2 = (yy - a2) + hp1;
     const bool p2 = p12 && !p1;
-    const uint64_t a23 = tlm_d2u(p2 ? a2 : tlm_u2d(tlm_d2u(b) ^ flip));
+    const uint64_t a23 = tlm_d2u(TLM_SEL(p2, a2, tlm_u2d(tlm_d2u(b) ^ flip)));
     // (range 1: b = x for every x but -0.0, whose reduction comes out as +0 -- the high word is x's own there: one 32-bit select)
-    const double a = tlm_u2d((uint64_t)(p1 ? hx : (uint32_t)(a23 >> 32)) << 32 | (uint32_t)a23);
-    const double da = p2 ? da2 : tlm_u2d(tlm_d2u(db) ^ flip);
+    r.a = tlm_u2d((uint64_t)tlm_sel_u32(p1, hx, (uint32_t)(a23 >> 32)) << 32 | (uint32_t)a23);
+    r.da = TLM_SEL(p2, da2, tlm_u2d(tlm_d2u(db) ^ flip));
     // do_sin / do_cos on (a, da): shared table row, first reduction and dx = da with a's sign
-    const uint64_t sa = tlm_d2u(a) & 0x8000000000000000ull;
-    const double aa = tlm_u2d(tlm_d2u(a) ^ sa);
-    const double u = TLM_BIG + aa;
-    const double xr = aa - (u - TLM_BIG);
-    const int row = (int)(uint32_t)tlm_d2u(u) * 4;
-    const double sn = tlm_u2d(tab[row]), ssn = tlm_u2d(tab[row + 1]), cs = tlm_u2d(tab[row + 2]), ccs = tlm_u2d(tab[row + 3]);
-    const double dx = tlm_u2d(tlm_d2u(da) ^ sa);
-    double cosv;
+    r.sa = tlm_d2u(r.a) & 0x8000000000000000ull;
+    r.aa = tlm_u2d(tlm_d2u(r.a) ^ r.sa);
+    const double u = TLM_BIG + r.aa;
+    r.xr = r.aa - (u - TLM_BIG);
+    r.row = (int)(uint32_t)tlm_d2u(u) * 4;
+    r.dx = tlm_u2d(tlm_d2u(r.da) ^ r.sa);
+    return r;
+}
+TLM_HD TlmSinCosB tlm_sincos_poly(const TlmSinCosA &r)
+{   // phase two: what the table row does not enter
+    TlmSinCosB p;
     {
-        const double xc = xr + dx;
+        const double xc = r.xr + r.dx;
         const double xx = xc * xc;
-        const double s = xc + (xc * xx) * (TLM_SN3 + xx * TLM_SN5);
-        const double c = xx * (TLM_CS2 + xx * (TLM_CS4 + xx * TLM_CS6));
-        cosv = cs + (((ccs - s * ssn) - cs * c) - sn * s);
+        p.cs_s = xc + (xc * xx) * (TLM_SN3 + xx * TLM_SN5);
+        p.cs_c = xx * (TLM_CS2 + xx * (TLM_CS4 + xx * TLM_CS6));
     }
-    double sinv;
     {
-        const double ty = tlm_taylor_sin(a * a, a, da);
-        const double xx = xr * xr;
-        const double s = xr + (dx + (xr * xx) * (TLM_SN3 + xx * TLM_SN5));
-        const double c = xr * dx + xx * (TLM_CS2 + xx * (TLM_CS4 + xx * TLM_CS6));
-        const double r = sn + (((ssn + s * ccs) - sn * c) + cs * s);
-        // do_sin returns the table value with a's sign; TAYLOR_SIN's value has a's sign by itself -- except for a = -0.0, where it is
-        // +0 and s_sincos.c's own |x| < 2^-27 case returns x: one copysign after the select serves both
-        const double sel = aa < 0.126 ? ty : r;
-        sinv = tlm_u2d((tlm_d2u(sel) & 0x7fffffffffffffffull) | sa);
+        p.ty = tlm_taylor_sin(r.a * r.a, r.a, r.da);
+        const double xx = r.xr * r.xr;
+        p.sn_s = r.xr + (r.dx + (r.xr * xx) * (TLM_SN3 + xx * TLM_SN5));
+        p.sn_c = r.xr * r.dx + xx * (TLM_CS2 + xx * (TLM_CS4 + xx * TLM_CS6));
     }
-    // who gets what: odd quadrants swap, quadrants 2 and 3 negate the cosine
-    const double c3 = tlm_u2d(tlm_d2u(cosv) ^ ((uint64_t)(q & 2u) << 62));
-    const bool odd = (q & 1u) != 0;
-    *sinx = odd ? c3 : sinv;
-    *cosx = odd ? sinv : c3;
+    return p;
+}
+TLM_HD void tlm_sincos_finish(const TlmSinCosA &r, const TlmSinCosB &p, double sn, double ssn, double cs, double ccs, double *sinx, double *cosx)
+{   // phase three: the row's four values against the polynomials, then who gets what
+    const double cosv = cs + (((ccs - p.cs_s * ssn) - cs * p.cs_c) - sn * p.cs_s);
+    const double rt = sn + (((ssn + p.sn_s * ccs) - sn * p.sn_c) + cs * p.sn_s);
+    // do_sin returns the table value with a's sign; TAYLOR_SIN's value has a's sign by itself -- except for a = -0.0, where it is
+    // +0 and s_sincos.c's own |x| < 2^-27 case returns x: one copysign after the select serves both
+    const double sel = TLM_SEL(r.aa < 0.126, p.ty, rt);
+    const double sinv = tlm_u2d((tlm_d2u(sel) & 0x7fffffffffffffffull) | r.sa);
+    // odd quadrants swap, quadrants 2 and 3 negate the cosine
+    const double c3 = tlm_u2d(tlm_d2u(cosv) ^ ((uint64_t)(r.q & 2u) << 62));
+    const bool odd = (r.q & 1u) != 0;
+    *sinx = TLM_SEL(odd, c3, sinv);
+    *cosx = TLM_SEL(odd, sinv, c3);
+}
+template <typename TAB>
+TLM_HD void tlm_sincos_sl(double x, double *sinx, double *cosx, TAB tab)
+{
+    const TlmSinCosA r = tlm_sincos_reduce(x);
+    const double sn = tlm_u2d(tab[r.row]), ssn = tlm_u2d(tab[r.row + 1]), cs = tlm_u2d(tab[r.row + 2]), ccs = tlm_u2d(tab[r.row + 3]);
+    const TlmSinCosB p = tlm_sincos_poly(r);
+    tlm_sincos_finish(r, p, sn, ssn, cs, ccs, sinx, cosx);
 }
 
 // atan2 for finite arguments: one quotient / remainder pair, both evaluation forms (polynomial below 1/16, table row
@@ -709,7 +753,7 @@ TLM_HD double tlm_atan2_sl(double y, double x, TAB cij)
         u = tlm_div_by_recip(num, den, rd);
     }
     // form B's table row is requested as soon as the first quotient names it; the second quotient and all of form A run while it is
-    // on its way (TLM_ATAN_SCHED pins that order on the device: the compiler otherwise waits for the row before the second division)
+    // on its way (the phased form below, tlm_atan2_head / _mid / _tail, lets a caller pin that order with scheduling fences)
     int i = (int)(uint32_t)tlm_d2u(TLM_FMA(u, 256.0, 0x1p52)) - 16;       // the low word of TWO52 + TWO8*u (defined for the NaN of 0/0 too: the lane's result is discarded)
     i = i < 0 ? 0 : i > 240 ? 240 : i;                                    // (only form A's lanes can leave the table)
     const double c0 = tlm_u2d(cij[7 * i]), c1 = tlm_u2d(cij[7 * i + 1]), c2 = tlm_u2d(cij[7 * i + 2]), c3 = tlm_u2d(cij[7 * i + 3]),
@@ -727,9 +771,6 @@ TLM_HD double tlm_atan2_sl(double y, double x, TAB cij)
     const double uv = u * v;
     const double zA1 = u + TLM_FMA(uv, pa, du);
     const double zz = uv * pa;
-#if defined(__HIP_DEVICE_COMPILE__) && TLM_ATAN_SCHED
-    __builtin_amdgcn_sched_barrier(0);                                    // everything above is issued before the first use of the row below
-#endif
     // form B: table row
     const double t3 = u - c0;
     const double w = t3 + du;
@@ -759,6 +800,90 @@ TLM_HD double tlm_atan2_sl(double y, double x, TAB cij)
     z = (bx << 1) == 0 ? hpi : z;
     z = (by << 1) == 0 ? (xpos ? 0.0 : opi) : z;
     return tlm_u2d((tlm_d2u(z) & 0x7fffffffffffffffull) | sy);
+}
+
+// The no-rescale form in three PHASES (as tlm_sincos_reduce / _poly / _finish): head = the first quotient and the table row it names,
+// mid = the second quotient and all of form A (nothing of the row enters), tail = form B on the row, the selection, the extreme ratios.
+// max(|y|, |x|) in [2^-443, 2^500] as for tlm_atan2_sl<false>; tools/libm_agree.cpp runs head + mid + tail against the host's atan2.
+struct TlmAtanA { uint64_t bx, by; double ax, ay, num, den, rd, u; int32_t de; int i; bool xpos, ylx; };
+struct TlmAtanB { double du, zA; };
+TLM_HD TlmAtanA tlm_atan2_head(double y, double x)
+{
+    TlmAtanA r;
+    r.bx = tlm_d2u(x); r.by = tlm_d2u(y);
+    const int32_t ux = (int32_t)(r.bx >> 32), uy = (int32_t)(r.by >> 32);
+    r.xpos = !(r.bx >> 63);
+    r.ax = tlm_u2d(r.bx & 0x7fffffffffffffffull); r.ay = tlm_u2d(r.by & 0x7fffffffffffffffull);
+    r.de = (uy & 0x7ff00000) - (ux & 0x7ff00000);
+    r.ylx = r.ay < r.ax;
+    r.num = r.ylx ? r.ay : r.ax; r.den = r.ylx ? r.ax : r.ay;
+    r.rd = tlm_recip_from(r.den, tlm_rcp_seed(r.den));
+    r.u = tlm_div_by_recip(r.num, r.den, r.rd);
+    int i = (int)(uint32_t)tlm_d2u(TLM_FMA(r.u, 256.0, 0x1p52)) - 16;
+    r.i = i < 0 ? 0 : i > 240 ? 240 : i;
+    return r;
+}
+TLM_HD TlmAtanB tlm_atan2_mid(const TlmAtanA &r)
+{
+    const double hpi = TLM_D(0x3ff921fb54442d18), hpi1 = TLM_D(0x3c91a62633145c07), opi = TLM_D(0x400921fb54442d18),
+                 opi1 = TLM_D(0x3ca1a62633145c07);
+    TlmAtanB m;
+    const double u = r.u;
+    const double pv = r.den * u;
+    m.du = tlm_div_by_recip((r.num - pv) - TLM_FMA(r.den, u, -pv), r.den, r.rd);
+    const double v = u * u;
+    const double pa = TLM_FMA_K(TLM_FMA_K(TLM_FMA_K(TLM_FMA_K(TLM_FMA_K(TLM_D(0x3fb375f08b31cbce), v, 0xbfb7458022b13c25), v, 0x3fbc71c6e5129a3b), v,
+                                                    0xbfc24924923f7603), v, 0x3fc99999999997fd), v, 0xbfd5555555555555);
+    const double uv = u * v;
+    const double zA1 = u + TLM_FMA(uv, pa, m.du);
+    const double zz = uv * pa;
+    const bool q1 = r.xpos && r.ylx, q2 = r.xpos && !r.ylx, q3 = !r.xpos && !r.ylx && r.ax < r.ay;
+    const double base = q3 || q2 ? hpi : opi, base1 = q3 || q2 ? hpi1 : opi1;
+    const uint64_t sg = q3 ? 0 : 0x8000000000000000ull;
+    const double su = tlm_u2d(tlm_d2u(u) ^ sg), sdu = tlm_u2d(tlm_d2u(m.du) ^ sg);
+    const double t2 = base + su;
+    const double cor = (base - t2) + su;
+    const double zA2 = (((cor + base1) + sdu) + tlm_u2d(tlm_d2u(zz) ^ sg)) + t2;
+    m.zA = TLM_SEL(q1, zA1, zA2);
+    return m;
+}
+TLM_HD double tlm_atan2_tail(const TlmAtanA &r, const TlmAtanB &m, double c0, double c1, double c2, double c3, double c4, double c5, double c6)
+{
+    const double hpi = TLM_D(0x3ff921fb54442d18), hpi1 = TLM_D(0x3c91a62633145c07), opi = TLM_D(0x400921fb54442d18),
+                 opi1 = TLM_D(0x3ca1a62633145c07);
+    const double u = r.u, du = m.du;
+    const double t3 = u - c0;
+    const double w = t3 + du;
+    const double p3 = TLM_FMA(TLM_FMA(TLM_FMA(c6, w, c5), w, c4), w, c3);
+    const double p2 = TLM_FMA(p3, w, c2);
+    const bool q1 = r.xpos && r.ylx, q2 = r.xpos && !r.ylx, q3 = !r.xpos && !r.ylx && r.ax < r.ay;
+    const double at3 = t3 < 0 ? -t3 : t3, adu = du < 0 ? -du : du;
+    const double dv = TLM_SEL(at3 > adu, (t3 - w) + du, (du - w) + t3);
+    const double zB1 = c1 + TLM_FMA(w, c2, TLM_FMA(dv, c2, (w * w) * p3));
+    const double base = q3 || q2 ? hpi : opi, base1 = q3 || q2 ? hpi1 : opi1;
+    const uint64_t sg = q3 ? 0 : 0x8000000000000000ull;
+    const double zB2 = (base + tlm_u2d(tlm_d2u(c1) ^ sg)) + TLM_FMA(tlm_u2d(tlm_d2u(w) ^ sg), p2, base1);
+    const double zB = TLM_SEL(q1, zB1, zB2);
+    double z = TLM_SEL(u < 0.0625, m.zA, zB);
+    // extreme ratios and zeros: an explicit, rarely taken branch BEHIND form B.  (As selects the compiler turns them into a branch of its
+    // own around the division and then sinks form B -- with the loads of the table row -- into that branch's other side, past every fence
+    // the caller has set.)
+    if (__builtin_expect(r.de <= -59768832 || r.de >= 59768832 || (r.bx << 1) == 0 || (r.by << 1) == 0, 0)) {
+        z = r.de <= -59768832 ? (r.xpos ? r.ay / r.ax : opi) : z;
+        z = r.de >= 59768832 ? hpi : z;
+        z = (r.bx << 1) == 0 ? hpi : z;
+        z = (r.by << 1) == 0 ? (r.xpos ? 0.0 : opi) : z;
+    }
+    return tlm_u2d((tlm_d2u(z) & 0x7fffffffffffffffull) | (r.by & 0x8000000000000000ull));
+}
+template <typename TAB>
+TLM_HD double tlm_atan2_phased(double y, double x, TAB cij)
+{
+    const TlmAtanA r = tlm_atan2_head(y, x);
+    const double c0 = tlm_u2d(cij[7 * r.i]), c1 = tlm_u2d(cij[7 * r.i + 1]), c2 = tlm_u2d(cij[7 * r.i + 2]), c3 = tlm_u2d(cij[7 * r.i + 3]),
+                 c4 = tlm_u2d(cij[7 * r.i + 4]), c5 = tlm_u2d(cij[7 * r.i + 5]), c6 = tlm_u2d(cij[7 * r.i + 6]);
+    const TlmAtanB m = tlm_atan2_mid(r);
+    return tlm_atan2_tail(r, m, c0, c1, c2, c3, c4, c5, c6);
 }
 
 // exp / pow(10, y) for results inside the normal range (|x| < 512 resp. |y * ln 10| < 512), no branches.

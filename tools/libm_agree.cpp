@@ -178,6 +178,8 @@ static void worker(int id, uint64_t per_fn, uint64_t seed)
                 T_atan2ns.n++;
                 const double got3 = tlm_atan2_sl<false>(y, xx, tlm_atan_cij);
                 if (!same(got3, want)) T_atan2ns.miss("y=%a x=%a got %a want %a", y, xx, got3, want);
+                const double got4 = tlm_atan2_phased(y, xx, tlm_atan_cij);        // head + mid + tail, what the psy-2 kernel's line loop calls
+                if (!same(got4, want)) T_atan2ns.miss("(phased) y=%a x=%a got %a want %a", y, xx, got4, want);
             }
         }
     }

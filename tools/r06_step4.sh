@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 6, GPU step 4: the phased line loop of the psy-2 kernel -- device parity, a psy 2 / 4 soak against the oracle, A/B
+cd ${GRAFT_REPO_ROOT:-$PWD}; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 1500 python3 -m pytest tests/test_hip_parity.py -x -q -m gpu -k "golden or psy2 or psy4 or configs4 or sweep or soak or mono or known_bad or degenerate or api_shapes" > gpurun_out/r06_s4_parity.log 2>&1; tail -3 gpurun_out/r06_s4_parity.log
+OUT=gpurun_out/soak_r06_a.txt; : > $OUT
+for seed in 6101 6102; do TL_SOAK_MODELS=2,4 timeout 900 python3 tools/soak_gpu.py 8192 12 $seed >> $OUT 2>&1; done
+for seed in 6111; do TL_SOAK_EDGE=1 TL_SOAK_MODELS=2,4 timeout 900 python3 tools/soak_gpu.py 8192 12 $seed >> $OUT 2>&1; done
+tail -4 $OUT
+rm -f gpurun_out/ab_libs.txt
+bash tools/ab_libs.sh "--psy 2" build/lib_r05.so build/lib_nophase.so default > /dev/null 2>&1
+bash tools/ab_libs.sh "--config 4" build/lib_r05.so build/lib_nophase.so default > /dev/null 2>&1
+cat gpurun_out/ab_libs.txt
+rm -f gpurun_out/pmc_quick.txt; bash tools/pmc_quick.sh "--psy 2" default > /dev/null 2>&1; cat gpurun_out/pmc_quick.txt | tail -2
+timeout 300 python3 tools/stage_profile.py 2 s 3072 2>&1 | grep "ch0\|ch1"
