@@ -266,6 +266,14 @@ def device_identity(torch, index):
         d["hbm_gb"] = round(pr.total_memory / 1e9, 1)
     except Exception as ex:  # noqa: BLE001
         d["error"] = str(ex)
+    if "pci_bus_id" not in d:          # a torch build without the PCI fields: ask the HIP runtime itself
+        try:
+            hip = C.CDLL("libamdhip64.so")
+            buf = C.create_string_buffer(32)
+            if hip.hipDeviceGetPCIBusId(buf, 32, int(index)) == 0:
+                d["pci_bus_id"] = buf.value.decode().lower()
+        except Exception:  # noqa: BLE001
+            pass
     return d
 
 
@@ -543,6 +551,7 @@ def node_in_process(M, np, gen_pcm, G, S, F, psy, mode, ndev, warmup, steps, mix
     for g in range(G):
         cfgs += stream_configs(M, S, psy, mode, mixed)
     nd = M.Node(cfgs, devices=[g % ndev for g in range(G)], plane="batch")
+    describe = nd.describe()
     distinct = min(S, 1024)
     base = np.stack([gen_pcm(k, 0, 0, 2 * F) for k in range(distinct)], axis=1)            # [2F][distinct][2][1152]
     host = np.tile(base, (1, (G * S + distinct - 1) // distinct, 1, 1))[:, :G * S]
@@ -581,7 +590,7 @@ def node_in_process(M, np, gen_pcm, G, S, F, psy, mode, ndev, warmup, steps, mix
     frames = G * S * F * steps
     return {"what": f"tlb_node_* (csrc/tlb_node.cpp): {G} shards x {S} streams in ONE process, one host thread per shard, devices {[g % ndev for g in range(G)]}, "
                     f"psy {psy}, {F} frames/stream/step, PCM resident per shard; no collective anywhere",
-            "shards": G, "devices": [g % ndev for g in range(G)], "value": round(frames / dt, 1), "unit": "frames/s", "steps": steps, "warmup": warmup,
+            "shards": G, "devices": [g % ndev for g in range(G)], "describe": describe, "value": round(frames / dt, 1), "unit": "frames/s", "steps": steps, "warmup": warmup,
             "ms_per_step": round(dt / steps * 1e3, 4), "frames_counted_by_the_node": tot["frames"] - c0["frames"],
             "per_shard": [{"shard": p_["shard"], "device": p_["device"], "first": p_["first"], "nstreams": p_["nstreams"], "frames": p_["frames"],
                            "busy_ms": round(p_["busy_ns"] / 1e6, 3)} for p_ in per],

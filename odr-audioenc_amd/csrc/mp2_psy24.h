@@ -29,6 +29,17 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
     if (TL_P2_LEVEL >= 7) return;                                    // diagnostic builds only (mp2_wave.h)
     {
         TL_STAMP(sq, 0);
+#if TL_P2_PARK
+        // The transform does not look at the prediction state; c[] / fthr[] (px) is dead until the line loop.  The state of two passes ago
+        // (r2: 16 registers) waits there while the transform runs, which is what lets its passes read the operands of both general butterflies
+        // ahead of their stores (TL_FHT_READS_FIRST 2, csrc/mp2_fht.h) without spilling.
+        TL_LANES_BEGIN
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int q = 0; q < 8; q++) cw[lane + 64 * q] = L(r2)[q];
+        TL_LANES_END
+#endif
         PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
         TL_LANES_BEGIN
         {
@@ -70,6 +81,14 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
         TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), T, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
         TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
         TL_LANES_BEGIN tl_fht_pass<8>(x, L(twa), lane); TL_LANES_END
+#if TL_P2_PARK
+        TL_LANES_BEGIN
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+        for (int q = 0; q < 8; q++) L(r2)[q] = cw[lane + 64 * q];
+        TL_LANES_END
+#endif
         TL_STAMP(sq, 1);
         // energy + phase (fft.c:1246-1275), unpredictability (psycho_2.c:119-140).
         // 64 lines per step: the transform is read through the layout map first, then the step's energies are written in
@@ -231,6 +250,27 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
             if (lane < P->npart) {
                 const int lo = P->part_lo[lane], hi = P->part_hi[lane];
                 int j = lo;
+#if TL_P2_PART_PIPE
+                // four lines' operands per LDS round trip, summed in line order, the NEXT four requested before these are added: the stage is
+                // a handful of lanes walking up to 77 lines each -- all latency, and a round trip per batch was most of it
+                double ev[4], cv[4];
+                if (j + 4 <= hi) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { ev[q] = energy[j + q]; cv[q] = cw[j + q]; }
+                    for (; j + 8 <= hi; j += 4) {
+                        double en[4], cn[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { en[q] = energy[j + 4 + q]; cn[q] = cw[j + 4 + q]; }
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { e += ev[q]; c += ev[q] * cv[q]; }
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { ev[q] = en[q]; cv[q] = cn[q]; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { e += ev[q]; c += ev[q] * cv[q]; }
+                    j += 4;
+                }
+#else
                 for (; j + 8 <= hi; j += 8) {                           // eight lines' operands per LDS round trip, summed in line order
                     double ev[8], cv[8];
 #ifndef TL_EMULATE
@@ -242,6 +282,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
 #endif
                     for (int q = 0; q < 8; q++) { e += ev[q]; c += ev[q] * cv[q]; }
                 }
+#endif
                 for (; j < hi; j++) { e += energy[j]; c += energy[j] * cw[j]; }
             }
             ge[2 * lane] = e; ge[2 * lane + 1] = c;
@@ -308,12 +349,35 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
             return;
         }
         // threshold per line (psycho_2.c:205-224): c[] is dead, reuse it for fthr[]
+        // (all nine lines of a lane at once: as a rolled loop every trip was a load of the partition number, then a dependent LDS read of its
+        // permissible noise, then the store -- nine memory round trips in a row for nine maxima; round 6: the table reads of all trips are
+        // requested first, then the LDS reads, then the stores -- one round trip of each kind)
+#if !TL_P2_THR_UNROLL
         TL_LANES_BEGIN
         for (int j = lane; j <= 512; j += 64) {
             const double t = nb[P->partition[j]], a = P->absthr[j];
             cw[j] = t > a ? t : a;
         }
         TL_LANES_END
+#else
+        TL_LANES_BEGIN
+        {
+            int pj[9]; double aj[9], tj[9];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 9; q++) { const int j = lane + 64 * q < 512 ? lane + 64 * q : 512; pj[q] = P->partition[j]; aj[q] = P->absthr[j]; }
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 9; q++) tj[q] = nb[pj[q]];
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 9; q++) { const int j = lane + 64 * q; if (j <= 512) cw[j] = tj[q] > aj[q] ? tj[q] : aj[q]; }
+        }
+        TL_LANES_END
+#endif
         TL_STAMP(sq, 5);
         if (TL_P2_LEVEL >= 1) {
             TL_LANES_BEGIN

@@ -1187,6 +1187,10 @@ def test_bench_two_ranks_on_the_gpu():
     assert line["config"]["baseline_config"] == 3 and "configs[3]" in line["config"]["workload"] and line["config"]["streams_per_gpu"] == 16384
     assert line["value"] > 0 and line["steps"] == 3 and line["output_check"]["checked"] and line["output_check"]["per_rank_ok"] == [True, True]
     assert line["roofline"]["hbm"]["achieved"] > 0 and line["roofline"]["bound"] == "valu_fp64" and 0 < line["roofline"]["frac"] < 1
+    # the line names the device of every rank, gathered over the collective -- here two ranks on ONE GPU, and it says so
+    dev = line["devices_observed"]
+    assert [d["rank"] for d in dev] == [0, 1] and all(d.get("name") and (d.get("uuid") or d.get("pci_bus_id")) for d in dev), dev
+    assert line["distinct_devices_observed"] == 1 and len({d["pid"] for d in dev}) == 2
 
 
 def test_bench_configs4_two_ranks_on_the_gpu():

@@ -214,6 +214,11 @@ def test_bench_forced_rccl_group_on_one_gpu():
     assert rf["bound"] == "valu_fp64" and rf["unit"] == "TFLOP/s" and rf["peak"] == 78.6 and 0 < rf["frac"] < 0.5
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0 < rf["hbm_frac"] < 0.1
     assert "valu_issue_utilisation" in rf and "NOT a roofline fraction" in rf["valu_issue_utilisation"]["what"]
+    # the N = 1 line carries the device's identity too (gathered over RCCL here), and the clock probe names the card it read by PCI address
+    dev = line["devices_observed"]
+    print("devices_observed:", dev)
+    assert len(dev) == 1 and line["distinct_devices_observed"] == 1 and dev[0]["name"] and (dev[0].get("pci_bus_id") or dev[0].get("uuid")), dev
+    assert dev[0]["compute_units"] == 256
 
 
 def test_bench_in_process_node_two_shards_on_the_gpu():
@@ -224,3 +229,5 @@ def test_bench_in_process_node_two_shards_on_the_gpu():
     assert nd["shards"] == 2 and nd["devices"] == [0, 0] and nd["value"] > 0 and nd["output_check"]["checked"]
     assert nd["frames_counted_by_the_node"] == 2 * 4096 * 32 * 3
     assert [p["nstreams"] for p in nd["per_shard"]] == [4096, 4096] and [p["first"] for p in nd["per_shard"]] == [0, 4096]
+    print(nd["describe"])
+    assert nd["describe"].count("shard ") == 2 and "256 CUs in 8 XCDs" in nd["describe"] and "uuid" in nd["describe"]
