@@ -72,62 +72,6 @@ TL_FN void tl_fht_pass(double *x, const double (&t)[8], int lane)
     constexpr int k1 = 1 << K, k2 = k1 << 1, k4 = k2 << 1, k3 = k2 + k1, kx = k1 >> 1;
     constexpr int NBLK = 128 / kx, NGEN = 128 - NBLK;
     constexpr int q1 = TL_FX(k1), q2 = TL_FX(k2), q3 = TL_FX(k3);
-#if TL_FHT_READS_FIRST
-    // Round 6: ALL of the lane's operands are read before the first result is stored -- the two general butterflies' and the trivial one's
-    // (every point of the buffer belongs to exactly one butterfly of a pass, so the order of reads and writes between butterflies is free).
-    // Written butterfly by butterfly the compiler has to keep each one's stores ahead of the next one's loads (it cannot see that the
-    // addresses differ): three dependent LDS round trips per pass and lane where one will do -- the passes ran at 29 wave cycles per vector
-    // instruction, latency and nothing else (profiles/stage_r06_psy1.txt).
-    double *fp[3][4], *gp[3][4];
-    double fv[3][4], gv[3][4];
-    bool on[3];
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int g = lane + 64 * it;
-        on[it] = g < NGEN;
-        const int gg = on[it] ? g : 0;
-        const int blk = gg / (kx - 1), i = 1 + (gg - blk * (kx - 1));
-        const int pb = TL_FX(blk * k4);
-        const int F = pb ^ TL_FX(i), G = pb ^ TL_FX(k1 - i);
-        fp[it][0] = x + F; fp[it][1] = x + (F ^ q1); fp[it][2] = x + (F ^ q2); fp[it][3] = x + (F ^ q3);
-        gp[it][0] = x + G; gp[it][1] = x + (G ^ q1); gp[it][2] = x + (G ^ q2); gp[it][3] = x + (G ^ q3);
-    }
-    constexpr int NB = TL_FHT_READS_FIRST == 2 ? 2 : 3;               // (2: the trivial butterfly keeps its own round trip -- the psy-2 kernel has no registers for it)
-    {
-        on[2] = lane < NBLK;
-        const int F = TL_FX((on[2] ? lane : 0) * k4), G = F ^ TL_FX(kx);
-        fp[2][0] = x + F; fp[2][1] = x + (F ^ q1); fp[2][2] = x + (F ^ q2); fp[2][3] = x + (F ^ q3);
-        gp[2][0] = x + G; gp[2][1] = x + (G ^ q1); gp[2][2] = x + (G ^ q2); gp[2][3] = x + (G ^ q3);
-    }
-#pragma unroll
-    for (int b = 0; b < NB; b++)                                      // (a lane without a butterfly b reads butterfly 0's points of block 0: valid addresses, values unused)
-#pragma unroll
-        for (int q = 0; q < 4; q++) { fv[b][q] = *fp[b][q]; gv[b][q] = *gp[b][q]; }
-#pragma unroll
-    for (int it = 0; it < 2; it++)
-        if (on[it]) {
-            const double c1 = t[4 * it], s1 = t[4 * it + 1], c2 = t[4 * it + 2], s2 = t[4 * it + 3];
-            double a, b2, g0, f0, f1, g1, f2, g2, f3, g3;
-            b2 = s2 * fv[it][1] - c2 * gv[it][1]; a = c2 * fv[it][1] + s2 * gv[it][1];
-            f1 = fv[it][0] - a; f0 = fv[it][0] + a; g1 = gv[it][0] - b2; g0 = gv[it][0] + b2;
-            b2 = s2 * fv[it][3] - c2 * gv[it][3]; a = c2 * fv[it][3] + s2 * gv[it][3];
-            f3 = fv[it][2] - a; f2 = fv[it][2] + a; g3 = gv[it][2] - b2; g2 = gv[it][2] + b2;
-            b2 = s1 * f2 - c1 * g3; a = c1 * f2 + s1 * g3;
-            *fp[it][2] = f0 - a; *fp[it][0] = f0 + a; *gp[it][3] = g1 - b2; *gp[it][1] = g1 + b2;
-            b2 = c1 * g2 - s1 * f3; a = s1 * g2 + c1 * f3;
-            *gp[it][2] = g0 - a; *gp[it][0] = g0 + a; *fp[it][3] = f1 - b2; *fp[it][1] = f1 + b2;
-        }
-    if (on[2]) {
-        if (NB == 2) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) { fv[2][q] = *fp[2][q]; gv[2][q] = *gp[2][q]; }
-        }
-        double f1 = fv[2][0] - fv[2][1], f0 = fv[2][0] + fv[2][1], f3 = fv[2][2] - fv[2][3], f2 = fv[2][2] + fv[2][3];
-        *fp[2][2] = f0 - f2; *fp[2][0] = f0 + f2; *fp[2][3] = f1 - f3; *fp[2][1] = f1 + f3;
-        double g1 = gv[2][0] - gv[2][1], g0 = gv[2][0] + gv[2][1], g3 = SQRT2 * gv[2][3], g2 = SQRT2 * gv[2][2];
-        *gp[2][2] = g0 - g2; *gp[2][0] = g0 + g2; *gp[2][3] = g1 - g3; *gp[2][1] = g1 + g3;
-    }
-#else
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         const int g = lane + 64 * it;
@@ -157,7 +101,6 @@ TL_FN void tl_fht_pass(double *x, const double (&t)[8], int lane)
         double g1 = *g0p - *g1p, g0 = *g0p + *g1p, g3 = SQRT2 * *g3p, g2 = SQRT2 * *g2p;
         *g2p = g0 - g2; *g0p = g0 + g2; *g3p = g1 - g3; *g1p = g1 + g3;
     }
-#endif
 }
 
 // Hann window of samples [t-192, t+832) + FHT + energy (psycho_1.c:57-76,215-239, fft.c:1278-1293).

@@ -29,17 +29,6 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
     if (TL_P2_LEVEL >= 7) return;                                    // diagnostic builds only (mp2_wave.h)
     {
         TL_STAMP(sq, 0);
-#if TL_P2_PARK
-        // The transform does not look at the prediction state; c[] / fthr[] (px) is dead until the line loop.  The state of two passes ago
-        // (r2: 16 registers) waits there while the transform runs, which is what lets its passes read the operands of both general butterflies
-        // ahead of their stores (TL_FHT_READS_FIRST 2, csrc/mp2_fht.h) without spilling.
-        TL_LANES_BEGIN
-#ifndef TL_EMULATE
-#pragma unroll
-#endif
-        for (int q = 0; q < 8; q++) cw[lane + 64 * q] = L(r2)[q];
-        TL_LANES_END
-#endif
         PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
         TL_LANES_BEGIN
         {
@@ -81,14 +70,6 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
         TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), T, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
         TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
         TL_LANES_BEGIN tl_fht_pass<8>(x, L(twa), lane); TL_LANES_END
-#if TL_P2_PARK
-        TL_LANES_BEGIN
-#ifndef TL_EMULATE
-#pragma unroll
-#endif
-        for (int q = 0; q < 8; q++) L(r2)[q] = cw[lane + 64 * q];
-        TL_LANES_END
-#endif
         TL_STAMP(sq, 1);
         // energy + phase (fft.c:1246-1275), unpredictability (psycho_2.c:119-140).
         // 64 lines per step: the transform is read through the layout map first, then the step's energies are written in
@@ -117,7 +98,6 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                 if (it == 0) { r_o5 = l5[0]; r_n5 = l5[1]; p_o5 = l5[2]; p_n5 = l5[3]; }
                 const double a = L(xa), b = L(xb);
                 if (TL_P2_LEVEL >= 6) { L(r1)[it] = a; L(p1)[it] = b; continue; }   // diagnostic: the transform alone, kept alive through the state
-#if TL_P2_PHASED
                 // The step in FIVE stretches with scheduling fences between them (tl_libm.h: tlm_atan2_head / _mid / _tail, tlm_sincos_reduce /
                 // _poly / _finish).  Every routine here ends in a table row -- the arctangent's in L1 / L2, the two sincos rows in LDS -- and the
                 // compiler, left alone, requests a row a handful of instructions before it waits for it: under the round-5 kernel a wave
@@ -126,82 +106,63 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                 // (2) the second quotient, form A, both polynomial sets of the predicted phase -- ~75 operations no row enters;
                 // (3) form B -> this pass's phase, the predicted phase's sine / cosine, the phase's own reduction, its row requested;
                 // (4) its polynomial sets and the square root of the energy; (5) its sine / cosine and the unpredictability measure.
-                constexpr bool full = !SEED && TL_P2_LEVEL < 5;
-                const TlmAtanA at = tlm_atan2_head(-a, b);
-                const uint64_t *arow = tlm_atan_cij + 7 * at.i;
-                const double c0 = tl_u2d(arow[0]), c1 = tl_u2d(arow[1]), c2 = tl_u2d(arow[2]), c3 = tl_u2d(arow[3]), c4 = tl_u2d(arow[4]),
-                             c5 = tl_u2d(arow[5]), c6 = tl_u2d(arow[6]);
+                // (TL_P2_SUB, diagnostic builds only: 1 = no sincos of the predicted phase, 2 = no sincos at all, 3 = no arctangent, 4 = no square roots / division)
+                constexpr bool full = !SEED && TL_P2_LEVEL < 5, sc2 = full && TL_P2_SUB != 1 && TL_P2_SUB != 2, sc1 = full && TL_P2_SUB != 2;
+                TlmAtanA at = {}; TlmAtanB am = {};
+                double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0;
+                if (TL_P2_SUB != 3) {
+                    at = tlm_atan2_head(-a, b);
+                    const uint64_t *arow = tlm_atan_cij + 7 * at.i;
+                    c0 = tl_u2d(arow[0]); c1 = tl_u2d(arow[1]); c2 = tl_u2d(arow[2]); c3 = tl_u2d(arow[3]); c4 = tl_u2d(arow[4]); c5 = tl_u2d(arow[5]); c6 = tl_u2d(arow[6]);
+                }
                 double e = (a * a + b * b) / 2.0;
                 TlmSinCosA s2 = {}; TlmSinCosB v2 = {};
                 double q_sn = 0, q_ssn = 0, q_cs = 0, q_ccs = 0, r_prime = 0;
-                if (full) {
+                if (sc2) {
                     s2 = tlm_sincos_reduce(2.0 * L(p1)[it] - L(p2)[it]);
                     q_sn = tl_u2d(sct[s2.row]); q_ssn = tl_u2d(sct[s2.row + 1]); q_cs = tl_u2d(sct[s2.row + 2]); q_ccs = tl_u2d(sct[s2.row + 3]);
                 }
                 TLM_SCHED_FENCE();
-                const TlmAtanB am = tlm_atan2_mid(at);
-                if (full) { v2 = tlm_sincos_poly(s2); r_prime = 2.0 * L(r1)[it] - L(r2)[it]; }
+                if (TL_P2_SUB != 3) am = tlm_atan2_mid(at);
+                if (sc2) v2 = tlm_sincos_poly(s2);
+                if (full) r_prime = 2.0 * L(r1)[it] - L(r2)[it];
                 TLM_SCHED_FENCE();
-                double phi = tlm_atan2_tail(at, am, c0, c1, c2, c3, c4, c5, c6) + 3.14159265358979 / 4;
+                double phi = (TL_P2_SUB == 3 ? b - a : tlm_atan2_tail(at, am, c0, c1, c2, c3, c4, c5, c6)) + 3.14159265358979 / 4;
                 const bool low = e < 0.0005;
                 e = tlm_sel(low, 0.0005, e); phi = tlm_sel(low, 0.0, phi);
                 e = tlm_sel(first, a * a, e); phi = tlm_sel(first, 0.0, phi);      // line 0: energy x_real[0]^2, phase 0
                 double spp = 0, cpp = 0, w_sn = 0, w_ssn = 0, w_cs = 0, w_ccs = 0;
                 TlmSinCosA s1 = {}; TlmSinCosB v1 = {};
-                if (full) {
-                    tlm_sincos_finish(s2, v2, q_sn, q_ssn, q_cs, q_ccs, &spp, &cpp);
+                if (sc2) tlm_sincos_finish(s2, v2, q_sn, q_ssn, q_cs, q_ccs, &spp, &cpp);
+                else if (full) { spp = L(p1)[it] + L(p2)[it]; cpp = r_prime; }
+                if (sc1) {
                     s1 = tlm_sincos_reduce(tlm_sel(first, 2.0 * p_o5 - p_n5, phi));
                     w_sn = tl_u2d(sct[s1.row]); w_ssn = tl_u2d(sct[s1.row + 1]); w_cs = tl_u2d(sct[s1.row + 2]); w_ccs = tl_u2d(sct[s1.row + 3]);
                 }
                 TLM_SCHED_FENCE();
-                const double rn = tlm_sqrt_ns(e);                    // e >= 0.0005, or line 0's x^2 (zero included): far from the exponent limits
-                if (full) v1 = tlm_sincos_poly(s1);
+                const double rn = TL_P2_SUB == 4 ? e + 1.0 : tlm_sqrt_ns(e);       // e >= 0.0005, or line 0's x^2 (zero included): far from the exponent limits
+                if (sc1) v1 = tlm_sincos_poly(s1);
                 TLM_SCHED_FENCE();
                 double spp5 = 0, cpp5 = 0;
                 if (full) {
-                    double sp, cp;
-                    tlm_sincos_finish(s1, v1, w_sn, w_ssn, w_cs, w_ccs, &sp, &cp);
+                    double sp = phi, cp = rn;
+                    if (sc1) tlm_sincos_finish(s1, v1, w_sn, w_ssn, w_cs, w_ccs, &sp, &cp);
                     spp5 = sp; cpp5 = cp;                                // sincos of line 512's predicted phase (lane 0 of step 0)
                     sp = tlm_sel(first, 0.0, sp); cp = tlm_sel(first, 1.0, cp);         // sincos(0.0)
                     const double t1 = rn * cp - r_prime * cpp;
                     const double t2 = rn * sp - r_prime * spp;
                     const double t3 = rn + fabs(r_prime);
                     // (t3 >= sqrt(0.0005) but for line 0; t1^2 + t2^2 is zero or above 1e-70: the unscaled square root and division, tl_libm.h)
-                    cw[j] = tlm_sel(t3 != 0, tlm_div_ns(tlm_sqrt_ns(t1 * t1 + t2 * t2), t3), 0.0);
+                    cw[j] = TL_P2_SUB == 4 ? t1 * t1 + t2 * t2 + t3 : tlm_sel(t3 != 0, tlm_div_ns(tlm_sqrt_ns(t1 * t1 + t2 * t2), t3), 0.0);
                     x[j] = e;
                 }
-#else
-                double e = (a * a + b * b) / 2.0;
-                const bool low = e < 0.0005;
-                double phi = (TL_P2_SUB == 3 ? b - a : tlm_atan2_sl<false>(-a, b, tlm_atan_cij)) + 3.14159265358979 / 4;
-                e = TL_SELECT(low, 0.0005, e); phi = TL_SELECT(low, 0.0, phi);
-                e = TL_SELECT(first, a * a, e); phi = TL_SELECT(first, 0.0, phi);      // line 0: energy x_real[0]^2, phase 0
-                const double rn = TL_P2_SUB == 4 ? e + 1.0 : TL_P2_NS ? tlm_sqrt_ns(e) : sqrt(e);     // e >= 0.0005, or line 0's x^2 (zero included): far from the exponent limits
-                double spp5 = 0, cpp5 = 0;
-                if (!SEED && TL_P2_LEVEL < 5) {
-                    const double r_prime = 2.0 * L(r1)[it] - L(r2)[it];
-                    const double phi_prime = 2.0 * L(p1)[it] - L(p2)[it];
-                    double sp, cp, spp, cpp;
-                    if (TL_P2_SUB == 2) { sp = phi; cp = rn; } else tlm_sincos_sl(TL_SELECT(first, 2.0 * p_o5 - p_n5, phi), &sp, &cp, sct);
-                    if (TL_P2_SUB == 1 || TL_P2_SUB == 2) { spp = phi_prime; cpp = r_prime; } else tlm_sincos_sl(phi_prime, &spp, &cpp, sct);
-                    spp5 = sp; cpp5 = cp;                                // sincos of line 512's predicted phase (lane 0 of step 0)
-                    sp = TL_SELECT(first, 0.0, sp); cp = TL_SELECT(first, 1.0, cp);         // sincos(0.0)
-                    const double t1 = rn * cp - r_prime * cpp;
-                    const double t2 = rn * sp - r_prime * spp;
-                    const double t3 = rn + fabs(r_prime);
-                    // (t3 >= sqrt(0.0005) but for line 0; t1^2 + t2^2 is zero or above 1e-70: the unscaled square root and division, tl_libm.h)
-                    cw[j] = TL_P2_SUB == 4 ? t1 * t1 + t2 * t2 + t3 : !TL_P2_NS ? (t3 != 0 ? sqrt(t1 * t1 + t2 * t2) / t3 : 0) :
-                            TL_SELECT(t3 != 0, tlm_div_ns(tlm_sqrt_ns(t1 * t1 + t2 * t2), t3), 0.0);
-                    x[j] = e;
-                }
-#endif
                 L(r2)[it] = L(r1)[it]; L(r1)[it] = rn; L(p2)[it] = L(p1)[it]; L(p1)[it] = phi;
                 if (it == 0) {                                       // line 512 (psycho_2.c:110-140 with fft.c:1274's phase), finished by lane 0
                     const double c5 = L(xc);
                     const double e5 = c5 * c5;
                     const bool neg5 = (tl_d2u(c5) >> 63) != 0;       // atan2(+0.0, x) = pi for x < 0 and x = -0, else +0
                     const double phi5 = neg5 ? tl_u2d(0x400921fb54442d18ull) : 0.0;
-                    const double rn5 = TL_P2_NS ? tlm_sqrt_ns(e5) : sqrt(e5);
+                    const double rn5 = tlm_sqrt_ns(e5);
                     double c512 = 0;
                     if (!SEED) {
                         const double sp5 = neg5 ? tl_u2d(0x3ca1a62633145c07ull) : 0.0, cp5 = neg5 ? -1.0 : 1.0;   // glibc's sincos of that pi / of 0
@@ -209,7 +170,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                         const double t15 = rn5 * cp5 - r_prime5 * cpp5;
                         const double t25 = rn5 * sp5 - r_prime5 * spp5;
                         const double t35 = rn5 + fabs(r_prime5);
-                        c512 = !TL_P2_NS ? (t35 != 0 ? sqrt(t15 * t15 + t25 * t25) / t35 : 0) : TL_SELECT(t35 != 0, tlm_div_ns(tlm_sqrt_ns(t15 * t15 + t25 * t25), t35), 0.0);
+                        c512 = tlm_sel(t35 != 0, tlm_div_ns(tlm_sqrt_ns(t15 * t15 + t25 * t25), t35), 0.0);
                     }
                     if (first) { l5[0] = rn5; l5[1] = r_o5; l5[2] = phi5; l5[3] = p_o5; if (!SEED) cw[512] = c512; }
                     L(e512) = e5;                                    // slot 512 of the transform buffer still holds a point step 7 reads
@@ -231,7 +192,6 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
         const double *energy = x;
         // the lane's first sixteen spreading coefficients (two batches of TL_P2_B), requested here, used after the partition sums
         PA(double, sva, TL_P2_B); PA(double, svb, TL_P2_B);
-        if (TL_P2_SPREAD_BAND) {
         TL_LANES_BEGIN
         {
             const double *sb = &P->s_band[0][0];
@@ -242,7 +202,6 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
             for (int q = 0; q < TL_P2_B; q++) { L(sva)[q] = sb[64 * q + lane]; L(svb)[q] = sb[64 * (TL_P2_B + q) + lane]; }
         }
         TL_LANES_END
-        }
         // grouped energy / weighted unpredictability per partition (psycho_2.c:146-155)
         TL_LANES_BEGIN
         {
@@ -250,7 +209,6 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
             if (lane < P->npart) {
                 const int lo = P->part_lo[lane], hi = P->part_hi[lane];
                 int j = lo;
-#if TL_P2_PART_PIPE
                 // four lines' operands per LDS round trip, summed in line order, the NEXT four requested before these are added: the stage is
                 // a handful of lanes walking up to 77 lines each -- all latency, and a round trip per batch was most of it
                 double ev[4], cv[4];
@@ -270,19 +228,6 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                     for (int q = 0; q < 4; q++) { e += ev[q]; c += ev[q] * cv[q]; }
                     j += 4;
                 }
-#else
-                for (; j + 8 <= hi; j += 8) {                           // eight lines' operands per LDS round trip, summed in line order
-                    double ev[8], cv[8];
-#ifndef TL_EMULATE
-#pragma unroll
-#endif
-                    for (int q = 0; q < 8; q++) { ev[q] = energy[j + q]; cv[q] = cw[j + q]; }
-#ifndef TL_EMULATE
-#pragma unroll
-#endif
-                    for (int q = 0; q < 8; q++) { e += ev[q]; c += ev[q] * cv[q]; }
-                }
-#endif
                 for (; j < hi; j++) { e += energy[j]; c += energy[j] * cw[j]; }
             }
             ge[2 * lane] = e; ge[2 * lane + 1] = c;
@@ -305,16 +250,6 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
         TL_LANES_BEGIN
         {
             double e = 0, c = 0;
-#if !TL_P2_SPREAD_BAND
-#pragma unroll
-            for (int k0 = 0; k0 < 64; k0 += 16) {                   // (round 5's form, kept for A/B builds: all 64 coefficients, sixteen loads in flight per round trip)
-                double sv[16];
-#pragma unroll
-                for (int q = 0; q < 16; q++) sv[q] = P->s_t[k0 + q][lane];
-#pragma unroll
-                for (int q = 0; q < 16; q++) { e += sv[q] * ge[2 * (k0 + q)]; c += sv[q] * ge[2 * (k0 + q) + 1]; }
-            }
-#else
             const double *gel = ge + 2 * P->band_lo[lane];
             const int nbat = (P->band_w + TL_P2_B - 1) / TL_P2_B;         // (uniform)
             double svc[TL_P2_B];
@@ -330,7 +265,6 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
 #undef TL_P2_LOAD
 #undef TL_P2_SUM
             static_assert(TL_P2_BAND == 6 * TL_P2_B, "six batches");
-#endif
             double cb = e != 0 ? c / e : 0;
             if (cb < .05) cb = 0.05; else if (cb > .5) cb = 0.5;
             const double tb = -0.434294482 * tlm_log_pn(cb, tlm_log_tab) - 0.301029996;
@@ -352,14 +286,6 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
         // (all nine lines of a lane at once: as a rolled loop every trip was a load of the partition number, then a dependent LDS read of its
         // permissible noise, then the store -- nine memory round trips in a row for nine maxima; round 6: the table reads of all trips are
         // requested first, then the LDS reads, then the stores -- one round trip of each kind)
-#if !TL_P2_THR_UNROLL
-        TL_LANES_BEGIN
-        for (int j = lane; j <= 512; j += 64) {
-            const double t = nb[P->partition[j]], a = P->absthr[j];
-            cw[j] = t > a ? t : a;
-        }
-        TL_LANES_END
-#else
         TL_LANES_BEGIN
         {
             int pj[9]; double aj[9], tj[9];
@@ -377,7 +303,6 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
             for (int q = 0; q < 9; q++) { const int j = lane + 64 * q; if (j <= 512) cw[j] = tj[q] > aj[q] ? tj[q] : aj[q]; }
         }
         TL_LANES_END
-#endif
         TL_STAMP(sq, 5);
         if (TL_P2_LEVEL >= 1) {
             TL_LANES_BEGIN

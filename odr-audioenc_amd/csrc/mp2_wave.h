@@ -324,34 +324,6 @@ static long tl_dbg_rounds = 0, tl_dbg_tones = 0, tl_dbg_deadheads = 0, tl_dbg_fr
 #ifndef TL_P2_SUB
 #define TL_P2_SUB 0
 #endif
-// A/B switches of the psy-2 kernel (tools/ab_libs.sh): the spreading sums over each partition's band (1) or over all 64 (0: round 5's form);
-// square roots and the division of the line loop without the compiler's exponent scaling (tl_libm.h, 1) or as sqrt() and `/` (0)
-#ifndef TL_P2_SPREAD_BAND
-#define TL_P2_SPREAD_BAND 1
-#endif
-#ifndef TL_P2_NS
-#define TL_P2_NS 1
-#endif
-// ... and the line loop's step in five stretches between scheduling fences (1) or as the plain sequence of the three routines (0)
-#ifndef TL_P2_PHASED
-#define TL_P2_PHASED 1
-#endif
-// ... the partition sums with the next batch of operands requested before the current one is added (1) or batch by batch (0)
-#ifndef TL_P2_PART_PIPE
-#define TL_P2_PART_PIPE 1
-#endif
-// ... the per-line thresholds with all of a lane's table and LDS reads requested before the first store (1) or as a rolled loop (0)
-#ifndef TL_P2_THR_UNROLL
-#define TL_P2_THR_UNROLL 1
-#endif
-// ... the oldest quarter of the prediction state parked in LDS while the transform runs (1) or kept in registers (0)
-#ifndef TL_P2_PARK
-#define TL_P2_PARK 0
-#endif
-// A/B switch of the transform (mp2_fht.h, tl_fht_pass): all of a lane's operands of a pass read before its first store (1), or butterfly by butterfly (0)
-#ifndef TL_FHT_READS_FIRST
-#define TL_FHT_READS_FIRST 0
-#endif
 #define TL_DBMIN (-200.0)
 #define TL_POWERNORM 90.3090
 #define TL_T_NOISE 10

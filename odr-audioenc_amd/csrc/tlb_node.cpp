@@ -167,7 +167,7 @@ void shard_identify(Shard &s)
 {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, s.device) != hipSuccess) { snprintf(s.device_name, sizeof s.device_name, "device %d (no properties)", s.device); return; }
-    snprintf(s.device_name, sizeof s.device_name, "%s", p.name);
+    snprintf(s.device_name, sizeof s.device_name, "%s%s%s", p.name, p.name[0] ? " " : "", p.gcnArchName);     // (some boxes report no marketing name: the ISA name says what it is)
     snprintf(s.pci, sizeof s.pci, "%04x:%02x:%02x.0", (unsigned)p.pciDomainID, (unsigned)p.pciBusID, (unsigned)p.pciDeviceID);
     for (int i = 0; i < 16; i++) snprintf(s.uuid + 2 * i, 3, "%02x", (unsigned)(unsigned char)p.uuid.bytes[i]);
     s.num_cu = p.multiProcessorCount;

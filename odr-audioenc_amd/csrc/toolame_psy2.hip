@@ -5,11 +5,6 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "mp2_host.h"
-// (the transform's passes butterfly by butterfly here: with the operands of two or three butterflies read ahead of the first store the run's
-// 64 registers of prediction state spill -- 10 / 78 registers; csrc/mp2_fht.h)
-#ifndef TL_FHT_READS_FIRST
-#define TL_FHT_READS_FIRST 0
-#endif
 #include "mp2_wave.h"
 #include "tl_kernel_util.h"
 
