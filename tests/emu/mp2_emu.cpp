@@ -176,6 +176,9 @@ int emu_psy2_table(long samplerate, int psy, const char *name, double *out, int 
     else if (f == "part_hi") v.assign(P.part_hi, P.part_hi + 64);
     else if (f == "partition") v.assign(P.partition, P.partition + 513);
     else if (f == "npart") v.assign(1, (double)P.npart);
+    else if (f == "band_w") v.assign(1, (double)P.band_w);
+    else if (f == "band_lo") v.assign(P.band_lo, P.band_lo + 64);
+    else if (f == "s_band") { v.resize(TL_P2_BAND * 64); for (int q = 0; q < TL_P2_BAND; q++) for (int j = 0; j < 64; j++) v[(size_t)j * TL_P2_BAND + q] = P.s_band[q][j]; }   // [j][q]
     else return -1;
     len = (int)v.size();
     if (n < len) return -1;

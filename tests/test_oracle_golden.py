@@ -196,3 +196,35 @@ def test_baseline_configs0_2000_frames_oracle_equals_live_reference():
         data, lens = O.oracle_stream(pcm, mode=mode, psy=1)
         assert data == ref["data"] and lens == ref["lens"], mode
         assert len(data) == 2000 * 384
+
+
+def test_spreading_bands_hold_every_nonzero_coefficient_of_the_partitions_that_exist():
+    """Round 6: the psy-2 kernel sums the spreading function over each partition's BAND (TlPsy2Tables::s_band, csrc/mp2_host.cpp tl_psy2_band) instead
+    of over all 64 columns.  For every table the device path builds (six rates x models 2 / 4): the window [band_lo, band_lo + window) of row j holds
+    EXACTLY row j's coefficients, every coefficient outside it that belongs to a partition that exists is zero (so the sums lose nothing: a zero
+    coefficient adds +0 to a sum of non-negative terms), the window stays inside the 64 columns and is a whole number of batches."""
+    import emulib
+    E = emulib.lib()
+    E.emu_psy2_table.argtypes = [C.c_long, C.c_int, C.c_char_p, C.c_void_p, C.c_int]
+
+    def tab(fs, psy, name, n):
+        buf = np.zeros(n)
+        got = E.emu_psy2_table(fs, psy, name.encode(), buf.ctypes.data, buf.size)
+        assert got > 0, name
+        return buf[:got]
+    for psy in (2, 4):
+        for fs in (48000, 44100, 32000, 24000, 22050, 16000):
+            s = tab(fs, psy, "s", 4096).reshape(64, 64)
+            npart, w = int(tab(fs, psy, "npart", 4)[0]), int(tab(fs, psy, "band_w", 4)[0])
+            lo = tab(fs, psy, "band_lo", 64).astype(int)
+            sb = tab(fs, psy, "s_band", 48 * 64).reshape(64, 48)
+            window = (w + 7) // 8 * 8
+            assert 0 < w <= window <= 48 and (psy == 4 or w > 32), (psy, fs, w)
+            for j in range(64):
+                assert 0 <= lo[j] and lo[j] + window <= 64
+                assert np.array_equal(sb[j, :window].view(np.uint64), s[j, lo[j]:lo[j] + window].view(np.uint64)), (psy, fs, j)
+                assert not sb[j, window:].any()
+                outside = np.ones(64, bool)
+                outside[lo[j]:lo[j] + window] = False
+                outside[npart:] = False                          # columns of partitions that do not exist multiply an exact +0 grouped energy
+                assert not s[j, outside].any(), (psy, fs, j)
