@@ -28,6 +28,8 @@ def M():
 
 @pytest.fixture(scope="module")
 def FI(M):
+    if not M.FAULT_LIB_PATH.exists():              # (a checkout without built artefacts: the test build is one `make fault` away -- host files only)
+        M.build()
     return M.load_fault_library()
 
 
