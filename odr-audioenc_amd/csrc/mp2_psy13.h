@@ -1338,7 +1338,12 @@ TL_FN void tl_psy3_back(TlPsyLds &w, const double *TL_RESTRICT db, const TlConfi
     // lines 128..135: the tone sum and the noise sum of a line are independent chains (psycho_3.c:350-395), so
     // lanes 0..7 run the tone chains and lanes 8..15 the noise chains of the eight lines side by side
     TL_LANES_BEGIN
+#if TL_P3_NOTAIL
+    if (lane < 16) w.nsum[lane] = TL_DBMIN;                           // diagnostic builds only (tools/variant_hip.sh notail): what the eight top lines cost
+    if (false) {
+#else
     if (lane < 16) {
+#endif
         const int j = 128 + (lane & 7), line = C->p3_subset[j];
         const double bj = bark[line];
         const TlMasker *mk = TL_MK4(w);

@@ -324,6 +324,10 @@ static long tl_dbg_rounds = 0, tl_dbg_tones = 0, tl_dbg_deadheads = 0, tl_dbg_fr
 #ifndef TL_P2_SUB
 #define TL_P2_SUB 0
 #endif
+// ... and for psy model 3: TL_P3_NOTAIL = 1 leaves out the threshold chains of the eight top subset lines (tl_psy3_back), to measure them
+#ifndef TL_P3_NOTAIL
+#define TL_P3_NOTAIL 0
+#endif
 #define TL_DBMIN (-200.0)
 #define TL_POWERNORM 90.3090
 #define TL_T_NOISE 10
