@@ -362,8 +362,8 @@ typedef struct {
     long steps;                    /* COMPLETED steps: ticks waited for (TICK) / encode calls retired by tlb_node_sync (BATCH); total record: the minimum over the shards */
     long frames;                   /* (stream, frame) pairs of the completed steps: sum of nstreams * frames per step (steps a shard lost by breaking are not counted) */
     double busy_ns;                /* host clock, this shard: submit (TICK) / the oldest queued encode call (BATCH) -> its results waited for (synced), summed; two ticks in flight overlap; total: the maximum */
-    double device_ms;              /* device clock.  TICK: tlb_tick_last_ms() summed over the ticks.  BATCH: tlb_last_kernel_ms() of the MOST RECENT launch at
-                                      every tlb_node_sync -- a lower bound when several encode calls were queued per sync (one pair of events per batch).  total: the maximum */
+    double device_ms;              /* device clock, summed over the completed steps.  TICK: tlb_tick_last_ms() of every tick.  BATCH: every queued encode call has its own
+                                      pair of events on the shard's stream (first kernel queued -> last kernel done), added up at tlb_node_sync.  total: the maximum */
     double wall_ns;                /* total record only: first submit -> last wait as the node saw them, summed over steps */
 } tlb_node_counter;
 /* health and identity of one shard (tlb_node_shard_status) */

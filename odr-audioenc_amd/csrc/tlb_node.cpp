@@ -46,6 +46,10 @@ struct Shard : TlbMailbox {
     double busy_ns = 0, device_ms = 0;
     std::deque<double> t_submit;                 // host clock of the steps in flight
     std::deque<long> f_submit;                   // their (stream, frame) pairs
+    // BATCH plane: one pair of timing events per queued encode call (recorded on the shard's stream around the launch), summed at sync:
+    // device_ms is the device time of EVERY step, however many were queued per sync
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::deque<std::pair<hipEvent_t, hipEvent_t>> ev_flight;
     // health (fault isolation): a shard whose device call failed is BROKEN -- skipped by every node-wide call, its accessors answer
     // NULL / 0 -- until tlb_node_shard_restart() has made it a fresh object; the other shards never notice
     bool broken = false;
@@ -67,6 +71,8 @@ struct Shard : TlbMailbox {
         broken = true; last_err = rc; failures++;
         lost_steps += (long)t_submit.size();                        // what was in flight is lost with it; the queues are emptied so that the
         t_submit.clear(); f_submit.clear();                         // counters stay those of completed steps
+        for (auto &e : ev_flight) ev_pool.push_back(e);
+        ev_flight.clear();
         return rc;
     }
     bool live() const { return !broken && (tick || batch); }
@@ -159,6 +165,10 @@ void shard_unmake(Shard &s)
     if (s.tick) tlb_tick_destroy(s.tick);
     if (s.batch) tlb_destroy(s.batch);
     if (s.stream) (void)hipStreamDestroy(s.stream);
+    for (auto &e : s.ev_flight) s.ev_pool.push_back(e);
+    s.ev_flight.clear();
+    for (auto &e : s.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    s.ev_pool.clear();
     s.tick = nullptr; s.batch = nullptr; s.stream = nullptr;
     s.t_submit.clear(); s.f_submit.clear();
 }
@@ -527,8 +537,16 @@ int tlb_node_encode_device(tlb_node *nd, const int16_t *const *d_pcm, int nframe
     const int rc = nd->live("tlb_encode_device_len", [&](Shard &s) {
         const int g = s.index;
         const double t = now_ns();
-        if (int r = tlb_encode_device_len(s.batch, d_pcm[g], nframes, d_xpad ? d_xpad[g] : nullptr, d_xpad_len ? d_xpad_len[g] : nullptr,
-                                          d_out[g], d_out_len ? d_out_len[g] : nullptr, s.stream)) return r;
+        if (hipSetDevice(s.device) != hipSuccess) return (int)TLB_ERR_HIP;
+        std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+        if (!s.ev_pool.empty()) { ev = s.ev_pool.back(); s.ev_pool.pop_back(); }
+        else if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) return (int)TLB_ERR_HIP;
+        int r = hipEventRecord(ev.first, s.stream) == hipSuccess ? 0 : (int)TLB_ERR_HIP;
+        if (!r) r = tlb_encode_device_len(s.batch, d_pcm[g], nframes, d_xpad ? d_xpad[g] : nullptr, d_xpad_len ? d_xpad_len[g] : nullptr,
+                                          d_out[g], d_out_len ? d_out_len[g] : nullptr, s.stream);
+        if (!r && hipEventRecord(ev.second, s.stream) != hipSuccess) r = (int)TLB_ERR_HIP;
+        if (r) { s.ev_pool.push_back(ev); return r; }
+        s.ev_flight.push_back(ev);
         s.t_submit.push_back(t); s.f_submit.push_back((long)s.n * nframes);
         return 0;
     });
@@ -549,8 +567,12 @@ int tlb_node_sync(tlb_node *nd)
         if (!s.t_submit.empty()) {
             // launches of one shard run in order on its stream: what is in flight is busy from the oldest submit to now
             s.busy_ns += t - s.t_submit.front();
-            const float ms = tlb_last_kernel_ms(s.batch);          // the most recent launch only: with several queued per sync a LOWER BOUND (the header says so)
-            if (ms > 0) s.device_ms += ms;
+            for (auto &e : s.ev_flight) {                           // every queued launch has its own pair of events: the sum is exact
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess && ms > 0) s.device_ms += ms;
+                s.ev_pool.push_back(e);
+            }
+            s.ev_flight.clear();
             while (!s.t_submit.empty()) { s.frames += s.f_submit.front(); s.steps++; s.t_submit.pop_front(); s.f_submit.pop_front(); }
         }
         return 0;

@@ -189,6 +189,29 @@ def test_node_parallel_runs_on_every_shard_thread(M):
     assert len({seen[g][2] for g in range(3)}) == 3 and threading.get_ident() not in {seen[g][2] for g in range(3)}
 
 
+def test_batch_plane_device_clock_sums_every_queued_step(M):
+    """the BATCH plane's device_ms is the device time of EVERY completed step: each queued encode call has its own pair of events on
+    the shard's stream (include/toolame_batch.h, tlb_node_counter.device_ms).  Four calls queued behind ONE sync cost about four times
+    one call's device time -- with only the last launch's figure (round 5) the two would read the same."""
+    cfgs = _cfgs(M, [(48000, "s", 128, 1)] * 512)
+    pcm = np.stack([gen_pcm(77 + (s & 7), 0, 0, 4) for s in range(512)], axis=1)
+    nd = M.Node(cfgs, devices=(0, 0), plane="batch")
+    nd.upload(pcm)
+    nd.encode_resident(); nd.sync()                                 # warm (tables, first-launch costs)
+    base = nd.counters()[1]["device_ms"]
+    nd.encode_resident(); nd.sync()
+    one = nd.counters()[1]["device_ms"] - base
+    base += one
+    for _ in range(4):
+        nd.encode_resident()
+    nd.sync()
+    per, tot = nd.counters()
+    four = tot["device_ms"] - base
+    nd.close()
+    assert one > 0 and 2.5 * one < four < 8 * one, (one, four)
+    assert all(p["steps"] == 6 and p["frames"] == 6 * 4 * 256 for p in per)
+
+
 def _bench(*args, timeout=900):
     import json
     import subprocess
