@@ -16,7 +16,7 @@
 // anywhere: two SEED passes (transform, square root, arctangent -- no unpredictability, nothing after it) over the 1152
 // samples before it rebuild exactly the state the chain would have carried there.  During a run the state lives in the wave's
 // REGISTERS: line lane + 64 it in slot `it` of r1/p1 (previous pass) and r2/p2 (the pass before), line 512 in four LDS words.
-#define TL_P2_L512(w) ((w).px + 516)     /* r1, r2, p1, p2 of line 512 (c[] / fthr[] end at px[512]) */
+#define TL_P2_L512(w) ((w).px + 532)     /* r1, r2, p1, p2 of line 512 (c[] ends at px[512], the padded fthr[] at px[528]) */
 template <bool SEED>
 TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_RESTRICT P, const TlPcmView &pv, int ch, int pass,
                         PARGA(double, r1, 8), PARGA(double, r2, 8), PARGA(double, p1, 8), PARGA(double, p2, 8),
@@ -215,6 +215,9 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                 if (j + 4 <= hi) {
 #pragma unroll
                     for (int q = 0; q < 4; q++) { ev[q] = energy[j + q]; cv[q] = cw[j + q]; }
+#ifndef TL_EMULATE
+#pragma unroll 2
+#endif
                     for (; j + 8 <= hi; j += 4) {
                         double en[4], cn[4];
 #pragma unroll
@@ -286,6 +289,11 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
         // (all nine lines of a lane at once: as a rolled loop every trip was a load of the partition number, then a dependent LDS read of its
         // permissible noise, then the store -- nine memory round trips in a row for nine maxima; round 6: the table reads of all trips are
         // requested first, then the LDS reads, then the stores -- one round trip of each kind)
+        // Both arrays the subband stage walks are laid out PADDED here -- line j at index j + (j >> 5) = lane + (lane >> 5) + 66 q: a subband's
+        // lane starts 16 lines after its neighbour's, 128 bytes, one LDS bank pair for all 32 of them; with one slot of padding per 32 lines
+        // the 32 starts fall on 32 different bank pairs.  The thresholds are written that way; the energies are moved in place (all nine
+        // reads of every lane before the first write; the partition sums above them are dead).
+        PA(double, ej, 9);
         TL_LANES_BEGIN
         {
             int pj[9]; double aj[9], tj[9];
@@ -296,11 +304,21 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-            for (int q = 0; q < 9; q++) tj[q] = nb[pj[q]];
+            for (int q = 0; q < 9; q++) { tj[q] = nb[pj[q]]; L(ej)[q] = energy[lane + 64 * q < 512 ? lane + 64 * q : 512]; }
+            const int jp = lane + (lane >> 5);
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-            for (int q = 0; q < 9; q++) { const int j = lane + 64 * q; if (j <= 512) cw[j] = tj[q] > aj[q] ? tj[q] : aj[q]; }
+            for (int q = 0; q < 9; q++) { if (lane + 64 * q <= 512) cw[jp + 66 * q] = tj[q] > aj[q] ? tj[q] : aj[q]; }
+        }
+        TL_LANES_END
+        TL_LANES_BEGIN
+        {
+            const int jp = lane + (lane >> 5);
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int q = 0; q < 9; q++) { if (lane + 64 * q <= 512) x[jp + 66 * q] = L(ej)[q]; }
         }
         TL_LANES_END
         TL_STAMP(sq, 5);
@@ -310,17 +328,27 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
             TL_LANES_END
             return;
         }
-        // 32 subbands (psycho_2.c:227-246)
+        // 32 subbands (psycho_2.c:227-246): lanes 0..31 walk a subband's 17 thresholds (their minimum below subband 13, their sum above),
+        // lanes 32..63 the same subband's 17 energies, both in line order from the padded arrays; the energy sums cross over through LDS
+        PV(double, sb_min); PV(double, sb_sum);
+        TL_LANES_BEGIN
+        {
+            const int sb = lane & 31;
+            const double *a = (lane < 32 ? cw : x) + 16 * sb + (sb >> 1);
+            double m = 60802371420160.0, t = 0.0;
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int k = 0; k < 16; k++) { const double v = a[k]; m = TLM_MIN_NN(m, v); t += v; }
+            { const double v = a[16 + (sb & 1)]; m = TLM_MIN_NN(m, v); t += v; }
+            L(sb_min) = m; L(sb_sum) = t;
+            if (lane >= 32) nb[sb] = t;
+        }
+        TL_LANES_END
         TL_LANES_BEGIN
         if (lane < 32) {
-            const int j = 16 * lane;
-            double minthres = lane < 13 ? 60802371420160.0 : 0.0, sum_energy = 0.0;
-            for (int k = 0; k < 17; k++) {
-                if (lane < 13) { if (minthres > cw[j + k]) minthres = cw[j + k]; }
-                else minthres += cw[j + k];
-                sum_energy += energy[j + k];
-            }
-            double snr = lane < 13 ? sum_energy / (minthres * 17.0) : sum_energy / minthres;
+            const double sum_energy = nb[lane];
+            double snr = lane < 13 ? sum_energy / (L(sb_min) * 17.0) : sum_energy / L(sb_sum);
             snr = 4.342944819 * tlm_log_pn(snr, tlm_log_tab);
             if (pass == 0) L(snr0) = snr;
             else smr_out[lane] = L(snr0) > snr ? L(snr0) : snr;

@@ -385,7 +385,7 @@ struct TlMainLds {
 // Per-wave LDS of the psy kernel of models 2 and 4: the transform / energies (partition sums in its dead upper half) and c[] / fthr[].
 struct alignas(16) TlPsy2Lds {       // (16: the partition sums are read as pairs, tl_psy2_pass)
     struct { double fft[1024]; } u;
-    double px[520];
+    double px[536];                  // (513 lines + one slot of padding per 32: tl_psy2_pass lays fthr[] out for the subband walk)
 };
 // Per-wave LDS of the psy kernel (models 1 and 3).
 struct TlPsyLds {

@@ -91,6 +91,20 @@ __device__ inline __attribute__((always_inline)) double tlm_fma_k_(double a, dou
 #else
 #define TLM_FMA_K(a, b, bits) TLM_FMA((a), (b), TLM_D(bits))
 #endif
+// TLM_MIN_NN(a, b): the smaller of two numbers, NEITHER a NaN (the caller's precondition): `b < a ? b : a` in one v_min_f64.  Through
+// fmin() the compiler first canonicalises every operand that comes from memory (a v_max_f64 x, x each: the instruction quiets signalling
+// NaNs and the language's fmin must not) -- twice the instructions for a case that cannot occur here.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline __attribute__((always_inline)) double tlm_min_nn_(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#define TLM_MIN_NN(a, b) tlm_min_nn_((a), (b))
+#else
+#define TLM_MIN_NN(a, b) ((b) < (a) ? (b) : (a))
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // log (e_log.c).  TAB = {invc, logc}[128] as bit patterns (global table or an LDS copy of it).
