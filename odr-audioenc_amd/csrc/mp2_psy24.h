@@ -153,7 +153,9 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                     const double t2 = rn * sp - r_prime * spp;
                     const double t3 = rn + fabs(r_prime);
                     // (t3 >= sqrt(0.0005) but for line 0; t1^2 + t2^2 is zero or above 1e-70: the unscaled square root and division, tl_libm.h)
-                    cw[j] = TL_P2_SUB == 4 ? t1 * t1 + t2 * t2 + t3 : tlm_sel(t3 != 0, tlm_div_ns(tlm_sqrt_ns(t1 * t1 + t2 * t2), t3), 0.0);
+                    // (stored as the partition sums' TERM energy x c, psycho_2.c:153: one multiplication here with 64 lanes at work instead of
+                    // one per line in the sums, where a handful of lanes walk the wide partitions)
+                    cw[j] = e * (TL_P2_SUB == 4 ? t1 * t1 + t2 * t2 + t3 : tlm_sel(t3 != 0, tlm_div_ns(tlm_sqrt_ns(t1 * t1 + t2 * t2), t3), 0.0));
                     x[j] = e;
                 }
                 L(r2)[it] = L(r1)[it]; L(r1)[it] = rn; L(p2)[it] = L(p1)[it]; L(p1)[it] = phi;
@@ -172,7 +174,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                         const double t35 = rn5 + fabs(r_prime5);
                         c512 = tlm_sel(t35 != 0, tlm_div_ns(tlm_sqrt_ns(t15 * t15 + t25 * t25), t35), 0.0);
                     }
-                    if (first) { l5[0] = rn5; l5[1] = r_o5; l5[2] = phi5; l5[3] = p_o5; if (!SEED) cw[512] = c512; }
+                    if (first) { l5[0] = rn5; l5[1] = r_o5; l5[2] = phi5; l5[3] = p_o5; if (!SEED) cw[512] = e5 * c512; }
                     L(e512) = e5;                                    // slot 512 of the transform buffer still holds a point step 7 reads
                 }
             }
@@ -202,38 +204,62 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
             for (int q = 0; q < TL_P2_B; q++) { L(sva)[q] = sb[64 * q + lane]; L(svb)[q] = sb[64 * (TL_P2_B + q) + lane]; }
         }
         TL_LANES_END
-        // grouped energy / weighted unpredictability per partition (psycho_2.c:146-155)
+        // grouped energy / weighted unpredictability per partition (psycho_2.c:146-155): two chains of additions per partition, each in
+        // line order.  The widest partitions set the stage's length (67 and 77 lines, most others under 10), so the TWO chains of a
+        // partition run on two lanes -- lanes 0..31 add the energies, lanes 32..63 the terms energy x c the line loop has left in c[] --
+        // in two rounds of 32 partitions: the upper 32 first (all the wide ones), then the rest.  Four lines per LDS round trip, the next
+        // four requested before these are added, the batch loop unrolled by two (no register rotation).
         TL_LANES_BEGIN
         {
-            double e = 0, c = 0;
-            if (lane < P->npart) {
-                const int lo = P->part_lo[lane], hi = P->part_hi[lane];
-                int j = lo;
-                // four lines' operands per LDS round trip, summed in line order, the NEXT four requested before these are added: the stage is
-                // a handful of lanes walking up to 77 lines each -- all latency, and a round trip per batch was most of it
-                double ev[4], cv[4];
-                if (j + 4 <= hi) {
+            const int l = lane & 31, half = lane >> 5, np = P->npart;
+            const double *arr = half ? cw : energy;
+            const int p0 = np - 32 + l, p1 = l;
+            const bool ok0 = p0 >= 0, ok1 = p1 < np - 32;
+            const int lo0 = P->part_lo[ok0 ? p0 : 0], hi0 = P->part_hi[ok0 ? p0 : 0], lo1 = P->part_lo[ok1 ? p1 : 0], hi1 = P->part_hi[ok1 ? p1 : 0];
+#ifndef TL_EMULATE
 #pragma unroll
-                    for (int q = 0; q < 4; q++) { ev[q] = energy[j + q]; cv[q] = cw[j + q]; }
+#endif
+            for (int r = 0; r < 2; r++) {
+                const bool ok = r ? ok1 : ok0;
+                const int hi = r ? hi1 : hi0;
+                int j = r ? lo1 : lo0;
+                double acc = 0;
+                if (ok) {
+                    double ev[4];
+                    if (j + 4 <= hi) {
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                        for (int q = 0; q < 4; q++) ev[q] = arr[j + q];
 #ifndef TL_EMULATE
 #pragma unroll 2
 #endif
-                    for (; j + 8 <= hi; j += 4) {
-                        double en[4], cn[4];
+                        for (; j + 8 <= hi; j += 4) {
+                            double en[4];
+#ifndef TL_EMULATE
 #pragma unroll
-                        for (int q = 0; q < 4; q++) { en[q] = energy[j + 4 + q]; cn[q] = cw[j + 4 + q]; }
+#endif
+                            for (int q = 0; q < 4; q++) en[q] = arr[j + 4 + q];
+#ifndef TL_EMULATE
 #pragma unroll
-                        for (int q = 0; q < 4; q++) { e += ev[q]; c += ev[q] * cv[q]; }
+#endif
+                            for (int q = 0; q < 4; q++) acc += ev[q];
+#ifndef TL_EMULATE
 #pragma unroll
-                        for (int q = 0; q < 4; q++) { ev[q] = en[q]; cv[q] = cn[q]; }
+#endif
+                            for (int q = 0; q < 4; q++) ev[q] = en[q];
+                        }
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+                        for (int q = 0; q < 4; q++) acc += ev[q];
+                        j += 4;
                     }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { e += ev[q]; c += ev[q] * cv[q]; }
-                    j += 4;
+                    for (; j < hi; j++) acc += arr[j];
+                    ge[2 * (r ? p1 : p0) + half] = acc;
                 }
-                for (; j < hi; j++) { e += energy[j]; c += energy[j] * cw[j]; }
             }
-            ge[2 * lane] = e; ge[2 * lane + 1] = c;
+            if (np < 64 && lane >= np) { ge[2 * lane] = 0; ge[2 * lane + 1] = 0; }    // (the spreading window may reach past the last partition: zeros, as before)
         }
         TL_LANES_END
         TL_STAMP(sq, 3);
