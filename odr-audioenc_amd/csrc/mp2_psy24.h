@@ -129,24 +129,32 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                 TLM_SCHED_FENCE();
                 double phi = (TL_P2_SUB == 3 ? b - a : tlm_atan2_tail(at, am, c0, c1, c2, c3, c4, c5, c6)) + 3.14159265358979 / 4;
                 const bool low = e < 0.0005;
-                e = tlm_sel(low, 0.0005, e); phi = tlm_sel(low, 0.0, phi);
+                e = TLM_MAX_NN(e, 0.0005); phi = tlm_sel(low, 0.0, phi);
                 e = tlm_sel(first, a * a, e); phi = tlm_sel(first, 0.0, phi);      // line 0: energy x_real[0]^2, phase 0
                 double spp = 0, cpp = 0, w_sn = 0, w_ssn = 0, w_cs = 0, w_ccs = 0;
                 TlmSinCosA s1 = {}; TlmSinCosB v1 = {};
-                if (sc2) tlm_sincos_finish(s2, v2, q_sn, q_ssn, q_cs, q_ccs, &spp, &cpp);
+                // Steps 1..7 need no sine and cosine by NAME: t1^2 + t2^2 below is symmetric in (cosines, sines), so where both phases' quadrants
+                // are of one parity the two raw pairs are used as they come, and where they differ ONE pair is exchanged (the phase's own)
+                if (sc2) { if (it == 0 || !sc1) tlm_sincos_finish(s2, v2, q_sn, q_ssn, q_cs, q_ccs, &spp, &cpp); else tlm_sincos_finish_raw(s2, v2, q_sn, q_ssn, q_cs, q_ccs, &spp, &cpp); }
                 else if (full) { spp = L(p1)[it] + L(p2)[it]; cpp = r_prime; }
                 if (sc1) {
                     s1 = tlm_sincos_reduce(tlm_sel(first, 2.0 * p_o5 - p_n5, phi));
                     w_sn = tl_u2d(sct[s1.row]); w_ssn = tl_u2d(sct[s1.row + 1]); w_cs = tl_u2d(sct[s1.row + 2]); w_ccs = tl_u2d(sct[s1.row + 3]);
                 }
                 TLM_SCHED_FENCE();
-                const double rn = TL_P2_SUB == 4 ? e + 1.0 : tlm_sqrt_ns(e);       // e >= 0.0005, or line 0's x^2 (zero included): far from the exponent limits
+                const double rn = TL_P2_SUB == 4 ? e + 1.0 : it == 0 ? tlm_sqrt_ns(e) : tlm_sqrt_nz(e);   // e >= 0.0005, or line 0's x^2 (step 0; zero included): far from the exponent limits
                 if (sc1) v1 = tlm_sincos_poly(s1);
                 TLM_SCHED_FENCE();
                 double spp5 = 0, cpp5 = 0;
                 if (full) {
                     double sp = phi, cp = rn;
-                    if (sc1) tlm_sincos_finish(s1, v1, w_sn, w_ssn, w_cs, w_ccs, &sp, &cp);
+                    if (sc1 && (it == 0 || !sc2)) tlm_sincos_finish(s1, v1, w_sn, w_ssn, w_cs, w_ccs, &sp, &cp);
+                    else if (sc1) {
+                        double ds, dc;
+                        tlm_sincos_finish_raw(s1, v1, w_sn, w_ssn, w_cs, w_ccs, &ds, &dc);
+                        const bool sw = ((s1.q ^ s2.q) & 1u) != 0;
+                        sp = tlm_sel(sw, dc, ds); cp = tlm_sel(sw, ds, dc);
+                    }
                     spp5 = sp; cpp5 = cp;                                // sincos of line 512's predicted phase (lane 0 of step 0)
                     sp = tlm_sel(first, 0.0, sp); cp = tlm_sel(first, 1.0, cp);         // sincos(0.0)
                     const double t1 = rn * cp - r_prime * cpp;
@@ -155,7 +163,9 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                     // (t3 >= sqrt(0.0005) but for line 0; t1^2 + t2^2 is zero or above 1e-70: the unscaled square root and division, tl_libm.h)
                     // (stored as the partition sums' TERM energy x c, psycho_2.c:153: one multiplication here with 64 lanes at work instead of
                     // one per line in the sums, where a handful of lanes walk the wide partitions)
-                    cw[j] = e * (TL_P2_SUB == 4 ? t1 * t1 + t2 * t2 + t3 : tlm_sel(t3 != 0, tlm_div_ns(tlm_sqrt_ns(t1 * t1 + t2 * t2), t3), 0.0));
+                    // (steps 1..7: t3 >= sqrt(0.0005), no zero divisor to select around)
+                    cw[j] = e * (TL_P2_SUB == 4 ? t1 * t1 + t2 * t2 + t3 : it == 0 ? tlm_sel(t3 != 0, tlm_div_ns(tlm_sqrt_ns(t1 * t1 + t2 * t2), t3), 0.0)
+                                                                               : tlm_div_ns(tlm_sqrt_ns(t1 * t1 + t2 * t2), t3));
                     x[j] = e;
                 }
                 L(r2)[it] = L(r1)[it]; L(r1)[it] = rn; L(p2)[it] = L(p1)[it]; L(p1)[it] = phi;

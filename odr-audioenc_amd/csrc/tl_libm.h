@@ -101,9 +101,17 @@ __device__ inline __attribute__((always_inline)) double tlm_min_nn_(double a, do
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ inline __attribute__((always_inline)) double tlm_max_nn_(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 #define TLM_MIN_NN(a, b) tlm_min_nn_((a), (b))
+#define TLM_MAX_NN(a, b) tlm_max_nn_((a), (b))
 #else
 #define TLM_MIN_NN(a, b) ((b) < (a) ? (b) : (a))
+#define TLM_MAX_NN(a, b) ((a) < (b) ? (b) : (a))
 #endif
 
 // ------------------------------------------------------------------------------------------------------------
@@ -626,6 +634,7 @@ TLM_HD double tlm_sqrt_from(double x, double y)
 }
 TLM_HD double tlm_div_ns(double n, double d) { return tlm_div_by_recip(n, d, tlm_recip_from(d, tlm_rcp_seed(d))); }
 TLM_HD double tlm_sqrt_ns(double x) { const double g = tlm_sqrt_from(x, tlm_rsq_seed(x)); return TLM_SEL(x == 0.0, x, g); }      // (x = 0: the seed is infinite)
+TLM_HD double tlm_sqrt_nz(double x) { return tlm_sqrt_from(x, tlm_rsq_seed(x)); }                                                // x > 0 by the caller's contract
 
 // ------------------------------------------------------------------------------------------------------------
 // Straight-line forms for the device: the lanes of a wave are spread over every branch of the routines above, so
@@ -709,17 +718,26 @@ TLM_HD TlmSinCosB tlm_sincos_poly(const TlmSinCosA &r)
     }
     return p;
 }
-TLM_HD void tlm_sincos_finish(const TlmSinCosA &r, const TlmSinCosB &p, double sn, double ssn, double cs, double ccs, double *sinx, double *cosx)
-{   // phase three: the row's four values against the polynomials, then who gets what
+// phase three: the row's four values against the polynomials -> do_sin's value (signed) and do_cos's (negated in quadrants 2, 3).  In an
+// EVEN quadrant (r.q & 1 == 0) they are the sine and the cosine, in an odd one the cosine and the sine: tlm_sincos_finish hands them out;
+// a caller that only forms symmetric expressions of several pairs can do with fewer exchanges (tl_psy2_pass).
+TLM_HD void tlm_sincos_finish_raw(const TlmSinCosA &r, const TlmSinCosB &p, double sn, double ssn, double cs, double ccs, double *dosin, double *docos)
+{
     const double cosv = cs + (((ccs - p.cs_s * ssn) - cs * p.cs_c) - sn * p.cs_s);
     const double rt = sn + (((ssn + p.sn_s * ccs) - sn * p.sn_c) + cs * p.sn_s);
     // do_sin returns the table value with a's sign; TAYLOR_SIN's value has a's sign by itself -- except for a = -0.0, where it is
     // +0 and s_sincos.c's own |x| < 2^-27 case returns x: one copysign after the select serves both
     const double sel = TLM_SEL(r.aa < 0.126, p.ty, rt);
     const double sinv = tlm_u2d((tlm_d2u(sel) & 0x7fffffffffffffffull) | r.sa);
-    // odd quadrants swap, quadrants 2 and 3 negate the cosine
-    const double c3 = tlm_u2d(tlm_d2u(cosv) ^ ((uint64_t)(r.q & 2u) << 62));
-    const bool odd = (r.q & 1u) != 0;
+    // quadrants 2 and 3 negate the cosine
+    *dosin = sinv;
+    *docos = tlm_u2d(tlm_d2u(cosv) ^ ((uint64_t)(r.q & 2u) << 62));
+}
+TLM_HD void tlm_sincos_finish(const TlmSinCosA &r, const TlmSinCosB &p, double sn, double ssn, double cs, double ccs, double *sinx, double *cosx)
+{
+    double sinv, c3;
+    tlm_sincos_finish_raw(r, p, sn, ssn, cs, ccs, &sinv, &c3);
+    const bool odd = (r.q & 1u) != 0;                                   // odd quadrants swap
     *sinx = TLM_SEL(odd, c3, sinv);
     *cosx = TLM_SEL(odd, sinv, c3);
 }
@@ -830,7 +848,7 @@ TLM_HD TlmAtanA tlm_atan2_head(double y, double x)
     r.ax = tlm_u2d(r.bx & 0x7fffffffffffffffull); r.ay = tlm_u2d(r.by & 0x7fffffffffffffffull);
     r.de = (uy & 0x7ff00000) - (ux & 0x7ff00000);
     r.ylx = r.ay < r.ax;
-    r.num = r.ylx ? r.ay : r.ax; r.den = r.ylx ? r.ax : r.ay;
+    r.num = TLM_MIN_NN(r.ax, r.ay); r.den = TLM_MAX_NN(r.ay, r.ax);    // (= ylx ? ay : ax and ylx ? ax : ay: finite magnitudes, equal where they tie)
     r.rd = tlm_recip_from(r.den, tlm_rcp_seed(r.den));
     r.u = tlm_div_by_recip(r.num, r.den, r.rd);
     int i = (int)(uint32_t)tlm_d2u(TLM_FMA(r.u, 256.0, 0x1p52)) - 16;
