@@ -43,27 +43,31 @@ TL_FN void tl_fht_head(double (&e)[16], const double (*TL_RESTRICT tw)[4])
         e[11] = g0 - a; e[3] = g0 + a; e[13] = f1 - b2; e[5] = f1 + b2;
     }
 }
+TL_FN double *tl_fht_at(double *x, int byte_offset) { return (double *)((char *)x + byte_offset); }
 TL_FN int tl_rev6(int lane) { int r = 0; for (int b = 0; b < 6; b++) r |= ((lane >> b) & 1) << (5 - b); return r; }
 TL_FN void tl_fht_store(double *x, int lane, const double (&e)[16])
 {
-    const int l = tl_rev6(lane), base = (16 * l) ^ (l >> 1);         // FX(16*l + t) = base ^ t for t < 16
+    const int l = tl_rev6(lane), base = ((16 * l) ^ (l >> 1)) << 3;  // FX(16*l + t) = base ^ t for t < 16 (as byte offsets: tl_fht_at)
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-    for (int t = 0; t < 16; t++) x[base ^ t] = e[t];
+    for (int t = 0; t < 16; t++) *tl_fht_at(x, base ^ (t << 3)) = e[t];
 }
-// Twiddles (c1,s1,c2,s2) of the (up to) two general butterflies a lane runs in pass K; fetched one pass ahead.
+// Twiddles (c1,s1,c2,s2) of the (up to) two general butterflies a lane runs in pass K, and where the butterflies are (TlTables::fht_fg_lane:
+// the byte offsets of their points f0 and g0 in the transform buffer, 16 bits each); fetched one pass ahead.
 template <int K>
-TL_FN void tl_fht_twiddles(double (&t)[8], const TlTables *TL_RESTRICT T, int lane)
+TL_FN void tl_fht_twiddles(double (&t)[8], uint32_t (&fg)[2], const TlTables *TL_RESTRICT T, int lane)
 {   // rows in lane order (TlTables::fht_tw_lane): one address per lane, no index arithmetic
     const double (*tw)[4] = T->fht_tw_lane[(K - 4) / 2];
 #pragma unroll
-    for (int it = 0; it < 2; it++)
+    for (int it = 0; it < 2; it++) {
 #pragma unroll
         for (int q = 0; q < 4; q++) t[4 * it + q] = tw[lane + 64 * it][q];
+        fg[it] = T->fht_fg_lane[(K - 4) / 2][lane + 64 * it];
+    }
 }
 template <int K>
-TL_FN void tl_fht_pass(double *x, const double (&t)[8], int lane)
+TL_FN void tl_fht_pass(double *x, const double (&t)[8], const uint32_t (&fg)[2], int lane)
 {   // fft.c:1104-1184: one pass = 128 independent 8-point butterflies: per block of 4*k1 points one with trivial /
     // sqrt(2) twiddles (i = 0) and kx-1 general ones.  The general ones are dealt densely to the lanes and the
     // trivial ones follow in their own step, so a wave never runs both code paths for one batch of butterflies.
@@ -76,12 +80,13 @@ TL_FN void tl_fht_pass(double *x, const double (&t)[8], int lane)
     for (int it = 0; it < 2; it++) {
         const int g = lane + 64 * it;
         if (g >= NGEN) break;
-        const int blk = g / (kx - 1), i = 1 + (g - blk * (kx - 1));
-        const int pb = TL_FX(blk * k4);
         const double c1 = t[4 * it], s1 = t[4 * it + 1], c2 = t[4 * it + 2], s2 = t[4 * it + 3];
-        const int F = pb ^ TL_FX(i), G = pb ^ TL_FX(k1 - i);
-        double *f0p = x + F, *f1p = x + (F ^ q1), *f2p = x + (F ^ q2), *f3p = x + (F ^ q3);
-        double *g0p = x + G, *g1p = x + (G ^ q1), *g2p = x + (G ^ q2), *g3p = x + (G ^ q3);
+        // (byte offsets: an exchange partner's address is (offset ^ constant) + base, ONE v_xad_u32; as indices it is an exclusive-or and then a shift-add)
+        // butterfly g = general butterfly i = 1 + g mod (kx - 1) of block g / (kx - 1): f0 at FX(block * k4) ^ FX(i), g0 at FX(block * k4) ^ FX(k1 - i),
+        // as byte offsets from the table (csrc/mp2_host.cpp tl_build_tables: the division and the layout map are the host's)
+        const int F = (int)(fg[it] & 0xffffu), G = (int)(fg[it] >> 16);
+        double *f0p = tl_fht_at(x, F), *f1p = tl_fht_at(x, F ^ (q1 << 3)), *f2p = tl_fht_at(x, F ^ (q2 << 3)), *f3p = tl_fht_at(x, F ^ (q3 << 3));
+        double *g0p = tl_fht_at(x, G), *g1p = tl_fht_at(x, G ^ (q1 << 3)), *g2p = tl_fht_at(x, G ^ (q2 << 3)), *g3p = tl_fht_at(x, G ^ (q3 << 3));
         double a, b2, g0, f0, f1, g1, f2, g2, f3, g3;
         b2 = s2 * *f1p - c2 * *g1p; a = c2 * *f1p + s2 * *g1p;
         f1 = *f0p - a; f0 = *f0p + a; g1 = *g0p - b2; g0 = *g0p + b2;
@@ -93,9 +98,9 @@ TL_FN void tl_fht_pass(double *x, const double (&t)[8], int lane)
         *g2p = g0 - a; *g0p = g0 + a; *f3p = f1 - b2; *f1p = f1 + b2;
     }
     if (lane < NBLK) {
-        const int F = TL_FX(lane * k4), G = F ^ TL_FX(kx);
-        double *f0p = x + F, *f1p = x + (F ^ q1), *f2p = x + (F ^ q2), *f3p = x + (F ^ q3);
-        double *g0p = x + G, *g1p = x + (G ^ q1), *g2p = x + (G ^ q2), *g3p = x + (G ^ q3);
+        const int F = TL_FX(lane * k4) << 3, G = F ^ (TL_FX(kx) << 3);
+        double *f0p = tl_fht_at(x, F), *f1p = tl_fht_at(x, F ^ (q1 << 3)), *f2p = tl_fht_at(x, F ^ (q2 << 3)), *f3p = tl_fht_at(x, F ^ (q3 << 3));
+        double *g0p = tl_fht_at(x, G), *g1p = tl_fht_at(x, G ^ (q1 << 3)), *g2p = tl_fht_at(x, G ^ (q2 << 3)), *g3p = tl_fht_at(x, G ^ (q3 << 3));
         double f1 = *f0p - *f1p, f0 = *f0p + *f1p, f3 = *f2p - *f3p, f2 = *f2p + *f3p;
         *f2p = f0 - f2; *f0p = f0 + f2; *f3p = f1 - f3; *f1p = f1 + f3;
         double g1 = *g0p - *g1p, g0 = *g0p + *g1p, g3 = SQRT2 * *g3p, g2 = SQRT2 * *g2p;
@@ -118,6 +123,7 @@ TL_FN void tl_psy_spectrum(TlPsyLds &w, const TlTables *TL_RESTRICT T, const TlP
     TL_STAMP(sq, 0);
     // twiddles travel one pass ahead of their use (twc: k=4 with the window, twb: k=6 during pass 4, twa: k=8 during pass 6): two sets live at most
     PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
+    PA(uint32_t, fga, 2); PA(uint32_t, fgb, 2); PA(uint32_t, fgc, 2);
     TL_LANES_BEGIN
     {
         // sample i = lane + 64*it of the analysis window: the last 192 samples of the history (it < 3), then the
@@ -129,7 +135,7 @@ TL_FN void tl_psy_spectrum(TlPsyLds &w, const TlTables *TL_RESTRICT T, const TlP
         // factor and commutes with the rounding of the product (nothing near the subnormal range), so the bits are the same
         const double *hann = T->hann_s;
         TL_LAUNDER(hann);
-        tl_fht_twiddles<4>(L(twc), T, lane);
+        tl_fht_twiddles<4>(L(twc), L(fgc), T, lane);
         double e[16];
         // the sixteen PCM samples are this unit's first touch of its input (HBM, not L2): all of them are requested before anything is
         // used; the window's coefficients (L2) follow in two batches of eight (sixteen doubles more in flight would spill)
@@ -167,9 +173,9 @@ TL_FN void tl_psy_spectrum(TlPsyLds &w, const TlTables *TL_RESTRICT T, const TlP
     TL_STAMP(sq, 1);
     TL_STAMP(sq, 2);
     TL_STAMP(sq, 3);
-    TL_LANES_BEGIN tl_fht_twiddles<6>(L(twb), T, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_twiddles<6>(L(twb), L(fgb), T, lane); tl_fht_pass<4>(x, L(twc), L(fgc), lane); TL_LANES_END
     TL_STAMP(sq, 4);
-    TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), T, lane); tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
+    TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), L(fga), T, lane); tl_fht_pass<6>(x, L(twb), L(fgb), lane); TL_LANES_END
     TL_STAMP(sq, 5);
     // Last pass (k=8) and energies (fft.c:1278-1293) in one go: the eight outputs of a k=8 butterfly are x[i+256q] and
     // x[256-i+256q], and line j pairs with 1024-j -- so butterfly i holds both members of the pairs of lines i, 256-i, 256+i
@@ -185,9 +191,10 @@ TL_FN void tl_psy_spectrum(TlPsyLds &w, const TlTables *TL_RESTRICT T, const TlP
 #endif
         for (int it = 0; it < 2; it++) {
             const int g = lane + 64 * it;                            // general butterflies i = 1 + g (g < 127); g = 127: the trivial one
-            const int F = g < 127 ? TL_FX(1 + g) : 0, G = g < 127 ? TL_FX(k1 - 1 - g) : TL_FX(kx);
-            L(fv)[4 * it] = x[F]; L(fv)[4 * it + 1] = x[F ^ q1]; L(fv)[4 * it + 2] = x[F ^ q2]; L(fv)[4 * it + 3] = x[F ^ q3];
-            L(gv)[4 * it] = x[G]; L(gv)[4 * it + 1] = x[G ^ q1]; L(gv)[4 * it + 2] = x[G ^ q2]; L(gv)[4 * it + 3] = x[G ^ q3];
+            // (byte offsets; the table's entry 127 of this pass is the trivial butterfly: f0 at 0, g0 at FX(kx))
+            const int F = (int)(L(fga)[it] & 0xffffu), G = (int)(L(fga)[it] >> 16);
+            L(fv)[4 * it] = *tl_fht_at(x, F); L(fv)[4 * it + 1] = *tl_fht_at(x, F ^ (q1 << 3)); L(fv)[4 * it + 2] = *tl_fht_at(x, F ^ (q2 << 3)); L(fv)[4 * it + 3] = *tl_fht_at(x, F ^ (q3 << 3));
+            L(gv)[4 * it] = *tl_fht_at(x, G); L(gv)[4 * it + 1] = *tl_fht_at(x, G ^ (q1 << 3)); L(gv)[4 * it + 2] = *tl_fht_at(x, G ^ (q2 << 3)); L(gv)[4 * it + 3] = *tl_fht_at(x, G ^ (q3 << 3));
         }
         TL_LANES_END
         TL_LANES_BEGIN

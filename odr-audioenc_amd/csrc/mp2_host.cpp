@@ -163,6 +163,13 @@ void tl_build_tables(TlTables *T)
         for (int g = 0; g < 128; g++) {
             const int gg = g < ngen ? g : 0, i = 1 + gg % (kx - 1);
             for (int q = 0; q < 4; q++) T->fht_tw_lane[p][g][q] = T->fht_tw[first_row[p] + i - 1][q];
+            // where the butterfly is (csrc/mp2_fht.h tl_fht_pass): block g / (kx - 1), f0 = block * 4 k1 + i, g0 = block * 4 k1 + k1 - i, through the
+            // buffer's layout map j -> j ^ (j >> 5), as byte offsets.  Pass k=8's last entry is its one trivial butterfly (f0 = 0, g0 = kx), which
+            // the fused last pass of models 1 / 3 deals to butterfly 127 (tl_psy_spectrum); the other passes' spare entries are never used.
+            const int k1 = 1 << (4 + 2 * p), blk = gg / (kx - 1);
+            int f0 = blk * 4 * k1 + i, g0 = blk * 4 * k1 + k1 - i;
+            if (p == 2 && g == 127) { f0 = 0; g0 = kx; }
+            T->fht_fg_lane[p][g] = (uint32_t)((f0 ^ (f0 >> 5)) << 3) | (uint32_t)((g0 ^ (g0 >> 5)) << 3) << 16;
         }
     }
 }

@@ -30,6 +30,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
     {
         TL_STAMP(sq, 0);
         PA(double, twa, 8); PA(double, twb, 8); PA(double, twc, 8);
+        PA(uint32_t, fga, 2); PA(uint32_t, fgb, 2); PA(uint32_t, fgc, 2);
         TL_LANES_BEGIN
         {
             // sample i = lane + 64*it of the pass's 1024-sample window (psycho_2.c:84-92); loads in batches of eight ahead
@@ -37,7 +38,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
             const double *win = P->window;
             TL_LAUNDER(win);
             const int16_t *pvh = ch ? pv.hist[1] : pv.hist[0], *pvc = ch ? pv.cur[1] : pv.cur[0];
-            tl_fht_twiddles<4>(L(twc), T, lane);
+            tl_fht_twiddles<4>(L(twc), L(fgc), T, lane);
             double e[16];
 #ifndef TL_EMULATE
 #pragma unroll
@@ -62,14 +63,14 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                     e[r4] = h[q] * (double)v[q];
                 }
             }
-            tl_fht_twiddles<6>(L(twb), T, lane);
+            tl_fht_twiddles<6>(L(twb), L(fgb), T, lane);
             tl_fht_head(e, T->fht_tw);
             tl_fht_store(x, lane, e);
         }
         TL_LANES_END
-        TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), T, lane); tl_fht_pass<4>(x, L(twc), lane); TL_LANES_END
-        TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), lane); TL_LANES_END
-        TL_LANES_BEGIN tl_fht_pass<8>(x, L(twa), lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), L(fga), T, lane); tl_fht_pass<4>(x, L(twc), L(fgc), lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), L(fgb), lane); TL_LANES_END
+        TL_LANES_BEGIN tl_fht_pass<8>(x, L(twa), L(fga), lane); TL_LANES_END
         TL_STAMP(sq, 1);
         // energy + phase (fft.c:1246-1275), unpredictability (psycho_2.c:119-140).
         // 64 lines per step: the transform is read through the layout map first, then the step's energies are written in

@@ -49,6 +49,7 @@ struct TlTables {
     double dbtable[1000];
     double fht_tw[166][4];       // (c1,s1,c2,s2) for passes k=2,4,6,8, i=1..kx-1
     double fht_tw_lane[3][128][4];   // the same rows in the order the lanes of passes k=4,6,8 use them: [pass][butterfly g][.]
+    uint32_t fht_fg_lane[3][128];    // where butterfly g of the pass is: byte offsets of its points f0 (low half) and g0 (high half) in the transform buffer
     double scalefactor[64];
     double snr[18];
     TlPackTables pack;
