@@ -346,7 +346,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
 #ifndef TL_EMULATE
 #pragma unroll
 #endif
-            for (int q = 0; q < 9; q++) { if (lane + 64 * q <= 512) cw[jp + 66 * q] = tj[q] > aj[q] ? tj[q] : aj[q]; }
+            for (int q = 0; q < 9; q++) { if (lane + 64 * q <= 512) cw[jp + 66 * q] = TLM_MAX_NN(aj[q], tj[q]); }      // (= tj > aj ? tj : aj: no NaN among permissible noise and threshold in quiet)
         }
         TL_LANES_END
         TL_LANES_BEGIN
