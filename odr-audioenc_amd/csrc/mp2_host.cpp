@@ -210,7 +210,7 @@ int tl_psy2_slot(long samplerate)
 // window.  A table whose rows do not fit the window would silently lose terms, so that is fatal here, at table build time.
 static void tl_psy2_band(TlPsy2Tables *P)
 {
-    int lo_[64], hi_[64];
+    int lo_[64];
     P->band_w = 0;
     for (int j = 0; j < 64; j++) {
         int lo = 64, hi = -1;
@@ -219,7 +219,7 @@ static void tl_psy2_band(TlPsy2Tables *P)
         const int w = hi - lo + 1;
         if (w > TL_P2_BAND) { fprintf(stderr, "libtoolame-dab-hip: spreading band of partition %d is %d wide (TL_P2_BAND %d)\n", j, w, TL_P2_BAND); abort(); }
         if (w > P->band_w) P->band_w = w;
-        lo_[j] = lo; hi_[j] = hi;
+        lo_[j] = lo;
     }
     // the device sums whole batches: the window is the table's widest band rounded up to batches, the same for every partition
     const int window = (P->band_w + TL_P2_B - 1) / TL_P2_B * TL_P2_B;
