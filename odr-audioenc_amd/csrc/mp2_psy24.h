@@ -20,8 +20,11 @@
 template <bool SEED>
 TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_RESTRICT P, const TlPcmView &pv, int ch, int pass,
                         PARGA(double, r1, 8), PARGA(double, r2, 8), PARGA(double, p1, 8), PARGA(double, p2, 8),
-                        PARG(double, snr0), double *smr_out, const uint64_t *sct, long long *sq)
+                        PARG(double, snr0), double *smr_out, const uint64_t *sct, long long *sq, const TlPsy2State *load_state = nullptr)
 {   // sct: glibc's __sincostab (tl_libm.h), the workgroup's LDS copy on the device
+    // load_state: the run's FIRST pass fetches the prediction state itself (32 KB per channel from HBM) -- behind the transform's own
+    // loads and with three transform passes to arrive in, instead of at the head of the unit where the first wait for a PCM sample
+    // is a wait for all of it (one frame per launch, the tick shape: a unit is two passes and this was a seventh of its time)
     double *x = w.u.fft;
     double *cw = w.px, *ge = w.u.fft + 520;  // c[] (unpredictability), then fthr[]; partition sums in the dead upper half of the FHT buffer:
     double *ecb = ge + 128, *nb = ecb + 64;  // ge[2 j], ge[2 j + 1] = grouped energy and weighted unpredictability of partition j (one 16-byte read per term of the spreading sums)
@@ -68,8 +71,25 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
             tl_fht_store(x, lane, e);
         }
         TL_LANES_END
-        TL_LANES_BEGIN tl_fht_twiddles<8>(L(twa), L(fga), T, lane); tl_fht_pass<4>(x, L(twc), L(fgc), lane); TL_LANES_END
-        TL_LANES_BEGIN tl_fht_pass<6>(x, L(twb), L(fgb), lane); TL_LANES_END
+        PA(double, s5, 4);
+        TL_LANES_BEGIN
+        tl_fht_twiddles<8>(L(twa), L(fga), T, lane);
+        if (load_state) {
+#ifndef TL_EMULATE
+#pragma unroll
+#endif
+            for (int it = 0; it < 8; it++) {
+                const int j = lane + 64 * it;
+                L(r1)[it] = load_state->r[ch][0][j]; L(r2)[it] = load_state->r[ch][1][j]; L(p1)[it] = load_state->phi[ch][0][j]; L(p2)[it] = load_state->phi[ch][1][j];
+            }
+            if (lane == 0) { L(s5)[0] = load_state->r[ch][0][512]; L(s5)[1] = load_state->r[ch][1][512]; L(s5)[2] = load_state->phi[ch][0][512]; L(s5)[3] = load_state->phi[ch][1][512]; }
+        }
+        tl_fht_pass<4>(x, L(twc), L(fgc), lane);
+        TL_LANES_END
+        TL_LANES_BEGIN
+        tl_fht_pass<6>(x, L(twb), L(fgb), lane);
+        if (load_state && lane == 0) { l5[0] = L(s5)[0]; l5[1] = L(s5)[1]; l5[2] = L(s5)[2]; l5[3] = L(s5)[3]; }
+        TL_LANES_END
         TL_LANES_BEGIN tl_fht_pass<8>(x, L(twa), L(fga), lane); TL_LANES_END
         TL_STAMP(sq, 1);
         // energy + phase (fft.c:1246-1275), unpredictability (psycho_2.c:119-140).

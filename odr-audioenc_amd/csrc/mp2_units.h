@@ -108,17 +108,11 @@ TL_FN void tl_psy2_chain(TlPsy2Lds &w, const TlLaunch &A, int s, int ch, int f0,
     const TlPsy2Tables *P = &A.psy2_tables[TL_UNI_I(C->psy2_tab)];
     PA(double, r1, 8); PA(double, r2, 8); PA(double, p1, 8); PA(double, p2, 8); PV(double, snr0);
     double *l5 = TL_P2_L512(w);
+    const TlPsy2State *S0 = nullptr;
     if (f0 == 0) {
-        const TlPsy2State *S = &A.psy2_state[2 * (size_t)s + (size_t)A.psy2_flip];
+        // the run starts with the stream's carried state: its first pass fetches it, behind the transform's own loads (tl_psy2_pass)
+        S0 = &A.psy2_state[2 * (size_t)s + (size_t)A.psy2_flip];
         TL_LANES_BEGIN
-#ifndef TL_EMULATE
-#pragma unroll
-#endif
-        for (int it = 0; it < 8; it++) {
-            const int j = lane + 64 * it;
-            L(r1)[it] = S->r[ch][0][j]; L(r2)[it] = S->r[ch][1][j]; L(p1)[it] = S->phi[ch][0][j]; L(p2)[it] = S->phi[ch][1][j];
-        }
-        if (lane == 0) { l5[0] = S->r[ch][0][512]; l5[1] = S->r[ch][1][512]; l5[2] = S->phi[ch][0][512]; l5[3] = S->phi[ch][1][512]; }
         L(snr0) = 0.0;
         TL_LANES_END
     } else {
@@ -138,7 +132,7 @@ TL_FN void tl_psy2_chain(TlPsy2Lds &w, const TlLaunch &A, int s, int ch, int f0,
         const size_t slot = (size_t)f * (size_t)A.nstreams + (size_t)s;
         const TlPcmView pv = tl_pcm_view(A, &A.state[s], s, f);
         long long *sp = A.stamps ? A.stamps + slot * 32 + 8 + 8 * ch : nullptr;
-        tl_psy2_pass<false>(w, A.tables, P, pv, ch, 0, r1, r2, p1, p2, snr0, &A.psy_out[slot].a[ch][0], sct, sp);
+        tl_psy2_pass<false>(w, A.tables, P, pv, ch, 0, r1, r2, p1, p2, snr0, &A.psy_out[slot].a[ch][0], sct, sp, f == f0 ? S0 : nullptr);
         tl_psy2_pass<false>(w, A.tables, P, pv, ch, 1, r1, r2, p1, p2, snr0, &A.psy_out[slot].a[ch][0], sct, nullptr);
     }
     if (f1 == A.nframes) {
