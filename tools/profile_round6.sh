@@ -58,3 +58,5 @@ cat gpurun_out/legacy_latency_${V}.txt
 # 8. round 6: the whole GPU suite on the same kernels (fault isolation included), its log kept
 ( time timeout 2400 python3 -m pytest tests -q -m gpu ) > gpurun_out/gputests_${V}_final.log 2>&1; tail -5 gpurun_out/gputests_${V}_final.log
 ls gpurun_out | grep ${V} | head -80
+# 9. the driver's smoke on the same box
+timeout 600 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke_${V}.log 2>&1; tail -2 gpurun_out/smoke_${V}.log
