@@ -69,21 +69,22 @@ TL_FN void tl_fht_twiddles(double (&t)[8], uint32_t (&fg)[2], const TlTables *TL
 template <int K>
 TL_FN void tl_fht_pass(double *x, const double (&t)[8], const uint32_t (&fg)[2], int lane)
 {   // fft.c:1104-1184: one pass = 128 independent 8-point butterflies: per block of 4*k1 points one with trivial /
-    // sqrt(2) twiddles (i = 0) and kx-1 general ones.  The general ones are dealt densely to the lanes and the
-    // trivial ones follow in their own step, so a wave never runs both code paths for one batch of butterflies.
+    // sqrt(2) twiddles (i = 0) and kx-1 general ones.  The general ones are dealt to 128 slots (two per lane) by the host's table -- which slot
+    // runs which (block, i) is chosen for the LDS banks, csrc/mp2_host.cpp -- and the trivial ones follow in their own step, so a wave never
+    // runs both code paths for one batch of butterflies.
     // Addresses: block, i (or k1-i) and q*k1 occupy disjoint bit fields, so each goes through TL_FX on its own.
     const double SQRT2 = 1.4142135623730951454746218587388284504414;
     constexpr int k1 = 1 << K, k2 = k1 << 1, k4 = k2 << 1, k3 = k2 + k1, kx = k1 >> 1;
-    constexpr int NBLK = 128 / kx, NGEN = 128 - NBLK;
+    constexpr int NBLK = 128 / kx;
     constexpr int q1 = TL_FX(k1), q2 = TL_FX(k2), q3 = TL_FX(k3);
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         const int g = lane + 64 * it;
-        if (g >= NGEN) break;
+        if (fg[it] == 0xffffffffu || g >= 127) continue;            // an idle slot of the host's dealing; k=8's slot 127 is that pass's TRIVIAL butterfly (below)
         const double c1 = t[4 * it], s1 = t[4 * it + 1], c2 = t[4 * it + 2], s2 = t[4 * it + 3];
         // (byte offsets: an exchange partner's address is (offset ^ constant) + base, ONE v_xad_u32; as indices it is an exclusive-or and then a shift-add)
-        // butterfly g = general butterfly i = 1 + g mod (kx - 1) of block g / (kx - 1): f0 at FX(block * k4) ^ FX(i), g0 at FX(block * k4) ^ FX(k1 - i),
-        // as byte offsets from the table (csrc/mp2_host.cpp tl_build_tables: the division and the layout map are the host's)
+        // slot g = the general butterfly (block, i) the host dealt to it -- by LDS banks, csrc/mp2_host.cpp tl_build_tables --: f0 at FX(block * k4) ^ FX(i),
+        // g0 at FX(block * k4) ^ FX(k1 - i), as byte offsets from the table (the dealing and the layout map are the host's)
         const int F = (int)(fg[it] & 0xffffu), G = (int)(fg[it] >> 16);
         double *f0p = tl_fht_at(x, F), *f1p = tl_fht_at(x, F ^ (q1 << 3)), *f2p = tl_fht_at(x, F ^ (q2 << 3)), *f3p = tl_fht_at(x, F ^ (q3 << 3));
         double *g0p = tl_fht_at(x, G), *g1p = tl_fht_at(x, G ^ (q1 << 3)), *g2p = tl_fht_at(x, G ^ (q2 << 3)), *g3p = tl_fht_at(x, G ^ (q3 << 3));

@@ -155,22 +155,44 @@ void tl_build_tables(TlTables *T)
             T->fht_tw[n][2] = c1 * c1 - s1 * s1; T->fht_tw[n][3] = 2 * (c1 * s1);
         }
     }
-    // butterfly g of pass k is the general butterfly i = 1 + g mod (kx-1) of its block (tl_fht_pass); row of (k, i) in
-    // fht_tw: first row of the pass + i - 1 (first rows: k=4 -> 1, k=6 -> 8, k=8 -> 39)
+    // Which general butterfly (block, i) of pass k the lanes' butterfly g is, is the HOST's choice -- the device takes its two base offsets and its
+    // twiddle row from these tables -- and it is made for the LDS banks (MI355X: ds_read_b64 is served per 32-lane half, bank = double index mod 32;
+    // ds_write_b64 per 16 lanes, mod 16; layout j -> j ^ (j >> 5)):
+    //   k=4 (16 blocks x 7): half h of the 128 slots holds i = 1 + 2h and 2 + 2h, eight blocks at a time (slots 0-7: i, blocks 0-7; 8-15: i + 1,
+    //        blocks 0-7; 16-23: i, blocks 8-15; 24-31: i + 1, blocks 8-15): banks i ^ 2 block -- 32 different ones per half, 16 per write group;
+    //        the last half has i = 7 alone (16 slots).  Dealt block by block (g / 7, 1 + g % 7) 28 lanes of a half shared 8 banks.
+    //   k=6 (4 blocks x 31): half h is block h, i = 1 + slot (slot 31 idle): banks i ^ 8 block.  Dealt densely a half straddled two blocks: 2-way.
+    //   k=8 (1 block x 127): i = 1 + g, consecutive addresses; entry 127 is the pass's one trivial butterfly (f0 = 0, g0 = kx), which the fused
+    //        last pass of models 1 / 3 deals to slot 127 (tl_psy_spectrum).
+    // An idle slot is marked 0xffffffff.  Row of (k, i) in fht_tw: first row of the pass + i - 1 (first rows: k=4 -> 1, k=6 -> 8, k=8 -> 39).
     const int first_row[3] = {1, 8, 39};
     for (int p = 0; p < 3; p++) {
-        const int kx = (1 << (4 + 2 * p)) >> 1, ngen = 128 - 128 / kx;
+        const int k1 = 1 << (4 + 2 * p), kx = k1 >> 1, nblk = 128 / kx;
+        int seen[16][128];
+        memset(seen, 0, sizeof seen);
         for (int g = 0; g < 128; g++) {
-            const int gg = g < ngen ? g : 0, i = 1 + gg % (kx - 1);
-            for (int q = 0; q < 4; q++) T->fht_tw_lane[p][g][q] = T->fht_tw[first_row[p] + i - 1][q];
-            // where the butterfly is (csrc/mp2_fht.h tl_fht_pass): block g / (kx - 1), f0 = block * 4 k1 + i, g0 = block * 4 k1 + k1 - i, through the
-            // buffer's layout map j -> j ^ (j >> 5), as byte offsets.  Pass k=8's last entry is its one trivial butterfly (f0 = 0, g0 = kx), which
-            // the fused last pass of models 1 / 3 deals to butterfly 127 (tl_psy_spectrum); the other passes' spare entries are never used.
-            const int k1 = 1 << (4 + 2 * p), blk = gg / (kx - 1);
+            const int h = g >> 5, r = g & 31;
+            int blk = 0, i = 1;
+            bool valid = true, trivial = false;
+            if (p == 0) {
+                if (h < 3) { const int sub = r >> 3; i = 1 + 2 * h + (sub & 1); blk = (r & 7) + 8 * (sub >> 1); }
+                else { i = 7; blk = r; valid = r < 16; }
+            } else if (p == 1) { blk = h; i = 1 + r; valid = r < 31; }
+            else { i = 1 + g; valid = g < 127; trivial = g == 127; }
+            if (!valid && !trivial) {
+                for (int q = 0; q < 4; q++) T->fht_tw_lane[p][g][q] = 0.0;
+                T->fht_fg_lane[p][g] = 0xffffffffu;
+                continue;
+            }
             int f0 = blk * 4 * k1 + i, g0 = blk * 4 * k1 + k1 - i;
-            if (p == 2 && g == 127) { f0 = 0; g0 = kx; }
+            if (trivial) { f0 = 0; g0 = kx; i = 1; }
+            else if (seen[blk][i]++) { fprintf(stderr, "libtoolame-dab-hip: transform pass %d deals butterfly (%d, %d) twice\n", p, blk, i); abort(); }
+            for (int q = 0; q < 4; q++) T->fht_tw_lane[p][g][q] = T->fht_tw[first_row[p] + i - 1][q];
             T->fht_fg_lane[p][g] = (uint32_t)((f0 ^ (f0 >> 5)) << 3) | (uint32_t)((g0 ^ (g0 >> 5)) << 3) << 16;
         }
+        for (int blk = 0; blk < nblk; blk++)
+            for (int i = 1; i < kx; i++)
+                if (!seen[blk][i]) { fprintf(stderr, "libtoolame-dab-hip: transform pass %d never deals butterfly (%d, %d)\n", p, blk, i); abort(); }
     }
 }
 
