@@ -16,6 +16,14 @@
 // anywhere: two SEED passes (transform, square root, arctangent -- no unpredictability, nothing after it) over the 1152
 // samples before it rebuild exactly the state the chain would have carried there.  During a run the state lives in the wave's
 // REGISTERS: line lane + 64 it in slot `it` of r1/p1 (previous pass) and r2/p2 (the pass before), line 512 in four LDS words.
+// glibc's sincos table as the kernel holds it in LDS: the rows' halves apart -- (sn, ssn) of row k at [2 k], (cs, ccs) at [220 + 2 k] -- instead of
+// 32-byte rows: a 16-byte gather of sixteen lanes then spreads over sixteen bank quads, not eight (row k's first half alone sat on banks 8 k .. 8 k + 3,
+// the other four idle during that read).  `row` = 4 k as tlm_sincos_reduce returns it.  The emulation reads glibc's own layout.
+#ifdef TL_EMULATE
+#define TL_SCT(t, row, j) ((t)[(row) + (j)])
+#else
+#define TL_SCT(t, row, j) ((t)[((row) >> 1) + ((j) & 1) + 220 * ((j) >> 1)])
+#endif
 #define TL_P2_L512(w) ((w).px + 532)     /* r1, r2, p1, p2 of line 512 (c[] ends at px[512], the padded fthr[] at px[528]) */
 template <bool SEED>
 TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy2Tables *TL_RESTRICT P, const TlPcmView &pv, int ch, int pass,
@@ -141,7 +149,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                 double q_sn = 0, q_ssn = 0, q_cs = 0, q_ccs = 0, r_prime = 0;
                 if (sc2) {
                     s2 = tlm_sincos_reduce(2.0 * L(p1)[it] - L(p2)[it]);
-                    q_sn = tl_u2d(sct[s2.row]); q_ssn = tl_u2d(sct[s2.row + 1]); q_cs = tl_u2d(sct[s2.row + 2]); q_ccs = tl_u2d(sct[s2.row + 3]);
+                    q_sn = tl_u2d(TL_SCT(sct, s2.row, 0)); q_ssn = tl_u2d(TL_SCT(sct, s2.row, 1)); q_cs = tl_u2d(TL_SCT(sct, s2.row, 2)); q_ccs = tl_u2d(TL_SCT(sct, s2.row, 3));
                 }
                 TLM_SCHED_FENCE();
                 if (TL_P2_SUB != 3) am = tlm_atan2_mid(at);
@@ -160,7 +168,7 @@ TL_FN void tl_psy2_pass(TlPsy2Lds &w, const TlTables *TL_RESTRICT T, const TlPsy
                 else if (full) { spp = L(p1)[it] + L(p2)[it]; cpp = r_prime; }
                 if (sc1) {
                     s1 = tlm_sincos_reduce(tlm_sel(first, 2.0 * p_o5 - p_n5, phi));
-                    w_sn = tl_u2d(sct[s1.row]); w_ssn = tl_u2d(sct[s1.row + 1]); w_cs = tl_u2d(sct[s1.row + 2]); w_ccs = tl_u2d(sct[s1.row + 3]);
+                    w_sn = tl_u2d(TL_SCT(sct, s1.row, 0)); w_ssn = tl_u2d(TL_SCT(sct, s1.row, 1)); w_cs = tl_u2d(TL_SCT(sct, s1.row, 2)); w_ccs = tl_u2d(TL_SCT(sct, s1.row, 3));
                 }
                 TLM_SCHED_FENCE();
                 const double rn = TL_P2_SUB == 4 ? e + 1.0 : it == 0 ? tlm_sqrt_ns(e) : tlm_sqrt_nz(e);   // e >= 0.0005, or line 0's x^2 (step 0; zero included): far from the exponent limits

@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(64 * TL_PSY2_WAVES) __attribute__((amdgpu_wave
 {
     __shared__ TlPsy2Lds lds[TL_PSY2_WAVES];
     __shared__ __attribute__((aligned(16))) uint64_t sct[440];      // glibc's sincos table: two 16-byte gathers per sincos stay on the CU
-    for (int i = (int)threadIdx.x; i < 440; i += 64 * TL_PSY2_WAVES) sct[i] = tlm_sincostab[i];
+    for (int i = (int)threadIdx.x; i < 440; i += 64 * TL_PSY2_WAVES) sct[2 * (i >> 2) + (i & 1) + 220 * ((i >> 1) & 1)] = tlm_sincostab[i];      // (TL_SCT, mp2_psy24.h)
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int wave_v = (int)(threadIdx.x >> 6);
