@@ -251,6 +251,14 @@ int emu_edi_pft(const uint8_t *af, const int32_t *af_len, int nframes, int nstre
     memcpy(pseq, next.data(), sizeof(uint16_t) * (size_t)nstreams);
     return 0;
 }
+// The transform's dealing table of the PRODUCT's host code (csrc/mp2_host.cpp tl_build_tables, TlTables::fht_fg_lane): out[3][128], low half = byte offset of a
+// slot's point f0, high half = of g0, 0xffffffff = idle slot.  tests/test_oracle_golden.py checks coverage and the LDS-bank property it is built for.
+int emu_fht_dealing(uint32_t *out)
+{
+    static TlTables T; tl_build_tables(&T);
+    memcpy(out, T.fht_fg_lane, sizeof T.fht_fg_lane);
+    return (int)(sizeof T.fht_fg_lane / sizeof(uint32_t));
+}
 int emu_sizeof_taps(void) { return (int)sizeof(TlTaps); }
 int emu_sizeof_lds(void) { return (int)sizeof(TlMainLds); }
 double emu_log10(double x) { return tlm_log10(x); }

@@ -228,3 +228,46 @@ def test_spreading_bands_hold_every_nonzero_coefficient_of_the_partitions_that_e
                 outside[lo[j]:lo[j] + window] = False
                 outside[npart:] = False                          # columns of partitions that do not exist multiply an exact +0 grouped energy
                 assert not s[j, outside].any(), (psy, fs, j)
+
+
+def test_transform_dealing_covers_every_butterfly_once_and_spreads_over_the_lds_banks():
+    """The host deals the general butterflies of the transform's passes k = 4, 6, 8 to 128 slots (two per lane; csrc/mp2_host.cpp tl_build_tables,
+    TlTables::fht_fg_lane).  (1) Every (block, i) of a pass appears exactly once (the table build aborts otherwise; here from the offsets themselves).
+    (2) The property the dealing exists for (MI355X_MICROARCH.md, LDS): a ds_read_b64 is served per 32-lane half with bank = double index mod 32, a
+    ds_write_b64 per 16 lanes with bank = double index mod 16 -- in passes k = 4 and k = 6 no two lanes of such a group share a bank, for any of a
+    butterfly's eight points (the exchange partners are the base offsets XOR a constant: a permutation of the banks)."""
+    import emulib
+    E = emulib.lib()
+    E.emu_fht_dealing.argtypes = [C.c_void_p]
+    buf = np.zeros(3 * 128, dtype=np.uint32)
+    assert E.emu_fht_dealing(buf.ctypes.data) == 384
+    fg = buf.reshape(3, 128)
+    unfx = lambda a: next(j for j in range(1024) if (j ^ (j >> 5)) == a)          # the layout map j -> j ^ (j >> 5), inverted
+    for p, K in enumerate((4, 6, 8)):
+        k1, kx = 1 << K, (1 << K) >> 1
+        seen = set()
+        for g in range(128):
+            v = int(fg[p, g])
+            if v == 0xFFFFFFFF or (p == 2 and g == 127):
+                continue
+            f0, g0 = unfx((v & 0xFFFF) >> 3), unfx((v >> 16) >> 3)
+            blk, i = f0 // (4 * k1), f0 % (4 * k1)
+            assert 1 <= i < kx and g0 == blk * 4 * k1 + k1 - i, (p, g, f0, g0)
+            assert (blk, i) not in seen
+            seen.add((blk, i))
+        assert len(seen) == (128 // kx) * (kx - 1), (p, len(seen))
+        assert int(fg[2, 127]) == ((128 ^ (128 >> 5)) << 3) << 16                 # k = 8's slot 127: the trivial butterfly, f0 = 0, g0 = kx
+        if p == 2:
+            continue
+        for half in (0, 16):                                                      # f0 in the low 16 bits, g0 in the high
+            for it in range(2):
+                idx = [(int(fg[p, 64 * it + lane]) >> half & 0xFFFF) >> 3 if int(fg[p, 64 * it + lane]) != 0xFFFFFFFF else None for lane in range(64)]
+                for lo in (0, 32):                                                # reads: 32-lane halves, 32 bank pairs
+                    banks = [a % 32 for a in idx[lo:lo + 32] if a is not None]
+                    assert len(banks) == len(set(banks)), (p, it, lo, "read")
+                for lo in range(0, 64, 16):                                       # writes: 16-lane groups, 16 bank pairs
+                    banks = [a % 16 for a in idx[lo:lo + 16] if a is not None]
+                    if p == 0 and it == 1 and lo == 32:                          # k = 4's last 16 slots hold i = 7 of all sixteen blocks: two lanes per bank pair
+                        assert max(banks.count(b) for b in set(banks)) <= 2
+                    else:
+                        assert len(banks) == len(set(banks)), (p, it, lo, "write")
